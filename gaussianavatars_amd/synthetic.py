@@ -1,0 +1,209 @@
+"""Seeded synthetic stand-ins for the assets BASELINE.json names but the reference snapshot lacks
+(media/306/point_cloud.ply, flame_param.npz, flame2023.pkl -- SURVEY.md F4).
+
+Everything here is plain numpy on the host so that the same bytes are produced on the CPU
+container and on the GPU box.  Shapes, distributions and seeds follow SURVEY.md section 8(d).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------------
+# cameras
+# --------------------------------------------------------------------------------------------
+
+
+@dataclass
+class SynthCamera:
+    """Duck-type of what gaussian_renderer/__init__.py:34-47 reads from a camera."""
+    FoVx: float
+    FoVy: float
+    image_height: int
+    image_width: int
+    world_view_transform: np.ndarray  # (4,4) = W2C^T   (scene/cameras.py:44)
+    full_proj_transform: np.ndarray   # (4,4) = (P @ W2C)^T
+    camera_center: np.ndarray         # (3,)
+    timestep: int = 0
+
+
+def orbit_camera(width: int, height: int, r: float = 1.0, fovy_deg: float = 20.0, znear: float = 0.01,
+                 zfar: float = 10.0, yaw_deg: float = 0.0, pitch_deg: float = 0.0) -> SynthCamera:
+    """Equivalent of fps_benchmark_demo.py:21-33 (OrbitCamera(W,H,r=1,fovy=20,'opencv'),
+    utils/viewer_utils.py:73-170) restated: camera on the +z axis at distance r looking at the
+    origin, OpenCV axes, OpenGL-style projection with z_sign=+1."""
+    focal = height / (2.0 * math.tan(math.radians(fovy_deg) / 2.0))
+    fovx = 2.0 * math.atan(width / (2.0 * focal))
+    cx, cy = width // 2, height // 2
+    # camera-to-world in OpenGL axes, then flip y,z columns for OpenCV
+    pose = np.eye(4, dtype=np.float64)
+    pose[2, 3] = r
+    cyw, syw = math.cos(math.radians(yaw_deg)), math.sin(math.radians(yaw_deg))
+    cp, sp = math.cos(math.radians(pitch_deg)), math.sin(math.radians(pitch_deg))
+    Ry = np.array([[cyw, 0, syw, 0], [0, 1, 0, 0], [-syw, 0, cyw, 0], [0, 0, 0, 1]], np.float64)
+    Rx = np.array([[1, 0, 0, 0], [0, cp, -sp, 0], [0, sp, cp, 0], [0, 0, 0, 1]], np.float64)
+    pose = Ry @ Rx @ pose
+    pose[:, [1, 2]] *= -1
+    w2c = np.linalg.inv(pose)
+    proj = np.zeros((4, 4), np.float64)
+    proj[0, 0] = focal * 2 / width
+    proj[1, 1] = focal * 2 / height
+    proj[0, 2] = (width - 2 * cx) / width
+    proj[1, 2] = (height - 2 * cy) / height
+    proj[2, 2] = (zfar + znear) / (zfar - znear)
+    proj[2, 3] = -2 * zfar * znear / (zfar - znear)
+    proj[3, 2] = 1.0
+    full = proj @ w2c
+    return SynthCamera(
+        FoVx=float(fovx), FoVy=float(math.radians(fovy_deg)), image_height=int(height), image_width=int(width),
+        world_view_transform=np.ascontiguousarray(w2c.T.astype(np.float32)),
+        full_proj_transform=np.ascontiguousarray(full.T.astype(np.float32)),
+        camera_center=pose[:3, 3].astype(np.float32),
+    )
+
+
+# --------------------------------------------------------------------------------------------
+# un-bound splat clouds (configs 1 and 5)
+# --------------------------------------------------------------------------------------------
+
+
+def random_splats(n: int, sh_degree: int, seed: int, xyz_sigma: float = 0.06, log_scale_mean: float = math.log(0.004),
+                  log_scale_sigma: float = 0.4, opacity_mu: float = 0.0, opacity_sigma: float = 1.5) -> Dict[str, np.ndarray]:
+    """Rasterizer-level inputs (already activated), SURVEY.md 8(d) cfg 1 / cfg 5."""
+    g = np.random.default_rng(seed)
+    M = (sh_degree + 1) ** 2
+    means3D = g.normal(0.0, xyz_sigma, (n, 3)).astype(np.float32)
+    scales = np.exp(g.normal(log_scale_mean, log_scale_sigma, (n, 3))).astype(np.float32)
+    rotations = g.normal(0.0, 1.0, (n, 4)).astype(np.float32)  # un-normalised, as the kernel receives it
+    opacities = (1.0 / (1.0 + np.exp(-g.normal(opacity_mu, opacity_sigma, (n, 1))))).astype(np.float32)
+    shs = np.zeros((n, M, 3), np.float32)
+    shs[:, 0, :] = g.normal(0.5, 0.5, (n, 3))
+    if M > 1:
+        shs[:, 1:, :] = g.normal(0.0, 0.08, (n, M - 1, 3))
+    return dict(means3D=means3D, scales=scales, rotations=rotations, opacities=opacities, shs=shs)
+
+
+# --------------------------------------------------------------------------------------------
+# FLAME-shaped synthetic rig (V=5143, F=10144, J=5) and bound splats (configs 2-4)
+# --------------------------------------------------------------------------------------------
+
+FLAME_V = 5143      # 5023 + 120 teeth vertices (flame_model/flame.py:186-483)
+FLAME_F = 10144     # 9976 + 168 teeth faces
+FLAME_J = 5
+FLAME_PARENTS = (-1, 0, 1, 1, 1)
+N_SHAPE, N_EXPR = 300, 100
+
+
+def head_mesh(half_extent: float = 0.12) -> Tuple[np.ndarray, np.ndarray]:
+    """An ellipsoid 'head' with exactly FLAME_V vertices and FLAME_F faces: a 53-ring x 97-segment
+    lat/long sphere (2 + 53*97 = 5143 vertices, 10282 faces) with a 138-face neck hole cut at the
+    south pole.  The true template (flame_model/assets/flame/head_template_mesh.obj) is licensed and
+    does not travel to the GPU box; only the counts and the index dtype matter to the kernels."""
+    rings, seg = 53, 97
+    verts = [(0.0, 1.0, 0.0)]
+    for i in range(1, rings + 1):
+        th = math.pi * i / (rings + 1)
+        for j in range(seg):
+            ph = 2 * math.pi * j / seg
+            verts.append((math.sin(th) * math.cos(ph), math.cos(th), math.sin(th) * math.sin(ph)))
+    verts.append((0.0, -1.0, 0.0))
+    verts = np.asarray(verts, np.float64)
+    assert verts.shape[0] == FLAME_V
+    faces = []
+    ring = lambda i, j: 1 + (i - 1) * seg + (j % seg)
+    for j in range(seg):
+        faces.append((0, ring(1, j + 1), ring(1, j)))
+    for i in range(1, rings):
+        for j in range(seg):
+            a, b, c, d = ring(i, j), ring(i, j + 1), ring(i + 1, j), ring(i + 1, j + 1)
+            faces.append((a, b, d))
+            faces.append((a, d, c))
+    south = FLAME_V - 1
+    for j in range(seg):
+        faces.append((south, ring(rings, j), ring(rings, j + 1)))
+    faces = np.asarray(faces, np.int64)
+    assert faces.shape[0] == 10282
+    faces = faces[: FLAME_F]  # drops the 97 south-pole fan triangles + 41 of the last band
+    verts = verts * np.array([0.8, 1.0, 0.9]) * half_extent
+    return verts.astype(np.float32), faces
+
+
+def flame_rig(seed: int = 4) -> Dict[str, np.ndarray]:
+    """Buffers with the schemas FlameHead registers (flame_model/flame.py:98-129, after add_teeth)."""
+    g = np.random.default_rng(seed)
+    v_template, faces = head_mesh()
+    V = FLAME_V
+    # smooth-ish blend directions: low-frequency functions of position times random weights
+    basis = np.concatenate([v_template / 0.12, np.sin(v_template / 0.12 * 3.0), np.cos(v_template / 0.12 * 2.0)], 1)  # (V,9)
+    mix = g.normal(0.0, 1.0, (9, 3 * (N_SHAPE + N_EXPR)))
+    shapedirs = (basis @ mix).reshape(V, 3, N_SHAPE + N_EXPR) * (2e-3 / 3.0)
+    shapedirs += g.normal(0.0, 2e-4, shapedirs.shape)
+    posedirs = g.normal(0.0, 1e-3, (36, 3 * V))
+    # joints: root at the neck base, neck, jaw, two eyes
+    joints = np.array([[0, -0.10, 0], [0, -0.05, 0], [0, -0.02, 0.03], [0.03, 0.04, 0.08], [-0.03, 0.04, 0.08]], np.float64)
+    J_regressor = np.zeros((FLAME_J, V))
+    lbs_weights = np.zeros((V, FLAME_J))
+    for j in range(FLAME_J):
+        d2 = ((v_template - joints[j]) ** 2).sum(1)
+        near = np.argsort(d2)[:50]
+        w = np.exp(-d2[near] / (2 * 0.02 ** 2))
+        J_regressor[j, near] = w / w.sum()
+        lbs_weights[:, j] = np.exp(-d2 / (2 * (0.06 if j < 3 else 0.015) ** 2))
+    lbs_weights[:, 0] += 1e-3
+    lbs_weights /= lbs_weights.sum(1, keepdims=True)
+    return dict(
+        v_template=v_template.astype(np.float32),
+        shapedirs=shapedirs.astype(np.float32),
+        posedirs=posedirs.astype(np.float32),
+        J_regressor=J_regressor.astype(np.float32),
+        lbs_weights=lbs_weights.astype(np.float32),
+        parents=np.asarray(FLAME_PARENTS, np.int64),
+        faces=faces,
+    )
+
+
+def flame_sequence(T: int, seed: int = 4) -> Dict[str, np.ndarray]:
+    """flame_param.npz schema (scene/flame_gaussian_model.py:61-71): smooth random walk of the
+    expression, sinusoidal jaw, small neck/global rotation, 1 cm translation jitter."""
+    g = np.random.default_rng(seed + 1000)
+    t = np.arange(T)[:, None]
+    expr = np.cumsum(g.normal(0, 0.15, (T, N_EXPR)), 0)
+    expr = expr / max(1.0, np.abs(expr).max() / 2.0)
+    jaw = np.zeros((T, 3))
+    jaw[:, 0] = 0.15 * (1 - np.cos(2 * np.pi * t[:, 0] / 60.0))
+    return dict(
+        shape=g.normal(0, 1.0, (N_SHAPE,)).astype(np.float32),
+        expr=expr.astype(np.float32),
+        rotation=(0.05 * np.sin(2 * np.pi * t / 150.0 + np.array([0, 1, 2]))).astype(np.float32),
+        neck_pose=(0.08 * np.sin(2 * np.pi * t / 90.0 + np.array([1, 2, 3]))).astype(np.float32),
+        jaw_pose=jaw.astype(np.float32),
+        eyes_pose=(0.1 * np.sin(2 * np.pi * t / 45.0 + np.arange(6))).astype(np.float32),
+        translation=g.normal(0, 0.01 / 3, (T, 3)).astype(np.float32),
+        static_offset=g.normal(0, 2e-4, (1, FLAME_V, 3)).astype(np.float32),
+        dynamic_offset=np.zeros((T, FLAME_V, 3), np.float32),
+    )
+
+
+def bound_splats(n: int, n_faces: int, sh_degree: int, seed: int) -> Dict[str, np.ndarray]:
+    """Leaf parameters of a mesh-bound GaussianModel (scene/gaussian_model.py:185-205 schema):
+    every face gets at least one splat, the remainder is uniform (SURVEY.md 8(d) cfg 2)."""
+    g = np.random.default_rng(seed)
+    assert n >= n_faces
+    binding = np.concatenate([np.arange(n_faces), g.integers(0, n_faces, n - n_faces)]).astype(np.int64)
+    g.shuffle(binding)
+    M = (sh_degree + 1) ** 2
+    rot = g.normal(0, 1, (n, 4))
+    rot /= np.linalg.norm(rot, axis=1, keepdims=True)
+    out = dict(
+        _xyz=g.normal(0, 0.35, (n, 3)).astype(np.float32),
+        _scaling=g.normal(math.log(0.35), 0.35, (n, 3)).astype(np.float32),
+        _rotation=rot.astype(np.float32),
+        _opacity=g.normal(1.0, 1.5, (n, 1)).astype(np.float32),
+        _features_dc=g.normal(0.5, 0.5, (n, 1, 3)).astype(np.float32),
+        _features_rest=g.normal(0.0, 0.08, (n, M - 1, 3)).astype(np.float32),
+        binding=binding,
+    )
+    return out
