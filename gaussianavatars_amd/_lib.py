@@ -1,0 +1,91 @@
+"""ctypes loader for the HIP shared libraries (C ABI of include/*.h).
+
+There is deliberately NO fallback: if the library is missing or does not export a symbol the
+import-time error says so.  The CPU oracle under oracle/ is test infrastructure and is never
+reachable from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+GSR_LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+
+GSR_OK = 0
+GSR_E_CAPACITY = 1
+
+
+class GsrSettings(C.Structure):
+    """include/gsr.h: GsrSettings"""
+    _fields_ = [
+        ("image_height", C.c_int32),
+        ("image_width", C.c_int32),
+        ("tanfovx", C.c_float),
+        ("tanfovy", C.c_float),
+        ("bg", C.c_void_p),
+        ("scale_modifier", C.c_float),
+        ("viewmatrix", C.c_void_p),
+        ("projmatrix", C.c_void_p),
+        ("sh_degree", C.c_int32),
+        ("campos", C.c_void_p),
+        ("prefiltered", C.c_int32),
+        ("debug", C.c_int32),
+    ]
+
+
+class GsrGeomLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in
+                ("depths", "xy", "conic_opacity", "rgb", "cov3D", "rect", "tiles_touched", "clamped", "total")]
+
+
+class GsrBinningLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in
+                ("keys", "point_list", "records", "ranges", "tile_count", "tile_start", "tile_cursor", "total")]
+
+
+class GsrImageLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("final_T", "n_contrib", "total")]
+
+
+#: every symbol include/gsr.h declares -> (restype, argtypes)
+GSR_SYMBOLS = {
+    "gsr_abi_version": (C.c_int, []),
+    "gsr_last_error": (C.c_char_p, []),
+    "gsr_geom_layout": (C.c_int, [C.c_int32, C.POINTER(GsrGeomLayout)]),
+    "gsr_binning_layout": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(GsrBinningLayout)]),
+    "gsr_image_layout": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(GsrImageLayout)]),
+    "gsr_forward": (C.c_int, [C.POINTER(GsrSettings), C.c_int32, C.c_int32] + [C.c_void_p] * 7 +
+                    [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                     C.POINTER(C.c_int64), C.c_void_p]),
+    "gsr_backward": (C.c_int, [C.POINTER(GsrSettings), C.c_int32, C.c_int32] + [C.c_void_p] * 6 +
+                     [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p] +
+                     [C.c_void_p] * 8 + [C.c_void_p]),
+    "gsr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_gsr = None
+
+
+def gsr():
+    """The rasterizer library; raises (never falls back) when it is not built."""
+    global _gsr
+    if _gsr is None:
+        if not os.path.exists(GSR_LIB_PATH):
+            raise RuntimeError(
+                f"{GSR_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+            )
+        lib = C.CDLL(GSR_LIB_PATH)
+        for name, (res, args) in GSR_SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        if lib.gsr_abi_version() != 1:
+            raise RuntimeError(f"gsr ABI version {lib.gsr_abi_version()} != 1")
+        _gsr = lib
+    return _gsr
+
+
+def gsr_error() -> str:
+    return gsr().gsr_last_error().decode("utf-8", "replace")

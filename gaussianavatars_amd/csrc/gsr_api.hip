@@ -1,0 +1,336 @@
+// gsr_api.hip -- the C ABI of include/gsr.h: argument checks, state-buffer layouts, the host
+// mailbox for the instance count, and the launch sequence.  No torch types; callers hand in raw
+// device pointers and a hipStream_t.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "gsr_device.h"
+
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return fail(GSR_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define KERNEL_CHECK(name, stream, debug)                                                                  \
+    do {                                                                                                   \
+        hipError_t e_ = hipGetLastError();                                                                 \
+        if (e_ != hipSuccess) return fail(GSR_E_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
+        if (debug) {                                                                                       \
+            e_ = hipStreamSynchronize(stream);                                                             \
+            if (e_ != hipSuccess) return fail(GSR_E_HIP, "%s faulted: %s", name, hipGetErrorString(e_));   \
+        }                                                                                                  \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- host mailbox: a small ring of 8-byte slots in mapped pinned memory -----------------------
+// k_tile_scan posts (seq << 40 | I) with one system-scope store; gsr_forward spins on the slot.
+struct Mailbox {
+    static constexpr int kSlots = 256;
+    unsigned long long* host = nullptr;
+    std::atomic<unsigned long long> seq{1};
+    std::mutex init_mu;
+    bool ready = false;
+    int init()
+    {
+        std::lock_guard<std::mutex> lk(init_mu);
+        if (ready) return 0;
+        HIP_TRY(hipHostMalloc((void**)&host, kSlots * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocPortable));
+        memset(host, 0, kSlots * sizeof(unsigned long long));
+        ready = true;
+        return 0;
+    }
+};
+Mailbox g_mail;
+
+gsr::Settings to_dev_settings(const GsrSettings* s)
+{
+    gsr::Settings d;
+    d.H = s->image_height;
+    d.W = s->image_width;
+    d.tanfovx = s->tanfovx;
+    d.tanfovy = s->tanfovy;
+    d.scale_modifier = s->scale_modifier;
+    d.sh_degree = s->sh_degree;
+    d.bg = s->bg;
+    d.viewmatrix = s->viewmatrix;
+    d.projmatrix = s->projmatrix;
+    d.campos = s->campos;
+    return d;
+}
+
+int check_settings(const GsrSettings* s)
+{
+    if (!s) return fail(GSR_E_ARG, "settings is NULL");
+    if (s->image_height <= 0 || s->image_width <= 0) return fail(GSR_E_ARG, "image size must be positive");
+    if (s->image_height > 65535 * 16 || s->image_width > 65535 * 16) return fail(GSR_E_ARG, "image too large for 16-bit tile rects");
+    if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->campos) return fail(GSR_E_ARG, "bg/viewmatrix/projmatrix/campos must be device pointers");
+    if (s->sh_degree < 0 || s->sh_degree > 3) return fail(GSR_E_ARG, "sh_degree must be in 0..3");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+const char* gsr_last_error(void) { return g_err; }
+
+int gsr_geom_layout(int32_t P, GsrGeomLayout* o)
+{
+    if (!o || P < 0) return fail(GSR_E_ARG, "gsr_geom_layout: bad arguments");
+    const size_t n = (size_t)P, A = 256;
+    size_t off = 0;
+    o->depths = off;        off = align_up(off + n * 4, A);
+    o->xy = off;            off = align_up(off + n * 8, A);
+    o->conic_opacity = off; off = align_up(off + n * 16, A);
+    o->rgb = off;           off = align_up(off + n * 16, A);
+    o->cov3D = off;         off = align_up(off + n * 24, A);
+    o->rect = off;          off = align_up(off + n * 8, A);
+    o->tiles_touched = off; off = align_up(off + n * 4, A);
+    o->clamped = off;       off = align_up(off + n, A);
+    o->total = off + A;
+    return 0;
+}
+
+int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, GsrBinningLayout* o)
+{
+    if (!o || capacity < 0 || width <= 0 || height <= 0) return fail(GSR_E_ARG, "gsr_binning_layout: bad arguments");
+    const size_t tiles = (size_t)((width + GSR_BLOCK_X - 1) / GSR_BLOCK_X) * (size_t)((height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y);
+    const size_t cap = (size_t)capacity, A = 256;
+    size_t off = 256;  // header: [0] = uint64 instance count of this frame
+    o->keys = off;        off = align_up(off + cap * 8, A);
+    o->point_list = off;  off = align_up(off + cap * 4, A);
+    o->records = off;     off = align_up(off + cap * 48, A);
+    o->ranges = off;      off = align_up(off + tiles * 8, A);
+    o->tile_count = off;  off = align_up(off + tiles * 4, A);
+    o->tile_start = off;  off = align_up(off + tiles * 4, A);
+    o->tile_cursor = off; off = align_up(off + tiles * 4, A);
+    o->total = off + A;
+    return 0;
+}
+
+int gsr_image_layout(int32_t width, int32_t height, GsrImageLayout* o)
+{
+    if (!o || width <= 0 || height <= 0) return fail(GSR_E_ARG, "gsr_image_layout: bad arguments");
+    const size_t hw = (size_t)width * (size_t)height, A = 256;
+    size_t off = 0;
+    o->final_T = off;   off = align_up(off + hw * 4, A);
+    o->n_contrib = off; off = align_up(off + hw * 4, A);
+    o->total = off + A;
+    return 0;
+}
+
+int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs,
+                const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
+                const float* cov3D_precomp, float* out_color, int32_t* radii, void* geom, void* binning,
+                int64_t binning_capacity, void* img, int64_t* num_rendered_host, void* stream_)
+{
+    if (int rc = check_settings(settings)) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0) return fail(GSR_E_ARG, "P must be >= 0");
+    if (!out_color || !num_rendered_host) return fail(GSR_E_ARG, "out_color / num_rendered_host is NULL");
+    if ((shs == nullptr) == (colors_precomp == nullptr))
+        return fail(GSR_E_ARG, "Please provide excatly one of either SHs or precomputed colors!");
+    const bool has_sr = scales != nullptr && rotations != nullptr;
+    if (((scales == nullptr) != (rotations == nullptr)) || (has_sr == (cov3D_precomp != nullptr)))
+        return fail(GSR_E_ARG, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (shs && M < (settings->sh_degree + 1) * (settings->sh_degree + 1))
+        return fail(GSR_E_ARG, "shs has %d coefficients per splat but sh_degree %d needs %d", M, settings->sh_degree,
+                    (settings->sh_degree + 1) * (settings->sh_degree + 1));
+    if (P > 0 && (!means3D || !opacities || !radii || !geom)) return fail(GSR_E_ARG, "NULL splat buffer");
+    if (!binning || !img) return fail(GSR_E_ARG, "NULL state buffer");
+    if (binning_capacity < 0 || binning_capacity >= (1ll << 32)) return fail(GSR_E_ARG, "binning_capacity out of range");
+
+    const int W = settings->image_width, H = settings->image_height;
+    const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    const int tiles = gx * gy;
+    const bool dbg = settings->debug != 0;
+    if (int rc = g_mail.init()) return rc;
+
+    GsrGeomLayout gl;
+    GsrBinningLayout bl;
+    GsrImageLayout il;
+    gsr_geom_layout(P, &gl);
+    gsr_binning_layout(binning_capacity, W, H, &bl);
+    gsr_image_layout(W, H, &il);
+    char* g = (char*)geom;
+    char* b = (char*)binning;
+    char* im = (char*)img;
+    unsigned long long* total_dev = (unsigned long long*)b;
+    uint32_t* tile_count = (uint32_t*)(b + bl.tile_count);
+
+    gsr::Settings ds = to_dev_settings(settings);
+    HIP_TRY(hipMemsetAsync(tile_count, 0, (size_t)tiles * 4, stream));
+
+    gsr::PreprocessArgs pa;
+    pa.P = P; pa.M = M;
+    pa.means3D = means3D; pa.shs = shs; pa.colors_precomp = colors_precomp; pa.opacities = opacities;
+    pa.scales = scales; pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp;
+    pa.radii = radii;
+    pa.depths = (float*)(g + gl.depths);
+    pa.xy = (float2*)(g + gl.xy);
+    pa.conic_opacity = (float4*)(g + gl.conic_opacity);
+    pa.rgb = (float4*)(g + gl.rgb);
+    pa.cov3D = (float*)(g + gl.cov3D);
+    pa.rect = (ushort4*)(g + gl.rect);
+    pa.tiles_touched = (uint32_t*)(g + gl.tiles_touched);
+    pa.clamped = (uint8_t*)(g + gl.clamped);
+    pa.tile_count = tile_count;
+    const int pblocks = (P + 255) / 256;
+    if (pblocks > 0) {
+        hipLaunchKernelGGL(gsr::k_preprocess, dim3(pblocks), dim3(256), 0, stream, ds, pa);
+        KERNEL_CHECK("k_preprocess", stream, dbg);
+    }
+
+    const unsigned long long seq = (g_mail.seq.fetch_add(1) % 0xFFFFFEull) + 1;  // 1 .. 2^24-2, never 0
+    volatile unsigned long long* slot = g_mail.host + (seq % Mailbox::kSlots);
+    *slot = 0;
+    unsigned long long* slot_dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void**)&slot_dev, (void*)slot, 0));
+    hipLaunchKernelGGL(gsr::k_tile_scan, dim3(1), dim3(1024), 0, stream, tiles, (const uint32_t*)tile_count,
+                       (uint32_t*)(b + bl.tile_start), (uint32_t*)(b + bl.tile_cursor), (uint2*)(b + bl.ranges), total_dev,
+                       slot_dev, seq);
+    KERNEL_CHECK("k_tile_scan", stream, dbg);
+
+    // Optimistic launch: the rest of the frame is enqueued against the caller's capacity before the
+    // host knows I; every kernel re-checks *total_dev <= capacity on the device and does nothing
+    // otherwise.  The host then waits only for the scan (early in the frame), not for the frame.
+    const unsigned long long cap = (unsigned long long)binning_capacity;
+    if (pblocks > 0) {
+        hipLaunchKernelGGL(gsr::k_scatter, dim3(pblocks), dim3(256), 0, stream, P, gx, (const float*)pa.depths,
+                           (const ushort4*)pa.rect, (const uint32_t*)pa.tiles_touched, (const uint32_t*)(b + bl.tile_start),
+                           (uint32_t*)(b + bl.tile_cursor), (unsigned long long*)(b + bl.keys), cap,
+                           (const unsigned long long*)total_dev);
+        KERNEL_CHECK("k_scatter", stream, dbg);
+        hipLaunchKernelGGL(gsr::k_tile_sort, dim3(tiles), dim3(256), 0, stream, tiles, (const uint32_t*)tile_count,
+                           (const uint32_t*)(b + bl.tile_start), (unsigned long long*)(b + bl.keys),
+                           (uint32_t*)(b + bl.point_list), (float4*)(b + bl.records), (const float2*)pa.xy,
+                           (const float4*)pa.conic_opacity, (const float4*)pa.rgb, cap, (const unsigned long long*)total_dev);
+        KERNEL_CHECK("k_tile_sort", stream, dbg);
+    }
+    hipLaunchKernelGGL(gsr::k_render, dim3(gx, gy), dim3(256), 0, stream, ds, (const uint2*)(b + bl.ranges),
+                       (const float4*)(b + bl.records), (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib), out_color,
+                       cap, (const unsigned long long*)total_dev);
+    KERNEL_CHECK("k_render", stream, dbg);
+
+    // wait for the scan's post
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long long v;
+    unsigned spins = 0;
+    for (;;) {
+        v = __atomic_load_n((unsigned long long*)slot, __ATOMIC_ACQUIRE);
+        if (v != 0 && (v >> 40) == seq) break;
+        if (++spins > 2000) {
+            std::this_thread::yield();
+            if ((spins & 0xFFF) == 0) {
+                if (hipStreamQuery(stream) != hipErrorNotReady) {
+                    // stream drained (or faulted) without a post
+                    v = __atomic_load_n((unsigned long long*)slot, __ATOMIC_ACQUIRE);
+                    if (v != 0 && (v >> 40) == seq) break;
+                    hipError_t e = hipStreamSynchronize(stream);
+                    return fail(GSR_E_HIP, "stream finished without posting the instance count: %s", hipGetErrorString(e));
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+                    return fail(GSR_E_TIMEOUT, "timed out waiting for the instance count");
+            }
+        }
+    }
+    const int64_t I = (int64_t)(v & 0xFFFFFFFFFFull);
+    *num_rendered_host = I;
+    if (I > binning_capacity) return fail(GSR_E_CAPACITY, "binning capacity %lld < %lld instances", (long long)binning_capacity, (long long)I);
+    return GSR_OK;
+}
+
+int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs,
+                 const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
+                 const int32_t* radii, const void* geom, const void* binning, int64_t binning_capacity, const void* img,
+                 int64_t num_rendered, const float* dL_dpix, float* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D,
+                 float* dL_dsh, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                 float* dL_dcov3D, void* stream_)
+{
+    if (int rc = check_settings(settings)) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0 || num_rendered < 0 || binning_capacity < num_rendered) return fail(GSR_E_ARG, "bad sizes");
+    if (P == 0) return GSR_OK;
+    if (!means3D || !radii || !geom || !binning || !img || !dL_dpix || !grad_scratch || !dL_dmeans3D || !dL_dmeans2D ||
+        !dL_dcolors || !dL_dopacity || !dL_dcov3D)
+        return fail(GSR_E_ARG, "NULL buffer");
+    const bool pre_col = colors_precomp != nullptr, pre_cov = cov3D_precomp != nullptr;
+    if (!pre_col && (!shs || !dL_dsh)) return fail(GSR_E_ARG, "shs / dL_dsh required when colours come from SH");
+    if (!pre_cov && (!scales || !rotations || !dL_dscales || !dL_drotations))
+        return fail(GSR_E_ARG, "scales/rotations and their gradients required when cov3D is not precomputed");
+
+    const int W = settings->image_width, H = settings->image_height;
+    const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    const bool dbg = settings->debug != 0;
+    GsrGeomLayout gl;
+    GsrBinningLayout bl;
+    GsrImageLayout il;
+    gsr_geom_layout(P, &gl);
+    gsr_binning_layout(binning_capacity, W, H, &bl);
+    gsr_image_layout(W, H, &il);
+    const char* g = (const char*)geom;
+    const char* b = (const char*)binning;
+    const char* im = (const char*)img;
+    gsr::Settings ds = to_dev_settings(settings);
+
+    HIP_TRY(hipMemsetAsync(grad_scratch, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), stream));
+    if (num_rendered > 0) {
+        hipLaunchKernelGGL(gsr::k_render_bwd, dim3(gx, gy), dim3(256), 0, stream, ds, (const uint2*)(b + bl.ranges),
+                           (const float4*)(b + bl.records), (const float*)(im + il.final_T),
+                           (const uint32_t*)(im + il.n_contrib), dL_dpix, grad_scratch);
+        KERNEL_CHECK("k_render_bwd", stream, dbg);
+    }
+    gsr::PreBwdArgs pa;
+    pa.P = P; pa.M = M;
+    pa.means3D = means3D; pa.shs = shs; pa.scales = scales; pa.rotations = rotations;
+    pa.cov3D = (const float*)(g + gl.cov3D);
+    pa.radii = radii;
+    pa.clamped = (const uint8_t*)(g + gl.clamped);
+    pa.acc = grad_scratch;
+    pa.use_precomp_cov = pre_cov ? 1 : 0;
+    pa.use_precomp_color = pre_col ? 1 : 0;
+    pa.dL_dmeans3D = dL_dmeans3D; pa.dL_dmeans2D = dL_dmeans2D; pa.dL_dsh = pre_col ? nullptr : dL_dsh;
+    pa.dL_dcolors = dL_dcolors; pa.dL_dopacity = dL_dopacity;
+    pa.dL_dscales = pre_cov ? nullptr : dL_dscales; pa.dL_drotations = pre_cov ? nullptr : dL_drotations;
+    pa.dL_dcov3D = dL_dcov3D;
+    hipLaunchKernelGGL(gsr::k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, stream, ds, pa);
+    KERNEL_CHECK("k_preprocess_bwd", stream, dbg);
+    return GSR_OK;
+}
+
+int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present, void* stream_)
+{
+    (void)projmatrix;
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return fail(GSR_E_ARG, "gsr_mark_visible: bad arguments");
+    if (P == 0) return GSR_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(gsr::k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, stream, P, means3D, viewmatrix, present);
+    KERNEL_CHECK("k_mark_visible", stream, false);
+    return GSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,340 @@
+// gsr_backward.hip -- backward kernels of the MI355X-native splat rasterizer (gfx950, wave64).
+//
+//   k_render_bwd      per tile : 4 waves x 8x8 pixels walk the tile's record stream back to front
+//                                (scalar-unit loads, as in the forward); the nine per-(pixel,splat)
+//                                partials are summed across the wave on the DPP network and
+//                                leave as ONE 9-lane atomic burst into a 48-byte-per-splat
+//                                accumulator -- 64x fewer atomics than a per-pixel formulation
+//   k_preprocess_bwd  per splat: conic -> cov2D -> (cov3D, mean), projective divide, SH, and
+//                                cov3D -> (scale, raw quaternion); writes every output row
+//                                (zeros for culled splats) so no gradient buffer needs a memset
+//
+// Behavioural spec: SURVEY.md Appendix A.4.  Summation order differs from any other
+// implementation (float atomics), so this path is compared with a tolerance, never bit-wise.
+#include "gsr_device.h"
+
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace gsr {
+
+__global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint2* __restrict__ ranges,
+                                                     const float4* __restrict__ records, const float* __restrict__ final_T,
+                                                     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                                                     float* __restrict__ acc /* [P][GSR_ACC_STRIDE] */)
+{
+    const int W = s.W, H = s.H;
+    const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X;
+    const int tile = blockIdx.y * gx + blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int pxi = blockIdx.x * GSR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
+    const int pyi = blockIdx.y * GSR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const float pixx = (float)pxi, pixy = (float)pyi;
+    const uint2 range = ranges[tile];
+    const float4* __restrict__ rec = records + (size_t)3 * range.x;
+
+    const int pix_id = W * pyi + pxi;
+    const size_t HW = (size_t)H * W;
+    const float T_final = inside ? final_T[pix_id] : 0.f;
+    const uint32_t last = inside ? n_contrib[pix_id] : 0u;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (inside) {
+        g0 = dL_dpix[0 * HW + pix_id];
+        g1 = dL_dpix[1 * HW + pix_id];
+        g2 = dL_dpix[2 * HW + pix_id];
+    }
+    const float bg_dot = s.bg[0] * g0 + s.bg[1] * g1 + s.bg[2] * g2;
+    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+
+    float T = T_final;
+    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f;      // colour accumulated behind the current splat
+    float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;      // colour of the previously visited splat
+    float last_alpha = 0.f;
+
+    const int jmax = (int)wave_max_u32(last);    // wave-uniform: the deepest contributor of any pixel
+    for (int j = jmax - 1; j >= 0; --j) {
+        const float4 r0 = rec[3 * j + 0];
+        const float4 r1 = rec[3 * j + 1];
+        const float4 r2 = rec[3 * j + 2];
+        float v_c0 = 0.f, v_c1 = 0.f, v_c2 = 0.f, v_mx = 0.f, v_my = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_op = 0.f;
+        bool hit = false;
+        if ((uint32_t)j < last) {
+            const float dx = r0.x - pixx;
+            const float dy = r0.y - pixy;
+            const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+            if (power <= 0.0f) {
+                const float G = gsr_expf(power);
+                const float alpha = sel_min(0.99f, r1.y * G);
+                if (alpha >= 1.0f / 255.0f) {
+                    hit = true;
+                    const float one_m = 1.f - alpha;
+                    T = T * __builtin_amdgcn_rcpf(one_m);
+                    const float w = alpha * T;
+                    ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0;
+                    ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1;
+                    ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2;
+                    lc0 = r1.z; lc1 = r1.w; lc2 = r2.x;
+                    float dL_dalpha = (lc0 - ar0) * g0 + (lc1 - ar1) * g1 + (lc2 - ar2) * g2;
+                    v_c0 = w * g0; v_c1 = w * g1; v_c2 = w * g2;
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final * __builtin_amdgcn_rcpf(one_m)) * bg_dot;
+                    const float dL_dG = r1.y * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * r0.z - gdy * r0.w;
+                    const float dG_ddely = -gdy * r1.x - gdx * r0.w;
+                    v_mx = dL_dG * dG_ddelx * ddelx_dx;
+                    v_my = dL_dG * dG_ddely * ddely_dy;
+                    v_ca = -0.5f * gdx * dx * dL_dG;
+                    v_cb = -0.5f * gdx * dy * dL_dG;
+                    v_cc = -0.5f * gdy * dy * dL_dG;
+                    v_op = G * dL_dalpha;
+                }
+            }
+        }
+        if (__ballot(hit) == 0ull) continue;      // no pixel of this wave touched the splat
+        v_c0 = wave_sum_hi(v_c0);
+        v_c1 = wave_sum_hi(v_c1);
+        v_c2 = wave_sum_hi(v_c2);
+        v_mx = wave_sum_hi(v_mx);
+        v_my = wave_sum_hi(v_my);
+        v_ca = wave_sum_hi(v_ca);
+        v_cb = wave_sum_hi(v_cb);
+        v_cc = wave_sum_hi(v_cc);
+        v_op = wave_sum_hi(v_op);
+        // lanes 48..56 each own one of the nine sums -> one 36-byte atomic burst
+        const int k = lane - 48;
+        float mine = v_c0;
+        mine = (k == 1) ? v_c1 : mine;
+        mine = (k == 2) ? v_c2 : mine;
+        mine = (k == 3) ? v_mx : mine;
+        mine = (k == 4) ? v_my : mine;
+        mine = (k == 5) ? v_ca : mine;
+        mine = (k == 6) ? v_cb : mine;
+        mine = (k == 7) ? v_cc : mine;
+        mine = (k == 8) ? v_op : mine;
+        const uint32_t id = __float_as_uint(r2.y);
+        if (k >= 0 && k < 9) unsafeAtomicAdd(acc + (size_t)GSR_ACC_STRIDE * id + k, mine);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.P) return;
+    const int M = a.M;
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dscale[3] = {0.f, 0.f, 0.f};
+    float drot[4] = {0.f, 0.f, 0.f, 0.f};
+    float gcol[3] = {0.f, 0.f, 0.f};
+    float g2x = 0.f, g2y = 0.f, gop = 0.f;
+    const bool vis = a.radii[i] > 0;
+    float* gsh = a.dL_dsh ? a.dL_dsh + (size_t)3 * M * i : nullptr;
+
+    if (vis) {
+        const float* ac = a.acc + (size_t)GSR_ACC_STRIDE * i;
+        gcol[0] = ac[0]; gcol[1] = ac[1]; gcol[2] = ac[2];
+        g2x = ac[3]; g2y = ac[4];
+        const float gA = ac[5], gB = ac[6], gC = ac[7];
+        gop = ac[8];
+        const float* vm = s.viewmatrix;
+        const float* proj = s.projmatrix;
+        const int W = s.W, H = s.H;
+        const float fx = (float)W / (2.0f * s.tanfovx), fy = (float)H / (2.0f * s.tanfovy);
+        const float mx = a.means3D[3 * i], my = a.means3D[3 * i + 1], mz = a.means3D[3 * i + 2];
+        const float* c6 = a.cov3D + 6 * i;
+
+        // ---- conic -> cov2D -> (Sigma, mean) -------------------------------------------------
+        float t0 = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
+        float t1 = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
+        const float t2 = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+        const float limx = 1.3f * s.tanfovx, limy = 1.3f * s.tanfovy;
+        const float txtz = t0 / t2, tytz = t1 / t2;
+        t0 = sel_min(limx, sel_max(-limx, txtz)) * t2;
+        t1 = sel_min(limy, sel_max(-limy, tytz)) * t2;
+        const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+        const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+        const float J00 = fx / t2, J02 = -(fx * t0) / (t2 * t2), J11 = fy / t2, J12 = -(fy * t1) / (t2 * t2);
+        float A[2][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            A[0][j] = J00 * vm[4 * j + 0] + J02 * vm[4 * j + 2];
+            A[1][j] = J11 * vm[4 * j + 1] + J12 * vm[4 * j + 2];
+        }
+        const float V[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+        float AV[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) AV[r][j] = A[r][0] * V[0][j] + A[r][1] * V[1][j] + A[r][2] * V[2][j];
+        const float ca = AV[0][0] * A[0][0] + AV[0][1] * A[0][1] + AV[0][2] * A[0][2] + 0.3f;
+        const float cb = AV[0][0] * A[1][0] + AV[0][1] * A[1][1] + AV[0][2] * A[1][2];
+        const float cc = AV[1][0] * A[1][0] + AV[1][1] * A[1][1] + AV[1][2] * A[1][2] + 0.3f;
+        const float denom = ca * cc - cb * cb;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        if (denom2inv != 0.f) {
+            dL_da = denom2inv * (-cc * cc * gA + 2.f * cb * cc * gB + (denom - ca * cc) * gC);
+            dL_dc = denom2inv * (-ca * ca * gC + 2.f * ca * cb * gB + (denom - ca * cc) * gA);
+            dL_db = denom2inv * 2.f * (cb * cc * gA - (denom + 2.f * cb * cb) * gB + ca * cb * gC);
+            gcov[0] = A[0][0] * A[0][0] * dL_da + A[0][0] * A[1][0] * dL_db + A[1][0] * A[1][0] * dL_dc;
+            gcov[3] = A[0][1] * A[0][1] * dL_da + A[0][1] * A[1][1] * dL_db + A[1][1] * A[1][1] * dL_dc;
+            gcov[5] = A[0][2] * A[0][2] * dL_da + A[0][2] * A[1][2] * dL_db + A[1][2] * A[1][2] * dL_dc;
+            gcov[1] = 2.f * A[0][0] * A[0][1] * dL_da + (A[0][0] * A[1][1] + A[0][1] * A[1][0]) * dL_db + 2.f * A[1][0] * A[1][1] * dL_dc;
+            gcov[2] = 2.f * A[0][0] * A[0][2] * dL_da + (A[0][0] * A[1][2] + A[0][2] * A[1][0]) * dL_db + 2.f * A[1][0] * A[1][2] * dL_dc;
+            gcov[4] = 2.f * A[0][2] * A[0][1] * dL_da + (A[0][1] * A[1][2] + A[0][2] * A[1][1]) * dL_db + 2.f * A[1][1] * A[1][2] * dL_dc;
+        }
+        float dA[2][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float a0v = A[0][0] * V[j][0] + A[0][1] * V[j][1] + A[0][2] * V[j][2];
+            const float a1v = A[1][0] * V[j][0] + A[1][1] * V[j][1] + A[1][2] * V[j][2];
+            dA[0][j] = 2.f * a0v * dL_da + a1v * dL_db;
+            dA[1][j] = 2.f * a1v * dL_dc + a0v * dL_db;
+        }
+        const float dJ00 = vm[0] * dA[0][0] + vm[4] * dA[0][1] + vm[8] * dA[0][2];
+        const float dJ02 = vm[2] * dA[0][0] + vm[6] * dA[0][1] + vm[10] * dA[0][2];
+        const float dJ11 = vm[1] * dA[1][0] + vm[5] * dA[1][1] + vm[9] * dA[1][2];
+        const float dJ12 = vm[2] * dA[1][0] + vm[6] * dA[1][1] + vm[10] * dA[1][2];
+        const float tz = 1.f / t2, tz2 = tz * tz, tz3 = tz2 * tz;
+        const float dtx = x_grad_mul * -fx * tz2 * dJ02;
+        const float dty = y_grad_mul * -fy * tz2 * dJ12;
+        const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * t0) * tz3 * dJ02 + (2.f * fy * t1) * tz3 * dJ12;
+        dmean[0] = vm[0] * dtx + vm[1] * dty + vm[2] * dtz;
+        dmean[1] = vm[4] * dtx + vm[5] * dty + vm[6] * dtz;
+        dmean[2] = vm[8] * dtx + vm[9] * dty + vm[10] * dtz;
+
+        // ---- projective divide: d(ndc.xy)/d(mean) --------------------------------------------
+        const float hw = proj[3] * mx + proj[7] * my + proj[11] * mz + proj[15];
+        const float m_w = 1.0f / (hw + 0.0000001f);
+        const float mul1 = (proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12]) * m_w * m_w;
+        const float mul2 = (proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13]) * m_w * m_w;
+        dmean[0] += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+        dmean[1] += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+        dmean[2] += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+
+        // ---- SH: coefficients and view direction ---------------------------------------------
+        if (!a.use_precomp_color) {
+            const float* sh = a.shs + (size_t)3 * M * i;
+            const int deg = s.sh_degree;
+            const float d0 = mx - s.campos[0], d1 = my - s.campos[1], d2 = mz - s.campos[2];
+            const float sum2 = d0 * d0 + d1 * d1 + d2 * d2;
+            const float inv_len = 1.0f / sqrtf(sum2);
+            const float x = d0 * inv_len, y = d1 * inv_len, z = d2 * inv_len;
+            const uint32_t cl = a.clamped[i];
+            float ddir[3] = {0.f, 0.f, 0.f};
+            const float xx = x * x, yy = y * y, zz = z * z, xy_ = x * y, yz = y * z, xz = x * z;
+            const int ncoef = (deg + 1) * (deg + 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float g = ((cl >> c) & 1u) ? 0.f : gcol[c];
+                float dxs = 0.f, dys = 0.f, dzs = 0.f;
+                gsh[0 + c] = kC0 * g;
+                if (deg > 0) {
+                    gsh[3 + c] = -kC1 * y * g;
+                    gsh[6 + c] = kC1 * z * g;
+                    gsh[9 + c] = -kC1 * x * g;
+                    dxs = -kC1 * sh[9 + c];
+                    dys = -kC1 * sh[3 + c];
+                    dzs = kC1 * sh[6 + c];
+                    if (deg > 1) {
+                        gsh[12 + c] = kC2_0 * xy_ * g;
+                        gsh[15 + c] = kC2_1 * yz * g;
+                        gsh[18 + c] = kC2_2 * (2.f * zz - xx - yy) * g;
+                        gsh[21 + c] = kC2_3 * xz * g;
+                        gsh[24 + c] = kC2_4 * (xx - yy) * g;
+                        dxs += kC2_0 * y * sh[12 + c] + kC2_2 * 2.f * -x * sh[18 + c] + kC2_3 * z * sh[21 + c] + kC2_4 * 2.f * x * sh[24 + c];
+                        dys += kC2_0 * x * sh[12 + c] + kC2_1 * z * sh[15 + c] + kC2_2 * 2.f * -y * sh[18 + c] + kC2_4 * 2.f * -y * sh[24 + c];
+                        dzs += kC2_1 * y * sh[15 + c] + kC2_2 * 2.f * 2.f * z * sh[18 + c] + kC2_3 * x * sh[21 + c];
+                        if (deg > 2) {
+                            gsh[27 + c] = kC3_0 * y * (3.f * xx - yy) * g;
+                            gsh[30 + c] = kC3_1 * xy_ * z * g;
+                            gsh[33 + c] = kC3_2 * y * (4.f * zz - xx - yy) * g;
+                            gsh[36 + c] = kC3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy) * g;
+                            gsh[39 + c] = kC3_4 * x * (4.f * zz - xx - yy) * g;
+                            gsh[42 + c] = kC3_5 * z * (xx - yy) * g;
+                            gsh[45 + c] = kC3_6 * x * (xx - 3.f * yy) * g;
+                            dxs += kC3_0 * sh[27 + c] * 3.f * 2.f * xy_ + kC3_1 * sh[30 + c] * yz + kC3_2 * sh[33 + c] * -2.f * xy_ +
+                                   kC3_3 * sh[36 + c] * -3.f * 2.f * xz + kC3_4 * sh[39 + c] * (-3.f * xx + 4.f * zz - yy) +
+                                   kC3_5 * sh[42 + c] * 2.f * xz + kC3_6 * sh[45 + c] * 3.f * (xx - yy);
+                            dys += kC3_0 * sh[27 + c] * 3.f * (xx - yy) + kC3_1 * sh[30 + c] * xz +
+                                   kC3_2 * sh[33 + c] * (-3.f * yy + 4.f * zz - xx) + kC3_3 * sh[36 + c] * -3.f * 2.f * yz +
+                                   kC3_4 * sh[39 + c] * -2.f * xy_ + kC3_5 * sh[42 + c] * -2.f * yz + kC3_6 * sh[45 + c] * -3.f * 2.f * xy_;
+                            dzs += kC3_1 * sh[30 + c] * xy_ + kC3_2 * sh[33 + c] * 4.f * 2.f * yz +
+                                   kC3_3 * sh[36 + c] * 3.f * (2.f * zz - xx - yy) + kC3_4 * sh[39 + c] * 4.f * 2.f * xz +
+                                   kC3_5 * sh[42 + c] * (xx - yy);
+                        }
+                    }
+                }
+                ddir[0] += dxs * g;
+                ddir[1] += dys * g;
+                ddir[2] += dzs * g;
+            }
+            for (int k = 3 * ncoef; k < 3 * M; ++k) gsh[k] = 0.f;   // coefficients above the active degree
+            const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            dmean[0] += ((sum2 - d0 * d0) * ddir[0] - d1 * d0 * ddir[1] - d2 * d0 * ddir[2]) * invsum32;
+            dmean[1] += (-d0 * d1 * ddir[0] + (sum2 - d1 * d1) * ddir[1] - d2 * d1 * ddir[2]) * invsum32;
+            dmean[2] += (-d0 * d2 * ddir[0] - d1 * d2 * ddir[1] + (sum2 - d2 * d2) * ddir[2]) * invsum32;
+        }
+
+        // ---- Sigma -> scale, raw quaternion --------------------------------------------------
+        if (!a.use_precomp_cov) {
+            const float4 q = reinterpret_cast<const float4*>(a.rotations)[i];
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            float R[3][3];
+            R[0][0] = 1.f - 2.f * (y * y + z * z);
+            R[0][1] = 2.f * (x * y - r * z);
+            R[0][2] = 2.f * (x * z + r * y);
+            R[1][0] = 2.f * (x * y + r * z);
+            R[1][1] = 1.f - 2.f * (x * x + z * z);
+            R[1][2] = 2.f * (y * z - r * x);
+            R[2][0] = 2.f * (x * z - r * y);
+            R[2][1] = 2.f * (y * z + r * x);
+            R[2][2] = 1.f - 2.f * (x * x + y * y);
+            const float mod = s.scale_modifier;
+            const float sc[3] = {mod * a.scales[3 * i], mod * a.scales[3 * i + 1], mod * a.scales[3 * i + 2]};
+            const float gS[3][3] = {{gcov[0], 0.5f * gcov[1], 0.5f * gcov[2]},
+                                    {0.5f * gcov[1], gcov[3], 0.5f * gcov[4]},
+                                    {0.5f * gcov[2], 0.5f * gcov[4], gcov[5]}};
+            float dR[3][3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float dMk[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    dMk[j] = 2.0f * sc[k] * (R[0][k] * gS[0][j] + R[1][k] * gS[1][j] + R[2][k] * gS[2][j]);
+                dscale[k] = mod * (R[0][k] * dMk[0] + R[1][k] * dMk[1] + R[2][k] * dMk[2]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) dR[j][k] = sc[k] * dMk[j];
+            }
+            drot[0] = 2.f * z * (dR[1][0] - dR[0][1]) + 2.f * y * (dR[0][2] - dR[2][0]) + 2.f * x * (dR[2][1] - dR[1][2]);
+            drot[1] = 2.f * y * (dR[0][1] + dR[1][0]) + 2.f * z * (dR[0][2] + dR[2][0]) + 2.f * r * (dR[2][1] - dR[1][2]) - 4.f * x * (dR[2][2] + dR[1][1]);
+            drot[2] = 2.f * x * (dR[0][1] + dR[1][0]) + 2.f * r * (dR[0][2] - dR[2][0]) + 2.f * z * (dR[1][2] + dR[2][1]) - 4.f * y * (dR[2][2] + dR[0][0]);
+            drot[3] = 2.f * r * (dR[1][0] - dR[0][1]) + 2.f * x * (dR[0][2] + dR[2][0]) + 2.f * y * (dR[1][2] + dR[2][1]) - 4.f * z * (dR[1][1] + dR[0][0]);
+        }
+    } else if (gsh) {
+        for (int k = 0; k < 3 * M; ++k) gsh[k] = 0.f;
+    }
+
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a.dL_dmeans3D[3 * i + k] = dmean[k];
+    a.dL_dmeans2D[3 * i + 0] = g2x;
+    a.dL_dmeans2D[3 * i + 1] = g2y;
+    a.dL_dmeans2D[3 * i + 2] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a.dL_dcolors[3 * i + k] = gcol[k];
+    a.dL_dopacity[i] = gop;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.dL_dcov3D[6 * i + k] = gcov[k];
+    if (a.dL_dscales) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.dL_dscales[3 * i + k] = dscale[k];
+    }
+    if (a.dL_drotations) reinterpret_cast<float4*>(a.dL_drotations)[i] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+}
+
+}  // namespace gsr

@@ -1,0 +1,218 @@
+// gsr_device.h -- device-side helpers shared by the rasterizer kernels (gfx950 only).
+//
+// Numerics contract of the FORWARD path (what makes it bit-reproducible against a CPU
+// restatement): fp32, translation units built with -ffp-contract=off, expressions evaluated in
+// the order written, IEEE division / sqrtf (hipcc's default correctly-rounded forms), and
+// gsr_expf() below instead of a library exp.  The one fp64 spot is ndc2pix, which the upstream
+// rasterizer writes with double literals.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gsr.h"
+
+#define GSR_WAVE 64
+#define GSR_TILE_PIX (GSR_BLOCK_X * GSR_BLOCK_Y)
+#define GSR_SORT_LDS_KEYS 8192   // 64 KiB of uint64 keys per workgroup in the tile sort
+#define GSR_ACC_STRIDE 12        // floats per splat in the backward accumulator (48 B, one atomic burst)
+
+namespace gsr {
+
+struct Settings {  // by-value kernel argument: scalars + the four device pointers of GsrSettings
+    int H, W;
+    float tanfovx, tanfovy;
+    float scale_modifier;
+    int sh_degree;
+    const float* __restrict__ bg;
+    const float* __restrict__ viewmatrix;
+    const float* __restrict__ projmatrix;
+    const float* __restrict__ campos;
+};
+
+// SH basis constants (values of the reference's utils/sh_utils.py:26-43)
+__device__ constexpr float kC0 = 0.28209479177387814f;
+__device__ constexpr float kC1 = 0.4886025119029199f;
+__device__ constexpr float kC2_0 = 1.0925484305920792f;
+__device__ constexpr float kC2_1 = -1.0925484305920792f;
+__device__ constexpr float kC2_2 = 0.31539156525252005f;
+__device__ constexpr float kC2_3 = -1.0925484305920792f;
+__device__ constexpr float kC2_4 = 0.5462742152960396f;
+__device__ constexpr float kC3_0 = -0.5900435899266435f;
+__device__ constexpr float kC3_1 = 2.890611442640554f;
+__device__ constexpr float kC3_2 = -0.4570457994644658f;
+__device__ constexpr float kC3_3 = 0.3731763325901154f;
+__device__ constexpr float kC3_4 = -0.4570457994644658f;
+__device__ constexpr float kC3_5 = 1.445305721320277f;
+__device__ constexpr float kC3_6 = -0.5900435899266435f;
+
+__device__ __forceinline__ float sel_min(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float sel_max(float a, float b) { return a > b ? a : b; }
+
+// exp(x) for the compositing weights: 2^(x*log2e) with n = rint(x*log2e), the fraction rebuilt by
+// two fmaf against a hi/lo split of log2e, a degree-7 polynomial for 2^f and an exact scale by 2^n.
+// Only fmaf / rint / ldexp, so a CPU evaluates the same bits.
+__device__ __forceinline__ float gsr_expf(float x)
+{
+    if (!(x > -87.0f)) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    const float l2e_hi = 1.44269502162933349609375f;
+    const float l2e_lo = 1.92596299112661746e-8f;
+    const float n = __builtin_rintf(x * l2e_hi);
+    float f = __builtin_fmaf(x, l2e_hi, -n);
+    f = __builtin_fmaf(x, l2e_lo, f);
+    float p = 1.52527338040598402800e-5f;
+    p = __builtin_fmaf(p, f, 1.54035303933816099544e-4f);
+    p = __builtin_fmaf(p, f, 1.33335581464284434234e-3f);
+    p = __builtin_fmaf(p, f, 9.61812910762847716197e-3f);
+    p = __builtin_fmaf(p, f, 5.55041086648215799532e-2f);
+    p = __builtin_fmaf(p, f, 2.40226506959100712334e-1f);
+    p = __builtin_fmaf(p, f, 6.93147180559945309417e-1f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    return __builtin_ldexpf(p, (int)n);
+}
+
+// float -> int32 with saturation and NaN -> 0 (what v_cvt_i32_f32 does, spelled out so that the
+// C++ out-of-range UB never enters)
+__device__ __forceinline__ int f2i_sat(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+
+__device__ __forceinline__ float ndc2pix(float v, int S)
+{
+    return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5);
+}
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// ---- wave64 reductions on the DPP network -------------------------------------------------
+// xor-butterfly inside each 16-lane row (quad_perm, row_half_mirror, row_mirror), then
+// row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3: lanes 48..63 end up holding the
+// full 64-lane sum.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_hi(float v)
+{
+    v += dpp_f<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x141, 0xf>(v);  // row_half_mirror
+    v += dpp_f<0x140, 0xf>(v);  // row_mirror
+    v += dpp_f<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+    v += dpp_f<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+    return v;                   // valid in lanes 48..63
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    // ds_swizzle-free max: butterfly through readlane-able DPP moves
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false));
+    uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+    uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
+    uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return mx(mx(a, b), mx(c, d));
+}
+
+// ---- tile-rect expansion shared by the counting and the scatter pass ------------------------
+// Calls f(tile_id, k) for every tile of the rect.  Splats touching <= SMALL tiles are expanded by
+// their own lane; larger ones are expanded cooperatively by the whole wave (one splat at a time,
+// lanes striding the rect) so a screen-filling splat does not serialise one lane for thousands of
+// iterations.  Must be called by all 64 lanes (n == 0 for idle ones).
+template <typename F>
+__device__ __forceinline__ void for_each_tile(int minx, int miny, int maxx, int maxy, uint32_t n, int gx, F f,
+                                              uint32_t payload0, uint32_t payload1)
+{
+    constexpr uint32_t SMALL = 16;
+    if (n > 0 && n <= SMALL) {
+        for (int y = miny; y < maxy; ++y)
+            for (int x = minx; x < maxx; ++x) f((uint32_t)(y * gx + x), payload0, payload1);
+    }
+    uint64_t big = __ballot(n > SMALL);
+    const int lane = lane_id();
+    while (big) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        const int bminx = __builtin_amdgcn_readlane(minx, src);
+        const int bminy = __builtin_amdgcn_readlane(miny, src);
+        const int bmaxx = __builtin_amdgcn_readlane(maxx, src);
+        const uint32_t bn = (uint32_t)__builtin_amdgcn_readlane((int)n, src);
+        const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)payload0, src);
+        const uint32_t p1 = (uint32_t)__builtin_amdgcn_readlane((int)payload1, src);
+        const uint32_t w = (uint32_t)(bmaxx - bminx);
+        for (uint32_t k = (uint32_t)lane; k < bn; k += GSR_WAVE) {
+            const uint32_t y = (uint32_t)bminy + k / w;
+            const uint32_t x = (uint32_t)bminx + k % w;
+            f(y * (uint32_t)gx + x, p0, p1);
+        }
+    }
+}
+
+// ---- kernel argument blocks and entry points (gsr_forward.hip / gsr_backward.hip) ----------------
+struct PreprocessArgs {
+    int P, M;
+    const float* __restrict__ means3D;
+    const float* __restrict__ shs;
+    const float* __restrict__ colors_precomp;
+    const float* __restrict__ opacities;
+    const float* __restrict__ scales;
+    const float* __restrict__ rotations;
+    const float* __restrict__ cov3D_precomp;
+    int32_t* __restrict__ radii;
+    float* __restrict__ depths;
+    float2* __restrict__ xy;
+    float4* __restrict__ conic_opacity;
+    float4* __restrict__ rgb;
+    float* __restrict__ cov3D;
+    ushort4* __restrict__ rect;
+    uint32_t* __restrict__ tiles_touched;
+    uint8_t* __restrict__ clamped;
+    uint32_t* __restrict__ tile_count;
+};
+
+struct PreBwdArgs {
+    int P, M;
+    const float* __restrict__ means3D;
+    const float* __restrict__ shs;
+    const float* __restrict__ scales;
+    const float* __restrict__ rotations;
+    const float* __restrict__ cov3D;      // forward's (P,6)
+    const int32_t* __restrict__ radii;
+    const uint8_t* __restrict__ clamped;
+    const float* __restrict__ acc;        // [P][12]: dcolor(3) dmean2D(2) dconic(3) dopacity(1)
+    int use_precomp_cov, use_precomp_color;
+    float* __restrict__ dL_dmeans3D;
+    float* __restrict__ dL_dmeans2D;      // (P,3)
+    float* __restrict__ dL_dsh;           // (P,M,3) or null
+    float* __restrict__ dL_dcolors;       // (P,3)
+    float* __restrict__ dL_dopacity;      // (P,1)
+    float* __restrict__ dL_dscales;       // (P,3) or null
+    float* __restrict__ dL_drotations;    // (P,4) or null
+    float* __restrict__ dL_dcov3D;        // (P,6)
+};
+
+__global__ void k_preprocess(Settings s, PreprocessArgs a);
+__global__ void k_tile_scan(int tiles, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, uint2* ranges,
+                            unsigned long long* total_dev, unsigned long long* mailbox, unsigned long long seq);
+__global__ void k_scatter(int P, int gx, const float* depths, const ushort4* rect, const uint32_t* tiles_touched,
+                          const uint32_t* tile_start, uint32_t* tile_cursor, unsigned long long* keys,
+                          unsigned long long capacity, const unsigned long long* total_dev);
+__global__ void k_tile_sort(int tiles, const uint32_t* tile_count, const uint32_t* tile_start, unsigned long long* keys,
+                            uint32_t* point_list, float4* records, const float2* xy, const float4* conic_opacity,
+                            const float4* rgb, unsigned long long capacity, const unsigned long long* total_dev);
+__global__ void k_render(Settings s, const uint2* ranges, const float4* records, float* final_T, uint32_t* n_contrib,
+                         float* out_color, unsigned long long capacity, const unsigned long long* total_dev);
+__global__ void k_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present);
+__global__ void k_render_bwd(Settings s, const uint2* ranges, const float4* records, const float* final_T,
+                             const uint32_t* n_contrib, const float* dL_dpix, float* acc);
+__global__ void k_preprocess_bwd(Settings s, PreBwdArgs a);
+
+}  // namespace gsr

@@ -1,0 +1,448 @@
+// gsr_forward.hip -- forward kernels of the MI355X-native splat rasterizer (gfx950, wave64).
+//
+// Pipeline (one frame):
+//   k_preprocess   per splat : project, EWA cov2D, conic, radius, tile rect, SH->RGB;
+//                              counts instances per tile with L2 atomics
+//   k_tile_scan    1 block   : exclusive scan of the per-tile counts -> tile_start / ranges / I,
+//                              posts I to the host mailbox
+//   k_scatter      per splat : drops (depth bits << 32 | splat) into its tiles' segments
+//   k_tile_sort    per tile  : LDS bitonic sort of the segment by (depth, splat) == the order a
+//                              stable radix sort of (tile << 32 | depth) produces; emits the
+//                              reference-format sorted keys / point list and a packed 48-byte
+//                              record per instance (geometry gathered once, here)
+//   k_render       per tile  : 4 waves x 8x8 pixels; every wave walks the tile's record stream
+//                              through the scalar unit (wave-uniform s_loads, no LDS, no
+//                              barriers) and composites front to back
+//
+// Behavioural spec: SURVEY.md Appendix A.1-A.3 (the reference's rasterizer is an un-vendored
+// submodule; call site gaussian_renderer/__init__.py:37-52,86-94).  This TU is built with
+// -ffp-contract=off: the arithmetic below is evaluated exactly as written.
+#include "gsr_device.h"
+
+namespace gsr {
+
+// ------------------------------------------------------------------------------------------
+// k_preprocess
+// ------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = s.W, H = s.H;
+    const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+
+    bool visible = false;
+    float depth = 0.f, px = 0.f, py = 0.f;
+    float con0 = 0.f, con1 = 0.f, con2 = 0.f, opac = 0.f;
+    float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float col[3] = {0.f, 0.f, 0.f};
+    uint32_t clampbits = 0;
+    int radius = 0;
+    int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
+
+    if (i < a.P) {
+        const float* vm = s.viewmatrix;
+        const float* pm = s.projmatrix;
+        const float mx = a.means3D[3 * i + 0], my = a.means3D[3 * i + 1], mz = a.means3D[3 * i + 2];
+        // view space (3 rows of W2C) and clip space (4 rows of P*W2C); storage is transposed
+        const float vx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
+        const float vy = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
+        const float vz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+        if (vz > 0.2f) {
+            const float hx = pm[0] * mx + pm[4] * my + pm[8] * mz + pm[12];
+            const float hy = pm[1] * mx + pm[5] * my + pm[9] * mz + pm[13];
+            const float hw = pm[3] * mx + pm[7] * my + pm[11] * mz + pm[15];
+            const float p_w = 1.0f / (hw + 0.0000001f);
+            const float ndc_x = hx * p_w, ndc_y = hy * p_w;
+
+            // ---- 3D covariance: Sigma = M^T M, M[k][j] = s_k * R[j][k], q used un-normalised
+            if (a.cov3D_precomp) {
+                for (int k = 0; k < 6; ++k) c6[k] = a.cov3D_precomp[6 * i + k];
+            } else {
+                const float4 q = reinterpret_cast<const float4*>(a.rotations)[i];
+                const float r = q.x, x = q.y, y = q.z, z = q.w;
+                float R[3][3];
+                R[0][0] = 1.f - 2.f * (y * y + z * z);
+                R[0][1] = 2.f * (x * y - r * z);
+                R[0][2] = 2.f * (x * z + r * y);
+                R[1][0] = 2.f * (x * y + r * z);
+                R[1][1] = 1.f - 2.f * (x * x + z * z);
+                R[1][2] = 2.f * (y * z - r * x);
+                R[2][0] = 2.f * (x * z - r * y);
+                R[2][1] = 2.f * (y * z + r * x);
+                R[2][2] = 1.f - 2.f * (x * x + y * y);
+                const float sc[3] = {s.scale_modifier * a.scales[3 * i + 0], s.scale_modifier * a.scales[3 * i + 1],
+                                     s.scale_modifier * a.scales[3 * i + 2]};
+                float Mm[3][3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) Mm[k][j] = sc[k] * R[j][k];
+                auto sig = [&](int p, int q2) { return Mm[0][p] * Mm[0][q2] + Mm[1][p] * Mm[1][q2] + Mm[2][p] * Mm[2][q2]; };
+                c6[0] = sig(0, 0);
+                c6[1] = sig(0, 1);
+                c6[2] = sig(0, 2);
+                c6[3] = sig(1, 1);
+                c6[4] = sig(1, 2);
+                c6[5] = sig(2, 2);
+            }
+
+            // ---- EWA: cov2D = A Sigma A^T with A = J * Rwc, tan-limit 1.3x, +0.3 low-pass
+            const float fx = (float)W / (2.0f * s.tanfovx);
+            const float fy = (float)H / (2.0f * s.tanfovy);
+            const float limx = 1.3f * s.tanfovx, limy = 1.3f * s.tanfovy;
+            const float txtz = vx / vz, tytz = vy / vz;
+            const float tx = sel_min(limx, sel_max(-limx, txtz)) * vz;
+            const float ty = sel_min(limy, sel_max(-limy, tytz)) * vz;
+            const float J00 = fx / vz;
+            const float J02 = -(fx * tx) / (vz * vz);
+            const float J11 = fy / vz;
+            const float J12 = -(fy * ty) / (vz * vz);
+            float A[2][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float r0 = vm[4 * j + 0], r1 = vm[4 * j + 1], r2 = vm[4 * j + 2];
+                A[0][j] = J00 * r0 + 0.0f * r1 + J02 * r2;
+                A[1][j] = 0.0f * r0 + J11 * r1 + J12 * r2;
+            }
+            const float V[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+            float AV[2][3];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) AV[r][j] = A[r][0] * V[0][j] + A[r][1] * V[1][j] + A[r][2] * V[2][j];
+            const float cxx = (AV[0][0] * A[0][0] + AV[0][1] * A[0][1] + AV[0][2] * A[0][2]) + 0.3f;
+            const float cxy = AV[0][0] * A[1][0] + AV[0][1] * A[1][1] + AV[0][2] * A[1][2];
+            const float cyy = (AV[1][0] * A[1][0] + AV[1][1] * A[1][1] + AV[1][2] * A[1][2]) + 0.3f;
+
+            const float det = cxx * cyy - cxy * cxy;
+            if (det != 0.0f) {
+                const float det_inv = 1.f / det;
+                const float mid = 0.5f * (cxx + cyy);
+                const float lambda1 = mid + sqrtf(sel_max(0.1f, mid * mid - det));
+                const float lambda2 = mid - sqrtf(sel_max(0.1f, mid * mid - det));
+                const float my_radius = ceilf(3.f * sqrtf(sel_max(lambda1, lambda2)));
+                const float ppx = ndc2pix(ndc_x, W), ppy = ndc2pix(ndc_y, H);
+                const int rad = f2i_sat(my_radius);
+                const float rf = (float)rad;
+                auto clampi = [](int v, int hi) { return min(hi, max(0, v)); };
+                const int x0 = clampi(f2i_sat((ppx - rf) / (float)GSR_BLOCK_X), gx);
+                const int y0 = clampi(f2i_sat((ppy - rf) / (float)GSR_BLOCK_Y), gy);
+                const int x1 = clampi(f2i_sat((ppx + rf + (float)GSR_BLOCK_X - 1.0f) / (float)GSR_BLOCK_X), gx);
+                const int y1 = clampi(f2i_sat((ppy + rf + (float)GSR_BLOCK_Y - 1.0f) / (float)GSR_BLOCK_Y), gy);
+                if ((x1 - x0) * (y1 - y0) != 0) {
+                    visible = true;
+                    depth = vz;
+                    px = ppx;
+                    py = ppy;
+                    radius = rad;
+                    con0 = cyy * det_inv;
+                    con1 = -cxy * det_inv;
+                    con2 = cxx * det_inv;
+                    opac = a.opacities[i];
+                    rminx = x0; rminy = y0; rmaxx = x1; rmaxy = y1;
+
+                    // ---- colour
+                    if (a.colors_precomp) {
+                        col[0] = a.colors_precomp[3 * i + 0];
+                        col[1] = a.colors_precomp[3 * i + 1];
+                        col[2] = a.colors_precomp[3 * i + 2];
+                    } else {
+                        const int deg = s.sh_degree;
+                        const float dx = mx - s.campos[0], dy = my - s.campos[1], dz = mz - s.campos[2];
+                        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                        const float x = dx / len, y = dy / len, z = dz / len;
+                        // (M,3) floats per splat; 16-byte aligned because M*12 % 16 == 0 only for M%4==0,
+                        // so load scalars and let the compiler merge what alignment allows
+                        const float* sh = a.shs + (size_t)3 * a.M * i;
+                        float res[3];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) res[c] = kC0 * sh[c];
+                        if (deg > 0) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                res[c] = res[c] - kC1 * y * sh[3 + c] + kC1 * z * sh[6 + c] - kC1 * x * sh[9 + c];
+                            if (deg > 1) {
+                                const float xx = x * x, yy = y * y, zz = z * z;
+                                const float xy_ = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+                                for (int c = 0; c < 3; ++c)
+                                    res[c] = res[c] + kC2_0 * xy_ * sh[12 + c] + kC2_1 * yz * sh[15 + c] +
+                                             kC2_2 * (2.0f * zz - xx - yy) * sh[18 + c] + kC2_3 * xz * sh[21 + c] +
+                                             kC2_4 * (xx - yy) * sh[24 + c];
+                                if (deg > 2) {
+#pragma unroll
+                                    for (int c = 0; c < 3; ++c)
+                                        res[c] = res[c] + kC3_0 * y * (3.0f * xx - yy) * sh[27 + c] +
+                                                 kC3_1 * xy_ * z * sh[30 + c] + kC3_2 * y * (4.0f * zz - xx - yy) * sh[33 + c] +
+                                                 kC3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + c] +
+                                                 kC3_4 * x * (4.0f * zz - xx - yy) * sh[39 + c] +
+                                                 kC3_5 * z * (xx - yy) * sh[42 + c] + kC3_6 * x * (xx - 3.0f * yy) * sh[45 + c];
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            res[c] += 0.5f;
+                            if (res[c] < 0.0f) clampbits |= (1u << c);
+                            col[c] = sel_max(res[c], 0.0f);
+                        }
+                    }
+                }
+            }
+        }
+        if (!visible) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c6[k] = 0.f;
+        }
+        const uint32_t n = visible ? (uint32_t)((rmaxx - rminx) * (rmaxy - rminy)) : 0u;
+        a.radii[i] = radius;
+        a.depths[i] = depth;
+        a.xy[i] = make_float2(px, py);
+        a.conic_opacity[i] = make_float4(con0, con1, con2, opac);
+        a.rgb[i] = make_float4(col[0], col[1], col[2], 0.f);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a.cov3D[6 * i + k] = c6[k];
+        a.rect[i] = make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy);
+        a.tiles_touched[i] = n;
+        a.clamped[i] = (uint8_t)clampbits;
+    }
+    // ---- instances per tile (all 64 lanes take part: idle lanes carry n == 0)
+    const uint32_t n = visible ? (uint32_t)((rmaxx - rminx) * (rmaxy - rminy)) : 0u;
+    uint32_t* tc = a.tile_count;
+    for_each_tile(rminx, rminy, rmaxx, rmaxy, n, gx,
+                  [tc](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&tc[tile], 1u); }, 0u, 0u);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_tile_scan: exclusive scan over the tile counters (single workgroup, 1024 threads)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_tile_scan(int tiles, const uint32_t* __restrict__ tile_count,
+                                                     uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
+                                                     uint2* __restrict__ ranges, unsigned long long* __restrict__ total_dev,
+                                                     unsigned long long* mailbox, unsigned long long seq)
+{
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    unsigned long long grand = 0;
+    for (int base = 0; base < tiles; base += 1024) {
+        const int t = base + tid;
+        const uint32_t v = (t < tiles) ? tile_count[t] : 0u;
+        // wave inclusive scan
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wid; ++w) wave_off += wave_tot[w];
+        const uint32_t carry = carry_s;
+        const uint32_t excl = carry + wave_off + incl - v;
+        if (t < tiles) {
+            tile_start[t] = excl;
+            tile_cursor[t] = 0u;
+            ranges[t] = v ? make_uint2(excl, excl + v) : make_uint2(0u, 0u);
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = excl + v;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        // the per-chunk carries are 32-bit like upstream's offsets; the host compares against capacity
+        grand = (unsigned long long)carry_s;
+        *total_dev = grand;
+        // post (seq, I) to the host: one 8-byte system-scope store into mapped pinned memory
+        __hip_atomic_store(mailbox, (seq << 40) | (grand & 0xFFFFFFFFFFull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_scatter: per splat, one (depth bits << 32 | splat) entry into every touched tile's segment
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scatter(int P, int gx, const float* __restrict__ depths,
+                                                  const ushort4* __restrict__ rect, const uint32_t* __restrict__ tiles_touched,
+                                                  const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
+                                                  unsigned long long* __restrict__ keys, unsigned long long capacity,
+                                                  const unsigned long long* __restrict__ total_dev)
+{
+    if (*total_dev > capacity) return;  // the host will grow the buffer and replay the frame
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = 0, dbits = 0;
+    int minx = 0, miny = 0, maxx = 0, maxy = 0;
+    if (i < P) {
+        n = tiles_touched[i];
+        const ushort4 r = rect[i];
+        minx = r.x; miny = r.y; maxx = r.z; maxy = r.w;
+        dbits = __float_as_uint(depths[i]);
+    }
+    for_each_tile(minx, miny, maxx, maxy, n, gx,
+                  [=](uint32_t tile, uint32_t db, uint32_t idx) {
+                      const uint32_t slot = tile_start[tile] + atomicAdd(&tile_cursor[tile], 1u);
+                      keys[slot] = ((unsigned long long)db << 32) | (unsigned long long)idx;
+                  },
+                  dbits, (uint32_t)i);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_tile_sort: one workgroup per tile.  Normalised bitonic network (every compare-exchange puts
+// the smaller key at the lower index), so a non-power-of-two segment works with virtual +inf
+// padding: exchanges whose partner index is >= n are no-ops.
+// ------------------------------------------------------------------------------------------
+template <typename KeyAcc>
+__device__ __forceinline__ void bitonic_sort(KeyAcc k, uint32_t n, int tid, int nthreads)
+{
+    uint32_t n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    for (uint32_t size = 2; size <= n2; size <<= 1) {
+        // first step of a merge: partner = i ^ (size - 1)
+        for (uint32_t t = tid; t < n2 / 2; t += nthreads) {
+            const uint32_t half = size >> 1;
+            const uint32_t i = (t / half) * size + (t % half);
+            const uint32_t p = i ^ (size - 1);
+            if (p < n) {
+                const unsigned long long a = k[i], b = k[p];
+                if (a > b) { k[i] = b; k[p] = a; }
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = size >> 2; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < n2 / 2; t += nthreads) {
+                const uint32_t i = (t / j) * (2 * j) + (t % j);
+                const uint32_t p = i + j;
+                if (p < n) {
+                    const unsigned long long a = k[i], b = k[p];
+                    if (a > b) { k[i] = b; k[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tile_sort(int tiles, const uint32_t* __restrict__ tile_count,
+                                                    const uint32_t* __restrict__ tile_start, unsigned long long* __restrict__ keys,
+                                                    uint32_t* __restrict__ point_list, float4* __restrict__ records,
+                                                    const float2* __restrict__ xy, const float4* __restrict__ conic_opacity,
+                                                    const float4* __restrict__ rgb, unsigned long long capacity,
+                                                    const unsigned long long* __restrict__ total_dev)
+{
+    __shared__ unsigned long long skeys[GSR_SORT_LDS_KEYS];
+    if (*total_dev > capacity) return;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t n = tile_count[tile];
+    if (n == 0) return;
+    const uint32_t start = tile_start[tile];
+    const int tid = threadIdx.x;
+    unsigned long long* seg = keys + start;
+    const bool in_lds = n <= GSR_SORT_LDS_KEYS;
+    if (in_lds) {
+        for (uint32_t i = tid; i < n; i += 256) skeys[i] = seg[i];
+        __syncthreads();
+        bitonic_sort(skeys, n, tid, 256);
+    } else {
+        __syncthreads();
+        bitonic_sort(seg, n, tid, 256);  // rare: > 8192 instances in one tile, sort in place in global memory
+    }
+    const unsigned long long tile_hi = (unsigned long long)tile << 32;
+    for (uint32_t i = tid; i < n; i += 256) {
+        const unsigned long long k = in_lds ? skeys[i] : seg[i];
+        const uint32_t idx = (uint32_t)k;
+        seg[i] = tile_hi | (k >> 32);  // reference-format key: tile id | depth bits
+        point_list[start + i] = idx;
+        const float2 p = xy[idx];
+        const float4 co = conic_opacity[idx];
+        const float4 c = rgb[idx];
+        float4* r = records + (size_t)3 * (start + i);
+        r[0] = make_float4(p.x, p.y, co.x, co.y);
+        r[1] = make_float4(co.z, co.w, c.x, c.y);
+        r[2] = make_float4(c.z, __uint_as_float(idx), 0.f, 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_render: front-to-back compositing.  Workgroup = one 16x16 tile = 4 independent waves, wave w
+// owns the 8x8 quadrant (w&1, w>>1).  The record index is wave-uniform, so the loads below are
+// scalar-unit loads: one 48-byte fetch serves all 64 pixels and the values sit in SGPRs.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_render(Settings s, const uint2* __restrict__ ranges,
+                                                 const float4* __restrict__ records, float* __restrict__ final_T,
+                                                 uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+                                                 unsigned long long capacity, const unsigned long long* __restrict__ total_dev)
+{
+    if (*total_dev > capacity) return;
+    const int W = s.W, H = s.H;
+    const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X;
+    const int tile = blockIdx.y * gx + blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int pxi = blockIdx.x * GSR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
+    const int pyi = blockIdx.y * GSR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const float pixx = (float)pxi, pixy = (float)pyi;
+
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    const float4* __restrict__ rec = records + (size_t)3 * range.x;
+
+    float T = 1.0f;
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    uint32_t last_contributor = 0;
+    bool done = !inside;
+
+    for (int j = 0; j < n; ++j) {
+        if (__all(done)) break;
+        const float4 r0 = rec[3 * j + 0];
+        const float4 r1 = rec[3 * j + 1];
+        const float cb = rec[3 * j + 2].x;
+        if (!done) {
+            const float dx = r0.x - pixx;
+            const float dy = r0.y - pixy;
+            const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+            if (power <= 0.0f) {
+                const float alpha = sel_min(0.99f, r1.y * gsr_expf(power));
+                if (alpha >= 1.0f / 255.0f) {
+                    const float test_T = T * (1.0f - alpha);
+                    if (test_T < 0.0001f) {
+                        done = true;
+                    } else {
+                        C0 += r1.z * alpha * T;
+                        C1 += r1.w * alpha * T;
+                        C2 += cb * alpha * T;
+                        T = test_T;
+                        last_contributor = (uint32_t)(j + 1);
+                    }
+                }
+            }
+        }
+    }
+    if (inside) {
+        const int pix_id = W * pyi + pxi;
+        final_T[pix_id] = T;
+        n_contrib[pix_id] = last_contributor;
+        const size_t HW = (size_t)H * W;
+        out_color[0 * HW + pix_id] = C0 + T * s.bg[0];
+        out_color[1 * HW + pix_id] = C1 + T * s.bg[1];
+        out_color[2 * HW + pix_id] = C2 + T * s.bg[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_mark_visible (upstream checkFrustum): present = view z > 0.2
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mark_visible(int P, const float* __restrict__ means3D,
+                                                       const float* __restrict__ vm, uint8_t* __restrict__ present)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float mx = means3D[3 * i], my = means3D[3 * i + 1], mz = means3D[3 * i + 2];
+    const float vz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+    present[i] = vz > 0.2f ? 1 : 0;
+}
+
+}  // namespace gsr

@@ -1,0 +1,67 @@
+"""Views into the opaque state buffers of one forward pass (layouts of include/gsr.h), so tests and
+the benchmark can look at every intermediate the reference keeps in geomBuffer / binningBuffer /
+imgBuffer.  Not used by the product path."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .rasterizer import GaussianRasterizationSettings, _RasterizeGaussians
+
+
+def _view(buf: torch.Tensor, off: int, count: int, dtype: torch.dtype) -> torch.Tensor:
+    nbytes = count * torch.empty((), dtype=dtype).element_size()
+    return buf[off: off + nbytes].view(dtype)
+
+
+def forward_state(rs: GaussianRasterizationSettings, means3D, shs, colors_precomp, opacities, scales, rotations,
+                  cov3D_precomp) -> dict:
+    """Runs the forward through the autograd Function (same code path as render()) and unpacks the
+    saved state.  Returns device tensors."""
+    lib = _lib.gsr()
+    e = torch.Tensor([])
+    args = [means3D, torch.zeros_like(means3D), e if shs is None else shs, e if colors_precomp is None else colors_precomp,
+            opacities, e if scales is None else scales, e if rotations is None else rotations,
+            e if cov3D_precomp is None else cov3D_precomp]
+
+    class _Ctx:
+        def save_for_backward(self, *t):
+            self.saved = t
+
+        def mark_non_differentiable(self, *t):
+            pass
+
+    ctx = _Ctx()
+    with torch.no_grad():
+        color, radii = _RasterizeGaussians.forward(ctx, *args, rs)
+    _, _, _, _, _, _, _, geom, binning, img = ctx.saved
+    P = means3D.shape[0]
+    H, W = int(rs.image_height), int(rs.image_width)
+    I, cap = ctx.num_rendered, ctx.capacity
+    gl, bl, il = _lib.GsrGeomLayout(), _lib.GsrBinningLayout(), _lib.GsrImageLayout()
+    lib.gsr_geom_layout(P, C.byref(gl))
+    lib.gsr_binning_layout(cap, W, H, C.byref(bl))
+    lib.gsr_image_layout(W, H, C.byref(il))
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    f32, u32, i16 = torch.float32, torch.int32, torch.int16
+    out = dict(
+        color=color, radii=radii, num_rendered=I, capacity=cap,
+        depths=_view(geom, gl.depths, P, f32),
+        xy=_view(geom, gl.xy, 2 * P, f32).view(P, 2),
+        conic_opacity=_view(geom, gl.conic_opacity, 4 * P, f32).view(P, 4),
+        rgb=_view(geom, gl.rgb, 4 * P, f32).view(P, 4)[:, :3],
+        cov3D=_view(geom, gl.cov3D, 6 * P, f32).view(P, 6),
+        rect=_view(geom, gl.rect, 4 * P, i16).view(P, 4),
+        tiles_touched=_view(geom, gl.tiles_touched, P, u32),
+        clamped=_view(geom, gl.clamped, P, torch.uint8),
+        keys=_view(binning, bl.keys, I, torch.int64),
+        point_list=_view(binning, bl.point_list, I, u32),
+        records=_view(binning, bl.records, 12 * I, f32).view(I, 12),
+        ranges=_view(binning, bl.ranges, 2 * tiles, u32).view(tiles, 2),
+        tile_count=_view(binning, bl.tile_count, tiles, u32),
+        final_T=_view(img, il.final_T, H * W, f32).view(H, W),
+        n_contrib=_view(img, il.n_contrib, H * W, u32).view(H, W),
+    )
+    return out

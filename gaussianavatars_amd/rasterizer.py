@@ -1,0 +1,220 @@
+"""Drop-in for the Python surface of the reference's `diff_gaussian_rasterization` package.
+
+The reference imports `GaussianRasterizationSettings, GaussianRasterizer` at
+gaussian_renderer/__init__.py:15, builds the 12-field settings at :37-50 and calls the rasterizer
+with keyword arguments at :86-94, expecting `(color (3,H,W) f32, radii (P,) int32)` and gradients
+for means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp.
+(The package itself is an un-vendored submodule -- .gitmodules:4-6 -- so names, argument meaning
+and error behaviour below restate its public contract)
+
+Everything numeric happens in libgsr_hip.so through the C ABI of include/gsr.h; torch is used for
+device memory, the current stream and autograd plumbing only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_forward_info"]
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+# ---- per-device running estimate of the binning capacity (instances per frame) -----------------
+_CAP_QUANTUM = 1 << 16
+_capacity_hint: dict = {}
+_last_info: dict = {}
+
+
+def last_forward_info() -> dict:
+    """{'num_rendered', 'capacity', 'replays'} of the most recent forward on this process."""
+    return dict(_last_info)
+
+
+def _round_cap(n: int) -> int:
+    return max(_CAP_QUANTUM, (int(n) + _CAP_QUANTUM - 1) // _CAP_QUANTUM * _CAP_QUANTUM)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a device tensor (got {t.device}); the MI355X rasterizer has no CPU path")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _make_settings(rs: GaussianRasterizationSettings, keep: list) -> _lib.GsrSettings:
+    s = _lib.GsrSettings()
+    s.image_height, s.image_width = int(rs.image_height), int(rs.image_width)
+    s.tanfovx, s.tanfovy = float(rs.tanfovx), float(rs.tanfovy)
+    s.scale_modifier = float(rs.scale_modifier)
+    s.sh_degree = int(rs.sh_degree)
+    s.prefiltered, s.debug = int(bool(rs.prefiltered)), int(bool(rs.debug))
+    for field in ("bg", "viewmatrix", "projmatrix", "campos"):
+        t = _f32c(getattr(rs, field), field)
+        keep.append(t)
+        setattr(s, field, t.data_ptr())
+    return s
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        lib = _lib.gsr()
+        dev = means3D.device
+        keep: list = []
+        s = _make_settings(raster_settings, keep)
+        means3D = _f32c(means3D, "means3D")
+        if means3D.dim() != 2 or means3D.shape[1] != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        P = means3D.shape[0]
+        H, W = s.image_height, s.image_width
+        sh = _f32c(sh, "shs") if sh.numel() else sh
+        colors_precomp = _f32c(colors_precomp, "colors_precomp") if colors_precomp.numel() else colors_precomp
+        opacities = _f32c(opacities, "opacities")
+        scales = _f32c(scales, "scales") if scales.numel() else scales
+        rotations = _f32c(rotations, "rotations") if rotations.numel() else rotations
+        cov3Ds_precomp = _f32c(cov3Ds_precomp, "cov3D_precomp") if cov3Ds_precomp.numel() else cov3Ds_precomp
+        M = int(sh.shape[1]) if sh.numel() else 0
+
+        gl, il = _lib.GsrGeomLayout(), _lib.GsrImageLayout()
+        lib.gsr_geom_layout(P, C.byref(gl))
+        lib.gsr_image_layout(W, H, C.byref(il))
+        u8 = dict(dtype=torch.uint8, device=dev)
+        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        geom = torch.empty(gl.total, **u8)
+        img = torch.empty(il.total, **u8)
+
+        key = (dev.index, H, W)
+        cap = _capacity_hint.get(key) or _round_cap(8 * P)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        n_host = C.c_int64(0)
+        replays = 0
+        with torch.cuda.device(dev):
+            while True:
+                bl = _lib.GsrBinningLayout()
+                lib.gsr_binning_layout(cap, W, H, C.byref(bl))
+                binning = torch.empty(bl.total, **u8)
+                rc = lib.gsr_forward(C.byref(s), P, M, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities),
+                                     _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(color), _ptr(radii),
+                                     _ptr(geom), _ptr(binning), cap, _ptr(img), C.byref(n_host), stream)
+                if rc == _lib.GSR_E_CAPACITY:
+                    cap = _round_cap(int(n_host.value * 1.25) + 1)
+                    replays += 1
+                    continue
+                if rc != _lib.GSR_OK:
+                    msg = _lib.gsr_error()
+                    if "provide" in msg:  # the two argument-contract errors are plain Exceptions upstream
+                        raise Exception(msg)
+                    raise RuntimeError(f"gsr_forward failed ({rc}): {msg}")
+                break
+        I = int(n_host.value)
+        # next frame: 25 % headroom over what this one needed, never shrinking below it
+        _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
+        _last_info.update(num_rendered=I, capacity=cap, replays=replays)
+
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = I
+        ctx.capacity = cap
+        ctx.M = M
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        lib = _lib.gsr()
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        rs = ctx.raster_settings
+        dev = means3D.device
+        keep: list = []
+        s = _make_settings(rs, keep)
+        P, M = means3D.shape[0], ctx.M
+        f32 = dict(dtype=torch.float32, device=dev)
+        grad_out_color = _f32c(grad_out_color, "grad_out_color")
+        scratch = torch.empty((P, 12), **f32)
+        g_means3D = torch.empty((P, 3), **f32)
+        g_means2D = torch.empty((P, 3), **f32)
+        g_colors = torch.empty((P, 3), **f32)
+        g_opacity = torch.empty((P, 1), **f32)
+        g_cov3D = torch.empty((P, 6), **f32)
+        use_sh, use_sr = sh.numel() > 0, scales.numel() > 0
+        g_sh = torch.empty((P, M, 3), **f32) if use_sh else None
+        g_scales = torch.empty((P, 3), **f32) if use_sr else None
+        g_rot = torch.empty((P, 4), **f32) if use_sr else None
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            rc = lib.gsr_backward(C.byref(s), P, M, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(scales),
+                                  _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(radii), _ptr(geom), _ptr(binning),
+                                  ctx.capacity, _ptr(img), ctx.num_rendered, _ptr(grad_out_color), _ptr(scratch),
+                                  _ptr(g_means3D), _ptr(g_means2D), _ptr(g_sh), _ptr(g_colors), _ptr(g_opacity),
+                                  _ptr(g_scales), _ptr(g_rot), _ptr(g_cov3D), stream)
+        if rc != _lib.GSR_OK:
+            raise RuntimeError(f"gsr_backward failed ({rc}): {_lib.gsr_error()}")
+        return (g_means3D, g_means2D, g_sh, g_colors if not use_sh else None, g_opacity, g_scales, g_rot,
+                g_cov3D if not use_sr else None, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """bool (P,): view-space depth > 0.2 (the only active test of upstream's frustum check)."""
+        rs = self.raster_settings
+        with torch.no_grad():
+            pos = _f32c(positions, "positions")
+            vm, pm = _f32c(rs.viewmatrix, "viewmatrix"), _f32c(rs.projmatrix, "projmatrix")
+            out = torch.empty((pos.shape[0],), dtype=torch.uint8, device=pos.device)
+            stream = C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
+            with torch.cuda.device(pos.device):
+                rc = _lib.gsr().gsr_mark_visible(pos.shape[0], _ptr(pos), _ptr(vm), _ptr(pm), _ptr(out), stream)
+            if rc != _lib.GSR_OK:
+                raise RuntimeError(f"gsr_mark_visible failed ({rc}): {_lib.gsr_error()}")
+        return out.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+            (scales is not None or rotations is not None) and cov3D_precomp is not None
+        ):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        empty = torch.Tensor([])
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)

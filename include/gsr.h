@@ -1,0 +1,149 @@
+/*
+ * gsr.h -- C ABI of the MI355X-native differentiable Gaussian-splat rasterizer.
+ *
+ * This is the drop-in boundary for the native half of the reference's
+ * `diff_gaussian_rasterization` package (un-vendored submodule; its Python call site is
+ * gaussian_renderer/__init__.py:15,37-52,86-94).  Upstream exposes three pybind entry points
+ * taking torch tensors (`_C.rasterize_gaussians`, `_C.rasterize_gaussians_backward`,
+ * `_C.mark_visible`); here the same three operations are plain C functions over raw device
+ * pointers + sizes + a hipStream_t, so that any host language can bind them (ctypes stub in
+ * INTEGRATION.md; the shipped binding is gaussianavatars_amd/rasterizer.py).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`
+ *   - all floating point is fp32; tensors are contiguous, row-major, shapes as in the reference
+ *   - every entry returns 0 on success, >0 for "call again" conditions (GSR_E_CAPACITY) and <0
+ *     on error; gsr_last_error() returns a thread-local message for the last non-zero return
+ *   - work is enqueued on `stream` (pass torch's current stream).  gsr_forward performs exactly
+ *     one host wait, scoped to `stream`, for the instance count (upstream blocks the whole device
+ *     with a cudaMemcpy D2H at the same point).  Nothing else synchronises.
+ */
+#ifndef GSR_H
+#define GSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_ABI_VERSION 1
+#define GSR_BLOCK_X 16
+#define GSR_BLOCK_Y 16
+
+#define GSR_OK 0
+#define GSR_E_CAPACITY 1   /* binning buffer too small; *num_rendered_host holds the needed count */
+#define GSR_E_ARG (-1)
+#define GSR_E_HIP (-2)
+#define GSR_E_TIMEOUT (-3)
+
+/* Mirrors the 12-field GaussianRasterizationSettings NamedTuple the reference constructs at
+ * gaussian_renderer/__init__.py:37-50.  bg / viewmatrix / projmatrix / campos stay on the device
+ * exactly as the reference passes them (no host copy, hence no sync). */
+typedef struct GsrSettings {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    const float* bg;          /* (3,)   */
+    float scale_modifier;
+    const float* viewmatrix;  /* (4,4) = W2C^T, row-major       */
+    const float* projmatrix;  /* (4,4) = (P*W2C)^T, row-major   */
+    int32_t sh_degree;        /* active degree 0..3             */
+    const float* campos;      /* (3,)   */
+    int32_t prefiltered;      /* accepted, ignored */
+    int32_t debug;            /* !=0: synchronise + check after every kernel */
+} GsrSettings;
+
+/* Byte offsets of the arrays inside the three opaque state buffers.  The state buffers play the
+ * role of upstream's geomBuffer / binningBuffer / imgBuffer (saved on the autograd ctx between
+ * forward and backward); the layout is published so tests can compare every intermediate with
+ * the oracle bit for bit. */
+typedef struct GsrGeomLayout {
+    size_t depths;         /* float  [P]                                   */
+    size_t xy;             /* float2 [P]   pixel centre                     */
+    size_t conic_opacity;  /* float4 [P]   (A, B, C, opacity)               */
+    size_t rgb;            /* float4 [P]   (r, g, b, unused)                */
+    size_t cov3D;          /* float  [6P]  xx xy xz yy yz zz                */
+    size_t rect;           /* uint16 [4P]  tile rect min.x min.y max.x max.y */
+    size_t tiles_touched;  /* uint32 [P]                                   */
+    size_t clamped;        /* uint8  [P]   bit c set <=> channel c clamped  */
+    size_t total;
+} GsrGeomLayout;
+
+typedef struct GsrBinningLayout {
+    size_t keys;        /* uint64 [cap]  sorted (tile << 32 | depth bits), upstream's point_list_keys */
+    size_t point_list;  /* uint32 [cap]  sorted splat index, upstream's point_list                    */
+    size_t records;     /* float4 [3cap] sorted per-instance record (x,y,A,B | C,opacity,r,g | b,idx,-,-) */
+    size_t ranges;      /* uint32 [2*tiles]  [start,end) per tile, (0,0) when empty                   */
+    size_t tile_count;  /* uint32 [tiles]                                                            */
+    size_t tile_start;  /* uint32 [tiles]                                                            */
+    size_t tile_cursor; /* uint32 [tiles]                                                            */
+    size_t total;
+} GsrBinningLayout;
+
+typedef struct GsrImageLayout {
+    size_t final_T;    /* float  [H*W] */
+    size_t n_contrib;  /* uint32 [H*W] */
+    size_t total;
+} GsrImageLayout;
+
+int gsr_abi_version(void);
+const char* gsr_last_error(void);
+
+/* sizes/layouts of the state buffers (pure host arithmetic, no device access) */
+int gsr_geom_layout(int32_t P, GsrGeomLayout* out);
+int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, GsrBinningLayout* out);
+int gsr_image_layout(int32_t width, int32_t height, GsrImageLayout* out);
+
+/*
+ * Forward pass.  Replaces `_C.rasterize_gaussians` (upstream rasterize_points.cu
+ * RasterizeGaussiansCUDA -> CudaRasterizer::Rasterizer::forward).
+ *   P splats, M SH coefficients per splat (shs is (P,M,3); 0 when colors_precomp is used).
+ *   Exactly one of shs / colors_precomp and exactly one of (scales,rotations) / cov3D_precomp
+ *   must be non-NULL.
+ *   out_color (3,H,W) and radii (P,) are fully written by the call.
+ *   geom / binning / img: caller-allocated state buffers of at least the sizes the layout
+ *   functions report for (P), (binning_capacity, W, H), (W, H).
+ *   *num_rendered_host receives the number of tile instances I.  If I > binning_capacity the
+ *   call returns GSR_E_CAPACITY with nothing valid but *num_rendered_host; re-call with a larger
+ *   binning buffer.
+ */
+int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M,
+                const float* means3D, const float* shs, const float* colors_precomp,
+                const float* opacities, const float* scales, const float* rotations,
+                const float* cov3D_precomp,
+                float* out_color, int32_t* radii,
+                void* geom, void* binning, int64_t binning_capacity, void* img,
+                int64_t* num_rendered_host, void* stream);
+
+/*
+ * Backward pass.  Replaces `_C.rasterize_gaussians_backward` (RasterizeGaussiansBackwardCUDA ->
+ * CudaRasterizer::Rasterizer::backward).  Inputs are the forward's inputs, its three state
+ * buffers (with the binning capacity they were laid out for) and num_rendered, plus dL_dpix (3,H,W).  Every gradient buffer is fully written
+ * (zeros for culled splats); pass NULL for dL_dsh when colours were precomputed, for
+ * dL_dscales/dL_drotations when cov3D was precomputed.
+ *   grad_scratch: (P,12) floats of scratch for the per-splat screen-space accumulators
+ *   dL_dmeans2D (P,3): [:, :2] NDC-scaled screen-space gradient, [:, 2] = 0
+ *   dL_dcolors  (P,3): gradient w.r.t. the per-splat RGB (the colors_precomp gradient)
+ *   dL_dcov3D   (P,6): gradient w.r.t. the packed 3D covariance
+ */
+int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* scales, const float* rotations, const float* cov3D_precomp,
+                 const int32_t* radii, const void* geom, const void* binning, int64_t binning_capacity,
+                 const void* img, int64_t num_rendered, const float* dL_dpix, float* grad_scratch,
+                 float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dsh, float* dL_dcolors,
+                 float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                 void* stream);
+
+/* Replaces `_C.mark_visible` (upstream markVisible / checkFrustum): present[i] = view-space z > 0.2.
+ * Unused by GaussianAvatars (no call site) but part of the package surface. */
+int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H */

@@ -1,0 +1,169 @@
+"""GPU parity tests proper: the HIP rasterizer (through the C ABI, via the autograd Function that
+render() uses) against the CPU oracle on the same seeded inputs.
+
+Bars: integer outputs (radii, tile rects, tiles_touched, sorted keys, point list, tile ranges,
+n_contrib, clamp flags) BIT-EXACT; forward floats bit-exact too (the forward TUs are built with
+-ffp-contract=off and share the oracle's exp polynomial) -- asserted as max-abs == 0 with a fallback
+tolerance of 0 documented here; backward gradients within rel 2e-4 of the oracle (float atomics
+reorder the sums) measured against the per-tensor max magnitude.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.scenes import scene, settings_args
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _run_both(oracle, name, use_precomp_color=False, use_precomp_cov=False):
+    from gaussianavatars_amd.debug import forward_state
+    from gaussianavatars_amd.rasterizer import GaussianRasterizationSettings
+
+    dev = _dev()
+    cam, sp, bg, deg, mod = scene(name)
+    a = settings_args(cam, bg, deg, mod)
+    s = oracle.make_settings(**a)
+    shs = None if use_precomp_color else sp["shs"]
+    colors = np.ascontiguousarray(np.abs(sp["shs"][:, 0, :])) if use_precomp_color else None
+    st0 = None
+    cov = None
+    if use_precomp_cov:
+        st0 = oracle.forward(s, sp["means3D"], sp["shs"], None, sp["opacities"], sp["scales"], sp["rotations"], None)
+        cov = np.ascontiguousarray(st0.cov3D.copy())
+        # culled splats have zeroed cov3D in the oracle state: give them something valid
+        cov[(st0.radii == 0)] = np.array([1e-4, 0, 0, 1e-4, 0, 1e-4], np.float32)
+    sc = None if use_precomp_cov else sp["scales"]
+    ro = None if use_precomp_cov else sp["rotations"]
+    st = oracle.forward(s, sp["means3D"], shs, colors, sp["opacities"], sc, ro, cov)
+    t = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    rs = GaussianRasterizationSettings(a["H"], a["W"], a["tanfovx"], a["tanfovy"], t(a["bg"]), mod, t(a["viewmatrix"]),
+                                       t(a["projmatrix"]), deg, t(a["campos"]), False, False)
+    hs = forward_state(rs, t(sp["means3D"]), t(shs), t(colors), t(sp["opacities"]), t(sc), t(ro), t(cov))
+    return s, st, hs, rs, dict(means3D=sp["means3D"], shs=shs, colors=colors, opacities=sp["opacities"], scales=sc,
+                               rotations=ro, cov=cov)
+
+
+def _np(x):
+    return x.detach().cpu().numpy()
+
+
+def _check_forward(st, hs):
+    I = st.num_rendered
+    assert hs["num_rendered"] == I
+    np.testing.assert_array_equal(_np(hs["radii"]), st.radii)
+    np.testing.assert_array_equal(_np(hs["tiles_touched"]).astype(np.uint32), st.tiles_touched)
+    vis = st.radii > 0
+    np.testing.assert_array_equal(_np(hs["rect"]).astype(np.int32)[vis], st.rect[vis])
+    cl = _np(hs["clamped"])
+    for c in range(3):
+        np.testing.assert_array_equal((cl >> c) & 1, st.clamped[:, c])
+    # sorted keys / values / ranges: bit-exact
+    np.testing.assert_array_equal(_np(hs["keys"]).view(np.uint64), st.keys)
+    np.testing.assert_array_equal(_np(hs["point_list"]).astype(np.uint32), st.point_list)
+    np.testing.assert_array_equal(_np(hs["ranges"]).astype(np.uint32), st.ranges)
+    # per-splat floats: bit-exact
+    for name in ("depths", "xy", "conic_opacity", "rgb", "cov3D"):
+        a, b = _np(hs[name])[vis], getattr(st, name)[vis]
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{name}: max abs diff {np.abs(a - b).max()}"
+    np.testing.assert_array_equal(_np(hs["n_contrib"]).astype(np.uint32), st.n_contrib)
+    assert np.array_equal(_np(hs["final_T"]).view(np.uint32), st.final_T.view(np.uint32))
+    img = _np(hs["color"])
+    assert np.array_equal(img.view(np.uint32), st.color.view(np.uint32)), f"image max abs diff {np.abs(img - st.color).max()}"
+    # records carry the same geometry in sorted order
+    rec = _np(hs["records"])
+    if I:
+        pl = st.point_list
+        np.testing.assert_array_equal(rec[:, 0:2], st.xy[pl])
+        np.testing.assert_array_equal(rec[:, 2:6], st.conic_opacity[pl])
+        np.testing.assert_array_equal(rec[:, 6:9], st.rgb[pl])
+        np.testing.assert_array_equal(rec[:, 9].view(np.uint32), pl)
+
+
+@pytest.mark.parametrize("name", ["cfg1", "sh3_small", "sh2_mod", "culls", "dense_tile", "empty_view"])
+def test_forward_bit_exact(oracle, name):
+    s, st, hs, rs, _ = _run_both(oracle, name)
+    _check_forward(st, hs)
+
+
+def test_forward_precomputed_inputs(oracle):
+    s, st, hs, rs, _ = _run_both(oracle, "sh3_small", use_precomp_color=True, use_precomp_cov=True)
+    _check_forward(st, hs)
+
+
+def _grad_check(oracle, name, use_precomp_color=False, use_precomp_cov=False, rtol=2e-4):
+    from gaussianavatars_amd.rasterizer import GaussianRasterizer
+
+    dev = _dev()
+    s, st, hs, rs, inp = _run_both(oracle, name, use_precomp_color, use_precomp_cov)
+    H, W = rs.image_height, rs.image_width
+    gpix = np.random.default_rng(5).normal(0, 1, (3, H, W)).astype(np.float32)
+    ref = oracle.backward(s, st, gpix)
+    tt = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x)).to(dev).requires_grad_(True)
+    m3, sh, col, op, sc, ro, cov = (tt(inp["means3D"]), tt(inp["shs"]), tt(inp["colors"]), tt(inp["opacities"]),
+                                    tt(inp["scales"]), tt(inp["rotations"]), tt(inp["cov"]))
+    m2 = torch.zeros_like(m3, requires_grad=True)
+    color, radii = GaussianRasterizer(rs)(means3D=m3, means2D=m2, shs=sh, colors_precomp=col, opacities=op, scales=sc,
+                                           rotations=ro, cov3D_precomp=cov)
+    assert radii.dtype == torch.int32 and not radii.requires_grad
+    (color * torch.from_numpy(gpix).to(dev)).sum().backward()
+    got = dict(means3D=m3.grad, means2D=m2.grad, shs=None if sh is None else sh.grad,
+               colors_precomp=None if col is None else col.grad, opacities=op.grad,
+               scales=None if sc is None else sc.grad, rotations=None if ro is None else ro.grad,
+               cov3D_precomp=None if cov is None else cov.grad)
+    for k, g in got.items():
+        r = ref[k]
+        if r is None:
+            assert g is None, k
+            continue
+        g = _np(g).reshape(r.shape)
+        scale = np.abs(r).max() + 1e-20
+        err = np.abs(g - r).max() / scale
+        assert err < rtol, f"{name}/{k}: rel err {err:.3e} (max |ref| {scale:.3e})"
+    assert float(m2.grad[:, 2].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["cfg1", "sh3_small", "sh2_mod", "culls"])
+def test_backward_matches_oracle(oracle, name):
+    _grad_check(oracle, name)
+
+
+def test_backward_precomputed_inputs(oracle):
+    _grad_check(oracle, "sh3_small", use_precomp_color=True, use_precomp_cov=True)
+
+
+def test_argument_contract():
+    from gaussianavatars_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+    dev = _dev()
+    z = lambda *s: torch.zeros(*s, device=dev)
+    rs = GaussianRasterizationSettings(32, 32, 0.5, 0.5, z(3), 1.0, torch.eye(4, device=dev), torch.eye(4, device=dev), 0,
+                                       z(3), False, False)
+    r = GaussianRasterizer(rs)
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(means3D=z(4, 3), means2D=z(4, 3), opacities=z(4, 1), scales=z(4, 3), rotations=z(4, 4))
+    with pytest.raises(Exception, match="scale/rotation pair"):
+        r(means3D=z(4, 3), means2D=z(4, 3), opacities=z(4, 1), shs=z(4, 1, 3), scales=z(4, 3))
+    vis = r.markVisible(torch.tensor([[0.0, 0.0, 1.0], [0.0, 0.0, 0.1]], device=dev))
+    assert vis.tolist() == [True, False]
+
+
+def test_replay_on_capacity_overflow(oracle):
+    """A frame needing more instances than the current capacity hint is replayed, not truncated."""
+    from gaussianavatars_amd import rasterizer as R
+
+    R._capacity_hint.clear()
+    s, st, hs, rs, _ = _run_both(oracle, "cfg1")
+    key = (0, rs.image_height, rs.image_width)
+    R._capacity_hint[key] = R._CAP_QUANTUM  # far below the 73k instances cfg1 needs? keep it honest:
+    if st.num_rendered <= R._CAP_QUANTUM:
+        pytest.skip("scene fits the minimum capacity")
+    s, st, hs, rs, _ = _run_both(oracle, "cfg1")
+    assert R.last_forward_info()["replays"] >= 1
+    _check_forward(st, hs)
