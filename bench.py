@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec forward+backward of the GaussianAvatars hot path on MI355X.
+
+One "step" = the reference's training inner loop on one frame (train.py:118-164 without optimiser /
+SSIM, i.e. BASELINE.json config 3):
+    select_mesh_by_timestep(t)  ->  render(cam, gaussians, pipe, white bg)  ->  l1_loss(image, white)
+    ->  loss.backward()
+on the synthetic stand-in for media/306 (100 000 mesh-bound SH-3 splats, 802x550, the camera of
+fps_benchmark_demo.py:21-33).  Inputs are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|render] [--binding fused|unfused]
+
+N > 1 is launched by torch.distributed.run (one rank per GPU): every rank holds a replica of the
+splats and renders its own frames (frame-parallel, weak scaling); the only collective is the
+all-reduce of the scalar loss (RCCL over xGMI).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a copy kernel reaches
+
+
+class Pipe:
+    debug = False
+    compute_cov3D_python = False
+    convert_SHs_python = False
+
+
+def build_scene(device, n_splats, sh_degree, width, height, n_frames, binding_impl, requires_grad):
+    from gaussianavatars_amd import synthetic as S
+    from gaussianavatars_amd.gaussian_model import FlameGaussianModel
+
+    rig = S.flame_rig(seed=4)
+    g = FlameGaussianModel(sh_degree, rig, binding_impl=binding_impl, device=device)
+    g.load_arrays(S.bound_splats(n_splats, S.FLAME_F, sh_degree, seed=2), device=device, requires_grad=requires_grad)
+    g.load_flame_param(S.flame_sequence(n_frames, seed=4), device=device, requires_grad=requires_grad)
+    cam = S.orbit_camera(width, height, r=1.0, fovy_deg=20.0)
+    for k in ("world_view_transform", "full_proj_transform", "camera_center"):
+        setattr(cam, k, torch.as_tensor(getattr(cam, k), device=device))
+    return g, cam
+
+
+def one_step(g, cam, bg, target, t, train):
+    from gaussianavatars_amd.gaussian_renderer import l1_loss, render
+
+    g.select_mesh_by_timestep(t)
+    pkg = render(cam, g, Pipe, bg)
+    if not train:
+        return pkg["render"].sum() * 0  # keep a device scalar for the (optional) all-reduce
+    loss = l1_loss(pkg["render"], target)
+    loss.backward()
+    return loss.detach()
+
+
+def zero_grads(g):
+    for p in (g._xyz, g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity):
+        p.grad = None
+    if g.flame_param is not None:
+        for v in g.flame_param.values():
+            if v.requires_grad:
+                v.grad = None
+
+
+def cpu_baseline(g, cam, bg, train, max_seconds=25.0):
+    """The CPU oracle (oracle/, a port -- the reference has no CPU rasterizer) timed on
+    this box's host cores on the same frame (rasterizer half only: world-space splats in, image and
+    gradients out)."""
+    import math
+
+    from oracle import gsr_oracle as O
+
+    O.build()
+    with torch.no_grad():
+        g.select_mesh_by_timestep(0)
+        arrs = dict(means3D=g.get_xyz, shs=g.get_features, opacities=g.get_opacity, scales=g.get_scaling,
+                    rotations=g.get_rotation)
+        arrs = {k: v.detach().float().cpu().numpy() for k, v in arrs.items()}
+    s = O.make_settings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
+                        bg.cpu().numpy(), 1.0, cam.world_view_transform.cpu().numpy(), cam.full_proj_transform.cpu().numpy(),
+                        g.active_sh_degree, cam.camera_center.cpu().numpy())
+    H, W = cam.image_height, cam.image_width
+    gpix = np.full((3, H, W), -1.0 / (3 * H * W), np.float32)  # d l1(image, white)/d image where image < 1
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        st = O.forward(s, arrs["means3D"], arrs["shs"], None, arrs["opacities"], arrs["scales"], arrs["rotations"], None)
+        if train:
+            O.backward(s, st, gpix)
+        frames += 1
+        el = time.perf_counter() - t0
+        if el > max_seconds or frames >= 8:
+            break
+    cores = os.cpu_count() or 1
+    return dict(value=frames / el, unit="frames/s", cores=cores, kind="port",
+                sample=f"{frames} frame(s) of the bench workload, rasterizer half ({'fwd+bwd' if train else 'fwd'}), "
+                       f"oracle/gsr_oracle.c with OpenMP on {cores} threads (render backward is single-threaded)",
+                ), st.num_rendered, int((st.radii > 0).sum())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--mode", choices=["train", "render"], default="train")
+    ap.add_argument("--binding", choices=["fused", "unfused"], default="fused")
+    ap.add_argument("--splats", type=int, default=100_000)
+    ap.add_argument("--width", type=int, default=550)
+    ap.add_argument("--height", type=int, default=802)
+    ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path for the rasterizer")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    n_gpus = world
+    train = args.mode == "train"
+
+    from gaussianavatars_amd import _lib
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd.frame_parallel import frames_for_rank
+
+    g, cam = build_scene(device, args.splats, 3, args.width, args.height, args.frames, args.binding, train)
+    bg = torch.ones(3, dtype=torch.float32, device=device)
+    target = torch.ones((3, args.height, args.width), dtype=torch.float32, device=device)
+    my_frames = frames_for_rank(args.frames, rank, world)
+
+    def run(n, offset):
+        loss_sum = torch.zeros((), device=device)
+        for i in range(n):
+            t = my_frames[(offset + i) % len(my_frames)]
+            with torch.set_grad_enabled(train):
+                l = one_step(g, cam, bg, target, t, train)
+            if dist is not None:
+                dist.all_reduce(l, op=dist.ReduceOp.SUM)  # the one collective of the path: a scalar
+            loss_sum += l
+            if train:
+                zero_grads(g)
+        return loss_sum
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    run(args.warmup, 0)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    info = R.last_forward_info()
+
+    # ---- per-kernel durations: HIP events on the launch stream, same K steps again --------------
+    kern = {}
+    if rank == 0 and not args.no_kernel_profile:
+        _lib.gsr_profile_enable(True)
+        run(args.steps, args.warmup)
+        torch.cuda.synchronize(device)
+        kern = _lib.gsr_profile_read()
+        _lib.gsr_profile_enable(False)
+    if dist is not None:
+        dist.barrier()
+
+    if rank == 0:
+        N, HW = args.splats, args.width * args.height
+        I = info.get("num_rendered", 0)
+        with torch.no_grad():
+            vis = 1.0
+        per_kernel = {k: dict(avg_us=1e3 * ms / max(n, 1), launches=n) for k, (ms, n) in kern.items() if n}
+        # algorithmic bytes per launch; v = visible fraction taken as 1 (measured below)
+        algo = {
+            "k_preprocess": 236 * N + (44 + (27 if train else 0)) * N,
+            "k_scatter": 20 * N + 8 * I,
+            "k_tile_sort": 8 * I + 12 * I + 36 * I + 48 * I,
+            "k_render": 48 * I + (12 + (8 if train else 0)) * HW,
+            "k_render_bwd": 20 * HW + 48 * I + 36 * N,
+            "k_preprocess_bwd": 300 * N + 256 * N,
+        }
+        roofline = None
+        if per_kernel:
+            dom = max((k for k in per_kernel if k in algo), key=lambda k: per_kernel[k]["avg_us"] * per_kernel[k]["launches"])
+            ach = algo[dom] / (per_kernel[dom]["avg_us"] * 1e-6) / 1e9
+            roofline = dict(kernel=dom, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
+                            algorithmic_bytes_per_launch=int(algo[dom]), avg_launch_us=round(per_kernel[dom]["avg_us"], 2),
+                            all_kernels={k: dict(avg_us=round(v["avg_us"], 2),
+                                                 algo_GBs=round(algo[k] / (v["avg_us"] * 1e-6) / 1e9, 1) if k in algo else None)
+                                         for k, v in per_kernel.items()})
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu, I_cpu, vis_cpu = cpu_baseline(g, cam, bg, train)
+            vis = vis_cpu / N
+        fps = n_gpus * args.steps / elapsed
+        out = {
+            "metric": "frames/sec fwd+bwd @100k SH-3 splats 802x550" if train else "frames/sec fwd @100k SH-3 splats 802x550",
+            "value": round(fps, 2),
+            "unit": "frames/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": ("BASELINE configs[2]: %d mesh-bound SH-3 splats (synthetic stand-in for media/306), %dx%d (HxW), "
+                             "select_mesh_by_timestep + render + L1-vs-white + backward, no optimiser step"
+                             if train else
+                             "BASELINE configs[1]: %d mesh-bound SH-3 splats, %dx%d (HxW), select_mesh_by_timestep + render, no_grad")
+                            % (N, args.height, args.width),
+                "splats": N, "width": args.width, "height": args.height, "sh_degree": 3,
+                "num_rendered": I, "visible_fraction": round(vis, 4), "binding": args.binding,
+                "parallelism": f"frame-parallel x{n_gpus}, scalar loss all-reduce",
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,7 +62,25 @@ GSR_SYMBOLS = {
                      [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p] +
                      [C.c_void_p] * 8 + [C.c_void_p]),
     "gsr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsr_profile_enable": (C.c_int, [C.c_int]),
+    "gsr_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "gsr_kernel_name": (C.c_char_p, [C.c_int]),
 }
+GSR_NUM_KERNELS = 8
+
+
+def gsr_profile_enable(on: bool) -> None:
+    gsr().gsr_profile_enable(1 if on else 0)
+
+
+def gsr_profile_read() -> dict:
+    """{kernel name: (total_ms, launches)} accumulated since the last read."""
+    ms = (C.c_double * GSR_NUM_KERNELS)()
+    n = (C.c_int64 * GSR_NUM_KERNELS)()
+    rc = gsr().gsr_profile_read(ms, n)
+    if rc != GSR_OK:
+        raise RuntimeError(f"gsr_profile_read failed: {gsr().gsr_last_error().decode()}")
+    return {gsr().gsr_kernel_name(i).decode(): (ms[i], n[i]) for i in range(GSR_NUM_KERNELS)}
 
 _gsr = None
 

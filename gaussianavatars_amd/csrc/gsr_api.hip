@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <thread>
+#include <vector>
 
 #include "gsr_device.h"
 
@@ -64,6 +65,42 @@ struct Mailbox {
     }
 };
 Mailbox g_mail;
+
+// ---- optional per-kernel event timing -------------------------------------------------------
+struct Profiler {
+    std::atomic<int> on{0};
+    std::mutex mu;
+    struct Pending { int id; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+Profiler g_prof;
+
+struct ScopedKernelTimer {
+    int id; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool active;
+    ScopedKernelTimer(int id_, hipStream_t s) : id(id_), st(s), active(g_prof.on.load() != 0)
+    {
+        if (!active) return;
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        a = g_prof.get(); b = g_prof.get();
+        (void)hipEventRecord(a, st);
+    }
+    ~ScopedKernelTimer()
+    {
+        if (!active) return;
+        (void)hipEventRecord(b, st);
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        g_prof.pending.push_back({id, a, b});
+    }
+};
+#define TIMED(id, stream) ScopedKernelTimer timer_##id(id, stream)
 
 gsr::Settings to_dev_settings(const GsrSettings* s)
 {
@@ -198,11 +235,28 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
     pa.rect = (ushort4*)(g + gl.rect);
     pa.tiles_touched = (uint32_t*)(g + gl.tiles_touched);
     pa.clamped = (uint8_t*)(g + gl.clamped);
-    pa.tile_count = tile_count;
     const int pblocks = (P + 255) / 256;
     if (pblocks > 0) {
-        hipLaunchKernelGGL(gsr::k_preprocess, dim3(pblocks), dim3(256), 0, stream, ds, pa);
-        KERNEL_CHECK("k_preprocess", stream, dbg);
+        {
+            TIMED(GSR_K_PREPROCESS, stream);
+    hipLaunchKernelGGL(gsr::k_preprocess, dim3(pblocks), dim3(256), 0, stream, ds, pa);
+                    KERNEL_CHECK("k_preprocess", stream, dbg);
+        }
+    }
+
+    // binning workgroups: each owns a contiguous chunk of splats and an LDS histogram over the tiles
+    const int bin_blocks = pblocks < 256 ? pblocks : 256;
+    const size_t hist_bytes = (size_t)tiles * sizeof(uint32_t);
+    if (hist_bytes > 160 * 1024) return fail(GSR_E_ARG, "image has %d tiles; the LDS tile histogram supports at most 40960", tiles);
+    if (hist_bytes > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+    }
+    if (pblocks > 0) {
+        TIMED(GSR_K_COUNT, stream);
+        hipLaunchKernelGGL(gsr::k_count, dim3(bin_blocks), dim3(256), hist_bytes, stream, P, gx, tiles, (const ushort4*)pa.rect,
+                           (const uint32_t*)pa.tiles_touched, tile_count);
+        KERNEL_CHECK("k_count", stream, dbg);
     }
 
     const unsigned long long seq = (g_mail.seq.fetch_add(1) % 0xFFFFFEull) + 1;  // 1 .. 2^24-2, never 0
@@ -210,31 +264,43 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
     *slot = 0;
     unsigned long long* slot_dev = nullptr;
     HIP_TRY(hipHostGetDevicePointer((void**)&slot_dev, (void*)slot, 0));
+    {
+        TIMED(GSR_K_TILE_SCAN, stream);
     hipLaunchKernelGGL(gsr::k_tile_scan, dim3(1), dim3(1024), 0, stream, tiles, (const uint32_t*)tile_count,
-                       (uint32_t*)(b + bl.tile_start), (uint32_t*)(b + bl.tile_cursor), (uint2*)(b + bl.ranges), total_dev,
-                       slot_dev, seq);
-    KERNEL_CHECK("k_tile_scan", stream, dbg);
+                               (uint32_t*)(b + bl.tile_start), (uint32_t*)(b + bl.tile_cursor), (uint2*)(b + bl.ranges), total_dev,
+                               slot_dev, seq);
+            KERNEL_CHECK("k_tile_scan", stream, dbg);
+    }
 
     // Optimistic launch: the rest of the frame is enqueued against the caller's capacity before the
     // host knows I; every kernel re-checks *total_dev <= capacity on the device and does nothing
     // otherwise.  The host then waits only for the scan (early in the frame), not for the frame.
     const unsigned long long cap = (unsigned long long)binning_capacity;
     if (pblocks > 0) {
-        hipLaunchKernelGGL(gsr::k_scatter, dim3(pblocks), dim3(256), 0, stream, P, gx, (const float*)pa.depths,
-                           (const ushort4*)pa.rect, (const uint32_t*)pa.tiles_touched, (const uint32_t*)(b + bl.tile_start),
-                           (uint32_t*)(b + bl.tile_cursor), (unsigned long long*)(b + bl.keys), cap,
-                           (const unsigned long long*)total_dev);
-        KERNEL_CHECK("k_scatter", stream, dbg);
-        hipLaunchKernelGGL(gsr::k_tile_sort, dim3(tiles), dim3(256), 0, stream, tiles, (const uint32_t*)tile_count,
-                           (const uint32_t*)(b + bl.tile_start), (unsigned long long*)(b + bl.keys),
-                           (uint32_t*)(b + bl.point_list), (float4*)(b + bl.records), (const float2*)pa.xy,
-                           (const float4*)pa.conic_opacity, (const float4*)pa.rgb, cap, (const unsigned long long*)total_dev);
-        KERNEL_CHECK("k_tile_sort", stream, dbg);
+        {
+            TIMED(GSR_K_SCATTER, stream);
+    hipLaunchKernelGGL(gsr::k_scatter, dim3(bin_blocks), dim3(256), hist_bytes, stream, P, gx, tiles, (const float*)pa.depths,
+                                       (const ushort4*)pa.rect, (const uint32_t*)pa.tiles_touched, (const uint32_t*)(b + bl.tile_start),
+                                       (uint32_t*)(b + bl.tile_cursor), (unsigned long long*)(b + bl.keys), cap,
+                                       (const unsigned long long*)total_dev);
+                    KERNEL_CHECK("k_scatter", stream, dbg);
+        }
+        {
+            TIMED(GSR_K_TILE_SORT, stream);
+    hipLaunchKernelGGL(gsr::k_tile_sort, dim3(tiles), dim3(256), 0, stream, tiles, (const uint32_t*)tile_count,
+                                       (const uint32_t*)(b + bl.tile_start), (unsigned long long*)(b + bl.keys),
+                                       (uint32_t*)(b + bl.point_list), (float4*)(b + bl.records), (const float2*)pa.xy,
+                                       (const float4*)pa.conic_opacity, (const float4*)pa.rgb, cap, (const unsigned long long*)total_dev);
+                    KERNEL_CHECK("k_tile_sort", stream, dbg);
+        }
     }
+    {
+        TIMED(GSR_K_RENDER, stream);
     hipLaunchKernelGGL(gsr::k_render, dim3(gx, gy), dim3(256), 0, stream, ds, (const uint2*)(b + bl.ranges),
-                       (const float4*)(b + bl.records), (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib), out_color,
-                       cap, (const unsigned long long*)total_dev);
-    KERNEL_CHECK("k_render", stream, dbg);
+                               (const float4*)(b + bl.records), (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib), out_color,
+                               cap, (const unsigned long long*)total_dev);
+            KERNEL_CHECK("k_render", stream, dbg);
+    }
 
     // wait for the scan's post
     const auto t0 = std::chrono::steady_clock::now();
@@ -299,10 +365,13 @@ int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M, const float*
 
     HIP_TRY(hipMemsetAsync(grad_scratch, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), stream));
     if (num_rendered > 0) {
-        hipLaunchKernelGGL(gsr::k_render_bwd, dim3(gx, gy), dim3(256), 0, stream, ds, (const uint2*)(b + bl.ranges),
-                           (const float4*)(b + bl.records), (const float*)(im + il.final_T),
-                           (const uint32_t*)(im + il.n_contrib), dL_dpix, grad_scratch);
-        KERNEL_CHECK("k_render_bwd", stream, dbg);
+        {
+            TIMED(GSR_K_RENDER_BWD, stream);
+    hipLaunchKernelGGL(gsr::k_render_bwd, dim3(gx, gy), dim3(256), 0, stream, ds, (const uint2*)(b + bl.ranges),
+                                       (const float4*)(b + bl.records), (const float*)(im + il.final_T),
+                                       (const uint32_t*)(im + il.n_contrib), dL_dpix, grad_scratch);
+                    KERNEL_CHECK("k_render_bwd", stream, dbg);
+        }
     }
     gsr::PreBwdArgs pa;
     pa.P = P; pa.M = M;
@@ -317,9 +386,41 @@ int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M, const float*
     pa.dL_dcolors = dL_dcolors; pa.dL_dopacity = dL_dopacity;
     pa.dL_dscales = pre_cov ? nullptr : dL_dscales; pa.dL_drotations = pre_cov ? nullptr : dL_drotations;
     pa.dL_dcov3D = dL_dcov3D;
+    {
+        TIMED(GSR_K_PREPROCESS_BWD, stream);
     hipLaunchKernelGGL(gsr::k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, stream, ds, pa);
-    KERNEL_CHECK("k_preprocess_bwd", stream, dbg);
+            KERNEL_CHECK("k_preprocess_bwd", stream, dbg);
+    }
     return GSR_OK;
+}
+
+int gsr_profile_enable(int on)
+{
+    g_prof.on.store(on ? 1 : 0);
+    return GSR_OK;
+}
+
+int gsr_profile_read(double* total_ms, int64_t* launches)
+{
+    if (!total_ms || !launches) return fail(GSR_E_ARG, "gsr_profile_read: NULL output");
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    for (auto& p : g_prof.pending) {
+        HIP_TRY(hipEventSynchronize(p.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
+        if (p.id >= 0 && p.id < GSR_NUM_KERNELS) { total_ms[p.id] += (double)ms; launches[p.id] += 1; }
+        g_prof.pool.push_back(p.a);
+        g_prof.pool.push_back(p.b);
+    }
+    g_prof.pending.clear();
+    return GSR_OK;
+}
+
+const char* gsr_kernel_name(int id)
+{
+    static const char* names[GSR_NUM_KERNELS] = {"k_preprocess", "k_tile_scan", "k_scatter", "k_tile_sort",
+                                                 "k_render", "k_render_bwd", "k_preprocess_bwd", "k_count"};
+    return (id >= 0 && id < GSR_NUM_KERNELS) ? names[id] : "?";
 }
 
 int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present, void* stream_)

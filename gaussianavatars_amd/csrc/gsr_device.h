@@ -175,7 +175,6 @@ struct PreprocessArgs {
     ushort4* __restrict__ rect;
     uint32_t* __restrict__ tiles_touched;
     uint8_t* __restrict__ clamped;
-    uint32_t* __restrict__ tile_count;
 };
 
 struct PreBwdArgs {
@@ -202,7 +201,8 @@ struct PreBwdArgs {
 __global__ void k_preprocess(Settings s, PreprocessArgs a);
 __global__ void k_tile_scan(int tiles, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, uint2* ranges,
                             unsigned long long* total_dev, unsigned long long* mailbox, unsigned long long seq);
-__global__ void k_scatter(int P, int gx, const float* depths, const ushort4* rect, const uint32_t* tiles_touched,
+__global__ void k_count(int P, int gx, int tiles, const ushort4* rect, const uint32_t* tiles_touched, uint32_t* tile_count);
+__global__ void k_scatter(int P, int gx, int tiles, const float* depths, const ushort4* rect, const uint32_t* tiles_touched,
                           const uint32_t* tile_start, uint32_t* tile_cursor, unsigned long long* keys,
                           unsigned long long capacity, const unsigned long long* total_dev);
 __global__ void k_tile_sort(int tiles, const uint32_t* tile_count, const uint32_t* tile_start, unsigned long long* keys,

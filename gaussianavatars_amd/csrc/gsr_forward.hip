@@ -207,11 +207,39 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         a.tiles_touched[i] = n;
         a.clamped[i] = (uint8_t)clampbits;
     }
-    // ---- instances per tile (all 64 lanes take part: idle lanes carry n == 0)
-    const uint32_t n = visible ? (uint32_t)((rmaxx - rminx) * (rmaxy - rminy)) : 0u;
-    uint32_t* tc = a.tile_count;
-    for_each_tile(rminx, rminy, rmaxx, rmaxy, n, gx,
-                  [tc](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&tc[tile], 1u); }, 0u, 0u);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_count: instances per tile.  Each workgroup owns a contiguous chunk of splats and histograms
+// their tile rects in LDS (ds_add, no return); only the non-empty bins go to the global counters,
+// so a hot tile sees one L2 atomic per workgroup instead of one per instance.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_count(int P, int gx, int tiles, const ushort4* __restrict__ rect,
+                                                const uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ tile_count)
+{
+    extern __shared__ uint32_t hist[];
+    const int tid = threadIdx.x;
+    for (int t = tid; t < tiles; t += 256) hist[t] = 0u;
+    __syncthreads();
+    const int chunk = ((P + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
+    const int begin = blockIdx.x * chunk;
+    const int end = min(P, begin + chunk);
+    for (int base = begin; base < end; base += 256) {
+        const int i = base + tid;
+        uint32_t n = 0;
+        int minx = 0, miny = 0, maxx = 0, maxy = 0;
+        if (i < end) {
+            n = tiles_touched[i];
+            const ushort4 r = rect[i];
+            minx = r.x; miny = r.y; maxx = r.z; maxy = r.w;
+        }
+        for_each_tile(minx, miny, maxx, maxy, n, gx, [](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&hist[tile], 1u); }, 0u, 0u);
+    }
+    __syncthreads();
+    for (int t = tid; t < tiles; t += 256) {
+        const uint32_t v = hist[t];
+        if (v) atomicAdd(&tile_count[t], v);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -263,30 +291,59 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int tiles, const uint32_t* _
 }
 
 // ------------------------------------------------------------------------------------------
-// k_scatter: per splat, one (depth bits << 32 | splat) entry into every touched tile's segment
+// k_scatter: one (depth bits << 32 | splat) entry into every touched tile's segment.  Same chunking
+// as k_count: the workgroup re-histograms its chunk in LDS, reserves one contiguous sub-range per
+// touched tile with a single returning L2 atomic, then hands out slots with returning LDS atomics.
+// Order inside a tile segment is arbitrary here; k_tile_sort fixes it.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_scatter(int P, int gx, const float* __restrict__ depths,
+__global__ __launch_bounds__(256) void k_scatter(int P, int gx, int tiles, const float* __restrict__ depths,
                                                   const ushort4* __restrict__ rect, const uint32_t* __restrict__ tiles_touched,
                                                   const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
                                                   unsigned long long* __restrict__ keys, unsigned long long capacity,
                                                   const unsigned long long* __restrict__ total_dev)
 {
+    extern __shared__ uint32_t hist[];
     if (*total_dev > capacity) return;  // the host will grow the buffer and replay the frame
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n = 0, dbits = 0;
-    int minx = 0, miny = 0, maxx = 0, maxy = 0;
-    if (i < P) {
-        n = tiles_touched[i];
-        const ushort4 r = rect[i];
-        minx = r.x; miny = r.y; maxx = r.z; maxy = r.w;
-        dbits = __float_as_uint(depths[i]);
+    const int tid = threadIdx.x;
+    for (int t = tid; t < tiles; t += 256) hist[t] = 0u;
+    __syncthreads();
+    const int chunk = ((P + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
+    const int begin = blockIdx.x * chunk;
+    const int end = min(P, begin + chunk);
+    for (int base = begin; base < end; base += 256) {
+        const int i = base + tid;
+        uint32_t n = 0;
+        int minx = 0, miny = 0, maxx = 0, maxy = 0;
+        if (i < end) {
+            n = tiles_touched[i];
+            const ushort4 r = rect[i];
+            minx = r.x; miny = r.y; maxx = r.z; maxy = r.w;
+        }
+        for_each_tile(minx, miny, maxx, maxy, n, gx, [](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&hist[tile], 1u); }, 0u, 0u);
     }
-    for_each_tile(minx, miny, maxx, maxy, n, gx,
-                  [=](uint32_t tile, uint32_t db, uint32_t idx) {
-                      const uint32_t slot = tile_start[tile] + atomicAdd(&tile_cursor[tile], 1u);
-                      keys[slot] = ((unsigned long long)db << 32) | (unsigned long long)idx;
-                  },
-                  dbits, (uint32_t)i);
+    __syncthreads();
+    for (int t = tid; t < tiles; t += 256) {
+        const uint32_t v = hist[t];
+        hist[t] = v ? tile_start[t] + atomicAdd(&tile_cursor[t], v) : 0u;   // first slot of this workgroup in tile t
+    }
+    __syncthreads();
+    for (int base = begin; base < end; base += 256) {
+        const int i = base + tid;
+        uint32_t n = 0, dbits = 0;
+        int minx = 0, miny = 0, maxx = 0, maxy = 0;
+        if (i < end) {
+            n = tiles_touched[i];
+            const ushort4 r = rect[i];
+            minx = r.x; miny = r.y; maxx = r.z; maxy = r.w;
+            dbits = __float_as_uint(depths[i]);
+        }
+        for_each_tile(minx, miny, maxx, maxy, n, gx,
+                      [=](uint32_t tile, uint32_t db, uint32_t idx) {
+                          const uint32_t slot = atomicAdd(&hist[tile], 1u);
+                          keys[slot] = ((unsigned long long)db << 32) | (unsigned long long)idx;
+                      },
+                      dbits, (uint32_t)i);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -395,30 +452,54 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint2* __restr
     uint32_t last_contributor = 0;
     bool done = !inside;
 
-    for (int j = 0; j < n; ++j) {
+    // The list is walked RB records at a time: the RB exponentials are independent (instruction-level
+    // parallelism for a wave that is alone on its SIMD), only the short T/C update is sequential.
+    // Skips are predicated (selects), so the arithmetic per contributing record is exactly A.3's.
+    constexpr int RB = 4;
+    for (int j0 = 0; j0 < n; j0 += RB) {
         if (__all(done)) break;
-        const float4 r0 = rec[3 * j + 0];
-        const float4 r1 = rec[3 * j + 1];
-        const float cb = rec[3 * j + 2].x;
-        if (!done) {
-            const float dx = r0.x - pixx;
-            const float dy = r0.y - pixy;
-            const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-            if (power <= 0.0f) {
-                const float alpha = sel_min(0.99f, r1.y * gsr_expf(power));
-                if (alpha >= 1.0f / 255.0f) {
-                    const float test_T = T * (1.0f - alpha);
-                    if (test_T < 0.0001f) {
-                        done = true;
-                    } else {
-                        C0 += r1.z * alpha * T;
-                        C1 += r1.w * alpha * T;
-                        C2 += cb * alpha * T;
-                        T = test_T;
-                        last_contributor = (uint32_t)(j + 1);
-                    }
-                }
-            }
+        float rx[RB], ry[RB], ca[RB], cb2[RB], cc[RB], op[RB], c_r[RB], c_g[RB], c_b[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int j = min(j0 + u, n - 1);   // tail: re-read the last record, masked out below
+            const float4 r0 = rec[3 * j + 0];
+            const float4 r1 = rec[3 * j + 1];
+            const float r2x = rec[3 * j + 2].x;
+            rx[u] = r0.x; ry[u] = r0.y; ca[u] = r0.z; cb2[u] = r0.w;
+            cc[u] = r1.x; op[u] = r1.y; c_r[u] = r1.z; c_g[u] = r1.w; c_b[u] = r2x;
+        }
+        float power[RB];
+        bool cand = false;
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const float dx = rx[u] - pixx;
+            const float dy = ry[u] - pixy;
+            power[u] = -0.5f * (ca[u] * dx * dx + cc[u] * dy * dy) - cb2[u] * dx * dy;
+            cand = cand || (power[u] <= 0.0f && (j0 + u) < n);
+        }
+        if (!__any(cand && !done)) continue;   // wave-uniform: none of the 64 pixels is near these splats
+        float alpha[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const float a = sel_min(0.99f, op[u] * gsr_expf(power[u]));
+            const bool ok = power[u] <= 0.0f && (j0 + u) < n && a >= 1.0f / 255.0f;
+            alpha[u] = ok ? a : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const bool live = !done && alpha[u] > 0.0f;
+            const float test_T = T * (1.0f - alpha[u]);
+            const bool stop = live && test_T < 0.0001f;
+            const bool acc = live && !stop;
+            const float n0 = C0 + c_r[u] * alpha[u] * T;
+            const float n1 = C1 + c_g[u] * alpha[u] * T;
+            const float n2 = C2 + c_b[u] * alpha[u] * T;
+            C0 = acc ? n0 : C0;
+            C1 = acc ? n1 : C1;
+            C2 = acc ? n2 : C2;
+            T = acc ? test_T : T;
+            last_contributor = acc ? (uint32_t)(j0 + u + 1) : last_contributor;
+            done = done || stop;
         }
     }
     if (inside) {

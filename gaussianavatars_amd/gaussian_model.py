@@ -1,0 +1,224 @@
+"""Host-side mirror of the model half of the hot path: the accessors of
+scene/gaussian_model.py:113-163 and the mesh update of scene/flame_gaussian_model.py:91-154, with
+the same names, attributes and lazy-init behaviour, so a caller written against the reference
+(`render()`, train.py's inner loop, fps_benchmark_demo.py) reads the same.
+
+Only the per-frame path is mirrored.  Optimiser surgery, densification, PLY io and dataset loading
+are out of scope and stay with the reference's own files.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import unfused
+
+
+class GaussianModel:
+    """Accessor surface of the reference GaussianModel (scene/gaussian_model.py:52-163)."""
+
+    def __init__(self, sh_degree: int, binding_impl: str = "fused"):
+        self.active_sh_degree = 0
+        self.max_sh_degree = sh_degree
+        self._xyz = torch.empty(0)
+        self._features_dc = torch.empty(0)
+        self._features_rest = torch.empty(0)
+        self._scaling = torch.empty(0)
+        self._rotation = torch.empty(0)
+        self._opacity = torch.empty(0)
+        self.max_radii2D = torch.empty(0)
+        # mesh binding (reference :64-72)
+        self.face_center = None
+        self.face_scaling = None
+        self.face_orien_mat = None
+        self.face_orien_quat = None
+        self.binding = None
+        self.binding_counter = None
+        self.timestep = None
+        self.num_timesteps = 1
+        if binding_impl not in ("fused", "unfused"):
+            raise ValueError("binding_impl must be 'fused' or 'unfused'")
+        self.binding_impl = binding_impl
+
+    # ---- parameter loading (synthetic stand-in for load_ply / create_from_pcd) ----------------
+    def load_arrays(self, arrs: Dict[str, np.ndarray], device="cuda", requires_grad: bool = True):
+        """arrs uses the reference's leaf names (_xyz, _features_dc, _features_rest, _scaling, _rotation,
+        _opacity, optional binding).  Like load_ply (:323) this activates the full SH degree."""
+        for k in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
+            t = torch.as_tensor(arrs[k], dtype=torch.float32, device=device).contiguous()
+            setattr(self, k, nn.Parameter(t.requires_grad_(requires_grad)))
+        if arrs.get("binding") is not None:
+            self.binding = torch.as_tensor(arrs["binding"], device=device)
+            nf = int(self.binding.max().item()) + 1
+            self.binding_counter = torch.bincount(self.binding.long(), minlength=nf).int()
+        self.active_sh_degree = self.max_sh_degree
+        self.max_radii2D = torch.zeros((self._xyz.shape[0]), device=device)
+
+    # ---- accessors ------------------------------------------------------------------------------
+    @property
+    def get_scaling(self):
+        if self.binding is None:
+            return torch.exp(self._scaling)
+        if self.face_scaling is None:
+            self.select_mesh_by_timestep(0)
+        return self._bound()[1]
+
+    @property
+    def get_rotation(self):
+        if self.binding is None:
+            return torch.nn.functional.normalize(self._rotation)
+        if self.face_orien_quat is None:
+            self.select_mesh_by_timestep(0)
+        return self._bound()[2]
+
+    @property
+    def get_xyz(self):
+        if self.binding is None:
+            return self._xyz
+        if self.face_center is None:
+            self.select_mesh_by_timestep(0)
+        return self._bound()[0]
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    @property
+    def get_opacity(self):
+        return torch.sigmoid(self._opacity)
+
+    def get_covariance(self, scaling_modifier=1):
+        # python cov3D path (pipe.compute_cov3D_python, default off): like the reference (:162-163) it
+        # uses the LOCAL rotation, which is only right for un-bound splats.
+        s = scaling_modifier * self.get_scaling
+        q = self._rotation / self._rotation.norm(dim=1, keepdim=True)
+        r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                         2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                         2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).view(-1, 3, 3)
+        L = R * s[:, None, :]
+        S = L @ L.transpose(1, 2)
+        return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1)
+
+    def select_mesh_by_timestep(self, timestep):
+        raise NotImplementedError
+
+    def oneupSHdegree(self):
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    # ---- bound transform: one evaluation per mesh update, shared by the three accessors -------
+    def _bound(self):
+        """(xyz_world, scaling_world, rotation_world) for the current mesh.  The reference recomputes
+        each accessor on every call (get_xyz twice per render(), gaussian_renderer/__init__.py:27,54);
+        the values only change when the mesh or a leaf does, so they are cached per (mesh version,
+        leaf versions) -- autograd connectivity to the leaves and the face tensors is unchanged."""
+        key = (self._mesh_version, self._xyz._version, self._scaling._version, self._rotation._version,
+               id(self._xyz), id(self._scaling), id(self._rotation), torch.is_grad_enabled())
+        if getattr(self, "_bound_key", None) != key:
+            if self.binding_impl == "unfused":
+                out = (unfused.bind_xyz(self._xyz, self.binding, self.face_orien_mat, self.face_scaling, self.face_center),
+                       unfused.bind_scaling(self._scaling, self.binding, self.face_scaling),
+                       unfused.bind_rotation(self._rotation, self.binding, self.face_orien_quat))
+            else:
+                from . import binding as fused
+                out = fused.bind_splats(self._xyz, self._scaling, self._rotation, self.binding, self.face_orien_mat,
+                                        self.face_scaling, self.face_center, self.face_orien_quat)
+            self._bound_cache = out
+            self._bound_key = key
+        return self._bound_cache
+
+    _mesh_version = 0
+
+
+class FlameHead(nn.Module):
+    """Buffers + forward of the reference FlameHead (flame_model/flame.py:83-184, 485-558) on a rig given
+    as arrays (the licensed flame2023.pkl is not available; gaussianavatars_amd.synthetic.flame_rig
+    produces the same schema)."""
+
+    def __init__(self, rig: Dict[str, np.ndarray], impl: str = "fused"):
+        super().__init__()
+        for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights"):
+            self.register_buffer(k, torch.as_tensor(rig[k], dtype=torch.float32).contiguous())
+        self.register_buffer("parents", torch.as_tensor(rig["parents"], dtype=torch.long))
+        self.register_buffer("faces", torch.as_tensor(rig["faces"], dtype=torch.long), persistent=False)
+        self.n_shape_params = 300
+        self.n_expr_params = self.shapedirs.shape[2] - 300
+        self.impl = impl
+
+    def forward(self, shape, expr, rotation, neck, jaw, eyes, translation, zero_centered_at_root_node=False,
+                return_landmarks=True, return_verts_cano=False, static_offset=None, dynamic_offset=None):
+        if zero_centered_at_root_node or return_landmarks:
+            raise NotImplementedError("only the per-frame path of GaussianAvatars is mirrored "
+                                      "(zero_centered_at_root_node=False, return_landmarks=False)")
+        if self.impl == "unfused":
+            rig = dict(v_template=self.v_template, shapedirs=self.shapedirs, posedirs=self.posedirs,
+                       J_regressor=self.J_regressor, lbs_weights=self.lbs_weights, parents=self.parents)
+            verts, v_shaped = unfused.flame_forward(rig, shape, expr, rotation, neck, jaw, eyes, translation, static_offset)
+        else:
+            from . import binding as fused
+            verts, v_shaped = fused.flame_forward(self, shape, expr, rotation, neck, jaw, eyes, translation, static_offset)
+        return [verts, v_shaped] if return_verts_cano else verts
+
+
+class FlameGaussianModel(GaussianModel):
+    """Mesh-update surface of scene/flame_gaussian_model.py:22-41,91-154."""
+
+    def __init__(self, sh_degree: int, rig: Dict[str, np.ndarray], disable_flame_static_offset=False,
+                 not_finetune_flame_params=False, n_shape=300, n_expr=100, binding_impl: str = "fused", device="cuda"):
+        super().__init__(sh_degree, binding_impl=binding_impl)
+        self.disable_flame_static_offset = disable_flame_static_offset
+        self.not_finetune_flame_params = not_finetune_flame_params
+        self.n_shape, self.n_expr = n_shape, n_expr
+        self.flame_model = FlameHead(rig, impl=binding_impl).to(device)
+        self.flame_param = None
+        self.flame_param_orig = None
+        if self.binding is None:
+            nf = len(self.flame_model.faces)
+            self.binding = torch.arange(nf, device=device)
+            self.binding_counter = torch.ones(nf, dtype=torch.int32, device=device)
+
+    def load_flame_param(self, arrs: Dict[str, np.ndarray], device="cuda", requires_grad: bool = False):
+        """flame_param.npz schema (scene/flame_gaussian_model.py:61-71,229-237)."""
+        fp = {k: torch.as_tensor(v, dtype=torch.float32, device=device) for k, v in arrs.items()}
+        if requires_grad:  # the rows train.py puts in Adam groups (:186-207)
+            for k in ("rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation", "expr"):
+                fp[k].requires_grad_(True)
+        self.flame_param = fp
+        self.num_timesteps = fp["expr"].shape[0]
+
+    def update_mesh_by_param_dict(self, flame_param):
+        shape = flame_param["shape"] if "shape" in flame_param else self.flame_param["shape"]
+        static_offset = flame_param["static_offset"] if "static_offset" in flame_param else self.flame_param["static_offset"]
+        dev = self.flame_model.v_template.device
+        verts, verts_cano = self.flame_model(
+            shape[None, ...], flame_param["expr"].to(dev), flame_param["rotation"].to(dev), flame_param["neck"].to(dev),
+            flame_param["jaw"].to(dev), flame_param["eyes"].to(dev), flame_param["translation"].to(dev),
+            zero_centered_at_root_node=False, return_landmarks=False, return_verts_cano=True, static_offset=static_offset)
+        self.update_mesh_properties(verts, verts_cano)
+
+    def select_mesh_by_timestep(self, timestep, original=False):
+        self.timestep = timestep
+        fp = self.flame_param_orig if original and self.flame_param_orig is not None else self.flame_param
+        verts, verts_cano = self.flame_model(
+            fp["shape"][None, ...], fp["expr"][[timestep]], fp["rotation"][[timestep]], fp["neck_pose"][[timestep]],
+            fp["jaw_pose"][[timestep]], fp["eyes_pose"][[timestep]], fp["translation"][[timestep]],
+            zero_centered_at_root_node=False, return_landmarks=False, return_verts_cano=True,
+            static_offset=fp["static_offset"], dynamic_offset=fp["dynamic_offset"][[timestep]])
+        self.update_mesh_properties(verts, verts_cano)
+
+    def update_mesh_properties(self, verts, verts_cano):
+        faces = self.flame_model.faces
+        if self.binding_impl == "unfused":
+            c, R, s, q = unfused.face_frames(verts.squeeze(0), faces)
+        else:
+            from . import binding as fused
+            c, R, s, q = fused.face_frames(verts.squeeze(0), faces)
+        self.face_center, self.face_orien_mat, self.face_scaling, self.face_orien_quat = c, R, s, q
+        self.verts = verts
+        self.faces = faces
+        self.verts_cano = verts_cano
+        self._mesh_version = self._mesh_version + 1

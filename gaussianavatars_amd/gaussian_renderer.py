@@ -1,0 +1,99 @@
+"""Mirror of the reference's render boundary, gaussian_renderer/__init__.py:19-101: same signature,
+same settings construction, same return dict.  (With the repository root on PYTHONPATH the
+reference's own file runs unchanged against the top-level `diff_gaussian_rasterization` package;
+this mirror exists because /root/reference does not travel to the GPU box.)"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+C0 = 0.28209479177387814
+
+
+_C1 = 0.4886025119029199
+_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+       1.445305721320277, -0.5900435899266435)
+
+
+def eval_sh(deg: int, sh: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
+    """Real SH basis up to degree 3 (the polynomial of utils/sh_utils.py:57-112) for coefficients laid
+    out (P, M, 3) and unit directions (P, 3) -> (P, 3)."""
+    x, y, z = dirs[:, 0:1], dirs[:, 1:2], dirs[:, 2:3]
+    res = C0 * sh[:, 0]
+    if deg > 0:
+        res = res - _C1 * y * sh[:, 1] + _C1 * z * sh[:, 2] - _C1 * x * sh[:, 3]
+    if deg > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        res = (res + _C2[0] * xy * sh[:, 4] + _C2[1] * yz * sh[:, 5] + _C2[2] * (2.0 * zz - xx - yy) * sh[:, 6]
+               + _C2[3] * xz * sh[:, 7] + _C2[4] * (xx - yy) * sh[:, 8])
+    if deg > 2:
+        res = (res + _C3[0] * y * (3 * xx - yy) * sh[:, 9] + _C3[1] * xy * z * sh[:, 10]
+               + _C3[2] * y * (4 * zz - xx - yy) * sh[:, 11] + _C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[:, 12]
+               + _C3[4] * x * (4 * zz - xx - yy) * sh[:, 13] + _C3[5] * z * (xx - yy) * sh[:, 14]
+               + _C3[6] * x * (xx - 3 * yy) * sh[:, 15])
+    return res
+
+
+def _dev(t, device):
+    return t if isinstance(t, torch.Tensor) and t.device == device else torch.as_tensor(t, device=device)
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
+    xyz = pc.get_xyz
+    device = xyz.device
+    # dummy leaf that receives dL/d(screen-space mean) (reference :27-31)
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height),
+        image_width=int(viewpoint_camera.image_width),
+        tanfovx=tanfovx,
+        tanfovy=tanfovy,
+        bg=bg_color,
+        scale_modifier=scaling_modifier,
+        viewmatrix=_dev(viewpoint_camera.world_view_transform, device),
+        projmatrix=_dev(viewpoint_camera.full_proj_transform, device),
+        sh_degree=pc.active_sh_degree,
+        campos=_dev(viewpoint_camera.camera_center, device),
+        prefiltered=False,
+        debug=pipe.debug,
+    )
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+    means3D = xyz
+    means2D = screenspace_points
+    opacity = pc.get_opacity
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales = pc.get_scaling
+        rotations = pc.get_rotation
+    shs = colors_precomp = None
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            # python SH path of the reference (:74-79): colours from composed torch ops
+            feats = pc.get_features  # (P, M, 3)
+            d = xyz - raster_settings.campos[None]
+            d = d / d.norm(dim=1, keepdim=True)
+            colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, feats, d) + 0.5, 0.0)
+        else:
+            shs = pc.get_features
+    else:
+        colors_precomp = override_color
+    rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
+                                       opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+
+
+def l1_loss(network_output, gt):
+    """utils/loss_utils.py:17-18"""
+    return torch.abs((network_output - gt)).mean()

@@ -143,6 +143,26 @@ int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M,
 int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);
 
+/*
+ * Optional per-kernel timing with hipEvents recorded on the launch stream (what bench.py's
+ * `roofline` object is computed from).  Off by default; when on, every kernel launched by
+ * gsr_forward / gsr_backward is bracketed by an event pair.  gsr_profile_read synchronises the
+ * pending events and ADDS their elapsed times into total_ms[id] / launches[id]
+ * (arrays of GSR_NUM_KERNELS), then forgets them.
+ */
+#define GSR_K_PREPROCESS 0
+#define GSR_K_TILE_SCAN 1
+#define GSR_K_SCATTER 2
+#define GSR_K_TILE_SORT 3
+#define GSR_K_RENDER 4
+#define GSR_K_RENDER_BWD 5
+#define GSR_K_PREPROCESS_BWD 6
+#define GSR_K_COUNT 7
+#define GSR_NUM_KERNELS 8
+int gsr_profile_enable(int on);
+int gsr_profile_read(double* total_ms, int64_t* launches);
+const char* gsr_kernel_name(int id);
+
 #ifdef __cplusplus
 }
 #endif
