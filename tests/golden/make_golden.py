@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by IMPORTING THE REFERENCE (read-only, /root/reference) in this
+container -- it cannot travel to the GPU box, so the vectors it produces are committed.
+
+    python tests/golden/make_golden.py
+
+Pins produced (the reference has no tests or golden vectors of its own):
+  raster_pins.npz   utils/sh_utils.eval_sh                         -> SH colour of the oracle's K1
+                    utils/general_utils.build_scaling_rotation/..  -> cov3D packing + quaternion->R
+                    utils/graphics_utils.getWorld2View2/getProjectionMatrix + scene/cameras.py:44-47
+                                                                   -> transposed-matrix convention, pixel coords
+  binding_pins.npz  flame_model/lbs.py (lbs, blend_shapes)         -> FLAME forward on a small synthetic rig
+                    utils/graphics_utils.compute_face_orientation  -> per-face frames
+                    scipy Rotation.from_matrix (roma's algorithm)  -> rotmat -> quaternion, up to sign
+"""
+import math
+import os
+import sys
+from unittest import mock
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from utils import sh_utils, graphics_utils, general_utils  # noqa: E402  (reference modules)
+from flame_model import lbs as ref_lbs  # noqa: E402
+
+from gaussianavatars_amd import synthetic as S  # noqa: E402
+
+
+def cpu_zeros():
+    orig = torch.zeros
+
+    def z(*a, **k):
+        k.pop("device", None)
+        return orig(*a, **k)
+
+    return mock.patch("torch.zeros", z)
+
+
+def raster_pins():
+    g = np.random.default_rng(101)
+    N = 400
+    # -- SH
+    means = g.normal(0, 0.2, (N, 3)).astype(np.float32)
+    campos = np.array([0.1, -0.2, 1.0], np.float32)
+    shs = g.normal(0, 0.4, (N, 16, 3)).astype(np.float32)
+    d = torch.tensor(means - campos)
+    d = d / d.norm(dim=1, keepdim=True)
+    rgb = {}
+    for deg in range(4):
+        sh_view = torch.tensor(shs).transpose(1, 2)  # (N,3,16) as gaussian_renderer/__init__.py:75
+        out = sh_utils.eval_sh(deg, sh_view, d)
+        rgb[deg] = torch.clamp_min(out + 0.5, 0.0).numpy()
+    # -- cov3D (the reference normalises q; the rasterizer uses it raw -> feed unit quaternions)
+    scales = np.exp(g.normal(-4, 0.5, (N, 3))).astype(np.float32)
+    q = g.normal(0, 1, (N, 4))
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    mod = 1.3
+    with cpu_zeros():
+        L = general_utils.build_scaling_rotation(mod * torch.tensor(scales), torch.tensor(q))
+        cov = general_utils.strip_symmetric(L @ L.transpose(1, 2)).numpy()
+    # -- camera conventions (dataset-style camera, scene/cameras.py:44-47)
+    th = 0.3
+    Rm = np.array([[math.cos(th), 0, math.sin(th)], [0, 1, 0], [-math.sin(th), 0, math.cos(th)]])
+    T = np.array([0.05, -0.02, 1.2])
+    fovx, fovy = 0.5, 0.7
+    W2Ct = torch.tensor(graphics_utils.getWorld2View2(Rm, T)).transpose(0, 1)
+    Pt = graphics_utils.getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy).transpose(0, 1)
+    full = (W2Ct.unsqueeze(0).bmm(Pt.unsqueeze(0))).squeeze(0)
+    center = W2Ct.inverse()[3, :3]
+    pts = torch.tensor(g.normal(0, 0.15, (N, 3)).astype(np.float32))
+    ph = torch.cat([pts, torch.ones(N, 1)], 1) @ full   # row-vector convention of the reference
+    pv = torch.cat([pts, torch.ones(N, 1)], 1) @ W2Ct
+    ndc = ph[:, :2] / (ph[:, 3:4] + 1e-7)
+    Wd, Hd = 320, 240
+    pix = torch.stack([((ndc[:, 0] + 1) * Wd - 1) * 0.5, ((ndc[:, 1] + 1) * Hd - 1) * 0.5], 1)
+    np.savez_compressed(
+        os.path.join(HERE, "raster_pins.npz"),
+        sh_means=means, sh_campos=campos, sh_shs=shs, sh_rgb0=rgb[0], sh_rgb1=rgb[1], sh_rgb2=rgb[2], sh_rgb3=rgb[3],
+        cov_scales=scales, cov_quat=q, cov_mod=np.float32(mod), cov_expected=cov,
+        cam_viewmatrix=W2Ct.numpy(), cam_projmatrix=full.numpy(), cam_center=center.numpy(), cam_fovx=np.float32(fovx),
+        cam_fovy=np.float32(fovy), cam_W=np.int32(Wd), cam_H=np.int32(Hd), cam_points=pts.numpy(), cam_pix=pix.numpy(),
+        cam_depth=pv[:, 2].numpy(),
+    )
+
+
+def binding_pins():
+    g = np.random.default_rng(202)
+    V, Fn, J, NB = 180, 300, 5, 40
+    rig = dict(
+        v_template=g.normal(0, 0.1, (V, 3)).astype(np.float32),
+        shapedirs=g.normal(0, 0.01, (V, 3, NB)).astype(np.float32),
+        posedirs=g.normal(0, 0.01, (36, 3 * V)).astype(np.float32),
+        J_regressor=np.abs(g.normal(0, 1, (J, V))).astype(np.float32),
+        lbs_weights=np.abs(g.normal(0, 1, (V, J))).astype(np.float32),
+        parents=np.array([-1, 0, 1, 1, 1], np.int64),
+    )
+    rig["J_regressor"] /= rig["J_regressor"].sum(1, keepdims=True)
+    rig["lbs_weights"] /= rig["lbs_weights"].sum(1, keepdims=True)
+    faces = np.stack([g.permutation(V)[:3] for _ in range(Fn)]).astype(np.int64)
+    B = 1
+    betas = g.normal(0, 1, (B, NB)).astype(np.float32)
+    pose = g.normal(0, 0.3, (B, 15)).astype(np.float32)
+    pose[0, 3:6] = 0.0   # one exactly-zero joint rotation: the 1e-8 epsilon path of batch_rodrigues
+    trans = g.normal(0, 0.05, (B, 3)).astype(np.float32)
+    static_offset = g.normal(0, 0.002, (1, V, 3)).astype(np.float32)
+    t = torch.tensor
+    # the reference's FlameHead.forward body (flame_model/flame.py:511-536), using its own lbs module
+    v_shaped = t(rig["v_template"])[None] + ref_lbs.blend_shapes(t(betas), t(rig["shapedirs"]))
+    v_shaped = v_shaped + t(static_offset)
+    verts, Jt, _ = ref_lbs.lbs(t(pose), v_shaped, t(rig["posedirs"]), t(rig["J_regressor"]), t(rig["parents"]),
+                               t(rig["lbs_weights"]), dtype=torch.float32)
+    verts = verts + t(trans)[:, None, :]
+    R, scale = graphics_utils.compute_face_orientation(verts[0], t(faces), return_scale=True)
+    center = verts[:, t(faces)].mean(dim=-2).squeeze(0)
+    from scipy.spatial.transform import Rotation
+
+    quat_xyzw = Rotation.from_matrix(R.numpy().astype(np.float64)).as_quat().astype(np.float32)
+    np.savez_compressed(
+        os.path.join(HERE, "binding_pins.npz"),
+        faces=faces, betas=betas, pose=pose, trans=trans, static_offset=static_offset,
+        verts=verts.numpy(), v_shaped=v_shaped.numpy(), face_R=R.numpy(), face_scale=scale.numpy(), face_center=center.numpy(),
+        face_quat_xyzw_scipy=quat_xyzw, **{"rig_" + k: v for k, v in rig.items()},
+    )
+
+
+if __name__ == "__main__":
+    raster_pins()
+    binding_pins()
+    for f in ("raster_pins.npz", "binding_pins.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
