@@ -105,5 +105,54 @@ def gsr():
     return _gsr
 
 
+# ------------------------------------------------------------------------------------------------
+# libgab_hip.so : FLAME / face-frame / splat binding kernels (include/gab.h)
+# ------------------------------------------------------------------------------------------------
+GAB_LIB_PATH = os.path.join(_HERE, "libgab_hip.so")
+GAB_FLAME_WS_FLOATS = 512
+_P = C.c_void_p
+
+
+class GabRig(C.Structure):
+    """include/gab.h: GabRig"""
+    _fields_ = [("V", C.c_int32), ("n_shape", C.c_int32), ("n_expr", C.c_int32), ("v_template", _P), ("shapedirs", _P),
+                ("posedirs", _P), ("J_regressor", _P), ("lbs_weights", _P), ("parents", C.c_int32 * 5)]
+
+
+GAB_SYMBOLS = {
+    "gab_abi_version": (C.c_int, []),
+    "gab_last_error": (C.c_char_p, []),
+    "gab_flame_forward": (C.c_int, [C.POINTER(GabRig)] + [_P] * 8 + [_P, _P, _P, _P]),
+    "gab_flame_backward": (C.c_int, [C.POINTER(GabRig)] + [_P] * 8 + [_P, _P, _P, _P] + [_P] * 8 + [_P, _P]),
+    "gab_face_frames_forward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P, _P]),
+    "gab_face_frames_backward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "gab_bind_forward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gab_bind_backward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+_gab = None
+
+
+def gab():
+    """The binding library; raises (never falls back) when it is not built."""
+    global _gab
+    if _gab is None:
+        if not os.path.exists(GAB_LIB_PATH):
+            raise RuntimeError(f"{GAB_LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950).  There is no CPU fallback.")
+        lib = C.CDLL(GAB_LIB_PATH)
+        for name, (res, args) in GAB_SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.gab_abi_version() != 1:
+            raise RuntimeError(f"gab ABI version {lib.gab_abi_version()} != 1")
+        _gab = lib
+    return _gab
+
+
+def gab_error() -> str:
+    return gab().gab_last_error().decode("utf-8", "replace")
+
+
 def gsr_error() -> str:
     return gsr().gsr_last_error().decode("utf-8", "replace")

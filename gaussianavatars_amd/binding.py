@@ -1,0 +1,216 @@
+"""Fused binding path: torch.autograd Functions over the C ABI of include/gab.h.
+
+Each function replaces one composed-torch stage of the reference (see gab.h for file:line) with
+one native call forward and one backward; torch supplies device memory, the current stream and the
+autograd graph.  `gaussianavatars_amd.unfused` holds the same math as composed torch ops (the fp32
+reference these kernels are tested against); nothing here falls back to it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {_lib.gab_error()}")
+
+
+def _need_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a device tensor (got {t.device}); the fused binding path has no CPU implementation")
+
+
+def _f32(t):
+    return t.detach().float().contiguous()
+
+
+def _idx(t):
+    t = t.detach()
+    if t.dtype not in (torch.int32, torch.int64):
+        t = t.long()
+    return t.contiguous(), int(t.dtype == torch.int64)
+
+
+# -------------------------------------------------------------------------------------------------
+# FLAME forward
+# -------------------------------------------------------------------------------------------------
+def _rig_struct(head) -> "_lib.GabRig":
+    r = getattr(head, "_gab_rig", None)
+    key = (head.v_template.data_ptr(), head.shapedirs.data_ptr(), head.posedirs.data_ptr(), head.J_regressor.data_ptr(),
+           head.lbs_weights.data_ptr())
+    if r is None or r[0] != key:
+        for name in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights"):
+            b = getattr(head, name)
+            _need_cuda(b, name)
+            assert b.dtype == torch.float32 and b.is_contiguous(), name
+        s = _lib.GabRig()
+        s.V = head.v_template.shape[0]
+        s.n_shape = int(head.n_shape_params)
+        s.n_expr = int(head.shapedirs.shape[2]) - int(head.n_shape_params)
+        s.v_template, s.shapedirs, s.posedirs = key[0], key[1], key[2]
+        s.J_regressor, s.lbs_weights = key[3], key[4]
+        par = [int(x) for x in head.parents.tolist()]
+        if len(par) != 5:
+            raise RuntimeError("the fused FLAME kernels are built for the 5-joint FLAME skeleton")
+        s.parents[:] = par
+        head._gab_rig = (key, s)
+        r = head._gab_rig
+    return r[1]
+
+
+class _FlameForward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, head, shape, expr, rotation, neck, jaw, eyes, translation, static_offset):
+        lib = _lib.gab()
+        rig = _rig_struct(head)
+        dev = head.v_template.device
+        V = rig.V
+        ins = [_f32(t).reshape(-1) for t in (shape, expr, rotation, neck, jaw, eyes, translation)]
+        if ins[0].numel() != rig.n_shape or ins[1].numel() != rig.n_expr or ins[5].numel() != 6:
+            raise RuntimeError("fused FLAME forward is batch-1: shape (1,n_shape), expr (1,n_expr), eyes (1,6)")
+        so = None if static_offset is None else _f32(static_offset).reshape(-1)
+        if so is not None and so.numel() != 3 * V:
+            raise RuntimeError("static_offset must be (1,V,3)")
+        verts = torch.empty((1, V, 3), dtype=torch.float32, device=dev)
+        v_shaped = torch.empty((1, V, 3), dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.GAB_FLAME_WS_FLOATS, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _chk(lib.gab_flame_forward(C.byref(rig), *[_p(t) for t in ins], _p(so), _p(verts), _p(v_shaped), _p(ws), _stream(dev)),
+                 "gab_flame_forward")
+        ctx.head = head
+        ctx.has_so = static_offset is not None
+        ctx.shapes = [t.shape for t in (shape, expr, rotation, neck, jaw, eyes, translation)]
+        ctx.so_shape = None if static_offset is None else static_offset.shape
+        ctx.save_for_backward(*ins, *( [so] if so is not None else []), v_shaped, ws)
+        return verts, v_shaped
+
+    @staticmethod
+    def backward(ctx, g_verts, g_vshaped):
+        lib = _lib.gab()
+        head = ctx.head
+        rig = _rig_struct(head)
+        saved = ctx.saved_tensors
+        ins = list(saved[:7])
+        so = saved[7] if ctx.has_so else None
+        v_shaped, ws = saved[-2], saved[-1]
+        dev = v_shaped.device
+        V = rig.V
+        need = ctx.needs_input_grad  # (head, shape, expr, rotation, neck, jaw, eyes, translation, static_offset)
+        f32 = dict(dtype=torch.float32, device=dev)
+        d_shape = torch.empty(rig.n_shape, **f32) if need[1] else None
+        d_expr = torch.empty(rig.n_expr, **f32)
+        d_rot, d_neck, d_jaw = torch.empty(3, **f32), torch.empty(3, **f32), torch.empty(3, **f32)
+        d_eyes, d_trans = torch.empty(6, **f32), torch.empty(3, **f32)
+        d_so = torch.empty(3 * V, **f32) if (ctx.has_so and need[8]) else None
+        scratch = torch.empty(3 * V, **f32)
+        gv = torch.zeros((V, 3), **f32) if g_verts is None else _f32(g_verts)
+        gvs = None if g_vshaped is None else _f32(g_vshaped)
+        with torch.cuda.device(dev):
+            _chk(lib.gab_flame_backward(C.byref(rig), *[_p(t) for t in ins], _p(so), _p(v_shaped), _p(ws.clone()), _p(gv), _p(gvs),
+                                        _p(d_shape), _p(d_expr), _p(d_rot), _p(d_neck), _p(d_jaw), _p(d_eyes), _p(d_trans), _p(d_so),
+                                        _p(scratch), _stream(dev)), "gab_flame_backward")
+        sh = ctx.shapes
+        outs = [None, None if d_shape is None else d_shape.view(sh[0]), d_expr.view(sh[1]), d_rot.view(sh[2]), d_neck.view(sh[3]),
+                d_jaw.view(sh[4]), d_eyes.view(sh[5]), d_trans.view(sh[6]), None if d_so is None else d_so.view(ctx.so_shape)]
+        return tuple(outs)
+
+
+def flame_forward(head, shape, expr, rotation, neck, jaw, eyes, translation, static_offset=None):
+    """-> (verts (1,V,3), v_shaped (1,V,3)); FlameHead.forward with return_verts_cano=True."""
+    return _FlameForward.apply(head, shape, expr, rotation, neck, jaw, eyes, translation, static_offset)
+
+
+# -------------------------------------------------------------------------------------------------
+# per-face frames
+# -------------------------------------------------------------------------------------------------
+class _FaceFrames(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, faces):
+        lib = _lib.gab()
+        _need_cuda(verts, "verts")
+        dev = verts.device
+        v = _f32(verts)
+        fi, is64 = _idx(faces)
+        V, F = v.shape[0], fi.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        center, R = torch.empty((F, 3), **f32), torch.empty((F, 3, 3), **f32)
+        scale, quat = torch.empty((F, 1), **f32), torch.empty((F, 4), **f32)
+        with torch.cuda.device(dev):
+            _chk(lib.gab_face_frames_forward(V, F, _p(v), _p(fi), is64, _p(center), _p(R), _p(scale), _p(quat), _stream(dev)),
+                 "gab_face_frames_forward")
+        ctx.save_for_backward(v, fi)
+        ctx.is64 = is64
+        return center, R, scale, quat
+
+    @staticmethod
+    def backward(ctx, g_center, g_R, g_scale, g_quat):
+        lib = _lib.gab()
+        v, fi = ctx.saved_tensors
+        dev = v.device
+        V, F = v.shape[0], fi.shape[0]
+        d_verts = torch.empty((V, 3), dtype=torch.float32, device=dev)
+        gs = [None if g is None else _f32(g) for g in (g_center, g_R, g_scale, g_quat)]
+        with torch.cuda.device(dev):
+            _chk(lib.gab_face_frames_backward(V, F, _p(v), _p(fi), ctx.is64, _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(gs[3]), _p(d_verts),
+                                              _stream(dev)), "gab_face_frames_backward")
+        return d_verts, None
+
+
+def face_frames(verts, faces):
+    """verts (V,3), faces (F,3) -> face_center (F,3), face_orien_mat (F,3,3), face_scaling (F,1), face_orien_quat (F,4) WXYZ."""
+    return _FaceFrames.apply(verts, faces)
+
+
+# -------------------------------------------------------------------------------------------------
+# per-splat local -> world
+# -------------------------------------------------------------------------------------------------
+class _BindSplats(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, log_scaling, rotation, binding, face_R, face_scale, face_center, face_quat):
+        lib = _lib.gab()
+        _need_cuda(xyz, "_xyz")
+        dev = xyz.device
+        x, ls, q = _f32(xyz), _f32(log_scaling), _f32(rotation)
+        b, is64 = _idx(binding)
+        fR, fs, fc, fq = _f32(face_R), _f32(face_scale), _f32(face_center), _f32(face_quat)
+        N, F = x.shape[0], fc.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        ox, osc, oq = torch.empty((N, 3), **f32), torch.empty((N, 3), **f32), torch.empty((N, 4), **f32)
+        with torch.cuda.device(dev):
+            _chk(lib.gab_bind_forward(N, F, _p(x), _p(ls), _p(q), _p(b), is64, _p(fc), _p(fR), _p(fs), _p(fq), _p(ox), _p(osc), _p(oq),
+                                      _stream(dev)), "gab_bind_forward")
+        ctx.save_for_backward(x, ls, q, b, fR, fs, fc, fq)
+        ctx.is64 = is64
+        return ox, osc, oq
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_scaling, g_rot):
+        lib = _lib.gab()
+        x, ls, q, b, fR, fs, fc, fq = ctx.saved_tensors
+        dev = x.device
+        N, F = x.shape[0], fc.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        d_x, d_ls, d_q = torch.empty((N, 3), **f32), torch.empty((N, 3), **f32), torch.empty((N, 4), **f32)
+        d_face = torch.empty((F, 17), **f32)
+        gs = [None if g is None else _f32(g) for g in (g_xyz, g_scaling, g_rot)]
+        with torch.cuda.device(dev):
+            _chk(lib.gab_bind_backward(N, F, _p(x), _p(ls), _p(q), _p(b), ctx.is64, _p(fc), _p(fR), _p(fs), _p(fq), _p(gs[0]), _p(gs[1]),
+                                       _p(gs[2]), _p(d_x), _p(d_ls), _p(d_q), _p(d_face), _stream(dev)), "gab_bind_backward")
+        return (d_x, d_ls, d_q, None, d_face[:, 3:12].reshape(F, 3, 3), d_face[:, 12:13], d_face[:, 0:3], d_face[:, 13:17])
+
+
+def bind_splats(xyz, log_scaling, rotation, binding, face_R, face_scale, face_center, face_quat):
+    """-> (get_xyz, get_scaling, get_rotation) of a mesh-bound GaussianModel, in one kernel."""
+    return _BindSplats.apply(xyz, log_scaling, rotation, binding, face_R, face_scale, face_center, face_quat)

@@ -1,0 +1,802 @@
+// gab_kernels.hip -- fused HIP kernels (gfx950, wave64) + C ABI (include/gab.h) for the FLAME-rigged
+// binding half of the GaussianAvatars hot path.  The reference executes this half as ~200 ATen
+// launches per frame; here it is 3 (FLAME) + 1 (face frames) + 1 (splats) launches forward and
+// 3 + 1 + 1 backward.  Every stage is HBM-/latency-bound (no GEMM-shaped work at batch 1 except
+// the 24.7 MB blend-shape GEMV, which is a pure streaming read), so the kernels are plain
+// coalesced VALU code: one wave per blend-shape row, one thread per vertex / face / splat.
+//
+// Reference semantics restated here (file:line relative to /root/reference):
+//   flame_model/flame.py:511-536, flame_model/lbs.py:25-57,101-195,218-304,
+//   utils/graphics_utils.py:90-135, scene/flame_gaussian_model.py:137-154,
+//   scene/gaussian_model.py:113-150, roma rotmat_to_unitquat / quat_product.
+#include <hip/hip_runtime.h>
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/gab.h"
+
+namespace gab {
+
+struct Rig {
+    int V, n_shape, n_expr;
+    const float* __restrict__ v_template;
+    const float* __restrict__ shapedirs;
+    const float* __restrict__ posedirs;
+    const float* __restrict__ J_regressor;
+    const float* __restrict__ lbs_weights;
+    int parents[GAB_NUM_JOINTS];
+};
+
+// workspace offsets (floats)
+constexpr int WS_J = 0;      // 15
+constexpr int WS_R = 16;     // 45
+constexpr int WS_PF = 64;    // 36
+constexpr int WS_A = 128;    // 60  A[j][r*4+c]
+constexpr int WS_DA = 256;   // 60
+constexpr int WS_DT = 320;   // 3
+constexpr int WS_DPF = 324;  // 36
+constexpr int WS_DJ = 384;   // 15
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// 64-lane sum; the result is valid in lanes 48..63
+__device__ __forceinline__ float wave_sum_hi(float v)
+{
+    v += dpp_f<0xB1, 0xf>(v);
+    v += dpp_f<0x4E, 0xf>(v);
+    v += dpp_f<0x141, 0xf>(v);
+    v += dpp_f<0x140, 0xf>(v);
+    v += dpp_f<0x142, 0xa>(v);
+    v += dpp_f<0x143, 0xc>(v);
+    return v;
+}
+
+__device__ __forceinline__ float beta_at(const float* shape, const float* expr, int n_shape, int l)
+{
+    return l < n_shape ? shape[l] : expr[l - n_shape];
+}
+
+// ---------------------------------------------------------------------------------------------
+// F1  v_shaped = v_template + shapedirs . [shape|expr] (+ static_offset): one wave per row of betas
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blend(Rig rig, const float* __restrict__ shape, const float* __restrict__ expr,
+                                                const float* __restrict__ static_offset, float* __restrict__ v_shaped)
+{
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int E = 3 * rig.V;
+    if (e >= E) return;
+    const int NB = rig.n_shape + rig.n_expr;
+    const float* row = rig.shapedirs + (size_t)e * NB;
+    float acc = 0.f;
+    if ((NB & 3) == 0 && (rig.n_shape & 3) == 0) {
+        const float4* row4 = reinterpret_cast<const float4*>(row);
+        for (int c = lane; c < NB / 4; c += 64) {
+            const float4 r = row4[c];
+            const int l = 4 * c;
+            const float4 b = l < rig.n_shape ? reinterpret_cast<const float4*>(shape)[c]
+                                             : reinterpret_cast<const float4*>(expr)[c - rig.n_shape / 4];
+            acc += r.x * b.x + r.y * b.y + r.z * b.z + r.w * b.w;
+        }
+    } else {
+        for (int l = lane; l < NB; l += 64) acc += row[l] * beta_at(shape, expr, rig.n_shape, l);
+    }
+    acc = wave_sum_hi(acc);
+    if (lane == 63) v_shaped[e] = rig.v_template[e] + acc + (static_offset ? static_offset[e] : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// small dense helpers for the 5-joint chain (thread-serial; 5 joints)
+// ---------------------------------------------------------------------------------------------
+__device__ inline void rodrigues(const float* r, float* R /*9*/)
+{
+    const float ux = r[0] + 1e-8f, uy = r[1] + 1e-8f, uz = r[2] + 1e-8f;   // epsilon on the vector, then the norm
+    const float th = sqrtf(ux * ux + uy * uy + uz * uz);
+    const float dx = r[0] / th, dy = r[1] / th, dz = r[2] / th;
+    const float s = sinf(th), c = cosf(th);
+    const float K[9] = {0.f, -dz, dy, dz, 0.f, -dx, -dy, dx, 0.f};
+    float KK[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) KK[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+    for (int i = 0; i < 9; ++i) R[i] = ((i % 4) == 0 ? 1.f : 0.f) + s * K[i] + (1.f - c) * KK[i];
+}
+
+// gradient of rodrigues w.r.t. the axis-angle vector
+__device__ inline void rodrigues_bwd(const float* r, const float* dR /*9*/, float* dr /*3*/)
+{
+    const float u[3] = {r[0] + 1e-8f, r[1] + 1e-8f, r[2] + 1e-8f};
+    const float th = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    const float d[3] = {r[0] / th, r[1] / th, r[2] / th};
+    const float s = sinf(th), c = cosf(th);
+    const float K[9] = {0.f, -d[2], d[1], d[2], 0.f, -d[0], -d[1], d[0], 0.f};
+    float KK[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) KK[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+    float g_s = 0.f, g_c = 0.f;
+    for (int i = 0; i < 9; ++i) { g_s += dR[i] * K[i]; g_c -= dR[i] * KK[i]; }
+    // dL/dK = s dR + (1-c) (dR K^T + K^T dR)
+    float dK[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < 3; ++k) {
+                a += dR[3 * i + k] * K[3 * j + k];   // dR K^T
+                b += K[3 * k + i] * dR[3 * k + j];   // K^T dR
+            }
+            dK[3 * i + j] = s * dR[3 * i + j] + (1.f - c) * (a + b);
+        }
+    const float gd[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
+    float g_th = g_s * c - g_c * s;
+    g_th -= (gd[0] * r[0] + gd[1] * r[1] + gd[2] * r[2]) / (th * th);
+    for (int k = 0; k < 3; ++k) dr[k] = gd[k] / th + g_th * u[k] / th;
+}
+
+// forward chain: G_i = G_parent [R_i | J_i - J_parent];  A_i = [Rg_i | tg_i - Rg_i J_i]
+__device__ inline void chain_forward(const int* parents, const float* R /*5x9*/, const float* J /*5x3*/, float* Rg /*5x9*/,
+                                     float* tg /*5x3*/)
+{
+    for (int i = 0; i < GAB_NUM_JOINTS; ++i) {
+        if (i == 0) {
+            for (int k = 0; k < 9; ++k) Rg[k] = R[k];
+            for (int k = 0; k < 3; ++k) tg[k] = J[k];
+            continue;
+        }
+        const int p = parents[i];
+        const float rel[3] = {J[3 * i] - J[3 * p], J[3 * i + 1] - J[3 * p + 1], J[3 * i + 2] - J[3 * p + 2]};
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c)
+                Rg[9 * i + 3 * r + c] = Rg[9 * p + 3 * r] * R[9 * i + c] + Rg[9 * p + 3 * r + 1] * R[9 * i + 3 + c] +
+                                        Rg[9 * p + 3 * r + 2] * R[9 * i + 6 + c];
+            tg[3 * i + r] = Rg[9 * p + 3 * r] * rel[0] + Rg[9 * p + 3 * r + 1] * rel[1] + Rg[9 * p + 3 * r + 2] * rel[2] + tg[3 * p + r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// F2  joints J = J_regressor . v_shaped (15 sums over V), Rodrigues, kinematic chain -> ws
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_joints_chain(Rig rig, const float* __restrict__ v_shaped, const float* __restrict__ rotation,
+                                                       const float* __restrict__ neck, const float* __restrict__ jaw,
+                                                       const float* __restrict__ eyes, float* __restrict__ ws)
+{
+    __shared__ float red[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float acc[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) acc[k] = 0.f;
+    for (int v = tid; v < rig.V; v += 256) {
+        const float x = v_shaped[3 * v], y = v_shaped[3 * v + 1], z = v_shaped[3 * v + 2];
+#pragma unroll
+        for (int j = 0; j < GAB_NUM_JOINTS; ++j) {
+            const float w = rig.J_regressor[(size_t)j * rig.V + v];
+            acc[3 * j] += w * x;
+            acc[3 * j + 1] += w * y;
+            acc[3 * j + 2] += w * z;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+        const float s = wave_sum_hi(acc[k]);
+        if (lane == 63) red[wid][k] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float J[15], R[45], Rg[45], tg[15];
+        for (int k = 0; k < 15; ++k) J[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        const float pose[15] = {rotation[0], rotation[1], rotation[2], neck[0], neck[1], neck[2], jaw[0], jaw[1], jaw[2],
+                                eyes[0], eyes[1], eyes[2], eyes[3], eyes[4], eyes[5]};
+        for (int j = 0; j < GAB_NUM_JOINTS; ++j) rodrigues(pose + 3 * j, R + 9 * j);
+        chain_forward(rig.parents, R, J, Rg, tg);
+        for (int k = 0; k < 15; ++k) ws[WS_J + k] = J[k];
+        for (int k = 0; k < 45; ++k) ws[WS_R + k] = R[k];
+        for (int j = 1; j < GAB_NUM_JOINTS; ++j)
+            for (int k = 0; k < 9; ++k) ws[WS_PF + 9 * (j - 1) + k] = R[9 * j + k] - ((k % 4) == 0 ? 1.f : 0.f);
+        for (int j = 0; j < GAB_NUM_JOINTS; ++j)
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) ws[WS_A + 12 * j + 4 * r + c] = Rg[9 * j + 3 * r + c];
+                ws[WS_A + 12 * j + 4 * r + 3] = tg[3 * j + r] - (Rg[9 * j + 3 * r] * J[3 * j] + Rg[9 * j + 3 * r + 1] * J[3 * j + 1] +
+                                                                 Rg[9 * j + 3 * r + 2] * J[3 * j + 2]);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// F3  per vertex: pose-corrective offsets, blended rigid transform, translation
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void vertex_posed_and_T(const Rig& rig, const float* __restrict__ ws, const float* __restrict__ v_shaped,
+                                                   int v, float* vp /*3*/, float* T /*12*/)
+{
+    const int E = 3 * rig.V;
+    float po[3] = {0.f, 0.f, 0.f};
+    for (int p = 0; p < GAB_POSE_FEATURES; ++p) {
+        const float f = ws[WS_PF + p];
+        const float* row = rig.posedirs + (size_t)p * E + 3 * v;
+        po[0] += f * row[0];
+        po[1] += f * row[1];
+        po[2] += f * row[2];
+    }
+    for (int k = 0; k < 3; ++k) vp[k] = po[k] + v_shaped[3 * v + k];
+    for (int k = 0; k < 12; ++k) T[k] = 0.f;
+    for (int j = 0; j < GAB_NUM_JOINTS; ++j) {
+        const float w = rig.lbs_weights[(size_t)v * GAB_NUM_JOINTS + j];
+        for (int k = 0; k < 12; ++k) T[k] += w * ws[WS_A + 12 * j + k];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_skin(Rig rig, const float* __restrict__ ws, const float* __restrict__ v_shaped,
+                                               const float* __restrict__ translation, float* __restrict__ verts)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= rig.V) return;
+    float vp[3], T[12];
+    vertex_posed_and_T(rig, ws, v_shaped, v, vp, T);
+    for (int r = 0; r < 3; ++r)
+        verts[3 * v + r] = T[4 * r] * vp[0] + T[4 * r + 1] * vp[1] + T[4 * r + 2] * vp[2] + T[4 * r + 3] + translation[r];
+}
+
+// ---------------------------------------------------------------------------------------------
+// B1  skinning backward: dL/dv_posed per vertex -> scratch; block-reduced sums for dA (60),
+//     d translation (3), d pose_feature (36) -> ws
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_skin_bwd(Rig rig, float* __restrict__ ws, const float* __restrict__ v_shaped,
+                                                   const float* __restrict__ dL_dverts, float* __restrict__ g_vs /*(V,3)*/)
+{
+    __shared__ float red[99];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 99) red[tid] = 0.f;
+    __syncthreads();
+    const int v = blockIdx.x * blockDim.x + tid;
+    const bool ok = v < rig.V;
+    const int E = 3 * rig.V;
+    float g[3] = {0.f, 0.f, 0.f}, vp[3] = {0.f, 0.f, 0.f}, T[12], gvp[3] = {0.f, 0.f, 0.f};
+    float w[GAB_NUM_JOINTS] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+        vertex_posed_and_T(rig, ws, v_shaped, v, vp, T);
+        for (int k = 0; k < 3; ++k) g[k] = dL_dverts[3 * v + k];
+        for (int c = 0; c < 3; ++c) gvp[c] = T[c] * g[0] + T[4 + c] * g[1] + T[8 + c] * g[2];
+        for (int k = 0; k < 3; ++k) g_vs[3 * v + k] = gvp[k];
+        for (int j = 0; j < GAB_NUM_JOINTS; ++j) w[j] = rig.lbs_weights[(size_t)v * GAB_NUM_JOINTS + j];
+    }
+    const float vph[4] = {vp[0], vp[1], vp[2], ok ? 1.f : 0.f};
+    // dA[j][r][c] += w_j g_r vph_c
+    for (int j = 0; j < GAB_NUM_JOINTS; ++j)
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c) {
+                const float s = wave_sum_hi(w[j] * g[r] * vph[c]);
+                if (lane == 63) atomicAdd(&red[12 * j + 4 * r + c], s);
+            }
+    for (int r = 0; r < 3; ++r) {
+        const float s = wave_sum_hi(g[r]);
+        if (lane == 63) atomicAdd(&red[60 + r], s);
+    }
+    for (int p = 0; p < GAB_POSE_FEATURES; ++p) {
+        float x = 0.f;
+        if (ok) {
+            const float* row = rig.posedirs + (size_t)p * E + 3 * v;
+            x = row[0] * gvp[0] + row[1] * gvp[1] + row[2] * gvp[2];
+        }
+        const float s = wave_sum_hi(x);
+        if (lane == 63) atomicAdd(&red[63 + p], s);
+    }
+    __syncthreads();
+    if (tid < 60) unsafeAtomicAdd(&ws[WS_DA + tid], red[tid]);
+    else if (tid < 63) unsafeAtomicAdd(&ws[WS_DT + tid - 60], red[tid]);
+    else if (tid < 99) unsafeAtomicAdd(&ws[WS_DPF + tid - 63], red[tid]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// B2  chain backward (one thread; 5 joints): dA, d pose_feature -> d pose (15), dJ (15)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_chain_bwd(Rig rig, float* __restrict__ ws, const float* __restrict__ rotation, const float* __restrict__ neck,
+                            const float* __restrict__ jaw, const float* __restrict__ eyes, float* __restrict__ d_rotation,
+                            float* __restrict__ d_neck, float* __restrict__ d_jaw, float* __restrict__ d_eyes,
+                            float* __restrict__ d_translation)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float J[15], R[45], Rg[45], tg[15];
+    for (int k = 0; k < 15; ++k) J[k] = ws[WS_J + k];
+    for (int k = 0; k < 45; ++k) R[k] = ws[WS_R + k];
+    chain_forward(rig.parents, R, J, Rg, tg);
+    float dRg[45], dtg[15], dJ[15], dR[45];
+    for (int k = 0; k < 45; ++k) { dRg[k] = 0.f; dR[k] = 0.f; }
+    for (int k = 0; k < 15; ++k) { dtg[k] = 0.f; dJ[k] = 0.f; }
+    // A_i = [Rg_i | tg_i - Rg_i J_i]
+    for (int i = 0; i < GAB_NUM_JOINTS; ++i) {
+        const float* dA = ws + WS_DA + 12 * i;
+        for (int r = 0; r < 3; ++r) {
+            const float dAt = dA[4 * r + 3];
+            for (int c = 0; c < 3; ++c) {
+                dRg[9 * i + 3 * r + c] += dA[4 * r + c] - dAt * J[3 * i + c];
+                dJ[3 * i + c] -= Rg[9 * i + 3 * r + c] * dAt;
+            }
+            dtg[3 * i + r] += dAt;
+        }
+    }
+    for (int i = GAB_NUM_JOINTS - 1; i >= 1; --i) {
+        const int p = rig.parents[i];
+        const float rel[3] = {J[3 * i] - J[3 * p], J[3 * i + 1] - J[3 * p + 1], J[3 * i + 2] - J[3 * p + 2]};
+        float drel[3] = {0.f, 0.f, 0.f};
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) {
+                dRg[9 * p + 3 * r + c] += dtg[3 * i + r] * rel[c];
+                drel[c] += Rg[9 * p + 3 * r + c] * dtg[3 * i + r];
+            }
+            dtg[3 * p + r] += dtg[3 * i + r];
+        }
+        for (int c = 0; c < 3; ++c) { dJ[3 * i + c] += drel[c]; dJ[3 * p + c] -= drel[c]; }
+        // Rg_i = Rg_p R_i
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                float a = 0.f, b = 0.f;
+                for (int k = 0; k < 3; ++k) {
+                    a += dRg[9 * i + 3 * r + k] * R[9 * i + 3 * c + k];      // dRg_i R_i^T
+                    b += Rg[9 * p + 3 * k + r] * dRg[9 * i + 3 * k + c];     // Rg_p^T dRg_i
+                }
+                dRg[9 * p + 3 * r + c] += a;
+                dR[9 * i + 3 * r + c] += b;
+            }
+    }
+    for (int k = 0; k < 9; ++k) dR[k] += dRg[k];
+    for (int c = 0; c < 3; ++c) dJ[c] += dtg[c];
+    for (int j = 1; j < GAB_NUM_JOINTS; ++j)
+        for (int k = 0; k < 9; ++k) dR[9 * j + k] += ws[WS_DPF + 9 * (j - 1) + k];
+    const float pose[15] = {rotation[0], rotation[1], rotation[2], neck[0], neck[1], neck[2], jaw[0], jaw[1], jaw[2],
+                            eyes[0], eyes[1], eyes[2], eyes[3], eyes[4], eyes[5]};
+    float dpose[15];
+    for (int j = 0; j < GAB_NUM_JOINTS; ++j) rodrigues_bwd(pose + 3 * j, dR + 9 * j, dpose + 3 * j);
+    for (int k = 0; k < 3; ++k) {
+        d_rotation[k] = dpose[k];
+        d_neck[k] = dpose[3 + k];
+        d_jaw[k] = dpose[6 + k];
+        d_translation[k] = ws[WS_DT + k];
+    }
+    for (int k = 0; k < 6; ++k) d_eyes[k] = dpose[9 + k];
+    for (int k = 0; k < 15; ++k) ws[WS_DJ + k] = dJ[k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// B3  blend backward: g_total = dL/dv_posed + J_regressor^T dJ (+ external dL/dv_shaped);
+//     d static_offset = g_total; d betas = shapedirs^T g_total (64 rows per workgroup)
+// ---------------------------------------------------------------------------------------------
+#define GAB_BLEND_BWD_ROWS 64
+__global__ __launch_bounds__(256) void k_blend_bwd(Rig rig, const float* __restrict__ ws, const float* __restrict__ g_vs,
+                                                    const float* __restrict__ dL_dv_shaped, float* __restrict__ d_static_offset,
+                                                    float* __restrict__ d_shape, float* __restrict__ d_expr)
+{
+    __shared__ float g[GAB_BLEND_BWD_ROWS];
+    const int tid = threadIdx.x;
+    const int E = 3 * rig.V;
+    const int e0 = blockIdx.x * GAB_BLEND_BWD_ROWS;
+    if (tid < GAB_BLEND_BWD_ROWS) {
+        const int e = e0 + tid;
+        float x = 0.f;
+        if (e < E) {
+            const int v = e / 3, k = e - 3 * v;
+            x = g_vs[e];
+            for (int j = 0; j < GAB_NUM_JOINTS; ++j) x += rig.J_regressor[(size_t)j * rig.V + v] * ws[WS_DJ + 3 * j + k];
+            if (dL_dv_shaped) x += dL_dv_shaped[e];
+            if (d_static_offset) d_static_offset[e] = x;
+        }
+        g[tid] = x;
+    }
+    __syncthreads();
+    const int NB = rig.n_shape + rig.n_expr;
+    const int rows = min(GAB_BLEND_BWD_ROWS, E - e0);
+    for (int l = tid; l < NB; l += 256) {
+        float* dst = l < rig.n_shape ? (d_shape ? d_shape + l : nullptr) : d_expr + (l - rig.n_shape);
+        if (!dst) continue;   // shape is not optimised by the reference: skip 3/4 of the stream
+        float acc = 0.f;
+        const float* col = rig.shapedirs + (size_t)e0 * NB + l;
+        for (int r = 0; r < rows; ++r) acc += col[(size_t)r * NB] * g[r];
+        unsafeAtomicAdd(dst, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-face frames
+// ---------------------------------------------------------------------------------------------
+struct Vec3 { float x, y, z; };
+__device__ __forceinline__ Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ Vec3 operator+(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ Vec3 operator*(Vec3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ Vec3 cross(Vec3 a, Vec3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ Vec3 ld3(const float* p, long long i) { return {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+
+__device__ __forceinline__ long long index_at(const void* idx, int is64, long long i)
+{
+    return is64 ? ((const long long*)idx)[i] : (long long)((const int*)idx)[i];
+}
+
+struct Frame {
+    Vec3 e1, e2, a0, a1, a2, n, m;
+    float l1, ln, lm, d;
+    bool c1, cn, cm;  // clamp active
+};
+__device__ __forceinline__ Frame make_frame(Vec3 v0, Vec3 v1, Vec3 v2)
+{
+    Frame f;
+    const float eps = 1e-20f;
+    f.e1 = v1 - v0;
+    f.e2 = v2 - v0;
+    float q = dot(f.e1, f.e1);
+    f.c1 = q < eps; f.l1 = sqrtf(f.c1 ? eps : q);
+    f.a0 = f.e1 * (1.f / f.l1);
+    f.n = cross(f.a0, f.e2);
+    q = dot(f.n, f.n);
+    f.cn = q < eps; f.ln = sqrtf(f.cn ? eps : q);
+    f.a1 = f.n * (1.f / f.ln);
+    f.m = cross(f.a1, f.a0);
+    q = dot(f.m, f.m);
+    f.cm = q < eps; f.lm = sqrtf(f.cm ? eps : q);
+    f.a2 = f.m * (-1.f / f.lm);
+    f.d = dot(f.a2, f.e2);
+    return f;
+}
+
+// R (row-major, columns a0 a1 a2) -> unnormalised XYZW quaternion + branch (SciPy/roma algorithm)
+__device__ __forceinline__ int quat_raw(const float* R, float* q)
+{
+    const float tr = R[0] + R[4] + R[8];
+    const float dec[4] = {R[0], R[4], R[8], tr};
+    int c = 0;
+    for (int k = 1; k < 4; ++k) if (dec[k] > dec[c]) c = k;
+    if (c < 3) {
+        const int i = c, j = (i + 1) % 3, k = (j + 1) % 3;
+        q[i] = 1.f - tr + 2.f * R[4 * i];
+        q[j] = R[3 * j + i] + R[3 * i + j];
+        q[k] = R[3 * k + i] + R[3 * i + k];
+        q[3] = R[3 * k + j] - R[3 * j + k];
+    } else {
+        q[0] = R[7] - R[5];
+        q[1] = R[2] - R[6];
+        q[2] = R[3] - R[1];
+        q[3] = 1.f + tr;
+    }
+    return c;
+}
+
+__global__ __launch_bounds__(256) void k_face_frames(int F, const float* __restrict__ verts, const void* __restrict__ faces, int is64,
+                                                      float* __restrict__ center, float* __restrict__ Rm, float* __restrict__ scaling,
+                                                      float* __restrict__ quat)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const Vec3 v0 = ld3(verts, index_at(faces, is64, 3ll * f)), v1 = ld3(verts, index_at(faces, is64, 3ll * f + 1)),
+               v2 = ld3(verts, index_at(faces, is64, 3ll * f + 2));
+    const Frame fr = make_frame(v0, v1, v2);
+    const Vec3 c = (v0 + v1 + v2) * (1.f / 3.f);
+    center[3 * f] = c.x; center[3 * f + 1] = c.y; center[3 * f + 2] = c.z;
+    const float R[9] = {fr.a0.x, fr.a1.x, fr.a2.x, fr.a0.y, fr.a1.y, fr.a2.y, fr.a0.z, fr.a1.z, fr.a2.z};
+    for (int k = 0; k < 9; ++k) Rm[9 * f + k] = R[k];
+    scaling[f] = (fr.l1 + fabsf(fr.d)) * 0.5f;
+    float q[4];
+    quat_raw(R, q);
+    const float inv = 1.f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    quat[4 * f] = q[3] * inv;       // WXYZ
+    quat[4 * f + 1] = q[0] * inv;
+    quat[4 * f + 2] = q[1] * inv;
+    quat[4 * f + 3] = q[2] * inv;
+}
+
+__device__ __forceinline__ Vec3 unit_bwd(Vec3 g_unit, Vec3 unit, float len, bool clamped)
+{
+    // y = x / len(x): dL/dx = (g - y (y.g)) / len; with the clamp active len is a constant
+    if (clamped) return g_unit * (1.f / len);
+    return (g_unit - unit * dot(unit, g_unit)) * (1.f / len);
+}
+
+__global__ __launch_bounds__(256) void k_face_frames_bwd(int F, const float* __restrict__ verts, const void* __restrict__ faces, int is64,
+                                                          const float* __restrict__ d_center, const float* __restrict__ d_R,
+                                                          const float* __restrict__ d_scaling, const float* __restrict__ d_quat,
+                                                          float* __restrict__ d_verts)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const long long i0 = index_at(faces, is64, 3ll * f), i1 = index_at(faces, is64, 3ll * f + 1), i2 = index_at(faces, is64, 3ll * f + 2);
+    const Vec3 v0 = ld3(verts, i0), v1 = ld3(verts, i1), v2 = ld3(verts, i2);
+    const Frame fr = make_frame(v0, v1, v2);
+    const float R[9] = {fr.a0.x, fr.a1.x, fr.a2.x, fr.a0.y, fr.a1.y, fr.a2.y, fr.a0.z, fr.a1.z, fr.a2.z};
+    float gR[9];
+    for (int k = 0; k < 9; ++k) gR[k] = d_R ? d_R[9 * f + k] : 0.f;
+    if (d_quat) {
+        float q[4];
+        const int c = quat_raw(R, q);
+        const float len = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        const float qn[4] = {q[0] / len, q[1] / len, q[2] / len, q[3] / len};
+        const float g[4] = {d_quat[4 * f + 1], d_quat[4 * f + 2], d_quat[4 * f + 3], d_quat[4 * f]};   // WXYZ -> XYZW
+        const float gd = qn[0] * g[0] + qn[1] * g[1] + qn[2] * g[2] + qn[3] * g[3];
+        float gq[4];
+        for (int k = 0; k < 4; ++k) gq[k] = (g[k] - qn[k] * gd) / len;
+        if (c < 3) {
+            const int i = c, j = (i + 1) % 3, k = (j + 1) % 3;
+            gR[0] -= gq[i]; gR[4] -= gq[i]; gR[8] -= gq[i];
+            gR[4 * i] += 2.f * gq[i];
+            gR[3 * j + i] += gq[j]; gR[3 * i + j] += gq[j];
+            gR[3 * k + i] += gq[k]; gR[3 * i + k] += gq[k];
+            gR[3 * k + j] += gq[3]; gR[3 * j + k] -= gq[3];
+        } else {
+            gR[7] += gq[0]; gR[5] -= gq[0];
+            gR[2] += gq[1]; gR[6] -= gq[1];
+            gR[3] += gq[2]; gR[1] -= gq[2];
+            gR[0] += gq[3]; gR[4] += gq[3]; gR[8] += gq[3];
+        }
+    }
+    Vec3 g_a0 = {gR[0], gR[3], gR[6]}, g_a1 = {gR[1], gR[4], gR[7]}, g_a2 = {gR[2], gR[5], gR[8]};
+    Vec3 g_e2 = {0.f, 0.f, 0.f};
+    float g_l1 = 0.f;
+    if (d_scaling) {
+        const float gs = d_scaling[f] * 0.5f;
+        g_l1 = gs;
+        const float sg = fr.d > 0.f ? 1.f : (fr.d < 0.f ? -1.f : 0.f);
+        g_a2 = g_a2 + fr.e2 * (gs * sg);
+        g_e2 = g_e2 + fr.a2 * (gs * sg);
+    }
+    // a2 = -(m / |m|)
+    const Vec3 u = fr.a2 * -1.f;
+    const Vec3 g_m = unit_bwd(g_a2 * -1.f, u, fr.lm, fr.cm);
+    // m = a1 x a0
+    g_a1 = g_a1 + cross(fr.a0, g_m);
+    g_a0 = g_a0 + cross(g_m, fr.a1);
+    // a1 = n / |n|,  n = a0 x e2
+    const Vec3 g_n = unit_bwd(g_a1, fr.a1, fr.ln, fr.cn);
+    g_a0 = g_a0 + cross(fr.e2, g_n);
+    g_e2 = g_e2 + cross(g_n, fr.a0);
+    // a0 = e1 / |e1|, l1 = |e1|
+    Vec3 g_e1 = unit_bwd(g_a0, fr.a0, fr.l1, fr.c1);
+    if (!fr.c1) g_e1 = g_e1 + fr.a0 * g_l1;
+    Vec3 gc = {0.f, 0.f, 0.f};
+    if (d_center) gc = Vec3{d_center[3 * f], d_center[3 * f + 1], d_center[3 * f + 2]} * (1.f / 3.f);
+    const Vec3 g0 = gc - g_e1 - g_e2, g1 = gc + g_e1, g2 = gc + g_e2;
+    unsafeAtomicAdd(&d_verts[3 * i0], g0.x); unsafeAtomicAdd(&d_verts[3 * i0 + 1], g0.y); unsafeAtomicAdd(&d_verts[3 * i0 + 2], g0.z);
+    unsafeAtomicAdd(&d_verts[3 * i1], g1.x); unsafeAtomicAdd(&d_verts[3 * i1 + 1], g1.y); unsafeAtomicAdd(&d_verts[3 * i1 + 2], g1.z);
+    unsafeAtomicAdd(&d_verts[3 * i2], g2.x); unsafeAtomicAdd(&d_verts[3 * i2 + 1], g2.y); unsafeAtomicAdd(&d_verts[3 * i2 + 2], g2.z);
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-splat mesh-local -> world (get_xyz, get_scaling, get_rotation in one pass)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 qmul(float4 a, float4 b)   // Hamilton product, WXYZ in .x.y.z.w
+{
+    return make_float4(a.x * b.x - a.y * b.y - a.z * b.z - a.w * b.w,
+                       a.x * b.y + b.x * a.y + (a.z * b.w - a.w * b.z),
+                       a.x * b.z + b.x * a.z + (a.w * b.y - a.y * b.w),
+                       a.x * b.w + b.x * a.w + (a.y * b.z - a.z * b.y));
+}
+__device__ __forceinline__ float4 qconj(float4 a) { return make_float4(a.x, -a.y, -a.z, -a.w); }
+__device__ __forceinline__ float qnorm_clamped(float4 q) { const float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w); return n > 1e-12f ? n : 1e-12f; }
+
+__global__ __launch_bounds__(256) void k_bind(int N, const float* __restrict__ xyz, const float* __restrict__ log_scaling,
+                                               const float* __restrict__ rotation, const void* __restrict__ binding, int is64,
+                                               const float* __restrict__ fc, const float* __restrict__ fR, const float* __restrict__ fs,
+                                               const float* __restrict__ fq, float* __restrict__ out_xyz, float* __restrict__ out_scaling,
+                                               float* __restrict__ out_rotation)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const long long f = index_at(binding, is64, i);
+    const float s = fs[f];
+    const float* R = fR + 9 * f;
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    for (int r = 0; r < 3; ++r) out_xyz[3 * i + r] = (R[3 * r] * x + R[3 * r + 1] * y + R[3 * r + 2] * z) * s + fc[3 * f + r];
+    for (int k = 0; k < 3; ++k) out_scaling[3 * i + k] = expf(log_scaling[3 * i + k]) * s;
+    const float4 qf = reinterpret_cast<const float4*>(fq)[f];
+    const float4 q = reinterpret_cast<const float4*>(rotation)[i];
+    const float na = 1.f / qnorm_clamped(qf), nb = 1.f / qnorm_clamped(q);
+    const float4 a = make_float4(qf.x * na, qf.y * na, qf.z * na, qf.w * na);
+    const float4 b = make_float4(q.x * nb, q.y * nb, q.z * nb, q.w * nb);
+    reinterpret_cast<float4*>(out_rotation)[i] = qmul(a, b);
+}
+
+__global__ __launch_bounds__(256) void k_bind_bwd(int N, const float* __restrict__ xyz, const float* __restrict__ log_scaling,
+                                                   const float* __restrict__ rotation, const void* __restrict__ binding, int is64,
+                                                   const float* __restrict__ fR, const float* __restrict__ fs, const float* __restrict__ fq,
+                                                   const float* __restrict__ g_xyz, const float* __restrict__ g_scaling,
+                                                   const float* __restrict__ g_rot, float* __restrict__ d_xyz,
+                                                   float* __restrict__ d_log_scaling, float* __restrict__ d_rotation, float* __restrict__ d_face)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const long long f = index_at(binding, is64, i);
+    const float s = fs[f];
+    const float* R = fR + 9 * f;
+    float* df = d_face + 17 * f;
+    float ds = 0.f;
+    const float x[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    const float gx[3] = {g_xyz ? g_xyz[3 * i] : 0.f, g_xyz ? g_xyz[3 * i + 1] : 0.f, g_xyz ? g_xyz[3 * i + 2] : 0.f};
+    for (int c = 0; c < 3; ++c) d_xyz[3 * i + c] = s * (R[c] * gx[0] + R[3 + c] * gx[1] + R[6 + c] * gx[2]);
+    if (g_xyz) {
+        for (int r = 0; r < 3; ++r) {
+            unsafeAtomicAdd(&df[r], gx[r]);
+            const float rx = R[3 * r] * x[0] + R[3 * r + 1] * x[1] + R[3 * r + 2] * x[2];
+            ds += gx[r] * rx;
+            for (int c = 0; c < 3; ++c) unsafeAtomicAdd(&df[3 + 3 * r + c], s * gx[r] * x[c]);
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        const float e = expf(log_scaling[3 * i + k]);
+        const float g = g_scaling ? g_scaling[3 * i + k] : 0.f;
+        d_log_scaling[3 * i + k] = g * e * s;
+        ds += g * e;
+    }
+    unsafeAtomicAdd(&df[12], ds);
+    const float4 qf = reinterpret_cast<const float4*>(fq)[f];
+    const float4 q = reinterpret_cast<const float4*>(rotation)[i];
+    const float na = qnorm_clamped(qf), nb = qnorm_clamped(q);
+    const float4 a = make_float4(qf.x / na, qf.y / na, qf.z / na, qf.w / na);
+    const float4 b = make_float4(q.x / nb, q.y / nb, q.z / nb, q.w / nb);
+    const float4 g = g_rot ? reinterpret_cast<const float4*>(g_rot)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 da = qmul(g, qconj(b));   // <g, a*b> = <g*conj(b), a>
+    const float4 db = qmul(qconj(a), g);   //           = <conj(a)*g, b>
+    const float ada = a.x * da.x + a.y * da.y + a.z * da.z + a.w * da.w;
+    const float bdb = b.x * db.x + b.y * db.y + b.z * db.z + b.w * db.w;
+    reinterpret_cast<float4*>(d_rotation)[i] = make_float4((db.x - b.x * bdb) / nb, (db.y - b.y * bdb) / nb, (db.z - b.z * bdb) / nb, (db.w - b.w * bdb) / nb);
+    if (g_rot) {
+        unsafeAtomicAdd(&df[13], (da.x - a.x * ada) / na);
+        unsafeAtomicAdd(&df[14], (da.y - a.y * ada) / na);
+        unsafeAtomicAdd(&df[15], (da.z - a.z * ada) / na);
+        unsafeAtomicAdd(&df[16], (da.w - a.w * ada) / na);
+    }
+}
+
+}  // namespace gab
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+namespace {
+thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return fail(GAB_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));     \
+    } while (0)
+#define LAUNCH_CHECK(name)                                                                               \
+    do {                                                                                                 \
+        hipError_t e_ = hipGetLastError();                                                               \
+        if (e_ != hipSuccess) return fail(GAB_E_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+int to_rig(const GabRig* r, gab::Rig* o)
+{
+    if (!r) return fail(GAB_E_ARG, "rig is NULL");
+    if (r->V <= 0 || r->n_shape < 0 || r->n_expr < 0 || r->n_shape + r->n_expr <= 0) return fail(GAB_E_ARG, "bad rig sizes");
+    if (!r->v_template || !r->shapedirs || !r->posedirs || !r->J_regressor || !r->lbs_weights) return fail(GAB_E_ARG, "NULL rig buffer");
+    if (r->parents[0] != -1) return fail(GAB_E_ARG, "parents[0] must be -1");
+    for (int i = 1; i < GAB_NUM_JOINTS; ++i)
+        if (r->parents[i] < 0 || r->parents[i] >= i) return fail(GAB_E_ARG, "parents must be topologically ordered");
+    o->V = r->V; o->n_shape = r->n_shape; o->n_expr = r->n_expr;
+    o->v_template = r->v_template; o->shapedirs = r->shapedirs; o->posedirs = r->posedirs;
+    o->J_regressor = r->J_regressor; o->lbs_weights = r->lbs_weights;
+    for (int i = 0; i < GAB_NUM_JOINTS; ++i) o->parents[i] = r->parents[i];
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int gab_abi_version(void) { return GAB_ABI_VERSION; }
+const char* gab_last_error(void) { return g_err; }
+
+int gab_flame_forward(const GabRig* rig_, const float* shape, const float* expr, const float* rotation, const float* neck,
+                      const float* jaw, const float* eyes, const float* translation, const float* static_offset, float* verts,
+                      float* v_shaped, float* ws, void* stream_)
+{
+    gab::Rig rig;
+    if (int rc = to_rig(rig_, &rig)) return rc;
+    if ((rig.n_shape && !shape) || (rig.n_expr && !expr) || !rotation || !neck || !jaw || !eyes || !translation || !verts || !v_shaped || !ws)
+        return fail(GAB_E_ARG, "gab_flame_forward: NULL buffer");
+    hipStream_t st = (hipStream_t)stream_;
+    const int E = 3 * rig.V;
+    hipLaunchKernelGGL(gab::k_blend, dim3((E + 3) / 4), dim3(256), 0, st, rig, shape, expr, static_offset, v_shaped);
+    LAUNCH_CHECK("k_blend");
+    hipLaunchKernelGGL(gab::k_joints_chain, dim3(1), dim3(256), 0, st, rig, (const float*)v_shaped, rotation, neck, jaw, eyes, ws);
+    LAUNCH_CHECK("k_joints_chain");
+    hipLaunchKernelGGL(gab::k_skin, dim3((rig.V + 255) / 256), dim3(256), 0, st, rig, (const float*)ws, (const float*)v_shaped, translation, verts);
+    LAUNCH_CHECK("k_skin");
+    return GAB_OK;
+}
+
+int gab_flame_backward(const GabRig* rig_, const float* shape, const float* expr, const float* rotation, const float* neck,
+                       const float* jaw, const float* eyes, const float* translation, const float* static_offset,
+                       const float* v_shaped, float* ws, const float* dL_dverts, const float* dL_dv_shaped, float* d_shape,
+                       float* d_expr, float* d_rotation, float* d_neck, float* d_jaw, float* d_eyes, float* d_translation,
+                       float* d_static_offset, float* scratch, void* stream_)
+{
+    (void)shape; (void)expr; (void)translation; (void)static_offset;
+    gab::Rig rig;
+    if (int rc = to_rig(rig_, &rig)) return rc;
+    if (!rotation || !neck || !jaw || !eyes || !v_shaped || !ws || !dL_dverts || !d_expr || !d_rotation || !d_neck || !d_jaw || !d_eyes ||
+        !d_translation || !scratch)
+        return fail(GAB_E_ARG, "gab_flame_backward: NULL buffer");
+    hipStream_t st = (hipStream_t)stream_;
+    const int E = 3 * rig.V;
+    HIP_TRY(hipMemsetAsync(ws + gab::WS_DA, 0, (gab::WS_DJ + 15 - gab::WS_DA) * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(d_expr, 0, (size_t)rig.n_expr * sizeof(float), st));
+    if (d_shape) HIP_TRY(hipMemsetAsync(d_shape, 0, (size_t)rig.n_shape * sizeof(float), st));
+    hipLaunchKernelGGL(gab::k_skin_bwd, dim3((rig.V + 255) / 256), dim3(256), 0, st, rig, ws, v_shaped, dL_dverts, scratch);
+    LAUNCH_CHECK("k_skin_bwd");
+    hipLaunchKernelGGL(gab::k_chain_bwd, dim3(1), dim3(64), 0, st, rig, ws, rotation, neck, jaw, eyes, d_rotation, d_neck, d_jaw, d_eyes, d_translation);
+    LAUNCH_CHECK("k_chain_bwd");
+    hipLaunchKernelGGL(gab::k_blend_bwd, dim3((E + GAB_BLEND_BWD_ROWS - 1) / GAB_BLEND_BWD_ROWS), dim3(256), 0, st, rig, (const float*)ws,
+                       (const float*)scratch, dL_dv_shaped, d_static_offset, d_shape, d_expr);
+    LAUNCH_CHECK("k_blend_bwd");
+    return GAB_OK;
+}
+
+int gab_face_frames_forward(int32_t V, int32_t F, const float* verts, const void* faces, int32_t is64, float* center, float* orien_mat,
+                            float* scaling, float* orien_quat, void* stream_)
+{
+    if (V <= 0 || F < 0) return fail(GAB_E_ARG, "bad sizes");
+    if (F == 0) return GAB_OK;
+    if (!verts || !faces || !center || !orien_mat || !scaling || !orien_quat) return fail(GAB_E_ARG, "gab_face_frames_forward: NULL buffer");
+    hipLaunchKernelGGL(gab::k_face_frames, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream_, F, verts, faces, is64, center, orien_mat,
+                       scaling, orien_quat);
+    LAUNCH_CHECK("k_face_frames");
+    return GAB_OK;
+}
+
+int gab_face_frames_backward(int32_t V, int32_t F, const float* verts, const void* faces, int32_t is64, const float* d_center,
+                             const float* d_orien_mat, const float* d_scaling, const float* d_orien_quat, float* d_verts, void* stream_)
+{
+    if (V <= 0 || F < 0) return fail(GAB_E_ARG, "bad sizes");
+    if (!d_verts) return fail(GAB_E_ARG, "d_verts is NULL");
+    hipStream_t st = (hipStream_t)stream_;
+    HIP_TRY(hipMemsetAsync(d_verts, 0, (size_t)V * 3 * sizeof(float), st));
+    if (F == 0) return GAB_OK;
+    if (!verts || !faces) return fail(GAB_E_ARG, "gab_face_frames_backward: NULL buffer");
+    hipLaunchKernelGGL(gab::k_face_frames_bwd, dim3((F + 255) / 256), dim3(256), 0, st, F, verts, faces, is64, d_center, d_orien_mat, d_scaling,
+                       d_orien_quat, d_verts);
+    LAUNCH_CHECK("k_face_frames_bwd");
+    return GAB_OK;
+}
+
+int gab_bind_forward(int32_t N, int32_t F, const float* xyz, const float* log_scaling, const float* rotation, const void* binding,
+                     int32_t is64, const float* face_center, const float* face_orien_mat, const float* face_scaling,
+                     const float* face_orien_quat, float* out_xyz, float* out_scaling, float* out_rotation, void* stream_)
+{
+    if (N < 0 || F <= 0) return fail(GAB_E_ARG, "bad sizes");
+    if (N == 0) return GAB_OK;
+    if (!xyz || !log_scaling || !rotation || !binding || !face_center || !face_orien_mat || !face_scaling || !face_orien_quat || !out_xyz ||
+        !out_scaling || !out_rotation)
+        return fail(GAB_E_ARG, "gab_bind_forward: NULL buffer");
+    hipLaunchKernelGGL(gab::k_bind, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream_, N, xyz, log_scaling, rotation, binding, is64,
+                       face_center, face_orien_mat, face_scaling, face_orien_quat, out_xyz, out_scaling, out_rotation);
+    LAUNCH_CHECK("k_bind");
+    return GAB_OK;
+}
+
+int gab_bind_backward(int32_t N, int32_t F, const float* xyz, const float* log_scaling, const float* rotation, const void* binding,
+                      int32_t is64, const float* face_center, const float* face_orien_mat, const float* face_scaling,
+                      const float* face_orien_quat, const float* d_out_xyz, const float* d_out_scaling, const float* d_out_rotation,
+                      float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face, void* stream_)
+{
+    (void)face_center;
+    if (N < 0 || F <= 0) return fail(GAB_E_ARG, "bad sizes");
+    if (!d_face) return fail(GAB_E_ARG, "d_face is NULL");
+    hipStream_t st = (hipStream_t)stream_;
+    HIP_TRY(hipMemsetAsync(d_face, 0, (size_t)F * 17 * sizeof(float), st));
+    if (N == 0) return GAB_OK;
+    if (!xyz || !log_scaling || !rotation || !binding || !face_orien_mat || !face_scaling || !face_orien_quat || !d_xyz || !d_log_scaling ||
+        !d_rotation)
+        return fail(GAB_E_ARG, "gab_bind_backward: NULL buffer");
+    hipLaunchKernelGGL(gab::k_bind_bwd, dim3((N + 255) / 256), dim3(256), 0, st, N, xyz, log_scaling, rotation, binding, is64, face_orien_mat,
+                       face_scaling, face_orien_quat, d_out_xyz, d_out_scaling, d_out_rotation, d_xyz, d_log_scaling, d_rotation, d_face);
+    LAUNCH_CHECK("k_bind_bwd");
+    return GAB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+/*
+ * gab.h -- C ABI of the MI355X-native FLAME-rigged binding path ("Gaussian-avatar binding").
+ *
+ * The reference runs this half of the per-frame hot path as ~200 small ATen launches per frame
+ * (SURVEY.md 2.1).  Each group below replaces one pure-torch stage of the reference with fused HIP
+ * kernels, forward and backward:
+ *
+ *   gab_flame_*        FlameHead.forward        flame_model/flame.py:485-558  (blend_shapes + lbs,
+ *                                               flame_model/lbs.py:25-57,101-195,218-304)
+ *   gab_face_frames_*  update_mesh_properties   scene/flame_gaussian_model.py:137-154
+ *                      (+ compute_face_orientation utils/graphics_utils.py:116-135 and
+ *                       roma.rotmat_to_unitquat / quat_xyzw_to_wxyz)
+ *   gab_bind_*         get_xyz / get_scaling / get_rotation   scene/gaussian_model.py:113-150
+ *                      (+ roma.quat_product)
+ *
+ * Conventions: every pointer is a DEVICE pointer; fp32; contiguous row-major tensors with the
+ * reference's shapes; index tensors may be int32 or int64 (the reference produces both,
+ * SURVEY.md H8) -- pass index_is_i64 accordingly.  Returns 0 / <0 like gsr.h; messages through
+ * gab_last_error().  All work is enqueued on `stream`; nothing synchronises.
+ */
+#ifndef GAB_H
+#define GAB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAB_ABI_VERSION 1
+#define GAB_OK 0
+#define GAB_E_ARG (-1)
+#define GAB_E_HIP (-2)
+
+#define GAB_NUM_JOINTS 5            /* FLAME: root, neck, jaw, eye_l, eye_r; parents -1,0,1,1,1 */
+#define GAB_POSE_FEATURES 36        /* (J-1)*9 */
+/* floats of per-frame workspace written by gab_flame_forward and read by gab_flame_backward */
+#define GAB_FLAME_WS_FLOATS 512
+
+/* The FLAME buffers FlameHead registers (flame_model/flame.py:98-129, after add_teeth). */
+typedef struct GabRig {
+    int32_t V;                 /* vertices (5143)                                   */
+    int32_t n_shape;           /* leading betas from `shape` (300)                  */
+    int32_t n_expr;            /* trailing betas from `expr` (100)                  */
+    const float* v_template;   /* (V,3)                                             */
+    const float* shapedirs;    /* (V,3,n_shape+n_expr)                              */
+    const float* posedirs;     /* (36, 3V)                                          */
+    const float* J_regressor;  /* (5,V) dense                                       */
+    const float* lbs_weights;  /* (V,5)                                             */
+    int32_t parents[GAB_NUM_JOINTS];  /* host values; parents[0] = -1               */
+} GabRig;
+
+int gab_abi_version(void);
+const char* gab_last_error(void);
+
+/* ---- FLAME forward / backward (batch 1, zero_centered_at_root_node=False, no landmarks) -------- */
+int gab_flame_forward(const GabRig* rig, const float* shape, const float* expr, const float* rotation,
+                      const float* neck, const float* jaw, const float* eyes /*6*/, const float* translation,
+                      const float* static_offset /*(V,3) or NULL*/,
+                      float* verts /*(V,3)*/, float* v_shaped /*(V,3)*/, float* ws /*GAB_FLAME_WS_FLOATS*/, void* stream);
+
+/* d_shape / d_static_offset / dL_dv_shaped may be NULL.  scratch: (V,3) floats.  Every non-NULL output
+ * is fully written. */
+int gab_flame_backward(const GabRig* rig, const float* shape, const float* expr, const float* rotation,
+                       const float* neck, const float* jaw, const float* eyes, const float* translation,
+                       const float* static_offset, const float* v_shaped, float* ws,
+                       const float* dL_dverts, const float* dL_dv_shaped,
+                       float* d_shape, float* d_expr, float* d_rotation, float* d_neck, float* d_jaw, float* d_eyes,
+                       float* d_translation, float* d_static_offset, float* scratch, void* stream);
+
+/* ---- per-face frames ----------------------------------------------------------------------- */
+int gab_face_frames_forward(int32_t V, int32_t F, const float* verts, const void* faces /*(F,3)*/, int32_t index_is_i64,
+                            float* center /*(F,3)*/, float* orien_mat /*(F,3,3)*/, float* scaling /*(F,1)*/,
+                            float* orien_quat /*(F,4) WXYZ*/, void* stream);
+int gab_face_frames_backward(int32_t V, int32_t F, const float* verts, const void* faces, int32_t index_is_i64,
+                             const float* d_center, const float* d_orien_mat, const float* d_scaling, const float* d_orien_quat,
+                             float* d_verts /*(V,3), fully written*/, void* stream);
+
+/* ---- per-splat mesh-local -> world ---------------------------------------------------------- */
+int gab_bind_forward(int32_t N, int32_t F, const float* xyz, const float* log_scaling, const float* rotation,
+                     const void* binding, int32_t index_is_i64, const float* face_center, const float* face_orien_mat,
+                     const float* face_scaling, const float* face_orien_quat,
+                     float* out_xyz, float* out_scaling, float* out_rotation, void* stream);
+/* d_face (F,17): per-face accumulator laid out center(3) | orien_mat(9) | scaling(1) | orien_quat(4),
+ * fully written (zero-filled, then accumulated). */
+int gab_bind_backward(int32_t N, int32_t F, const float* xyz, const float* log_scaling, const float* rotation,
+                      const void* binding, int32_t index_is_i64, const float* face_center, const float* face_orien_mat,
+                      const float* face_scaling, const float* face_orien_quat,
+                      const float* d_out_xyz, const float* d_out_scaling, const float* d_out_rotation,
+                      float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face /*(F,17)*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAB_H */

@@ -1,0 +1,95 @@
+"""CPU tests of the binding half: the composed-torch restatement (gaussianavatars_amd/unfused.py, the
+fp32 reference the fused kernels are checked against on the GPU) against golden vectors generated
+from the REFERENCE's own flame_model/lbs.py and utils/graphics_utils.py (tests/golden/make_golden.py),
+and the roma stand-ins against SciPy."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gaussianavatars_amd import unfused as U
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def pins():
+    return np.load(os.path.join(G, "binding_pins.npz"))
+
+
+def _rig(pins, device="cpu"):
+    return {k[4:]: torch.as_tensor(pins[k], device=device) for k in pins.files if k.startswith("rig_")}
+
+
+def test_flame_forward_matches_reference_lbs(pins):
+    rig = _rig(pins)
+    t = torch.as_tensor
+    betas, pose = t(pins["betas"]), t(pins["pose"])
+    rig2 = dict(rig)
+    verts, v_shaped = U.flame_forward(rig2, betas[:, :30], betas[:, 30:], pose[:, 0:3], pose[:, 3:6], pose[:, 6:9], pose[:, 9:15],
+                                      t(pins["trans"]), t(pins["static_offset"]))
+    np.testing.assert_allclose(v_shaped.numpy(), pins["v_shaped"], atol=1e-6)
+    np.testing.assert_allclose(verts.numpy(), pins["verts"], atol=2e-6)
+
+
+def test_face_frames_match_reference_compute_face_orientation(pins):
+    verts = torch.as_tensor(pins["verts"])[0]
+    c, R, s, q = U.face_frames(verts, torch.as_tensor(pins["faces"]))
+    np.testing.assert_allclose(c.numpy(), pins["face_center"], atol=1e-6)
+    np.testing.assert_allclose(R.numpy(), pins["face_R"], atol=1e-5)
+    np.testing.assert_allclose(s.numpy(), pins["face_scale"], atol=1e-6)
+    # quaternion: SciPy's from_matrix (the algorithm roma implements), equal up to sign
+    qs = pins["face_quat_xyzw_scipy"]
+    qx = U.quat_wxyz_to_xyzw(q).numpy()
+    sign = np.sign((qx * qs).sum(1, keepdims=True))
+    np.testing.assert_allclose(qx * sign, qs, atol=2e-5)
+
+
+def test_quat_product_matches_scipy():
+    from scipy.spatial.transform import Rotation
+
+    g = np.random.default_rng(0)
+    p, q = g.normal(size=(50, 4)), g.normal(size=(50, 4))
+    p /= np.linalg.norm(p, axis=1, keepdims=True)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    ours = U.quat_product(torch.as_tensor(p), torch.as_tensor(q)).numpy()
+    ref = (Rotation.from_quat(p) * Rotation.from_quat(q)).as_quat()
+    sign = np.sign((ours * ref).sum(1, keepdims=True))
+    np.testing.assert_allclose(ours * sign, ref, atol=1e-12)
+
+
+def test_bind_rotation_equals_rotation_composition():
+    """get_rotation = face rotation o local rotation (scene/gaussian_model.py:125-138)."""
+    from scipy.spatial.transform import Rotation
+
+    g = np.random.default_rng(1)
+    fq = g.normal(size=(7, 4))
+    rot = g.normal(size=(40, 4))
+    b = g.integers(0, 7, 40)
+    out = U.bind_rotation(torch.as_tensor(rot), torch.as_tensor(b), torch.as_tensor(fq)).numpy()  # WXYZ
+    to_xyzw = lambda a: np.roll(a, -1, axis=1)
+    Rf = Rotation.from_quat(to_xyzw(fq / np.linalg.norm(fq, axis=1, keepdims=True)))[b]
+    Rl = Rotation.from_quat(to_xyzw(rot / np.linalg.norm(rot, axis=1, keepdims=True)))
+    np.testing.assert_allclose(Rotation.from_quat(to_xyzw(out)).as_matrix(), (Rf * Rl).as_matrix(), atol=1e-10)
+
+
+def test_gab_library_exports_every_declared_symbol():
+    import re
+
+    from gaussianavatars_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "gab.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(gab_[a-z0-9_]+)\s*\(", txt)))
+    lib = _lib.gab()
+    assert len(names) == 8
+    for n in names:
+        assert hasattr(lib, n) and n in _lib.GAB_SYMBOLS, n
+
+
+def test_fused_path_refuses_cpu_tensors():
+    from gaussianavatars_amd import binding as B
+
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        B.face_frames(torch.zeros(4, 3), torch.zeros(2, 3, dtype=torch.long))

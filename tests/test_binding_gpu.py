@@ -1,0 +1,143 @@
+"""GPU parity of the fused binding kernels (include/gab.h) against (a) golden vectors generated from
+the reference's own lbs / compute_face_orientation code and (b) the composed-torch fp32 restatement
+on the same device, forward and backward.  Tolerances (fp32, different summation order):
+forward rel 2e-5 of the tensor's max magnitude, gradients rel 2e-4."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gaussianavatars_amd import synthetic as S
+from gaussianavatars_amd import unfused as U
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _close(a, b, rtol, what):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    scale = float(b.abs().max()) + 1e-30
+    err = float((a - b).abs().max()) / scale
+    assert err < rtol, f"{what}: rel err {err:.3e} (max |ref| {scale:.3e})"
+
+
+class _Head:
+    def __init__(self, rig, dev, n_shape):
+        for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights"):
+            setattr(self, k, torch.as_tensor(rig[k], dtype=torch.float32, device=dev).contiguous())
+        self.parents = torch.as_tensor(rig["parents"], device=dev)
+        self.n_shape_params = n_shape
+
+    def rigdict(self):
+        return dict(v_template=self.v_template, shapedirs=self.shapedirs, posedirs=self.posedirs, J_regressor=self.J_regressor,
+                    lbs_weights=self.lbs_weights, parents=self.parents)
+
+
+def test_flame_forward_matches_reference_golden():
+    from gaussianavatars_amd import binding as B
+
+    dev = _dev()
+    pins = np.load(os.path.join(G, "binding_pins.npz"))
+    rig = {k[4:]: pins[k] for k in pins.files if k.startswith("rig_")}
+    head = _Head(rig, dev, 30)
+    t = lambda a: torch.as_tensor(a, device=dev)
+    betas, pose = t(pins["betas"]), t(pins["pose"])
+    verts, v_shaped = B.flame_forward(head, betas[:, :30], betas[:, 30:], pose[:, 0:3], pose[:, 3:6], pose[:, 6:9], pose[:, 9:15],
+                                      t(pins["trans"]), t(pins["static_offset"]))
+    _close(v_shaped, torch.as_tensor(pins["v_shaped"]), 2e-5, "v_shaped vs reference")
+    _close(verts, torch.as_tensor(pins["verts"]), 2e-5, "verts vs reference lbs")
+    c, R, s, q = B.face_frames(verts[0], t(pins["faces"]))
+    _close(c, torch.as_tensor(pins["face_center"]), 2e-5, "face_center")
+    _close(R, torch.as_tensor(pins["face_R"]), 5e-5, "face_orien_mat vs compute_face_orientation")
+    _close(s, torch.as_tensor(pins["face_scale"]), 2e-5, "face_scaling")
+    qs = torch.as_tensor(pins["face_quat_xyzw_scipy"])
+    qx = torch.roll(q.cpu(), -1, dims=-1)
+    sign = torch.sign((qx * qs).sum(1, keepdim=True))
+    _close(qx * sign, qs, 1e-4, "face_orien_quat vs SciPy")
+
+
+@pytest.mark.parametrize("with_shape_grad", [False, True])
+def test_flame_full_size_forward_backward_vs_torch(with_shape_grad):
+    from gaussianavatars_amd import binding as B
+
+    dev = _dev()
+    rig = S.flame_rig(4)
+    seq = S.flame_sequence(8, 4)
+    head = _Head(rig, dev, 300)
+    t = lambda a, g=True: torch.as_tensor(a, device=dev).clone().requires_grad_(g)
+    mk = lambda: dict(shape=t(seq["shape"][None], with_shape_grad), expr=t(seq["expr"][[3]]), rot=t(seq["rotation"][[3]]),
+                      neck=t(seq["neck_pose"][[3]]), jaw=t(seq["jaw_pose"][[3]]), eyes=t(seq["eyes_pose"][[3]]),
+                      trans=t(seq["translation"][[3]]), so=t(seq["static_offset"], with_shape_grad))
+    a, b = mk(), mk()
+    v1, vs1 = B.flame_forward(head, a["shape"], a["expr"], a["rot"], a["neck"], a["jaw"], a["eyes"], a["trans"], a["so"])
+    v2, vs2 = U.flame_forward(head.rigdict(), b["shape"], b["expr"], b["rot"], b["neck"], b["jaw"], b["eyes"], b["trans"], b["so"])
+    _close(v1, v2, 2e-5, "verts")
+    _close(vs1, vs2, 2e-5, "v_shaped")
+    g = torch.Generator(device="cpu").manual_seed(0)
+    w1 = torch.randn(v1.shape, generator=g).to(dev)
+    w2 = torch.randn(v1.shape, generator=g).to(dev) * 0.1
+    ((v1 * w1).sum() + (vs1 * w2).sum()).backward()
+    ((v2 * w1).sum() + (vs2 * w2).sum()).backward()
+    for k in a:
+        if a[k].requires_grad:
+            _close(a[k].grad, b[k].grad, 3e-4, f"d{k}")
+        else:
+            assert a[k].grad is None
+
+
+def test_face_frames_and_bind_forward_backward_vs_torch():
+    from gaussianavatars_amd import binding as B
+
+    dev = _dev()
+    verts0, faces = S.head_mesh()
+    g = np.random.default_rng(3)
+    verts0 = verts0 + g.normal(0, 5e-4, verts0.shape).astype(np.float32)
+    sp = S.bound_splats(30000, S.FLAME_F, 3, 2)
+    for idx_dtype in (torch.int64, torch.int32):
+        t = lambda a: torch.as_tensor(a, device=dev).clone().requires_grad_(True)
+        va, vb = t(verts0), t(verts0)
+        fa = torch.as_tensor(faces, device=dev).to(idx_dtype)
+        binding = torch.as_tensor(sp["binding"], device=dev).to(idx_dtype)
+        xa, sa, ra = t(sp["_xyz"]), t(sp["_scaling"]), t(sp["_rotation"])
+        xb, sb, rb = t(sp["_xyz"]), t(sp["_scaling"]), t(sp["_rotation"])
+        c1, R1, s1, q1 = B.face_frames(va, fa)
+        c2, R2, s2, q2 = U.face_frames(vb, fa.long())
+        for n, x, y in (("center", c1, c2), ("R", R1, R2), ("scale", s1, s2), ("quat", q1, q2)):
+            _close(x, y, 5e-5, f"face {n}")
+        o1 = B.bind_splats(xa, sa, ra, binding, R1, s1, c1, q1)
+        o2 = (U.bind_xyz(xb, binding, R2, s2, c2), U.bind_scaling(sb, binding, s2), U.bind_rotation(rb, binding, q2))
+        gen = torch.Generator(device="cpu").manual_seed(1)
+        loss1 = loss2 = 0.0
+        for n, x, y in zip(("xyz", "scaling", "rotation"), o1, o2):
+            _close(x, y, 2e-5, f"bound {n}")
+            w = torch.randn(x.shape, generator=gen).to(dev)
+            loss1 = loss1 + (x * w).sum()
+            loss2 = loss2 + (y * w).sum()
+        loss1.backward()
+        loss2.backward()
+        for n, x, y in (("_xyz", xa, xb), ("_scaling", sa, sb), ("_rotation", ra, rb), ("verts", va, vb)):
+            _close(x.grad, y.grad, 3e-4, f"d{n} ({idx_dtype})")
+
+
+def test_model_fused_equals_unfused_end_to_end():
+    """select_mesh_by_timestep -> render -> L1 -> backward through the mirrored model, both binding modes."""
+    import bench
+
+    dev = _dev()
+    outs = {}
+    for mode in ("fused", "unfused"):
+        g, cam = bench.build_scene(dev, 20000, 3, 200, 288, 6, mode, True)
+        bg = torch.ones(3, device=dev)
+        target = torch.ones((3, 288, 200), device=dev)
+        loss = bench.one_step(g, cam, bg, target, 2, True)
+        outs[mode] = dict(loss=loss, xyz=g._xyz.grad, rot=g._rotation.grad, sc=g._scaling.grad, expr=g.flame_param["expr"].grad,
+                          jaw=g.flame_param["jaw_pose"].grad, trans=g.flame_param["translation"].grad, dc=g._features_dc.grad)
+    for k in outs["fused"]:
+        _close(outs["fused"][k], outs["unfused"][k], 2e-3, f"end-to-end {k}")
