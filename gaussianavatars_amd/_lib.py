@@ -41,11 +41,11 @@ class GsrGeomLayout(C.Structure):
 
 class GsrBinningLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
-                ("keys", "point_list", "records", "ranges", "tile_count", "tile_start", "tile_cursor", "total")]
+                ("keys", "point_list", "qrecords", "qcount", "ranges", "tile_count", "tile_start", "tile_cursor", "total")]
 
 
 class GsrImageLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("final_T", "n_contrib", "total")]
+    _fields_ = [(n, C.c_size_t) for n in ("final_T", "n_contrib", "n_contrib_q", "total")]
 
 
 #: every symbol include/gsr.h declares -> (restype, argtypes)

@@ -160,7 +160,8 @@ int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, GsrBinni
     size_t off = 256;  // header: [0] = uint64 instance count of this frame
     o->keys = off;        off = align_up(off + cap * 8, A);
     o->point_list = off;  off = align_up(off + cap * 4, A);
-    o->records = off;     off = align_up(off + cap * 48, A);
+    o->qrecords = off;    off = align_up(off + cap * 4 * 48, A);
+    o->qcount = off;      off = align_up(off + tiles * 16, A);
     o->ranges = off;      off = align_up(off + tiles * 8, A);
     o->tile_count = off;  off = align_up(off + tiles * 4, A);
     o->tile_start = off;  off = align_up(off + tiles * 4, A);
@@ -176,6 +177,7 @@ int gsr_image_layout(int32_t width, int32_t height, GsrImageLayout* o)
     size_t off = 0;
     o->final_T = off;   off = align_up(off + hw * 4, A);
     o->n_contrib = off; off = align_up(off + hw * 4, A);
+    o->n_contrib_q = off; off = align_up(off + hw * 4, A);
     o->total = off + A;
     return 0;
 }
@@ -287,9 +289,9 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
         }
         {
             TIMED(GSR_K_TILE_SORT, stream);
-    hipLaunchKernelGGL(gsr::k_tile_sort, dim3(tiles), dim3(256), 0, stream, tiles, (const uint32_t*)tile_count,
+    hipLaunchKernelGGL(gsr::k_tile_sort, dim3(tiles), dim3(256), 0, stream, gx, (const uint32_t*)tile_count,
                                        (const uint32_t*)(b + bl.tile_start), (unsigned long long*)(b + bl.keys),
-                                       (uint32_t*)(b + bl.point_list), (float4*)(b + bl.records), (const float2*)pa.xy,
+                                       (uint32_t*)(b + bl.point_list), (float4*)(b + bl.qrecords), (uint32_t*)(b + bl.qcount), (const float2*)pa.xy,
                                        (const float4*)pa.conic_opacity, (const float4*)pa.rgb, cap, (const unsigned long long*)total_dev);
                     KERNEL_CHECK("k_tile_sort", stream, dbg);
         }
@@ -297,7 +299,8 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
     {
         TIMED(GSR_K_RENDER, stream);
     hipLaunchKernelGGL(gsr::k_render, dim3(gx, gy), dim3(256), 0, stream, ds, (const uint2*)(b + bl.ranges),
-                               (const float4*)(b + bl.records), (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib), out_color,
+                               (const uint32_t*)(b + bl.qcount), (const float4*)(b + bl.qrecords), (float*)(im + il.final_T),
+                               (uint32_t*)(im + il.n_contrib), (uint32_t*)(im + il.n_contrib_q), out_color,
                                cap, (const unsigned long long*)total_dev);
             KERNEL_CHECK("k_render", stream, dbg);
     }
@@ -368,8 +371,8 @@ int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M, const float*
         {
             TIMED(GSR_K_RENDER_BWD, stream);
     hipLaunchKernelGGL(gsr::k_render_bwd, dim3(gx, gy), dim3(256), 0, stream, ds, (const uint2*)(b + bl.ranges),
-                                       (const float4*)(b + bl.records), (const float*)(im + il.final_T),
-                                       (const uint32_t*)(im + il.n_contrib), dL_dpix, grad_scratch);
+                                       (const uint32_t*)(b + bl.qcount), (const float4*)(b + bl.qrecords), (const float*)(im + il.final_T),
+                                       (const uint32_t*)(im + il.n_contrib_q), dL_dpix, grad_scratch);
                     KERNEL_CHECK("k_render_bwd", stream, dbg);
         }
     }

@@ -17,9 +17,32 @@
 
 namespace gsr {
 
-__global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint2* __restrict__ ranges,
-                                                     const float4* __restrict__ records, const float* __restrict__ final_T,
-                                                     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+// 64-lane sums of RB(=4) x 9 values with a transposed reduction: v_permlane32_swap halves the lane
+// count and doubles the records per register, v_permlane16_swap does it again, then a 4-step DPP
+// butterfly finishes inside each 16-lane row.  Afterwards row r of t[c] holds, in every lane, the full
+// sum of component c of record kRowRec[r].  ~105 VALU ops for 36 sums (a plain butterfly needs 216).
+__device__ __forceinline__ float swap32_add(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);   // lanes 0-31: a summed over halves, lanes 32-63: b
+}
+__device__ __forceinline__ float swap16_add(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);   // rows 0,2: a's row pairs, rows 1,3: b's
+}
+__device__ __forceinline__ float row_sum(float v)
+{
+    v += dpp_f<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x141, 0xf>(v);  // row_half_mirror
+    v += dpp_f<0x140, 0xf>(v);  // row_mirror
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint2* __restrict__ ranges, const uint32_t* __restrict__ qcount,
+                                                     const float4* __restrict__ qrecords, const float* __restrict__ final_T,
+                                                     const uint32_t* __restrict__ n_contrib_q, const float* __restrict__ dL_dpix,
                                                      float* __restrict__ acc /* [P][GSR_ACC_STRIDE] */)
 {
     const int W = s.W, H = s.H;
@@ -32,12 +55,14 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint2* __r
     const bool inside = pxi < W && pyi < H;
     const float pixx = (float)pxi, pixy = (float)pyi;
     const uint2 range = ranges[tile];
-    const float4* __restrict__ rec = records + (size_t)3 * range.x;
+    const uint32_t nt = range.y - range.x;
+    const int nq = (int)qcount[4 * tile + wave];
+    const float4* __restrict__ rec = qrecords + (size_t)3 * ((size_t)4 * range.x + (size_t)wave * nt);
 
     const int pix_id = W * pyi + pxi;
     const size_t HW = (size_t)H * W;
     const float T_final = inside ? final_T[pix_id] : 0.f;
-    const uint32_t last = inside ? n_contrib[pix_id] : 0u;
+    const int last = inside ? (int)n_contrib_q[pix_id] : 0;
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (inside) {
         g0 = dL_dpix[0 * HW + pix_id];
@@ -52,70 +77,89 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint2* __r
     float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;      // colour of the previously visited splat
     float last_alpha = 0.f;
 
-    const int jmax = (int)wave_max_u32(last);    // wave-uniform: the deepest contributor of any pixel
-    for (int j = jmax - 1; j >= 0; --j) {
-        const float4 r0 = rec[3 * j + 0];
-        const float4 r1 = rec[3 * j + 1];
-        const float4 r2 = rec[3 * j + 2];
-        float v_c0 = 0.f, v_c1 = 0.f, v_c2 = 0.f, v_mx = 0.f, v_my = 0.f, v_ca = 0.f, v_cb = 0.f, v_cc = 0.f, v_op = 0.f;
-        bool hit = false;
-        if ((uint32_t)j < last) {
-            const float dx = r0.x - pixx;
-            const float dy = r0.y - pixy;
-            const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-            if (power <= 0.0f) {
-                const float G = gsr_expf(power);
-                const float alpha = sel_min(0.99f, r1.y * G);
-                if (alpha >= 1.0f / 255.0f) {
-                    hit = true;
-                    const float one_m = 1.f - alpha;
-                    T = T * __builtin_amdgcn_rcpf(one_m);
-                    const float w = alpha * T;
-                    ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0;
-                    ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1;
-                    ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2;
-                    lc0 = r1.z; lc1 = r1.w; lc2 = r2.x;
-                    float dL_dalpha = (lc0 - ar0) * g0 + (lc1 - ar1) * g1 + (lc2 - ar2) * g2;
-                    v_c0 = w * g0; v_c1 = w * g1; v_c2 = w * g2;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-T_final * __builtin_amdgcn_rcpf(one_m)) * bg_dot;
-                    const float dL_dG = r1.y * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * r0.z - gdy * r0.w;
-                    const float dG_ddely = -gdy * r1.x - gdx * r0.w;
-                    v_mx = dL_dG * dG_ddelx * ddelx_dx;
-                    v_my = dL_dG * dG_ddely * ddely_dy;
-                    v_ca = -0.5f * gdx * dx * dL_dG;
-                    v_cb = -0.5f * gdx * dy * dL_dG;
-                    v_cc = -0.5f * gdy * dy * dL_dG;
-                    v_op = G * dL_dalpha;
-                }
-            }
+    constexpr int RB = 4;
+    const int jmax = min((int)wave_max_u32((uint32_t)last), nq);   // deepest contributor of any pixel of this wave
+    for (int jb = ((jmax + RB - 1) / RB) * RB - RB; jb >= 0; jb -= RB) {
+        float rx[RB], ry[RB], ca[RB], cb2[RB], cc[RB], op[RB], c_r[RB], c_g[RB], c_b[RB];
+        uint32_t id[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int j = min(jb + u, nq - 1);
+            const float4 r0 = rec[3 * j + 0];
+            const float4 r1 = rec[3 * j + 1];
+            const float4 r2 = rec[3 * j + 2];
+            rx[u] = r0.x; ry[u] = r0.y; ca[u] = r0.z; cb2[u] = r0.w;
+            cc[u] = r1.x; op[u] = r1.y; c_r[u] = r1.z; c_g[u] = r1.w; c_b[u] = r2.x;
+            id[u] = __float_as_uint(r2.y);
         }
-        if (__ballot(hit) == 0ull) continue;      // no pixel of this wave touched the splat
-        v_c0 = wave_sum_hi(v_c0);
-        v_c1 = wave_sum_hi(v_c1);
-        v_c2 = wave_sum_hi(v_c2);
-        v_mx = wave_sum_hi(v_mx);
-        v_my = wave_sum_hi(v_my);
-        v_ca = wave_sum_hi(v_ca);
-        v_cb = wave_sum_hi(v_cb);
-        v_cc = wave_sum_hi(v_cc);
-        v_op = wave_sum_hi(v_op);
-        // lanes 48..56 each own one of the nine sums -> one 36-byte atomic burst
-        const int k = lane - 48;
-        float mine = v_c0;
-        mine = (k == 1) ? v_c1 : mine;
-        mine = (k == 2) ? v_c2 : mine;
-        mine = (k == 3) ? v_mx : mine;
-        mine = (k == 4) ? v_my : mine;
-        mine = (k == 5) ? v_ca : mine;
-        mine = (k == 6) ? v_cb : mine;
-        mine = (k == 7) ? v_cc : mine;
-        mine = (k == 8) ? v_op : mine;
-        const uint32_t id = __float_as_uint(r2.y);
-        if (k >= 0 && k < 9) unsafeAtomicAdd(acc + (size_t)GSR_ACC_STRIDE * id + k, mine);
+        // independent part: G, alpha, hit
+        float G[RB], alpha[RB], dxs[RB], dys[RB];
+        bool hit[RB];
+        bool any_hit = false;
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            dxs[u] = rx[u] - pixx;
+            dys[u] = ry[u] - pixy;
+            const float power = -0.5f * (ca[u] * dxs[u] * dxs[u] + cc[u] * dys[u] * dys[u]) - cb2[u] * dxs[u] * dys[u];
+            G[u] = gsr_expf(power);
+            alpha[u] = sel_min(0.99f, op[u] * G[u]);
+            hit[u] = (jb + u) < last && power <= 0.0f && alpha[u] >= 1.0f / 255.0f;
+            any_hit = any_hit || hit[u];
+        }
+        if (__ballot(any_hit) == 0ull) continue;      // no pixel of this wave touched these splats
+        // sequential part, back to front
+        float v[RB][9];
+#pragma unroll
+        for (int u = RB - 1; u >= 0; --u) {
+            const float one_m = 1.f - alpha[u];
+            const float rinv = __builtin_amdgcn_rcpf(one_m);
+            const float Tn = T * rinv;
+            const float w = alpha[u] * Tn;
+            const float n0 = last_alpha * lc0 + (1.f - last_alpha) * ar0;
+            const float n1 = last_alpha * lc1 + (1.f - last_alpha) * ar1;
+            const float n2 = last_alpha * lc2 + (1.f - last_alpha) * ar2;
+            float dL_dalpha = ((c_r[u] - n0) * g0 + (c_g[u] - n1) * g1 + (c_b[u] - n2) * g2) * Tn;
+            dL_dalpha += (-T_final * rinv) * bg_dot;
+            const float dL_dG = op[u] * dL_dalpha;
+            const float gdx = G[u] * dxs[u], gdy = G[u] * dys[u];
+            const float dG_ddelx = -gdx * ca[u] - gdy * cb2[u];
+            const float dG_ddely = -gdy * cc[u] - gdx * cb2[u];
+            const bool h = hit[u];
+            v[u][0] = h ? w * g0 : 0.f;
+            v[u][1] = h ? w * g1 : 0.f;
+            v[u][2] = h ? w * g2 : 0.f;
+            v[u][3] = h ? dL_dG * dG_ddelx * ddelx_dx : 0.f;
+            v[u][4] = h ? dL_dG * dG_ddely * ddely_dy : 0.f;
+            v[u][5] = h ? -0.5f * gdx * dxs[u] * dL_dG : 0.f;
+            v[u][6] = h ? -0.5f * gdx * dys[u] * dL_dG : 0.f;
+            v[u][7] = h ? -0.5f * gdy * dys[u] * dL_dG : 0.f;
+            v[u][8] = h ? G[u] * dL_dalpha : 0.f;
+            T = h ? Tn : T;
+            ar0 = h ? n0 : ar0;
+            ar1 = h ? n1 : ar1;
+            ar2 = h ? n2 : ar2;
+            lc0 = h ? c_r[u] : lc0;
+            lc1 = h ? c_g[u] : lc1;
+            lc2 = h ? c_b[u] : lc2;
+            last_alpha = h ? alpha[u] : last_alpha;
+        }
+        // transposed reduction: rows 0..3 of t[c] <- records 0, 2, 1, 3
+        float mine = 0.f;
+        const int c_sel = lane & 15;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const float s01 = swap32_add(v[0][c], v[1][c]);
+            const float s23 = swap32_add(v[2][c], v[3][c]);
+            const float t = row_sum(swap16_add(s01, s23));
+            mine = (c_sel == c) ? t : mine;
+        }
+        const int row = lane >> 4;
+        uint32_t myid = id[0];
+        myid = (row == 1) ? id[2] : myid;
+        myid = (row == 2) ? id[1] : myid;
+        myid = (row == 3) ? id[3] : myid;
+        const int rec_u = (row == 1) ? 2 : ((row == 2) ? 1 : row);
+        if (c_sel < 9 && (jb + rec_u) < nq && mine != 0.f) unsafeAtomicAdd(acc + (size_t)GSR_ACC_STRIDE * myid + c_sel, mine);
     }
 }
 

@@ -382,20 +382,24 @@ __device__ __forceinline__ void bitonic_sort(KeyAcc k, uint32_t n, int tid, int 
     }
 }
 
-__global__ __launch_bounds__(256) void k_tile_sort(int tiles, const uint32_t* __restrict__ tile_count,
+__global__ __launch_bounds__(256) void k_tile_sort(int gx, const uint32_t* __restrict__ tile_count,
                                                     const uint32_t* __restrict__ tile_start, unsigned long long* __restrict__ keys,
-                                                    uint32_t* __restrict__ point_list, float4* __restrict__ records,
-                                                    const float2* __restrict__ xy, const float4* __restrict__ conic_opacity,
-                                                    const float4* __restrict__ rgb, unsigned long long capacity,
-                                                    const unsigned long long* __restrict__ total_dev)
+                                                    uint32_t* __restrict__ point_list, float4* __restrict__ qrecords,
+                                                    uint32_t* __restrict__ qcount, const float2* __restrict__ xy,
+                                                    const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb,
+                                                    unsigned long long capacity, const unsigned long long* __restrict__ total_dev)
 {
     __shared__ unsigned long long skeys[GSR_SORT_LDS_KEYS];
+    __shared__ uint32_t wave_cnt[4][4];   // [quadrant][wave]
     if (*total_dev > capacity) return;
     const uint32_t tile = blockIdx.x;
     const uint32_t n = tile_count[tile];
-    if (n == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (n == 0) {
+        if (tid < 4) qcount[4 * tile + tid] = 0u;
+        return;
+    }
     const uint32_t start = tile_start[tile];
-    const int tid = threadIdx.x;
     unsigned long long* seg = keys + start;
     const bool in_lds = n <= GSR_SORT_LDS_KEYS;
     if (in_lds) {
@@ -406,31 +410,87 @@ __global__ __launch_bounds__(256) void k_tile_sort(int tiles, const uint32_t* __
         __syncthreads();
         bitonic_sort(seg, n, tid, 256);  // rare: > 8192 instances in one tile, sort in place in global memory
     }
+    // ---- epilogue: reference-format keys / point list, and the four 8x8-quadrant record streams --------
+    // A record goes to quadrant q only if the exact ellipse {alpha >= 1/255} of the splat can reach a pixel
+    // centre of q (conservatively padded), i.e. only (record, quadrant) pairs the blend would skip for every
+    // pixel are dropped: the composited result is unchanged, the blend's lists get ~3x shorter.  Order inside
+    // a quadrant stream is the tile order (stable compaction), r2.z keeps the position in the tile list.
     const unsigned long long tile_hi = (unsigned long long)tile << 32;
-    for (uint32_t i = tid; i < n; i += 256) {
-        const unsigned long long k = in_lds ? skeys[i] : seg[i];
-        const uint32_t idx = (uint32_t)k;
-        seg[i] = tile_hi | (k >> 32);  // reference-format key: tile id | depth bits
-        point_list[start + i] = idx;
-        const float2 p = xy[idx];
-        const float4 co = conic_opacity[idx];
-        const float4 c = rgb[idx];
-        float4* r = records + (size_t)3 * (start + i);
-        r[0] = make_float4(p.x, p.y, co.x, co.y);
-        r[1] = make_float4(co.z, co.w, c.x, c.y);
-        r[2] = make_float4(c.z, __uint_as_float(idx), 0.f, 0.f);
+    const float ox = (float)((tile % (uint32_t)gx) * GSR_BLOCK_X), oy = (float)((tile / (uint32_t)gx) * GSR_BLOCK_Y);
+    uint32_t running[4] = {0u, 0u, 0u, 0u};
+    float4* const qbase = qrecords + (size_t)3 * 4 * start;
+    for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t i = base + tid;
+        const bool valid = i < n;
+        bool f[4] = {false, false, false, false};
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+        if (valid) {
+            const unsigned long long k = in_lds ? skeys[i] : seg[i];
+            const uint32_t idx = (uint32_t)k;
+            seg[i] = tile_hi | (k >> 32);
+            point_list[start + i] = idx;
+            const float2 p = xy[idx];
+            const float4 co = conic_opacity[idx];
+            const float4 c = rgb[idx];
+            r0 = make_float4(p.x, p.y, co.x, co.y);
+            r1 = make_float4(co.z, co.w, c.x, c.y);
+            r2 = make_float4(c.z, __uint_as_float(idx), __uint_as_float(i), 0.f);
+            if (co.w * 255.0f >= 1.0f) {   // alpha = min(0.99, o * G) can reach 1/255 only if o >= 1/255
+                float hx = 3.0e38f, hy = 3.0e38f;
+                const float det = co.x * co.z - co.y * co.y;
+                if (det > 0.f) {
+                    const float tau = logf(255.0f * co.w) * 1.0001f + 1e-3f;       // power >= -tau is necessary
+                    hx = sqrtf(2.f * tau * co.z / det) * 1.01f + 1.0f;             // |dx| <= sqrt(2 tau cov.xx), padded
+                    hy = sqrtf(2.f * tau * co.x / det) * 1.01f + 1.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float qx0 = ox + (float)((q & 1) * 8), qy0 = oy + (float)((q >> 1) * 8);
+                    f[q] = (p.x + hx >= qx0) && (p.x - hx <= qx0 + 7.f) && (p.y + hy >= qy0) && (p.y - hy <= qy0 + 7.f);
+                }
+            }
+        }
+        uint32_t prefix[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned long long bal = __ballot(f[q]);
+            prefix[q] = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (lane == 0) wave_cnt[q][wid] = (uint32_t)__builtin_popcountll(bal);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t off = running[q], tot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t cw = wave_cnt[q][w];
+                if (w < wid) off += cw;
+                tot += cw;
+            }
+            if (f[q]) {
+                float4* dst = qbase + (size_t)3 * ((size_t)q * n + off + prefix[q]);
+                dst[0] = r0;
+                dst[1] = r1;
+                dst[2] = r2;
+            }
+            running[q] += tot;
+        }
+        __syncthreads();
     }
+    if (tid < 4) qcount[4 * tile + tid] = running[tid];
 }
 
 // ------------------------------------------------------------------------------------------
 // k_render: front-to-back compositing.  Workgroup = one 16x16 tile = 4 independent waves, wave w
-// owns the 8x8 quadrant (w&1, w>>1).  The record index is wave-uniform, so the loads below are
-// scalar-unit loads: one 48-byte fetch serves all 64 pixels and the values sit in SGPRs.
+// owns the 8x8 quadrant (w&1, w>>1) and walks that quadrant's record stream.  The record index is
+// wave-uniform, so the loads below are scalar-unit loads: one 48-byte fetch serves all 64 pixels
+// and the values sit in SGPRs -- no LDS staging, no barriers, each wave stops on its own.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_render(Settings s, const uint2* __restrict__ ranges,
-                                                 const float4* __restrict__ records, float* __restrict__ final_T,
-                                                 uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-                                                 unsigned long long capacity, const unsigned long long* __restrict__ total_dev)
+__global__ __launch_bounds__(256) void k_render(Settings s, const uint2* __restrict__ ranges, const uint32_t* __restrict__ qcount,
+                                                 const float4* __restrict__ qrecords, float* __restrict__ final_T,
+                                                 uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ n_contrib_q,
+                                                 float* __restrict__ out_color, unsigned long long capacity,
+                                                 const unsigned long long* __restrict__ total_dev)
 {
     if (*total_dev > capacity) return;
     const int W = s.W, H = s.H;
@@ -444,45 +504,45 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint2* __restr
     const float pixx = (float)pxi, pixy = (float)pyi;
 
     const uint2 range = ranges[tile];
-    const int n = (int)(range.y - range.x);
-    const float4* __restrict__ rec = records + (size_t)3 * range.x;
+    const uint32_t nt = range.y - range.x;
+    const int n = (int)qcount[4 * tile + wave];
+    const float4* __restrict__ rec = qrecords + (size_t)3 * ((size_t)4 * range.x + (size_t)wave * nt);
 
     float T = 1.0f;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    uint32_t last_contributor = 0;
+    uint32_t last_contributor = 0, last_q = 0;
     bool done = !inside;
 
-    // The list is walked RB records at a time: the RB exponentials are independent (instruction-level
+    // The stream is walked RB records at a time: the RB exponentials are independent (instruction-level
     // parallelism for a wave that is alone on its SIMD), only the short T/C update is sequential.
     // Skips are predicated (selects), so the arithmetic per contributing record is exactly A.3's.
     constexpr int RB = 4;
-    for (int j0 = 0; j0 < n; j0 += RB) {
-        if (__all(done)) break;
+    constexpr int TAIL_LANES = 8;     // switch to record-parallel mode when this few pixels are still open
+    int j0 = 0;
+    for (; j0 < n; j0 += RB) {
+        const unsigned long long open_mask = __ballot(!done);
+        if (open_mask == 0ull) break;
+        if (__builtin_popcountll(open_mask) <= TAIL_LANES && n - j0 > 2 * GSR_WAVE) break;   // -> tail mode below
         float rx[RB], ry[RB], ca[RB], cb2[RB], cc[RB], op[RB], c_r[RB], c_g[RB], c_b[RB];
+        uint32_t orig[RB];
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
             const int j = min(j0 + u, n - 1);   // tail: re-read the last record, masked out below
             const float4 r0 = rec[3 * j + 0];
             const float4 r1 = rec[3 * j + 1];
-            const float r2x = rec[3 * j + 2].x;
+            const float4 r2 = rec[3 * j + 2];
             rx[u] = r0.x; ry[u] = r0.y; ca[u] = r0.z; cb2[u] = r0.w;
-            cc[u] = r1.x; op[u] = r1.y; c_r[u] = r1.z; c_g[u] = r1.w; c_b[u] = r2x;
+            cc[u] = r1.x; op[u] = r1.y; c_r[u] = r1.z; c_g[u] = r1.w; c_b[u] = r2.x;
+            orig[u] = __float_as_uint(r2.z);
         }
-        float power[RB];
-        bool cand = false;
+        float alpha[RB];
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
             const float dx = rx[u] - pixx;
             const float dy = ry[u] - pixy;
-            power[u] = -0.5f * (ca[u] * dx * dx + cc[u] * dy * dy) - cb2[u] * dx * dy;
-            cand = cand || (power[u] <= 0.0f && (j0 + u) < n);
-        }
-        if (!__any(cand && !done)) continue;   // wave-uniform: none of the 64 pixels is near these splats
-        float alpha[RB];
-#pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const float a = sel_min(0.99f, op[u] * gsr_expf(power[u]));
-            const bool ok = power[u] <= 0.0f && (j0 + u) < n && a >= 1.0f / 255.0f;
+            const float power = -0.5f * (ca[u] * dx * dx + cc[u] * dy * dy) - cb2[u] * dx * dy;
+            const float a = sel_min(0.99f, op[u] * gsr_expf(power));
+            const bool ok = power <= 0.0f && (j0 + u) < n && a >= 1.0f / 255.0f;
             alpha[u] = ok ? a : 0.0f;
         }
 #pragma unroll
@@ -498,14 +558,67 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint2* __restr
             C1 = acc ? n1 : C1;
             C2 = acc ? n2 : C2;
             T = acc ? test_T : T;
-            last_contributor = acc ? (uint32_t)(j0 + u + 1) : last_contributor;
+            last_contributor = acc ? orig[u] + 1u : last_contributor;
+            last_q = acc ? (uint32_t)(j0 + u + 1) : last_q;
             done = done || stop;
+        }
+    }
+
+    // ---- tail mode: record-parallel --------------------------------------------------------------
+    // A few pixels that never saturate (silhouettes) would otherwise drag the whole wave through the
+    // rest of a long stream with 60 idle lanes.  Here the roles flip: for one open pixel at a time the
+    // 64 lanes evaluate 64 *records* in parallel, and only the records that actually touch the pixel
+    // (ballot) go through the sequential T/C update, in stream order -- the arithmetic per contributing
+    // record and its order are unchanged, so results stay bit-identical.
+    if (j0 < n) {
+        unsigned long long open_mask = __ballot(!done);
+        while (open_mask) {
+            const int p = __builtin_ctzll(open_mask);
+            open_mask &= open_mask - 1;
+            const float ppx = (float)(blockIdx.x * GSR_BLOCK_X + (wave & 1) * 8 + (p & 7));
+            const float ppy = (float)(blockIdx.y * GSR_BLOCK_Y + (wave >> 1) * 8 + (p >> 3));
+            float Tp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(T), p));
+            float A0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C0), p));
+            float A1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C1), p));
+            float A2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C2), p));
+            uint32_t lastp = (uint32_t)__builtin_amdgcn_readlane((int)last_contributor, p);
+            uint32_t lastqp = (uint32_t)__builtin_amdgcn_readlane((int)last_q, p);
+            bool donep = false;
+            for (int c0 = j0; c0 < n && !donep; c0 += GSR_WAVE) {
+                const int j = c0 + lane;
+                const bool valid = j < n;
+                const int jc = valid ? j : n - 1;
+                const float4 r0 = rec[3 * jc + 0];
+                const float4 r1 = rec[3 * jc + 1];
+                const float4 r2 = rec[3 * jc + 2];
+                const float dx = r0.x - ppx;
+                const float dy = r0.y - ppy;
+                const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+                const float a = sel_min(0.99f, r1.y * gsr_expf(power));
+                const bool ok = valid && power <= 0.0f && a >= 1.0f / 255.0f;
+                unsigned long long hits = __ballot(ok);
+                while (hits) {
+                    const int k = __builtin_ctzll(hits);
+                    hits &= hits - 1;
+                    const float ak = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), k));
+                    const float test_T = Tp * (1.0f - ak);
+                    if (test_T < 0.0001f) { donep = true; break; }
+                    A0 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.z), k)) * ak * Tp;
+                    A1 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.w), k)) * ak * Tp;
+                    A2 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r2.x), k)) * ak * Tp;
+                    Tp = test_T;
+                    lastp = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(r2.z), k) + 1u;
+                    lastqp = (uint32_t)(c0 + k + 1);
+                }
+            }
+            if (lane == p) { T = Tp; C0 = A0; C1 = A1; C2 = A2; last_contributor = lastp; last_q = lastqp; }
         }
     }
     if (inside) {
         const int pix_id = W * pyi + pxi;
         final_T[pix_id] = T;
         n_contrib[pix_id] = last_contributor;
+        n_contrib_q[pix_id] = last_q;
         const size_t HW = (size_t)H * W;
         out_color[0 * HW + pix_id] = C0 + T * s.bg[0];
         out_color[1 * HW + pix_id] = C1 + T * s.bg[1];

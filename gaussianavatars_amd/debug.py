@@ -58,10 +58,12 @@ def forward_state(rs: GaussianRasterizationSettings, means3D, shs, colors_precom
         clamped=_view(geom, gl.clamped, P, torch.uint8),
         keys=_view(binning, bl.keys, I, torch.int64),
         point_list=_view(binning, bl.point_list, I, u32),
-        records=_view(binning, bl.records, 12 * I, f32).view(I, 12),
+        qrecords=_view(binning, bl.qrecords, 12 * 4 * cap, f32).view(4 * cap, 12),
+        qcount=_view(binning, bl.qcount, 4 * tiles, u32).view(tiles, 4),
         ranges=_view(binning, bl.ranges, 2 * tiles, u32).view(tiles, 2),
         tile_count=_view(binning, bl.tile_count, tiles, u32),
         final_T=_view(img, il.final_T, H * W, f32).view(H, W),
         n_contrib=_view(img, il.n_contrib, H * W, u32).view(H, W),
+        n_contrib_q=_view(img, il.n_contrib_q, H * W, u32).view(H, W),
     )
     return out

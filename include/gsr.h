@@ -75,7 +75,9 @@ typedef struct GsrGeomLayout {
 typedef struct GsrBinningLayout {
     size_t keys;        /* uint64 [cap]  sorted (tile << 32 | depth bits), upstream's point_list_keys */
     size_t point_list;  /* uint32 [cap]  sorted splat index, upstream's point_list                    */
-    size_t records;     /* float4 [3cap] sorted per-instance record (x,y,A,B | C,opacity,r,g | b,idx,-,-) */
+    size_t qrecords;    /* float4 [3*4cap] per tile (at 4*start) four 8x8-quadrant streams of up to n records each,
+                           record = (x,y,A,B | C,opacity,r,g | b, splat idx, index in the tile list, -)          */
+    size_t qcount;      /* uint32 [4*tiles] records in each quadrant stream                                       */
     size_t ranges;      /* uint32 [2*tiles]  [start,end) per tile, (0,0) when empty                   */
     size_t tile_count;  /* uint32 [tiles]                                                            */
     size_t tile_start;  /* uint32 [tiles]                                                            */
@@ -85,7 +87,8 @@ typedef struct GsrBinningLayout {
 
 typedef struct GsrImageLayout {
     size_t final_T;    /* float  [H*W] */
-    size_t n_contrib;  /* uint32 [H*W] */
+    size_t n_contrib;  /* uint32 [H*W] last contributor, index+1 in the TILE list (== the reference's n_contrib) */
+    size_t n_contrib_q;/* uint32 [H*W] the same position inside the pixel's quadrant stream (what the backward walks) */
     size_t total;
 } GsrImageLayout;
 

@@ -40,10 +40,10 @@ def test_layouts_are_disjoint_and_aligned():
     segs = [(gl.depths, 4 * P), (gl.xy, 8 * P), (gl.conic_opacity, 16 * P), (gl.rgb, 16 * P), (gl.cov3D, 24 * P),
             (gl.rect, 8 * P), (gl.tiles_touched, 4 * P), (gl.clamped, P)]
     _check(segs, gl.total)
-    segs = [(bl.keys, 8 * cap), (bl.point_list, 4 * cap), (bl.records, 48 * cap), (bl.ranges, 8 * tiles),
+    segs = [(bl.keys, 8 * cap), (bl.point_list, 4 * cap), (bl.qrecords, 4 * 48 * cap), (bl.qcount, 16 * tiles), (bl.ranges, 8 * tiles),
             (bl.tile_count, 4 * tiles), (bl.tile_start, 4 * tiles), (bl.tile_cursor, 4 * tiles)]
     _check(segs, bl.total)
-    _check([(il.final_T, 4 * HW), (il.n_contrib, 4 * HW)], il.total)
+    _check([(il.final_T, 4 * HW), (il.n_contrib, 4 * HW), (il.n_contrib_q, 4 * HW)], il.total)
     assert lib.gsr_geom_layout(-1, C.byref(gl)) < 0 and b"bad arguments" in lib.gsr_last_error()
 
 

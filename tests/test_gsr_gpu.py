@@ -76,14 +76,25 @@ def _check_forward(st, hs):
     assert np.array_equal(_np(hs["final_T"]).view(np.uint32), st.final_T.view(np.uint32))
     img = _np(hs["color"])
     assert np.array_equal(img.view(np.uint32), st.color.view(np.uint32)), f"image max abs diff {np.abs(img - st.color).max()}"
-    # records carry the same geometry in sorted order
-    rec = _np(hs["records"])
-    if I:
-        pl = st.point_list
-        np.testing.assert_array_equal(rec[:, 0:2], st.xy[pl])
-        np.testing.assert_array_equal(rec[:, 2:6], st.conic_opacity[pl])
-        np.testing.assert_array_equal(rec[:, 6:9], st.rgb[pl])
-        np.testing.assert_array_equal(rec[:, 9].view(np.uint32), pl)
+    # quadrant streams: ordered sub-sequences of the tile list carrying the same geometry
+    qrec, qcnt, rng = _np(hs["qrecords"]), _np(hs["qcount"]).astype(np.int64), st.ranges.astype(np.int64)
+    assert (qcnt <= (rng[:, 1] - rng[:, 0])[:, None]).all()
+    checked = 0
+    for t in np.argsort(-(rng[:, 1] - rng[:, 0]))[:6]:
+        n, start = rng[t, 1] - rng[t, 0], rng[t, 0]
+        if n == 0:
+            continue
+        for q in range(4):
+            r = qrec[4 * start + q * n: 4 * start + q * n + qcnt[t, q]]
+            pos = r[:, 10].view(np.uint32).astype(np.int64)
+            assert (np.diff(pos) > 0).all() and (pos < n).all()
+            ids = st.point_list[start + pos]
+            np.testing.assert_array_equal(r[:, 9].view(np.uint32), ids)
+            np.testing.assert_array_equal(r[:, 0:2], st.xy[ids])
+            np.testing.assert_array_equal(r[:, 2:6], st.conic_opacity[ids])
+            np.testing.assert_array_equal(r[:, 6:9], st.rgb[ids])
+            checked += 1
+    assert checked or I == 0
 
 
 @pytest.mark.parametrize("name", ["cfg1", "sh3_small", "sh2_mod", "culls", "dense_tile", "empty_view"])
