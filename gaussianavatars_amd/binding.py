@@ -117,8 +117,9 @@ class _FlameForward(torch.autograd.Function):
         scratch = torch.empty(3 * V, **f32)
         gv = torch.zeros((V, 3), **f32) if g_verts is None else _f32(g_verts)
         gvs = None if g_vshaped is None else _f32(g_vshaped)
+        ws_bwd = ws.clone()  # the backward accumulates into its workspace; keep the saved one pristine
         with torch.cuda.device(dev):
-            _chk(lib.gab_flame_backward(C.byref(rig), *[_p(t) for t in ins], _p(so), _p(v_shaped), _p(ws.clone()), _p(gv), _p(gvs),
+            _chk(lib.gab_flame_backward(C.byref(rig), *[_p(t) for t in ins], _p(so), _p(v_shaped), _p(ws_bwd), _p(gv), _p(gvs),
                                         _p(d_shape), _p(d_expr), _p(d_rot), _p(d_neck), _p(d_jaw), _p(d_eyes), _p(d_trans), _p(d_so),
                                         _p(scratch), _stream(dev)), "gab_flame_backward")
         sh = ctx.shapes

@@ -297,17 +297,22 @@ __global__ void k_chain_bwd(Rig rig, float* __restrict__ ws, const float* __rest
                             float* __restrict__ d_neck, float* __restrict__ d_jaw, float* __restrict__ d_eyes,
                             float* __restrict__ d_translation)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // stage the whole workspace through LDS with one coalesced pass, then a single lane runs the
+    // (inherently serial, 5-joint) chain out of LDS instead of ~250 dependent global loads
+    __shared__ float sw[GAB_FLAME_WS_FLOATS];
+    for (int k = threadIdx.x; k < GAB_FLAME_WS_FLOATS; k += blockDim.x) sw[k] = ws[k];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     float J[15], R[45], Rg[45], tg[15];
-    for (int k = 0; k < 15; ++k) J[k] = ws[WS_J + k];
-    for (int k = 0; k < 45; ++k) R[k] = ws[WS_R + k];
+    for (int k = 0; k < 15; ++k) J[k] = sw[WS_J + k];
+    for (int k = 0; k < 45; ++k) R[k] = sw[WS_R + k];
     chain_forward(rig.parents, R, J, Rg, tg);
     float dRg[45], dtg[15], dJ[15], dR[45];
     for (int k = 0; k < 45; ++k) { dRg[k] = 0.f; dR[k] = 0.f; }
     for (int k = 0; k < 15; ++k) { dtg[k] = 0.f; dJ[k] = 0.f; }
     // A_i = [Rg_i | tg_i - Rg_i J_i]
     for (int i = 0; i < GAB_NUM_JOINTS; ++i) {
-        const float* dA = ws + WS_DA + 12 * i;
+        const float* dA = sw + WS_DA + 12 * i;
         for (int r = 0; r < 3; ++r) {
             const float dAt = dA[4 * r + 3];
             for (int c = 0; c < 3; ++c) {
@@ -344,7 +349,7 @@ __global__ void k_chain_bwd(Rig rig, float* __restrict__ ws, const float* __rest
     for (int k = 0; k < 9; ++k) dR[k] += dRg[k];
     for (int c = 0; c < 3; ++c) dJ[c] += dtg[c];
     for (int j = 1; j < GAB_NUM_JOINTS; ++j)
-        for (int k = 0; k < 9; ++k) dR[9 * j + k] += ws[WS_DPF + 9 * (j - 1) + k];
+        for (int k = 0; k < 9; ++k) dR[9 * j + k] += sw[WS_DPF + 9 * (j - 1) + k];
     const float pose[15] = {rotation[0], rotation[1], rotation[2], neck[0], neck[1], neck[2], jaw[0], jaw[1], jaw[2],
                             eyes[0], eyes[1], eyes[2], eyes[3], eyes[4], eyes[5]};
     float dpose[15];
@@ -353,7 +358,7 @@ __global__ void k_chain_bwd(Rig rig, float* __restrict__ ws, const float* __rest
         d_rotation[k] = dpose[k];
         d_neck[k] = dpose[3 + k];
         d_jaw[k] = dpose[6 + k];
-        d_translation[k] = ws[WS_DT + k];
+        d_translation[k] = sw[WS_DT + k];
     }
     for (int k = 0; k < 6; ++k) d_eyes[k] = dpose[9 + k];
     for (int k = 0; k < 15; ++k) ws[WS_DJ + k] = dJ[k];

@@ -14,6 +14,7 @@
 #define GSR_WAVE 64
 #define GSR_TILE_PIX (GSR_BLOCK_X * GSR_BLOCK_Y)
 #define GSR_SORT_LDS_KEYS 8192   // 64 KiB of uint64 keys per workgroup in the tile sort
+#define GSR_SORT_SMALL_KEYS 2048 // tiles up to this many entries take the 256-thread / 16 KiB class
 #define GSR_ACC_STRIDE 12        // floats per splat in the backward accumulator (48 B, one atomic burst)
 
 namespace gsr {
@@ -205,7 +206,8 @@ __global__ void k_count(int P, int gx, int tiles, const ushort4* rect, const uin
 __global__ void k_scatter(int P, int gx, int tiles, const float* depths, const ushort4* rect, const uint32_t* tiles_touched,
                           const uint32_t* tile_start, uint32_t* tile_cursor, unsigned long long* keys,
                           unsigned long long capacity, const unsigned long long* total_dev);
-__global__ void k_tile_sort(int gx, const uint32_t* tile_count, const uint32_t* tile_start, unsigned long long* keys,
+template <int KEYS, int THREADS>
+__global__ void k_tile_sort(uint32_t n_lo, uint32_t n_hi, int gx, const uint32_t* tile_count, const uint32_t* tile_start, unsigned long long* keys,
                             uint32_t* point_list, float4* qrecords, uint32_t* qcount, const float2* xy, const float4* conic_opacity,
                             const float4* rgb, unsigned long long capacity, const unsigned long long* total_dev);
 __global__ void k_render(Settings s, const uint2* ranges, const uint32_t* qcount, const float4* qrecords, float* final_T,

@@ -382,33 +382,37 @@ __device__ __forceinline__ void bitonic_sort(KeyAcc k, uint32_t n, int tid, int 
     }
 }
 
-__global__ __launch_bounds__(256) void k_tile_sort(int gx, const uint32_t* __restrict__ tile_count,
+// Two size classes share this body: tiles with n_lo < n <= n_hi are handled, the rest exit at once.
+//   small: <= 2048 entries, 256 threads, 16 KiB LDS  (many workgroups per CU)
+//   large: 1024 threads, 64 KiB LDS; beyond 8192 entries the sort runs in place in global memory
+template <int KEYS, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n_hi, int gx, const uint32_t* __restrict__ tile_count,
                                                     const uint32_t* __restrict__ tile_start, unsigned long long* __restrict__ keys,
                                                     uint32_t* __restrict__ point_list, float4* __restrict__ qrecords,
                                                     uint32_t* __restrict__ qcount, const float2* __restrict__ xy,
                                                     const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb,
                                                     unsigned long long capacity, const unsigned long long* __restrict__ total_dev)
 {
-    __shared__ unsigned long long skeys[GSR_SORT_LDS_KEYS];
-    __shared__ uint32_t wave_cnt[4][4];   // [quadrant][wave]
+    __shared__ unsigned long long skeys[KEYS];
+    __shared__ uint32_t wave_cnt[4][THREADS / 64];   // [quadrant][wave]
     if (*total_dev > capacity) return;
     const uint32_t tile = blockIdx.x;
     const uint32_t n = tile_count[tile];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (n == 0) {
-        if (tid < 4) qcount[4 * tile + tid] = 0u;
+    if (n <= n_lo || n > n_hi) {
+        if (n == 0 && n_lo == 0 && tid < 4) qcount[4 * tile + tid] = 0u;
         return;
     }
     const uint32_t start = tile_start[tile];
     unsigned long long* seg = keys + start;
-    const bool in_lds = n <= GSR_SORT_LDS_KEYS;
+    const bool in_lds = n <= (uint32_t)KEYS;
     if (in_lds) {
-        for (uint32_t i = tid; i < n; i += 256) skeys[i] = seg[i];
+        for (uint32_t i = tid; i < n; i += THREADS) skeys[i] = seg[i];
         __syncthreads();
-        bitonic_sort(skeys, n, tid, 256);
+        bitonic_sort(skeys, n, tid, THREADS);
     } else {
         __syncthreads();
-        bitonic_sort(seg, n, tid, 256);  // rare: > 8192 instances in one tile, sort in place in global memory
+        bitonic_sort(seg, n, tid, THREADS);  // rare: > 8192 instances in one tile, sort in place in global memory
     }
     // ---- epilogue: reference-format keys / point list, and the four 8x8-quadrant record streams --------
     // A record goes to quadrant q only if the exact ellipse {alpha >= 1/255} of the splat can reach a pixel
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(int gx, const uint32_t* __res
     const float ox = (float)((tile % (uint32_t)gx) * GSR_BLOCK_X), oy = (float)((tile / (uint32_t)gx) * GSR_BLOCK_Y);
     uint32_t running[4] = {0u, 0u, 0u, 0u};
     float4* const qbase = qrecords + (size_t)3 * 4 * start;
-    for (uint32_t base = 0; base < n; base += 256) {
+    for (uint32_t base = 0; base < n; base += THREADS) {
         const uint32_t i = base + tid;
         const bool valid = i < n;
         bool f[4] = {false, false, false, false};
@@ -436,17 +440,35 @@ __global__ __launch_bounds__(256) void k_tile_sort(int gx, const uint32_t* __res
             r1 = make_float4(co.z, co.w, c.x, c.y);
             r2 = make_float4(c.z, __uint_as_float(idx), __uint_as_float(i), 0.f);
             if (co.w * 255.0f >= 1.0f) {   // alpha = min(0.99, o * G) can reach 1/255 only if o >= 1/255
-                float hx = 3.0e38f, hy = 3.0e38f;
-                const float det = co.x * co.z - co.y * co.y;
-                if (det > 0.f) {
-                    const float tau = logf(255.0f * co.w) * 1.0001f + 1e-3f;       // power >= -tau is necessary
-                    hx = sqrtf(2.f * tau * co.z / det) * 1.01f + 1.0f;             // |dx| <= sqrt(2 tau cov.xx), padded
-                    hy = sqrtf(2.f * tau * co.x / det) * 1.01f + 1.0f;
-                }
+                // alpha >= 1/255  <=>  Q(d) = 1/2 (A dx^2 + 2 B dx dy + C dy^2) <= tau = ln(255 o).  Keep the record
+                // for quadrant q iff the minimum of the convex Q over the quadrant's pixel rectangle can be <= tau
+                // (0 if the centre is inside, else attained on one of the four edges); padded so fp32 rounding in
+                // the blend can never turn a dropped pair into a contributor.
+                const float tau = logf(255.0f * co.w) * 1.0001f + 1e-3f;
+                const float A = co.x, B = co.y, Cc = co.z;
+                const bool pd = A > 0.f && Cc > 0.f && (A * Cc - B * B) > 0.f;
+                auto edge_x = [&](float a, float b0, float b1) {   // dx = a fixed, dy in [b0,b1]
+                    const float dy = fminf(fmaxf(-B * a / Cc, b0), b1);
+                    return 0.5f * (A * a * a + 2.f * B * a * dy + Cc * dy * dy);
+                };
+                auto edge_y = [&](float b, float a0, float a1) {   // dy = b fixed, dx in [a0,a1]
+                    const float dx = fminf(fmaxf(-B * b / A, a0), a1);
+                    return 0.5f * (A * dx * dx + 2.f * B * dx * b + Cc * b * b);
+                };
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float qx0 = ox + (float)((q & 1) * 8), qy0 = oy + (float)((q >> 1) * 8);
-                    f[q] = (p.x + hx >= qx0) && (p.x - hx <= qx0 + 7.f) && (p.y + hy >= qy0) && (p.y - hy <= qy0 + 7.f);
+                    const float a0 = p.x - (qx0 + 7.f), a1 = p.x - qx0;   // dx range over the quadrant's pixel centres
+                    const float b0 = p.y - (qy0 + 7.f), b1 = p.y - qy0;
+                    bool keep = true;
+                    if (pd) {
+                        const bool inside = a0 <= 0.f && a1 >= 0.f && b0 <= 0.f && b1 >= 0.f;
+                        if (!inside) {
+                            const float m = fminf(fminf(edge_x(a0, b0, b1), edge_x(a1, b0, b1)), fminf(edge_y(b0, a0, a1), edge_y(b1, a0, a1)));
+                            keep = m * 0.999f - 1e-3f <= tau;
+                        }
+                    }
+                    f[q] = keep;
                 }
             }
         }
@@ -462,7 +484,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(int gx, const uint32_t* __res
         for (int q = 0; q < 4; ++q) {
             uint32_t off = running[q], tot = 0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < THREADS / 64; ++w) {
                 const uint32_t cw = wave_cnt[q][w];
                 if (w < wid) off += cw;
                 tot += cw;
@@ -479,6 +501,13 @@ __global__ __launch_bounds__(256) void k_tile_sort(int gx, const uint32_t* __res
     }
     if (tid < 4) qcount[4 * tile + tid] = running[tid];
 }
+
+template __global__ void k_tile_sort<GSR_SORT_SMALL_KEYS, 256>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
+                                                                float4*, uint32_t*, const float2*, const float4*, const float4*, unsigned long long,
+                                                                const unsigned long long*);
+template __global__ void k_tile_sort<GSR_SORT_LDS_KEYS, 1024>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
+                                                               float4*, uint32_t*, const float2*, const float4*, const float4*, unsigned long long,
+                                                               const unsigned long long*);
 
 // ------------------------------------------------------------------------------------------
 // k_render: front-to-back compositing.  Workgroup = one 16x16 tile = 4 independent waves, wave w
