@@ -194,22 +194,32 @@ def main():
         with torch.no_grad():
             vis = 1.0
         per_kernel = {k: dict(avg_us=1e3 * ms / max(n, 1), launches=n) for k, (ms, n) in kern.items() if n}
-        # algorithmic bytes per launch; v = visible fraction taken as 1 (measured below)
+        # algorithmic bytes per launch: SURVEY.md 8(d)'s per-unit figures x the units of one frame;
+        # v (visible fraction) = 1 for this scene (measured by the oracle leg below)
+        sort_bytes = 12 * I + 12 * I + 8 * I      # keys+idx written, one ideal sort pass read, range scan
         algo = {
             "k_preprocess": 236 * N + (44 + (27 if train else 0)) * N,
-            "k_scatter": 20 * N + 8 * I,
-            "k_tile_sort": 8 * I + 12 * I + 36 * I + 48 * I,
-            "k_render": 48 * I + (12 + (8 if train else 0)) * HW,
-            "k_render_bwd": 20 * HW + 48 * I + 36 * N,
+            "k_scatter": 12 * I,
+            "k_tile_sort": sort_bytes - 12 * I,
+            "k_render": 40 * I + (12 + (8 if train else 0)) * HW,
+            "k_render_bwd": 20 * HW + 40 * I + 36 * N,
             "k_preprocess_bwd": 300 * N + 256 * N,
         }
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "r01_b_pmc_fetch_write_per_launch.json")
+        if os.path.exists(pmc_path):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/README.md)
+            for k, v in json.load(open(pmc_path)).items():
+                name = k.replace("void ", "").split("::")[-1].split("<")[0]   # the two k_tile_sort classes add up
+                # FETCH_SIZE/WRITE_SIZE are KB; gfx950 FETCH_SIZE counts half of a wide streaming read (MI355X_MICROARCH.md)
+                pmc[name] = pmc.get(name, 0) + int((2 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024)
         roofline = None
         if per_kernel:
             dom = max((k for k in per_kernel if k in algo), key=lambda k: per_kernel[k]["avg_us"] * per_kernel[k]["launches"])
             ach = algo[dom] / (per_kernel[dom]["avg_us"] * 1e-6) / 1e9
             roofline = dict(kernel=dom, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
+                            frac=round(ach / HBM_PEAK_GBS, 5), traffic=pmc.get(dom),
                             algorithmic_bytes_per_launch=int(algo[dom]), avg_launch_us=round(per_kernel[dom]["avg_us"], 2),
+                            note="alpha-blend kernels are VALU/latency-bound (exp + per-wave critical path), HBM fraction reported as asked",
                             all_kernels={k: dict(avg_us=round(v["avg_us"], 2),
                                                  algo_GBs=round(algo[k] / (v["avg_us"] * 1e-6) / 1e9, 1) if k in algo else None)
                                          for k, v in per_kernel.items()})
