@@ -133,6 +133,81 @@ def flame_forward(head, shape, expr, rotation, neck, jaw, eyes, translation, sta
     return _FlameForward.apply(head, shape, expr, rotation, neck, jaw, eyes, translation, static_offset)
 
 
+class _FlameForwardTimestep(torch.autograd.Function):
+    """FLAME forward on row `t` of the per-timestep parameter tables (what select_mesh_by_timestep does,
+    scene/flame_gaussian_model.py:117-135) without the seven fancy-index gathers and their index_put
+    backward: the kernels read row t in place, the backward writes row t of ONE zero-filled buffer whose
+    slices are returned as the gradients of the full (T, k) tables."""
+
+    _ROWS = ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation")
+
+    @staticmethod
+    def forward(ctx, head, t, shape, expr, rotation, neck, jaw, eyes, translation, static_offset):
+        lib = _lib.gab()
+        rig = _rig_struct(head)
+        dev = head.v_template.device
+        V = rig.V
+        tabs = [_f32(x) for x in (expr, rotation, neck, jaw, eyes, translation)]
+        T = tabs[0].shape[0]
+        widths = [int(x.shape[1]) for x in tabs]
+        if widths != [rig.n_expr, 3, 3, 3, 6, 3] or any(x.shape[0] != T for x in tabs) or not (0 <= t < T):
+            raise RuntimeError("flame_forward_timestep: expected (T,n_expr),(T,3),(T,3),(T,3),(T,6),(T,3) tables and 0 <= t < T")
+        sh = _f32(shape).reshape(-1)
+        so = None if static_offset is None else _f32(static_offset).reshape(-1)
+        rows = [C.c_void_p(x.data_ptr() + 4 * t * w) for x, w in zip(tabs, widths)]
+        verts = torch.empty((1, V, 3), dtype=torch.float32, device=dev)
+        v_shaped = torch.empty((1, V, 3), dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.GAB_FLAME_WS_FLOATS, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _chk(lib.gab_flame_forward(C.byref(rig), _p(sh), *rows, _p(so), _p(verts), _p(v_shaped), _p(ws), _stream(dev)),
+                 "gab_flame_forward")
+        ctx.head, ctx.t, ctx.T, ctx.widths = head, t, T, widths
+        ctx.has_so = so is not None
+        ctx.shape_shape = shape.shape
+        ctx.so_shape = None if static_offset is None else static_offset.shape
+        ctx.save_for_backward(sh, *tabs, *([so] if so is not None else []), v_shaped, ws)
+        return verts, v_shaped
+
+    @staticmethod
+    def backward(ctx, g_verts, g_vshaped):
+        lib = _lib.gab()
+        rig = _rig_struct(ctx.head)
+        saved = ctx.saved_tensors
+        sh, tabs = saved[0], list(saved[1:7])
+        so = saved[7] if ctx.has_so else None
+        v_shaped, ws = saved[-2], saved[-1]
+        dev = v_shaped.device
+        V, T, t, widths = rig.V, ctx.T, ctx.t, ctx.widths
+        need = ctx.needs_input_grad  # (head, t, shape, expr, rotation, neck, jaw, eyes, translation, static_offset)
+        f32 = dict(dtype=torch.float32, device=dev)
+        flat = torch.zeros(T * sum(widths), **f32)
+        offs, o = [], 0
+        for w in widths:
+            offs.append(o)
+            o += T * w
+        outp = [C.c_void_p(flat.data_ptr() + 4 * (off + t * w)) for off, w in zip(offs, widths)]
+        d_shape = torch.empty(rig.n_shape, **f32) if need[2] else None
+        d_so = torch.empty(3 * V, **f32) if (ctx.has_so and need[9]) else None
+        scratch = torch.empty(3 * V, **f32)
+        gv = torch.zeros((V, 3), **f32) if g_verts is None else _f32(g_verts)
+        gvs = None if g_vshaped is None else _f32(g_vshaped)
+        ws_bwd = ws.clone()
+        rows = [C.c_void_p(x.data_ptr() + 4 * t * w) for x, w in zip(tabs, widths)]
+        with torch.cuda.device(dev):
+            _chk(lib.gab_flame_backward(C.byref(rig), _p(sh), *rows, _p(so), _p(v_shaped), _p(ws_bwd), _p(gv), _p(gvs), _p(d_shape),
+                                        *outp, _p(d_so), _p(scratch), _stream(dev)), "gab_flame_backward")
+        grads = [flat[off: off + T * w].view(T, w) if need[3 + i] else None for i, (off, w) in enumerate(zip(offs, widths))]
+        return (None, None, None if d_shape is None else d_shape.view(ctx.shape_shape), *grads,
+                None if d_so is None else d_so.view(ctx.so_shape))
+
+
+def flame_forward_timestep(head, flame_param: dict, t: int):
+    """select_mesh_by_timestep's FLAME call on the flame_param dict (npz schema) -> (verts, v_shaped)."""
+    fp = flame_param
+    return _FlameForwardTimestep.apply(head, int(t), fp["shape"], fp["expr"], fp["rotation"], fp["neck_pose"], fp["jaw_pose"],
+                                       fp["eyes_pose"], fp["translation"], fp.get("static_offset"))
+
+
 # -------------------------------------------------------------------------------------------------
 # per-face frames
 # -------------------------------------------------------------------------------------------------

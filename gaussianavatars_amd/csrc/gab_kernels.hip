@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_blend(Rig rig, const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 // small dense helpers for the 5-joint chain (thread-serial; 5 joints)
 // ---------------------------------------------------------------------------------------------
-__device__ inline void rodrigues(const float* r, float* R /*9*/)
+__device__ __forceinline__ void rodrigues(const float* r, float* R /*9*/)
 {
     const float ux = r[0] + 1e-8f, uy = r[1] + 1e-8f, uz = r[2] + 1e-8f;   // epsilon on the vector, then the norm
     const float th = sqrtf(ux * ux + uy * uy + uz * uz);
@@ -101,13 +101,16 @@ __device__ inline void rodrigues(const float* r, float* R /*9*/)
     const float s = sinf(th), c = cosf(th);
     const float K[9] = {0.f, -dz, dy, dz, 0.f, -dx, -dy, dx, 0.f};
     float KK[9];
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j) KK[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+#pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = ((i % 4) == 0 ? 1.f : 0.f) + s * K[i] + (1.f - c) * KK[i];
 }
 
 // gradient of rodrigues w.r.t. the axis-angle vector
-__device__ inline void rodrigues_bwd(const float* r, const float* dR /*9*/, float* dr /*3*/)
+__device__ __forceinline__ void rodrigues_bwd(const float* r, const float* dR /*9*/, float* dr /*3*/)
 {
     const float u[3] = {r[0] + 1e-8f, r[1] + 1e-8f, r[2] + 1e-8f};
     const float th = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
@@ -115,15 +118,21 @@ __device__ inline void rodrigues_bwd(const float* r, const float* dR /*9*/, floa
     const float s = sinf(th), c = cosf(th);
     const float K[9] = {0.f, -d[2], d[1], d[2], 0.f, -d[0], -d[1], d[0], 0.f};
     float KK[9];
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j) KK[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
     float g_s = 0.f, g_c = 0.f;
+#pragma unroll
     for (int i = 0; i < 9; ++i) { g_s += dR[i] * K[i]; g_c -= dR[i] * KK[i]; }
     // dL/dK = s dR + (1-c) (dR K^T + K^T dR)
     float dK[9];
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j) {
             float a = 0.f, b = 0.f;
+#pragma unroll
             for (int k = 0; k < 3; ++k) {
                 a += dR[3 * i + k] * K[3 * j + k];   // dR K^T
                 b += K[3 * k + i] * dR[3 * k + j];   // K^T dR
@@ -133,22 +142,36 @@ __device__ inline void rodrigues_bwd(const float* r, const float* dR /*9*/, floa
     const float gd[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
     float g_th = g_s * c - g_c * s;
     g_th -= (gd[0] * r[0] + gd[1] * r[1] + gd[2] * r[2]) / (th * th);
+#pragma unroll
     for (int k = 0; k < 3; ++k) dr[k] = gd[k] / th + g_th * u[k] / th;
 }
 
 // forward chain: G_i = G_parent [R_i | J_i - J_parent];  A_i = [Rg_i | tg_i - Rg_i J_i]
-__device__ inline void chain_forward(const int* parents, const float* R /*5x9*/, const float* J /*5x3*/, float* Rg /*5x9*/,
-                                     float* tg /*5x3*/)
+// FLAME's kinematic tree.  The serial chain code below indexes small local arrays by parent id; with the
+// tree known at compile time (and every loop unrolled) those arrays stay in registers, a run-time tree
+// sends them to scratch memory (~10x slower for the one lane that runs the chain).
+__device__ constexpr int kFlameParents[GAB_NUM_JOINTS] = {-1, 0, 1, 1, 1};
+template <bool FLAME_TREE>
+__device__ __forceinline__ int parent_of(const int* parents, int i) { return FLAME_TREE ? kFlameParents[i] : parents[i]; }
+
+template <bool FLAME_TREE>
+__device__ __forceinline__ void chain_forward(const int* parents, const float* R /*5x9*/, const float* J /*5x3*/, float* Rg /*5x9*/,
+                                              float* tg /*5x3*/)
 {
+#pragma unroll
     for (int i = 0; i < GAB_NUM_JOINTS; ++i) {
         if (i == 0) {
+#pragma unroll
             for (int k = 0; k < 9; ++k) Rg[k] = R[k];
+#pragma unroll
             for (int k = 0; k < 3; ++k) tg[k] = J[k];
             continue;
         }
-        const int p = parents[i];
+        const int p = parent_of<FLAME_TREE>(parents, i);
         const float rel[3] = {J[3 * i] - J[3 * p], J[3 * i + 1] - J[3 * p + 1], J[3 * i + 2] - J[3 * p + 2]};
+#pragma unroll
         for (int r = 0; r < 3; ++r) {
+#pragma unroll
             for (int c = 0; c < 3; ++c)
                 Rg[9 * i + 3 * r + c] = Rg[9 * p + 3 * r] * R[9 * i + c] + Rg[9 * p + 3 * r + 1] * R[9 * i + 3 + c] +
                                         Rg[9 * p + 3 * r + 2] * R[9 * i + 6 + c];
@@ -160,6 +183,7 @@ __device__ inline void chain_forward(const int* parents, const float* R /*5x9*/,
 // ---------------------------------------------------------------------------------------------
 // F2  joints J = J_regressor . v_shaped (15 sums over V), Rodrigues, kinematic chain -> ws
 // ---------------------------------------------------------------------------------------------
+template <bool FLAME_TREE>
 __global__ __launch_bounds__(256) void k_joints_chain(Rig rig, const float* __restrict__ v_shaped, const float* __restrict__ rotation,
                                                        const float* __restrict__ neck, const float* __restrict__ jaw,
                                                        const float* __restrict__ eyes, float* __restrict__ ws)
@@ -187,17 +211,26 @@ __global__ __launch_bounds__(256) void k_joints_chain(Rig rig, const float* __re
     __syncthreads();
     if (tid == 0) {
         float J[15], R[45], Rg[45], tg[15];
+#pragma unroll
         for (int k = 0; k < 15; ++k) J[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
         const float pose[15] = {rotation[0], rotation[1], rotation[2], neck[0], neck[1], neck[2], jaw[0], jaw[1], jaw[2],
                                 eyes[0], eyes[1], eyes[2], eyes[3], eyes[4], eyes[5]};
+#pragma unroll
         for (int j = 0; j < GAB_NUM_JOINTS; ++j) rodrigues(pose + 3 * j, R + 9 * j);
-        chain_forward(rig.parents, R, J, Rg, tg);
+        chain_forward<FLAME_TREE>(rig.parents, R, J, Rg, tg);
+#pragma unroll
         for (int k = 0; k < 15; ++k) ws[WS_J + k] = J[k];
+#pragma unroll
         for (int k = 0; k < 45; ++k) ws[WS_R + k] = R[k];
+#pragma unroll
         for (int j = 1; j < GAB_NUM_JOINTS; ++j)
+#pragma unroll
             for (int k = 0; k < 9; ++k) ws[WS_PF + 9 * (j - 1) + k] = R[9 * j + k] - ((k % 4) == 0 ? 1.f : 0.f);
+#pragma unroll
         for (int j = 0; j < GAB_NUM_JOINTS; ++j)
+#pragma unroll
             for (int r = 0; r < 3; ++r) {
+#pragma unroll
                 for (int c = 0; c < 3; ++c) ws[WS_A + 12 * j + 4 * r + c] = Rg[9 * j + 3 * r + c];
                 ws[WS_A + 12 * j + 4 * r + 3] = tg[3 * j + r] - (Rg[9 * j + 3 * r] * J[3 * j] + Rg[9 * j + 3 * r + 1] * J[3 * j + 1] +
                                                                  Rg[9 * j + 3 * r + 2] * J[3 * j + 2]);
@@ -292,7 +325,8 @@ __global__ __launch_bounds__(256) void k_skin_bwd(Rig rig, float* __restrict__ w
 // ---------------------------------------------------------------------------------------------
 // B2  chain backward (one thread; 5 joints): dA, d pose_feature -> d pose (15), dJ (15)
 // ---------------------------------------------------------------------------------------------
-__global__ void k_chain_bwd(Rig rig, float* __restrict__ ws, const float* __restrict__ rotation, const float* __restrict__ neck,
+template <bool FLAME_TREE>
+__global__ __launch_bounds__(64) void k_chain_bwd(Rig rig, float* __restrict__ ws, const float* __restrict__ rotation, const float* __restrict__ neck,
                             const float* __restrict__ jaw, const float* __restrict__ eyes, float* __restrict__ d_rotation,
                             float* __restrict__ d_neck, float* __restrict__ d_jaw, float* __restrict__ d_eyes,
                             float* __restrict__ d_translation)
@@ -300,21 +334,28 @@ __global__ void k_chain_bwd(Rig rig, float* __restrict__ ws, const float* __rest
     // stage the whole workspace through LDS with one coalesced pass, then a single lane runs the
     // (inherently serial, 5-joint) chain out of LDS instead of ~250 dependent global loads
     __shared__ float sw[GAB_FLAME_WS_FLOATS];
-    for (int k = threadIdx.x; k < GAB_FLAME_WS_FLOATS; k += blockDim.x) sw[k] = ws[k];
+    for (int kk = threadIdx.x; kk < GAB_FLAME_WS_FLOATS; kk += 64) sw[kk] = ws[kk];
     __syncthreads();
     if (threadIdx.x != 0) return;
     float J[15], R[45], Rg[45], tg[15];
+#pragma unroll
     for (int k = 0; k < 15; ++k) J[k] = sw[WS_J + k];
+#pragma unroll
     for (int k = 0; k < 45; ++k) R[k] = sw[WS_R + k];
-    chain_forward(rig.parents, R, J, Rg, tg);
+    chain_forward<FLAME_TREE>(rig.parents, R, J, Rg, tg);
     float dRg[45], dtg[15], dJ[15], dR[45];
+#pragma unroll
     for (int k = 0; k < 45; ++k) { dRg[k] = 0.f; dR[k] = 0.f; }
+#pragma unroll
     for (int k = 0; k < 15; ++k) { dtg[k] = 0.f; dJ[k] = 0.f; }
     // A_i = [Rg_i | tg_i - Rg_i J_i]
+#pragma unroll
     for (int i = 0; i < GAB_NUM_JOINTS; ++i) {
         const float* dA = sw + WS_DA + 12 * i;
+#pragma unroll
         for (int r = 0; r < 3; ++r) {
             const float dAt = dA[4 * r + 3];
+#pragma unroll
             for (int c = 0; c < 3; ++c) {
                 dRg[9 * i + 3 * r + c] += dA[4 * r + c] - dAt * J[3 * i + c];
                 dJ[3 * i + c] -= Rg[9 * i + 3 * r + c] * dAt;
@@ -322,22 +363,29 @@ __global__ void k_chain_bwd(Rig rig, float* __restrict__ ws, const float* __rest
             dtg[3 * i + r] += dAt;
         }
     }
+#pragma unroll
     for (int i = GAB_NUM_JOINTS - 1; i >= 1; --i) {
-        const int p = rig.parents[i];
+        const int p = parent_of<FLAME_TREE>(rig.parents, i);
         const float rel[3] = {J[3 * i] - J[3 * p], J[3 * i + 1] - J[3 * p + 1], J[3 * i + 2] - J[3 * p + 2]};
         float drel[3] = {0.f, 0.f, 0.f};
+#pragma unroll
         for (int r = 0; r < 3; ++r) {
+#pragma unroll
             for (int c = 0; c < 3; ++c) {
                 dRg[9 * p + 3 * r + c] += dtg[3 * i + r] * rel[c];
                 drel[c] += Rg[9 * p + 3 * r + c] * dtg[3 * i + r];
             }
             dtg[3 * p + r] += dtg[3 * i + r];
         }
+#pragma unroll
         for (int c = 0; c < 3; ++c) { dJ[3 * i + c] += drel[c]; dJ[3 * p + c] -= drel[c]; }
         // Rg_i = Rg_p R_i
+#pragma unroll
         for (int r = 0; r < 3; ++r)
+#pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float a = 0.f, b = 0.f;
+#pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     a += dRg[9 * i + 3 * r + k] * R[9 * i + 3 * c + k];      // dRg_i R_i^T
                     b += Rg[9 * p + 3 * k + r] * dRg[9 * i + 3 * k + c];     // Rg_p^T dRg_i
@@ -346,21 +394,29 @@ __global__ void k_chain_bwd(Rig rig, float* __restrict__ ws, const float* __rest
                 dR[9 * i + 3 * r + c] += b;
             }
     }
+#pragma unroll
     for (int k = 0; k < 9; ++k) dR[k] += dRg[k];
+#pragma unroll
     for (int c = 0; c < 3; ++c) dJ[c] += dtg[c];
+#pragma unroll
     for (int j = 1; j < GAB_NUM_JOINTS; ++j)
+#pragma unroll
         for (int k = 0; k < 9; ++k) dR[9 * j + k] += sw[WS_DPF + 9 * (j - 1) + k];
     const float pose[15] = {rotation[0], rotation[1], rotation[2], neck[0], neck[1], neck[2], jaw[0], jaw[1], jaw[2],
                             eyes[0], eyes[1], eyes[2], eyes[3], eyes[4], eyes[5]};
     float dpose[15];
+#pragma unroll
     for (int j = 0; j < GAB_NUM_JOINTS; ++j) rodrigues_bwd(pose + 3 * j, dR + 9 * j, dpose + 3 * j);
+#pragma unroll
     for (int k = 0; k < 3; ++k) {
         d_rotation[k] = dpose[k];
         d_neck[k] = dpose[3 + k];
         d_jaw[k] = dpose[6 + k];
         d_translation[k] = sw[WS_DT + k];
     }
+#pragma unroll
     for (int k = 0; k < 6; ++k) d_eyes[k] = dpose[9 + k];
+#pragma unroll
     for (int k = 0; k < 15; ++k) ws[WS_DJ + k] = dJ[k];
 }
 
@@ -708,7 +764,11 @@ int gab_flame_forward(const GabRig* rig_, const float* shape, const float* expr,
     const int E = 3 * rig.V;
     hipLaunchKernelGGL(gab::k_blend, dim3((E + 3) / 4), dim3(256), 0, st, rig, shape, expr, static_offset, v_shaped);
     LAUNCH_CHECK("k_blend");
-    hipLaunchKernelGGL(gab::k_joints_chain, dim3(1), dim3(256), 0, st, rig, (const float*)v_shaped, rotation, neck, jaw, eyes, ws);
+    const bool flame_tree = rig.parents[1] == 0 && rig.parents[2] == 1 && rig.parents[3] == 1 && rig.parents[4] == 1;
+    if (flame_tree)
+        hipLaunchKernelGGL(gab::k_joints_chain<true>, dim3(1), dim3(256), 0, st, rig, (const float*)v_shaped, rotation, neck, jaw, eyes, ws);
+    else
+        hipLaunchKernelGGL(gab::k_joints_chain<false>, dim3(1), dim3(256), 0, st, rig, (const float*)v_shaped, rotation, neck, jaw, eyes, ws);
     LAUNCH_CHECK("k_joints_chain");
     hipLaunchKernelGGL(gab::k_skin, dim3((rig.V + 255) / 256), dim3(256), 0, st, rig, (const float*)ws, (const float*)v_shaped, translation, verts);
     LAUNCH_CHECK("k_skin");
@@ -734,7 +794,11 @@ int gab_flame_backward(const GabRig* rig_, const float* shape, const float* expr
     if (d_shape) HIP_TRY(hipMemsetAsync(d_shape, 0, (size_t)rig.n_shape * sizeof(float), st));
     hipLaunchKernelGGL(gab::k_skin_bwd, dim3((rig.V + 255) / 256), dim3(256), 0, st, rig, ws, v_shaped, dL_dverts, scratch);
     LAUNCH_CHECK("k_skin_bwd");
-    hipLaunchKernelGGL(gab::k_chain_bwd, dim3(1), dim3(64), 0, st, rig, ws, rotation, neck, jaw, eyes, d_rotation, d_neck, d_jaw, d_eyes, d_translation);
+    const bool flame_tree = rig.parents[1] == 0 && rig.parents[2] == 1 && rig.parents[3] == 1 && rig.parents[4] == 1;
+    if (flame_tree)
+        hipLaunchKernelGGL(gab::k_chain_bwd<true>, dim3(1), dim3(64), 0, st, rig, ws, rotation, neck, jaw, eyes, d_rotation, d_neck, d_jaw, d_eyes, d_translation);
+    else
+        hipLaunchKernelGGL(gab::k_chain_bwd<false>, dim3(1), dim3(64), 0, st, rig, ws, rotation, neck, jaw, eyes, d_rotation, d_neck, d_jaw, d_eyes, d_translation);
     LAUNCH_CHECK("k_chain_bwd");
     hipLaunchKernelGGL(gab::k_blend_bwd, dim3((E + GAB_BLEND_BWD_ROWS - 1) / GAB_BLEND_BWD_ROWS), dim3(256), 0, st, rig, (const float*)ws,
                        (const float*)scratch, dL_dv_shaped, d_static_offset, d_shape, d_expr);

@@ -203,6 +203,11 @@ class FlameGaussianModel(GaussianModel):
     def select_mesh_by_timestep(self, timestep, original=False):
         self.timestep = timestep
         fp = self.flame_param_orig if original and self.flame_param_orig is not None else self.flame_param
+        if self.binding_impl == "fused":
+            from . import binding as fused
+            verts, verts_cano = fused.flame_forward_timestep(self.flame_model, fp, timestep)
+            self.update_mesh_properties(verts, verts_cano)
+            return
         verts, verts_cano = self.flame_model(
             fp["shape"][None, ...], fp["expr"][[timestep]], fp["rotation"][[timestep]], fp["neck_pose"][[timestep]],
             fp["jaw_pose"][[timestep]], fp["eyes_pose"][[timestep]], fp["translation"][[timestep]],
