@@ -128,6 +128,7 @@ GAB_SYMBOLS = {
     "gab_face_frames_backward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "gab_bind_forward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gab_bind_backward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gab_bind_backward_csr": (C.c_int, [C.c_int32, C.c_int32] + [_P] * 16),
 }
 
 _gab = None

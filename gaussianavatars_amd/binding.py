@@ -252,9 +252,19 @@ def face_frames(verts, faces):
 # -------------------------------------------------------------------------------------------------
 # per-splat local -> world
 # -------------------------------------------------------------------------------------------------
+def binding_csr(binding: torch.Tensor, num_faces: int):
+    """(order int32 (N,), face_begin int32 (F+1,)) for gab_bind_backward_csr; depends on `binding` only."""
+    b = binding.detach().long()
+    order = torch.sort(b, stable=True).indices.to(torch.int32).contiguous()
+    counts = torch.bincount(b, minlength=num_faces)
+    face_begin = torch.zeros(num_faces + 1, dtype=torch.int32, device=b.device)
+    face_begin[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return order, face_begin
+
+
 class _BindSplats(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, log_scaling, rotation, binding, face_R, face_scale, face_center, face_quat):
+    def forward(ctx, xyz, log_scaling, rotation, binding, face_R, face_scale, face_center, face_quat, csr=None):
         lib = _lib.gab()
         _need_cuda(xyz, "_xyz")
         dev = xyz.device
@@ -269,6 +279,7 @@ class _BindSplats(torch.autograd.Function):
                                       _stream(dev)), "gab_bind_forward")
         ctx.save_for_backward(x, ls, q, b, fR, fs, fc, fq)
         ctx.is64 = is64
+        ctx.csr = csr
         return ox, osc, oq
 
     @staticmethod
@@ -282,11 +293,19 @@ class _BindSplats(torch.autograd.Function):
         d_face = torch.empty((F, 17), **f32)
         gs = [None if g is None else _f32(g) for g in (g_xyz, g_scaling, g_rot)]
         with torch.cuda.device(dev):
-            _chk(lib.gab_bind_backward(N, F, _p(x), _p(ls), _p(q), _p(b), ctx.is64, _p(fc), _p(fR), _p(fs), _p(fq), _p(gs[0]), _p(gs[1]),
-                                       _p(gs[2]), _p(d_x), _p(d_ls), _p(d_q), _p(d_face), _stream(dev)), "gab_bind_backward")
-        return (d_x, d_ls, d_q, None, d_face[:, 3:12].reshape(F, 3, 3), d_face[:, 12:13], d_face[:, 0:3], d_face[:, 13:17])
+            if ctx.csr is not None:
+                order, face_begin = ctx.csr
+                _chk(lib.gab_bind_backward_csr(N, F, _p(x), _p(ls), _p(q), _p(fR), _p(fs), _p(fq), _p(gs[0]), _p(gs[1]), _p(gs[2]),
+                                               _p(order), _p(face_begin), _p(d_x), _p(d_ls), _p(d_q), _p(d_face), _stream(dev)),
+                     "gab_bind_backward_csr")
+            else:
+                _chk(lib.gab_bind_backward(N, F, _p(x), _p(ls), _p(q), _p(b), ctx.is64, _p(fc), _p(fR), _p(fs), _p(fq), _p(gs[0]),
+                                           _p(gs[1]), _p(gs[2]), _p(d_x), _p(d_ls), _p(d_q), _p(d_face), _stream(dev)),
+                     "gab_bind_backward")
+        return (d_x, d_ls, d_q, None, d_face[:, 3:12].reshape(F, 3, 3), d_face[:, 12:13], d_face[:, 0:3], d_face[:, 13:17], None)
 
 
-def bind_splats(xyz, log_scaling, rotation, binding, face_R, face_scale, face_center, face_quat):
-    """-> (get_xyz, get_scaling, get_rotation) of a mesh-bound GaussianModel, in one kernel."""
-    return _BindSplats.apply(xyz, log_scaling, rotation, binding, face_R, face_scale, face_center, face_quat)
+def bind_splats(xyz, log_scaling, rotation, binding, face_R, face_scale, face_center, face_quat, csr=None):
+    """-> (get_xyz, get_scaling, get_rotation) of a mesh-bound GaussianModel, in one kernel.
+    csr = binding_csr(binding, F) selects the atomic-free deterministic backward."""
+    return _BindSplats.apply(xyz, log_scaling, rotation, binding, face_R, face_scale, face_center, face_quat, csr)

@@ -705,6 +705,87 @@ __global__ __launch_bounds__(256) void k_bind_bwd(int N, const float* __restrict
     }
 }
 
+// Atomic-free variant: splats are visited face by face through a CSR (order, face_begin) built once per
+// binding change.  8 lanes share a face (lane k takes splats k, k+8, ...), the 17 per-face sums are reduced
+// over the 8 lanes on the DPP network and written once -- deterministic, no memset, no L2 atomics.
+__global__ __launch_bounds__(256) void k_bind_bwd_csr(int F, const float* __restrict__ xyz, const float* __restrict__ log_scaling,
+                                                       const float* __restrict__ rotation, const float* __restrict__ fR,
+                                                       const float* __restrict__ fs, const float* __restrict__ fq,
+                                                       const float* __restrict__ g_xyz, const float* __restrict__ g_scaling,
+                                                       const float* __restrict__ g_rot, const int* __restrict__ order,
+                                                       const int* __restrict__ face_begin, float* __restrict__ d_xyz,
+                                                       float* __restrict__ d_log_scaling, float* __restrict__ d_rotation,
+                                                       float* __restrict__ d_face)
+{
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = gtid >> 3, sub = gtid & 7;
+    const bool okf = f < F;
+    float acc[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) acc[k] = 0.f;
+    if (okf) {
+        const float s = fs[f];
+        float R[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = fR[9 * f + k];
+        const float4 qf = reinterpret_cast<const float4*>(fq)[f];
+        const float na = qnorm_clamped(qf);
+        const float4 a = make_float4(qf.x / na, qf.y / na, qf.z / na, qf.w / na);
+        const int b0 = face_begin[f], b1 = face_begin[f + 1];
+        for (int j = b0 + sub; j < b1; j += 8) {
+            const int i = order[j];
+            const float x[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+            const float gx[3] = {g_xyz ? g_xyz[3 * i] : 0.f, g_xyz ? g_xyz[3 * i + 1] : 0.f, g_xyz ? g_xyz[3 * i + 2] : 0.f};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d_xyz[3 * i + c] = s * (R[c] * gx[0] + R[3 + c] * gx[1] + R[6 + c] * gx[2]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                acc[r] += gx[r];
+                acc[12] += gx[r] * (R[3 * r] * x[0] + R[3 * r + 1] * x[1] + R[3 * r + 2] * x[2]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[3 + 3 * r + c] += s * gx[r] * x[c];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float e = expf(log_scaling[3 * i + k]);
+                const float g = g_scaling ? g_scaling[3 * i + k] : 0.f;
+                d_log_scaling[3 * i + k] = g * e * s;
+                acc[12] += g * e;
+            }
+            const float4 q = reinterpret_cast<const float4*>(rotation)[i];
+            const float nb = qnorm_clamped(q);
+            const float4 b = make_float4(q.x / nb, q.y / nb, q.z / nb, q.w / nb);
+            const float4 g = g_rot ? reinterpret_cast<const float4*>(g_rot)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 da = qmul(g, qconj(b));
+            const float4 db = qmul(qconj(a), g);
+            const float ada = a.x * da.x + a.y * da.y + a.z * da.z + a.w * da.w;
+            const float bdb = b.x * db.x + b.y * db.y + b.z * db.z + b.w * db.w;
+            reinterpret_cast<float4*>(d_rotation)[i] =
+                make_float4((db.x - b.x * bdb) / nb, (db.y - b.y * bdb) / nb, (db.z - b.z * bdb) / nb, (db.w - b.w * bdb) / nb);
+            acc[13] += (da.x - a.x * ada) / na;
+            acc[14] += (da.y - a.y * ada) / na;
+            acc[15] += (da.z - a.z * ada) / na;
+            acc[16] += (da.w - a.w * ada) / na;
+        }
+    }
+    // 8-lane sums (quad xor 1, xor 2, half-row mirror); every lane of the group ends with the total
+#pragma unroll
+    for (int k = 0; k < 17; ++k) {
+        float v = acc[k];
+        v += dpp_f<0xB1, 0xf>(v);
+        v += dpp_f<0x4E, 0xf>(v);
+        v += dpp_f<0x141, 0xf>(v);
+        acc[k] = v;
+    }
+    if (okf) {
+        // lanes 0..7 of the group write 17 floats: lane k writes k, k+8, k+16
+        float* df = d_face + 17 * f;
+#pragma unroll
+        for (int k = 0; k < 17; ++k)
+            if ((k & 7) == sub) df[k] = acc[k];
+    }
+}
+
 }  // namespace gab
 
 // =================================================================================================
@@ -865,6 +946,24 @@ int gab_bind_backward(int32_t N, int32_t F, const float* xyz, const float* log_s
     hipLaunchKernelGGL(gab::k_bind_bwd, dim3((N + 255) / 256), dim3(256), 0, st, N, xyz, log_scaling, rotation, binding, is64, face_orien_mat,
                        face_scaling, face_orien_quat, d_out_xyz, d_out_scaling, d_out_rotation, d_xyz, d_log_scaling, d_rotation, d_face);
     LAUNCH_CHECK("k_bind_bwd");
+    return GAB_OK;
+}
+
+int gab_bind_backward_csr(int32_t N, int32_t F, const float* xyz, const float* log_scaling, const float* rotation,
+                          const float* face_orien_mat, const float* face_scaling, const float* face_orien_quat,
+                          const float* d_out_xyz, const float* d_out_scaling, const float* d_out_rotation, const int32_t* order,
+                          const int32_t* face_begin, float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face, void* stream_)
+{
+    if (N < 0 || F <= 0) return fail(GAB_E_ARG, "bad sizes");
+    if (!d_face || !order || !face_begin) return fail(GAB_E_ARG, "gab_bind_backward_csr: NULL buffer");
+    if (N > 0 && (!xyz || !log_scaling || !rotation || !face_orien_mat || !face_scaling || !face_orien_quat || !d_xyz || !d_log_scaling ||
+                  !d_rotation))
+        return fail(GAB_E_ARG, "gab_bind_backward_csr: NULL buffer");
+    const long long threads = 8ll * F;
+    hipLaunchKernelGGL(gab::k_bind_bwd_csr, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, F, xyz, log_scaling,
+                       rotation, face_orien_mat, face_scaling, face_orien_quat, d_out_xyz, d_out_scaling, d_out_rotation, order, face_begin,
+                       d_xyz, d_log_scaling, d_rotation, d_face);
+    LAUNCH_CHECK("k_bind_bwd_csr");
     return GAB_OK;
 }
 

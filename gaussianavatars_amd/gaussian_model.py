@@ -125,8 +125,12 @@ class GaussianModel:
                        unfused.bind_rotation(self._rotation, self.binding, self.face_orien_quat))
             else:
                 from . import binding as fused
+                ckey = (id(self.binding), self.binding._version, self.face_center.shape[0])
+                if getattr(self, "_csr_key", None) != ckey:   # rebuilt only when the binding changes (densification)
+                    self._csr = fused.binding_csr(self.binding, self.face_center.shape[0])
+                    self._csr_key = ckey
                 out = fused.bind_splats(self._xyz, self._scaling, self._rotation, self.binding, self.face_orien_mat,
-                                        self.face_scaling, self.face_center, self.face_orien_quat)
+                                        self.face_scaling, self.face_center, self.face_orien_quat, csr=self._csr)
             self._bound_cache = out
             self._bound_key = key
         return self._bound_cache

@@ -90,6 +90,15 @@ int gab_bind_backward(int32_t N, int32_t F, const float* xyz, const float* log_s
                       const float* d_out_xyz, const float* d_out_scaling, const float* d_out_rotation,
                       float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face /*(F,17)*/, void* stream);
 
+/* Atomic-free, deterministic variant of gab_bind_backward.  `order` (int32 N): splat indices sorted by face;
+ * `face_begin` (int32 F+1): CSR offsets into `order`.  Both depend only on `binding` (build them once per
+ * densification step).  Every splat must appear exactly once; d_face needs no zero-fill. */
+int gab_bind_backward_csr(int32_t N, int32_t F, const float* xyz, const float* log_scaling, const float* rotation,
+                          const float* face_orien_mat, const float* face_scaling, const float* face_orien_quat,
+                          const float* d_out_xyz, const float* d_out_scaling, const float* d_out_rotation,
+                          const int32_t* order, const int32_t* face_begin,
+                          float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face /*(F,17)*/, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

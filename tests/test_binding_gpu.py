@@ -111,7 +111,8 @@ def test_face_frames_and_bind_forward_backward_vs_torch():
         c2, R2, s2, q2 = U.face_frames(vb, fa.long())
         for n, x, y in (("center", c1, c2), ("R", R1, R2), ("scale", s1, s2), ("quat", q1, q2)):
             _close(x, y, 5e-5, f"face {n}")
-        o1 = B.bind_splats(xa, sa, ra, binding, R1, s1, c1, q1)
+        csr = B.binding_csr(binding, fa.shape[0]) if idx_dtype == torch.int32 else None   # both backward variants
+        o1 = B.bind_splats(xa, sa, ra, binding, R1, s1, c1, q1, csr=csr)
         o2 = (U.bind_xyz(xb, binding, R2, s2, c2), U.bind_scaling(sb, binding, s2), U.bind_rotation(rb, binding, q2))
         gen = torch.Generator(device="cpu").manual_seed(1)
         loss1 = loss2 = 0.0
