@@ -382,6 +382,100 @@ __device__ __forceinline__ void bitonic_sort(KeyAcc k, uint32_t n, int tid, int 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Register-resident block sort for the in-LDS size classes: 8 keys per thread (index i = 8*tid + k).
+// Same normalised bitonic network as bitonic_sort() above, but a compare-exchange whose partner index
+// i ^ M differs only in the low 3 bits is done in registers, one that differs in lane bits goes through
+// the cross-lane network (ds_bpermute), and only masks reaching across waves (M >= 512) touch LDS with
+// a barrier: 10 barrier steps instead of 91 for 8192 keys.  Every mask is a compile-time constant, so
+// the key array stays in VGPRs.  Slots >= n hold ~0 (+inf) and sink to the end.
+// ------------------------------------------------------------------------------------------
+typedef unsigned long long u64;
+__device__ __forceinline__ u64 shfl64(u64 v, int src_lane)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)v);
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)(v >> 32));
+    return ((u64)(uint32_t)hi << 32) | (u64)(uint32_t)lo;
+}
+constexpr int top_bit(int m) { int b = 1; while ((b << 1) <= m) b <<= 1; return b; }
+
+template <int M, int THREADS>
+__device__ __forceinline__ void cx_step(u64 (&key)[8], u64* __restrict__ sk, int tid)
+{
+    constexpr int KM = M & 7;
+    constexpr int LM = (M >> 3) & 63;
+    constexpr int WM = M >> 9;
+    if constexpr (LM == 0 && WM == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if ((k ^ KM) > k) {
+                const u64 a = key[k], b = key[k ^ KM];
+                const bool sw = a > b;
+                key[k] = sw ? b : a;
+                key[k ^ KM] = sw ? a : b;
+            }
+        }
+    } else {
+        constexpr int TOP = top_bit(M);                  // >= 8 here: decided by the thread id alone
+        const bool keep_min = (tid & (TOP >> 3)) == 0;
+        u64 other[8];
+        if constexpr (WM == 0) {
+            const int pl = (tid & 63) ^ LM;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) other[k] = shfl64(key[k ^ KM], pl);
+        } else {
+            // staging layout sk[k * THREADS + tid]: consecutive lanes hit consecutive banks
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sk[k * THREADS + tid] = key[k];
+            __syncthreads();
+            const int pt = tid ^ (M >> 3);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) other[k] = sk[(k ^ KM) * THREADS + pt];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const u64 a = key[k], b = other[k];
+            const bool a_gt = a > b;
+            key[k] = (a_gt == keep_min) ? b : a;      // keep_min: take the smaller, else the larger
+        }
+    }
+}
+
+template <int J, int THREADS>
+__device__ __forceinline__ void cx_tail(u64 (&key)[8], u64* __restrict__ sk, int tid)
+{
+    if constexpr (J > 0) {
+        cx_step<J, THREADS>(key, sk, tid);
+        cx_tail<(J >> 1), THREADS>(key, sk, tid);
+    }
+}
+template <int SIZE, int N, int THREADS>
+__device__ __forceinline__ void cx_stage(u64 (&key)[8], u64* __restrict__ sk, int tid)
+{
+    if constexpr (SIZE <= N) {
+        cx_step<SIZE - 1, THREADS>(key, sk, tid);            // first step of a merge: partner = i ^ (size - 1)
+        cx_tail<(SIZE >> 2), THREADS>(key, sk, tid);         // then i ^ j for j = size/4 ... 1
+        cx_stage<(SIZE << 1), N, THREADS>(key, sk, tid);
+    }
+}
+
+// sorts seg[0..n) (n <= 8*THREADS) and leaves the sorted keys in sk[0..n) in natural order
+template <int THREADS>
+__device__ __forceinline__ void block_sort_regs(u64* __restrict__ sk, const u64* __restrict__ seg, uint32_t n, int tid)
+{
+    u64 key[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t i = (uint32_t)tid * 8u + (uint32_t)k;
+        key[k] = i < n ? seg[i] : ~0ull;
+    }
+    cx_stage<2, 8 * THREADS, THREADS>(key, sk, tid);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sk[tid * 8 + k] = key[k];
+    __syncthreads();
+}
+
 // Two size classes share this body: tiles with n_lo < n <= n_hi are handled, the rest exit at once.
 //   small: <= 2048 entries, 256 threads, 16 KiB LDS  (many workgroups per CU)
 //   large: 1024 threads, 64 KiB LDS; beyond 8192 entries the sort runs in place in global memory
@@ -407,9 +501,8 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
     unsigned long long* seg = keys + start;
     const bool in_lds = n <= (uint32_t)KEYS;
     if (in_lds) {
-        for (uint32_t i = tid; i < n; i += THREADS) skeys[i] = seg[i];
-        __syncthreads();
-        bitonic_sort(skeys, n, tid, THREADS);
+        static_assert(KEYS == 8 * THREADS, "register sort holds 8 keys per thread");
+        block_sort_regs<THREADS>(skeys, seg, n, tid);
     } else {
         __syncthreads();
         bitonic_sort(seg, n, tid, THREADS);  // rare: > 8192 instances in one tile, sort in place in global memory
