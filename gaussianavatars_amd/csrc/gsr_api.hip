@@ -166,6 +166,7 @@ int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, GsrBinni
     o->tile_count = off;  off = align_up(off + tiles * 4, A);
     o->tile_start = off;  off = align_up(off + tiles * 4, A);
     o->tile_cursor = off; off = align_up(off + tiles * 4, A);
+    o->tile_order = off;  off = align_up(off + tiles * 4, A);
     o->total = off + A;
     return 0;
 }
@@ -269,7 +270,8 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
     {
         TIMED(GSR_K_TILE_SCAN, stream);
     hipLaunchKernelGGL(gsr::k_tile_scan, dim3(1), dim3(1024), 0, stream, tiles, (const uint32_t*)tile_count,
-                               (uint32_t*)(b + bl.tile_start), (uint32_t*)(b + bl.tile_cursor), (uint2*)(b + bl.ranges), total_dev,
+                               (uint32_t*)(b + bl.tile_start), (uint32_t*)(b + bl.tile_cursor), (uint2*)(b + bl.ranges),
+                               (uint32_t*)(b + bl.tile_order), total_dev,
                                slot_dev, seq);
             KERNEL_CHECK("k_tile_scan", stream, dbg);
     }
@@ -291,12 +293,12 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
             TIMED(GSR_K_TILE_SORT, stream);
     // large tiles first (long, few), then the small class (short, many)
             hipLaunchKernelGGL((gsr::k_tile_sort<GSR_SORT_LDS_KEYS, 1024>), dim3(tiles), dim3(1024), 0, stream, (uint32_t)GSR_SORT_SMALL_KEYS,
-                               0xFFFFFFFFu, gx, (const uint32_t*)tile_count, (const uint32_t*)(b + bl.tile_start),
+                               0xFFFFFFFFu, gx, (const uint32_t*)(b + bl.tile_order), (const uint32_t*)tile_count, (const uint32_t*)(b + bl.tile_start),
                                (unsigned long long*)(b + bl.keys), (uint32_t*)(b + bl.point_list), (float4*)(b + bl.qrecords),
                                (uint32_t*)(b + bl.qcount), (const float2*)pa.xy, (const float4*)pa.conic_opacity, (const float4*)pa.rgb, cap,
                                (const unsigned long long*)total_dev);
             hipLaunchKernelGGL((gsr::k_tile_sort<GSR_SORT_SMALL_KEYS, 256>), dim3(tiles), dim3(256), 0, stream, 0u,
-                               (uint32_t)GSR_SORT_SMALL_KEYS, gx, (const uint32_t*)tile_count, (const uint32_t*)(b + bl.tile_start),
+                               (uint32_t)GSR_SORT_SMALL_KEYS, gx, (const uint32_t*)(b + bl.tile_order), (const uint32_t*)tile_count, (const uint32_t*)(b + bl.tile_start),
                                (unsigned long long*)(b + bl.keys), (uint32_t*)(b + bl.point_list), (float4*)(b + bl.qrecords),
                                (uint32_t*)(b + bl.qcount), (const float2*)pa.xy, (const float4*)pa.conic_opacity, (const float4*)pa.rgb, cap,
                                (const unsigned long long*)total_dev);
@@ -305,7 +307,7 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
     }
     {
         TIMED(GSR_K_RENDER, stream);
-    hipLaunchKernelGGL(gsr::k_render, dim3(gx, gy), dim3(256), 0, stream, ds, (const uint2*)(b + bl.ranges),
+    hipLaunchKernelGGL(gsr::k_render, dim3(tiles), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order), (const uint2*)(b + bl.ranges),
                                (const uint32_t*)(b + bl.qcount), (const float4*)(b + bl.qrecords), (float*)(im + il.final_T),
                                (uint32_t*)(im + il.n_contrib), (uint32_t*)(im + il.n_contrib_q), out_color,
                                cap, (const unsigned long long*)total_dev);
@@ -377,7 +379,7 @@ int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M, const float*
     if (num_rendered > 0) {
         {
             TIMED(GSR_K_RENDER_BWD, stream);
-    hipLaunchKernelGGL(gsr::k_render_bwd, dim3(gx, gy), dim3(256), 0, stream, ds, (const uint2*)(b + bl.ranges),
+    hipLaunchKernelGGL(gsr::k_render_bwd, dim3(gx * gy), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order), (const uint2*)(b + bl.ranges),
                                        (const uint32_t*)(b + bl.qcount), (const float4*)(b + bl.qrecords), (const float*)(im + il.final_T),
                                        (const uint32_t*)(im + il.n_contrib_q), dL_dpix, grad_scratch);
                     KERNEL_CHECK("k_render_bwd", stream, dbg);

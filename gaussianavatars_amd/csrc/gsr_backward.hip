@@ -40,18 +40,20 @@ __device__ __forceinline__ float row_sum(float v)
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint2* __restrict__ ranges, const uint32_t* __restrict__ qcount,
+__global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
+                                                     const uint32_t* __restrict__ qcount,
                                                      const float4* __restrict__ qrecords, const float* __restrict__ final_T,
                                                      const uint32_t* __restrict__ n_contrib_q, const float* __restrict__ dL_dpix,
                                                      float* __restrict__ acc /* [P][GSR_ACC_STRIDE] */)
 {
     const int W = s.W, H = s.H;
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X;
-    const int tile = blockIdx.y * gx + blockIdx.x;
+    const int tile = (int)tile_order[blockIdx.x];
+    const int tile_x = tile % gx, tile_y = tile / gx;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const int pxi = blockIdx.x * GSR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
-    const int pyi = blockIdx.y * GSR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
+    const int pxi = tile_x * GSR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
+    const int pyi = tile_y * GSR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = pxi < W && pyi < H;
     const float pixx = (float)pxi, pixy = (float)pyi;
     const uint2 range = ranges[tile];
@@ -78,7 +80,10 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint2* __r
     float last_alpha = 0.f;
 
     constexpr int RB = 4;
-    const int jmax = min((int)wave_max_u32((uint32_t)last), nq);   // deepest contributor of any pixel of this wave
+    const int jmax = min((int)wave_max_u32((uint32_t)last), nq);
+    if (jmax > 2048) __builtin_amdgcn_s_setprio(3);
+    else if (jmax > 1024) __builtin_amdgcn_s_setprio(2);
+    else if (jmax > 512) __builtin_amdgcn_s_setprio(1);   // deepest contributor of any pixel of this wave
     for (int jb = ((jmax + RB - 1) / RB) * RB - RB; jb >= 0; jb -= RB) {
         float rx[RB], ry[RB], ca[RB], cb2[RB], cc[RB], op[RB], c_r[RB], c_g[RB], c_b[RB];
         uint32_t id[RB];

@@ -201,20 +201,20 @@ struct PreBwdArgs {
 
 __global__ void k_preprocess(Settings s, PreprocessArgs a);
 __global__ void k_tile_scan(int tiles, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, uint2* ranges,
-                            unsigned long long* total_dev, unsigned long long* mailbox, unsigned long long seq);
+                            uint32_t* tile_order, unsigned long long* total_dev, unsigned long long* mailbox, unsigned long long seq);
 __global__ void k_count(int P, int gx, int tiles, const ushort4* rect, const uint32_t* tiles_touched, uint32_t* tile_count);
 __global__ void k_scatter(int P, int gx, int tiles, const float* depths, const ushort4* rect, const uint32_t* tiles_touched,
                           const uint32_t* tile_start, uint32_t* tile_cursor, unsigned long long* keys,
                           unsigned long long capacity, const unsigned long long* total_dev);
 template <int KEYS, int THREADS>
-__global__ void k_tile_sort(uint32_t n_lo, uint32_t n_hi, int gx, const uint32_t* tile_count, const uint32_t* tile_start, unsigned long long* keys,
+__global__ void k_tile_sort(uint32_t n_lo, uint32_t n_hi, int gx, const uint32_t* tile_order, const uint32_t* tile_count, const uint32_t* tile_start, unsigned long long* keys,
                             uint32_t* point_list, float4* qrecords, uint32_t* qcount, const float2* xy, const float4* conic_opacity,
                             const float4* rgb, unsigned long long capacity, const unsigned long long* total_dev);
-__global__ void k_render(Settings s, const uint2* ranges, const uint32_t* qcount, const float4* qrecords, float* final_T,
+__global__ void k_render(Settings s, const uint32_t* tile_order, const uint2* ranges, const uint32_t* qcount, const float4* qrecords, float* final_T,
                          uint32_t* n_contrib, uint32_t* n_contrib_q, float* out_color, unsigned long long capacity,
                          const unsigned long long* total_dev);
 __global__ void k_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present);
-__global__ void k_render_bwd(Settings s, const uint2* ranges, const uint32_t* qcount, const float4* qrecords, const float* final_T,
+__global__ void k_render_bwd(Settings s, const uint32_t* tile_order, const uint2* ranges, const uint32_t* qcount, const float4* qrecords, const float* final_T,
                              const uint32_t* n_contrib_q, const float* dL_dpix, float* acc);
 __global__ void k_preprocess_bwd(Settings s, PreBwdArgs a);
 

@@ -247,11 +247,13 @@ __global__ __launch_bounds__(256) void k_count(int P, int gx, int tiles, const u
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_tile_scan(int tiles, const uint32_t* __restrict__ tile_count,
                                                      uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
-                                                     uint2* __restrict__ ranges, unsigned long long* __restrict__ total_dev,
-                                                     unsigned long long* mailbox, unsigned long long seq)
+                                                     uint2* __restrict__ ranges, uint32_t* __restrict__ tile_order,
+                                                     unsigned long long* __restrict__ total_dev, unsigned long long* mailbox,
+                                                     unsigned long long seq)
 {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
+    __shared__ uint32_t bucket[34];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
@@ -288,6 +290,22 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int tiles, const uint32_t* _
         // post (seq, I) to the host: one 8-byte system-scope store into mapped pinned memory
         __hip_atomic_store(mailbox, (seq << 40) | (grand & 0xFFFFFFFFFFull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    // ---- heavy-first launch order for the per-tile kernels --------------------------------------------
+    // Per-tile work is heavy-tailed (a few tiles hold thousands of instances).  The dispatcher hands out
+    // workgroups in index order, so listing tiles by descending instance count (bucketed by log2, one
+    // counting-sort pass in LDS) lets the light tiles fill in behind the heavy ones instead of a heavy
+    // tile starting late on an already busy CU.  Pure scheduling: results do not depend on the order.
+    if (tid < 34) bucket[tid] = 0u;
+    __syncthreads();
+    auto bucket_of = [](uint32_t c) { return c ? 32u - (uint32_t)(31 - __builtin_clz(c)) - 1u : 32u; };   // big counts first, empty last
+    for (int t = tid; t < tiles; t += 1024) atomicAdd(&bucket[bucket_of(tile_count[t])], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < 33; ++b) { const uint32_t c = bucket[b]; bucket[b] = run; run += c; }
+    }
+    __syncthreads();
+    for (int t = tid; t < tiles; t += 1024) tile_order[atomicAdd(&bucket[bucket_of(tile_count[t])], 1u)] = (uint32_t)t;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -480,7 +498,8 @@ __device__ __forceinline__ void block_sort_regs(u64* __restrict__ sk, const u64*
 //   small: <= 2048 entries, 256 threads, 16 KiB LDS  (many workgroups per CU)
 //   large: 1024 threads, 64 KiB LDS; beyond 8192 entries the sort runs in place in global memory
 template <int KEYS, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n_hi, int gx, const uint32_t* __restrict__ tile_count,
+__global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n_hi, int gx, const uint32_t* __restrict__ tile_order,
+                                                        const uint32_t* __restrict__ tile_count,
                                                     const uint32_t* __restrict__ tile_start, unsigned long long* __restrict__ keys,
                                                     uint32_t* __restrict__ point_list, float4* __restrict__ qrecords,
                                                     uint32_t* __restrict__ qcount, const float2* __restrict__ xy,
@@ -490,7 +509,7 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
     __shared__ unsigned long long skeys[KEYS];
     __shared__ uint32_t wave_cnt[4][THREADS / 64];   // [quadrant][wave]
     if (*total_dev > capacity) return;
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = tile_order[blockIdx.x];
     const uint32_t n = tile_count[tile];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (n <= n_lo || n > n_hi) {
@@ -595,10 +614,10 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
     if (tid < 4) qcount[4 * tile + tid] = running[tid];
 }
 
-template __global__ void k_tile_sort<GSR_SORT_SMALL_KEYS, 256>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
+template __global__ void k_tile_sort<GSR_SORT_SMALL_KEYS, 256>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
                                                                 float4*, uint32_t*, const float2*, const float4*, const float4*, unsigned long long,
                                                                 const unsigned long long*);
-template __global__ void k_tile_sort<GSR_SORT_LDS_KEYS, 1024>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
+template __global__ void k_tile_sort<GSR_SORT_LDS_KEYS, 1024>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
                                                                float4*, uint32_t*, const float2*, const float4*, const float4*, unsigned long long,
                                                                const unsigned long long*);
 
@@ -608,7 +627,8 @@ template __global__ void k_tile_sort<GSR_SORT_LDS_KEYS, 1024>(uint32_t, uint32_t
 // wave-uniform, so the loads below are scalar-unit loads: one 48-byte fetch serves all 64 pixels
 // and the values sit in SGPRs -- no LDS staging, no barriers, each wave stops on its own.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_render(Settings s, const uint2* __restrict__ ranges, const uint32_t* __restrict__ qcount,
+__global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
+                                                 const uint32_t* __restrict__ qcount,
                                                  const float4* __restrict__ qrecords, float* __restrict__ final_T,
                                                  uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ n_contrib_q,
                                                  float* __restrict__ out_color, unsigned long long capacity,
@@ -617,11 +637,12 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint2* __restr
     if (*total_dev > capacity) return;
     const int W = s.W, H = s.H;
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X;
-    const int tile = blockIdx.y * gx + blockIdx.x;
+    const int tile = (int)tile_order[blockIdx.x];
+    const int tile_x = tile % gx, tile_y = tile / gx;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const int pxi = blockIdx.x * GSR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
-    const int pyi = blockIdx.y * GSR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
+    const int pxi = tile_x * GSR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
+    const int pyi = tile_y * GSR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = pxi < W && pyi < H;
     const float pixx = (float)pxi, pixy = (float)pyi;
 
@@ -634,6 +655,11 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint2* __restr
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last_contributor = 0, last_q = 0;
     bool done = !inside;
+
+    // the kernel ends when its longest stream ends: let those waves win issue arbitration on their SIMD
+    if (n > 2048) __builtin_amdgcn_s_setprio(3);
+    else if (n > 1024) __builtin_amdgcn_s_setprio(2);
+    else if (n > 512) __builtin_amdgcn_s_setprio(1);
 
     // The stream is walked RB records at a time: the RB exponentials are independent (instruction-level
     // parallelism for a wave that is alone on its SIMD), only the short T/C update is sequential.
@@ -697,8 +723,8 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint2* __restr
         while (open_mask) {
             const int p = __builtin_ctzll(open_mask);
             open_mask &= open_mask - 1;
-            const float ppx = (float)(blockIdx.x * GSR_BLOCK_X + (wave & 1) * 8 + (p & 7));
-            const float ppy = (float)(blockIdx.y * GSR_BLOCK_Y + (wave >> 1) * 8 + (p >> 3));
+            const float ppx = (float)(tile_x * GSR_BLOCK_X + (wave & 1) * 8 + (p & 7));
+            const float ppy = (float)(tile_y * GSR_BLOCK_Y + (wave >> 1) * 8 + (p >> 3));
             float Tp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(T), p));
             float A0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C0), p));
             float A1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C1), p));

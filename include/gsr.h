@@ -82,6 +82,7 @@ typedef struct GsrBinningLayout {
     size_t tile_count;  /* uint32 [tiles]                                                            */
     size_t tile_start;  /* uint32 [tiles]                                                            */
     size_t tile_cursor; /* uint32 [tiles]                                                            */
+    size_t tile_order;  /* uint32 [tiles]  launch order of the per-tile kernels: heaviest tiles first         */
     size_t total;
 } GsrBinningLayout;
 
