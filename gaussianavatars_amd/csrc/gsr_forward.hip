@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
 
     float T = 1.0f;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    uint32_t last_contributor = 0, last_q = 0;
+    uint32_t last_q = 0;
     bool done = !inside;
 
     // the kernel ends when its longest stream ends: let those waves win issue arbitration on their SIMD
@@ -664,33 +664,29 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     // The stream is walked RB records at a time: the RB exponentials are independent (instruction-level
     // parallelism for a wave that is alone on its SIMD), only the short T/C update is sequential.
     // Skips are predicated (selects), so the arithmetic per contributing record is exactly A.3's.
-    constexpr int RB = 4;
+    constexpr int RB = 3;
     constexpr int TAIL_LANES = 8;     // switch to record-parallel mode when this few pixels are still open
-    int j0 = 0;
-    for (; j0 < n; j0 += RB) {
-        const unsigned long long open_mask = __ballot(!done);
-        if (open_mask == 0ull) break;
-        if (__builtin_popcountll(open_mask) <= TAIL_LANES && n - j0 > 2 * GSR_WAVE) break;   // -> tail mode below
-        float rx[RB], ry[RB], ca[RB], cb2[RB], cc[RB], op[RB], c_r[RB], c_g[RB], c_b[RB];
-        uint32_t orig[RB];
+    struct Rec4 { float rx[RB], ry[RB], ca[RB], cb[RB], cc[RB], op[RB], cr[RB], cg[RB], cbl[RB]; };
+    auto load4 = [&](int jb, Rec4& R) {
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
-            const int j = min(j0 + u, n - 1);   // tail: re-read the last record, masked out below
+            const int j = min(jb + u, n - 1);   // past the end: re-read the last record, masked out in blend4
             const float4 r0 = rec[3 * j + 0];
             const float4 r1 = rec[3 * j + 1];
-            const float4 r2 = rec[3 * j + 2];
-            rx[u] = r0.x; ry[u] = r0.y; ca[u] = r0.z; cb2[u] = r0.w;
-            cc[u] = r1.x; op[u] = r1.y; c_r[u] = r1.z; c_g[u] = r1.w; c_b[u] = r2.x;
-            orig[u] = __float_as_uint(r2.z);
+            const float r2x = rec[3 * j + 2].x;
+            R.rx[u] = r0.x; R.ry[u] = r0.y; R.ca[u] = r0.z; R.cb[u] = r0.w;
+            R.cc[u] = r1.x; R.op[u] = r1.y; R.cr[u] = r1.z; R.cg[u] = r1.w; R.cbl[u] = r2x;
         }
+    };
+    auto blend4 = [&](int jb, const Rec4& R) {
         float alpha[RB];
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
-            const float dx = rx[u] - pixx;
-            const float dy = ry[u] - pixy;
-            const float power = -0.5f * (ca[u] * dx * dx + cc[u] * dy * dy) - cb2[u] * dx * dy;
-            const float a = sel_min(0.99f, op[u] * gsr_expf(power));
-            const bool ok = power <= 0.0f && (j0 + u) < n && a >= 1.0f / 255.0f;
+            const float dx = R.rx[u] - pixx;
+            const float dy = R.ry[u] - pixy;
+            const float power = -0.5f * (R.ca[u] * dx * dx + R.cc[u] * dy * dy) - R.cb[u] * dx * dy;
+            const float a = sel_min(0.99f, R.op[u] * gsr_expf(power));
+            const bool ok = power <= 0.0f && (jb + u) < n && a >= 1.0f / 255.0f;
             alpha[u] = ok ? a : 0.0f;
         }
 #pragma unroll
@@ -699,16 +695,40 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
             const float test_T = T * (1.0f - alpha[u]);
             const bool stop = live && test_T < 0.0001f;
             const bool acc = live && !stop;
-            const float n0 = C0 + c_r[u] * alpha[u] * T;
-            const float n1 = C1 + c_g[u] * alpha[u] * T;
-            const float n2 = C2 + c_b[u] * alpha[u] * T;
+            const float n0 = C0 + R.cr[u] * alpha[u] * T;
+            const float n1 = C1 + R.cg[u] * alpha[u] * T;
+            const float n2 = C2 + R.cbl[u] * alpha[u] * T;
             C0 = acc ? n0 : C0;
             C1 = acc ? n1 : C1;
             C2 = acc ? n2 : C2;
             T = acc ? test_T : T;
-            last_contributor = acc ? orig[u] + 1u : last_contributor;
-            last_q = acc ? (uint32_t)(j0 + u + 1) : last_q;
+            last_q = acc ? (uint32_t)(jb + u + 1) : last_q;
             done = done || stop;
+        }
+    };
+    auto keep_going = [&](int jb) {
+        const unsigned long long open_mask = __ballot(!done);
+        if (open_mask == 0ull) return false;
+        return !(__builtin_popcountll(open_mask) <= TAIL_LANES && n - jb > 2 * GSR_WAVE);   // few open pixels -> tail mode
+    };
+    // Software-pipelined walk: the scalar loads of batch k+1 are issued BEFORE batch k is blended.  Scalar
+    // loads return out of order, so the only wait is lgkmcnt(0); the empty asm pins that wait (first use of
+    // the current batch, whose loads were issued a whole batch ago) ahead of the next issue, instead of
+    // letting it land after it and stall on the fresh loads.
+    int j0 = 0;
+    if (n > 0) {
+        Rec4 A, B;
+        load4(0, A);
+        while (j0 < n && keep_going(j0)) {
+            asm volatile("" ::"s"(A.rx[0]) : "memory");
+            if (j0 + RB < n) load4(j0 + RB, B);
+            blend4(j0, A);
+            j0 += RB;
+            if (!(j0 < n && keep_going(j0))) break;
+            asm volatile("" ::"s"(B.rx[0]) : "memory");
+            if (j0 + RB < n) load4(j0 + RB, A);
+            blend4(j0, B);
+            j0 += RB;
         }
     }
 
@@ -729,7 +749,6 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
             float A0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C0), p));
             float A1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C1), p));
             float A2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C2), p));
-            uint32_t lastp = (uint32_t)__builtin_amdgcn_readlane((int)last_contributor, p);
             uint32_t lastqp = (uint32_t)__builtin_amdgcn_readlane((int)last_q, p);
             bool donep = false;
             for (int c0 = j0; c0 < n && !donep; c0 += GSR_WAVE) {
@@ -755,15 +774,16 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
                     A1 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.w), k)) * ak * Tp;
                     A2 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r2.x), k)) * ak * Tp;
                     Tp = test_T;
-                    lastp = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(r2.z), k) + 1u;
                     lastqp = (uint32_t)(c0 + k + 1);
                 }
             }
-            if (lane == p) { T = Tp; C0 = A0; C1 = A1; C2 = A2; last_contributor = lastp; last_q = lastqp; }
+            if (lane == p) { T = Tp; C0 = A0; C1 = A1; C2 = A2; last_q = lastqp; }
         }
     }
     if (inside) {
         const int pix_id = W * pyi + pxi;
+        // the reference's n_contrib counts positions in the TILE list: look it up from the last record used
+        const uint32_t last_contributor = last_q ? __float_as_uint(rec[3 * (last_q - 1) + 2].z) + 1u : 0u;
         final_T[pix_id] = T;
         n_contrib[pix_id] = last_contributor;
         n_contrib_q[pix_id] = last_q;
