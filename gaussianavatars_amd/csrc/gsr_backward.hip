@@ -84,38 +84,44 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
     if (jmax > 2048) __builtin_amdgcn_s_setprio(3);
     else if (jmax > 1024) __builtin_amdgcn_s_setprio(2);
     else if (jmax > 512) __builtin_amdgcn_s_setprio(1);   // deepest contributor of any pixel of this wave
-    for (int jb = ((jmax + RB - 1) / RB) * RB - RB; jb >= 0; jb -= RB) {
-        float rx[RB], ry[RB], ca[RB], cb2[RB], cc[RB], op[RB], c_r[RB], c_g[RB], c_b[RB];
-        uint32_t id[RB];
+    struct Rec2 { float rx[2], ry[2], ca[2], cb[2], cc[2], op[2], cr[2], cg[2], cbl[2]; uint32_t id[2]; };
+    auto load2 = [&](int jp, Rec2& R) {
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const int j = min(jb + u, nq - 1);
+        for (int u = 0; u < 2; ++u) {
+            const int j = min(jp + u, nq - 1);
             const float4 r0 = rec[3 * j + 0];
             const float4 r1 = rec[3 * j + 1];
             const float4 r2 = rec[3 * j + 2];
-            rx[u] = r0.x; ry[u] = r0.y; ca[u] = r0.z; cb2[u] = r0.w;
-            cc[u] = r1.x; op[u] = r1.y; c_r[u] = r1.z; c_g[u] = r1.w; c_b[u] = r2.x;
-            id[u] = __float_as_uint(r2.y);
+            R.rx[u] = r0.x; R.ry[u] = r0.y; R.ca[u] = r0.z; R.cb[u] = r0.w;
+            R.cc[u] = r1.x; R.op[u] = r1.y; R.cr[u] = r1.z; R.cg[u] = r1.w; R.cbl[u] = r2.x;
+            R.id[u] = __float_as_uint(r2.y);
         }
-        // independent part: G, alpha, hit
-        float G[RB], alpha[RB], dxs[RB], dys[RB];
-        bool hit[RB];
-        bool any_hit = false;
+    };
+    float v[RB][9];
+    uint32_t id[RB];
+    // records jp, jp+1 (visited jp+1 first: back to front) -> v[uo], v[uo+1]
+    auto grad2 = [&](int jp, const Rec2& R, int uo) -> bool {
+        float G[2], alpha[2], dxs[2], dys[2];
+        bool hit[2];
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            dxs[u] = rx[u] - pixx;
-            dys[u] = ry[u] - pixy;
-            const float power = -0.5f * (ca[u] * dxs[u] * dxs[u] + cc[u] * dys[u] * dys[u]) - cb2[u] * dxs[u] * dys[u];
+        for (int u = 0; u < 2; ++u) {
+            dxs[u] = R.rx[u] - pixx;
+            dys[u] = R.ry[u] - pixy;
+            const float power = -0.5f * (R.ca[u] * dxs[u] * dxs[u] + R.cc[u] * dys[u] * dys[u]) - R.cb[u] * dxs[u] * dys[u];
             G[u] = gsr_expf(power);
-            alpha[u] = sel_min(0.99f, op[u] * G[u]);
-            hit[u] = (jb + u) < last && power <= 0.0f && alpha[u] >= 1.0f / 255.0f;
-            any_hit = any_hit || hit[u];
+            alpha[u] = sel_min(0.99f, R.op[u] * G[u]);
+            hit[u] = (jp + u) < last && power <= 0.0f && alpha[u] >= 1.0f / 255.0f;
+            id[uo + u] = R.id[u];
         }
-        if (__ballot(any_hit) == 0ull) continue;      // no pixel of this wave touched these splats
-        // sequential part, back to front
-        float v[RB][9];
+        if (__ballot(hit[0] || hit[1]) == 0ull) {      // no pixel of this wave touched these two splats
 #pragma unroll
-        for (int u = RB - 1; u >= 0; --u) {
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int c = 0; c < 9; ++c) v[uo + u][c] = 0.f;
+            return false;
+        }
+#pragma unroll
+        for (int u = 1; u >= 0; --u) {
             const float one_m = 1.f - alpha[u];
             const float rinv = __builtin_amdgcn_rcpf(one_m);
             const float Tn = T * rinv;
@@ -123,48 +129,67 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
             const float n0 = last_alpha * lc0 + (1.f - last_alpha) * ar0;
             const float n1 = last_alpha * lc1 + (1.f - last_alpha) * ar1;
             const float n2 = last_alpha * lc2 + (1.f - last_alpha) * ar2;
-            float dL_dalpha = ((c_r[u] - n0) * g0 + (c_g[u] - n1) * g1 + (c_b[u] - n2) * g2) * Tn;
+            float dL_dalpha = ((R.cr[u] - n0) * g0 + (R.cg[u] - n1) * g1 + (R.cbl[u] - n2) * g2) * Tn;
             dL_dalpha += (-T_final * rinv) * bg_dot;
-            const float dL_dG = op[u] * dL_dalpha;
+            const float dL_dG = R.op[u] * dL_dalpha;
             const float gdx = G[u] * dxs[u], gdy = G[u] * dys[u];
-            const float dG_ddelx = -gdx * ca[u] - gdy * cb2[u];
-            const float dG_ddely = -gdy * cc[u] - gdx * cb2[u];
+            const float dG_ddelx = -gdx * R.ca[u] - gdy * R.cb[u];
+            const float dG_ddely = -gdy * R.cc[u] - gdx * R.cb[u];
             const bool h = hit[u];
-            v[u][0] = h ? w * g0 : 0.f;
-            v[u][1] = h ? w * g1 : 0.f;
-            v[u][2] = h ? w * g2 : 0.f;
-            v[u][3] = h ? dL_dG * dG_ddelx * ddelx_dx : 0.f;
-            v[u][4] = h ? dL_dG * dG_ddely * ddely_dy : 0.f;
-            v[u][5] = h ? -0.5f * gdx * dxs[u] * dL_dG : 0.f;
-            v[u][6] = h ? -0.5f * gdx * dys[u] * dL_dG : 0.f;
-            v[u][7] = h ? -0.5f * gdy * dys[u] * dL_dG : 0.f;
-            v[u][8] = h ? G[u] * dL_dalpha : 0.f;
+            float* vv = v[uo + u];
+            vv[0] = h ? w * g0 : 0.f;
+            vv[1] = h ? w * g1 : 0.f;
+            vv[2] = h ? w * g2 : 0.f;
+            vv[3] = h ? dL_dG * dG_ddelx * ddelx_dx : 0.f;
+            vv[4] = h ? dL_dG * dG_ddely * ddely_dy : 0.f;
+            vv[5] = h ? -0.5f * gdx * dxs[u] * dL_dG : 0.f;
+            vv[6] = h ? -0.5f * gdx * dys[u] * dL_dG : 0.f;
+            vv[7] = h ? -0.5f * gdy * dys[u] * dL_dG : 0.f;
+            vv[8] = h ? G[u] * dL_dalpha : 0.f;
             T = h ? Tn : T;
             ar0 = h ? n0 : ar0;
             ar1 = h ? n1 : ar1;
             ar2 = h ? n2 : ar2;
-            lc0 = h ? c_r[u] : lc0;
-            lc1 = h ? c_g[u] : lc1;
-            lc2 = h ? c_b[u] : lc2;
+            lc0 = h ? R.cr[u] : lc0;
+            lc1 = h ? R.cg[u] : lc1;
+            lc2 = h ? R.cbl[u] : lc2;
             last_alpha = h ? alpha[u] : last_alpha;
         }
-        // transposed reduction: rows 0..3 of t[c] <- records 0, 2, 1, 3
-        float mine = 0.f;
-        const int c_sel = lane & 15;
+        return true;
+    };
+    // Batches of RB records, back to front; inside a batch the high pair, then the low pair.  The scalar
+    // loads of the NEXT pair are issued before the current pair is processed (same lgkmcnt(0) pinning as
+    // the forward kernel).
+    int jb = ((jmax + RB - 1) / RB) * RB - RB;
+    if (jb >= 0) {
+        Rec2 A, B;
+        load2(jb + 2, A);
+        for (; jb >= 0; jb -= RB) {
+            asm volatile("" ::"s"(A.rx[0]) : "memory");
+            load2(jb, B);
+            const bool h1 = grad2(jb + 2, A, 2);
+            asm volatile("" ::"s"(B.rx[0]) : "memory");
+            if (jb - RB >= 0) load2(jb - RB + 2, A);
+            const bool h0 = grad2(jb, B, 0);
+            if (!(h0 || h1)) continue;
+            // transposed reduction: rows 0..3 of t[c] <- records 0, 2, 1, 3
+            float mine = 0.f;
+            const int c_sel = lane & 15;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            const float s01 = swap32_add(v[0][c], v[1][c]);
-            const float s23 = swap32_add(v[2][c], v[3][c]);
-            const float t = row_sum(swap16_add(s01, s23));
-            mine = (c_sel == c) ? t : mine;
+            for (int c = 0; c < 9; ++c) {
+                const float s01 = swap32_add(v[0][c], v[1][c]);
+                const float s23 = swap32_add(v[2][c], v[3][c]);
+                const float t = row_sum(swap16_add(s01, s23));
+                mine = (c_sel == c) ? t : mine;
+            }
+            const int row = lane >> 4;
+            uint32_t myid = id[0];
+            myid = (row == 1) ? id[2] : myid;
+            myid = (row == 2) ? id[1] : myid;
+            myid = (row == 3) ? id[3] : myid;
+            const int rec_u = (row == 1) ? 2 : ((row == 2) ? 1 : row);
+            if (c_sel < 9 && (jb + rec_u) < nq && mine != 0.f) unsafeAtomicAdd(acc + (size_t)GSR_ACC_STRIDE * myid + c_sel, mine);
         }
-        const int row = lane >> 4;
-        uint32_t myid = id[0];
-        myid = (row == 1) ? id[2] : myid;
-        myid = (row == 2) ? id[1] : myid;
-        myid = (row == 3) ? id[3] : myid;
-        const int rec_u = (row == 1) ? 2 : ((row == 2) ? 1 : row);
-        if (c_sel < 9 && (jb + rec_u) < nq && mine != 0.f) unsafeAtomicAdd(acc + (size_t)GSR_ACC_STRIDE * myid + c_sel, mine);
     }
 }
 
