@@ -478,20 +478,157 @@ __device__ __forceinline__ void cx_stage(u64 (&key)[8], u64* __restrict__ sk, in
     }
 }
 
-// sorts seg[0..n) (n <= 8*THREADS) and leaves the sorted keys in sk[0..n) in natural order
+// sorts seg[0..n) (n <= 8*THREADS); thread t ends up holding sorted positions 8t .. 8t+7 in key[]
 template <int THREADS>
-__device__ __forceinline__ void block_sort_regs(u64* __restrict__ sk, const u64* __restrict__ seg, uint32_t n, int tid)
+__device__ __forceinline__ void block_sort_regs(u64 (&key)[8], u64* __restrict__ sk, const u64* __restrict__ seg, uint32_t n, int tid)
 {
-    u64 key[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const uint32_t i = (uint32_t)tid * 8u + (uint32_t)k;
         key[k] = i < n ? seg[i] : ~0ull;
     }
     cx_stage<2, 8 * THREADS, THREADS>(key, sk, tid);
+}
+
+// Which of the tile's four 8x8 quadrants can the splat's {alpha >= 1/255} ellipse reach?  (bit q set = keep)
+// alpha >= 1/255  <=>  Q(d) = 1/2 (A dx^2 + 2 B dx dy + C dy^2) <= tau = ln(255 o).  The record is kept for
+// quadrant q iff the minimum of the convex Q over the quadrant's pixel rectangle can be <= tau (0 if the centre
+// is inside, else attained on one of the four edges); padded so fp32 rounding in the blend can never turn a
+// dropped pair into a contributor.
+__device__ __forceinline__ uint32_t quadrant_mask(float2 p, float4 co, float ox, float oy)
+{
+    if (!(co.w * 255.0f >= 1.0f)) return 0u;   // alpha = min(0.99, o * G) can reach 1/255 only if o >= 1/255
+    const float tau = logf(255.0f * co.w) * 1.0001f + 1e-3f;
+    const float A = co.x, B = co.y, Cc = co.z;
+    if (!(A > 0.f && Cc > 0.f && (A * Cc - B * B) > 0.f)) return 0xFu;   // not positive definite: keep everywhere
+    const float nBiC = -B / Cc, nBiA = -B / A;
+    auto edge_x = [&](float a, float b0, float b1) {   // dx = a fixed, dy in [b0,b1]
+        const float dy = fminf(fmaxf(nBiC * a, b0), b1);
+        return 0.5f * (A * a * a + 2.f * B * a * dy + Cc * dy * dy);
+    };
+    auto edge_y = [&](float b, float a0, float a1) {   // dy = b fixed, dx in [a0,a1]
+        const float dx = fminf(fmaxf(nBiA * b, a0), a1);
+        return 0.5f * (A * dx * dx + 2.f * B * dx * b + Cc * b * b);
+    };
+    uint32_t m = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float qx0 = ox + (float)((q & 1) * 8), qy0 = oy + (float)((q >> 1) * 8);
+        const float a0 = p.x - (qx0 + 7.f), a1 = p.x - qx0;   // dx range over the quadrant's pixel centres
+        const float b0 = p.y - (qy0 + 7.f), b1 = p.y - qy0;
+        bool keep = a0 <= 0.f && a1 >= 0.f && b0 <= 0.f && b1 >= 0.f;
+        if (!keep) {
+            const float mn = fminf(fminf(edge_x(a0, b0, b1), edge_x(a1, b0, b1)), fminf(edge_y(b0, a0, a1), edge_y(b1, a0, a1)));
+            keep = mn * 0.999f - 1e-3f <= tau;
+        }
+        m |= keep ? (1u << q) : 0u;
+    }
+    return m;
+}
+
+// Epilogue for the register-sorted classes.  The sorted keys are first laid out in LDS in natural order so
+// that thread t handles entries c*THREADS + t (c = 0..7): consecutive lanes own consecutive entries and
+// their compacted records land next to each other (coalesced stores).  Membership is one 4-bit mask per
+// entry; the stable compaction into the four quadrant streams uses ballots for the in-wave rank and ONE
+// exclusive scan over the (chunk, wave) counters -- three barriers in total, gathers issued four chunks at a time.
+template <int THREADS>
+__device__ __forceinline__ void epilogue_striped(const u64 (&key)[8], uint32_t n, uint32_t tile, uint32_t start, float ox, float oy,
+                                                 u64* __restrict__ seg, uint32_t* __restrict__ point_list, float4* __restrict__ qbase,
+                                                 uint32_t* __restrict__ qcount, const float2* __restrict__ xy,
+                                                 const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb,
+                                                 u64* __restrict__ sk, uint32_t (*__restrict__ cntw)[8 * (THREADS / 64) + 1], int tid)
+{
+    constexpr int NW = THREADS / 64, NE = 8 * NW;   // waves, (chunk, wave) counters per quadrant
+    const int lane = tid & 63, wid = tid >> 6;
 #pragma unroll
     for (int k = 0; k < 8; ++k) sk[tid * 8 + k] = key[k];
     __syncthreads();
+    uint32_t msk[8], rank[8];   // rank: 4 x 8-bit in-wave exclusive ranks (0..63)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float2 p[4];
+        float4 co[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = (uint32_t)(4 * h + k) * THREADS + (uint32_t)tid;
+            const uint32_t idx = i < n ? (uint32_t)sk[i] : 0u;
+            p[k] = xy[idx];
+            co[k] = conic_opacity[idx];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * h + k;
+            const uint32_t i = (uint32_t)c * THREADS + (uint32_t)tid;
+            const uint32_t m = i < n ? quadrant_mask(p[k], co[k], ox, oy) : 0u;
+            msk[c] = m;
+            uint32_t r = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned long long bal = __ballot((m >> q) & 1u);
+                r |= (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u)) << (8 * q);
+                if (lane == 0) cntw[q][c * NW + wid] = (uint32_t)__builtin_popcountll(bal);
+            }
+            rank[c] = r;
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the NE counters of each quadrant (wave q scans quadrant q; NE <= 128 = 2 per lane)
+    if (wid < 4) {
+        const int e0 = 2 * lane, e1 = 2 * lane + 1;
+        const uint32_t a0 = e0 < NE ? cntw[wid][e0] : 0u, a1 = e1 < NE ? cntw[wid][e1] : 0u;
+        uint32_t incl = a0 + a1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__builtin_amdgcn_ds_bpermute((lane >= d ? lane - d : lane) << 2, (int)incl);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t excl = incl - (a0 + a1);
+        if (e0 < NE) cntw[wid][e0] = excl;
+        if (e1 < NE) cntw[wid][e1] = excl + a0;
+        if (lane == 63) cntw[wid][NE] = incl;   // total
+    }
+    __syncthreads();
+    const u64 tile_hi = (u64)tile << 32;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float2 p[4];
+        float4 co[4], cl[4];
+        u64 kk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = (uint32_t)(4 * h + k) * THREADS + (uint32_t)tid;
+            kk[k] = i < n ? sk[i] : 0ull;
+            const uint32_t idx = (uint32_t)kk[k];
+            p[k] = xy[idx];
+            co[k] = conic_opacity[idx];
+            cl[k] = rgb[idx];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * h + k;
+            const uint32_t i = (uint32_t)c * THREADS + (uint32_t)tid;
+            if (i < n) {
+                const uint32_t idx = (uint32_t)kk[k];
+                seg[i] = tile_hi | (kk[k] >> 32);   // reference-format key: tile id | depth bits
+                point_list[start + i] = idx;
+                const uint32_t m = msk[c];
+                const float4 r0 = make_float4(p[k].x, p[k].y, co[k].x, co[k].y);
+                const float4 r1 = make_float4(co[k].z, co[k].w, cl[k].x, cl[k].y);
+                const float4 r2 = make_float4(cl[k].z, __uint_as_float(idx), __uint_as_float(i), 0.f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if ((m >> q) & 1u) {
+                        const uint32_t pos = cntw[q][c * NW + wid] + ((rank[c] >> (8 * q)) & 0xFFu);
+                        float4* dst = qbase + (size_t)3 * ((size_t)q * n + pos);
+                        dst[0] = r0;
+                        dst[1] = r1;
+                        dst[2] = r2;
+                    }
+                }
+            }
+        }
+    }
+    if (tid < 4) qcount[4 * tile + tid] = cntw[tid][NE];
 }
 
 // Two size classes share this body: tiles with n_lo < n <= n_hi are handled, the rest exit at once.
@@ -507,7 +644,8 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
                                                     unsigned long long capacity, const unsigned long long* __restrict__ total_dev)
 {
     __shared__ unsigned long long skeys[KEYS];
-    __shared__ uint32_t wave_cnt[4][THREADS / 64];   // [quadrant][wave]
+    __shared__ uint32_t wave_cnt[4][THREADS / 64];   // [quadrant][wave]  (chunked fallback epilogue)
+    __shared__ uint32_t cntw[4][8 * (THREADS / 64) + 1];   // [quadrant][(chunk, wave)] + total  (striped epilogue)
     if (*total_dev > capacity) return;
     const uint32_t tile = tile_order[blockIdx.x];
     const uint32_t n = tile_count[tile];
@@ -519,9 +657,15 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
     const uint32_t start = tile_start[tile];
     unsigned long long* seg = keys + start;
     const bool in_lds = n <= (uint32_t)KEYS;
+    const float ox = (float)((tile % (uint32_t)gx) * GSR_BLOCK_X), oy = (float)((tile / (uint32_t)gx) * GSR_BLOCK_Y);
+    float4* const qbase = qrecords + (size_t)3 * 4 * start;
     if (in_lds) {
         static_assert(KEYS == 8 * THREADS, "register sort holds 8 keys per thread");
-        block_sort_regs<THREADS>(skeys, seg, n, tid);
+        static_assert(KEYS <= 65535, "quadrant counters are packed 16 bits each");
+        u64 key[8];
+        block_sort_regs<THREADS>(key, skeys, seg, n, tid);
+        epilogue_striped<THREADS>(key, n, tile, start, ox, oy, seg, point_list, qbase, qcount, xy, conic_opacity, rgb, skeys, cntw, tid);
+        return;
     } else {
         __syncthreads();
         bitonic_sort(seg, n, tid, THREADS);  // rare: > 8192 instances in one tile, sort in place in global memory
@@ -532,9 +676,7 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
     // pixel are dropped: the composited result is unchanged, the blend's lists get ~3x shorter.  Order inside
     // a quadrant stream is the tile order (stable compaction), r2.z keeps the position in the tile list.
     const unsigned long long tile_hi = (unsigned long long)tile << 32;
-    const float ox = (float)((tile % (uint32_t)gx) * GSR_BLOCK_X), oy = (float)((tile / (uint32_t)gx) * GSR_BLOCK_Y);
     uint32_t running[4] = {0u, 0u, 0u, 0u};
-    float4* const qbase = qrecords + (size_t)3 * 4 * start;
     for (uint32_t base = 0; base < n; base += THREADS) {
         const uint32_t i = base + tid;
         const bool valid = i < n;
@@ -551,38 +693,9 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
             r0 = make_float4(p.x, p.y, co.x, co.y);
             r1 = make_float4(co.z, co.w, c.x, c.y);
             r2 = make_float4(c.z, __uint_as_float(idx), __uint_as_float(i), 0.f);
-            if (co.w * 255.0f >= 1.0f) {   // alpha = min(0.99, o * G) can reach 1/255 only if o >= 1/255
-                // alpha >= 1/255  <=>  Q(d) = 1/2 (A dx^2 + 2 B dx dy + C dy^2) <= tau = ln(255 o).  Keep the record
-                // for quadrant q iff the minimum of the convex Q over the quadrant's pixel rectangle can be <= tau
-                // (0 if the centre is inside, else attained on one of the four edges); padded so fp32 rounding in
-                // the blend can never turn a dropped pair into a contributor.
-                const float tau = logf(255.0f * co.w) * 1.0001f + 1e-3f;
-                const float A = co.x, B = co.y, Cc = co.z;
-                const bool pd = A > 0.f && Cc > 0.f && (A * Cc - B * B) > 0.f;
-                auto edge_x = [&](float a, float b0, float b1) {   // dx = a fixed, dy in [b0,b1]
-                    const float dy = fminf(fmaxf(-B * a / Cc, b0), b1);
-                    return 0.5f * (A * a * a + 2.f * B * a * dy + Cc * dy * dy);
-                };
-                auto edge_y = [&](float b, float a0, float a1) {   // dy = b fixed, dx in [a0,a1]
-                    const float dx = fminf(fmaxf(-B * b / A, a0), a1);
-                    return 0.5f * (A * dx * dx + 2.f * B * dx * b + Cc * b * b);
-                };
+            const uint32_t m = quadrant_mask(p, co, ox, oy);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float qx0 = ox + (float)((q & 1) * 8), qy0 = oy + (float)((q >> 1) * 8);
-                    const float a0 = p.x - (qx0 + 7.f), a1 = p.x - qx0;   // dx range over the quadrant's pixel centres
-                    const float b0 = p.y - (qy0 + 7.f), b1 = p.y - qy0;
-                    bool keep = true;
-                    if (pd) {
-                        const bool inside = a0 <= 0.f && a1 >= 0.f && b0 <= 0.f && b1 >= 0.f;
-                        if (!inside) {
-                            const float m = fminf(fminf(edge_x(a0, b0, b1), edge_x(a1, b0, b1)), fminf(edge_y(b0, a0, a1), edge_y(b1, a0, a1)));
-                            keep = m * 0.999f - 1e-3f <= tau;
-                        }
-                    }
-                    f[q] = keep;
-                }
-            }
+            for (int q = 0; q < 4; ++q) f[q] = (m >> q) & 1u;
         }
         uint32_t prefix[4];
 #pragma unroll
