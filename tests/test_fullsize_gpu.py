@@ -1,0 +1,130 @@
+"""GPU parity at BASELINE.json's full sizes.
+
+config 2/3 (100 000 mesh-bound SH-3 splats, 802x550): the oracle still finishes in seconds, so the
+forward is compared bit for bit and the backward within tolerance, in addition to the size-independent
+properties.  config 5 (2 000 000 SH-3 splats, 1600x1100, forward only): sortedness / range / count
+invariants, run-to-run bit-stability, and a bit-exact image against the oracle.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _np(x):
+    return x.detach().cpu().numpy()
+
+
+def _invariants(hs, H, W):
+    I = hs["num_rendered"]
+    keys = _np(hs["keys"]).view(np.uint64)
+    pl = _np(hs["point_list"]).astype(np.int64)
+    assert int(_np(hs["tiles_touched"]).astype(np.int64).sum()) == I
+    if I:
+        d = np.diff(keys.astype(np.uint64))
+        assert (keys[1:] >= keys[:-1]).all()                      # sorted by (tile, depth)
+        same = d == 0
+        assert (np.diff(pl)[same] > 0).all()                      # stable: ties keep ascending splat index
+    rng = _np(hs["ranges"]).astype(np.int64)
+    cnt = rng[:, 1] - rng[:, 0]
+    assert cnt.sum() == I and (cnt >= 0).all()
+    tiles_of_keys = (keys >> np.uint64(32)).astype(np.int64)
+    nz = np.nonzero(cnt)[0]
+    assert (tiles_of_keys[rng[nz, 0]] == nz).all() and (tiles_of_keys[rng[nz, 1] - 1] == nz).all()
+    gx = (W + 15) // 16
+    ys, xs = np.mgrid[0:H, 0:W]
+    tile_of_px = (ys // 16) * gx + xs // 16
+    assert (_np(hs["n_contrib"]).astype(np.int64) <= cnt[tile_of_px]).all()
+    fT = _np(hs["final_T"])
+    assert np.isfinite(fT).all() and (fT >= 0).all() and (fT <= 1).all()
+    assert np.isfinite(_np(hs["color"])).all()
+    assert (_np(hs["qcount"]).astype(np.int64) <= cnt[:, None]).all()
+
+
+def test_config2_100k_bound_forward_backward_vs_oracle(oracle):
+    import bench
+    from gaussianavatars_amd.debug import forward_state
+    from gaussianavatars_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+    dev = _dev()
+    H, W = 802, 550
+    g, cam = bench.build_scene(dev, 100_000, 3, W, H, 4, "fused", False)
+    with torch.no_grad():
+        g.select_mesh_by_timestep(1)
+        ins = dict(means3D=g.get_xyz, shs=g.get_features, opacities=g.get_opacity, scales=g.get_scaling, rotations=g.get_rotation)
+        ins = {k: v.detach().clone() for k, v in ins.items()}
+    tfx, tfy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    bg = torch.ones(3, device=dev)
+    rs = GaussianRasterizationSettings(H, W, tfx, tfy, bg, 1.0, cam.world_view_transform, cam.full_proj_transform, 3,
+                                       cam.camera_center, False, False)
+    hs = forward_state(rs, ins["means3D"], ins["shs"], None, ins["opacities"], ins["scales"], ins["rotations"], None)
+    _invariants(hs, H, W)
+    hs2 = forward_state(rs, ins["means3D"], ins["shs"], None, ins["opacities"], ins["scales"], ins["rotations"], None)
+    assert torch.equal(hs["color"], hs2["color"]) and torch.equal(hs["keys"], hs2["keys"])       # forward is deterministic
+    # full-size oracle
+    s = oracle.make_settings(H, W, tfx, tfy, [1, 1, 1], 1.0, _np(cam.world_view_transform), _np(cam.full_proj_transform), 3,
+                             _np(cam.camera_center))
+    a = {k: _np(v) for k, v in ins.items()}
+    st = oracle.forward(s, a["means3D"], a["shs"], None, a["opacities"], a["scales"], a["rotations"], None)
+    assert st.num_rendered == hs["num_rendered"]
+    np.testing.assert_array_equal(_np(hs["radii"]), st.radii)
+    np.testing.assert_array_equal(_np(hs["keys"]).view(np.uint64), st.keys)
+    np.testing.assert_array_equal(_np(hs["point_list"]).astype(np.uint32), st.point_list)
+    np.testing.assert_array_equal(_np(hs["n_contrib"]).astype(np.uint32), st.n_contrib)
+    assert np.array_equal(_np(hs["color"]).view(np.uint32), st.color.view(np.uint32))
+    # backward: L1 vs white (config 3) against the oracle
+    t = {k: v.clone().requires_grad_(True) for k, v in ins.items()}
+    m2 = torch.zeros_like(t["means3D"], requires_grad=True)
+    color, _ = GaussianRasterizer(rs)(means3D=t["means3D"], means2D=m2, shs=t["shs"], opacities=t["opacities"], scales=t["scales"],
+                                      rotations=t["rotations"])
+    (color - 1.0).abs().mean().backward()
+    gpix = (np.sign(st.color - 1.0) / st.color.size).astype(np.float32)
+    ref = oracle.backward(s, st, gpix)
+    for k, got in (("means3D", t["means3D"].grad), ("means2D", m2.grad), ("shs", t["shs"].grad), ("opacities", t["opacities"].grad),
+                   ("scales", t["scales"].grad), ("rotations", t["rotations"].grad)):
+        r = ref[k]
+        err = np.abs(_np(got).reshape(r.shape) - r).max() / (np.abs(r).max() + 1e-30)
+        assert err < 5e-4, f"{k}: rel err {err:.2e}"
+    # linearity of the backward in dL/dpixel
+    t2 = {k: v.clone().requires_grad_(True) for k, v in ins.items()}
+    color2, _ = GaussianRasterizer(rs)(means3D=t2["means3D"], means2D=torch.zeros_like(m2, requires_grad=True), shs=t2["shs"],
+                                       opacities=t2["opacities"], scales=t2["scales"], rotations=t2["rotations"])
+    (2.0 * (color2 - 1.0).abs().mean()).backward()
+    err = (t2["means3D"].grad - 2 * t["means3D"].grad).abs().max() / (2 * t["means3D"].grad.abs().max())
+    assert float(err) < 1e-4
+
+
+def test_config5_2m_stress_forward(oracle):
+    from gaussianavatars_amd import synthetic as S
+    from gaussianavatars_amd.debug import forward_state
+    from gaussianavatars_amd.rasterizer import GaussianRasterizationSettings
+
+    dev = _dev()
+    H, W, N = 1100, 1600, 2_000_000
+    cam = S.orbit_camera(W, H)
+    sp = S.random_splats(N, 3, 5, xyz_sigma=0.08, log_scale_mean=math.log(0.0015), log_scale_sigma=0.4)
+    sp["rotations"] /= np.linalg.norm(sp["rotations"], axis=1, keepdims=True)   # unit quaternions: I/N ~ 2-4 as the config asks
+    tfx, tfy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rs = GaussianRasterizationSettings(H, W, tfx, tfy, torch.ones(3, device=dev), 1.0, t(cam.world_view_transform),
+                                       t(cam.full_proj_transform), 3, t(cam.camera_center), False, False)
+    args = (t(sp["means3D"]), t(sp["shs"]), None, t(sp["opacities"]), t(sp["scales"]), t(sp["rotations"]), None)
+    hs = forward_state(rs, *args)
+    assert 1.0 < hs["num_rendered"] / N < 12.0
+    _invariants(hs, H, W)
+    hs2 = forward_state(rs, *args)
+    assert torch.equal(hs["color"], hs2["color"]) and torch.equal(hs["point_list"], hs2["point_list"])
+    s = oracle.make_settings(H, W, tfx, tfy, [1, 1, 1], 1.0, cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center)
+    st = oracle.forward(s, sp["means3D"], sp["shs"], None, sp["opacities"], sp["scales"], sp["rotations"], None)
+    assert st.num_rendered == hs["num_rendered"]
+    np.testing.assert_array_equal(_np(hs["point_list"]).astype(np.uint32), st.point_list)
+    assert np.array_equal(_np(hs["color"]).view(np.uint32), st.color.view(np.uint32))
