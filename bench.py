@@ -51,10 +51,30 @@ def build_scene(device, n_splats, sh_degree, width, height, n_frames, binding_im
     return g, cam
 
 
+def build_unbound_scene(device, n_splats, sh_degree, width, height):
+    """BASELINE configs[4]: un-bound GaussianModel path (SURVEY.md 8(d) cfg 5), forward only."""
+    import math
+
+    from gaussianavatars_amd import synthetic as S
+    from gaussianavatars_amd.gaussian_model import GaussianModel
+
+    sp = S.random_splats(n_splats, sh_degree, 5, xyz_sigma=0.08, log_scale_mean=math.log(0.0015), log_scale_sigma=0.4)
+    op = np.clip(sp["opacities"], 1e-6, 1 - 1e-6)
+    arrs = dict(_xyz=sp["means3D"], _scaling=np.log(sp["scales"]), _rotation=sp["rotations"], _opacity=np.log(op / (1 - op)),
+                _features_dc=sp["shs"][:, :1], _features_rest=sp["shs"][:, 1:])
+    g = GaussianModel(sh_degree)
+    g.load_arrays(arrs, device=device, requires_grad=False)
+    cam = S.orbit_camera(width, height, r=1.0, fovy_deg=20.0)
+    for k in ("world_view_transform", "full_proj_transform", "camera_center"):
+        setattr(cam, k, torch.as_tensor(getattr(cam, k), device=device))
+    return g, cam
+
+
 def one_step(g, cam, bg, target, t, train):
     from gaussianavatars_amd.gaussian_renderer import l1_loss, render
 
-    g.select_mesh_by_timestep(t)
+    if g.binding is not None:
+        g.select_mesh_by_timestep(t)
     pkg = render(cam, g, Pipe, bg)
     if not train:
         return pkg["render"].sum() * 0  # keep a device scalar for the (optional) all-reduce
@@ -82,7 +102,8 @@ def cpu_baseline(g, cam, bg, train, max_seconds=25.0):
 
     O.build()
     with torch.no_grad():
-        g.select_mesh_by_timestep(0)
+        if g.binding is not None:
+            g.select_mesh_by_timestep(0)
         arrs = dict(means3D=g.get_xyz, shs=g.get_features, opacities=g.get_opacity, scales=g.get_scaling,
                     rotations=g.get_rotation)
         arrs = {k: v.detach().float().cpu().numpy() for k, v in arrs.items()}
@@ -118,9 +139,20 @@ def main():
     ap.add_argument("--width", type=int, default=550)
     ap.add_argument("--height", type=int, default=802)
     ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--workload", choices=["cfg3", "cfg2", "cfg4", "cfg5"], default="cfg3",
+                    help="BASELINE.json configs: cfg3 = configs[2] fwd+bwd 100k (the metric, default); cfg2 = configs[1] forward; "
+                         "cfg4 = configs[3] 200k-splat 300-frame sequence fwd+bwd; cfg5 = configs[4] 2M-splat 1600x1100 forward stress")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     args = ap.parse_args()
+    if args.workload == "cfg3" and args.mode == "render":
+        args.workload = "cfg2"
+    if args.workload == "cfg2":
+        args.mode = "render"
+    elif args.workload == "cfg4":
+        args.splats, args.frames = 200_000, 300
+    elif args.workload == "cfg5":
+        args.mode, args.splats, args.width, args.height = "render", 2_000_000, 1600, 1100
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -142,7 +174,10 @@ def main():
     from gaussianavatars_amd import rasterizer as R
     from gaussianavatars_amd.frame_parallel import frames_for_rank
 
-    g, cam = build_scene(device, args.splats, 3, args.width, args.height, args.frames, args.binding, train)
+    if args.workload == "cfg5":
+        g, cam = build_unbound_scene(device, args.splats, 3, args.width, args.height)
+    else:
+        g, cam = build_scene(device, args.splats, 3, args.width, args.height, args.frames, args.binding, train)
     bg = torch.ones(3, dtype=torch.float32, device=device)
     target = torch.ones((3, args.height, args.width), dtype=torch.float32, device=device)
     my_frames = frames_for_rank(args.frames, rank, world)
@@ -229,7 +264,7 @@ def main():
             vis = vis_cpu / N
         fps = n_gpus * args.steps / elapsed
         out = {
-            "metric": "frames/sec fwd+bwd @100k SH-3 splats 802x550" if train else "frames/sec fwd @100k SH-3 splats 802x550",
+            "metric": ("frames/sec fwd+bwd" if train else "frames/sec fwd") + " @%dk SH-3 splats %dx%d" % (N // 1000, args.height, args.width),
             "value": round(fps, 2),
             "unit": "frames/s",
             "n_gpus": n_gpus,
@@ -242,11 +277,13 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": ("BASELINE configs[2]: %d mesh-bound SH-3 splats (synthetic stand-in for media/306), %dx%d (HxW), "
-                             "select_mesh_by_timestep + render + L1-vs-white + backward, no optimiser step"
-                             if train else
-                             "BASELINE configs[1]: %d mesh-bound SH-3 splats, %dx%d (HxW), select_mesh_by_timestep + render, no_grad")
-                            % (N, args.height, args.width),
+                "workload": {"cfg3": "BASELINE configs[2]: %d mesh-bound SH-3 splats (synthetic stand-in for media/306), %dx%d (HxW), "
+                                     "select_mesh_by_timestep + render + L1-vs-white + backward, no optimiser step",
+                             "cfg2": "BASELINE configs[1]: %d mesh-bound SH-3 splats, %dx%d (HxW), select_mesh_by_timestep + render, no_grad",
+                             "cfg4": "BASELINE configs[3]: %d splats bound to the 5143-vertex synthetic FLAME rig, 300-frame expression "
+                                     "sequence, %dx%d (HxW), fwd+bwd, frames sharded over the ranks",
+                             "cfg5": "BASELINE configs[4]: %d un-bound SH-3 splats, %dx%d (HxW), forward only (stress / roofline run)"}[
+                                 args.workload] % (N, args.height, args.width),
                 "splats": N, "width": args.width, "height": args.height, "sh_degree": 3,
                 "num_rendered": I, "visible_fraction": round(vis, 4), "binding": args.binding,
                 "parallelism": f"frame-parallel x{n_gpus}, scalar loss all-reduce",

@@ -291,9 +291,14 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
         }
         {
             TIMED(GSR_K_TILE_SORT, stream);
-    // large tiles first (long, few), then the small class (short, many)
-            hipLaunchKernelGGL((gsr::k_tile_sort<GSR_SORT_LDS_KEYS, 1024>), dim3(tiles), dim3(1024), 0, stream, (uint32_t)GSR_SORT_SMALL_KEYS,
+    // largest tiles first (long, few), then the small class (short, many)
+            hipLaunchKernelGGL((gsr::k_tile_sort<GSR_SORT_XL_KEYS, 1024>), dim3(tiles), dim3(1024), 0, stream, (uint32_t)GSR_SORT_LDS_KEYS,
                                0xFFFFFFFFu, gx, (const uint32_t*)(b + bl.tile_order), (const uint32_t*)tile_count, (const uint32_t*)(b + bl.tile_start),
+                               (unsigned long long*)(b + bl.keys), (uint32_t*)(b + bl.point_list), (float4*)(b + bl.qrecords),
+                               (uint32_t*)(b + bl.qcount), (const float2*)pa.xy, (const float4*)pa.conic_opacity, (const float4*)pa.rgb, cap,
+                               (const unsigned long long*)total_dev);
+            hipLaunchKernelGGL((gsr::k_tile_sort<GSR_SORT_LDS_KEYS, 1024>), dim3(tiles), dim3(1024), 0, stream, (uint32_t)GSR_SORT_SMALL_KEYS,
+                               (uint32_t)GSR_SORT_LDS_KEYS, gx, (const uint32_t*)(b + bl.tile_order), (const uint32_t*)tile_count, (const uint32_t*)(b + bl.tile_start),
                                (unsigned long long*)(b + bl.keys), (uint32_t*)(b + bl.point_list), (float4*)(b + bl.qrecords),
                                (uint32_t*)(b + bl.qcount), (const float2*)pa.xy, (const float4*)pa.conic_opacity, (const float4*)pa.rgb, cap,
                                (const unsigned long long*)total_dev);

@@ -14,6 +14,7 @@
 #define GSR_WAVE 64
 #define GSR_TILE_PIX (GSR_BLOCK_X * GSR_BLOCK_Y)
 #define GSR_SORT_LDS_KEYS 8192   // 64 KiB of uint64 keys per workgroup in the tile sort
+#define GSR_SORT_XL_KEYS 16384  // 128 KiB of LDS, 16 keys per thread; beyond this the sort runs in global memory
 #define GSR_SORT_SMALL_KEYS 2048 // tiles up to this many entries take the 256-thread / 16 KiB class
 #define GSR_ACC_STRIDE 12        // floats per splat in the backward accumulator (48 B, one atomic burst)
 

@@ -417,15 +417,16 @@ __device__ __forceinline__ u64 shfl64(u64 v, int src_lane)
 }
 constexpr int top_bit(int m) { int b = 1; while ((b << 1) <= m) b <<= 1; return b; }
 
-template <int M, int THREADS>
-__device__ __forceinline__ void cx_step(u64 (&key)[8], u64* __restrict__ sk, int tid)
+template <int M, int THREADS, int EPT>
+__device__ __forceinline__ void cx_step(u64 (&key)[EPT], u64* __restrict__ sk, int tid)
 {
-    constexpr int KM = M & 7;
-    constexpr int LM = (M >> 3) & 63;
-    constexpr int WM = M >> 9;
+    constexpr int LE = EPT == 16 ? 4 : 3;                 // log2(keys per thread)
+    constexpr int KM = M & (EPT - 1);
+    constexpr int LM = (M >> LE) & 63;
+    constexpr int WM = M >> (LE + 6);
     if constexpr (LM == 0 && WM == 0) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < EPT; ++k) {
             if ((k ^ KM) > k) {
                 const u64 a = key[k], b = key[k ^ KM];
                 const bool sw = a > b;
@@ -434,25 +435,25 @@ __device__ __forceinline__ void cx_step(u64 (&key)[8], u64* __restrict__ sk, int
             }
         }
     } else {
-        constexpr int TOP = top_bit(M);                  // >= 8 here: decided by the thread id alone
-        const bool keep_min = (tid & (TOP >> 3)) == 0;
-        u64 other[8];
+        constexpr int TOP = top_bit(M);                  // >= EPT here: decided by the thread id alone
+        const bool keep_min = (tid & (TOP >> LE)) == 0;
+        u64 other[EPT];
         if constexpr (WM == 0) {
             const int pl = (tid & 63) ^ LM;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) other[k] = shfl64(key[k ^ KM], pl);
+            for (int k = 0; k < EPT; ++k) other[k] = shfl64(key[k ^ KM], pl);
         } else {
             // staging layout sk[k * THREADS + tid]: consecutive lanes hit consecutive banks
 #pragma unroll
-            for (int k = 0; k < 8; ++k) sk[k * THREADS + tid] = key[k];
+            for (int k = 0; k < EPT; ++k) sk[k * THREADS + tid] = key[k];
             __syncthreads();
-            const int pt = tid ^ (M >> 3);
+            const int pt = tid ^ (M >> LE);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) other[k] = sk[(k ^ KM) * THREADS + pt];
+            for (int k = 0; k < EPT; ++k) other[k] = sk[(k ^ KM) * THREADS + pt];
             __syncthreads();
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < EPT; ++k) {
             const u64 a = key[k], b = other[k];
             const bool a_gt = a > b;
             key[k] = (a_gt == keep_min) ? b : a;      // keep_min: take the smaller, else the larger
@@ -460,34 +461,34 @@ __device__ __forceinline__ void cx_step(u64 (&key)[8], u64* __restrict__ sk, int
     }
 }
 
-template <int J, int THREADS>
-__device__ __forceinline__ void cx_tail(u64 (&key)[8], u64* __restrict__ sk, int tid)
+template <int J, int THREADS, int EPT>
+__device__ __forceinline__ void cx_tail(u64 (&key)[EPT], u64* __restrict__ sk, int tid)
 {
     if constexpr (J > 0) {
-        cx_step<J, THREADS>(key, sk, tid);
-        cx_tail<(J >> 1), THREADS>(key, sk, tid);
+        cx_step<J, THREADS, EPT>(key, sk, tid);
+        cx_tail<(J >> 1), THREADS, EPT>(key, sk, tid);
     }
 }
-template <int SIZE, int N, int THREADS>
-__device__ __forceinline__ void cx_stage(u64 (&key)[8], u64* __restrict__ sk, int tid)
+template <int SIZE, int N, int THREADS, int EPT>
+__device__ __forceinline__ void cx_stage(u64 (&key)[EPT], u64* __restrict__ sk, int tid)
 {
     if constexpr (SIZE <= N) {
-        cx_step<SIZE - 1, THREADS>(key, sk, tid);            // first step of a merge: partner = i ^ (size - 1)
-        cx_tail<(SIZE >> 2), THREADS>(key, sk, tid);         // then i ^ j for j = size/4 ... 1
-        cx_stage<(SIZE << 1), N, THREADS>(key, sk, tid);
+        cx_step<SIZE - 1, THREADS, EPT>(key, sk, tid);            // first step of a merge: partner = i ^ (size - 1)
+        cx_tail<(SIZE >> 2), THREADS, EPT>(key, sk, tid);         // then i ^ j for j = size/4 ... 1
+        cx_stage<(SIZE << 1), N, THREADS, EPT>(key, sk, tid);
     }
 }
 
-// sorts seg[0..n) (n <= 8*THREADS); thread t ends up holding sorted positions 8t .. 8t+7 in key[]
-template <int THREADS>
-__device__ __forceinline__ void block_sort_regs(u64 (&key)[8], u64* __restrict__ sk, const u64* __restrict__ seg, uint32_t n, int tid)
+// sorts seg[0..n) (n <= EPT*THREADS); thread t ends up holding sorted positions EPT*t .. EPT*t+EPT-1 in key[]
+template <int THREADS, int EPT>
+__device__ __forceinline__ void block_sort_regs(u64 (&key)[EPT], u64* __restrict__ sk, const u64* __restrict__ seg, uint32_t n, int tid)
 {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const uint32_t i = (uint32_t)tid * 8u + (uint32_t)k;
+    for (int k = 0; k < EPT; ++k) {
+        const uint32_t i = (uint32_t)tid * (uint32_t)EPT + (uint32_t)k;
         key[k] = i < n ? seg[i] : ~0ull;
     }
-    cx_stage<2, 8 * THREADS, THREADS>(key, sk, tid);
+    cx_stage<2, EPT * THREADS, THREADS, EPT>(key, sk, tid);
 }
 
 // Which of the tile's four 8x8 quadrants can the splat's {alpha >= 1/255} ellipse reach?  (bit q set = keep)
@@ -531,21 +532,22 @@ __device__ __forceinline__ uint32_t quadrant_mask(float2 p, float4 co, float ox,
 // their compacted records land next to each other (coalesced stores).  Membership is one 4-bit mask per
 // entry; the stable compaction into the four quadrant streams uses ballots for the in-wave rank and ONE
 // exclusive scan over the (chunk, wave) counters -- three barriers in total, gathers issued four chunks at a time.
-template <int THREADS>
-__device__ __forceinline__ void epilogue_striped(const u64 (&key)[8], uint32_t n, uint32_t tile, uint32_t start, float ox, float oy,
+template <int THREADS, int EPT>
+__device__ __forceinline__ void epilogue_striped(const u64 (&key)[EPT], uint32_t n, uint32_t tile, uint32_t start, float ox, float oy,
                                                  u64* __restrict__ seg, uint32_t* __restrict__ point_list, float4* __restrict__ qbase,
                                                  uint32_t* __restrict__ qcount, const float2* __restrict__ xy,
                                                  const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb,
-                                                 u64* __restrict__ sk, uint32_t (*__restrict__ cntw)[8 * (THREADS / 64) + 1], int tid)
+                                                 u64* __restrict__ sk, uint32_t (*__restrict__ cntw)[EPT * (THREADS / 64) + 1], int tid)
 {
-    constexpr int NW = THREADS / 64, NE = 8 * NW;   // waves, (chunk, wave) counters per quadrant
+    constexpr int NW = THREADS / 64, NE = EPT * NW;   // waves, (chunk, wave) counters per quadrant
+    constexpr int PER = (NE + 63) / 64;               // counters per lane in the scan
     const int lane = tid & 63, wid = tid >> 6;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) sk[tid * 8 + k] = key[k];
+    for (int k = 0; k < EPT; ++k) sk[tid * EPT + k] = key[k];
     __syncthreads();
-    uint32_t msk[8], rank[8];   // rank: 4 x 8-bit in-wave exclusive ranks (0..63)
+    uint32_t msk[EPT], rank[EPT];   // rank: 4 x 8-bit in-wave exclusive ranks (0..63)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < EPT / 4; ++h) {
         float2 p[4];
         float4 co[4];
 #pragma unroll
@@ -574,23 +576,32 @@ __device__ __forceinline__ void epilogue_striped(const u64 (&key)[8], uint32_t n
     __syncthreads();
     // exclusive scan of the NE counters of each quadrant (wave q scans quadrant q; NE <= 128 = 2 per lane)
     if (wid < 4) {
-        const int e0 = 2 * lane, e1 = 2 * lane + 1;
-        const uint32_t a0 = e0 < NE ? cntw[wid][e0] : 0u, a1 = e1 < NE ? cntw[wid][e1] : 0u;
-        uint32_t incl = a0 + a1;
+        uint32_t a[PER], sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int e = PER * lane + j;
+            a[j] = e < NE ? cntw[wid][e] : 0u;
+            sum += a[j];
+        }
+        uint32_t incl = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t up = (uint32_t)__builtin_amdgcn_ds_bpermute((lane >= d ? lane - d : lane) << 2, (int)incl);
             if (lane >= d) incl += up;
         }
-        const uint32_t excl = incl - (a0 + a1);
-        if (e0 < NE) cntw[wid][e0] = excl;
-        if (e1 < NE) cntw[wid][e1] = excl + a0;
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int e = PER * lane + j;
+            if (e < NE) cntw[wid][e] = run;
+            run += a[j];
+        }
         if (lane == 63) cntw[wid][NE] = incl;   // total
     }
     __syncthreads();
     const u64 tile_hi = (u64)tile << 32;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < EPT / 4; ++h) {
         float2 p[4];
         float4 co[4], cl[4];
         u64 kk[4];
@@ -631,9 +642,65 @@ __device__ __forceinline__ void epilogue_striped(const u64 (&key)[8], uint32_t n
     if (tid < 4) qcount[4 * tile + tid] = cntw[tid][NE];
 }
 
-// Two size classes share this body: tiles with n_lo < n <= n_hi are handled, the rest exit at once.
-//   small: <= 2048 entries, 256 threads, 16 KiB LDS  (many workgroups per CU)
-//   large: 1024 threads, 64 KiB LDS; beyond 8192 entries the sort runs in place in global memory
+// ------------------------------------------------------------------------------------------
+// Oversize tiles (more entries than the LDS class holds): sort KEYS-sized chunks with the register sort,
+// then merge the runs pairwise in global memory (merge path: every thread binary-searches its diagonal
+// and merges a private output slice).  `tmp` is scratch of at least n keys (the tile's still-unused
+// quadrant-record region); the sorted result always ends in seg[0..n).  Keys are unique per tile.
+// ------------------------------------------------------------------------------------------
+template <int THREADS, int EPT>
+__device__ __forceinline__ void oversize_sort(u64* __restrict__ seg, u64* __restrict__ tmp, u64* __restrict__ sk, uint32_t n, int tid)
+{
+    constexpr uint32_t CH = (uint32_t)(THREADS * EPT);
+    for (uint32_t c0 = 0; c0 < n; c0 += CH) {
+        const uint32_t m = min(CH, n - c0);
+        u64 key[EPT];
+        block_sort_regs<THREADS, EPT>(key, sk, seg + c0, m, tid);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const uint32_t i = (uint32_t)tid * (uint32_t)EPT + (uint32_t)k;
+            if (i < m) tmp[c0 + i] = key[k];
+        }
+        __syncthreads();
+    }
+    u64* src = tmp;
+    u64* dst = seg;
+    for (uint32_t w = CH; w < n; w <<= 1) {
+        for (uint32_t p0 = 0; p0 < n; p0 += 2 * w) {
+            const u64* A = src + p0;
+            const uint32_t na = min(w, n - p0);
+            const u64* B = A + na;
+            const uint32_t nb = (p0 + na < n) ? min(w, n - p0 - na) : 0u;
+            const uint32_t total = na + nb;
+            const uint32_t S = (total + THREADS - 1) / THREADS;
+            const uint32_t d0 = min((uint32_t)tid * S, total), d1 = min(d0 + S, total);
+            // merge path: a = number of A elements among the first d0 outputs
+            uint32_t lo = d0 > nb ? d0 - nb : 0u, hi = min(d0, na);
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (A[mid] < B[d0 - 1 - mid]) lo = mid + 1; else hi = mid;
+            }
+            uint32_t a = lo, b = d0 - lo;
+            for (uint32_t o = d0; o < d1; ++o) {
+                const bool takeA = b >= nb || (a < na && A[a] < B[b]);
+                dst[p0 + o] = takeA ? A[a] : B[b];
+                a += takeA ? 1u : 0u;
+                b += takeA ? 0u : 1u;
+            }
+        }
+        __syncthreads();
+        u64* t = src; src = dst; dst = t;
+    }
+    if (src != seg) {   // odd number of passes (or none): bring the result home
+        for (uint32_t i = tid; i < n; i += THREADS) seg[i] = src[i];
+        __syncthreads();
+    }
+}
+
+// Three size classes share this body: tiles with n_lo < n <= n_hi are handled, the rest exit at once.
+//   small: <= 2048 entries, 256 threads x 8 keys, 16 KiB LDS (many workgroups per CU)
+//   large: <= 8192 entries, 1024 threads x 8 keys, 64 KiB LDS
+//   xl:    <= 16384 entries, 1024 threads x 16 keys, 128 KiB LDS; beyond that chunked sorts + merges in global memory
 template <int KEYS, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n_hi, int gx, const uint32_t* __restrict__ tile_order,
                                                         const uint32_t* __restrict__ tile_count,
@@ -645,7 +712,8 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
 {
     __shared__ unsigned long long skeys[KEYS];
     __shared__ uint32_t wave_cnt[4][THREADS / 64];   // [quadrant][wave]  (chunked fallback epilogue)
-    __shared__ uint32_t cntw[4][8 * (THREADS / 64) + 1];   // [quadrant][(chunk, wave)] + total  (striped epilogue)
+    constexpr int EPT = KEYS / THREADS;
+    __shared__ uint32_t cntw[4][EPT * (THREADS / 64) + 1];   // [quadrant][(chunk, wave)] + total  (striped epilogue)
     if (*total_dev > capacity) return;
     const uint32_t tile = tile_order[blockIdx.x];
     const uint32_t n = tile_count[tile];
@@ -660,15 +728,14 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
     const float ox = (float)((tile % (uint32_t)gx) * GSR_BLOCK_X), oy = (float)((tile / (uint32_t)gx) * GSR_BLOCK_Y);
     float4* const qbase = qrecords + (size_t)3 * 4 * start;
     if (in_lds) {
-        static_assert(KEYS == 8 * THREADS, "register sort holds 8 keys per thread");
-        static_assert(KEYS <= 65535, "quadrant counters are packed 16 bits each");
-        u64 key[8];
-        block_sort_regs<THREADS>(key, skeys, seg, n, tid);
-        epilogue_striped<THREADS>(key, n, tile, start, ox, oy, seg, point_list, qbase, qcount, xy, conic_opacity, rgb, skeys, cntw, tid);
+        static_assert(EPT == 8 || EPT == 16, "register sort holds 8 or 16 keys per thread");
+        u64 key[EPT];
+        block_sort_regs<THREADS, EPT>(key, skeys, seg, n, tid);
+        epilogue_striped<THREADS, EPT>(key, n, tile, start, ox, oy, seg, point_list, qbase, qcount, xy, conic_opacity, rgb, skeys, cntw, tid);
         return;
     } else {
-        __syncthreads();
-        bitonic_sort(seg, n, tid, THREADS);  // rare: > 8192 instances in one tile, sort in place in global memory
+        // more entries than this class holds in LDS: chunked register sorts + global merge passes
+        oversize_sort<THREADS, EPT>(seg, reinterpret_cast<u64*>(qbase), skeys, n, tid);
     }
     // ---- epilogue: reference-format keys / point list, and the four 8x8-quadrant record streams --------
     // A record goes to quadrant q only if the exact ellipse {alpha >= 1/255} of the splat can reach a pixel
@@ -733,6 +800,9 @@ template __global__ void k_tile_sort<GSR_SORT_SMALL_KEYS, 256>(uint32_t, uint32_
 template __global__ void k_tile_sort<GSR_SORT_LDS_KEYS, 1024>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
                                                                float4*, uint32_t*, const float2*, const float4*, const float4*, unsigned long long,
                                                                const unsigned long long*);
+template __global__ void k_tile_sort<GSR_SORT_XL_KEYS, 1024>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
+                                                              float4*, uint32_t*, const float2*, const float4*, const float4*, unsigned long long,
+                                                              const unsigned long long*);
 
 // ------------------------------------------------------------------------------------------
 // k_render: front-to-back compositing.  Workgroup = one 16x16 tile = 4 independent waves, wave w
