@@ -198,8 +198,17 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
 __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.P) return;
     const int M = a.M;
+    // SH coefficients in, SH gradients out: both as one coalesced stream per workgroup through LDS
+    // (gsr_device.h); each thread reads its coefficient row and then overwrites it with the gradient row.
+    __shared__ float sh_lds[GSR_SH_ROWS * GSR_SH_MAX_STRIDE];
+    const bool sh_staged = !a.use_precomp_color && a.dL_dsh != nullptr && M <= 16;
+    const int first = blockIdx.x * GSR_SH_ROWS, rows = min(GSR_SH_ROWS, a.P - first);
+    if (sh_staged) {
+        sh_rows_load(sh_lds, a.shs, first, rows, M, (int)threadIdx.x);
+        __syncthreads();
+    }
+    if (i < a.P) {
     float dmean[3] = {0.f, 0.f, 0.f};
     float gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f};
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
     float gcol[3] = {0.f, 0.f, 0.f};
     float g2x = 0.f, g2y = 0.f, gop = 0.f;
     const bool vis = a.radii[i] > 0;
-    float* gsh = a.dL_dsh ? a.dL_dsh + (size_t)3 * M * i : nullptr;
+    float* gsh = a.dL_dsh ? (sh_staged ? sh_lds + (int)threadIdx.x * sh_row_stride(M) : a.dL_dsh + (size_t)3 * M * i) : nullptr;
 
     if (vis) {
         const float* ac = a.acc + (size_t)GSR_ACC_STRIDE * i;
@@ -293,7 +302,14 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
 
         // ---- SH: coefficients and view direction ---------------------------------------------
         if (!a.use_precomp_color) {
-            const float* sh = a.shs + (size_t)3 * M * i;
+            // the coefficient row is copied to registers first: in staged mode the gradient row overwrites it in LDS
+            float shr[48];
+            {
+                const float* row = sh_staged ? sh_lds + (int)threadIdx.x * sh_row_stride(M) : a.shs + (size_t)3 * M * i;
+#pragma unroll
+                for (int k = 0; k < 48; ++k) shr[k] = k < 3 * M ? row[k] : 0.f;
+            }
+            const float* sh = shr;
             const int deg = s.sh_degree;
             const float d0 = mx - s.campos[0], d1 = my - s.campos[1], d2 = mz - s.campos[2];
             const float sum2 = d0 * d0 + d1 * d1 + d2 * d2;
@@ -409,6 +425,11 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
         for (int k = 0; k < 3; ++k) a.dL_dscales[3 * i + k] = dscale[k];
     }
     if (a.dL_drotations) reinterpret_cast<float4*>(a.dL_drotations)[i] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    }   // i < P
+    if (sh_staged) {
+        __syncthreads();
+        sh_rows_store(sh_lds, a.dL_dsh, first, rows, M, (int)threadIdx.x);
+    }
 }
 
 }  // namespace gsr

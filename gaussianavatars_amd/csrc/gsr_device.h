@@ -158,6 +158,63 @@ __device__ __forceinline__ void for_each_tile(int minx, int miny, int maxx, int 
     }
 }
 
+// ---- SH rows staged through LDS -------------------------------------------------------------------
+// A splat's SH block is 3*M contiguous floats (192 B at degree 3).  Read or written per thread that is a
+// 192-byte stride between lanes; instead the workgroup moves its 256 rows as one contiguous, fully
+// coalesced float4 stream to/from LDS and every thread works on its own LDS row.  Row stride (3M)|1 is odd,
+// so the per-thread dword accesses are bank-conflict free.
+#define GSR_SH_ROWS 256
+#define GSR_SH_MAX_STRIDE 49
+__device__ __forceinline__ int sh_row_stride(int M) { return (3 * M) | 1; }
+
+__device__ __forceinline__ void sh_rows_load(float* __restrict__ lds, const float* __restrict__ src, int first, int rows, int M, int tid)
+{
+    const int w = 3 * M, stride = sh_row_stride(M), total = rows * w;
+    const float* base = src + (size_t)first * w;
+    if ((total & 3) == 0 && ((((size_t)first * w) & 3) == 0)) {
+        const float4* b4 = reinterpret_cast<const float4*>(base);
+        for (int f = tid * 4; f < total; f += GSR_SH_ROWS * 4) {
+            const float4 v = b4[f >> 2];
+            int r = f / w, c = f - r * w;
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                lds[r * stride + c] = e[k];
+                if (++c == w) { c = 0; ++r; }
+            }
+        }
+    } else {
+        for (int f = tid; f < total; f += GSR_SH_ROWS) {
+            const int r = f / w, c = f - r * w;
+            lds[r * stride + c] = base[f];
+        }
+    }
+}
+
+__device__ __forceinline__ void sh_rows_store(const float* __restrict__ lds, float* __restrict__ dst, int first, int rows, int M, int tid)
+{
+    const int w = 3 * M, stride = sh_row_stride(M), total = rows * w;
+    float* base = dst + (size_t)first * w;
+    if ((total & 3) == 0 && ((((size_t)first * w) & 3) == 0)) {
+        float4* b4 = reinterpret_cast<float4*>(base);
+        for (int f = tid * 4; f < total; f += GSR_SH_ROWS * 4) {
+            int r = f / w, c = f - r * w;
+            float e[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                e[k] = lds[r * stride + c];
+                if (++c == w) { c = 0; ++r; }
+            }
+            b4[f >> 2] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+    } else {
+        for (int f = tid; f < total; f += GSR_SH_ROWS) {
+            const int r = f / w, c = f - r * w;
+            base[f] = lds[r * stride + c];
+        }
+    }
+}
+
 // ---- kernel argument blocks and entry points (gsr_forward.hip / gsr_backward.hip) ----------------
 struct PreprocessArgs {
     int P, M;

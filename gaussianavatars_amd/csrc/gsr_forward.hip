@@ -152,8 +152,8 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
                         const float dx = mx - s.campos[0], dy = my - s.campos[1], dz = mz - s.campos[2];
                         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
                         const float x = dx / len, y = dy / len, z = dz / len;
-                        // (M,3) floats per splat; 16-byte aligned because M*12 % 16 == 0 only for M%4==0,
-                        // so load scalars and let the compiler merge what alignment allows
+                        // 3*M contiguous floats per splat, consumed entirely by this thread: the 192-byte rows are
+                        // fetched line by line through L1 (measured faster than staging them through LDS here)
                         const float* sh = a.shs + (size_t)3 * a.M * i;
                         float res[3];
 #pragma unroll
