@@ -57,6 +57,21 @@ class GaussianModel:
         self.active_sh_degree = self.max_sh_degree
         self.max_radii2D = torch.zeros((self._xyz.shape[0]), device=device)
 
+    def load_ply(self, path, device="cuda", **kwargs):
+        """scene/gaussian_model.py:282-332: leaf tensors from the reference's PLY (binding -> int32)."""
+        from . import io as gio
+
+        self.load_arrays(gio.load_ply(str(path), self.max_sh_degree), device=device)
+
+    def save_ply(self, path):
+        """scene/gaussian_model.py:253-275"""
+        from . import io as gio
+
+        arrs = {k: getattr(self, k).detach().cpu().numpy() for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")}
+        if self.binding is not None:
+            arrs["binding"] = self.binding.detach().cpu().numpy()
+        gio.save_ply(str(path), arrs)
+
     # ---- accessors ------------------------------------------------------------------------------
     @property
     def get_scaling(self):
@@ -193,6 +208,26 @@ class FlameGaussianModel(GaussianModel):
                 fp[k].requires_grad_(True)
         self.flame_param = fp
         self.num_timesteps = fp["expr"].shape[0]
+
+    def load_ply(self, path, device="cuda", **kwargs):
+        """scene/flame_gaussian_model.py:229-237: the PLY plus the flame_param.npz stored next to it."""
+        import os
+
+        from . import io as gio
+
+        super().load_ply(path, device=device)
+        if not kwargs.get("has_target", False):
+            self.load_flame_param(gio.load_flame_param(os.path.join(os.path.dirname(str(path)), "flame_param.npz")), device=device)
+
+    def save_ply(self, path):
+        """scene/flame_gaussian_model.py:219-224"""
+        import os
+
+        from . import io as gio
+
+        super().save_ply(path)
+        gio.save_flame_param(os.path.join(os.path.dirname(str(path)), "flame_param.npz"),
+                             {k: v.detach().cpu().numpy() for k, v in self.flame_param.items()})
 
     def update_mesh_by_param_dict(self, flame_param):
         shape = flame_param["shape"] if "shape" in flame_param else self.flame_param["shape"]
