@@ -183,16 +183,28 @@ def main():
     my_frames = frames_for_rank(args.frames, rank, world)
 
     def run(n, offset):
+        """n steps.  The scalar all-reduce of step k is issued asynchronously (RCCL runs it on its own stream)
+        and only waited for after step k+1 has been enqueued, so its latency never idles the compute stream."""
         loss_sum = torch.zeros((), device=device)
+        pending = None
         for i in range(n):
             t = my_frames[(offset + i) % len(my_frames)]
             with torch.set_grad_enabled(train):
                 l = one_step(g, cam, bg, target, t, train)
             if dist is not None:
-                dist.all_reduce(l, op=dist.ReduceOp.SUM)  # the one collective of the path: a scalar
-            loss_sum += l
+                buf = l.reshape(1).clone()
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)  # the one collective of the path: a scalar
+                if pending is not None:
+                    pending[0].wait()
+                    loss_sum += pending[1][0]
+                pending = (work, buf)
+            else:
+                loss_sum += l
             if train:
                 zero_grads(g)
+        if pending is not None:
+            pending[0].wait()
+            loss_sum += pending[1][0]
         return loss_sum
 
     def fence():

@@ -192,11 +192,13 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0) return fail(GSR_E_ARG, "P must be >= 0");
     if (!out_color || !num_rendered_host) return fail(GSR_E_ARG, "out_color / num_rendered_host is NULL");
-    if ((shs == nullptr) == (colors_precomp == nullptr))
-        return fail(GSR_E_ARG, "Please provide excatly one of either SHs or precomputed colors!");
-    const bool has_sr = scales != nullptr && rotations != nullptr;
-    if (((scales == nullptr) != (rotations == nullptr)) || (has_sr == (cov3D_precomp != nullptr)))
-        return fail(GSR_E_ARG, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (P > 0) {   // with no splats there is nothing to point at: empty tensors legitimately arrive as NULL
+        if ((shs == nullptr) == (colors_precomp == nullptr))
+            return fail(GSR_E_ARG, "Please provide excatly one of either SHs or precomputed colors!");
+        const bool has_sr = scales != nullptr && rotations != nullptr;
+        if (((scales == nullptr) != (rotations == nullptr)) || (has_sr == (cov3D_precomp != nullptr)))
+            return fail(GSR_E_ARG, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    }
     if (shs && M < (settings->sh_degree + 1) * (settings->sh_degree + 1))
         return fail(GSR_E_ARG, "shs has %d coefficients per splat but sh_degree %d needs %d", M, settings->sh_degree,
                     (settings->sh_degree + 1) * (settings->sh_degree + 1));
@@ -240,11 +242,9 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
     pa.clamped = (uint8_t*)(g + gl.clamped);
     const int pblocks = (P + 255) / 256;
     if (pblocks > 0) {
-        {
-            TIMED(GSR_K_PREPROCESS, stream);
-    hipLaunchKernelGGL(gsr::k_preprocess, dim3(pblocks), dim3(256), 0, stream, ds, pa);
-                    KERNEL_CHECK("k_preprocess", stream, dbg);
-        }
+        TIMED(GSR_K_PREPROCESS, stream);
+        hipLaunchKernelGGL(gsr::k_preprocess, dim3(pblocks), dim3(256), 0, stream, ds, pa);
+        KERNEL_CHECK("k_preprocess", stream, dbg);
     }
 
     // binning workgroups: each owns a contiguous chunk of splats and an LDS histogram over the tiles
@@ -267,56 +267,53 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
     *slot = 0;
     unsigned long long* slot_dev = nullptr;
     HIP_TRY(hipHostGetDevicePointer((void**)&slot_dev, (void*)slot, 0));
+    uint32_t* tile_start = (uint32_t*)(b + bl.tile_start);
+    uint32_t* tile_cursor = (uint32_t*)(b + bl.tile_cursor);
+    uint32_t* tile_order = (uint32_t*)(b + bl.tile_order);
+    uint2* ranges = (uint2*)(b + bl.ranges);
     {
         TIMED(GSR_K_TILE_SCAN, stream);
-    hipLaunchKernelGGL(gsr::k_tile_scan, dim3(1), dim3(1024), 0, stream, tiles, (const uint32_t*)tile_count,
-                               (uint32_t*)(b + bl.tile_start), (uint32_t*)(b + bl.tile_cursor), (uint2*)(b + bl.ranges),
-                               (uint32_t*)(b + bl.tile_order), total_dev,
-                               slot_dev, seq);
-            KERNEL_CHECK("k_tile_scan", stream, dbg);
+        hipLaunchKernelGGL(gsr::k_tile_scan, dim3(1), dim3(1024), 0, stream, tiles, (const uint32_t*)tile_count, tile_start, tile_cursor,
+                           ranges, tile_order, total_dev, slot_dev, seq);
+        KERNEL_CHECK("k_tile_scan", stream, dbg);
     }
 
     // Optimistic launch: the rest of the frame is enqueued against the caller's capacity before the
     // host knows I; every kernel re-checks *total_dev <= capacity on the device and does nothing
     // otherwise.  The host then waits only for the scan (early in the frame), not for the frame.
     const unsigned long long cap = (unsigned long long)binning_capacity;
+    unsigned long long* keys = (unsigned long long*)(b + bl.keys);
+    uint32_t* point_list = (uint32_t*)(b + bl.point_list);
+    float4* qrecords = (float4*)(b + bl.qrecords);
+    uint32_t* qcount = (uint32_t*)(b + bl.qcount);
     if (pblocks > 0) {
-        {
-            TIMED(GSR_K_SCATTER, stream);
-    hipLaunchKernelGGL(gsr::k_scatter, dim3(bin_blocks), dim3(256), hist_bytes, stream, P, gx, tiles, (const float*)pa.depths,
-                                       (const ushort4*)pa.rect, (const uint32_t*)pa.tiles_touched, (const uint32_t*)(b + bl.tile_start),
-                                       (uint32_t*)(b + bl.tile_cursor), (unsigned long long*)(b + bl.keys), cap,
-                                       (const unsigned long long*)total_dev);
-                    KERNEL_CHECK("k_scatter", stream, dbg);
-        }
-        {
-            TIMED(GSR_K_TILE_SORT, stream);
-    // largest tiles first (long, few), then the small class (short, many)
-            hipLaunchKernelGGL((gsr::k_tile_sort<GSR_SORT_XL_KEYS, 1024>), dim3(tiles), dim3(1024), 0, stream, (uint32_t)GSR_SORT_LDS_KEYS,
-                               0xFFFFFFFFu, gx, (const uint32_t*)(b + bl.tile_order), (const uint32_t*)tile_count, (const uint32_t*)(b + bl.tile_start),
-                               (unsigned long long*)(b + bl.keys), (uint32_t*)(b + bl.point_list), (float4*)(b + bl.qrecords),
-                               (uint32_t*)(b + bl.qcount), (const float2*)pa.xy, (const float4*)pa.conic_opacity, (const float4*)pa.rgb, cap,
+        TIMED(GSR_K_SCATTER, stream);
+        hipLaunchKernelGGL(gsr::k_scatter, dim3(bin_blocks), dim3(256), hist_bytes, stream, P, gx, tiles, (const float*)pa.depths,
+                           (const ushort4*)pa.rect, (const uint32_t*)pa.tiles_touched, (const uint32_t*)tile_start, tile_cursor, keys, cap,
+                           (const unsigned long long*)total_dev);
+        KERNEL_CHECK("k_scatter", stream, dbg);
+    }
+    {
+        // per-tile sort + quadrant streams: three size classes, the long (few) ones first.  Launched even when
+        // P == 0 so that every tile's quadrant counters are written.
+        TIMED(GSR_K_TILE_SORT, stream);
+        auto sort_class = [&](auto kernel, int threads, uint32_t n_lo, uint32_t n_hi) {
+            hipLaunchKernelGGL(kernel, dim3(tiles), dim3(threads), 0, stream, n_lo, n_hi, gx, (const uint32_t*)tile_order,
+                               (const uint32_t*)tile_count, (const uint32_t*)tile_start, keys, point_list, qrecords, qcount,
+                               (const float2*)pa.xy, (const float4*)pa.conic_opacity, (const float4*)pa.rgb, cap,
                                (const unsigned long long*)total_dev);
-            hipLaunchKernelGGL((gsr::k_tile_sort<GSR_SORT_LDS_KEYS, 1024>), dim3(tiles), dim3(1024), 0, stream, (uint32_t)GSR_SORT_SMALL_KEYS,
-                               (uint32_t)GSR_SORT_LDS_KEYS, gx, (const uint32_t*)(b + bl.tile_order), (const uint32_t*)tile_count, (const uint32_t*)(b + bl.tile_start),
-                               (unsigned long long*)(b + bl.keys), (uint32_t*)(b + bl.point_list), (float4*)(b + bl.qrecords),
-                               (uint32_t*)(b + bl.qcount), (const float2*)pa.xy, (const float4*)pa.conic_opacity, (const float4*)pa.rgb, cap,
-                               (const unsigned long long*)total_dev);
-            hipLaunchKernelGGL((gsr::k_tile_sort<GSR_SORT_SMALL_KEYS, 256>), dim3(tiles), dim3(256), 0, stream, 0u,
-                               (uint32_t)GSR_SORT_SMALL_KEYS, gx, (const uint32_t*)(b + bl.tile_order), (const uint32_t*)tile_count, (const uint32_t*)(b + bl.tile_start),
-                               (unsigned long long*)(b + bl.keys), (uint32_t*)(b + bl.point_list), (float4*)(b + bl.qrecords),
-                               (uint32_t*)(b + bl.qcount), (const float2*)pa.xy, (const float4*)pa.conic_opacity, (const float4*)pa.rgb, cap,
-                               (const unsigned long long*)total_dev);
-            KERNEL_CHECK("k_tile_sort", stream, dbg);
-        }
+        };
+        sort_class(gsr::k_tile_sort<GSR_SORT_XL_KEYS, 1024>, 1024, (uint32_t)GSR_SORT_LDS_KEYS, 0xFFFFFFFFu);
+        sort_class(gsr::k_tile_sort<GSR_SORT_LDS_KEYS, 1024>, 1024, (uint32_t)GSR_SORT_SMALL_KEYS, (uint32_t)GSR_SORT_LDS_KEYS);
+        sort_class(gsr::k_tile_sort<GSR_SORT_SMALL_KEYS, 256>, 256, 0u, (uint32_t)GSR_SORT_SMALL_KEYS);
+        KERNEL_CHECK("k_tile_sort", stream, dbg);
     }
     {
         TIMED(GSR_K_RENDER, stream);
-    hipLaunchKernelGGL(gsr::k_render, dim3(tiles), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order), (const uint2*)(b + bl.ranges),
-                               (const uint32_t*)(b + bl.qcount), (const float4*)(b + bl.qrecords), (float*)(im + il.final_T),
-                               (uint32_t*)(im + il.n_contrib), (uint32_t*)(im + il.n_contrib_q), out_color,
-                               cap, (const unsigned long long*)total_dev);
-            KERNEL_CHECK("k_render", stream, dbg);
+        hipLaunchKernelGGL(gsr::k_render, dim3(tiles), dim3(256), 0, stream, ds, (const uint32_t*)tile_order, (const uint2*)ranges,
+                           (const uint32_t*)qcount, (const float4*)qrecords, (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib),
+                           (uint32_t*)(im + il.n_contrib_q), out_color, cap, (const unsigned long long*)total_dev);
+        KERNEL_CHECK("k_render", stream, dbg);
     }
 
     // wait for the scan's post
@@ -382,13 +379,11 @@ int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M, const float*
 
     HIP_TRY(hipMemsetAsync(grad_scratch, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), stream));
     if (num_rendered > 0) {
-        {
-            TIMED(GSR_K_RENDER_BWD, stream);
-    hipLaunchKernelGGL(gsr::k_render_bwd, dim3(gx * gy), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order), (const uint2*)(b + bl.ranges),
-                                       (const uint32_t*)(b + bl.qcount), (const float4*)(b + bl.qrecords), (const float*)(im + il.final_T),
-                                       (const uint32_t*)(im + il.n_contrib_q), dL_dpix, grad_scratch);
-                    KERNEL_CHECK("k_render_bwd", stream, dbg);
-        }
+        TIMED(GSR_K_RENDER_BWD, stream);
+        hipLaunchKernelGGL(gsr::k_render_bwd, dim3(gx * gy), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order),
+                           (const uint2*)(b + bl.ranges), (const uint32_t*)(b + bl.qcount), (const float4*)(b + bl.qrecords),
+                           (const float*)(im + il.final_T), (const uint32_t*)(im + il.n_contrib_q), dL_dpix, grad_scratch);
+        KERNEL_CHECK("k_render_bwd", stream, dbg);
     }
     gsr::PreBwdArgs pa;
     pa.P = P; pa.M = M;
@@ -405,8 +400,8 @@ int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M, const float*
     pa.dL_dcov3D = dL_dcov3D;
     {
         TIMED(GSR_K_PREPROCESS_BWD, stream);
-    hipLaunchKernelGGL(gsr::k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, stream, ds, pa);
-            KERNEL_CHECK("k_preprocess_bwd", stream, dbg);
+        hipLaunchKernelGGL(gsr::k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, stream, ds, pa);
+        KERNEL_CHECK("k_preprocess_bwd", stream, dbg);
     }
     return GSR_OK;
 }

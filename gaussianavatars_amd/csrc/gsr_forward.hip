@@ -1,18 +1,18 @@
 // gsr_forward.hip -- forward kernels of the MI355X-native splat rasterizer (gfx950, wave64).
 //
 // Pipeline (one frame):
-//   k_preprocess   per splat : project, EWA cov2D, conic, radius, tile rect, SH->RGB;
-//                              counts instances per tile with L2 atomics
-//   k_tile_scan    1 block   : exclusive scan of the per-tile counts -> tile_start / ranges / I,
-//                              posts I to the host mailbox
-//   k_scatter      per splat : drops (depth bits << 32 | splat) into its tiles' segments
-//   k_tile_sort    per tile  : LDS bitonic sort of the segment by (depth, splat) == the order a
-//                              stable radix sort of (tile << 32 | depth) produces; emits the
-//                              reference-format sorted keys / point list and a packed 48-byte
-//                              record per instance (geometry gathered once, here)
-//   k_render       per tile  : 4 waves x 8x8 pixels; every wave walks the tile's record stream
-//                              through the scalar unit (wave-uniform s_loads, no LDS, no
-//                              barriers) and composites front to back
+//   k_preprocess   per splat : project, EWA cov2D, conic, radius, tile rect, SH->RGB
+//   k_count        <=256 WGs : tile histogram of a chunk of splats in LDS, non-empty bins -> L2 atomics
+//   k_tile_scan    1 block   : exclusive scan of the per-tile counts -> tile_start / ranges / I, posts I to the
+//                              host mailbox, and lists the tiles heaviest-first for the per-tile kernels
+//   k_scatter      same WGs  : drops (depth bits << 32 | splat) into its tiles' segments (LDS slot allocation)
+//   k_tile_sort    per tile  : register/cross-lane bitonic sort of the segment by (depth, splat) == the order a
+//                              stable radix sort of (tile << 32 | depth) produces; emits the reference-format
+//                              sorted keys / point list and, per 8x8 quadrant, a stream of packed 48-byte records
+//                              culled with the exact {alpha >= 1/255} ellipse (geometry gathered once, here)
+//   k_render       per tile  : 4 waves x 8x8 pixels; every wave walks its quadrant's record stream through the
+//                              scalar unit (wave-uniform s_loads, software-pipelined, no LDS, no barriers) and
+//                              composites front to back
 //
 // Behavioural spec: SURVEY.md Appendix A.1-A.3 (the reference's rasterizer is an un-vendored
 // submodule; call site gaussian_renderer/__init__.py:37-52,86-94).  This TU is built with
@@ -365,44 +365,9 @@ __global__ __launch_bounds__(256) void k_scatter(int P, int gx, int tiles, const
 }
 
 // ------------------------------------------------------------------------------------------
-// k_tile_sort: one workgroup per tile.  Normalised bitonic network (every compare-exchange puts
-// the smaller key at the lower index), so a non-power-of-two segment works with virtual +inf
-// padding: exchanges whose partner index is >= n are no-ops.
-// ------------------------------------------------------------------------------------------
-template <typename KeyAcc>
-__device__ __forceinline__ void bitonic_sort(KeyAcc k, uint32_t n, int tid, int nthreads)
-{
-    uint32_t n2 = 1;
-    while (n2 < n) n2 <<= 1;
-    for (uint32_t size = 2; size <= n2; size <<= 1) {
-        // first step of a merge: partner = i ^ (size - 1)
-        for (uint32_t t = tid; t < n2 / 2; t += nthreads) {
-            const uint32_t half = size >> 1;
-            const uint32_t i = (t / half) * size + (t % half);
-            const uint32_t p = i ^ (size - 1);
-            if (p < n) {
-                const unsigned long long a = k[i], b = k[p];
-                if (a > b) { k[i] = b; k[p] = a; }
-            }
-        }
-        __syncthreads();
-        for (uint32_t j = size >> 2; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < n2 / 2; t += nthreads) {
-                const uint32_t i = (t / j) * (2 * j) + (t % j);
-                const uint32_t p = i + j;
-                if (p < n) {
-                    const unsigned long long a = k[i], b = k[p];
-                    if (a > b) { k[i] = b; k[p] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Register-resident block sort for the in-LDS size classes: 8 keys per thread (index i = 8*tid + k).
-// Same normalised bitonic network as bitonic_sort() above, but a compare-exchange whose partner index
+// Normalised bitonic network (every compare-exchange puts the smaller key at the lower index, first step
+// of a merge pairs i with i ^ (size-1), the rest with i ^ j), but a compare-exchange whose partner index
 // i ^ M differs only in the low 3 bits is done in registers, one that differs in lane bits goes through
 // the cross-lane network (ds_bpermute), and only masks reaching across waves (M >= 512) touch LDS with
 // a barrier: 10 barrier steps instead of 91 for 8192 keys.  Every mask is a compile-time constant, so

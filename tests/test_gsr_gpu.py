@@ -165,6 +165,18 @@ def test_argument_contract():
     assert vis.tolist() == [True, False]
 
 
+def test_zero_splats_renders_background():
+    from gaussianavatars_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+    dev = _dev()
+    z = lambda *s: torch.zeros(*s, device=dev)
+    bg = torch.tensor([0.25, 0.5, 0.75], device=dev)
+    rs = GaussianRasterizationSettings(37, 53, 0.5, 0.5, bg, 1.0, torch.eye(4, device=dev), torch.eye(4, device=dev), 0, z(3), False, False)
+    color, radii = GaussianRasterizer(rs)(means3D=z(0, 3), means2D=z(0, 3), opacities=z(0, 1), shs=z(0, 1, 3), scales=z(0, 3), rotations=z(0, 4))
+    assert radii.numel() == 0
+    assert torch.equal(color, bg[:, None, None].expand(3, 37, 53))
+
+
 def test_replay_on_capacity_overflow(oracle):
     """A frame needing more instances than the current capacity hint is replayed, not truncated."""
     from gaussianavatars_amd import rasterizer as R
