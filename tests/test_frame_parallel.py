@@ -37,6 +37,11 @@ def _worker(rank, world, port, out):
     assert (r, w) == (rank, world)
     total, count = fp.run_frames(lambda t: torch.tensor(float(t * t)), 21, r, w)
     one = fp.allreduce_scalar(torch.tensor(float(rank + 1)), "max")
+    # data-parallel gradient all-reduce (bucketed): two leaves, tiny bucket size to force several buckets
+    a, b = torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7))
+    a.grad, b.grad = torch.full((5, 3), float(rank + 1)), torch.arange(7.0) * (rank + 1)
+    fp.allreduce_gradients([a, b], average=True, bucket_bytes=32)
+    assert torch.allclose(a.grad, torch.full((5, 3), 1.5)) and torch.allclose(b.grad, torch.arange(7.0) * 1.5)
     out.put((rank, float(total), count, float(one)))
     dist.barrier()
     dist.destroy_process_group()
