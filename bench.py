@@ -253,8 +253,9 @@ def main():
             "k_preprocess_bwd": 300 * N + 256 * N,
         }
         pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "r01_b_pmc_fetch_write_per_launch.json")
-        if os.path.exists(pmc_path):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/README.md)
+        pmc_tag = "cfg5" if args.workload == "cfg5" else ("cfg3" if args.workload in ("cfg3", "cfg2") else None)
+        pmc_path = os.path.join(ROOT, "profiles", f"r01_d_{pmc_tag}_pmc_fetch_write_per_launch.json")
+        if pmc_tag and os.path.exists(pmc_path):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/README.md)
             for k, v in json.load(open(pmc_path)).items():
                 name = k.replace("void ", "").split("::")[-1].split("<")[0]   # the two k_tile_sort classes add up
                 # FETCH_SIZE/WRITE_SIZE are KB; gfx950 FETCH_SIZE counts half of a wide streaming read (MI355X_MICROARCH.md)

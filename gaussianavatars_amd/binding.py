@@ -290,7 +290,7 @@ class _BindSplats(torch.autograd.Function):
         N, F = x.shape[0], fc.shape[0]
         f32 = dict(dtype=torch.float32, device=dev)
         d_x, d_ls, d_q = torch.empty((N, 3), **f32), torch.empty((N, 3), **f32), torch.empty((N, 4), **f32)
-        d_face = torch.empty((F, 17), **f32)
+        d_face = torch.empty(17 * F, **f32)   # four contiguous blocks: center | orien_mat | scaling | orien_quat
         gs = [None if g is None else _f32(g) for g in (g_xyz, g_scaling, g_rot)]
         with torch.cuda.device(dev):
             if ctx.csr is not None:
@@ -302,7 +302,8 @@ class _BindSplats(torch.autograd.Function):
                 _chk(lib.gab_bind_backward(N, F, _p(x), _p(ls), _p(q), _p(b), ctx.is64, _p(fc), _p(fR), _p(fs), _p(fq), _p(gs[0]),
                                            _p(gs[1]), _p(gs[2]), _p(d_x), _p(d_ls), _p(d_q), _p(d_face), _stream(dev)),
                      "gab_bind_backward")
-        return (d_x, d_ls, d_q, None, d_face[:, 3:12].reshape(F, 3, 3), d_face[:, 12:13], d_face[:, 0:3], d_face[:, 13:17], None)
+        return (d_x, d_ls, d_q, None, d_face[3 * F: 12 * F].view(F, 3, 3), d_face[12 * F: 13 * F].view(F, 1), d_face[: 3 * F].view(F, 3),
+                d_face[13 * F:].view(F, 4), None)
 
 
 def bind_splats(xyz, log_scaling, rotation, binding, face_R, face_scale, face_center, face_quat, csr=None):

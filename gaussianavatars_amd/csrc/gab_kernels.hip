@@ -659,24 +659,28 @@ __global__ __launch_bounds__(256) void k_bind_bwd(int N, const float* __restrict
                                                    const float* __restrict__ fR, const float* __restrict__ fs, const float* __restrict__ fq,
                                                    const float* __restrict__ g_xyz, const float* __restrict__ g_scaling,
                                                    const float* __restrict__ g_rot, float* __restrict__ d_xyz,
-                                                   float* __restrict__ d_log_scaling, float* __restrict__ d_rotation, float* __restrict__ d_face)
+                                                   float* __restrict__ d_log_scaling, float* __restrict__ d_rotation, float* __restrict__ d_face, int F)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const long long f = index_at(binding, is64, i);
     const float s = fs[f];
     const float* R = fR + 9 * f;
-    float* df = d_face + 17 * f;
+    // d_face: four contiguous blocks  center (F,3) | orien_mat (F,9) | scaling (F,1) | orien_quat (F,4)
+    float* dfc = d_face + 3 * f;
+    float* dfR = d_face + (size_t)3 * F + 9 * f;
+    float* dfs = d_face + (size_t)12 * F + f;
+    float* dfq = d_face + (size_t)13 * F + 4 * f;
     float ds = 0.f;
     const float x[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
     const float gx[3] = {g_xyz ? g_xyz[3 * i] : 0.f, g_xyz ? g_xyz[3 * i + 1] : 0.f, g_xyz ? g_xyz[3 * i + 2] : 0.f};
     for (int c = 0; c < 3; ++c) d_xyz[3 * i + c] = s * (R[c] * gx[0] + R[3 + c] * gx[1] + R[6 + c] * gx[2]);
     if (g_xyz) {
         for (int r = 0; r < 3; ++r) {
-            unsafeAtomicAdd(&df[r], gx[r]);
+            unsafeAtomicAdd(&dfc[r], gx[r]);
             const float rx = R[3 * r] * x[0] + R[3 * r + 1] * x[1] + R[3 * r + 2] * x[2];
             ds += gx[r] * rx;
-            for (int c = 0; c < 3; ++c) unsafeAtomicAdd(&df[3 + 3 * r + c], s * gx[r] * x[c]);
+            for (int c = 0; c < 3; ++c) unsafeAtomicAdd(&dfR[3 * r + c], s * gx[r] * x[c]);
         }
     }
     for (int k = 0; k < 3; ++k) {
@@ -685,7 +689,7 @@ __global__ __launch_bounds__(256) void k_bind_bwd(int N, const float* __restrict
         d_log_scaling[3 * i + k] = g * e * s;
         ds += g * e;
     }
-    unsafeAtomicAdd(&df[12], ds);
+    unsafeAtomicAdd(dfs, ds);
     const float4 qf = reinterpret_cast<const float4*>(fq)[f];
     const float4 q = reinterpret_cast<const float4*>(rotation)[i];
     const float na = qnorm_clamped(qf), nb = qnorm_clamped(q);
@@ -698,10 +702,10 @@ __global__ __launch_bounds__(256) void k_bind_bwd(int N, const float* __restrict
     const float bdb = b.x * db.x + b.y * db.y + b.z * db.z + b.w * db.w;
     reinterpret_cast<float4*>(d_rotation)[i] = make_float4((db.x - b.x * bdb) / nb, (db.y - b.y * bdb) / nb, (db.z - b.z * bdb) / nb, (db.w - b.w * bdb) / nb);
     if (g_rot) {
-        unsafeAtomicAdd(&df[13], (da.x - a.x * ada) / na);
-        unsafeAtomicAdd(&df[14], (da.y - a.y * ada) / na);
-        unsafeAtomicAdd(&df[15], (da.z - a.z * ada) / na);
-        unsafeAtomicAdd(&df[16], (da.w - a.w * ada) / na);
+        unsafeAtomicAdd(&dfq[0], (da.x - a.x * ada) / na);
+        unsafeAtomicAdd(&dfq[1], (da.y - a.y * ada) / na);
+        unsafeAtomicAdd(&dfq[2], (da.z - a.z * ada) / na);
+        unsafeAtomicAdd(&dfq[3], (da.w - a.w * ada) / na);
     }
 }
 
@@ -778,11 +782,17 @@ __global__ __launch_bounds__(256) void k_bind_bwd_csr(int F, const float* __rest
         acc[k] = v;
     }
     if (okf) {
-        // lanes 0..7 of the group write 17 floats: lane k writes k, k+8, k+16
-        float* df = d_face + 17 * f;
+        // the 8 lanes of the group share the 17 stores; d_face is four contiguous blocks
+        // center (F,3) | orien_mat (F,9) | scaling (F,1) | orien_quat (F,4)
 #pragma unroll
-        for (int k = 0; k < 17; ++k)
-            if ((k & 7) == sub) df[k] = acc[k];
+        for (int k = 0; k < 17; ++k) {
+            if ((k & 7) != sub) continue;
+            float* dst = k < 3 ? d_face + 3 * f + k
+                       : k < 12 ? d_face + (size_t)3 * F + 9 * f + (k - 3)
+                       : k < 13 ? d_face + (size_t)12 * F + f
+                                : d_face + (size_t)13 * F + 4 * f + (k - 13);
+            *dst = acc[k];
+        }
     }
 }
 
@@ -944,7 +954,7 @@ int gab_bind_backward(int32_t N, int32_t F, const float* xyz, const float* log_s
         !d_rotation)
         return fail(GAB_E_ARG, "gab_bind_backward: NULL buffer");
     hipLaunchKernelGGL(gab::k_bind_bwd, dim3((N + 255) / 256), dim3(256), 0, st, N, xyz, log_scaling, rotation, binding, is64, face_orien_mat,
-                       face_scaling, face_orien_quat, d_out_xyz, d_out_scaling, d_out_rotation, d_xyz, d_log_scaling, d_rotation, d_face);
+                       face_scaling, face_orien_quat, d_out_xyz, d_out_scaling, d_out_rotation, d_xyz, d_log_scaling, d_rotation, d_face, F);
     LAUNCH_CHECK("k_bind_bwd");
     return GAB_OK;
 }

@@ -82,13 +82,13 @@ int gab_bind_forward(int32_t N, int32_t F, const float* xyz, const float* log_sc
                      const void* binding, int32_t index_is_i64, const float* face_center, const float* face_orien_mat,
                      const float* face_scaling, const float* face_orien_quat,
                      float* out_xyz, float* out_scaling, float* out_rotation, void* stream);
-/* d_face (F,17): per-face accumulator laid out center(3) | orien_mat(9) | scaling(1) | orien_quat(4),
- * fully written (zero-filled, then accumulated). */
+/* d_face: 17*F floats, four contiguous blocks  center (F,3) | orien_mat (F,3,3) | scaling (F,1) | orien_quat (F,4)
+ * (so each block is directly the gradient tensor of one face attribute), fully written (zero-filled, then accumulated). */
 int gab_bind_backward(int32_t N, int32_t F, const float* xyz, const float* log_scaling, const float* rotation,
                       const void* binding, int32_t index_is_i64, const float* face_center, const float* face_orien_mat,
                       const float* face_scaling, const float* face_orien_quat,
                       const float* d_out_xyz, const float* d_out_scaling, const float* d_out_rotation,
-                      float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face /*(F,17)*/, void* stream);
+                      float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face /*17*F, see above*/, void* stream);
 
 /* Atomic-free, deterministic variant of gab_bind_backward.  `order` (int32 N): splat indices sorted by face;
  * `face_begin` (int32 F+1): CSR offsets into `order`.  Both depend only on `binding` (build them once per
@@ -97,7 +97,7 @@ int gab_bind_backward_csr(int32_t N, int32_t F, const float* xyz, const float* l
                           const float* face_orien_mat, const float* face_scaling, const float* face_orien_quat,
                           const float* d_out_xyz, const float* d_out_scaling, const float* d_out_rotation,
                           const int32_t* order, const int32_t* face_begin,
-                          float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face /*(F,17)*/, void* stream);
+                          float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face /*17*F, same four blocks*/, void* stream);
 
 #ifdef __cplusplus
 }
