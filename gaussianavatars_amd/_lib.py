@@ -36,7 +36,7 @@ class GsrSettings(C.Structure):
 
 class GsrGeomLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
-                ("depths", "xy", "conic_opacity", "rgb", "cov3D", "rect", "tiles_touched", "clamped", "total")]
+                ("depths", "grec", "cov3D", "rect", "tiles_touched", "clamped", "total")]
 
 
 class GsrBinningLayout(C.Structure):

@@ -141,9 +141,7 @@ int gsr_geom_layout(int32_t P, GsrGeomLayout* o)
     const size_t n = (size_t)P, A = 256;
     size_t off = 0;
     o->depths = off;        off = align_up(off + n * 4, A);
-    o->xy = off;            off = align_up(off + n * 8, A);
-    o->conic_opacity = off; off = align_up(off + n * 16, A);
-    o->rgb = off;           off = align_up(off + n * 16, A);
+    o->grec = off;          off = align_up(off + n * 48, A);
     o->cov3D = off;         off = align_up(off + n * 24, A);
     o->rect = off;          off = align_up(off + n * 8, A);
     o->tiles_touched = off; off = align_up(off + n * 4, A);
@@ -233,9 +231,7 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
     pa.scales = scales; pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp;
     pa.radii = radii;
     pa.depths = (float*)(g + gl.depths);
-    pa.xy = (float2*)(g + gl.xy);
-    pa.conic_opacity = (float4*)(g + gl.conic_opacity);
-    pa.rgb = (float4*)(g + gl.rgb);
+    pa.grec = (float4*)(g + gl.grec);
     pa.cov3D = (float*)(g + gl.cov3D);
     pa.rect = (ushort4*)(g + gl.rect);
     pa.tiles_touched = (uint32_t*)(g + gl.tiles_touched);
@@ -300,7 +296,7 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
         auto sort_class = [&](auto kernel, int threads, uint32_t n_lo, uint32_t n_hi) {
             hipLaunchKernelGGL(kernel, dim3(tiles), dim3(threads), 0, stream, n_lo, n_hi, gx, (const uint32_t*)tile_order,
                                (const uint32_t*)tile_count, (const uint32_t*)tile_start, keys, point_list, qrecords, qcount,
-                               (const float2*)pa.xy, (const float4*)pa.conic_opacity, (const float4*)pa.rgb, cap,
+                               (const float4*)pa.grec, cap,
                                (const unsigned long long*)total_dev);
         };
         sort_class(gsr::k_tile_sort<GSR_SORT_XL_KEYS, 1024>, 1024, (uint32_t)GSR_SORT_LDS_KEYS, 0xFFFFFFFFu);

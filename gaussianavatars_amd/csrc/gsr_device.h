@@ -227,9 +227,7 @@ struct PreprocessArgs {
     const float* __restrict__ cov3D_precomp;
     int32_t* __restrict__ radii;
     float* __restrict__ depths;
-    float2* __restrict__ xy;
-    float4* __restrict__ conic_opacity;
-    float4* __restrict__ rgb;
+    float4* __restrict__ grec;
     float* __restrict__ cov3D;
     ushort4* __restrict__ rect;
     uint32_t* __restrict__ tiles_touched;
@@ -266,8 +264,8 @@ __global__ void k_scatter(int P, int gx, int tiles, const float* depths, const u
                           unsigned long long capacity, const unsigned long long* total_dev);
 template <int KEYS, int THREADS>
 __global__ void k_tile_sort(uint32_t n_lo, uint32_t n_hi, int gx, const uint32_t* tile_order, const uint32_t* tile_count, const uint32_t* tile_start, unsigned long long* keys,
-                            uint32_t* point_list, float4* qrecords, uint32_t* qcount, const float2* xy, const float4* conic_opacity,
-                            const float4* rgb, unsigned long long capacity, const unsigned long long* total_dev);
+                            uint32_t* point_list, float4* qrecords, uint32_t* qcount, const float4* grec,
+                            unsigned long long capacity, const unsigned long long* total_dev);
 __global__ void k_render(Settings s, const uint32_t* tile_order, const uint2* ranges, const uint32_t* qcount, const float4* qrecords, float* final_T,
                          uint32_t* n_contrib, uint32_t* n_contrib_q, float* out_color, unsigned long long capacity,
                          const unsigned long long* total_dev);

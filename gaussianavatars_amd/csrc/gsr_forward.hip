@@ -198,9 +198,9 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         const uint32_t n = visible ? (uint32_t)((rmaxx - rminx) * (rmaxy - rminy)) : 0u;
         a.radii[i] = radius;
         a.depths[i] = depth;
-        a.xy[i] = make_float2(px, py);
-        a.conic_opacity[i] = make_float4(con0, con1, con2, opac);
-        a.rgb[i] = make_float4(col[0], col[1], col[2], 0.f);
+        a.grec[3 * i + 0] = make_float4(px, py, con0, con1);
+        a.grec[3 * i + 1] = make_float4(con2, opac, col[0], col[1]);
+        a.grec[3 * i + 2] = make_float4(col[2], 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < 6; ++k) a.cov3D[6 * i + k] = c6[k];
         a.rect[i] = make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy);
@@ -500,8 +500,7 @@ __device__ __forceinline__ uint32_t quadrant_mask(float2 p, float4 co, float ox,
 template <int THREADS, int EPT>
 __device__ __forceinline__ void epilogue_striped(const u64 (&key)[EPT], uint32_t n, uint32_t tile, uint32_t start, float ox, float oy,
                                                  u64* __restrict__ seg, uint32_t* __restrict__ point_list, float4* __restrict__ qbase,
-                                                 uint32_t* __restrict__ qcount, const float2* __restrict__ xy,
-                                                 const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb,
+                                                 uint32_t* __restrict__ qcount, const float4* __restrict__ grec,
                                                  u64* __restrict__ sk, uint32_t (*__restrict__ cntw)[EPT * (THREADS / 64) + 1], int tid)
 {
     constexpr int NW = THREADS / 64, NE = EPT * NW;   // waves, (chunk, wave) counters per quadrant
@@ -513,20 +512,19 @@ __device__ __forceinline__ void epilogue_striped(const u64 (&key)[EPT], uint32_t
     uint32_t msk[EPT], rank[EPT];   // rank: 4 x 8-bit in-wave exclusive ranks (0..63)
 #pragma unroll
     for (int h = 0; h < EPT / 4; ++h) {
-        float2 p[4];
-        float4 co[4];
+        float4 g0[4], g1[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t i = (uint32_t)(4 * h + k) * THREADS + (uint32_t)tid;
             const uint32_t idx = i < n ? (uint32_t)sk[i] : 0u;
-            p[k] = xy[idx];
-            co[k] = conic_opacity[idx];
+            g0[k] = grec[3 * (size_t)idx + 0];
+            g1[k] = grec[3 * (size_t)idx + 1];
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = 4 * h + k;
             const uint32_t i = (uint32_t)c * THREADS + (uint32_t)tid;
-            const uint32_t m = i < n ? quadrant_mask(p[k], co[k], ox, oy) : 0u;
+            const uint32_t m = i < n ? quadrant_mask(make_float2(g0[k].x, g0[k].y), make_float4(g0[k].z, g0[k].w, g1[k].x, g1[k].y), ox, oy) : 0u;
             msk[c] = m;
             uint32_t r = 0;
 #pragma unroll
@@ -567,17 +565,17 @@ __device__ __forceinline__ void epilogue_striped(const u64 (&key)[EPT], uint32_t
     const u64 tile_hi = (u64)tile << 32;
 #pragma unroll
     for (int h = 0; h < EPT / 4; ++h) {
-        float2 p[4];
-        float4 co[4], cl[4];
+        float4 g0[4], g1[4];
+        float g2x[4];
         u64 kk[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t i = (uint32_t)(4 * h + k) * THREADS + (uint32_t)tid;
             kk[k] = i < n ? sk[i] : 0ull;
             const uint32_t idx = (uint32_t)kk[k];
-            p[k] = xy[idx];
-            co[k] = conic_opacity[idx];
-            cl[k] = rgb[idx];
+            g0[k] = grec[3 * (size_t)idx + 0];
+            g1[k] = grec[3 * (size_t)idx + 1];
+            g2x[k] = grec[3 * (size_t)idx + 2].x;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -588,9 +586,9 @@ __device__ __forceinline__ void epilogue_striped(const u64 (&key)[EPT], uint32_t
                 seg[i] = tile_hi | (kk[k] >> 32);   // reference-format key: tile id | depth bits
                 point_list[start + i] = idx;
                 const uint32_t m = msk[c];
-                const float4 r0 = make_float4(p[k].x, p[k].y, co[k].x, co[k].y);
-                const float4 r1 = make_float4(co[k].z, co[k].w, cl[k].x, cl[k].y);
-                const float4 r2 = make_float4(cl[k].z, __uint_as_float(idx), __uint_as_float(i), 0.f);
+                const float4 r0 = g0[k];
+                const float4 r1 = g1[k];
+                const float4 r2 = make_float4(g2x[k], __uint_as_float(idx), __uint_as_float(i), 0.f);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if ((m >> q) & 1u) {
@@ -671,8 +669,7 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
                                                         const uint32_t* __restrict__ tile_count,
                                                     const uint32_t* __restrict__ tile_start, unsigned long long* __restrict__ keys,
                                                     uint32_t* __restrict__ point_list, float4* __restrict__ qrecords,
-                                                    uint32_t* __restrict__ qcount, const float2* __restrict__ xy,
-                                                    const float4* __restrict__ conic_opacity, const float4* __restrict__ rgb,
+                                                    uint32_t* __restrict__ qcount, const float4* __restrict__ grec,
                                                     unsigned long long capacity, const unsigned long long* __restrict__ total_dev)
 {
     __shared__ unsigned long long skeys[KEYS];
@@ -696,7 +693,7 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
         static_assert(EPT == 8 || EPT == 16, "register sort holds 8 or 16 keys per thread");
         u64 key[EPT];
         block_sort_regs<THREADS, EPT>(key, skeys, seg, n, tid);
-        epilogue_striped<THREADS, EPT>(key, n, tile, start, ox, oy, seg, point_list, qbase, qcount, xy, conic_opacity, rgb, skeys, cntw, tid);
+        epilogue_striped<THREADS, EPT>(key, n, tile, start, ox, oy, seg, point_list, qbase, qcount, grec, skeys, cntw, tid);
         return;
     } else {
         // more entries than this class holds in LDS: chunked register sorts + global merge passes
@@ -719,13 +716,10 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
             const uint32_t idx = (uint32_t)k;
             seg[i] = tile_hi | (k >> 32);
             point_list[start + i] = idx;
-            const float2 p = xy[idx];
-            const float4 co = conic_opacity[idx];
-            const float4 c = rgb[idx];
-            r0 = make_float4(p.x, p.y, co.x, co.y);
-            r1 = make_float4(co.z, co.w, c.x, c.y);
-            r2 = make_float4(c.z, __uint_as_float(idx), __uint_as_float(i), 0.f);
-            const uint32_t m = quadrant_mask(p, co, ox, oy);
+            r0 = grec[3 * (size_t)idx + 0];
+            r1 = grec[3 * (size_t)idx + 1];
+            r2 = make_float4(grec[3 * (size_t)idx + 2].x, __uint_as_float(idx), __uint_as_float(i), 0.f);
+            const uint32_t m = quadrant_mask(make_float2(r0.x, r0.y), make_float4(r0.z, r0.w, r1.x, r1.y), ox, oy);
 #pragma unroll
             for (int q = 0; q < 4; ++q) f[q] = (m >> q) & 1u;
         }
@@ -760,13 +754,13 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
 }
 
 template __global__ void k_tile_sort<GSR_SORT_SMALL_KEYS, 256>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
-                                                                float4*, uint32_t*, const float2*, const float4*, const float4*, unsigned long long,
+                                                                float4*, uint32_t*, const float4*, unsigned long long,
                                                                 const unsigned long long*);
 template __global__ void k_tile_sort<GSR_SORT_LDS_KEYS, 1024>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
-                                                               float4*, uint32_t*, const float2*, const float4*, const float4*, unsigned long long,
+                                                               float4*, uint32_t*, const float4*, unsigned long long,
                                                                const unsigned long long*);
 template __global__ void k_tile_sort<GSR_SORT_XL_KEYS, 1024>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
-                                                              float4*, uint32_t*, const float2*, const float4*, const float4*, unsigned long long,
+                                                              float4*, uint32_t*, const float4*, unsigned long long,
                                                               const unsigned long long*);
 
 // ------------------------------------------------------------------------------------------

@@ -49,9 +49,9 @@ def forward_state(rs: GaussianRasterizationSettings, means3D, shs, colors_precom
     out = dict(
         color=color, radii=radii, num_rendered=I, capacity=cap,
         depths=_view(geom, gl.depths, P, f32),
-        xy=_view(geom, gl.xy, 2 * P, f32).view(P, 2),
-        conic_opacity=_view(geom, gl.conic_opacity, 4 * P, f32).view(P, 4),
-        rgb=_view(geom, gl.rgb, 4 * P, f32).view(P, 4)[:, :3],
+        xy=_view(geom, gl.grec, 12 * P, f32).view(P, 12)[:, 0:2],
+        conic_opacity=_view(geom, gl.grec, 12 * P, f32).view(P, 12)[:, 2:6],
+        rgb=_view(geom, gl.grec, 12 * P, f32).view(P, 12)[:, 6:9],
         cov3D=_view(geom, gl.cov3D, 6 * P, f32).view(P, 6),
         rect=_view(geom, gl.rect, 4 * P, i16).view(P, 4),
         tiles_touched=_view(geom, gl.tiles_touched, P, u32),

@@ -62,9 +62,9 @@ typedef struct GsrSettings {
  * the oracle bit for bit. */
 typedef struct GsrGeomLayout {
     size_t depths;         /* float  [P]                                   */
-    size_t xy;             /* float2 [P]   pixel centre                     */
-    size_t conic_opacity;  /* float4 [P]   (A, B, C, opacity)               */
-    size_t rgb;            /* float4 [P]   (r, g, b, unused)                */
+    size_t grec;           /* float4 [3P]  per-splat blend record, 48 B in ONE place so the binning gathers touch
+                              one line per instance:  (x, y, A, B | C, opacity, r, g | b, 0, 0, 0)
+                              x,y = pixel centre, A,B,C = conic                                         */
     size_t cov3D;          /* float  [6P]  xx xy xz yy yz zz                */
     size_t rect;           /* uint16 [4P]  tile rect min.x min.y max.x max.y */
     size_t tiles_touched;  /* uint32 [P]                                   */
