@@ -61,6 +61,12 @@ GSR_SYMBOLS = {
     "gsr_backward": (C.c_int, [C.POINTER(GsrSettings), C.c_int32, C.c_int32] + [C.c_void_p] * 6 +
                      [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p] +
                      [C.c_void_p] * 8 + [C.c_void_p]),
+    "gsr_forward_ex": (C.c_int, [C.POINTER(GsrSettings), C.c_int32, C.c_int32] + [C.c_void_p] * 8 +
+                       [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                        C.POINTER(C.c_int64), C.c_void_p]),
+    "gsr_backward_ex": (C.c_int, [C.POINTER(GsrSettings), C.c_int32, C.c_int32] + [C.c_void_p] * 7 +
+                        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p] +
+                        [C.c_void_p] * 9 + [C.c_void_p]),
     "gsr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_profile_enable": (C.c_int, [C.c_int]),
     "gsr_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -129,6 +135,7 @@ GAB_SYMBOLS = {
     "gab_bind_forward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gab_bind_backward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gab_bind_backward_csr": (C.c_int, [C.c_int32, C.c_int32] + [_P] * 16),
+    "gab_zero_buffers": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _P]),
 }
 
 _gab = None

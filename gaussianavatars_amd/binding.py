@@ -180,12 +180,12 @@ class _FlameForwardTimestep(torch.autograd.Function):
         V, T, t, widths = rig.V, ctx.T, ctx.t, ctx.widths
         need = ctx.needs_input_grad  # (head, t, shape, expr, rotation, neck, jaw, eyes, translation, static_offset)
         f32 = dict(dtype=torch.float32, device=dev)
-        flat = torch.zeros(T * sum(widths), **f32)
-        offs, o = [], 0
-        for w in widths:
-            offs.append(o)
-            o += T * w
-        outp = [C.c_void_p(flat.data_ptr() + 4 * (off + t * w)) for off, w in zip(offs, widths)]
+        # full (T,k) gradient tables: separately allocated (autograd can adopt them as .grad without a copy),
+        # zero-filled by ONE launch, then row t is written by the backward kernels
+        tables = [torch.empty((T, w), **f32) for w in widths]
+        ptrs = (C.c_void_p * len(tables))(*[x.data_ptr() for x in tables])
+        sizes = (C.c_int32 * len(tables))(*[T * w for w in widths])
+        outp = [C.c_void_p(x.data_ptr() + 4 * t * w) for x, w in zip(tables, widths)]
         d_shape = torch.empty(rig.n_shape, **f32) if need[2] else None
         d_so = torch.empty(3 * V, **f32) if (ctx.has_so and need[9]) else None
         scratch = torch.empty(3 * V, **f32)
@@ -194,9 +194,10 @@ class _FlameForwardTimestep(torch.autograd.Function):
         ws_bwd = ws.clone()
         rows = [C.c_void_p(x.data_ptr() + 4 * t * w) for x, w in zip(tabs, widths)]
         with torch.cuda.device(dev):
+            _chk(lib.gab_zero_buffers(len(tables), ptrs, sizes, _stream(dev)), "gab_zero_buffers")
             _chk(lib.gab_flame_backward(C.byref(rig), _p(sh), *rows, _p(so), _p(v_shaped), _p(ws_bwd), _p(gv), _p(gvs), _p(d_shape),
                                         *outp, _p(d_so), _p(scratch), _stream(dev)), "gab_flame_backward")
-        grads = [flat[off: off + T * w].view(T, w) if need[3 + i] else None for i, (off, w) in enumerate(zip(offs, widths))]
+        grads = [tb if need[3 + i] else None for i, tb in enumerate(tables)]
         return (None, None, None if d_shape is None else d_shape.view(ctx.shape_shape), *grads,
                 None if d_so is None else d_so.view(ctx.so_shape))
 

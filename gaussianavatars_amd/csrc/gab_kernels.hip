@@ -796,6 +796,16 @@ __global__ __launch_bounds__(256) void k_bind_bwd_csr(int F, const float* __rest
     }
 }
 
+// one launch that zero-fills up to 8 small buffers (the full-table gradients of the per-timestep FLAME rows)
+struct ZeroSpec { float* p[8]; int n[8]; int count; };
+__global__ __launch_bounds__(256) void k_zero_many(ZeroSpec z)
+{
+    const int b = blockIdx.y;
+    if (b >= z.count) return;
+    float* p = z.p[b];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < z.n[b]; i += gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
 }  // namespace gab
 
 // =================================================================================================
@@ -974,6 +984,27 @@ int gab_bind_backward_csr(int32_t N, int32_t F, const float* xyz, const float* l
                        rotation, face_orien_mat, face_scaling, face_orien_quat, d_out_xyz, d_out_scaling, d_out_rotation, order, face_begin,
                        d_xyz, d_log_scaling, d_rotation, d_face);
     LAUNCH_CHECK("k_bind_bwd_csr");
+    return GAB_OK;
+}
+
+int gab_zero_buffers(int32_t count, float* const* buffers_host, const int32_t* sizes_host, void* stream_)
+{
+    if (count < 0 || count > 8 || (count > 0 && (!buffers_host || !sizes_host))) return fail(GAB_E_ARG, "gab_zero_buffers: 0..8 buffers");
+    if (count == 0) return GAB_OK;
+    gab::ZeroSpec z;
+    z.count = count;
+    int mx = 0;
+    for (int i = 0; i < 8; ++i) {
+        z.p[i] = i < count ? buffers_host[i] : nullptr;
+        z.n[i] = i < count ? sizes_host[i] : 0;
+        if (i < count && (sizes_host[i] < 0 || (sizes_host[i] > 0 && !buffers_host[i]))) return fail(GAB_E_ARG, "gab_zero_buffers: bad buffer %d", i);
+        if (z.n[i] > mx) mx = z.n[i];
+    }
+    int bx = (mx + 255) / 256;
+    if (bx < 1) bx = 1;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(gab::k_zero_many, dim3(bx, count), dim3(256), 0, (hipStream_t)stream_, z);
+    LAUNCH_CHECK("k_zero_many");
     return GAB_OK;
 }
 

@@ -181,8 +181,8 @@ int gsr_image_layout(int32_t width, int32_t height, GsrImageLayout* o)
     return 0;
 }
 
-int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs,
-                const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
+int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs, const float* shs_rest,
+                   const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
                 const float* cov3D_precomp, float* out_color, int32_t* radii, void* geom, void* binning,
                 int64_t binning_capacity, void* img, int64_t* num_rendered_host, void* stream_)
 {
@@ -197,6 +197,7 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
         if (((scales == nullptr) != (rotations == nullptr)) || (has_sr == (cov3D_precomp != nullptr)))
             return fail(GSR_E_ARG, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
     }
+    if (shs_rest && (!shs || M < 2 || M > 16)) return fail(GSR_E_ARG, "split SH needs shs (P,1,3) + shs_rest (P,M-1,3) with 2 <= M <= 16");
     if (shs && M < (settings->sh_degree + 1) * (settings->sh_degree + 1))
         return fail(GSR_E_ARG, "shs has %d coefficients per splat but sh_degree %d needs %d", M, settings->sh_degree,
                     (settings->sh_degree + 1) * (settings->sh_degree + 1));
@@ -227,7 +228,7 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
 
     gsr::PreprocessArgs pa;
     pa.P = P; pa.M = M;
-    pa.means3D = means3D; pa.shs = shs; pa.colors_precomp = colors_precomp; pa.opacities = opacities;
+    pa.means3D = means3D; pa.shs = shs; pa.shs_rest = shs_rest; pa.colors_precomp = colors_precomp; pa.opacities = opacities;
     pa.scales = scales; pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp;
     pa.radii = radii;
     pa.depths = (float*)(g + gl.depths);
@@ -340,11 +341,20 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
     return GSR_OK;
 }
 
-int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs,
-                 const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
+int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs,
+                const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
+                const float* cov3D_precomp, float* out_color, int32_t* radii, void* geom, void* binning,
+                int64_t binning_capacity, void* img, int64_t* num_rendered_host, void* stream)
+{
+    return gsr_forward_ex(settings, P, M, means3D, shs, nullptr, colors_precomp, opacities, scales, rotations, cov3D_precomp, out_color,
+                          radii, geom, binning, binning_capacity, img, num_rendered_host, stream);
+}
+
+int gsr_backward_ex(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs, const float* shs_rest,
+                    const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
                  const int32_t* radii, const void* geom, const void* binning, int64_t binning_capacity, const void* img,
                  int64_t num_rendered, const float* dL_dpix, float* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D,
-                 float* dL_dsh, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                 float* dL_dsh, float* dL_dsh_rest, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
                  float* dL_dcov3D, void* stream_)
 {
     if (int rc = check_settings(settings)) return rc;
@@ -356,6 +366,7 @@ int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M, const float*
         return fail(GSR_E_ARG, "NULL buffer");
     const bool pre_col = colors_precomp != nullptr, pre_cov = cov3D_precomp != nullptr;
     if (!pre_col && (!shs || !dL_dsh)) return fail(GSR_E_ARG, "shs / dL_dsh required when colours come from SH");
+    if (shs_rest && (pre_col || !dL_dsh_rest || M < 2 || M > 16)) return fail(GSR_E_ARG, "split SH backward needs dL_dsh (P,1,3) + dL_dsh_rest (P,M-1,3), 2 <= M <= 16");
     if (!pre_cov && (!scales || !rotations || !dL_dscales || !dL_drotations))
         return fail(GSR_E_ARG, "scales/rotations and their gradients required when cov3D is not precomputed");
 
@@ -383,14 +394,14 @@ int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M, const float*
     }
     gsr::PreBwdArgs pa;
     pa.P = P; pa.M = M;
-    pa.means3D = means3D; pa.shs = shs; pa.scales = scales; pa.rotations = rotations;
+    pa.means3D = means3D; pa.shs = shs; pa.shs_rest = shs_rest; pa.scales = scales; pa.rotations = rotations;
     pa.cov3D = (const float*)(g + gl.cov3D);
     pa.radii = radii;
     pa.clamped = (const uint8_t*)(g + gl.clamped);
     pa.acc = grad_scratch;
     pa.use_precomp_cov = pre_cov ? 1 : 0;
     pa.use_precomp_color = pre_col ? 1 : 0;
-    pa.dL_dmeans3D = dL_dmeans3D; pa.dL_dmeans2D = dL_dmeans2D; pa.dL_dsh = pre_col ? nullptr : dL_dsh;
+    pa.dL_dmeans3D = dL_dmeans3D; pa.dL_dmeans2D = dL_dmeans2D; pa.dL_dsh = pre_col ? nullptr : dL_dsh; pa.dL_dsh_rest = shs_rest ? dL_dsh_rest : nullptr;
     pa.dL_dcolors = dL_dcolors; pa.dL_dopacity = dL_dopacity;
     pa.dL_dscales = pre_cov ? nullptr : dL_dscales; pa.dL_drotations = pre_cov ? nullptr : dL_drotations;
     pa.dL_dcov3D = dL_dcov3D;
@@ -400,6 +411,18 @@ int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M, const float*
         KERNEL_CHECK("k_preprocess_bwd", stream, dbg);
     }
     return GSR_OK;
+}
+
+int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs,
+                 const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
+                 const int32_t* radii, const void* geom, const void* binning, int64_t binning_capacity, const void* img,
+                 int64_t num_rendered, const float* dL_dpix, float* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D,
+                 float* dL_dsh, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                 float* dL_dcov3D, void* stream)
+{
+    return gsr_backward_ex(settings, P, M, means3D, shs, nullptr, colors_precomp, scales, rotations, cov3D_precomp, radii, geom, binning,
+                           binning_capacity, img, num_rendered, dL_dpix, grad_scratch, dL_dmeans3D, dL_dmeans2D, dL_dsh, nullptr,
+                           dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, stream);
 }
 
 int gsr_profile_enable(int on)

@@ -204,8 +204,14 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
     __shared__ float sh_lds[GSR_SH_ROWS * GSR_SH_MAX_STRIDE];
     const bool sh_staged = !a.use_precomp_color && a.dL_dsh != nullptr && M <= 16;
     const int first = blockIdx.x * GSR_SH_ROWS, rows = min(GSR_SH_ROWS, a.P - first);
+    const int sh_stride = sh_row_stride(M);
     if (sh_staged) {
-        sh_rows_load(sh_lds, a.shs, first, rows, M, (int)threadIdx.x);
+        if (a.shs_rest) {   // the model's two leaf tensors: DC (P,1,3) and rest (P,M-1,3)
+            sh_rows_load(sh_lds, a.shs, first, rows, 3, sh_stride, 0, (int)threadIdx.x);
+            sh_rows_load(sh_lds, a.shs_rest, first, rows, 3 * (M - 1), sh_stride, 3, (int)threadIdx.x);
+        } else {
+            sh_rows_load(sh_lds, a.shs, first, rows, 3 * M, sh_stride, 0, (int)threadIdx.x);
+        }
         __syncthreads();
     }
     if (i < a.P) {
@@ -428,7 +434,12 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
     }   // i < P
     if (sh_staged) {
         __syncthreads();
-        sh_rows_store(sh_lds, a.dL_dsh, first, rows, M, (int)threadIdx.x);
+        if (a.shs_rest) {
+            sh_rows_store(sh_lds, a.dL_dsh, first, rows, 3, sh_stride, 0, (int)threadIdx.x);
+            sh_rows_store(sh_lds, a.dL_dsh_rest, first, rows, 3 * (M - 1), sh_stride, 3, (int)threadIdx.x);
+        } else {
+            sh_rows_store(sh_lds, a.dL_dsh, first, rows, 3 * M, sh_stride, 0, (int)threadIdx.x);
+        }
     }
 }
 

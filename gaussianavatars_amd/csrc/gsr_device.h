@@ -167,9 +167,11 @@ __device__ __forceinline__ void for_each_tile(int minx, int miny, int maxx, int 
 #define GSR_SH_MAX_STRIDE 49
 __device__ __forceinline__ int sh_row_stride(int M) { return (3 * M) | 1; }
 
-__device__ __forceinline__ void sh_rows_load(float* __restrict__ lds, const float* __restrict__ src, int first, int rows, int M, int tid)
+// copies `rows` source rows of width w into LDS columns [col0, col0+w) of rows laid out with `stride`
+__device__ __forceinline__ void sh_rows_load(float* __restrict__ lds, const float* __restrict__ src, int first, int rows, int w, int stride,
+                                             int col0, int tid)
 {
-    const int w = 3 * M, stride = sh_row_stride(M), total = rows * w;
+    const int total = rows * w;
     const float* base = src + (size_t)first * w;
     if ((total & 3) == 0 && ((((size_t)first * w) & 3) == 0)) {
         const float4* b4 = reinterpret_cast<const float4*>(base);
@@ -179,21 +181,22 @@ __device__ __forceinline__ void sh_rows_load(float* __restrict__ lds, const floa
             const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                lds[r * stride + c] = e[k];
+                lds[r * stride + col0 + c] = e[k];
                 if (++c == w) { c = 0; ++r; }
             }
         }
     } else {
         for (int f = tid; f < total; f += GSR_SH_ROWS) {
             const int r = f / w, c = f - r * w;
-            lds[r * stride + c] = base[f];
+            lds[r * stride + col0 + c] = base[f];
         }
     }
 }
 
-__device__ __forceinline__ void sh_rows_store(const float* __restrict__ lds, float* __restrict__ dst, int first, int rows, int M, int tid)
+__device__ __forceinline__ void sh_rows_store(const float* __restrict__ lds, float* __restrict__ dst, int first, int rows, int w, int stride,
+                                              int col0, int tid)
 {
-    const int w = 3 * M, stride = sh_row_stride(M), total = rows * w;
+    const int total = rows * w;
     float* base = dst + (size_t)first * w;
     if ((total & 3) == 0 && ((((size_t)first * w) & 3) == 0)) {
         float4* b4 = reinterpret_cast<float4*>(base);
@@ -202,7 +205,7 @@ __device__ __forceinline__ void sh_rows_store(const float* __restrict__ lds, flo
             float e[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                e[k] = lds[r * stride + c];
+                e[k] = lds[r * stride + col0 + c];
                 if (++c == w) { c = 0; ++r; }
             }
             b4[f >> 2] = make_float4(e[0], e[1], e[2], e[3]);
@@ -210,7 +213,7 @@ __device__ __forceinline__ void sh_rows_store(const float* __restrict__ lds, flo
     } else {
         for (int f = tid; f < total; f += GSR_SH_ROWS) {
             const int r = f / w, c = f - r * w;
-            base[f] = lds[r * stride + c];
+            base[f] = lds[r * stride + col0 + c];
         }
     }
 }
@@ -220,6 +223,7 @@ struct PreprocessArgs {
     int P, M;
     const float* __restrict__ means3D;
     const float* __restrict__ shs;
+    const float* __restrict__ shs_rest;   // non-null: shs is (P,1,3) and this is (P,M-1,3) (the model's two leaf tensors)
     const float* __restrict__ colors_precomp;
     const float* __restrict__ opacities;
     const float* __restrict__ scales;
@@ -238,6 +242,7 @@ struct PreBwdArgs {
     int P, M;
     const float* __restrict__ means3D;
     const float* __restrict__ shs;
+    const float* __restrict__ shs_rest;
     const float* __restrict__ scales;
     const float* __restrict__ rotations;
     const float* __restrict__ cov3D;      // forward's (P,6)
@@ -247,7 +252,8 @@ struct PreBwdArgs {
     int use_precomp_cov, use_precomp_color;
     float* __restrict__ dL_dmeans3D;
     float* __restrict__ dL_dmeans2D;      // (P,3)
-    float* __restrict__ dL_dsh;           // (P,M,3) or null
+    float* __restrict__ dL_dsh;           // (P,M,3) or null   ((P,1,3) when split)
+    float* __restrict__ dL_dsh_rest;      // (P,M-1,3) when split
     float* __restrict__ dL_dcolors;       // (P,3)
     float* __restrict__ dL_dopacity;      // (P,1)
     float* __restrict__ dL_dscales;       // (P,3) or null

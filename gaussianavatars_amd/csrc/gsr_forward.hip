@@ -154,10 +154,12 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
                         const float x = dx / len, y = dy / len, z = dz / len;
                         // 3*M contiguous floats per splat, consumed entirely by this thread: the 192-byte rows are
                         // fetched line by line through L1 (measured faster than staging them through LDS here)
-                        const float* sh = a.shs + (size_t)3 * a.M * i;
+                        // split layout: sh0 = the DC triple, sh = the rest block shifted so that sh[3k+c] is coefficient k
+                        const float* sh0 = a.shs_rest ? a.shs + (size_t)3 * i : a.shs + (size_t)3 * a.M * i;
+                        const float* sh = a.shs_rest ? a.shs_rest + (size_t)3 * (a.M - 1) * i - 3 : sh0;
                         float res[3];
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) res[c] = kC0 * sh[c];
+                        for (int c = 0; c < 3; ++c) res[c] = kC0 * sh0[c];
                         if (deg > 0) {
 #pragma unroll
                             for (int c = 0; c < 3; ++c)

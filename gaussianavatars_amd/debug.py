@@ -36,7 +36,7 @@ def forward_state(rs: GaussianRasterizationSettings, means3D, shs, colors_precom
     ctx = _Ctx()
     with torch.no_grad():
         color, radii = _RasterizeGaussians.forward(ctx, *args, rs)
-    _, _, _, _, _, _, _, geom, binning, img = ctx.saved
+    geom, binning, img = ctx.saved[7], ctx.saved[8], ctx.saved[9]
     P = means3D.shape[0]
     H, W = int(rs.image_height), int(rs.image_width)
     I, cap = ctx.num_rendered, ctx.capacity

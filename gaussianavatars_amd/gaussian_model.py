@@ -102,6 +102,11 @@ class GaussianModel:
         return torch.cat((self._features_dc, self._features_rest), dim=1)
 
     @property
+    def get_features_split(self):
+        """(dc (N,1,3), rest (N,K,3)) for the rasterizer's split-SH entry; None when there is no rest block."""
+        return (self._features_dc, self._features_rest) if self._features_rest.shape[1] > 0 else None
+
+    @property
     def get_opacity(self):
         return torch.sigmoid(self._opacity)
 

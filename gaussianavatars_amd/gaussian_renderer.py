@@ -77,7 +77,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     else:
         scales = pc.get_scaling
         rotations = pc.get_rotation
-    shs = colors_precomp = None
+    shs = shs_rest = colors_precomp = None
     if override_color is None:
         if pipe.convert_SHs_python:
             # python SH path of the reference (:74-79): colours from composed torch ops
@@ -86,11 +86,18 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
             d = d / d.norm(dim=1, keepdim=True)
             colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, feats, d) + 0.5, 0.0)
         else:
-            shs = pc.get_features
+            # the reference passes pc.get_features (a per-frame cat of the two leaf tensors); when the model offers
+            # them separately the rasterizer reads both in place
+            split = getattr(pc, "get_features_split", None)
+            if split is not None:
+                shs, shs_rest = split
+            else:
+                shs = pc.get_features
     else:
         colors_precomp = override_color
     rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
-                                       opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+                                       opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp,
+                                       **({"shs_rest": shs_rest} if shs_rest is not None else {}))
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
 
 

@@ -81,7 +81,7 @@ def _make_settings(rs: GaussianRasterizationSettings, keep: list) -> _lib.GsrSet
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, sh_rest=None):
         lib = _lib.gsr()
         dev = means3D.device
         keep: list = []
@@ -97,7 +97,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         scales = _f32c(scales, "scales") if scales.numel() else scales
         rotations = _f32c(rotations, "rotations") if rotations.numel() else rotations
         cov3Ds_precomp = _f32c(cov3Ds_precomp, "cov3D_precomp") if cov3Ds_precomp.numel() else cov3Ds_precomp
-        M = int(sh.shape[1]) if sh.numel() else 0
+        split = sh_rest is not None and sh_rest.numel() > 0
+        if split:   # the model's two leaf tensors, read in place (include/gsr.h: gsr_forward_ex)
+            sh_rest = _f32c(sh_rest, "shs_rest")
+            if sh.dim() != 3 or sh.shape[1] != 1 or sh_rest.shape[0] != sh.shape[0]:
+                raise RuntimeError("split SH: shs must be (P,1,3) and shs_rest (P,M-1,3)")
+        else:
+            sh_rest = torch.empty(0, device=dev)
+        M = (int(sh.shape[1]) + (int(sh_rest.shape[1]) if split else 0)) if sh.numel() else 0
 
         gl, il = _lib.GsrGeomLayout(), _lib.GsrImageLayout()
         lib.gsr_geom_layout(P, C.byref(gl))
@@ -118,7 +125,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 bl = _lib.GsrBinningLayout()
                 lib.gsr_binning_layout(cap, W, H, C.byref(bl))
                 binning = torch.empty(bl.total, **u8)
-                rc = lib.gsr_forward(C.byref(s), P, M, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities),
+                rc = lib.gsr_forward_ex(C.byref(s), P, M, _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors_precomp), _ptr(opacities),
                                      _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(color), _ptr(radii),
                                      _ptr(geom), _ptr(binning), cap, _ptr(img), C.byref(n_host), stream)
                 if rc == _lib.GSR_E_CAPACITY:
@@ -140,14 +147,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = I
         ctx.capacity = cap
         ctx.M = M
-        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
+        ctx.split = split
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img, sh_rest)
         ctx.mark_non_differentiable(radii)
         return color, radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
         lib = _lib.gsr()
-        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img, sh_rest = ctx.saved_tensors
         rs = ctx.raster_settings
         dev = means3D.device
         keep: list = []
@@ -162,25 +170,27 @@ class _RasterizeGaussians(torch.autograd.Function):
         g_opacity = torch.empty((P, 1), **f32)
         g_cov3D = torch.empty((P, 6), **f32)
         use_sh, use_sr = sh.numel() > 0, scales.numel() > 0
-        g_sh = torch.empty((P, M, 3), **f32) if use_sh else None
+        g_sh = torch.empty((P, 1 if ctx.split else M, 3), **f32) if use_sh else None
+        g_sh_rest = torch.empty((P, M - 1, 3), **f32) if ctx.split else None
         g_scales = torch.empty((P, 3), **f32) if use_sr else None
         g_rot = torch.empty((P, 4), **f32) if use_sr else None
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         with torch.cuda.device(dev):
-            rc = lib.gsr_backward(C.byref(s), P, M, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(scales),
+            rc = lib.gsr_backward_ex(C.byref(s), P, M, _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors_precomp), _ptr(scales),
                                   _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(radii), _ptr(geom), _ptr(binning),
                                   ctx.capacity, _ptr(img), ctx.num_rendered, _ptr(grad_out_color), _ptr(scratch),
-                                  _ptr(g_means3D), _ptr(g_means2D), _ptr(g_sh), _ptr(g_colors), _ptr(g_opacity),
+                                  _ptr(g_means3D), _ptr(g_means2D), _ptr(g_sh), _ptr(g_sh_rest), _ptr(g_colors), _ptr(g_opacity),
                                   _ptr(g_scales), _ptr(g_rot), _ptr(g_cov3D), stream)
         if rc != _lib.GSR_OK:
             raise RuntimeError(f"gsr_backward failed ({rc}): {_lib.gsr_error()}")
         return (g_means3D, g_means2D, g_sh, g_colors if not use_sh else None, g_opacity, g_scales, g_rot,
-                g_cov3D if not use_sr else None, None)
+                g_cov3D if not use_sr else None, None, g_sh_rest)
 
 
-def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                        sh_rest=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, sh_rest)
 
 
 class GaussianRasterizer(nn.Module):
@@ -203,7 +213,9 @@ class GaussianRasterizer(nn.Module):
         return out.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, shs_rest=None):
+        """Same keywords as the reference.  Extension: `shs_rest` -- pass the model's `_features_dc` as `shs` and
+        `_features_rest` here to skip the per-frame concatenation (get_features)."""
         rs = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
@@ -217,4 +229,4 @@ class GaussianRasterizer(nn.Module):
         scales = empty if scales is None else scales
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs, shs_rest)

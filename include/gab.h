@@ -99,6 +99,11 @@ int gab_bind_backward_csr(int32_t N, int32_t F, const float* xyz, const float* l
                           const int32_t* order, const int32_t* face_begin,
                           float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face /*17*F, same four blocks*/, void* stream);
 
+/* Utility: zero-fills up to 8 device buffers (sizes in floats) with ONE launch.  `buffers_host` / `sizes_host` are
+ * HOST arrays of device pointers / element counts.  Used to build the full (T,k) gradient tables of the per-timestep
+ * FLAME parameters around the single row gab_flame_backward writes. */
+int gab_zero_buffers(int32_t count, float* const* buffers_host, const int32_t* sizes_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -142,6 +142,28 @@ int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M,
                  float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                  void* stream);
 
+/*
+ * Split-SH variants.  The model keeps the SH coefficients as two leaf tensors,
+ * `_features_dc (P,1,3)` and `_features_rest (P,M-1,3)`, and the reference concatenates them every frame
+ * (scene/gaussian_model.py:152-156: a 19 MB copy at 100k splats, plus the split of the gradient on the way
+ * back).  These entries read / write the two tensors in place: `shs` = DC block, `shs_rest` = the rest, M = total
+ * coefficient count (2..16).  With shs_rest == NULL they are exactly gsr_forward / gsr_backward.
+ */
+int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M,
+                   const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp,
+                   const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
+                   float* out_color, int32_t* radii,
+                   void* geom, void* binning, int64_t binning_capacity, void* img,
+                   int64_t* num_rendered_host, void* stream);
+int gsr_backward_ex(const GsrSettings* settings, int32_t P, int32_t M,
+                    const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp,
+                    const float* scales, const float* rotations, const float* cov3D_precomp,
+                    const int32_t* radii, const void* geom, const void* binning, int64_t binning_capacity,
+                    const void* img, int64_t num_rendered, const float* dL_dpix, float* grad_scratch,
+                    float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dsh, float* dL_dsh_rest, float* dL_dcolors,
+                    float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                    void* stream);
+
 /* Replaces `_C.mark_visible` (upstream markVisible / checkFrustum): present[i] = view-space z > 0.2.
  * Unused by GaussianAvatars (no call site) but part of the package surface. */
 int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -149,6 +149,32 @@ def test_backward_precomputed_inputs(oracle):
     _grad_check(oracle, "sh3_small", use_precomp_color=True, use_precomp_cov=True)
 
 
+def test_split_sh_equals_concatenated(oracle):
+    """gsr_forward_ex / gsr_backward_ex read the model's two SH leaf tensors in place: same image bit for bit,
+    same gradients as the concatenated (reference) path."""
+    from gaussianavatars_amd.rasterizer import GaussianRasterizer
+
+    dev = _dev()
+    s, st, hs, rs, inp = _run_both(oracle, "sh3_small")
+    tt = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev).requires_grad_(True)
+    outs = []
+    for split in (False, True):
+        m3, op, sc, ro = tt(inp["means3D"]), tt(inp["opacities"]), tt(inp["scales"]), tt(inp["rotations"])
+        m2 = torch.zeros_like(m3, requires_grad=True)
+        if split:
+            dc, rest = tt(inp["shs"][:, :1]), tt(inp["shs"][:, 1:])
+            color, radii = GaussianRasterizer(rs)(means3D=m3, means2D=m2, shs=dc, shs_rest=rest, opacities=op, scales=sc, rotations=ro)
+        else:
+            sh = tt(inp["shs"])
+            color, radii = GaussianRasterizer(rs)(means3D=m3, means2D=m2, shs=sh, opacities=op, scales=sc, rotations=ro)
+        (color * color).sum().backward()
+        gsh = torch.cat([dc.grad, rest.grad], 1) if split else sh.grad
+        outs.append((color.detach(), radii, gsh, m3.grad, op.grad))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][2:], outs[1][2:]):
+        assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max())
+
+
 def test_argument_contract():
     from gaussianavatars_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
