@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
             dxs[u] = R.rx[u] - pixx;
             dys[u] = R.ry[u] - pixy;
             const float power = -0.5f * (R.ca[u] * dxs[u] * dxs[u] + R.cc[u] * dys[u] * dys[u]) - R.cb[u] * dxs[u] * dys[u];
-            G[u] = gsr_expf(power);
+            G[u] = gsr_expf_blend(power);
             alpha[u] = sel_min(0.99f, R.op[u] * G[u]);
             hit[u] = (jp + u) < last && power <= 0.0f && alpha[u] >= 1.0f / 255.0f;
             id[uo + u] = R.id[u];

@@ -73,6 +73,27 @@ __device__ __forceinline__ float gsr_expf(float x)
     return __builtin_ldexpf(p, (int)n);
 }
 
+// Same polynomial without the range guards, for the blend loops: there the result is only USED when
+// -87 < x <= 0 (x > 0 is skipped, and below -87 the un-guarded value is < 2^-125, which fails the
+// alpha >= 1/255 test exactly like the guarded 0 does), so every used value is bit-identical to gsr_expf.
+__device__ __forceinline__ float gsr_expf_blend(float x)
+{
+    const float l2e_hi = 1.44269502162933349609375f;
+    const float l2e_lo = 1.92596299112661746e-8f;
+    const float n = __builtin_rintf(x * l2e_hi);
+    float f = __builtin_fmaf(x, l2e_hi, -n);
+    f = __builtin_fmaf(x, l2e_lo, f);
+    float p = 1.52527338040598402800e-5f;
+    p = __builtin_fmaf(p, f, 1.54035303933816099544e-4f);
+    p = __builtin_fmaf(p, f, 1.33335581464284434234e-3f);
+    p = __builtin_fmaf(p, f, 9.61812910762847716197e-3f);
+    p = __builtin_fmaf(p, f, 5.55041086648215799532e-2f);
+    p = __builtin_fmaf(p, f, 2.40226506959100712334e-1f);
+    p = __builtin_fmaf(p, f, 6.93147180559945309417e-1f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    return __builtin_ldexpf(p, (int)n);
+}
+
 // float -> int32 with saturation and NaN -> 0 (what v_cvt_i32_f32 does, spelled out so that the
 // C++ out-of-range UB never enters)
 __device__ __forceinline__ int f2i_sat(float v)

@@ -829,7 +829,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
             const float dx = R.rx[u] - pixx;
             const float dy = R.ry[u] - pixy;
             const float power = -0.5f * (R.ca[u] * dx * dx + R.cc[u] * dy * dy) - R.cb[u] * dx * dy;
-            const float a = sel_min(0.99f, R.op[u] * gsr_expf(power));
+            const float a = sel_min(0.99f, R.op[u] * gsr_expf_blend(power));
             const bool ok = power <= 0.0f && (jb + u) < n && a >= 1.0f / 255.0f;
             alpha[u] = ok ? a : 0.0f;
         }
@@ -839,12 +839,10 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
             const float test_T = T * (1.0f - alpha[u]);
             const bool stop = live && test_T < 0.0001f;
             const bool acc = live && !stop;
-            const float n0 = C0 + R.cr[u] * alpha[u] * T;
-            const float n1 = C1 + R.cg[u] * alpha[u] * T;
-            const float n2 = C2 + R.cbl[u] * alpha[u] * T;
-            C0 = acc ? n0 : C0;
-            C1 = acc ? n1 : C1;
-            C2 = acc ? n2 : C2;
+            const float ae = acc ? alpha[u] : 0.0f;   // adding (c * 0) * T == +0 leaves C bit-identical: no selects on C
+            C0 = C0 + R.cr[u] * ae * T;
+            C1 = C1 + R.cg[u] * ae * T;
+            C2 = C2 + R.cbl[u] * ae * T;
             T = acc ? test_T : T;
             last_q = acc ? (uint32_t)(jb + u + 1) : last_q;
             done = done || stop;
