@@ -246,8 +246,8 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
 
     // binning workgroups: each owns a contiguous chunk of splats and an LDS histogram over the tiles
     const int bin_blocks = pblocks < 256 ? pblocks : 256;
-    const size_t hist_bytes = (size_t)tiles * sizeof(uint32_t);
-    if (hist_bytes > 160 * 1024) return fail(GSR_E_ARG, "image has %d tiles; the LDS tile histogram supports at most 40960", tiles);
+    // (grids beyond GSR_LDS_HIST_TILES tiles -- past ~3200x3200 px -- fall back to per-instance L2 atomics)
+    const size_t hist_bytes = tiles > GSR_LDS_HIST_TILES ? 0 : (size_t)tiles * sizeof(uint32_t);
     if (hist_bytes > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
@@ -337,6 +337,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     }
     const int64_t I = (int64_t)(v & 0xFFFFFFFFFFull);
     *num_rendered_host = I;
+    if (I > 0xFFFFFFFFll) return fail(GSR_E_ARG, "%lld (splat, tile) instances exceed the 32-bit offsets of the binning state", (long long)I);
     if (I > binning_capacity) return fail(GSR_E_CAPACITY, "binning capacity %lld < %lld instances", (long long)binning_capacity, (long long)I);
     return GSR_OK;
 }

@@ -17,6 +17,7 @@
 #define GSR_SORT_XL_KEYS 16384  // 128 KiB of LDS, 16 keys per thread; beyond this the sort runs in global memory
 #define GSR_SORT_SMALL_KEYS 2048 // tiles up to this many entries take the 256-thread / 16 KiB class
 #define GSR_ACC_STRIDE 12        // floats per splat in the backward accumulator (48 B, one atomic burst)
+#define GSR_LDS_HIST_TILES 40960 // 160 KB of LDS / 4 B: the largest tile grid k_count / k_scatter privatise
 
 namespace gsr {
 

@@ -221,8 +221,11 @@ __global__ __launch_bounds__(256) void k_count(int P, int gx, int tiles, const u
 {
     extern __shared__ uint32_t hist[];
     const int tid = threadIdx.x;
-    for (int t = tid; t < tiles; t += 256) hist[t] = 0u;
-    __syncthreads();
+    const bool direct = tiles > GSR_LDS_HIST_TILES;   // tile grid too large for an LDS histogram: count in L2 (slow path)
+    if (!direct) {
+        for (int t = tid; t < tiles; t += 256) hist[t] = 0u;
+        __syncthreads();
+    }
     const int chunk = ((P + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
     const int begin = blockIdx.x * chunk;
     const int end = min(P, begin + chunk);
@@ -235,8 +238,12 @@ __global__ __launch_bounds__(256) void k_count(int P, int gx, int tiles, const u
             const ushort4 r = rect[i];
             minx = r.x; miny = r.y; maxx = r.z; maxy = r.w;
         }
-        for_each_tile(minx, miny, maxx, maxy, n, gx, [](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&hist[tile], 1u); }, 0u, 0u);
+        if (direct)
+            for_each_tile(minx, miny, maxx, maxy, n, gx, [=](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&tile_count[tile], 1u); }, 0u, 0u);
+        else
+            for_each_tile(minx, miny, maxx, maxy, n, gx, [](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&hist[tile], 1u); }, 0u, 0u);
     }
+    if (direct) return;
     __syncthreads();
     for (int t = tid; t < tiles; t += 256) {
         const uint32_t v = hist[t];
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int tiles, const uint32_t* _
                                                      unsigned long long seq)
 {
     __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry_s;
+    __shared__ unsigned long long carry_s;
     __shared__ uint32_t bucket[34];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) carry_s = 0;
@@ -274,20 +281,19 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int tiles, const uint32_t* _
         __syncthreads();
         uint32_t wave_off = 0;
         for (int w = 0; w < wid; ++w) wave_off += wave_tot[w];
-        const uint32_t carry = carry_s;
-        const uint32_t excl = carry + wave_off + incl - v;
+        const unsigned long long carry = carry_s;
+        const uint32_t excl = (uint32_t)carry + wave_off + incl - v;   // offsets are 32-bit like upstream's
         if (t < tiles) {
             tile_start[t] = excl;
             tile_cursor[t] = 0u;
             ranges[t] = v ? make_uint2(excl, excl + v) : make_uint2(0u, 0u);
         }
         __syncthreads();
-        if (tid == 1023) carry_s = excl + v;
+        if (tid == 1023) carry_s = carry + wave_off + incl;   // 64-bit running total: a frame past 2^32 instances is reported, not wrapped
         __syncthreads();
     }
     if (tid == 0) {
-        // the per-chunk carries are 32-bit like upstream's offsets; the host compares against capacity
-        grand = (unsigned long long)carry_s;
+        grand = carry_s;
         *total_dev = grand;
         // post (seq, I) to the host: one 8-byte system-scope store into mapped pinned memory
         __hip_atomic_store(mailbox, (seq << 40) | (grand & 0xFFFFFFFFFFull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -325,11 +331,33 @@ __global__ __launch_bounds__(256) void k_scatter(int P, int gx, int tiles, const
     extern __shared__ uint32_t hist[];
     if (*total_dev > capacity) return;  // the host will grow the buffer and replay the frame
     const int tid = threadIdx.x;
-    for (int t = tid; t < tiles; t += 256) hist[t] = 0u;
-    __syncthreads();
+    const bool direct = tiles > GSR_LDS_HIST_TILES;
     const int chunk = ((P + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
     const int begin = blockIdx.x * chunk;
     const int end = min(P, begin + chunk);
+    if (direct) {
+        // slow path for tile grids beyond the LDS histogram: one returning L2 atomic per instance
+        for (int base = begin; base < end; base += 256) {
+            const int i = base + tid;
+            uint32_t n = 0, dbits = 0;
+            int minx = 0, miny = 0, maxx = 0, maxy = 0;
+            if (i < end) {
+                n = tiles_touched[i];
+                const ushort4 r = rect[i];
+                minx = r.x; miny = r.y; maxx = r.z; maxy = r.w;
+                dbits = __float_as_uint(depths[i]);
+            }
+            for_each_tile(minx, miny, maxx, maxy, n, gx,
+                          [=](uint32_t tile, uint32_t db, uint32_t idx) {
+                              const uint32_t slot = tile_start[tile] + atomicAdd(&tile_cursor[tile], 1u);
+                              keys[slot] = ((unsigned long long)db << 32) | (unsigned long long)idx;
+                          },
+                          dbits, (uint32_t)i);
+        }
+        return;
+    }
+    for (int t = tid; t < tiles; t += 256) hist[t] = 0u;
+    __syncthreads();
     for (int base = begin; base < end; base += 256) {
         const int i = base + tid;
         uint32_t n = 0;

@@ -29,6 +29,9 @@ def scene(name):
     if name == "dense_tile_xl":  # > 16384 instances in one tile: the global-memory sort fallback
         sp = S.random_splats(20000, 0, 16, xyz_sigma=0.002, log_scale_mean=math.log(0.0008), log_scale_sigma=0.2)
         return S.orbit_camera(64, 64), sp, [1.0, 1.0, 1.0], 0, 1.0
+    if name == "huge_grid":  # 207x207 = 42849 tiles: beyond the LDS tile histogram, the L2-atomic binning path
+        sp = S.random_splats(1500, 1, 17, xyz_sigma=0.12, log_scale_mean=math.log(0.004), log_scale_sigma=0.6)
+        return S.orbit_camera(3300, 3300), sp, [0.3, 0.3, 0.3], 1, 1.0
     if name == "empty_view":  # nothing visible
         sp = S.random_splats(500, 0, 15)
         sp["means3D"][:, 2] += 3.0
