@@ -158,6 +158,45 @@ def gab():
     return _gab
 
 
+# ------------------------------------------------------------------------------------------------
+# libgls_hip.so : fused L1 + SSIM loss and densification statistics (include/gls.h)
+# ------------------------------------------------------------------------------------------------
+GLS_LIB_PATH = os.path.join(_HERE, "libgls_hip.so")
+GLS_SYMBOLS = {
+    "gls_abi_version": (C.c_int, []),
+    "gls_last_error": (C.c_char_p, []),
+    "gls_partial_floats": (C.c_int64, [C.c_int32] * 4),
+    "gls_l1_ssim_forward": (C.c_int, [C.c_int32] * 4 + [_P, _P, C.c_float] + [_P] * 4),
+    "gls_l1_ssim_backward": (C.c_int, [C.c_int32] * 4 + [_P] * 4 + [C.c_float, _P, _P]),
+    "gls_l1_forward": (C.c_int, [C.c_int64, _P, _P, C.c_float, _P, _P, _P]),
+    "gls_l1_backward": (C.c_int, [C.c_int64, _P, _P, _P, C.c_float, _P, _P]),
+    "gls_densification_stats": (C.c_int, [C.c_int32] + [_P] * 6),
+}
+
+_gls = None
+
+
+def gls():
+    """The loss / statistics library; raises (never falls back) when it is not built."""
+    global _gls
+    if _gls is None:
+        if not os.path.exists(GLS_LIB_PATH):
+            raise RuntimeError(f"{GLS_LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950).  There is no CPU fallback.")
+        lib = C.CDLL(GLS_LIB_PATH)
+        for name, (res, args) in GLS_SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.gls_abi_version() != 1:
+            raise RuntimeError(f"gls ABI version {lib.gls_abi_version()} != 1")
+        _gls = lib
+    return _gls
+
+
+def gls_error() -> str:
+    return gls().gls_last_error().decode("utf-8", "replace")
+
+
 def gab_error() -> str:
     return gab().gab_last_error().decode("utf-8", "replace")
 

@@ -1,0 +1,367 @@
+// gls_kernels.hip -- fused L1 + SSIM image loss (forward / backward) and the densification statistics
+// update: the training-step neighbours of the render path (include/gls.h).
+//
+// SSIM forward, per 16x16 output tile: the 26x26 halo of both images goes to LDS once (zero padding as
+// F.conv2d(padding=5)), the five windowed moments E[x], E[y], E[x^2], E[y^2], E[xy] are formed separably
+// (11 horizontal taps into LDS, 11 vertical taps in registers), the SSIM map and |x-y| are reduced per
+// workgroup into fixed-order partials, and the three partial derivatives the backward needs are written
+// as planes.  Backward: the same separable window over those three planes, combined with x and y.
+// All of it is HBM-trivial (5 MB images); the point is ~4 launches instead of ~60.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/gls.h"
+
+namespace gls {
+
+constexpr int WIN = GLS_SSIM_WINDOW, RAD = WIN / 2;
+constexpr int TX = 16, TY = 16, HX = TX + 2 * RAD, HY = TY + 2 * RAD;
+constexpr float SSIM_C1 = 0.01f * 0.01f, SSIM_C2 = 0.03f * 0.03f;
+
+struct Window {
+    float w[WIN];
+};
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// sum over the 64 lanes, valid in lane 63
+__device__ __forceinline__ float wave_sum_hi(float v)
+{
+    v += dpp_f<0xB1, 0xf>(v);
+    v += dpp_f<0x4E, 0xf>(v);
+    v += dpp_f<0x141, 0xf>(v);
+    v += dpp_f<0x140, 0xf>(v);
+    v += dpp_f<0x142, 0xa>(v);
+    v += dpp_f<0x143, 0xc>(v);
+    return v;
+}
+
+// loads the (HY x HX) halo of one plane into LDS, zero outside the image
+__device__ __forceinline__ void load_halo(float (*dst)[HX + 1], const float* __restrict__ plane, int H, int W, int x0, int y0, int tid)
+{
+    for (int i = tid; i < HY * HX; i += 256) {
+        const int r = i / HX, c = i - r * HX;
+        const int gy = y0 + r - RAD, gx = x0 + c - RAD;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        dst[r][c] = in ? plane[(size_t)gy * W + gx] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_l1_ssim_fwd(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
+                                                      Window win, float* __restrict__ maps, size_t map_stride,
+                                                      float2* __restrict__ partial)
+{
+    __shared__ float sx[HY][HX + 1], sy[HY][HX + 1];
+    __shared__ float hq[5][HY][TX];
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x;
+    const int plane = blockIdx.z, x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    const size_t poff = (size_t)plane * H * W;
+    load_halo(sx, img1 + poff, H, W, x0, y0, tid);
+    load_halo(sy, img2 + poff, H, W, x0, y0, tid);
+    __syncthreads();
+    for (int i = tid; i < HY * TX; i += 256) {
+        const int r = i >> 4, c = i & 15;
+        float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) {
+            const float x = sx[r][c + k], y = sy[r][c + k], w = win.w[k];
+            a += w * x;
+            b += w * y;
+            aa += w * (x * x);
+            bb += w * (y * y);
+            ab += w * (x * y);
+        }
+        hq[0][r][c] = a; hq[1][r][c] = b; hq[2][r][c] = aa; hq[3][r][c] = bb; hq[4][r][c] = ab;
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+    for (int k = 0; k < WIN; ++k) {
+        const float w = win.w[k];
+        mu1 += w * hq[0][ty + k][tx];
+        mu2 += w * hq[1][ty + k][tx];
+        e11 += w * hq[2][ty + k][tx];
+        e22 += w * hq[3][ty + k][tx];
+        e12 += w * hq[4][ty + k][tx];
+    }
+    const int px = x0 + tx, py = y0 + ty;
+    const bool valid = px < W && py < H;
+    float l1 = 0.f, ss = 0.f;
+    if (valid) {
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+        const float A = 2.f * mu12 + SSIM_C1, Bv = 2.f * s12 + SSIM_C2;
+        const float Cv = mu1_sq + mu2_sq + SSIM_C1, D = s1 + s2 + SSIM_C2;
+        const float inv = 1.f / (Cv * D);
+        const float m = A * Bv * inv;
+        ss = m;
+        l1 = fabsf(sx[ty + RAD][tx + RAD] - sy[ty + RAD][tx + RAD]);
+        if (maps) {
+            const size_t o = poff + (size_t)py * W + px;
+            maps[o] = (2.f * mu2 * (Bv - A) - m * 2.f * mu1 * (D - Cv)) * inv;   // d m / d mu1  (E[x^2], E[xy] held fixed)
+            maps[o + map_stride] = -m / D;                                       // d m / d E[x^2]
+            maps[o + 2 * map_stride] = 2.f * A * inv;                            // d m / d E[xy]
+        }
+    }
+    l1 = wave_sum_hi(l1);
+    ss = wave_sum_hi(ss);
+    if ((tid & 63) == 63) { red[0][tid >> 6] = l1; red[1][tid >> 6] = ss; }
+    __syncthreads();
+    if (tid == 0) {
+        const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[blk] = make_float2((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    }
+}
+
+// one workgroup per image: fixed-order sum of that image's partials
+__global__ __launch_bounds__(256) void k_reduce_partials(const float2* __restrict__ partial, int per_image, float scale, float2* __restrict__ sums)
+{
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x;
+    const float2* p = partial + (size_t)blockIdx.x * per_image;
+    float a = 0.f, b = 0.f;
+    for (int i = tid; i < per_image; i += 256) {
+        const float2 v = p[i];
+        a += v.x;
+        b += v.y;
+    }
+    a = wave_sum_hi(a);
+    b = wave_sum_hi(b);
+    if ((tid & 63) == 63) { red[0][tid >> 6] = a; red[1][tid >> 6] = b; }
+    __syncthreads();
+    if (tid == 0)
+        sums[blockIdx.x] = make_float2(scale * ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])),
+                                       scale * ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])));
+}
+
+__global__ __launch_bounds__(256) void k_l1_ssim_bwd(int C, int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
+                                                      const float* __restrict__ maps, size_t map_stride, Window win,
+                                                      const float2* __restrict__ g, float scale, float* __restrict__ d_img1)
+{
+    __shared__ float sm[3][HY][HX + 1];
+    __shared__ float hq[3][HY][TX];
+    const int tid = threadIdx.x;
+    const int plane = blockIdx.z, x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    const size_t poff = (size_t)plane * H * W;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) load_halo(sm[q], maps + q * map_stride + poff, H, W, x0, y0, tid);
+    __syncthreads();
+    for (int i = tid; i < HY * TX; i += 256) {
+        const int r = i >> 4, c = i & 15;
+        float a = 0.f, b = 0.f, d = 0.f;
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) {
+            const float w = win.w[k];
+            a += w * sm[0][r][c + k];
+            b += w * sm[1][r][c + k];
+            d += w * sm[2][r][c + k];
+        }
+        hq[0][r][c] = a; hq[1][r][c] = b; hq[2][r][c] = d;
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    float ca = 0.f, cb = 0.f, cc = 0.f;
+#pragma unroll
+    for (int k = 0; k < WIN; ++k) {
+        const float w = win.w[k];
+        ca += w * hq[0][ty + k][tx];
+        cb += w * hq[1][ty + k][tx];
+        cc += w * hq[2][ty + k][tx];
+    }
+    const int px = x0 + tx, py = y0 + ty;
+    if (px < W && py < H) {
+        const size_t o = poff + (size_t)py * W + px;
+        const float x = img1[o], y = img2[o];
+        float2 gi = g[plane / C];
+        gi.x *= scale;
+        gi.y *= scale;
+        const float df = x - y;
+        const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+        d_img1[o] = gi.y * (ca + 2.f * x * cb + y * cc) + gi.x * sgn;
+    }
+}
+
+// ---- plain L1 -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_l1_fwd(long long n, const float* __restrict__ a, const float* __restrict__ b, float2* __restrict__ partial)
+{
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const long long n4 = n >> 2;
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 u = ((const float4*)a)[i], v = ((const float4*)b)[i];
+        s += (fabsf(u.x - v.x) + fabsf(u.y - v.y)) + (fabsf(u.z - v.z) + fabsf(u.w - v.w));
+    }
+    if (blockIdx.x == 0 && tid < (int)(n & 3)) s += fabsf(a[(n4 << 2) + tid] - b[(n4 << 2) + tid]);
+    s = wave_sum_hi(s);
+    if ((tid & 63) == 63) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) partial[blockIdx.x] = make_float2((red[0] + red[1]) + (red[2] + red[3]), 0.f);
+}
+__global__ __launch_bounds__(256) void k_l1_reduce(const float2* __restrict__ partial, int count, float scale, float* __restrict__ sum)
+{
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    float s = 0.f;
+    for (int i = tid; i < count; i += 256) s += partial[i].x;
+    s = wave_sum_hi(s);
+    if ((tid & 63) == 63) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) *sum = scale * ((red[0] + red[1]) + (red[2] + red[3]));
+}
+__device__ __forceinline__ float sgn_scaled(float d, float g) { return d > 0.f ? g : (d < 0.f ? -g : 0.f); }
+__global__ __launch_bounds__(256) void k_l1_bwd(long long n, const float* __restrict__ a, const float* __restrict__ b,
+                                                 const float* __restrict__ g, float scale, float* __restrict__ d_a)
+{
+    const float gv = *g * scale;
+    const long long n4 = n >> 2;
+    const int tid = threadIdx.x;
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 u = ((const float4*)a)[i], v = ((const float4*)b)[i];
+        ((float4*)d_a)[i] = make_float4(sgn_scaled(u.x - v.x, gv), sgn_scaled(u.y - v.y, gv), sgn_scaled(u.z - v.z, gv), sgn_scaled(u.w - v.w, gv));
+    }
+    if (blockIdx.x == 0 && tid < (int)(n & 3)) {
+        const long long i = (n4 << 2) + tid;
+        d_a[i] = sgn_scaled(a[i] - b[i], gv);
+    }
+}
+
+// ---- densification statistics -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_densify_stats(int P, const int* __restrict__ radii, const float* __restrict__ vgrad,
+                                                        float* __restrict__ max_radii2D, float* __restrict__ accum, float* __restrict__ denom)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    max_radii2D[i] = fmaxf(max_radii2D[i], (float)r);
+    const float gx = vgrad[3 * i], gy = vgrad[3 * i + 1];
+    accum[i] += sqrtf(gx * gx + gy * gy);
+    denom[i] += 1.f;
+}
+
+}  // namespace gls
+
+// ---------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define LAUNCH_CHECK(what)                                                                            \
+    do {                                                                                              \
+        hipError_t e_ = hipGetLastError();                                                            \
+        if (e_ != hipSuccess) return fail(GLS_E_HIP, "%s: %s", what, hipGetErrorString(e_));          \
+    } while (0)
+
+static gls::Window make_window()
+{
+    // utils/loss_utils.py:23-25: exp(-(x - 5)^2 / (2 * 1.5^2)) held in fp32, divided by its fp32 sum
+    gls::Window w;
+    float sum = 0.f;
+    for (int x = 0; x < gls::WIN; ++x) {
+        w.w[x] = (float)std::exp(-(double)((x - gls::RAD) * (x - gls::RAD)) / (2.0 * 1.5 * 1.5));
+        sum += w.w[x];
+    }
+    for (int x = 0; x < gls::WIN; ++x) w.w[x] /= sum;
+    return w;
+}
+static const int kL1Blocks = 1024;
+
+extern "C" {
+
+int gls_abi_version(void) { return GLS_ABI_VERSION; }
+const char* gls_last_error(void) { return g_err; }
+
+static bool image_args_ok(int32_t B, int32_t C, int32_t H, int32_t W)
+{
+    return B > 0 && C > 0 && H > 0 && W > 0 && (int64_t)B * C <= 65535 && (H + gls::TY - 1) / gls::TY <= 65535;
+}
+
+int64_t gls_partial_floats(int32_t B, int32_t C, int32_t H, int32_t W)
+{
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 2 * kL1Blocks;
+    const int64_t tiles = (int64_t)((W + gls::TX - 1) / gls::TX) * ((H + gls::TY - 1) / gls::TY) * B * C;
+    return 2 * (tiles > kL1Blocks ? tiles : kL1Blocks);
+}
+
+int gls_l1_ssim_forward(int32_t B, int32_t C, int32_t H, int32_t W, const float* img1, const float* img2, float scale, float* sums,
+                        float* maps, float* partial, void* stream_)
+{
+    if (!image_args_ok(B, C, H, W)) return fail(GLS_E_ARG, "bad image shape (%d,%d,%d,%d)", B, C, H, W);
+    if (!img1 || !img2 || !sums || !partial) return fail(GLS_E_ARG, "null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid((W + gls::TX - 1) / gls::TX, (H + gls::TY - 1) / gls::TY, B * C);
+    const size_t stride = (size_t)B * C * H * W;
+    hipLaunchKernelGGL(gls::k_l1_ssim_fwd, grid, dim3(256), 0, stream, H, W, img1, img2, make_window(), maps, stride, (float2*)partial);
+    LAUNCH_CHECK("k_l1_ssim_fwd");
+    hipLaunchKernelGGL(gls::k_reduce_partials, dim3(B), dim3(256), 0, stream, (const float2*)partial, (int)(grid.x * grid.y * C), scale, (float2*)sums);
+    LAUNCH_CHECK("k_reduce_partials");
+    return GLS_OK;
+}
+
+int gls_l1_ssim_backward(int32_t B, int32_t C, int32_t H, int32_t W, const float* img1, const float* img2, const float* maps,
+                         const float* g, float scale, float* d_img1, void* stream_)
+{
+    if (!image_args_ok(B, C, H, W)) return fail(GLS_E_ARG, "bad image shape (%d,%d,%d,%d)", B, C, H, W);
+    if (!img1 || !img2 || !maps || !g || !d_img1) return fail(GLS_E_ARG, "null pointer");
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid((W + gls::TX - 1) / gls::TX, (H + gls::TY - 1) / gls::TY, B * C);
+    const size_t stride = (size_t)B * C * H * W;
+    hipLaunchKernelGGL(gls::k_l1_ssim_bwd, grid, dim3(256), 0, stream, C, H, W, img1, img2, maps, stride, make_window(), (const float2*)g, scale, d_img1);
+    LAUNCH_CHECK("k_l1_ssim_bwd");
+    return GLS_OK;
+}
+
+int gls_l1_forward(int64_t n, const float* a, const float* b, float scale, float* sum, float* partial, void* stream_)
+{
+    if (n < 0 || !sum || !partial || (n > 0 && (!a || !b))) return fail(GLS_E_ARG, "bad arguments");
+    if ((((uintptr_t)a) | ((uintptr_t)b)) & 15) return fail(GLS_E_ARG, "inputs must be 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    int blocks = (int)(((n >> 2) + 255) / 256);
+    blocks = blocks < 1 ? 1 : (blocks > kL1Blocks ? kL1Blocks : blocks);
+    hipLaunchKernelGGL(gls::k_l1_fwd, dim3(blocks), dim3(256), 0, stream, (long long)n, a, b, (float2*)partial);
+    LAUNCH_CHECK("k_l1_fwd");
+    hipLaunchKernelGGL(gls::k_l1_reduce, dim3(1), dim3(256), 0, stream, (const float2*)partial, blocks, scale, sum);
+    LAUNCH_CHECK("k_l1_reduce");
+    return GLS_OK;
+}
+
+int gls_l1_backward(int64_t n, const float* a, const float* b, const float* g, float scale, float* d_a, void* stream_)
+{
+    if (n < 0 || !g || (n > 0 && (!a || !b || !d_a))) return fail(GLS_E_ARG, "bad arguments");
+    if ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)d_a)) & 15) return fail(GLS_E_ARG, "buffers must be 16-byte aligned");
+    if (n == 0) return GLS_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    int blocks = (int)(((n >> 2) + 255) / 256);
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(gls::k_l1_bwd, dim3(blocks), dim3(256), 0, stream, (long long)n, a, b, g, scale, d_a);
+    LAUNCH_CHECK("k_l1_bwd");
+    return GLS_OK;
+}
+
+int gls_densification_stats(int32_t P, const int32_t* radii, const float* viewspace_grad, float* max_radii2D, float* xyz_gradient_accum,
+                            float* denom, void* stream_)
+{
+    if (P < 0) return fail(GLS_E_ARG, "P < 0");
+    if (P == 0) return GLS_OK;
+    if (!radii || !viewspace_grad || !max_radii2D || !xyz_gradient_accum || !denom) return fail(GLS_E_ARG, "null pointer");
+    hipLaunchKernelGGL(gls::k_densify_stats, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, P, radii, viewspace_grad,
+                       max_radii2D, xyz_gradient_accum, denom);
+    LAUNCH_CHECK("k_densify_stats");
+    return GLS_OK;
+}
+
+}  // extern "C"

@@ -56,6 +56,9 @@ class GaussianModel:
             self.binding_counter = torch.bincount(self.binding.long(), minlength=nf).int()
         self.active_sh_degree = self.max_sh_degree
         self.max_radii2D = torch.zeros((self._xyz.shape[0]), device=device)
+        # densification statistics, as training_setup allocates them (scene/gaussian_model.py:210-211)
+        self.xyz_gradient_accum = torch.zeros((self._xyz.shape[0], 1), device=device)
+        self.denom = torch.zeros((self._xyz.shape[0], 1), device=device)
 
     def load_ply(self, path, device="cuda", **kwargs):
         """scene/gaussian_model.py:282-332: leaf tensors from the reference's PLY (binding -> int32)."""
@@ -125,6 +128,17 @@ class GaussianModel:
 
     def select_mesh_by_timestep(self, timestep):
         raise NotImplementedError
+
+    def update_densification_stats(self, viewspace_point_tensor, radii):
+        """The two statistics lines of a training iteration, train.py:197-198, as one launch (include/gls.h):
+            self.max_radii2D[vis] = max(self.max_radii2D[vis], radii[vis])          # train.py:197
+            self.add_densification_stats(viewspace_point_tensor, vis)              # gaussian_model.py:517-519
+        with vis = radii > 0 (render()'s visibility_filter)."""
+        from .loss import densification_stats
+
+        if viewspace_point_tensor.grad is None:
+            raise RuntimeError("viewspace_point_tensor has no .grad: call backward() first")
+        densification_stats(radii, viewspace_point_tensor.grad, self.max_radii2D, self.xyz_gradient_accum, self.denom)
 
     def oneupSHdegree(self):
         if self.active_sh_degree < self.max_sh_degree:

@@ -102,5 +102,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
 
 
 def l1_loss(network_output, gt):
-    """utils/loss_utils.py:17-18"""
-    return torch.abs((network_output - gt)).mean()
+    """utils/loss_utils.py:17-18, on the fused kernel of include/gls.h (see loss.py)."""
+    from .loss import l1_loss as _l1
+
+    return _l1(network_output, gt)

@@ -1,0 +1,166 @@
+"""Mirror of utils/loss_utils.py (l1_loss :17-18, ssim :36-63) and of the statistics update train.py performs right
+after backward (train.py:197-198, scene/gaussian_model.py:517-519) on the fused HIP kernels of include/gls.h.
+
+`l1_loss(a, b)` and `ssim(img1, img2)` keep the reference's names, arguments and return values so
+train.py:131-132 reads unchanged; `l1_ssim(image, gt)` returns both from one pass over the pair (what a training
+step should call).  There is no torch fallback: a CPU tensor or a missing library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {_lib.gls_error()}")
+
+
+def _as_input(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a device tensor (the HIP kernels are the only implementation)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+class _L1Ssim(torch.autograd.Function):
+    """(B,C,H,W) x (B,C,H,W) -> (B,2) = [mean |a-b|, mean ssim_map] per image."""
+
+    @staticmethod
+    def forward(ctx, img1, img2):
+        lib = _lib.gls()
+        B, Cc, H, W = img1.shape
+        dev = img1.device
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        partial = torch.empty(int(lib.gls_partial_floats(B, Cc, H, W)), dtype=torch.float32, device=dev)
+        maps = torch.empty((3, B, Cc, H, W), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        _check(lib.gls_l1_ssim_forward(B, Cc, H, W, _p(img1), _p(img2), 1.0 / float(Cc * H * W), _p(sums), _p(maps), _p(partial),
+                                       _stream(dev)), "gls_l1_ssim_forward")
+        if need:
+            ctx.save_for_backward(img1, img2, maps)
+        return sums
+
+    @staticmethod
+    def backward(ctx, g):
+        img1, img2, maps = ctx.saved_tensors
+        lib = _lib.gls()
+        B, Cc, H, W = img1.shape
+        dev = img1.device
+        gs = g.to(torch.float32).contiguous()
+        scale = 1.0 / float(Cc * H * W)
+        d1 = d2 = None
+        if ctx.needs_input_grad[0]:
+            d1 = torch.empty_like(img1)
+            _check(lib.gls_l1_ssim_backward(B, Cc, H, W, _p(img1), _p(img2), _p(maps), _p(gs), scale, _p(d1), _stream(dev)),
+                   "gls_l1_ssim_backward")
+        if ctx.needs_input_grad[1]:
+            # both statistics are symmetric in their arguments: the gradient w.r.t. the second image is the gradient
+            # w.r.t. the first of the swapped pair (rare: the ground truth is data)
+            partial = torch.empty(int(lib.gls_partial_floats(B, Cc, H, W)), dtype=torch.float32, device=dev)
+            sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
+            maps2 = torch.empty((3, B, Cc, H, W), dtype=torch.float32, device=dev)
+            _check(lib.gls_l1_ssim_forward(B, Cc, H, W, _p(img2), _p(img1), scale, _p(sums), _p(maps2), _p(partial), _stream(dev)),
+                   "gls_l1_ssim_forward")
+            d2 = torch.empty_like(img2)
+            _check(lib.gls_l1_ssim_backward(B, Cc, H, W, _p(img2), _p(img1), _p(maps2), _p(gs), scale, _p(d2), _stream(dev)),
+                   "gls_l1_ssim_backward")
+        return d1, d2
+
+
+def _batched(img1, img2):
+    if img1.shape != img2.shape:
+        raise ValueError(f"image shapes differ: {tuple(img1.shape)} vs {tuple(img2.shape)}")
+    if img1.dim() == 3:
+        return img1[None], img2[None]
+    if img1.dim() == 4:
+        return img1, img2
+    raise ValueError("images must be (C,H,W) or (B,C,H,W)")
+
+
+def l1_ssim(image: torch.Tensor, gt: torch.Tensor):
+    """-> (l1, ssim): the two scalars train.py:131-132 combines, from ONE pass over (image, gt).
+    l1 == l1_loss(image, gt), ssim == ssim(image, gt) (size_average=True)."""
+    a, b = _batched(_as_input(image, "image"), _as_input(gt, "gt"))
+    m = _L1Ssim.apply(a, b)
+    m = m[0] if m.shape[0] == 1 else m.mean(dim=0)
+    return m[0], m[1]
+
+
+def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_average: bool = True):
+    """utils/loss_utils.py:36-63.  Only the reference's window (11, sigma 1.5) exists in the kernel."""
+    if window_size != 11:
+        raise NotImplementedError("the fused SSIM kernel implements the reference's 11x11 window only")
+    a, b = _batched(_as_input(img1, "img1"), _as_input(img2, "img2"))
+    per_image = _L1Ssim.apply(a, b)[:, 1]
+    if not size_average:
+        return per_image
+    return per_image[0] if per_image.shape[0] == 1 else per_image.mean()
+
+
+class _L1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _lib.gls()
+        dev = a.device
+        n = a.numel()
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        partial = torch.empty(int(lib.gls_partial_floats(1, 1, 1, 1)), dtype=torch.float32, device=dev)
+        _check(lib.gls_l1_forward(n, _p(a), _p(b), 1.0 / float(max(n, 1)), _p(out), _p(partial), _stream(dev)), "gls_l1_forward")
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        lib = _lib.gls()
+        dev = a.device
+        n = a.numel()
+        gs = g.to(torch.float32).contiguous()
+        scale = 1.0 / float(max(n, 1))
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty_like(a)
+            _check(lib.gls_l1_backward(n, _p(a), _p(b), _p(gs), scale, _p(da), _stream(dev)), "gls_l1_backward")
+        if ctx.needs_input_grad[1]:
+            db = torch.empty_like(b)
+            _check(lib.gls_l1_backward(n, _p(b), _p(a), _p(gs), scale, _p(db), _stream(dev)), "gls_l1_backward")
+        return da, db
+
+
+def l1_loss(network_output: torch.Tensor, gt: torch.Tensor):
+    """utils/loss_utils.py:17-18: mean |network_output - gt| (2 launches forward, 1 backward)."""
+    if network_output.shape != gt.shape:
+        gt = gt.expand_as(network_output)
+    return _L1.apply(_as_input(network_output, "network_output"), _as_input(gt, "gt"))
+
+
+@torch.no_grad()
+def densification_stats(radii: torch.Tensor, viewspace_grad: torch.Tensor, max_radii2D: torch.Tensor,
+                        xyz_gradient_accum: torch.Tensor, denom: torch.Tensor) -> None:
+    """train.py:197 + scene/gaussian_model.py:517-519 for update_filter = radii > 0, in place, one launch:
+        max_radii2D[vis] = max(max_radii2D[vis], radii[vis]);  xyz_gradient_accum[vis] += |grad[vis, :2]|;  denom[vis] += 1
+    """
+    P = radii.shape[0]
+    if radii.dtype != torch.int32:
+        raise TypeError("radii must be int32 (as the rasterizer returns them)")
+    for name, t in (("max_radii2D", max_radii2D), ("xyz_gradient_accum", xyz_gradient_accum), ("denom", denom)):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != P or not t.is_cuda:
+            raise ValueError(f"{name} must be a contiguous float32 device tensor with {P} elements")
+    if tuple(viewspace_grad.shape) != (P, 3) or viewspace_grad.dtype != torch.float32:
+        raise ValueError("viewspace_grad must be (P,3) float32")
+    vg = viewspace_grad.contiguous()
+    _check(_lib.gls().gls_densification_stats(P, _p(radii.contiguous()), _p(vg), _p(max_radii2D), _p(xyz_gradient_accum), _p(denom),
+                                              _stream(radii.device)), "gls_densification_stats")

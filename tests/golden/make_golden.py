@@ -12,6 +12,9 @@ Pins produced (the reference has no tests or golden vectors of i
   binding_pins.npz  flame_model/lbs.py (lbs, blend_shapes)         -> FLAME forward on a small synthetic rig
                     utils/graphics_utils.compute_face_orientation  -> per-face frames
                     scipy Rotation.from_matrix (roma's algorithm)  -> rotmat -> quaternion, up to sign
+  loss_pins.npz     utils/loss_utils.l1_loss / ssim (values + autograd gradients, fp32 torch-CPU)
+                    scene/gaussian_model.GaussianModel.add_densification_stats + train.py:197
+                                                                   -> densification statistics update
 """
 import math
 import os
@@ -130,8 +133,61 @@ def binding_pins():
     )
 
 
+def loss_pins():
+    from utils import loss_utils  # reference module
+
+    g = np.random.default_rng(303)
+    out = {}
+    # smooth-ish images in [0,1] (a flat patch, an edge and noise) so every branch of the map matters
+    def image(shape):
+        img = g.uniform(0, 1, shape).astype(np.float32)
+        img[..., : shape[-2] // 3, :] = 0.5 + 0.01 * g.normal(size=img[..., : shape[-2] // 3, :].shape)
+        return np.clip(img, 0, 1).astype(np.float32)
+
+    cases = {"chw": (3, 45, 37), "bchw": (2, 3, 20, 33), "tiny": (1, 7, 5)}
+    for name, shape in cases.items():
+        a, b = image(shape), image(shape)
+        b[..., ::4, ::3] = a[..., ::4, ::3]   # exact ties: d|x-y| = 0 there
+        ta = torch.tensor(a, requires_grad=True)
+        tb = torch.tensor(b)
+        l1 = loss_utils.l1_loss(ta, tb)
+        (g_l1,) = torch.autograd.grad(l1, ta)
+        ss = loss_utils.ssim(ta, tb)
+        (g_ss,) = torch.autograd.grad(ss, ta)
+        out.update({f"{name}_a": a, f"{name}_b": b, f"{name}_l1": l1.detach().numpy(), f"{name}_ssim": ss.detach().numpy(),
+                    f"{name}_g_l1": g_l1.numpy(), f"{name}_g_ssim": g_ss.numpy()})
+        if len(shape) == 4:
+            out[f"{name}_ssim_per_image"] = loss_utils.ssim(ta, tb, size_average=False).detach().numpy()
+    out["window_2d"] = loss_utils.create_window(11, 1)[0, 0].numpy()
+
+    # densification statistics: the reference method itself (its module needs three absent packages only at import)
+    absent = ("plyfile", "simple_knn", "simple_knn._C", "roma", "iopath", "iopath.common", "iopath.common.file_io", "cv2",
+              "PIL", "PIL.Image", "tyro", "dearpygui", "dearpygui.dearpygui", "lpips", "tensorboard", "matplotlib", "matplotlib.pyplot")
+    with mock.patch.dict(sys.modules, {k: mock.MagicMock() for k in absent if k not in sys.modules}):
+        from scene.gaussian_model import GaussianModel as RefGaussianModel
+    P = 500
+    radii = g.integers(-0, 40, P).astype(np.int32)
+    radii[g.uniform(size=P) < 0.4] = 0
+    vgrad = g.normal(0, 1e-3, (P, 3)).astype(np.float32)
+    max_r = g.integers(0, 30, P).astype(np.float32)
+    acc = np.abs(g.normal(0, 1e-3, (P, 1))).astype(np.float32)
+    den = g.integers(0, 9, (P, 1)).astype(np.float32)
+    m = RefGaussianModel.__new__(RefGaussianModel)
+    m.xyz_gradient_accum, m.denom, m.max_radii2D = torch.tensor(acc), torch.tensor(den), torch.tensor(max_r)
+    vis = torch.tensor(radii) > 0
+    tr = torch.tensor(radii)
+    m.max_radii2D[vis] = torch.max(m.max_radii2D[vis], tr[vis])  # train.py:197
+    vp = torch.zeros(P, 3, requires_grad=True)
+    vp.grad = torch.tensor(vgrad)
+    m.add_densification_stats(vp, vis)                           # gaussian_model.py:517-519
+    out.update(ds_radii=radii, ds_vgrad=vgrad, ds_max_in=max_r, ds_acc_in=acc, ds_den_in=den,
+               ds_max_out=m.max_radii2D.numpy(), ds_acc_out=m.xyz_gradient_accum.numpy(), ds_den_out=m.denom.numpy())
+    np.savez_compressed(os.path.join(HERE, "loss_pins.npz"), **out)
+
+
 if __name__ == "__main__":
     raster_pins()
     binding_pins()
-    for f in ("raster_pins.npz", "binding_pins.npz"):
+    loss_pins()
+    for f in ("raster_pins.npz", "binding_pins.npz", "loss_pins.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

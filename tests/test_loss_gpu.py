@@ -1,0 +1,166 @@
+"""GPU parity tests of the fused loss / statistics kernels (include/gls.h) through the Python mirror of
+utils/loss_utils.py.  Bars (fp32 kernels, separable window vs the reference's 2-D window):
+value of l1 within 2e-6 abs, ssim within 2e-5 abs; l1 gradient exact up to the 1/n scale (rel 1e-6);
+ssim gradient within 3e-4 of the per-tensor max magnitude; statistics update: integer-valued outputs
+exact, accumulated norm within 2 ulp."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_oracle as LO
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+PINS = np.load(os.path.join(HERE, "golden", "loss_pins.npz"))
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _t(x, dev, grad=False):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev).requires_grad_(grad)
+
+
+@pytest.mark.parametrize("case", ["chw", "bchw", "tiny"])
+def test_matches_reference_pins(case):
+    from gaussianavatars_amd import loss
+
+    dev = _dev()
+    a, b = PINS[f"{case}_a"], PINS[f"{case}_b"]
+    ta, tb = _t(a, dev, True), _t(b, dev)
+    l1 = loss.l1_loss(ta, tb)
+    (g_l1,) = torch.autograd.grad(l1, ta)
+    ss = loss.ssim(ta, tb)
+    (g_ss,) = torch.autograd.grad(ss, ta)
+    assert abs(float(l1) - float(PINS[f"{case}_l1"])) < 2e-6
+    assert abs(float(ss) - float(PINS[f"{case}_ssim"])) < 2e-5
+    np.testing.assert_allclose(g_l1.cpu().numpy(), PINS[f"{case}_g_l1"], rtol=1e-6, atol=1e-10)
+    ref = PINS[f"{case}_g_ssim"]
+    assert np.abs(g_ss.cpu().numpy() - ref).max() < 3e-4 * np.abs(ref).max()
+    # the fused pair equals the two separate calls, values and combined gradient
+    ta2 = _t(a, dev, True)
+    f1, fs = loss.l1_ssim(ta2, tb)
+    assert float(f1) == float(l1) and float(fs) == float(ss)
+    (0.8 * f1 + 0.2 * (1.0 - fs)).backward()
+    comb = 0.8 * g_l1 - 0.2 * g_ss
+    assert float((ta2.grad - comb).abs().max()) < 1e-6 * float(comb.abs().max()) + 1e-12
+    if a.ndim == 4:
+        per = loss.ssim(ta, tb, size_average=False)
+        np.testing.assert_allclose(per.detach().cpu().numpy(), PINS[f"{case}_ssim_per_image"], rtol=0, atol=2e-5)
+
+
+def test_full_size_against_oracle():
+    """BASELINE image size (3 x 802 x 550): ragged right/bottom tiles, value + gradient vs the fp64 oracle."""
+    from gaussianavatars_amd import loss
+
+    dev = _dev()
+    g = np.random.default_rng(9)
+    yy, xx = np.mgrid[0:802, 0:550]
+    base = 0.5 + 0.4 * np.sin(xx / 37.0)[None] * np.cos(yy / 23.0)[None] * np.array([1.0, 0.7, 0.4])[:, None, None]
+    a = np.clip(base + g.normal(0, 0.05, base.shape), 0, 1).astype(np.float32)
+    b = np.clip(base + g.normal(0, 0.02, base.shape), 0, 1).astype(np.float32)
+    ta, tb = _t(a, dev, True), _t(b, dev)
+    l1, ss = loss.l1_ssim(ta, tb)
+    (0.8 * l1 + 0.2 * (1.0 - ss)).backward()
+    assert abs(float(l1) - LO.l1(a, b)) < 2e-6
+    assert abs(float(ss) - LO.ssim(a, b)) < 2e-5
+    ref = 0.8 * LO.l1_grad(a, b) - 0.2 * LO.ssim_grad(a, b)
+    assert np.abs(ta.grad.cpu().numpy() - ref).max() < 3e-4 * np.abs(ref).max()
+    # deterministic: a second evaluation is bit-identical
+    l1b, ssb = loss.l1_ssim(_t(a, dev), tb)
+    assert float(l1b) == float(l1) and float(ssb) == float(ss)
+
+
+def test_gradient_wrt_second_image_and_identity():
+    from gaussianavatars_amd import loss
+
+    dev = _dev()
+    a, b = PINS["chw_a"], PINS["chw_b"]
+    ta, tb = _t(a, dev), _t(b, dev, True)
+    loss.ssim(ta, tb).backward()
+    ref = LO.ssim_grad(b, a)
+    assert np.abs(tb.grad.cpu().numpy() - ref).max() < 3e-4 * np.abs(ref).max()
+    assert abs(float(loss.ssim(ta, ta)) - 1.0) < 1e-6 and float(loss.l1_loss(ta, ta)) == 0.0
+
+
+def test_l1_odd_sizes():
+    from gaussianavatars_amd import loss
+
+    dev = _dev()
+    g = np.random.default_rng(3)
+    for n in (1, 3, 4, 5, 1027, 3 * 802 * 550 + 1):
+        a, b = g.normal(size=n).astype(np.float32), g.normal(size=n).astype(np.float32)
+        ta = _t(a, dev, True)
+        l = loss.l1_loss(ta, _t(b, dev))
+        l.backward()
+        assert abs(float(l) - LO.l1(a, b)) < 2e-6 * max(1.0, LO.l1(a, b))
+        np.testing.assert_allclose(ta.grad.cpu().numpy(), LO.l1_grad(a, b), rtol=1e-6, atol=0)
+
+
+def test_densification_stats():
+    from gaussianavatars_amd import loss
+
+    dev = _dev()
+    mr, acc, dn = _t(PINS["ds_max_in"], dev), _t(PINS["ds_acc_in"], dev), _t(PINS["ds_den_in"], dev)
+    loss.densification_stats(_t(PINS["ds_radii"], dev), _t(PINS["ds_vgrad"], dev), mr, acc, dn)
+    np.testing.assert_array_equal(mr.cpu().numpy(), PINS["ds_max_out"])
+    np.testing.assert_array_equal(dn.cpu().numpy(), PINS["ds_den_out"])
+    np.testing.assert_allclose(acc.cpu().numpy(), PINS["ds_acc_out"], rtol=3e-7, atol=0)
+
+
+def test_training_iteration_statistics_and_loss():
+    """Three iterations shaped like train.py:118-198 on a bound model: select -> render -> fused L1+SSIM -> backward ->
+    fused statistics; the loss / image gradient / statistics are compared with the same lines written in composed torch
+    ops (the reference's formulation) on the same rendered image."""
+    import torch.nn.functional as F
+
+    import bench
+    from gaussianavatars_amd import loss
+    from gaussianavatars_amd.gaussian_renderer import render
+
+    dev = _dev()
+    g, cam = bench.build_scene(dev, 20_000, 3, 320, 256, 3, "fused", True)
+    bg = torch.ones(3, device=dev)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    gt = torch.rand(3, cam.image_height, cam.image_width, generator=gen).to(dev)
+    w1 = torch.from_numpy(LO.window_1d()).to(dev)
+    win = (w1[:, None] * w1[None, :]).expand(3, 1, 11, 11).contiguous()
+
+    def torch_ssim(a, b):  # utils/loss_utils.py:43-63 written out
+        conv = lambda x: F.conv2d(x[None], win, padding=5, groups=3)[0]
+        mu1, mu2 = conv(a), conv(b)
+        s1, s2, s12 = conv(a * a) - mu1 * mu1, conv(b * b) - mu2 * mu2, conv(a * b) - mu1 * mu2
+        return (((2 * mu1 * mu2 + LO.C1) * (2 * s12 + LO.C2)) / ((mu1 * mu1 + mu2 * mu2 + LO.C1) * (s1 + s2 + LO.C2))).mean()
+
+    P = g._xyz.shape[0]
+    ref_max, ref_acc, ref_den = torch.zeros(P, device=dev), torch.zeros(P, 1, device=dev), torch.zeros(P, 1, device=dev)
+    lam = 0.2
+    for it in range(3):
+        bench.zero_grads(g)
+        g.select_mesh_by_timestep(it)
+        pkg = render(cam, g, bench.Pipe, bg)
+        image, vsp, radii = pkg["render"], pkg["viewspace_points"], pkg["radii"]
+        l1, ss = loss.l1_ssim(image, gt)
+        total = (1.0 - lam) * l1 + lam * (1.0 - ss)
+        # the same loss in torch on a detached copy of the image
+        img2 = image.detach().clone().requires_grad_(True)
+        total_ref = (1.0 - lam) * (img2 - gt).abs().mean() + lam * (1.0 - torch_ssim(img2, gt))
+        total_ref.backward()
+        image.retain_grad()
+        total.backward()
+        assert abs(float(total) - float(total_ref)) < 2e-5
+        assert float((image.grad - img2.grad).abs().max()) < 3e-4 * float(img2.grad.abs().max())
+        assert g._xyz.grad is not None and float(g._xyz.grad.abs().sum()) > 0
+        g.update_densification_stats(vsp, radii)
+        vis = radii > 0
+        ref_max[vis] = torch.max(ref_max[vis], radii[vis])
+        ref_acc[vis] += torch.norm(vsp.grad[vis, :2], dim=-1, keepdim=True)
+        ref_den[vis] += 1
+    assert int(vis.sum()) > 1000
+    assert torch.equal(g.max_radii2D, ref_max) and torch.equal(g.denom, ref_den)
+    assert float((g.xyz_gradient_accum - ref_acc).abs().max()) <= 4e-7 * float(ref_acc.abs().max())
