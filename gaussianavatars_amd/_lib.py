@@ -36,7 +36,7 @@ class GsrSettings(C.Structure):
 
 class GsrGeomLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
-                ("depths", "grec", "cov3D", "rect", "tiles_touched", "clamped", "total")]
+                ("depths", "grec", "cov3D", "rect", "tiles_touched", "clamped", "acc", "total")]
 
 
 class GsrBinningLayout(C.Structure):
@@ -59,13 +59,13 @@ GSR_SYMBOLS = {
                     [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                      C.POINTER(C.c_int64), C.c_void_p]),
     "gsr_backward": (C.c_int, [C.POINTER(GsrSettings), C.c_int32, C.c_int32] + [C.c_void_p] * 6 +
-                     [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p] +
+                     [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p] +
                      [C.c_void_p] * 8 + [C.c_void_p]),
     "gsr_forward_ex": (C.c_int, [C.POINTER(GsrSettings), C.c_int32, C.c_int32] + [C.c_void_p] * 8 +
                        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                         C.POINTER(C.c_int64), C.c_void_p]),
     "gsr_backward_ex": (C.c_int, [C.POINTER(GsrSettings), C.c_int32, C.c_int32] + [C.c_void_p] * 7 +
-                        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p] +
+                        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p] +
                         [C.c_void_p] * 9 + [C.c_void_p]),
     "gsr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_profile_enable": (C.c_int, [C.c_int]),

@@ -73,6 +73,7 @@ def _rig_struct(head) -> "_lib.GabRig":
 class _FlameForward(torch.autograd.Function):
     @staticmethod
     def forward(ctx, head, shape, expr, rotation, neck, jaw, eyes, translation, static_offset):
+        ctx.set_materialize_grads(False)   # the backward takes NULL for an unused output's gradient
         lib = _lib.gab()
         rig = _rig_struct(head)
         dev = head.v_template.device
@@ -117,9 +118,8 @@ class _FlameForward(torch.autograd.Function):
         scratch = torch.empty(3 * V, **f32)
         gv = torch.zeros((V, 3), **f32) if g_verts is None else _f32(g_verts)
         gvs = None if g_vshaped is None else _f32(g_vshaped)
-        ws_bwd = ws.clone()  # the backward accumulates into its workspace; keep the saved one pristine
         with torch.cuda.device(dev):
-            _chk(lib.gab_flame_backward(C.byref(rig), *[_p(t) for t in ins], _p(so), _p(v_shaped), _p(ws_bwd), _p(gv), _p(gvs),
+            _chk(lib.gab_flame_backward(C.byref(rig), *[_p(t) for t in ins], _p(so), _p(v_shaped), _p(ws), _p(gv), _p(gvs),
                                         _p(d_shape), _p(d_expr), _p(d_rot), _p(d_neck), _p(d_jaw), _p(d_eyes), _p(d_trans), _p(d_so),
                                         _p(scratch), _stream(dev)), "gab_flame_backward")
         sh = ctx.shapes
@@ -143,6 +143,7 @@ class _FlameForwardTimestep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, head, t, shape, expr, rotation, neck, jaw, eyes, translation, static_offset):
+        ctx.set_materialize_grads(False)
         lib = _lib.gab()
         rig = _rig_struct(head)
         dev = head.v_template.device
@@ -191,11 +192,10 @@ class _FlameForwardTimestep(torch.autograd.Function):
         scratch = torch.empty(3 * V, **f32)
         gv = torch.zeros((V, 3), **f32) if g_verts is None else _f32(g_verts)
         gvs = None if g_vshaped is None else _f32(g_vshaped)
-        ws_bwd = ws.clone()
         rows = [C.c_void_p(x.data_ptr() + 4 * t * w) for x, w in zip(tabs, widths)]
         with torch.cuda.device(dev):
             _chk(lib.gab_zero_buffers(len(tables), ptrs, sizes, _stream(dev)), "gab_zero_buffers")
-            _chk(lib.gab_flame_backward(C.byref(rig), _p(sh), *rows, _p(so), _p(v_shaped), _p(ws_bwd), _p(gv), _p(gvs), _p(d_shape),
+            _chk(lib.gab_flame_backward(C.byref(rig), _p(sh), *rows, _p(so), _p(v_shaped), _p(ws), _p(gv), _p(gvs), _p(d_shape),
                                         *outp, _p(d_so), _p(scratch), _stream(dev)), "gab_flame_backward")
         grads = [tb if need[3 + i] else None for i, tb in enumerate(tables)]
         return (None, None, None if d_shape is None else d_shape.view(ctx.shape_shape), *grads,
@@ -215,6 +215,7 @@ def flame_forward_timestep(head, flame_param: dict, t: int):
 class _FaceFrames(torch.autograd.Function):
     @staticmethod
     def forward(ctx, verts, faces):
+        ctx.set_materialize_grads(False)
         lib = _lib.gab()
         _need_cuda(verts, "verts")
         dev = verts.device

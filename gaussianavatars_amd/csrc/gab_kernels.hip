@@ -190,6 +190,9 @@ __global__ __launch_bounds__(256) void k_joints_chain(Rig rig, const float* __re
 {
     __shared__ float red[4][16];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // the backward's accumulators live in the same workspace: hand them over zeroed (k_chain_bwd zeroes them again
+    // after consuming them), so no memset precedes the backward's atomics
+    for (int k = WS_DA + tid; k < GAB_FLAME_WS_FLOATS; k += 256) ws[k] = 0.f;
     float acc[15];
 #pragma unroll
     for (int k = 0; k < 15; ++k) acc[k] = 0.f;
@@ -329,13 +332,18 @@ template <bool FLAME_TREE>
 __global__ __launch_bounds__(64) void k_chain_bwd(Rig rig, float* __restrict__ ws, const float* __restrict__ rotation, const float* __restrict__ neck,
                             const float* __restrict__ jaw, const float* __restrict__ eyes, float* __restrict__ d_rotation,
                             float* __restrict__ d_neck, float* __restrict__ d_jaw, float* __restrict__ d_eyes,
-                            float* __restrict__ d_translation)
+                            float* __restrict__ d_translation, float* __restrict__ d_expr, float* __restrict__ d_shape)
 {
     // stage the whole workspace through LDS with one coalesced pass, then a single lane runs the
     // (inherently serial, 5-joint) chain out of LDS instead of ~250 dependent global loads
     __shared__ float sw[GAB_FLAME_WS_FLOATS];
     for (int kk = threadIdx.x; kk < GAB_FLAME_WS_FLOATS; kk += 64) sw[kk] = ws[kk];
     __syncthreads();
+    // consumed: leave the accumulators zeroed for the next backward, and zero the targets k_blend_bwd adds into
+    for (int kk = WS_DA + (int)threadIdx.x; kk < WS_DJ; kk += 64) ws[kk] = 0.f;
+    for (int kk = threadIdx.x; kk < rig.n_expr; kk += 64) d_expr[kk] = 0.f;
+    if (d_shape)
+        for (int kk = threadIdx.x; kk < rig.n_shape; kk += 64) d_shape[kk] = 0.f;
     if (threadIdx.x != 0) return;
     float J[15], R[45], Rg[45], tg[15];
 #pragma unroll
@@ -890,16 +898,13 @@ int gab_flame_backward(const GabRig* rig_, const float* shape, const float* expr
         return fail(GAB_E_ARG, "gab_flame_backward: NULL buffer");
     hipStream_t st = (hipStream_t)stream_;
     const int E = 3 * rig.V;
-    HIP_TRY(hipMemsetAsync(ws + gab::WS_DA, 0, (gab::WS_DJ + 15 - gab::WS_DA) * sizeof(float), st));
-    HIP_TRY(hipMemsetAsync(d_expr, 0, (size_t)rig.n_expr * sizeof(float), st));
-    if (d_shape) HIP_TRY(hipMemsetAsync(d_shape, 0, (size_t)rig.n_shape * sizeof(float), st));
     hipLaunchKernelGGL(gab::k_skin_bwd, dim3((rig.V + 255) / 256), dim3(256), 0, st, rig, ws, v_shaped, dL_dverts, scratch);
     LAUNCH_CHECK("k_skin_bwd");
     const bool flame_tree = rig.parents[1] == 0 && rig.parents[2] == 1 && rig.parents[3] == 1 && rig.parents[4] == 1;
     if (flame_tree)
-        hipLaunchKernelGGL(gab::k_chain_bwd<true>, dim3(1), dim3(64), 0, st, rig, ws, rotation, neck, jaw, eyes, d_rotation, d_neck, d_jaw, d_eyes, d_translation);
+        hipLaunchKernelGGL(gab::k_chain_bwd<true>, dim3(1), dim3(64), 0, st, rig, ws, rotation, neck, jaw, eyes, d_rotation, d_neck, d_jaw, d_eyes, d_translation, d_expr, d_shape);
     else
-        hipLaunchKernelGGL(gab::k_chain_bwd<false>, dim3(1), dim3(64), 0, st, rig, ws, rotation, neck, jaw, eyes, d_rotation, d_neck, d_jaw, d_eyes, d_translation);
+        hipLaunchKernelGGL(gab::k_chain_bwd<false>, dim3(1), dim3(64), 0, st, rig, ws, rotation, neck, jaw, eyes, d_rotation, d_neck, d_jaw, d_eyes, d_translation, d_expr, d_shape);
     LAUNCH_CHECK("k_chain_bwd");
     hipLaunchKernelGGL(gab::k_blend_bwd, dim3((E + GAB_BLEND_BWD_ROWS - 1) / GAB_BLEND_BWD_ROWS), dim3(256), 0, st, rig, (const float*)ws,
                        (const float*)scratch, dL_dv_shaped, d_static_offset, d_shape, d_expr);

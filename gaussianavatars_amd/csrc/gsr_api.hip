@@ -146,6 +146,7 @@ int gsr_geom_layout(int32_t P, GsrGeomLayout* o)
     o->rect = off;          off = align_up(off + n * 8, A);
     o->tiles_touched = off; off = align_up(off + n * 4, A);
     o->clamped = off;       off = align_up(off + n, A);
+    o->acc = off;           off = align_up(off + n * GSR_ACC_STRIDE * 4, A);
     o->total = off + A;
     return 0;
 }
@@ -224,7 +225,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     uint32_t* tile_count = (uint32_t*)(b + bl.tile_count);
 
     gsr::Settings ds = to_dev_settings(settings);
-    HIP_TRY(hipMemsetAsync(tile_count, 0, (size_t)tiles * 4, stream));
+    if (P == 0) HIP_TRY(hipMemsetAsync(tile_count, 0, (size_t)tiles * 4, stream));   // otherwise k_preprocess zeroes it
 
     gsr::PreprocessArgs pa;
     pa.P = P; pa.M = M;
@@ -237,6 +238,9 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     pa.rect = (ushort4*)(g + gl.rect);
     pa.tiles_touched = (uint32_t*)(g + gl.tiles_touched);
     pa.clamped = (uint8_t*)(g + gl.clamped);
+    pa.acc = (float4*)(g + gl.acc);
+    pa.tile_count = tile_count;
+    pa.tiles = tiles;
     const int pblocks = (P + 255) / 256;
     if (pblocks > 0) {
         TIMED(GSR_K_PREPROCESS, stream);
@@ -353,8 +357,8 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
 
 int gsr_backward_ex(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs, const float* shs_rest,
                     const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
-                 const int32_t* radii, const void* geom, const void* binning, int64_t binning_capacity, const void* img,
-                 int64_t num_rendered, const float* dL_dpix, float* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D,
+                 const int32_t* radii, void* geom, const void* binning, int64_t binning_capacity, const void* img,
+                 int64_t num_rendered, const float* dL_dpix, float* dL_dmeans3D, float* dL_dmeans2D,
                  float* dL_dsh, float* dL_dsh_rest, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
                  float* dL_dcov3D, void* stream_)
 {
@@ -362,7 +366,7 @@ int gsr_backward_ex(const GsrSettings* settings, int32_t P, int32_t M, const flo
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0 || num_rendered < 0 || binning_capacity < num_rendered) return fail(GSR_E_ARG, "bad sizes");
     if (P == 0) return GSR_OK;
-    if (!means3D || !radii || !geom || !binning || !img || !dL_dpix || !grad_scratch || !dL_dmeans3D || !dL_dmeans2D ||
+    if (!means3D || !radii || !geom || !binning || !img || !dL_dpix || !dL_dmeans3D || !dL_dmeans2D ||
         !dL_dcolors || !dL_dopacity || !dL_dcov3D)
         return fail(GSR_E_ARG, "NULL buffer");
     const bool pre_col = colors_precomp != nullptr, pre_cov = cov3D_precomp != nullptr;
@@ -380,12 +384,11 @@ int gsr_backward_ex(const GsrSettings* settings, int32_t P, int32_t M, const flo
     gsr_geom_layout(P, &gl);
     gsr_binning_layout(binning_capacity, W, H, &bl);
     gsr_image_layout(W, H, &il);
-    const char* g = (const char*)geom;
+    char* g = (char*)geom;
     const char* b = (const char*)binning;
     const char* im = (const char*)img;
     gsr::Settings ds = to_dev_settings(settings);
-
-    HIP_TRY(hipMemsetAsync(grad_scratch, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), stream));
+    float* grad_scratch = (float*)(g + gl.acc);   // zeroed by the forward (and by the previous backward)
     if (num_rendered > 0) {
         TIMED(GSR_K_RENDER_BWD, stream);
         hipLaunchKernelGGL(gsr::k_render_bwd, dim3(gx * gy), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order),
@@ -416,13 +419,13 @@ int gsr_backward_ex(const GsrSettings* settings, int32_t P, int32_t M, const flo
 
 int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs,
                  const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
-                 const int32_t* radii, const void* geom, const void* binning, int64_t binning_capacity, const void* img,
-                 int64_t num_rendered, const float* dL_dpix, float* grad_scratch, float* dL_dmeans3D, float* dL_dmeans2D,
+                 const int32_t* radii, void* geom, const void* binning, int64_t binning_capacity, const void* img,
+                 int64_t num_rendered, const float* dL_dpix, float* dL_dmeans3D, float* dL_dmeans2D,
                  float* dL_dsh, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
                  float* dL_dcov3D, void* stream)
 {
     return gsr_backward_ex(settings, P, M, means3D, shs, nullptr, colors_precomp, scales, rotations, cov3D_precomp, radii, geom, binning,
-                           binning_capacity, img, num_rendered, dL_dpix, grad_scratch, dL_dmeans3D, dL_dmeans2D, dL_dsh, nullptr,
+                           binning_capacity, img, num_rendered, dL_dpix, dL_dmeans3D, dL_dmeans2D, dL_dsh, nullptr,
                            dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, stream);
 }
 

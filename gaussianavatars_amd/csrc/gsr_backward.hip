@@ -225,11 +225,16 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
     float* gsh = a.dL_dsh ? (sh_staged ? sh_lds + (int)threadIdx.x * sh_row_stride(M) : a.dL_dsh + (size_t)3 * M * i) : nullptr;
 
     if (vis) {
-        const float* ac = a.acc + (size_t)GSR_ACC_STRIDE * i;
-        gcol[0] = ac[0]; gcol[1] = ac[1]; gcol[2] = ac[2];
-        g2x = ac[3]; g2y = ac[4];
-        const float gA = ac[5], gB = ac[6], gC = ac[7];
-        gop = ac[8];
+        float4* ac4 = (float4*)(a.acc + (size_t)GSR_ACC_STRIDE * i);
+        const float4 q0 = ac4[0], q1 = ac4[1], q2 = ac4[2];
+        {   // leave the accumulators zeroed: the state is ready for another backward
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            ac4[0] = z; ac4[1] = z; ac4[2] = z;
+        }
+        gcol[0] = q0.x; gcol[1] = q0.y; gcol[2] = q0.z;
+        g2x = q0.w; g2y = q1.x;
+        const float gA = q1.y, gB = q1.z, gC = q1.w;
+        gop = q2.x;
         const float* vm = s.viewmatrix;
         const float* proj = s.projmatrix;
         const int W = s.W, H = s.H;

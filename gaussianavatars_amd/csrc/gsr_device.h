@@ -258,6 +258,9 @@ struct PreprocessArgs {
     ushort4* __restrict__ rect;
     uint32_t* __restrict__ tiles_touched;
     uint8_t* __restrict__ clamped;
+    float4* __restrict__ acc;             // [P][3] backward accumulators, zeroed here for visible splats
+    uint32_t* __restrict__ tile_count;    // [tiles] zeroed here (the binning histogram of this frame)
+    int tiles;
 };
 
 struct PreBwdArgs {
@@ -270,7 +273,7 @@ struct PreBwdArgs {
     const float* __restrict__ cov3D;      // forward's (P,6)
     const int32_t* __restrict__ radii;
     const uint8_t* __restrict__ clamped;
-    const float* __restrict__ acc;        // [P][12]: dcolor(3) dmean2D(2) dconic(3) dopacity(1)
+    float* __restrict__ acc;              // [P][12]: dcolor(3) dmean2D(2) dconic(3) dopacity(1); re-zeroed after use
     int use_precomp_cov, use_precomp_color;
     float* __restrict__ dL_dmeans3D;
     float* __restrict__ dL_dmeans2D;      // (P,3)

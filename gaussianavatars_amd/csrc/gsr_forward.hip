@@ -30,6 +30,8 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int W = s.W, H = s.H;
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
+    // this frame's tile histogram starts at zero (k_count runs after this kernel)
+    for (int t = i; t < a.tiles; t += (int)(gridDim.x * blockDim.x)) a.tile_count[t] = 0u;
 
     bool visible = false;
     float depth = 0.f, px = 0.f, py = 0.f;
@@ -208,6 +210,10 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         a.rect[i] = make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy);
         a.tiles_touched[i] = n;
         a.clamped[i] = (uint8_t)clampbits;
+        if (visible) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            a.acc[3 * i + 0] = z; a.acc[3 * i + 1] = z; a.acc[3 * i + 2] = z;
+        }
     }
 }
 

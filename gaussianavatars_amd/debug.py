@@ -33,6 +33,9 @@ def forward_state(rs: GaussianRasterizationSettings, means3D, shs, colors_precom
         def mark_non_differentiable(self, *t):
             pass
 
+        def set_materialize_grads(self, flag):
+            pass
+
     ctx = _Ctx()
     with torch.no_grad():
         color, radii = _RasterizeGaussians.forward(ctx, *args, rs)

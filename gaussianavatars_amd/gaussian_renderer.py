@@ -38,6 +38,23 @@ def eval_sh(deg: int, sh: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
     return res
 
 
+_ZERO_POINTS: dict = {}
+
+
+def _screenspace_leaf(xyz: torch.Tensor) -> torch.Tensor:
+    """The dummy (P,3) tensor whose .grad receives dL/d(screen-space mean) (reference :27-31).  The reference builds
+    `zeros_like(xyz) + 0` and calls retain_grad() every frame (a fill, an add and a gradient copy); the rasterizer never
+    reads the values, so every frame gets a fresh LEAF over one cached block of zeros: autograd adopts the rasterizer's
+    gradient buffer as its .grad without a copy."""
+    key = (xyz.device, tuple(xyz.shape), xyz.dtype)
+    z = _ZERO_POINTS.get(key)
+    if z is None:
+        if len(_ZERO_POINTS) > 8:
+            _ZERO_POINTS.clear()
+        z = _ZERO_POINTS[key] = torch.zeros(xyz.shape, dtype=xyz.dtype, device=xyz.device)
+    return z.detach().requires_grad_(True)
+
+
 def _dev(t, device):
     return t if isinstance(t, torch.Tensor) and t.device == device else torch.as_tensor(t, device=device)
 
@@ -45,12 +62,7 @@ def _dev(t, device):
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
     xyz = pc.get_xyz
     device = xyz.device
-    # dummy leaf that receives dL/d(screen-space mean) (reference :27-31)
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    screenspace_points = _screenspace_leaf(xyz)
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
     raster_settings = GaussianRasterizationSettings(

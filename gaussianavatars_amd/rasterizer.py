@@ -82,6 +82,7 @@ def _make_settings(rs: GaussianRasterizationSettings, keep: list) -> _lib.GsrSet
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, sh_rest=None):
+        ctx.set_materialize_grads(False)   # no zeros tensor for the (integer, non-differentiable) radii output
         lib = _lib.gsr()
         dev = means3D.device
         keep: list = []
@@ -154,6 +155,8 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
+        if grad_out_color is None:
+            return (None,) * 10
         lib = _lib.gsr()
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img, sh_rest = ctx.saved_tensors
         rs = ctx.raster_settings
@@ -163,7 +166,6 @@ class _RasterizeGaussians(torch.autograd.Function):
         P, M = means3D.shape[0], ctx.M
         f32 = dict(dtype=torch.float32, device=dev)
         grad_out_color = _f32c(grad_out_color, "grad_out_color")
-        scratch = torch.empty((P, 12), **f32)
         g_means3D = torch.empty((P, 3), **f32)
         g_means2D = torch.empty((P, 3), **f32)
         g_colors = torch.empty((P, 3), **f32)
@@ -178,7 +180,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(dev):
             rc = lib.gsr_backward_ex(C.byref(s), P, M, _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors_precomp), _ptr(scales),
                                   _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(radii), _ptr(geom), _ptr(binning),
-                                  ctx.capacity, _ptr(img), ctx.num_rendered, _ptr(grad_out_color), _ptr(scratch),
+                                  ctx.capacity, _ptr(img), ctx.num_rendered, _ptr(grad_out_color),
                                   _ptr(g_means3D), _ptr(g_means2D), _ptr(g_sh), _ptr(g_sh_rest), _ptr(g_colors), _ptr(g_opacity),
                                   _ptr(g_scales), _ptr(g_rot), _ptr(g_cov3D), stream)
         if rc != _lib.GSR_OK:

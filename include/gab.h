@@ -61,7 +61,8 @@ int gab_flame_forward(const GabRig* rig, const float* shape, const float* expr, 
                       float* verts /*(V,3)*/, float* v_shaped /*(V,3)*/, float* ws /*GAB_FLAME_WS_FLOATS*/, void* stream);
 
 /* d_shape / d_static_offset / dL_dv_shaped may be NULL.  scratch: (V,3) floats.  Every non-NULL output
- * is fully written. */
+ * is fully written.  `ws` must be the workspace gab_flame_forward wrote for this frame: it carries the backward's
+ * accumulators, zeroed by the forward and zeroed again by this call (so the call may be repeated; no memset). */
 int gab_flame_backward(const GabRig* rig, const float* shape, const float* expr, const float* rotation,
                        const float* neck, const float* jaw, const float* eyes, const float* translation,
                        const float* static_offset, const float* v_shaped, float* ws,

@@ -69,6 +69,10 @@ typedef struct GsrGeomLayout {
     size_t rect;           /* uint16 [4P]  tile rect min.x min.y max.x max.y */
     size_t tiles_touched;  /* uint32 [P]                                   */
     size_t clamped;        /* uint8  [P]   bit c set <=> channel c clamped  */
+    size_t acc;            /* float  [12P] backward accumulators of the screen-space gradients (dcolor 3, dmean2D 2,
+                              dconic 3, dopacity 1, pad 3).  The forward zeroes the entries of visible splats and the
+                              backward zeroes them again after consuming them, so a state is always ready for a
+                              backward and no per-frame memset exists.                                 */
     size_t total;
 } GsrGeomLayout;
 
@@ -128,7 +132,7 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M,
  * buffers (with the binning capacity they were laid out for) and num_rendered, plus dL_dpix (3,H,W).  Every gradient buffer is fully written
  * (zeros for culled splats); pass NULL for dL_dsh when colours were precomputed, for
  * dL_dscales/dL_drotations when cov3D was precomputed.
- *   grad_scratch: (P,12) floats of scratch for the per-splat screen-space accumulators
+ *   geom is read AND written: the per-splat accumulators live in it (GsrGeomLayout.acc) and are left zeroed.
  *   dL_dmeans2D (P,3): [:, :2] NDC-scaled screen-space gradient, [:, 2] = 0
  *   dL_dcolors  (P,3): gradient w.r.t. the per-splat RGB (the colors_precomp gradient)
  *   dL_dcov3D   (P,6): gradient w.r.t. the packed 3D covariance
@@ -136,8 +140,8 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M,
 int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M,
                  const float* means3D, const float* shs, const float* colors_precomp,
                  const float* scales, const float* rotations, const float* cov3D_precomp,
-                 const int32_t* radii, const void* geom, const void* binning, int64_t binning_capacity,
-                 const void* img, int64_t num_rendered, const float* dL_dpix, float* grad_scratch,
+                 const int32_t* radii, void* geom, const void* binning, int64_t binning_capacity,
+                 const void* img, int64_t num_rendered, const float* dL_dpix,
                  float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dsh, float* dL_dcolors,
                  float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                  void* stream);
@@ -158,8 +162,8 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M,
 int gsr_backward_ex(const GsrSettings* settings, int32_t P, int32_t M,
                     const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp,
                     const float* scales, const float* rotations, const float* cov3D_precomp,
-                    const int32_t* radii, const void* geom, const void* binning, int64_t binning_capacity,
-                    const void* img, int64_t num_rendered, const float* dL_dpix, float* grad_scratch,
+                    const int32_t* radii, void* geom, const void* binning, int64_t binning_capacity,
+                    const void* img, int64_t num_rendered, const float* dL_dpix,
                     float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dsh, float* dL_dsh_rest, float* dL_dcolors,
                     float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                     void* stream);

@@ -128,3 +128,26 @@ def test_config5_2m_stress_forward(oracle):
     assert st.num_rendered == hs["num_rendered"]
     np.testing.assert_array_equal(_np(hs["point_list"]).astype(np.uint32), st.point_list)
     assert np.array_equal(_np(hs["color"]).view(np.uint32), st.color.view(np.uint32))
+
+
+def test_second_backward_through_the_same_graph():
+    """retain_graph: the gradient accumulators live in the saved state (GsrGeomLayout.acc, the FLAME workspace) and each
+    backward leaves them zeroed, so a second backward through the same forward reproduces the first one's gradients."""
+    import bench
+    from gaussianavatars_amd.gaussian_renderer import l1_loss, render
+
+    dev = _dev()
+    g, cam = bench.build_scene(dev, 30_000, 3, 320, 256, 2, "fused", True)
+    bg = torch.ones(3, device=dev)
+    target = torch.full((3, cam.image_height, cam.image_width), 0.3, device=dev)
+    g.select_mesh_by_timestep(1)
+    pkg = render(cam, g, bench.Pipe, bg)
+    loss = l1_loss(pkg["render"], target)
+    params = [g._xyz, g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity, g.flame_param["expr"],
+              g.flame_param["jaw_pose"], g.flame_param["rotation"], g.flame_param["translation"]]
+    first = torch.autograd.grad(loss, params, retain_graph=True)
+    second = torch.autograd.grad(loss, params)
+    for a, b, p in zip(first, second, params):
+        scale = float(a.abs().max()) + 1e-30
+        assert scale > 1e-12
+        assert float((a - b).abs().max()) / scale < 2e-4   # float atomics reorder the sums between the two runs

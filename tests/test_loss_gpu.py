@@ -37,6 +37,7 @@ def test_matches_reference_pins(case):
     (g_l1,) = torch.autograd.grad(l1, ta)
     ss = loss.ssim(ta, tb)
     (g_ss,) = torch.autograd.grad(ss, ta)
+    l1, ss = l1.detach(), ss.detach()
     assert abs(float(l1) - float(PINS[f"{case}_l1"])) < 2e-6
     assert abs(float(ss) - float(PINS[f"{case}_ssim"])) < 2e-5
     np.testing.assert_allclose(g_l1.cpu().numpy(), PINS[f"{case}_g_l1"], rtol=1e-6, atol=1e-10)
@@ -45,7 +46,7 @@ def test_matches_reference_pins(case):
     # the fused pair equals the two separate calls, values and combined gradient
     ta2 = _t(a, dev, True)
     f1, fs = loss.l1_ssim(ta2, tb)
-    assert float(f1) == float(l1) and float(fs) == float(ss)
+    assert float(f1.detach()) == float(l1) and float(fs.detach()) == float(ss)
     (0.8 * f1 + 0.2 * (1.0 - fs)).backward()
     comb = 0.8 * g_l1 - 0.2 * g_ss
     assert float((ta2.grad - comb).abs().max()) < 1e-6 * float(comb.abs().max()) + 1e-12
