@@ -185,7 +185,7 @@ def main():
     def run(n, offset):
         """n steps.  The scalar all-reduce of step k is issued asynchronously (RCCL runs it on its own stream)
         and only waited for after step k+1 has been enqueued, so its latency never idles the compute stream."""
-        loss_sum = torch.zeros((), device=device)
+        losses = []   # per-step device scalars; summed once at the end of the run (still inside the timed region)
         pending = None
         for i in range(n):
             t = my_frames[(offset + i) % len(my_frames)]
@@ -196,16 +196,16 @@ def main():
                 work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)  # the one collective of the path: a scalar
                 if pending is not None:
                     pending[0].wait()
-                    loss_sum += pending[1][0]
+                    losses.append(pending[1][0])
                 pending = (work, buf)
             else:
-                loss_sum += l
+                losses.append(l)
             if train:
                 zero_grads(g)
         if pending is not None:
             pending[0].wait()
-            loss_sum += pending[1][0]
-        return loss_sum
+            losses.append(pending[1][0])
+        return torch.stack(losses).sum() if losses else torch.zeros((), device=device)
 
     def fence():
         if dist is not None:
@@ -214,10 +214,12 @@ def main():
 
     run(args.warmup, 0)
     fence()
+    _lib.gsr_wait_stats()   # reset
     t0 = time.perf_counter()
     run(args.steps, args.warmup)
     fence()
     elapsed = time.perf_counter() - t0
+    wait_ms, waits = _lib.gsr_wait_stats()
     if dist is not None:
         te = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -305,6 +307,8 @@ def main():
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
+            # the frame's single host wait (for the instance count): ~0 would mean the host paces the loop, not the GPU
+            "host": {"scan_wait_ms_per_step": round(wait_ms / max(waits, 1), 4)},
         }
         print(json.dumps(out))
     if dist is not None:

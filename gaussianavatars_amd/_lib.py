@@ -71,6 +71,7 @@ GSR_SYMBOLS = {
     "gsr_profile_enable": (C.c_int, [C.c_int]),
     "gsr_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "gsr_kernel_name": (C.c_char_p, [C.c_int]),
+    "gsr_wait_stats": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 GSR_NUM_KERNELS = 8
 
@@ -87,6 +88,13 @@ def gsr_profile_read() -> dict:
     if rc != GSR_OK:
         raise RuntimeError(f"gsr_profile_read failed: {gsr().gsr_last_error().decode()}")
     return {gsr().gsr_kernel_name(i).decode(): (ms[i], n[i]) for i in range(GSR_NUM_KERNELS)}
+
+def gsr_wait_stats():
+    """(total host wait in ms, number of waits) since the last call -- see include/gsr.h."""
+    ms, n = C.c_double(), C.c_int64()
+    gsr().gsr_wait_stats(C.byref(ms), C.byref(n))
+    return ms.value, n.value
+
 
 _gsr = None
 
@@ -130,8 +138,8 @@ GAB_SYMBOLS = {
     "gab_last_error": (C.c_char_p, []),
     "gab_flame_forward": (C.c_int, [C.POINTER(GabRig)] + [_P] * 8 + [_P, _P, _P, _P]),
     "gab_flame_backward": (C.c_int, [C.POINTER(GabRig)] + [_P] * 8 + [_P, _P, _P, _P] + [_P] * 8 + [_P, _P]),
-    "gab_face_frames_forward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P, _P]),
-    "gab_face_frames_backward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "gab_face_frames_forward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "gab_face_frames_backward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "gab_bind_forward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gab_bind_backward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gab_bind_backward_csr": (C.c_int, [C.c_int32, C.c_int32] + [_P] * 16),

@@ -225,9 +225,11 @@ class _FaceFrames(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         center, R = torch.empty((F, 3), **f32), torch.empty((F, 3, 3), **f32)
         scale, quat = torch.empty((F, 1), **f32), torch.empty((F, 4), **f32)
+        # the backward scatters into a zeroed (V,3) buffer: let the forward kernel zero it on the side (no memset launch later)
+        ctx.d_verts = torch.empty((V, 3), **f32) if ctx.needs_input_grad[0] else None
         with torch.cuda.device(dev):
-            _chk(lib.gab_face_frames_forward(V, F, _p(v), _p(fi), is64, _p(center), _p(R), _p(scale), _p(quat), _stream(dev)),
-                 "gab_face_frames_forward")
+            _chk(lib.gab_face_frames_forward(V, F, _p(v), _p(fi), is64, _p(center), _p(R), _p(scale), _p(quat), _p(ctx.d_verts),
+                                             _stream(dev)), "gab_face_frames_forward")
         ctx.save_for_backward(v, fi)
         ctx.is64 = is64
         return center, R, scale, quat
@@ -238,11 +240,14 @@ class _FaceFrames(torch.autograd.Function):
         v, fi = ctx.saved_tensors
         dev = v.device
         V, F = v.shape[0], fi.shape[0]
-        d_verts = torch.empty((V, 3), dtype=torch.float32, device=dev)
+        d_verts, ctx.d_verts = ctx.d_verts, None    # the pre-zeroed buffer serves one backward; a repeat allocates + memsets
+        prepared = d_verts is not None
+        if not prepared:
+            d_verts = torch.empty((V, 3), dtype=torch.float32, device=dev)
         gs = [None if g is None else _f32(g) for g in (g_center, g_R, g_scale, g_quat)]
         with torch.cuda.device(dev):
             _chk(lib.gab_face_frames_backward(V, F, _p(v), _p(fi), ctx.is64, _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(gs[3]), _p(d_verts),
-                                              _stream(dev)), "gab_face_frames_backward")
+                                              1 if prepared else 0, _stream(dev)), "gab_face_frames_backward")
         return d_verts, None
 
 

@@ -184,19 +184,24 @@ __device__ __forceinline__ void chain_forward(const int* parents, const float* R
 // F2  joints J = J_regressor . v_shaped (15 sums over V), Rodrigues, kinematic chain -> ws
 // ---------------------------------------------------------------------------------------------
 template <bool FLAME_TREE>
-__global__ __launch_bounds__(256) void k_joints_chain(Rig rig, const float* __restrict__ v_shaped, const float* __restrict__ rotation,
-                                                       const float* __restrict__ neck, const float* __restrict__ jaw,
-                                                       const float* __restrict__ eyes, float* __restrict__ ws)
+__global__ __launch_bounds__(1024) void k_joints_chain(Rig rig, const float* __restrict__ v_shaped, const float* __restrict__ rotation,
+                                                        const float* __restrict__ neck, const float* __restrict__ jaw,
+                                                        const float* __restrict__ eyes, float* __restrict__ ws)
 {
-    __shared__ float red[4][16];
+    // One workgroup (the 15 sums feed a 5-joint serial chain), but a wide one: 1024 lanes keep the whole regression in
+    // flight at once (5-6 vertices per lane), Rodrigues runs on five lanes in parallel, only the chain itself is serial,
+    // and the 256-float forward half of the workspace is assembled in LDS and stored with one coalesced pass.
+    __shared__ float red[16][16];
+    __shared__ float out[WS_DA];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // the backward's accumulators live in the same workspace: hand them over zeroed (k_chain_bwd zeroes them again
     // after consuming them), so no memset precedes the backward's atomics
-    for (int k = WS_DA + tid; k < GAB_FLAME_WS_FLOATS; k += 256) ws[k] = 0.f;
+    if (tid < GAB_FLAME_WS_FLOATS - WS_DA) ws[WS_DA + tid] = 0.f;
+    if (tid < WS_DA) out[tid] = 0.f;
     float acc[15];
 #pragma unroll
     for (int k = 0; k < 15; ++k) acc[k] = 0.f;
-    for (int v = tid; v < rig.V; v += 256) {
+    for (int v = tid; v < rig.V; v += 1024) {
         const float x = v_shaped[3 * v], y = v_shaped[3 * v + 1], z = v_shaped[3 * v + 2];
 #pragma unroll
         for (int j = 0; j < GAB_NUM_JOINTS; ++j) {
@@ -212,33 +217,43 @@ __global__ __launch_bounds__(256) void k_joints_chain(Rig rig, const float* __re
         if (lane == 63) red[wid][k] = s;
     }
     __syncthreads();
+    if (tid < 15) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) sum += red[w][tid];
+        out[WS_J + tid] = sum;
+    } else if (tid >= 64 && tid < 64 + GAB_NUM_JOINTS) {
+        const int j = tid - 64;
+        const float* pj = j == 0 ? rotation : j == 1 ? neck : j == 2 ? jaw : eyes + 3 * (j - 3);
+        const float pose[3] = {pj[0], pj[1], pj[2]};
+        float R[9];
+        rodrigues(pose, R);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            out[WS_R + 9 * j + k] = R[k];
+            if (j >= 1) out[WS_PF + 9 * (j - 1) + k] = R[k] - ((k % 4) == 0 ? 1.f : 0.f);
+        }
+    }
+    __syncthreads();
     if (tid == 0) {
         float J[15], R[45], Rg[45], tg[15];
 #pragma unroll
-        for (int k = 0; k < 15; ++k) J[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
-        const float pose[15] = {rotation[0], rotation[1], rotation[2], neck[0], neck[1], neck[2], jaw[0], jaw[1], jaw[2],
-                                eyes[0], eyes[1], eyes[2], eyes[3], eyes[4], eyes[5]};
+        for (int k = 0; k < 15; ++k) J[k] = out[WS_J + k];
 #pragma unroll
-        for (int j = 0; j < GAB_NUM_JOINTS; ++j) rodrigues(pose + 3 * j, R + 9 * j);
+        for (int k = 0; k < 45; ++k) R[k] = out[WS_R + k];
         chain_forward<FLAME_TREE>(rig.parents, R, J, Rg, tg);
-#pragma unroll
-        for (int k = 0; k < 15; ++k) ws[WS_J + k] = J[k];
-#pragma unroll
-        for (int k = 0; k < 45; ++k) ws[WS_R + k] = R[k];
-#pragma unroll
-        for (int j = 1; j < GAB_NUM_JOINTS; ++j)
-#pragma unroll
-            for (int k = 0; k < 9; ++k) ws[WS_PF + 9 * (j - 1) + k] = R[9 * j + k] - ((k % 4) == 0 ? 1.f : 0.f);
 #pragma unroll
         for (int j = 0; j < GAB_NUM_JOINTS; ++j)
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) ws[WS_A + 12 * j + 4 * r + c] = Rg[9 * j + 3 * r + c];
-                ws[WS_A + 12 * j + 4 * r + 3] = tg[3 * j + r] - (Rg[9 * j + 3 * r] * J[3 * j] + Rg[9 * j + 3 * r + 1] * J[3 * j + 1] +
-                                                                 Rg[9 * j + 3 * r + 2] * J[3 * j + 2]);
+                for (int c = 0; c < 3; ++c) out[WS_A + 12 * j + 4 * r + c] = Rg[9 * j + 3 * r + c];
+                out[WS_A + 12 * j + 4 * r + 3] = tg[3 * j + r] - (Rg[9 * j + 3 * r] * J[3 * j] + Rg[9 * j + 3 * r + 1] * J[3 * j + 1] +
+                                                                  Rg[9 * j + 3 * r + 2] * J[3 * j + 2]);
             }
     }
+    __syncthreads();
+    if (tid < WS_DA) ws[tid] = out[tid];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -344,7 +359,8 @@ __global__ __launch_bounds__(64) void k_chain_bwd(Rig rig, float* __restrict__ w
     for (int kk = threadIdx.x; kk < rig.n_expr; kk += 64) d_expr[kk] = 0.f;
     if (d_shape)
         for (int kk = threadIdx.x; kk < rig.n_shape; kk += 64) d_shape[kk] = 0.f;
-    if (threadIdx.x != 0) return;
+    __shared__ float sdR[45];
+    if (threadIdx.x == 0) {
     float J[15], R[45], Rg[45], tg[15];
 #pragma unroll
     for (int k = 0; k < 15; ++k) J[k] = sw[WS_J + k];
@@ -410,22 +426,26 @@ __global__ __launch_bounds__(64) void k_chain_bwd(Rig rig, float* __restrict__ w
     for (int j = 1; j < GAB_NUM_JOINTS; ++j)
 #pragma unroll
         for (int k = 0; k < 9; ++k) dR[9 * j + k] += sw[WS_DPF + 9 * (j - 1) + k];
-    const float pose[15] = {rotation[0], rotation[1], rotation[2], neck[0], neck[1], neck[2], jaw[0], jaw[1], jaw[2],
-                            eyes[0], eyes[1], eyes[2], eyes[3], eyes[4], eyes[5]};
-    float dpose[15];
 #pragma unroll
-    for (int j = 0; j < GAB_NUM_JOINTS; ++j) rodrigues_bwd(pose + 3 * j, dR + 9 * j, dpose + 3 * j);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        d_rotation[k] = dpose[k];
-        d_neck[k] = dpose[3 + k];
-        d_jaw[k] = dpose[6 + k];
-        d_translation[k] = sw[WS_DT + k];
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) d_eyes[k] = dpose[9 + k];
+    for (int k = 0; k < 45; ++k) sdR[k] = dR[k];
 #pragma unroll
     for (int k = 0; k < 15; ++k) ws[WS_DJ + k] = dJ[k];
+    }
+    __syncthreads();
+    // Rodrigues backward: one lane per joint
+    const int j = threadIdx.x;
+    if (j < GAB_NUM_JOINTS) {
+        const float* pj = j == 0 ? rotation : j == 1 ? neck : j == 2 ? jaw : eyes + 3 * (j - 3);
+        float* dj = j == 0 ? d_rotation : j == 1 ? d_neck : j == 2 ? d_jaw : d_eyes + 3 * (j - 3);
+        const float pose[3] = {pj[0], pj[1], pj[2]};
+        float dRj[9], dpose[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dRj[k] = sdR[9 * j + k];
+        rodrigues_bwd(pose, dRj, dpose);
+        dj[0] = dpose[0]; dj[1] = dpose[1]; dj[2] = dpose[2];
+    } else if (j >= 8 && j < 11) {
+        d_translation[j - 8] = sw[WS_DT + j - 8];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -532,9 +552,11 @@ __device__ __forceinline__ int quat_raw(const float* R, float* q)
 
 __global__ __launch_bounds__(256) void k_face_frames(int F, const float* __restrict__ verts, const void* __restrict__ faces, int is64,
                                                       float* __restrict__ center, float* __restrict__ Rm, float* __restrict__ scaling,
-                                                      float* __restrict__ quat)
+                                                      float* __restrict__ quat, float* __restrict__ zero_fill, int zero_count)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero_fill)   // the backward's accumulation target, prepared here so that no memset precedes its atomics
+        for (int k = f; k < zero_count; k += (int)(gridDim.x * blockDim.x)) zero_fill[k] = 0.f;
     if (f >= F) return;
     const Vec3 v0 = ld3(verts, index_at(faces, is64, 3ll * f)), v1 = ld3(verts, index_at(faces, is64, 3ll * f + 1)),
                v2 = ld3(verts, index_at(faces, is64, 3ll * f + 2));
@@ -718,8 +740,9 @@ __global__ __launch_bounds__(256) void k_bind_bwd(int N, const float* __restrict
 }
 
 // Atomic-free variant: splats are visited face by face through a CSR (order, face_begin) built once per
-// binding change.  8 lanes share a face (lane k takes splats k, k+8, ...), the 17 per-face sums are reduced
-// over the 8 lanes on the DPP network and written once -- deterministic, no memset, no L2 atomics.
+// binding change.  16 lanes share a face (lane k takes splats k, k+16, ...; ~10 splats per face, so nearly every
+// splat has its own lane and all gathers are in flight at once), the 17 per-face sums are reduced
+// over the 16 lanes on the DPP network and written once -- deterministic, no memset, no L2 atomics.
 __global__ __launch_bounds__(256) void k_bind_bwd_csr(int F, const float* __restrict__ xyz, const float* __restrict__ log_scaling,
                                                        const float* __restrict__ rotation, const float* __restrict__ fR,
                                                        const float* __restrict__ fs, const float* __restrict__ fq,
@@ -730,7 +753,7 @@ __global__ __launch_bounds__(256) void k_bind_bwd_csr(int F, const float* __rest
                                                        float* __restrict__ d_face)
 {
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int f = gtid >> 3, sub = gtid & 7;
+    const int f = gtid >> 4, sub = gtid & 15;
     const bool okf = f < F;
     float acc[17];
 #pragma unroll
@@ -744,7 +767,7 @@ __global__ __launch_bounds__(256) void k_bind_bwd_csr(int F, const float* __rest
         const float na = qnorm_clamped(qf);
         const float4 a = make_float4(qf.x / na, qf.y / na, qf.z / na, qf.w / na);
         const int b0 = face_begin[f], b1 = face_begin[f + 1];
-        for (int j = b0 + sub; j < b1; j += 8) {
+        for (int j = b0 + sub; j < b1; j += 16) {
             const int i = order[j];
             const float x[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
             const float gx[3] = {g_xyz ? g_xyz[3 * i] : 0.f, g_xyz ? g_xyz[3 * i + 1] : 0.f, g_xyz ? g_xyz[3 * i + 2] : 0.f};
@@ -780,21 +803,22 @@ __global__ __launch_bounds__(256) void k_bind_bwd_csr(int F, const float* __rest
             acc[16] += (da.w - a.w * ada) / na;
         }
     }
-    // 8-lane sums (quad xor 1, xor 2, half-row mirror); every lane of the group ends with the total
+    // 16-lane sums (quad xor 1, xor 2, half-row mirror, row mirror); every lane of the group ends with the total
 #pragma unroll
     for (int k = 0; k < 17; ++k) {
         float v = acc[k];
         v += dpp_f<0xB1, 0xf>(v);
         v += dpp_f<0x4E, 0xf>(v);
         v += dpp_f<0x141, 0xf>(v);
+        v += dpp_f<0x140, 0xf>(v);
         acc[k] = v;
     }
     if (okf) {
-        // the 8 lanes of the group share the 17 stores; d_face is four contiguous blocks
+        // the 16 lanes of the group share the 17 stores; d_face is four contiguous blocks
         // center (F,3) | orien_mat (F,9) | scaling (F,1) | orien_quat (F,4)
 #pragma unroll
         for (int k = 0; k < 17; ++k) {
-            if ((k & 7) != sub) continue;
+            if ((k & 15) != sub) continue;
             float* dst = k < 3 ? d_face + 3 * f + k
                        : k < 12 ? d_face + (size_t)3 * F + 9 * f + (k - 3)
                        : k < 13 ? d_face + (size_t)12 * F + f
@@ -875,9 +899,9 @@ int gab_flame_forward(const GabRig* rig_, const float* shape, const float* expr,
     LAUNCH_CHECK("k_blend");
     const bool flame_tree = rig.parents[1] == 0 && rig.parents[2] == 1 && rig.parents[3] == 1 && rig.parents[4] == 1;
     if (flame_tree)
-        hipLaunchKernelGGL(gab::k_joints_chain<true>, dim3(1), dim3(256), 0, st, rig, (const float*)v_shaped, rotation, neck, jaw, eyes, ws);
+        hipLaunchKernelGGL(gab::k_joints_chain<true>, dim3(1), dim3(1024), 0, st, rig, (const float*)v_shaped, rotation, neck, jaw, eyes, ws);
     else
-        hipLaunchKernelGGL(gab::k_joints_chain<false>, dim3(1), dim3(256), 0, st, rig, (const float*)v_shaped, rotation, neck, jaw, eyes, ws);
+        hipLaunchKernelGGL(gab::k_joints_chain<false>, dim3(1), dim3(1024), 0, st, rig, (const float*)v_shaped, rotation, neck, jaw, eyes, ws);
     LAUNCH_CHECK("k_joints_chain");
     hipLaunchKernelGGL(gab::k_skin, dim3((rig.V + 255) / 256), dim3(256), 0, st, rig, (const float*)ws, (const float*)v_shaped, translation, verts);
     LAUNCH_CHECK("k_skin");
@@ -913,24 +937,28 @@ int gab_flame_backward(const GabRig* rig_, const float* shape, const float* expr
 }
 
 int gab_face_frames_forward(int32_t V, int32_t F, const float* verts, const void* faces, int32_t is64, float* center, float* orien_mat,
-                            float* scaling, float* orien_quat, void* stream_)
+                            float* scaling, float* orien_quat, float* d_verts_zeroed, void* stream_)
 {
     if (V <= 0 || F < 0) return fail(GAB_E_ARG, "bad sizes");
-    if (F == 0) return GAB_OK;
+    if (F == 0) {
+        if (d_verts_zeroed) HIP_TRY(hipMemsetAsync(d_verts_zeroed, 0, (size_t)V * 3 * sizeof(float), (hipStream_t)stream_));
+        return GAB_OK;
+    }
     if (!verts || !faces || !center || !orien_mat || !scaling || !orien_quat) return fail(GAB_E_ARG, "gab_face_frames_forward: NULL buffer");
     hipLaunchKernelGGL(gab::k_face_frames, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream_, F, verts, faces, is64, center, orien_mat,
-                       scaling, orien_quat);
+                       scaling, orien_quat, d_verts_zeroed, 3 * V);
     LAUNCH_CHECK("k_face_frames");
     return GAB_OK;
 }
 
 int gab_face_frames_backward(int32_t V, int32_t F, const float* verts, const void* faces, int32_t is64, const float* d_center,
-                             const float* d_orien_mat, const float* d_scaling, const float* d_orien_quat, float* d_verts, void* stream_)
+                             const float* d_orien_mat, const float* d_scaling, const float* d_orien_quat, float* d_verts,
+                             int32_t d_verts_is_zero, void* stream_)
 {
     if (V <= 0 || F < 0) return fail(GAB_E_ARG, "bad sizes");
     if (!d_verts) return fail(GAB_E_ARG, "d_verts is NULL");
     hipStream_t st = (hipStream_t)stream_;
-    HIP_TRY(hipMemsetAsync(d_verts, 0, (size_t)V * 3 * sizeof(float), st));
+    if (!d_verts_is_zero) HIP_TRY(hipMemsetAsync(d_verts, 0, (size_t)V * 3 * sizeof(float), st));
     if (F == 0) return GAB_OK;
     if (!verts || !faces) return fail(GAB_E_ARG, "gab_face_frames_backward: NULL buffer");
     hipLaunchKernelGGL(gab::k_face_frames_bwd, dim3((F + 255) / 256), dim3(256), 0, st, F, verts, faces, is64, d_center, d_orien_mat, d_scaling,
@@ -984,7 +1012,7 @@ int gab_bind_backward_csr(int32_t N, int32_t F, const float* xyz, const float* l
     if (N > 0 && (!xyz || !log_scaling || !rotation || !face_orien_mat || !face_scaling || !face_orien_quat || !d_xyz || !d_log_scaling ||
                   !d_rotation))
         return fail(GAB_E_ARG, "gab_bind_backward_csr: NULL buffer");
-    const long long threads = 8ll * F;
+    const long long threads = 16ll * F;
     hipLaunchKernelGGL(gab::k_bind_bwd_csr, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, F, xyz, log_scaling,
                        rotation, face_orien_mat, face_scaling, face_orien_quat, d_out_xyz, d_out_scaling, d_out_rotation, order, face_begin,
                        d_xyz, d_log_scaling, d_rotation, d_face);

@@ -65,6 +65,7 @@ struct Mailbox {
     }
 };
 Mailbox g_mail;
+std::atomic<long long> g_wait_ns{0}, g_waits{0};
 
 // ---- optional per-kernel event timing -------------------------------------------------------
 struct Profiler {
@@ -339,6 +340,8 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
             }
         }
     }
+    g_wait_ns.fetch_add((long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+    g_waits.fetch_add(1);
     const int64_t I = (int64_t)(v & 0xFFFFFFFFFFull);
     *num_rendered_host = I;
     if (I > 0xFFFFFFFFll) return fail(GSR_E_ARG, "%lld (splat, tile) instances exceed the 32-bit offsets of the binning state", (long long)I);
@@ -448,6 +451,14 @@ int gsr_profile_read(double* total_ms, int64_t* launches)
         g_prof.pool.push_back(p.b);
     }
     g_prof.pending.clear();
+    return GSR_OK;
+}
+
+int gsr_wait_stats(double* total_wait_ms, int64_t* waits)
+{
+    if (!total_wait_ms || !waits) return fail(GSR_E_ARG, "gsr_wait_stats: NULL output");
+    *total_wait_ms = (double)g_wait_ns.exchange(0) * 1e-6;
+    *waits = (int64_t)g_waits.exchange(0);
     return GSR_OK;
 }
 

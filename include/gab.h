@@ -71,12 +71,16 @@ int gab_flame_backward(const GabRig* rig, const float* shape, const float* expr,
                        float* d_translation, float* d_static_offset, float* scratch, void* stream);
 
 /* ---- per-face frames ----------------------------------------------------------------------- */
+/* d_verts_zeroed: optional (V,3) buffer the forward zero-fills on the side, to be handed to the backward as its
+ * pre-zeroed accumulation target (saves the backward's memset, which costs as much as its kernel); NULL to skip. */
 int gab_face_frames_forward(int32_t V, int32_t F, const float* verts, const void* faces /*(F,3)*/, int32_t index_is_i64,
                             float* center /*(F,3)*/, float* orien_mat /*(F,3,3)*/, float* scaling /*(F,1)*/,
-                            float* orien_quat /*(F,4) WXYZ*/, void* stream);
+                            float* orien_quat /*(F,4) WXYZ*/, float* d_verts_zeroed, void* stream);
+/* d_verts (V,3) receives the gradient.  d_verts_is_zero != 0: the caller guarantees it is all-zero already (the buffer the
+ * forward prepared); otherwise it is zero-filled first. */
 int gab_face_frames_backward(int32_t V, int32_t F, const float* verts, const void* faces, int32_t index_is_i64,
                              const float* d_center, const float* d_orien_mat, const float* d_scaling, const float* d_orien_quat,
-                             float* d_verts /*(V,3), fully written*/, void* stream);
+                             float* d_verts, int32_t d_verts_is_zero, void* stream);
 
 /* ---- per-splat mesh-local -> world ---------------------------------------------------------- */
 int gab_bind_forward(int32_t N, int32_t F, const float* xyz, const float* log_scaling, const float* rotation,

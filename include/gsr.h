@@ -193,6 +193,11 @@ int gsr_profile_enable(int on);
 int gsr_profile_read(double* total_ms, int64_t* launches);
 const char* gsr_kernel_name(int id);
 
+/* Host-side diagnostic: time gsr_forward spent waiting for the device to post the instance count (the frame's only
+ * host wait) and the number of waits, accumulated since the previous call.  A wait near zero means the host, not the
+ * GPU, paces the frame loop. */
+int gsr_wait_stats(double* total_wait_ms, int64_t* waits);
+
 #ifdef __cplusplus
 }
 #endif
