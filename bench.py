@@ -241,7 +241,10 @@ def main():
 
     if rank == 0:
         N, HW = args.splats, args.width * args.height
-        I = info.get("num_rendered", 0)
+        I_binned = info.get("num_rendered", 0)
+        # the unit count of the algorithmic-bytes model is the reference's instance count (sum of tiles_touched); with
+        # tile culling on, fewer instances are actually binned (num_binned below)
+        I = info.get("rect_instances", I_binned)
         with torch.no_grad():
             vis = 1.0
         per_kernel = {k: dict(avg_us=1e3 * ms / max(n, 1), launches=n) for k, (ms, n) in kern.items() if n}
@@ -302,7 +305,8 @@ def main():
                              "cfg5": "BASELINE configs[4]: %d un-bound SH-3 splats, %dx%d (HxW), forward only (stress / roofline run)"}[
                                  args.workload] % (N, args.height, args.width),
                 "splats": N, "width": args.width, "height": args.height, "sh_degree": 3,
-                "num_rendered": I, "visible_fraction": round(vis, 4), "binding": args.binding,
+                "num_rendered": I, "num_binned": I_binned, "tile_culling": bool(info.get("tile_culling", False)),
+                "visible_fraction": round(vis, 4), "binding": args.binding,
                 "parallelism": f"frame-parallel x{n_gpus}, scalar loss all-reduce",
             },
             "roofline": roofline,

@@ -31,6 +31,7 @@ class GsrSettings(C.Structure):
         ("campos", C.c_void_p),
         ("prefiltered", C.c_int32),
         ("debug", C.c_int32),
+        ("tile_culling", C.c_int32),
     ]
 
 

@@ -224,9 +224,13 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     char* im = (char*)img;
     unsigned long long* total_dev = (unsigned long long*)b;
     uint32_t* tile_count = (uint32_t*)(b + bl.tile_count);
+    unsigned long long* rect_total = total_dev + 1;   // header word 1: sum of tiles_touched (the reference's num_rendered)
 
     gsr::Settings ds = to_dev_settings(settings);
-    if (P == 0) HIP_TRY(hipMemsetAsync(tile_count, 0, (size_t)tiles * 4, stream));   // otherwise k_preprocess zeroes it
+    if (P == 0) {   // otherwise k_preprocess zeroes both
+        HIP_TRY(hipMemsetAsync(tile_count, 0, (size_t)tiles * 4, stream));
+        HIP_TRY(hipMemsetAsync(rect_total, 0, 8, stream));
+    }
 
     gsr::PreprocessArgs pa;
     pa.P = P; pa.M = M;
@@ -241,6 +245,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     pa.clamped = (uint8_t*)(g + gl.clamped);
     pa.acc = (float4*)(g + gl.acc);
     pa.tile_count = tile_count;
+    pa.rect_total = rect_total;
     pa.tiles = tiles;
     const int pblocks = (P + 255) / 256;
     if (pblocks > 0) {
@@ -254,13 +259,16 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     // (grids beyond GSR_LDS_HIST_TILES tiles -- past ~3200x3200 px -- fall back to per-instance L2 atomics)
     const size_t hist_bytes = tiles > GSR_LDS_HIST_TILES ? 0 : (size_t)tiles * sizeof(uint32_t);
     if (hist_bytes > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
-        HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_count<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
     }
+    const bool cull = settings->tile_culling != 0;
     if (pblocks > 0) {
         TIMED(GSR_K_COUNT, stream);
-        hipLaunchKernelGGL(gsr::k_count, dim3(bin_blocks), dim3(256), hist_bytes, stream, P, gx, tiles, (const ushort4*)pa.rect,
-                           (const uint32_t*)pa.tiles_touched, tile_count);
+        hipLaunchKernelGGL(cull ? gsr::k_count<true> : gsr::k_count<false>, dim3(bin_blocks), dim3(256), hist_bytes, stream, P, gx, tiles,
+                           (const ushort4*)pa.rect, (const uint32_t*)pa.tiles_touched, (const float4*)pa.grec, tile_count, rect_total);
         KERNEL_CHECK("k_count", stream, dbg);
     }
 
@@ -290,9 +298,9 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     uint32_t* qcount = (uint32_t*)(b + bl.qcount);
     if (pblocks > 0) {
         TIMED(GSR_K_SCATTER, stream);
-        hipLaunchKernelGGL(gsr::k_scatter, dim3(bin_blocks), dim3(256), hist_bytes, stream, P, gx, tiles, (const float*)pa.depths,
-                           (const ushort4*)pa.rect, (const uint32_t*)pa.tiles_touched, (const uint32_t*)tile_start, tile_cursor, keys, cap,
-                           (const unsigned long long*)total_dev);
+        hipLaunchKernelGGL(cull ? gsr::k_scatter<true> : gsr::k_scatter<false>, dim3(bin_blocks), dim3(256), hist_bytes, stream, P, gx, tiles,
+                           (const float*)pa.depths, (const ushort4*)pa.rect, (const uint32_t*)pa.tiles_touched, (const float4*)pa.grec,
+                           (const uint32_t*)tile_start, tile_cursor, keys, cap, (const unsigned long long*)total_dev);
         KERNEL_CHECK("k_scatter", stream, dbg);
     }
     {

@@ -151,6 +151,67 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 // their own lane; larger ones are expanded cooperatively by the whole wave (one splat at a time,
 // lanes striding the rect) so a screen-filling splat does not serialise one lane for thousands of
 // iterations.  Must be called by all 64 lanes (n == 0 for idle ones).
+// ---- exact reach test ------------------------------------------------------------------------------------
+// Can the splat's {alpha >= 1/255} ellipse reach a rectangle of pixel centres?
+// alpha >= 1/255  <=>  Q(d) = 1/2 (A dx^2 + 2 B dx dy + C dy^2) <= tau = ln(255 o).  A rectangle is reachable iff the
+// minimum of the convex Q over it can be <= tau (0 if the centre is inside, else attained on one of the four edges);
+// padded so fp32 rounding in the blend can never turn a dropped pair into a contributor.
+struct Reach {
+    float px, py, A, B, C, tau, nBiC, nBiA;
+    int mode;   // 0: test, 1: keep everywhere (conic not positive definite), 2: never (opacity < 1/255)
+};
+__device__ __forceinline__ Reach reach_of(float px, float py, float A, float B, float C, float opacity)
+{
+    Reach r;
+    r.px = px; r.py = py; r.A = A; r.B = B; r.C = C;
+    r.tau = 0.f; r.nBiC = 0.f; r.nBiA = 0.f;
+    if (!(opacity * 255.0f >= 1.0f)) { r.mode = 2; return r; }   // alpha = min(0.99, o * G) can reach 1/255 only if o >= 1/255
+    r.tau = logf(255.0f * opacity) * 1.0001f + 1e-3f;
+    if (!(A > 0.f && C > 0.f && (A * C - B * B) > 0.f)) { r.mode = 1; return r; }
+    r.nBiC = -B / C;
+    r.nBiA = -B / A;
+    r.mode = 0;
+    return r;
+}
+// rectangle of pixel centres [x0, x0 + w] x [y0, y0 + h]
+__device__ __forceinline__ bool rect_reach(const Reach& r, float x0, float y0, float w, float h)
+{
+    if (r.mode) return r.mode == 1;
+    const float a0 = r.px - (x0 + w), a1 = r.px - x0;   // dx range over the rectangle
+    const float b0 = r.py - (y0 + h), b1 = r.py - y0;
+    if (a0 <= 0.f && a1 >= 0.f && b0 <= 0.f && b1 >= 0.f) return true;
+    auto edge_x = [&](float a) {   // dx = a fixed, dy in [b0,b1]
+        const float dy = fminf(fmaxf(r.nBiC * a, b0), b1);
+        return 0.5f * (r.A * a * a + 2.f * r.B * a * dy + r.C * dy * dy);
+    };
+    auto edge_y = [&](float b) {   // dy = b fixed, dx in [a0,a1]
+        const float dx = fminf(fmaxf(r.nBiA * b, a0), a1);
+        return 0.5f * (r.A * dx * dx + 2.f * r.B * dx * b + r.C * b * b);
+    };
+    const float mn = fminf(fminf(edge_x(a0), edge_x(a1)), fminf(edge_y(b0), edge_y(b1)));
+    return mn * 0.999f - 1e-3f <= r.tau;
+}
+
+// Snug tile rect (GsrSettings.tile_culling): the axis-aligned bounding box of the {alpha >= 1/255} ellipse
+//   |dx| <= sqrt(2 tau C / det),  |dy| <= sqrt(2 tau A / det),  det = A C - B^2
+// intersected with the reference's 3-sigma rect.  A tile column tx holds pixel centres 16 tx .. 16 tx + 15, so it is
+// reachable iff 16 tx <= px + xr and 16 tx + 15 >= px - xr.  Costs a few instructions per splat and nothing per tile.
+__device__ __forceinline__ void snug_rect(const Reach& r, int& minx, int& miny, int& maxx, int& maxy, uint32_t& n)
+{
+    if (r.mode == 1 || n == 0) return;
+    if (r.mode == 2) { n = 0; return; }
+    const float det = r.A * r.C - r.B * r.B;
+    const float k = 2.f * r.tau / det;
+    const float xr = sqrtf(k * r.C) * 1.001f + 1e-2f, yr = sqrtf(k * r.A) * 1.001f + 1e-2f;
+    if (!(xr < 1e9f && yr < 1e9f)) return;   // degenerate: keep the reference's rect
+    const float fx = (float)GSR_BLOCK_X, fy = (float)GSR_BLOCK_Y;
+    const int lox = (int)ceilf((r.px - xr - (fx - 1.f)) / fx), hix = (int)floorf((r.px + xr) / fx) + 1;
+    const int loy = (int)ceilf((r.py - yr - (fy - 1.f)) / fy), hiy = (int)floorf((r.py + yr) / fy) + 1;
+    minx = max(minx, lox); maxx = min(maxx, hix);
+    miny = max(miny, loy); maxy = min(maxy, hiy);
+    n = (maxx > minx && maxy > miny) ? (uint32_t)((maxx - minx) * (maxy - miny)) : 0u;
+}
+
 template <typename F>
 __device__ __forceinline__ void for_each_tile(int minx, int miny, int maxx, int maxy, uint32_t n, int gx, F f,
                                               uint32_t payload0, uint32_t payload1)
@@ -260,6 +321,7 @@ struct PreprocessArgs {
     uint8_t* __restrict__ clamped;
     float4* __restrict__ acc;             // [P][3] backward accumulators, zeroed here for visible splats
     uint32_t* __restrict__ tile_count;    // [tiles] zeroed here (the binning histogram of this frame)
+    unsigned long long* __restrict__ rect_total;   // zeroed here; k_count sums tiles_touched into it
     int tiles;
 };
 
@@ -289,8 +351,11 @@ struct PreBwdArgs {
 __global__ void k_preprocess(Settings s, PreprocessArgs a);
 __global__ void k_tile_scan(int tiles, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, uint2* ranges,
                             uint32_t* tile_order, unsigned long long* total_dev, unsigned long long* mailbox, unsigned long long seq);
-__global__ void k_count(int P, int gx, int tiles, const ushort4* rect, const uint32_t* tiles_touched, uint32_t* tile_count);
-__global__ void k_scatter(int P, int gx, int tiles, const float* depths, const ushort4* rect, const uint32_t* tiles_touched,
+template <bool CULL>
+__global__ void k_count(int P, int gx, int tiles, const ushort4* rect, const uint32_t* tiles_touched, const float4* grec, uint32_t* tile_count,
+                        unsigned long long* rect_total);
+template <bool CULL>
+__global__ void k_scatter(int P, int gx, int tiles, const float* depths, const ushort4* rect, const uint32_t* tiles_touched, const float4* grec,
                           const uint32_t* tile_start, uint32_t* tile_cursor, unsigned long long* keys,
                           unsigned long long capacity, const unsigned long long* total_dev);
 template <int KEYS, int THREADS>

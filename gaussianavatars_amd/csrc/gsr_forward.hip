@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
     // this frame's tile histogram starts at zero (k_count runs after this kernel)
     for (int t = i; t < a.tiles; t += (int)(gridDim.x * blockDim.x)) a.tile_count[t] = 0u;
+    if (i == 0) *a.rect_total = 0ull;
 
     bool visible = false;
     float depth = 0.f, px = 0.f, py = 0.f;
@@ -222,10 +223,13 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
 // their tile rects in LDS (ds_add, no return); only the non-empty bins go to the global counters,
 // so a hot tile sees one L2 atomic per workgroup instead of one per instance.
 // ------------------------------------------------------------------------------------------
+template <bool CULL>
 __global__ __launch_bounds__(256) void k_count(int P, int gx, int tiles, const ushort4* __restrict__ rect,
-                                                const uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ tile_count)
+                                                const uint32_t* __restrict__ tiles_touched, const float4* __restrict__ grec,
+                                                uint32_t* __restrict__ tile_count, unsigned long long* __restrict__ rect_total)
 {
     extern __shared__ uint32_t hist[];
+    __shared__ unsigned long long rect_sum[4];
     const int tid = threadIdx.x;
     const bool direct = tiles > GSR_LDS_HIST_TILES;   // tile grid too large for an LDS histogram: count in L2 (slow path)
     if (!direct) {
@@ -235,27 +239,40 @@ __global__ __launch_bounds__(256) void k_count(int P, int gx, int tiles, const u
     const int chunk = ((P + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
     const int begin = blockIdx.x * chunk;
     const int end = min(P, begin + chunk);
+    unsigned long long touched = 0;
     for (int base = begin; base < end; base += 256) {
         const int i = base + tid;
         uint32_t n = 0;
         int minx = 0, miny = 0, maxx = 0, maxy = 0;
         if (i < end) {
             n = tiles_touched[i];
+            touched += n;
             const ushort4 r = rect[i];
             minx = r.x; miny = r.y; maxx = r.z; maxy = r.w;
+            if (CULL && n) {
+                const float4 g0 = grec[3 * (size_t)i], g1 = grec[3 * (size_t)i + 1];
+                snug_rect(reach_of(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y), minx, miny, maxx, maxy, n);
+            }
         }
         if (direct)
             for_each_tile(minx, miny, maxx, maxy, n, gx, [=](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&tile_count[tile], 1u); }, 0u, 0u);
         else
             for_each_tile(minx, miny, maxx, maxy, n, gx, [](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&hist[tile], 1u); }, 0u, 0u);
     }
-    if (direct) return;
+    // the rect-based instance count (the reference's num_rendered) is kept beside the culled one: sum of tiles_touched
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) touched += __shfl_xor(touched, d, 64);
+    if ((tid & 63) == 0) rect_sum[tid >> 6] = touched;
     __syncthreads();
+    if (tid == 0) atomicAdd(rect_total, rect_sum[0] + rect_sum[1] + rect_sum[2] + rect_sum[3]);
+    if (direct) return;
     for (int t = tid; t < tiles; t += 256) {
         const uint32_t v = hist[t];
         if (v) atomicAdd(&tile_count[t], v);
     }
 }
+template __global__ void k_count<false>(int, int, int, const ushort4*, const uint32_t*, const float4*, uint32_t*, unsigned long long*);
+template __global__ void k_count<true>(int, int, int, const ushort4*, const uint32_t*, const float4*, uint32_t*, unsigned long long*);
 
 // ------------------------------------------------------------------------------------------
 // k_tile_scan: exclusive scan over the tile counters (single workgroup, 1024 threads)
@@ -328,9 +345,10 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int tiles, const uint32_t* _
 // touched tile with a single returning L2 atomic, then hands out slots with returning LDS atomics.
 // Order inside a tile segment is arbitrary here; k_tile_sort fixes it.
 // ------------------------------------------------------------------------------------------
+template <bool CULL>
 __global__ __launch_bounds__(256) void k_scatter(int P, int gx, int tiles, const float* __restrict__ depths,
                                                   const ushort4* __restrict__ rect, const uint32_t* __restrict__ tiles_touched,
-                                                  const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
+                                                  const float4* __restrict__ grec, const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
                                                   unsigned long long* __restrict__ keys, unsigned long long capacity,
                                                   const unsigned long long* __restrict__ total_dev)
 {
@@ -347,11 +365,15 @@ __global__ __launch_bounds__(256) void k_scatter(int P, int gx, int tiles, const
             const int i = base + tid;
             uint32_t n = 0, dbits = 0;
             int minx = 0, miny = 0, maxx = 0, maxy = 0;
-            if (i < end) {
+                if (i < end) {
                 n = tiles_touched[i];
                 const ushort4 r = rect[i];
                 minx = r.x; miny = r.y; maxx = r.z; maxy = r.w;
                 dbits = __float_as_uint(depths[i]);
+                if (CULL && n) {
+                    const float4 g0 = grec[3 * (size_t)i], g1 = grec[3 * (size_t)i + 1];
+                    snug_rect(reach_of(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y), minx, miny, maxx, maxy, n);
+                }
             }
             for_each_tile(minx, miny, maxx, maxy, n, gx,
                           [=](uint32_t tile, uint32_t db, uint32_t idx) {
@@ -372,6 +394,10 @@ __global__ __launch_bounds__(256) void k_scatter(int P, int gx, int tiles, const
             n = tiles_touched[i];
             const ushort4 r = rect[i];
             minx = r.x; miny = r.y; maxx = r.z; maxy = r.w;
+            if (CULL && n) {
+                const float4 g0 = grec[3 * (size_t)i], g1 = grec[3 * (size_t)i + 1];
+                snug_rect(reach_of(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y), minx, miny, maxx, maxy, n);
+            }
         }
         for_each_tile(minx, miny, maxx, maxy, n, gx, [](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&hist[tile], 1u); }, 0u, 0u);
     }
@@ -389,6 +415,10 @@ __global__ __launch_bounds__(256) void k_scatter(int P, int gx, int tiles, const
             n = tiles_touched[i];
             const ushort4 r = rect[i];
             minx = r.x; miny = r.y; maxx = r.z; maxy = r.w;
+            if (CULL && n) {
+                const float4 g0 = grec[3 * (size_t)i], g1 = grec[3 * (size_t)i + 1];
+                snug_rect(reach_of(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y), minx, miny, maxx, maxy, n);
+            }
             dbits = __float_as_uint(depths[i]);
         }
         for_each_tile(minx, miny, maxx, maxy, n, gx,
@@ -399,6 +429,10 @@ __global__ __launch_bounds__(256) void k_scatter(int P, int gx, int tiles, const
                       dbits, (uint32_t)i);
     }
 }
+template __global__ void k_scatter<false>(int, int, int, const float*, const ushort4*, const uint32_t*, const float4*, const uint32_t*, uint32_t*,
+                                          unsigned long long*, unsigned long long, const unsigned long long*);
+template __global__ void k_scatter<true>(int, int, int, const float*, const ushort4*, const uint32_t*, const float4*, const uint32_t*, uint32_t*,
+                                         unsigned long long*, unsigned long long, const unsigned long long*);
 
 // ------------------------------------------------------------------------------------------
 // Register-resident block sort for the in-LDS size classes: 8 keys per thread (index i = 8*tid + k).
@@ -493,38 +527,15 @@ __device__ __forceinline__ void block_sort_regs(u64 (&key)[EPT], u64* __restrict
 }
 
 // Which of the tile's four 8x8 quadrants can the splat's {alpha >= 1/255} ellipse reach?  (bit q set = keep)
-// alpha >= 1/255  <=>  Q(d) = 1/2 (A dx^2 + 2 B dx dy + C dy^2) <= tau = ln(255 o).  The record is kept for
-// quadrant q iff the minimum of the convex Q over the quadrant's pixel rectangle can be <= tau (0 if the centre
-// is inside, else attained on one of the four edges); padded so fp32 rounding in the blend can never turn a
-// dropped pair into a contributor.
+// Same test as the tile-level one (rect_reach, gsr_device.h), on the quadrant's rectangle of pixel centres.
 __device__ __forceinline__ uint32_t quadrant_mask(float2 p, float4 co, float ox, float oy)
 {
-    if (!(co.w * 255.0f >= 1.0f)) return 0u;   // alpha = min(0.99, o * G) can reach 1/255 only if o >= 1/255
-    const float tau = logf(255.0f * co.w) * 1.0001f + 1e-3f;
-    const float A = co.x, B = co.y, Cc = co.z;
-    if (!(A > 0.f && Cc > 0.f && (A * Cc - B * B) > 0.f)) return 0xFu;   // not positive definite: keep everywhere
-    const float nBiC = -B / Cc, nBiA = -B / A;
-    auto edge_x = [&](float a, float b0, float b1) {   // dx = a fixed, dy in [b0,b1]
-        const float dy = fminf(fmaxf(nBiC * a, b0), b1);
-        return 0.5f * (A * a * a + 2.f * B * a * dy + Cc * dy * dy);
-    };
-    auto edge_y = [&](float b, float a0, float a1) {   // dy = b fixed, dx in [a0,a1]
-        const float dx = fminf(fmaxf(nBiA * b, a0), a1);
-        return 0.5f * (A * dx * dx + 2.f * B * dx * b + Cc * b * b);
-    };
+    const Reach r = reach_of(p.x, p.y, co.x, co.y, co.z, co.w);
+    if (r.mode) return r.mode == 1 ? 0xFu : 0u;
     uint32_t m = 0u;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float qx0 = ox + (float)((q & 1) * 8), qy0 = oy + (float)((q >> 1) * 8);
-        const float a0 = p.x - (qx0 + 7.f), a1 = p.x - qx0;   // dx range over the quadrant's pixel centres
-        const float b0 = p.y - (qy0 + 7.f), b1 = p.y - qy0;
-        bool keep = a0 <= 0.f && a1 >= 0.f && b0 <= 0.f && b1 >= 0.f;
-        if (!keep) {
-            const float mn = fminf(fminf(edge_x(a0, b0, b1), edge_x(a1, b0, b1)), fminf(edge_y(b0, a0, a1), edge_y(b1, a0, a1)));
-            keep = mn * 0.999f - 1e-3f <= tau;
-        }
-        m |= keep ? (1u << q) : 0u;
-    }
+    for (int q = 0; q < 4; ++q)
+        m |= rect_reach(r, ox + (float)((q & 1) * 8), oy + (float)((q >> 1) * 8), 7.f, 7.f) ? (1u << q) : 0u;
     return m;
 }
 

@@ -17,9 +17,20 @@ def _view(buf: torch.Tensor, off: int, count: int, dtype: torch.dtype) -> torch.
 
 
 def forward_state(rs: GaussianRasterizationSettings, means3D, shs, colors_precomp, opacities, scales, rotations,
-                  cov3D_precomp) -> dict:
+                  cov3D_precomp, tile_culling: bool = False) -> dict:
     """Runs the forward through the autograd Function (same code path as render()) and unpacks the
-    saved state.  Returns device tensors."""
+    saved state.  Returns device tensors.  tile_culling=False (default here) keeps the reference's rect-based
+    instance lists so that keys / point_list / ranges / n_contrib compare with the oracle index for index."""
+    from . import rasterizer as _R
+
+    prev = _R.set_tile_culling(tile_culling)
+    try:
+        return _forward_state(rs, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+    finally:
+        _R.set_tile_culling(prev)
+
+
+def _forward_state(rs, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp) -> dict:
     lib = _lib.gsr()
     e = torch.Tensor([])
     args = [means3D, torch.zeros_like(means3D), e if shs is None else shs, e if colors_precomp is None else colors_precomp,
@@ -51,6 +62,7 @@ def forward_state(rs: GaussianRasterizationSettings, means3D, shs, colors_precom
     f32, u32, i16 = torch.float32, torch.int32, torch.int16
     out = dict(
         color=color, radii=radii, num_rendered=I, capacity=cap,
+        rect_instances=int(_view(binning, 8, 1, torch.int64).item()),
         depths=_view(geom, gl.depths, P, f32),
         xy=_view(geom, gl.grec, 12 * P, f32).view(P, 12)[:, 0:2],
         conic_opacity=_view(geom, gl.grec, 12 * P, f32).view(P, 12)[:, 2:6],

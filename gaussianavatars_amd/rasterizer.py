@@ -13,6 +13,7 @@ device memory, the current stream and autograd plumbing only.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -20,7 +21,8 @@ from torch import nn
 
 from . import _lib
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_forward_info"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_forward_info", "set_tile_culling",
+           "get_tile_culling"]
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -38,15 +40,42 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+# ---- exact tile culling (include/gsr.h: GsrSettings.tile_culling) --------------------------------
+# On by default: instances that cannot reach a tile are not binned (same image / radii / gradients, about a third
+# fewer keys to sort).  GSR_TILE_CULLING=0 or set_tile_culling(False) keeps the reference's rect-based lists, which is
+# what the parity tests compare with the oracle index for index.
+_tile_culling = os.environ.get("GSR_TILE_CULLING", "1") != "0"
+
+
+def set_tile_culling(enabled: bool) -> bool:
+    """Process-wide switch; returns the previous value."""
+    global _tile_culling
+    prev, _tile_culling = _tile_culling, bool(enabled)
+    return prev
+
+
+def get_tile_culling() -> bool:
+    return _tile_culling
+
+
 # ---- per-device running estimate of the binning capacity (instances per frame) -----------------
 _CAP_QUANTUM = 1 << 16
 _capacity_hint: dict = {}
 _last_info: dict = {}
 
 
+_last_binning: list = [None]
+
+
 def last_forward_info() -> dict:
-    """{'num_rendered', 'capacity', 'replays'} of the most recent forward on this process."""
-    return dict(_last_info)
+    """{'num_rendered', 'capacity', 'replays', 'tile_culling', 'rect_instances'} of the most recent forward on this
+    process.  num_rendered counts the instances actually binned; rect_instances is the reference's rect-based count
+    (sum of tiles_touched; equal to num_rendered without tile culling) -- read back from the device on request."""
+    info = dict(_last_info)
+    b = _last_binning[0]
+    if b is not None:
+        info["rect_instances"] = int(b[8:16].view(torch.int64).item())
+    return info
 
 
 def _round_cap(n: int) -> int:
@@ -72,6 +101,7 @@ def _make_settings(rs: GaussianRasterizationSettings, keep: list) -> _lib.GsrSet
     s.scale_modifier = float(rs.scale_modifier)
     s.sh_degree = int(rs.sh_degree)
     s.prefiltered, s.debug = int(bool(rs.prefiltered)), int(bool(rs.debug))
+    s.tile_culling = int(_tile_culling)
     for field in ("bg", "viewmatrix", "projmatrix", "campos"):
         t = _f32c(getattr(rs, field), field)
         keep.append(t)
@@ -142,7 +172,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         I = int(n_host.value)
         # next frame: 25 % headroom over what this one needed, never shrinking below it
         _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
-        _last_info.update(num_rendered=I, capacity=cap, replays=replays)
+        _last_info.update(num_rendered=I, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling))
+        _last_binning[0] = binning
 
         ctx.raster_settings = raster_settings
         ctx.num_rendered = I

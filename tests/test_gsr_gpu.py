@@ -142,7 +142,9 @@ def _grad_check(oracle, name, use_precomp_color=False, use_precomp_cov=False, rt
 
 @pytest.mark.parametrize("name", ["cfg1", "sh3_small", "sh2_mod", "culls", "huge_grid"])
 def test_backward_matches_oracle(oracle, name):
-    _grad_check(oracle, name)
+    # huge_grid: screen-filling splats sum ~10^7 per-pixel terms through fp32 atomics; the run-to-run spread of the most
+    # cancellation-prone gradient (rotations) reaches 3e-4 of its max, so that scene gets 1e-3
+    _grad_check(oracle, name, rtol=1e-3 if name == "huge_grid" else 2e-4)
 
 
 def test_backward_precomputed_inputs(oracle):
@@ -216,3 +218,75 @@ def test_replay_on_capacity_overflow(oracle):
     s, st, hs, rs, _ = _run_both(oracle, "cfg1")
     assert R.last_forward_info()["replays"] >= 1
     _check_forward(st, hs)
+
+
+@pytest.mark.parametrize("name", ["cfg1", "sh3_small", "sh2_mod", "culls", "dense_tile", "empty_view"])
+def test_tile_culling_changes_only_the_binning_state(oracle, name):
+    """GsrSettings.tile_culling: instances whose {alpha >= 1/255} ellipse cannot reach a tile are not binned.  The image,
+    final_T and radii must be the same BITS as without culling (and as the oracle's); the culled lists must be ordered
+    subsequences of the reference-exact ones that still contain every instance the exact mode streams to a quadrant."""
+    from gaussianavatars_amd.debug import forward_state
+    from gaussianavatars_amd.rasterizer import GaussianRasterizationSettings
+
+    dev = _dev()
+    cam, sp, bg, deg, mod = scene(name)
+    a = settings_args(cam, bg, deg, mod)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    rs = GaussianRasterizationSettings(a["H"], a["W"], a["tanfovx"], a["tanfovy"], t(a["bg"]), mod, t(a["viewmatrix"]),
+                                       t(a["projmatrix"]), deg, t(a["campos"]), False, False)
+    args = (t(sp["means3D"]), t(sp["shs"]), None, t(sp["opacities"]), t(sp["scales"]), t(sp["rotations"]), None)
+    ex = forward_state(rs, *args, tile_culling=False)
+    cu = forward_state(rs, *args, tile_culling=True)
+    st = oracle.forward(oracle.make_settings(**a), sp["means3D"], sp["shs"], None, sp["opacities"], sp["scales"], sp["rotations"], None)
+    assert ex["num_rendered"] == st.num_rendered == ex["rect_instances"] == cu["rect_instances"]
+    assert cu["num_rendered"] <= ex["num_rendered"]
+    for k in ("color", "final_T"):
+        assert np.array_equal(_np(cu[k]).view(np.uint32), _np(ex[k]).view(np.uint32)), k
+    assert np.array_equal(_np(cu["color"]).view(np.uint32), st.color.view(np.uint32))
+    np.testing.assert_array_equal(_np(cu["radii"]), _np(ex["radii"]))
+    rex, rcu = _np(ex["ranges"]).astype(np.int64), _np(cu["ranges"]).astype(np.int64)
+    kex, kcu = _np(ex["keys"]).view(np.uint64), _np(cu["keys"]).view(np.uint64)
+    pex, pcu = _np(ex["point_list"]).astype(np.int64), _np(cu["point_list"]).astype(np.int64)
+    qex, cex = _np(ex["qrecords"]), _np(ex["qcount"]).astype(np.int64)
+    dropped = 0
+    for tile in range(rex.shape[0]):
+        e0, e1, c0, c1 = rex[tile, 0], rex[tile, 1], rcu[tile, 0], rcu[tile, 1]
+        assert (kex[e0:e1] >> np.uint64(32) == tile).all() and (kcu[c0:c1] >> np.uint64(32) == tile).all()
+        # (depth bits, splat index) is unique inside a tile and is the order both lists are sorted in
+        ke = ((kex[e0:e1] & np.uint64(0xFFFFFFFF)) << np.uint64(32)) | pex[e0:e1].astype(np.uint64)
+        kc = ((kcu[c0:c1] & np.uint64(0xFFFFFFFF)) << np.uint64(32)) | pcu[c0:c1].astype(np.uint64)
+        assert (np.diff(ke.astype(np.int64)) > 0).all() and (np.diff(kc.astype(np.int64)) > 0).all()
+        # subsequence: every culled-mode entry appears in the exact list
+        pos = np.searchsorted(ke, kc)
+        assert (pos < len(ke)).all() and np.array_equal(ke[pos], kc), f"tile {tile}: culled list is not a subsequence"
+        # nothing that reaches a quadrant in exact mode was dropped
+        n = e1 - e0
+        if n:
+            reach = np.zeros(n, bool)
+            for q in range(4):
+                r = qex[4 * e0 + q * n: 4 * e0 + q * n + cex[tile, q]]
+                reach[r[:, 10].view(np.uint32)] = True
+            kept = np.zeros(n, bool)
+            kept[pos] = True
+            assert not (reach & ~kept).any(), f"tile {tile}: a reachable instance was culled"
+        dropped += n - (c1 - c0)
+    assert dropped == ex["num_rendered"] - cu["num_rendered"]
+    if name in ("sh3_small", "dense_tile"):
+        assert dropped > 0
+
+
+def test_tile_culling_gradients_equal_exact_mode(oracle):
+    from gaussianavatars_amd import rasterizer as R
+
+    prev = R.set_tile_culling(False)
+    try:
+        _grad_check(oracle, "sh3_small")
+    finally:
+        R.set_tile_culling(prev)
+    assert R.get_tile_culling() == prev
+    prev = R.set_tile_culling(True)
+    try:
+        _grad_check(oracle, "sh3_small")
+        _grad_check(oracle, "culls")
+    finally:
+        R.set_tile_culling(prev)
