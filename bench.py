@@ -261,8 +261,10 @@ def main():
         }
         pmc = {}
         pmc_tag = "cfg5" if args.workload == "cfg5" else ("cfg3" if args.workload in ("cfg3", "cfg2") else None)
-        pmc_path = os.path.join(ROOT, "profiles", f"r01_d_{pmc_tag}_pmc_fetch_write_per_launch.json")
-        if pmc_tag and os.path.exists(pmc_path):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/README.md)
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{pmc_tag}_pmc_fetch_write_per_launch.json"))) if pmc_tag else []
+        pmc_path = cands[-1] if cands else ""   # the newest committed PMC summary of this workload
+        if pmc_path:   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/README.md)
             for k, v in json.load(open(pmc_path)).items():
                 name = k.replace("void ", "").split("::")[-1].split("<")[0]   # the two k_tile_sort classes add up
                 # FETCH_SIZE/WRITE_SIZE are KB; gfx950 FETCH_SIZE counts half of a wide streaming read (MI355X_MICROARCH.md)
