@@ -37,7 +37,7 @@ class GsrSettings(C.Structure):
 
 class GsrGeomLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
-                ("depths", "grec", "cov3D", "rect", "tiles_touched", "clamped", "acc", "total")]
+                ("depths", "grec", "cov3D", "rect", "tiles_touched", "clamped", "visible", "acc", "total")]
 
 
 class GsrBinningLayout(C.Structure):
@@ -138,12 +138,13 @@ GAB_SYMBOLS = {
     "gab_abi_version": (C.c_int, []),
     "gab_last_error": (C.c_char_p, []),
     "gab_flame_forward": (C.c_int, [C.POINTER(GabRig)] + [_P] * 8 + [_P, _P, _P, _P]),
-    "gab_flame_backward": (C.c_int, [C.POINTER(GabRig)] + [_P] * 8 + [_P, _P, _P, _P] + [_P] * 8 + [_P, _P]),
+    "gab_flame_backward": (C.c_int, [C.POINTER(GabRig)] + [_P] * 8 + [_P, _P, _P, _P] + [_P] * 8 + [_P] +
+                           [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _P]),
     "gab_face_frames_forward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "gab_face_frames_backward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P]),
-    "gab_bind_forward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "gab_bind_backward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "gab_bind_backward_csr": (C.c_int, [C.c_int32, C.c_int32] + [_P] * 16),
+    "gab_bind_forward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gab_bind_backward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gab_bind_backward_csr": (C.c_int, [C.c_int32, C.c_int32] + [_P] * 19),
     "gab_zero_buffers": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _P]),
 }
 

@@ -121,7 +121,7 @@ class _FlameForward(torch.autograd.Function):
         with torch.cuda.device(dev):
             _chk(lib.gab_flame_backward(C.byref(rig), *[_p(t) for t in ins], _p(so), _p(v_shaped), _p(ws), _p(gv), _p(gvs),
                                         _p(d_shape), _p(d_expr), _p(d_rot), _p(d_neck), _p(d_jaw), _p(d_eyes), _p(d_trans), _p(d_so),
-                                        _p(scratch), _stream(dev)), "gab_flame_backward")
+                                        _p(scratch), 0, None, None, _stream(dev)), "gab_flame_backward")
         sh = ctx.shapes
         outs = [None, None if d_shape is None else d_shape.view(sh[0]), d_expr.view(sh[1]), d_rot.view(sh[2]), d_neck.view(sh[3]),
                 d_jaw.view(sh[4]), d_eyes.view(sh[5]), d_trans.view(sh[6]), None if d_so is None else d_so.view(ctx.so_shape)]
@@ -194,9 +194,9 @@ class _FlameForwardTimestep(torch.autograd.Function):
         gvs = None if g_vshaped is None else _f32(g_vshaped)
         rows = [C.c_void_p(x.data_ptr() + 4 * t * w) for x, w in zip(tabs, widths)]
         with torch.cuda.device(dev):
-            _chk(lib.gab_zero_buffers(len(tables), ptrs, sizes, _stream(dev)), "gab_zero_buffers")
+            # the (T,k) tables are zero-filled by the backward's first kernel (no launch of their own)
             _chk(lib.gab_flame_backward(C.byref(rig), _p(sh), *rows, _p(so), _p(v_shaped), _p(ws), _p(gv), _p(gvs), _p(d_shape),
-                                        *outp, _p(d_so), _p(scratch), _stream(dev)), "gab_flame_backward")
+                                        *outp, _p(d_so), _p(scratch), len(tables), ptrs, sizes, _stream(dev)), "gab_flame_backward")
         grads = [tb if need[3 + i] else None for i, tb in enumerate(tables)]
         return (None, None, None if d_shape is None else d_shape.view(ctx.shape_shape), *grads,
                 None if d_so is None else d_so.view(ctx.so_shape))
@@ -271,7 +271,7 @@ def binding_csr(binding: torch.Tensor, num_faces: int):
 
 class _BindSplats(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, log_scaling, rotation, binding, face_R, face_scale, face_center, face_quat, csr=None):
+    def forward(ctx, xyz, log_scaling, rotation, binding, face_R, face_scale, face_center, face_quat, csr=None, opacity_logit=None):
         lib = _lib.gab()
         _need_cuda(xyz, "_xyz")
         dev = xyz.device
@@ -281,39 +281,46 @@ class _BindSplats(torch.autograd.Function):
         N, F = x.shape[0], fc.shape[0]
         f32 = dict(dtype=torch.float32, device=dev)
         ox, osc, oq = torch.empty((N, 3), **f32), torch.empty((N, 3), **f32), torch.empty((N, 4), **f32)
+        ol = None if opacity_logit is None else _f32(opacity_logit)
+        oo = None if ol is None else torch.empty_like(ol)
         with torch.cuda.device(dev):
             _chk(lib.gab_bind_forward(N, F, _p(x), _p(ls), _p(q), _p(b), is64, _p(fc), _p(fR), _p(fs), _p(fq), _p(ox), _p(osc), _p(oq),
-                                      _stream(dev)), "gab_bind_forward")
-        ctx.save_for_backward(x, ls, q, b, fR, fs, fc, fq)
+                                      _p(ol), _p(oo), _stream(dev)), "gab_bind_forward")
+        ctx.save_for_backward(x, ls, q, b, fR, fs, fc, fq, oo)
         ctx.is64 = is64
         ctx.csr = csr
-        return ox, osc, oq
+        if oo is None:
+            return ox, osc, oq
+        return ox, osc, oq, oo
 
     @staticmethod
-    def backward(ctx, g_xyz, g_scaling, g_rot):
+    def backward(ctx, g_xyz, g_scaling, g_rot, g_opacity=None):
         lib = _lib.gab()
-        x, ls, q, b, fR, fs, fc, fq = ctx.saved_tensors
+        x, ls, q, b, fR, fs, fc, fq, oo = ctx.saved_tensors
         dev = x.device
         N, F = x.shape[0], fc.shape[0]
         f32 = dict(dtype=torch.float32, device=dev)
         d_x, d_ls, d_q = torch.empty((N, 3), **f32), torch.empty((N, 3), **f32), torch.empty((N, 4), **f32)
         d_face = torch.empty(17 * F, **f32)   # four contiguous blocks: center | orien_mat | scaling | orien_quat
         gs = [None if g is None else _f32(g) for g in (g_xyz, g_scaling, g_rot)]
+        go = None if (oo is None or g_opacity is None) else _f32(g_opacity)
+        d_ol = None if oo is None else torch.empty_like(oo)
         with torch.cuda.device(dev):
             if ctx.csr is not None:
                 order, face_begin = ctx.csr
                 _chk(lib.gab_bind_backward_csr(N, F, _p(x), _p(ls), _p(q), _p(fR), _p(fs), _p(fq), _p(gs[0]), _p(gs[1]), _p(gs[2]),
-                                               _p(order), _p(face_begin), _p(d_x), _p(d_ls), _p(d_q), _p(d_face), _stream(dev)),
-                     "gab_bind_backward_csr")
+                                               _p(order), _p(face_begin), _p(d_x), _p(d_ls), _p(d_q), _p(d_face), _p(oo), _p(go), _p(d_ol),
+                                               _stream(dev)), "gab_bind_backward_csr")
             else:
                 _chk(lib.gab_bind_backward(N, F, _p(x), _p(ls), _p(q), _p(b), ctx.is64, _p(fc), _p(fR), _p(fs), _p(fq), _p(gs[0]),
-                                           _p(gs[1]), _p(gs[2]), _p(d_x), _p(d_ls), _p(d_q), _p(d_face), _stream(dev)),
-                     "gab_bind_backward")
+                                           _p(gs[1]), _p(gs[2]), _p(d_x), _p(d_ls), _p(d_q), _p(d_face), _p(oo), _p(go), _p(d_ol),
+                                           _stream(dev)), "gab_bind_backward")
         return (d_x, d_ls, d_q, None, d_face[3 * F: 12 * F].view(F, 3, 3), d_face[12 * F: 13 * F].view(F, 1), d_face[: 3 * F].view(F, 3),
-                d_face[13 * F:].view(F, 4), None)
+                d_face[13 * F:].view(F, 4), None, d_ol)
 
 
-def bind_splats(xyz, log_scaling, rotation, binding, face_R, face_scale, face_center, face_quat, csr=None):
+def bind_splats(xyz, log_scaling, rotation, binding, face_R, face_scale, face_center, face_quat, csr=None, opacity_logit=None):
     """-> (get_xyz, get_scaling, get_rotation) of a mesh-bound GaussianModel, in one kernel.
-    csr = binding_csr(binding, F) selects the atomic-free deterministic backward."""
-    return _BindSplats.apply(xyz, log_scaling, rotation, binding, face_R, face_scale, face_center, face_quat, csr)
+    csr = binding_csr(binding, F) selects the atomic-free deterministic backward.
+    opacity_logit = the model's `_opacity`: a fourth output, get_opacity = sigmoid(_opacity), from the same launches."""
+    return _BindSplats.apply(xyz, log_scaling, rotation, binding, face_R, face_scale, face_center, face_quat, csr, opacity_logit)

@@ -309,16 +309,22 @@ __global__ __launch_bounds__(256) void k_skin(Rig rig, const float* __restrict__
         verts[3 * v + r] = T[4 * r] * vp[0] + T[4 * r + 1] * vp[1] + T[4 * r + 2] * vp[2] + T[4 * r + 3] + translation[r];
 }
 
+struct ZeroSpec { float* p[8]; int n[8]; int count; };   // up to 8 buffers a kernel zero-fills on the side
+
 // ---------------------------------------------------------------------------------------------
 // B1  skinning backward: dL/dv_posed per vertex -> scratch; block-reduced sums for dA (60),
 //     d translation (3), d pose_feature (36) -> ws
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_skin_bwd(Rig rig, float* __restrict__ ws, const float* __restrict__ v_shaped,
-                                                   const float* __restrict__ dL_dverts, float* __restrict__ g_vs /*(V,3)*/)
+                                                   const float* __restrict__ dL_dverts, float* __restrict__ g_vs /*(V,3)*/, ZeroSpec zero)
 {
     __shared__ float red[4][100];   // per-wave partials of the 99 sums (no LDS atomics)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int v = blockIdx.x * blockDim.x + tid;
+    // first kernel of the FLAME backward: zero-fill the caller's gradient tables on the side (rows of them are written by the
+    // kernels that follow), instead of a launch of their own
+    for (int b = 0; b < zero.count; ++b)
+        for (int i = v; i < zero.n[b]; i += (int)(gridDim.x * blockDim.x)) zero.p[b][i] = 0.f;
     const bool ok = v < rig.V;
     const int E = 3 * rig.V;
     float g[3] = {0.f, 0.f, 0.f}, vp[3] = {0.f, 0.f, 0.f}, T[12], gvp[3] = {0.f, 0.f, 0.f};
@@ -720,10 +726,12 @@ __global__ __launch_bounds__(256) void k_bind(int N, const float* __restrict__ x
                                                const float* __restrict__ rotation, const void* __restrict__ binding, int is64,
                                                const float* __restrict__ fc, const float* __restrict__ fR, const float* __restrict__ fs,
                                                const float* __restrict__ fq, float* __restrict__ out_xyz, float* __restrict__ out_scaling,
-                                               float* __restrict__ out_rotation)
+                                               float* __restrict__ out_rotation, const float* __restrict__ opacity_logit,
+                                               float* __restrict__ out_opacity)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
+    if (opacity_logit) out_opacity[i] = 1.f / (1.f + expf(-opacity_logit[i]));   // get_opacity (scene/gaussian_model.py:158-160) on the side
     const long long f = index_at(binding, is64, i);
     const float s = fs[f];
     const float* R = fR + 9 * f;
@@ -743,10 +751,16 @@ __global__ __launch_bounds__(256) void k_bind_bwd(int N, const float* __restrict
                                                    const float* __restrict__ fR, const float* __restrict__ fs, const float* __restrict__ fq,
                                                    const float* __restrict__ g_xyz, const float* __restrict__ g_scaling,
                                                    const float* __restrict__ g_rot, float* __restrict__ d_xyz,
-                                                   float* __restrict__ d_log_scaling, float* __restrict__ d_rotation, float* __restrict__ d_face, int F)
+                                                   float* __restrict__ d_log_scaling, float* __restrict__ d_rotation, float* __restrict__ d_face, int F,
+                                                   const float* __restrict__ out_opacity, const float* __restrict__ g_opacity,
+                                                   float* __restrict__ d_opacity_logit)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
+    if (d_opacity_logit) {
+        const float o = out_opacity[i];
+        d_opacity_logit[i] = (g_opacity ? g_opacity[i] : 0.f) * o * (1.f - o);
+    }
     const long long f = index_at(binding, is64, i);
     const float s = fs[f];
     const float* R = fR + 9 * f;
@@ -804,7 +818,8 @@ __global__ __launch_bounds__(256) void k_bind_bwd_csr(int F, const float* __rest
                                                        const float* __restrict__ g_rot, const int* __restrict__ order,
                                                        const int* __restrict__ face_begin, float* __restrict__ d_xyz,
                                                        float* __restrict__ d_log_scaling, float* __restrict__ d_rotation,
-                                                       float* __restrict__ d_face)
+                                                       float* __restrict__ d_face, const float* __restrict__ out_opacity,
+                                                       const float* __restrict__ g_opacity, float* __restrict__ d_opacity_logit)
 {
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
     const int f = gtid >> 4, sub = gtid & 15;
@@ -823,6 +838,10 @@ __global__ __launch_bounds__(256) void k_bind_bwd_csr(int F, const float* __rest
         const int b0 = face_begin[f], b1 = face_begin[f + 1];
         for (int j = b0 + sub; j < b1; j += 16) {
             const int i = order[j];
+            if (d_opacity_logit) {
+                const float o = out_opacity[i];
+                d_opacity_logit[i] = (g_opacity ? g_opacity[i] : 0.f) * o * (1.f - o);
+            }
             const float x[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
             const float gx[3] = {g_xyz ? g_xyz[3 * i] : 0.f, g_xyz ? g_xyz[3 * i + 1] : 0.f, g_xyz ? g_xyz[3 * i + 2] : 0.f};
 #pragma unroll
@@ -883,7 +902,6 @@ __global__ __launch_bounds__(256) void k_bind_bwd_csr(int F, const float* __rest
 }
 
 // one launch that zero-fills up to 8 small buffers (the full-table gradients of the per-timestep FLAME rows)
-struct ZeroSpec { float* p[8]; int n[8]; int count; };
 __global__ __launch_bounds__(256) void k_zero_many(ZeroSpec z)
 {
     const int b = blockIdx.y;
@@ -966,9 +984,19 @@ int gab_flame_backward(const GabRig* rig_, const float* shape, const float* expr
                        const float* jaw, const float* eyes, const float* translation, const float* static_offset,
                        const float* v_shaped, float* ws, const float* dL_dverts, const float* dL_dv_shaped, float* d_shape,
                        float* d_expr, float* d_rotation, float* d_neck, float* d_jaw, float* d_eyes, float* d_translation,
-                       float* d_static_offset, float* scratch, void* stream_)
+                       float* d_static_offset, float* scratch, int32_t zero_count, float* const* zero_buffers_host,
+                       const int32_t* zero_sizes_host, void* stream_)
 {
     (void)shape; (void)expr; (void)translation; (void)static_offset;
+    if (zero_count < 0 || zero_count > 8 || (zero_count > 0 && (!zero_buffers_host || !zero_sizes_host)))
+        return fail(GAB_E_ARG, "gab_flame_backward: 0..8 zero-fill buffers");
+    gab::ZeroSpec zs;
+    zs.count = zero_count;
+    for (int i = 0; i < 8; ++i) {
+        zs.p[i] = i < zero_count ? zero_buffers_host[i] : nullptr;
+        zs.n[i] = i < zero_count ? zero_sizes_host[i] : 0;
+        if (i < zero_count && (zs.n[i] < 0 || (zs.n[i] > 0 && !zs.p[i]))) return fail(GAB_E_ARG, "gab_flame_backward: bad zero-fill buffer %d", i);
+    }
     gab::Rig rig;
     if (int rc = to_rig(rig_, &rig)) return rc;
     if (!rotation || !neck || !jaw || !eyes || !v_shaped || !ws || !dL_dverts || !d_expr || !d_rotation || !d_neck || !d_jaw || !d_eyes ||
@@ -976,7 +1004,7 @@ int gab_flame_backward(const GabRig* rig_, const float* shape, const float* expr
         return fail(GAB_E_ARG, "gab_flame_backward: NULL buffer");
     hipStream_t st = (hipStream_t)stream_;
     const int E = 3 * rig.V;
-    hipLaunchKernelGGL(gab::k_skin_bwd, dim3((rig.V + 255) / 256), dim3(256), 0, st, rig, ws, v_shaped, dL_dverts, scratch);
+    hipLaunchKernelGGL(gab::k_skin_bwd, dim3((rig.V + 255) / 256), dim3(256), 0, st, rig, ws, v_shaped, dL_dverts, scratch, zs);
     LAUNCH_CHECK("k_skin_bwd");
     const bool flame_tree = rig.parents[1] == 0 && rig.parents[2] == 1 && rig.parents[3] == 1 && rig.parents[4] == 1;
     if (flame_tree)
@@ -1023,15 +1051,17 @@ int gab_face_frames_backward(int32_t V, int32_t F, const float* verts, const voi
 
 int gab_bind_forward(int32_t N, int32_t F, const float* xyz, const float* log_scaling, const float* rotation, const void* binding,
                      int32_t is64, const float* face_center, const float* face_orien_mat, const float* face_scaling,
-                     const float* face_orien_quat, float* out_xyz, float* out_scaling, float* out_rotation, void* stream_)
+                     const float* face_orien_quat, float* out_xyz, float* out_scaling, float* out_rotation, const float* opacity_logit,
+                     float* out_opacity, void* stream_)
 {
     if (N < 0 || F <= 0) return fail(GAB_E_ARG, "bad sizes");
     if (N == 0) return GAB_OK;
+    if ((opacity_logit == nullptr) != (out_opacity == nullptr)) return fail(GAB_E_ARG, "opacity_logit and out_opacity go together");
     if (!xyz || !log_scaling || !rotation || !binding || !face_center || !face_orien_mat || !face_scaling || !face_orien_quat || !out_xyz ||
         !out_scaling || !out_rotation)
         return fail(GAB_E_ARG, "gab_bind_forward: NULL buffer");
     hipLaunchKernelGGL(gab::k_bind, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream_, N, xyz, log_scaling, rotation, binding, is64,
-                       face_center, face_orien_mat, face_scaling, face_orien_quat, out_xyz, out_scaling, out_rotation);
+                       face_center, face_orien_mat, face_scaling, face_orien_quat, out_xyz, out_scaling, out_rotation, opacity_logit, out_opacity);
     LAUNCH_CHECK("k_bind");
     return GAB_OK;
 }
@@ -1039,9 +1069,11 @@ int gab_bind_forward(int32_t N, int32_t F, const float* xyz, const float* log_sc
 int gab_bind_backward(int32_t N, int32_t F, const float* xyz, const float* log_scaling, const float* rotation, const void* binding,
                       int32_t is64, const float* face_center, const float* face_orien_mat, const float* face_scaling,
                       const float* face_orien_quat, const float* d_out_xyz, const float* d_out_scaling, const float* d_out_rotation,
-                      float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face, void* stream_)
+                      float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face, const float* out_opacity,
+                      const float* d_out_opacity, float* d_opacity_logit, void* stream_)
 {
     (void)face_center;
+    if (d_opacity_logit && !out_opacity) return fail(GAB_E_ARG, "d_opacity_logit needs out_opacity");
     if (N < 0 || F <= 0) return fail(GAB_E_ARG, "bad sizes");
     if (!d_face) return fail(GAB_E_ARG, "d_face is NULL");
     hipStream_t st = (hipStream_t)stream_;
@@ -1051,7 +1083,8 @@ int gab_bind_backward(int32_t N, int32_t F, const float* xyz, const float* log_s
         !d_rotation)
         return fail(GAB_E_ARG, "gab_bind_backward: NULL buffer");
     hipLaunchKernelGGL(gab::k_bind_bwd, dim3((N + 255) / 256), dim3(256), 0, st, N, xyz, log_scaling, rotation, binding, is64, face_orien_mat,
-                       face_scaling, face_orien_quat, d_out_xyz, d_out_scaling, d_out_rotation, d_xyz, d_log_scaling, d_rotation, d_face, F);
+                       face_scaling, face_orien_quat, d_out_xyz, d_out_scaling, d_out_rotation, d_xyz, d_log_scaling, d_rotation, d_face, F,
+                       out_opacity, d_out_opacity, d_opacity_logit);
     LAUNCH_CHECK("k_bind_bwd");
     return GAB_OK;
 }
@@ -1059,8 +1092,10 @@ int gab_bind_backward(int32_t N, int32_t F, const float* xyz, const float* log_s
 int gab_bind_backward_csr(int32_t N, int32_t F, const float* xyz, const float* log_scaling, const float* rotation,
                           const float* face_orien_mat, const float* face_scaling, const float* face_orien_quat,
                           const float* d_out_xyz, const float* d_out_scaling, const float* d_out_rotation, const int32_t* order,
-                          const int32_t* face_begin, float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face, void* stream_)
+                          const int32_t* face_begin, float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face,
+                          const float* out_opacity, const float* d_out_opacity, float* d_opacity_logit, void* stream_)
 {
+    if (d_opacity_logit && !out_opacity) return fail(GAB_E_ARG, "d_opacity_logit needs out_opacity");
     if (N < 0 || F <= 0) return fail(GAB_E_ARG, "bad sizes");
     if (!d_face || !order || !face_begin) return fail(GAB_E_ARG, "gab_bind_backward_csr: NULL buffer");
     if (N > 0 && (!xyz || !log_scaling || !rotation || !face_orien_mat || !face_scaling || !face_orien_quat || !d_xyz || !d_log_scaling ||
@@ -1069,7 +1104,7 @@ int gab_bind_backward_csr(int32_t N, int32_t F, const float* xyz, const float* l
     const long long threads = 16ll * F;
     hipLaunchKernelGGL(gab::k_bind_bwd_csr, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, F, xyz, log_scaling,
                        rotation, face_orien_mat, face_scaling, face_orien_quat, d_out_xyz, d_out_scaling, d_out_rotation, order, face_begin,
-                       d_xyz, d_log_scaling, d_rotation, d_face);
+                       d_xyz, d_log_scaling, d_rotation, d_face, out_opacity, d_out_opacity, d_opacity_logit);
     LAUNCH_CHECK("k_bind_bwd_csr");
     return GAB_OK;
 }

@@ -147,6 +147,7 @@ int gsr_geom_layout(int32_t P, GsrGeomLayout* o)
     o->rect = off;          off = align_up(off + n * 8, A);
     o->tiles_touched = off; off = align_up(off + n * 4, A);
     o->clamped = off;       off = align_up(off + n, A);
+    o->visible = off;       off = align_up(off + n, A);
     o->acc = off;           off = align_up(off + n * GSR_ACC_STRIDE * 4, A);
     o->total = off + A;
     return 0;
@@ -243,6 +244,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     pa.rect = (ushort4*)(g + gl.rect);
     pa.tiles_touched = (uint32_t*)(g + gl.tiles_touched);
     pa.clamped = (uint8_t*)(g + gl.clamped);
+    pa.visible = (uint8_t*)(g + gl.visible);
     pa.acc = (float4*)(g + gl.acc);
     pa.tile_count = tile_count;
     pa.rect_total = rect_total;

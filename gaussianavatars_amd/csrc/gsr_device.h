@@ -319,6 +319,7 @@ struct PreprocessArgs {
     ushort4* __restrict__ rect;
     uint32_t* __restrict__ tiles_touched;
     uint8_t* __restrict__ clamped;
+    uint8_t* __restrict__ visible;        // [P] radii > 0
     float4* __restrict__ acc;             // [P][3] backward accumulators, zeroed here for visible splats
     uint32_t* __restrict__ tile_count;    // [tiles] zeroed here (the binning histogram of this frame)
     unsigned long long* __restrict__ rect_total;   // zeroed here; k_count sums tiles_touched into it

@@ -49,7 +49,7 @@ def _forward_state(rs, means3D, shs, colors_precomp, opacities, scales, rotation
 
     ctx = _Ctx()
     with torch.no_grad():
-        color, radii = _RasterizeGaussians.forward(ctx, *args, rs)
+        color, radii, _visible = _RasterizeGaussians.forward(ctx, *args, rs)
     geom, binning, img = ctx.saved[7], ctx.saved[8], ctx.saved[9]
     P = means3D.shape[0]
     H, W = int(rs.image_height), int(rs.image_width)

@@ -111,6 +111,8 @@ class GaussianModel:
 
     @property
     def get_opacity(self):
+        if self.binding is not None and self.binding_impl == "fused" and self.face_center is not None:
+            return self._bound()[3]   # the activation rides along with the bound transform (one launch for all four accessors)
         return torch.sigmoid(self._opacity)
 
     def get_covariance(self, scaling_modifier=1):
@@ -150,13 +152,13 @@ class GaussianModel:
         each accessor on every call (get_xyz twice per render(), gaussian_renderer/__init__.py:27,54);
         the values only change when the mesh or a leaf does, so they are cached per (mesh version,
         leaf versions) -- autograd connectivity to the leaves and the face tensors is unchanged."""
-        key = (self._mesh_version, self._xyz._version, self._scaling._version, self._rotation._version,
-               id(self._xyz), id(self._scaling), id(self._rotation), torch.is_grad_enabled())
+        key = (self._mesh_version, self._xyz._version, self._scaling._version, self._rotation._version, self._opacity._version,
+               id(self._xyz), id(self._scaling), id(self._rotation), id(self._opacity), torch.is_grad_enabled())
         if getattr(self, "_bound_key", None) != key:
             if self.binding_impl == "unfused":
                 out = (unfused.bind_xyz(self._xyz, self.binding, self.face_orien_mat, self.face_scaling, self.face_center),
                        unfused.bind_scaling(self._scaling, self.binding, self.face_scaling),
-                       unfused.bind_rotation(self._rotation, self.binding, self.face_orien_quat))
+                       unfused.bind_rotation(self._rotation, self.binding, self.face_orien_quat), torch.sigmoid(self._opacity))
             else:
                 from . import binding as fused
                 ckey = (id(self.binding), self.binding._version, self.face_center.shape[0])
@@ -164,7 +166,8 @@ class GaussianModel:
                     self._csr = fused.binding_csr(self.binding, self.face_center.shape[0])
                     self._csr_key = ckey
                 out = fused.bind_splats(self._xyz, self._scaling, self._rotation, self.binding, self.face_orien_mat,
-                                        self.face_scaling, self.face_center, self.face_orien_quat, csr=self._csr)
+                                        self.face_scaling, self.face_center, self.face_orien_quat, csr=self._csr,
+                                        opacity_logit=self._opacity)
             self._bound_cache = out
             self._bound_key = key
         return self._bound_cache

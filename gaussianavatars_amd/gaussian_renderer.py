@@ -110,7 +110,10 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
                                        opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp,
                                        **({"shs_rest": shs_rest} if shs_rest is not None else {}))
-    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+    visible = getattr(rasterizer, "visibility_filter", None)   # our rasterizer hands out radii > 0 from its forward kernel
+    if visible is None:
+        visible = radii > 0
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": visible, "radii": radii}
 
 
 def l1_loss(network_output, gt):

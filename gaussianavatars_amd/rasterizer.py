@@ -181,11 +181,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.M = M
         ctx.split = split
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img, sh_rest)
-        ctx.mark_non_differentiable(radii)
-        return color, radii
+        # render()'s visibility_filter (radii > 0) as the forward wrote it: a bool view of the state buffer, no comparison launch
+        visible = geom[gl.visible: gl.visible + P].view(torch.bool)
+        ctx.mark_non_differentiable(radii, visible)
+        return color, radii, visible
 
     @staticmethod
-    def backward(ctx, grad_out_color, _grad_radii):
+    def backward(ctx, grad_out_color, _grad_radii, _grad_visible=None):
         if grad_out_color is None:
             return (None,) * 10
         lib = _lib.gsr()
@@ -222,8 +224,9 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
                         sh_rest=None):
+    """-> (color, radii), the reference's pair."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, sh_rest)
+                                     cov3Ds_precomp, raster_settings, sh_rest)[:2]
 
 
 class GaussianRasterizer(nn.Module):
@@ -262,4 +265,8 @@ class GaussianRasterizer(nn.Module):
         scales = empty if scales is None else scales
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs, shs_rest)
+        color, radii, visible = _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                                          cov3D_precomp, rs, shs_rest)
+        # extension: `radii > 0` of THIS call as the forward kernel wrote it (what render() returns as visibility_filter)
+        self.visibility_filter = visible
+        return color, radii

@@ -62,13 +62,16 @@ int gab_flame_forward(const GabRig* rig, const float* shape, const float* expr, 
 
 /* d_shape / d_static_offset / dL_dv_shaped may be NULL.  scratch: (V,3) floats.  Every non-NULL output
  * is fully written.  `ws` must be the workspace gab_flame_forward wrote for this frame: it carries the backward's
- * accumulators, zeroed by the forward and zeroed again by this call (so the call may be repeated; no memset). */
+ * accumulators, zeroed by the forward and zeroed again by this call (so the call may be repeated; no memset).
+ * zero_*: up to 8 device buffers (HOST arrays of pointers / float counts, as gab_zero_buffers) that the first backward kernel
+ * zero-fills before anything else writes -- the full (T,k) gradient tables whose row t the d_* pointers address; 0 to skip. */
 int gab_flame_backward(const GabRig* rig, const float* shape, const float* expr, const float* rotation,
                        const float* neck, const float* jaw, const float* eyes, const float* translation,
                        const float* static_offset, const float* v_shaped, float* ws,
                        const float* dL_dverts, const float* dL_dv_shaped,
                        float* d_shape, float* d_expr, float* d_rotation, float* d_neck, float* d_jaw, float* d_eyes,
-                       float* d_translation, float* d_static_offset, float* scratch, void* stream);
+                       float* d_translation, float* d_static_offset, float* scratch,
+                       int32_t zero_count, float* const* zero_buffers_host, const int32_t* zero_sizes_host, void* stream);
 
 /* ---- per-face frames ----------------------------------------------------------------------- */
 /* d_verts_zeroed: optional (V,3) buffer the forward zero-fills on the side, to be handed to the backward as its
@@ -83,17 +86,22 @@ int gab_face_frames_backward(int32_t V, int32_t F, const float* verts, const voi
                              float* d_verts, int32_t d_verts_is_zero, void* stream);
 
 /* ---- per-splat mesh-local -> world ---------------------------------------------------------- */
+/* opacity_logit / out_opacity (N floats each, both or neither): get_opacity = sigmoid(_opacity) (scene/gaussian_model.py:158-160)
+ * evaluated by the same launch; the backward entries take out_opacity + d_out_opacity and write d_opacity_logit (all three NULL
+ * to skip).  Saves the two elementwise launches the activation costs per frame. */
 int gab_bind_forward(int32_t N, int32_t F, const float* xyz, const float* log_scaling, const float* rotation,
                      const void* binding, int32_t index_is_i64, const float* face_center, const float* face_orien_mat,
                      const float* face_scaling, const float* face_orien_quat,
-                     float* out_xyz, float* out_scaling, float* out_rotation, void* stream);
+                     float* out_xyz, float* out_scaling, float* out_rotation,
+                     const float* opacity_logit, float* out_opacity, void* stream);
 /* d_face: 17*F floats, four contiguous blocks  center (F,3) | orien_mat (F,3,3) | scaling (F,1) | orien_quat (F,4)
  * (so each block is directly the gradient tensor of one face attribute), fully written (zero-filled, then accumulated). */
 int gab_bind_backward(int32_t N, int32_t F, const float* xyz, const float* log_scaling, const float* rotation,
                       const void* binding, int32_t index_is_i64, const float* face_center, const float* face_orien_mat,
                       const float* face_scaling, const float* face_orien_quat,
                       const float* d_out_xyz, const float* d_out_scaling, const float* d_out_rotation,
-                      float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face /*17*F, see above*/, void* stream);
+                      float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face /*17*F, see above*/,
+                      const float* out_opacity, const float* d_out_opacity, float* d_opacity_logit, void* stream);
 
 /* Atomic-free, deterministic variant of gab_bind_backward.  `order` (int32 N): splat indices sorted by face;
  * `face_begin` (int32 F+1): CSR offsets into `order`.  Both depend only on `binding` (build them once per
@@ -102,7 +110,8 @@ int gab_bind_backward_csr(int32_t N, int32_t F, const float* xyz, const float* l
                           const float* face_orien_mat, const float* face_scaling, const float* face_orien_quat,
                           const float* d_out_xyz, const float* d_out_scaling, const float* d_out_rotation,
                           const int32_t* order, const int32_t* face_begin,
-                          float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face /*17*F, same four blocks*/, void* stream);
+                          float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face /*17*F, same four blocks*/,
+                          const float* out_opacity, const float* d_out_opacity, float* d_opacity_logit, void* stream);
 
 /* Utility: zero-fills up to 8 device buffers (sizes in floats) with ONE launch.  `buffers_host` / `sizes_host` are
  * HOST arrays of device pointers / element counts.  Used to build the full (T,k) gradient tables of the per-timestep

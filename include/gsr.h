@@ -76,6 +76,8 @@ typedef struct GsrGeomLayout {
     size_t rect;           /* uint16 [4P]  tile rect min.x min.y max.x max.y */
     size_t tiles_touched;  /* uint32 [P]                                   */
     size_t clamped;        /* uint8  [P]   bit c set <=> channel c clamped  */
+    size_t visible;        /* uint8  [P]   1 <=> radii > 0 (render()'s visibility_filter, written by the forward so that no
+                              separate comparison kernel is needed)                                    */
     size_t acc;            /* float  [12P] backward accumulators of the screen-space gradients (dcolor 3, dmean2D 2,
                               dconic 3, dopacity 1, pad 3).  The forward zeroes the entries of visible splats and the
                               backward zeroes them again after consuming them, so a state is always ready for a

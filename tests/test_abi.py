@@ -38,7 +38,7 @@ def test_layouts_are_disjoint_and_aligned():
     assert lib.gsr_image_layout(550, 802, C.byref(il)) == 0
     P, cap, tiles, HW = 100_000, 3_000_000, 35 * 51, 550 * 802
     segs = [(gl.depths, 4 * P), (gl.grec, 48 * P), (gl.cov3D, 24 * P),
-            (gl.rect, 8 * P), (gl.tiles_touched, 4 * P), (gl.clamped, P), (gl.acc, 48 * P)]
+            (gl.rect, 8 * P), (gl.tiles_touched, 4 * P), (gl.clamped, P), (gl.visible, P), (gl.acc, 48 * P)]
     _check(segs, gl.total)
     segs = [(bl.keys, 8 * cap), (bl.point_list, 4 * cap), (bl.qrecords, 4 * 48 * cap), (bl.qcount, 16 * tiles), (bl.ranges, 8 * tiles),
             (bl.tile_count, 4 * tiles), (bl.tile_start, 4 * tiles), (bl.tile_cursor, 4 * tiles)]

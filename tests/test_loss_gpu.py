@@ -146,6 +146,7 @@ def test_training_iteration_statistics_and_loss():
         g.select_mesh_by_timestep(it)
         pkg = render(cam, g, bench.Pipe, bg)
         image, vsp, radii = pkg["render"], pkg["viewspace_points"], pkg["radii"]
+        assert pkg["visibility_filter"].dtype == torch.bool and torch.equal(pkg["visibility_filter"], radii > 0)
         l1, ss = loss.l1_ssim(image, gt)
         total = (1.0 - lam) * l1 + lam * (1.0 - ss)
         # the same loss in torch on a detached copy of the image
