@@ -70,6 +70,9 @@ def build_unbound_scene(device, n_splats, sh_degree, width, height):
     return g, cam
 
 
+SSIM_STEP = False   # --workload train: the loss and statistics lines of train.py:131-132,197-198 ride along
+
+
 def one_step(g, cam, bg, target, t, train):
     from gaussianavatars_amd.gaussian_renderer import l1_loss, render
 
@@ -78,6 +81,14 @@ def one_step(g, cam, bg, target, t, train):
     pkg = render(cam, g, Pipe, bg)
     if not train:
         return pkg["render"].sum() * 0  # keep a device scalar for the (optional) all-reduce
+    if SSIM_STEP:
+        from gaussianavatars_amd.loss import l1_ssim
+
+        l1, ss = l1_ssim(pkg["render"], target)
+        loss = 0.8 * l1 + 0.2 * (1.0 - ss)            # lambda_dssim = 0.2 (arguments/__init__.py)
+        loss.backward()
+        g.update_densification_stats(pkg["viewspace_points"], pkg["radii"])
+        return loss.detach()
     loss = l1_loss(pkg["render"], target)
     loss.backward()
     return loss.detach()
@@ -139,7 +150,7 @@ def main():
     ap.add_argument("--width", type=int, default=550)
     ap.add_argument("--height", type=int, default=802)
     ap.add_argument("--frames", type=int, default=300)
-    ap.add_argument("--workload", choices=["cfg3", "cfg2", "cfg4", "cfg5"], default="cfg3",
+    ap.add_argument("--workload", choices=["cfg3", "cfg2", "cfg4", "cfg5", "train"], default="cfg3",
                     help="BASELINE.json configs: cfg3 = configs[2] fwd+bwd 100k (the metric, default); cfg2 = configs[1] forward; "
                          "cfg4 = configs[3] 200k-splat 300-frame sequence fwd+bwd; cfg5 = configs[4] 2M-splat 1600x1100 forward stress")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -147,6 +158,9 @@ def main():
     args = ap.parse_args()
     if args.workload == "cfg3" and args.mode == "render":
         args.workload = "cfg2"
+    if args.workload == "train":   # not a BASELINE config: cfg3 plus the fused L1+SSIM loss and the densification statistics (N3)
+        global SSIM_STEP
+        SSIM_STEP = True
     if args.workload == "cfg2":
         args.mode = "render"
     elif args.workload == "cfg4":
@@ -286,7 +300,8 @@ def main():
             vis = vis_cpu / N
         fps = n_gpus * args.steps / elapsed
         out = {
-            "metric": ("frames/sec fwd+bwd" if train else "frames/sec fwd") + " @%dk SH-3 splats %dx%d" % (N // 1000, args.height, args.width),
+            "metric": ("frames/sec fwd+bwd" if train else "frames/sec fwd") + (" (L1+SSIM loss, densification stats)" if SSIM_STEP else "") +
+                      " @%dk SH-3 splats %dx%d" % (N // 1000, args.height, args.width),
             "value": round(fps, 2),
             "unit": "frames/s",
             "n_gpus": n_gpus,
@@ -304,7 +319,9 @@ def main():
                              "cfg2": "BASELINE configs[1]: %d mesh-bound SH-3 splats, %dx%d (HxW), select_mesh_by_timestep + render, no_grad",
                              "cfg4": "BASELINE configs[3]: %d splats bound to the 5143-vertex synthetic FLAME rig, 300-frame expression "
                                      "sequence, %dx%d (HxW), fwd+bwd, frames sharded over the ranks",
-                             "cfg5": "BASELINE configs[4]: %d un-bound SH-3 splats, %dx%d (HxW), forward only (stress / roofline run)"}[
+                             "cfg5": "BASELINE configs[4]: %d un-bound SH-3 splats, %dx%d (HxW), forward only (stress / roofline run)",
+                             "train": "cfg3 + train.py:131-132,197-198: %d mesh-bound SH-3 splats, %dx%d (HxW), fused L1+SSIM loss vs a white "
+                                      "target, backward, densification statistics; no optimiser step"}[
                                  args.workload] % (N, args.height, args.width),
                 "splats": N, "width": args.width, "height": args.height, "sh_degree": 3,
                 "num_rendered": I, "num_binned": I_binned, "tile_culling": bool(info.get("tile_culling", False)),
