@@ -267,6 +267,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
         HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
     }
     const bool cull = settings->tile_culling != 0;
+    const bool write_lists = settings->tile_culling != 1;   // 1 = production: the sorted key / point lists are not materialised
     if (pblocks > 0) {
         TIMED(GSR_K_COUNT, stream);
         hipLaunchKernelGGL(cull ? gsr::k_count<true> : gsr::k_count<false>, dim3(bin_blocks), dim3(256), hist_bytes, stream, P, gx, tiles,
@@ -311,7 +312,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
         TIMED(GSR_K_TILE_SORT, stream);
         auto sort_class = [&](auto kernel, int threads, uint32_t n_lo, uint32_t n_hi) {
             hipLaunchKernelGGL(kernel, dim3(tiles), dim3(threads), 0, stream, n_lo, n_hi, gx, (const uint32_t*)tile_order,
-                               (const uint32_t*)tile_count, (const uint32_t*)tile_start, keys, point_list, qrecords, qcount,
+                               (const uint32_t*)tile_count, (const uint32_t*)tile_start, keys, write_lists ? point_list : nullptr, qrecords, qcount,
                                (const float4*)pa.grec, cap,
                                (const unsigned long long*)total_dev);
         };

@@ -631,8 +631,10 @@ __device__ __forceinline__ void epilogue_striped(const u64 (&key)[EPT], uint32_t
             const uint32_t i = (uint32_t)c * THREADS + (uint32_t)tid;
             if (i < n) {
                 const uint32_t idx = (uint32_t)kk[k];
-                seg[i] = tile_hi | (kk[k] >> 32);   // reference-format key: tile id | depth bits
-                point_list[start + i] = idx;
+                if (point_list) {   // the reference-format lists are a parity/debug artefact: nothing downstream reads them
+                    seg[i] = tile_hi | (kk[k] >> 32);   // reference-format key: tile id | depth bits
+                    point_list[start + i] = idx;
+                }
                 const uint32_t m = msk[c];
                 const float4 r0 = g0[k];
                 const float4 r1 = g1[k];
@@ -762,8 +764,10 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
         if (valid) {
             const unsigned long long k = in_lds ? skeys[i] : seg[i];
             const uint32_t idx = (uint32_t)k;
-            seg[i] = tile_hi | (k >> 32);
-            point_list[start + i] = idx;
+            if (point_list) {
+                seg[i] = tile_hi | (k >> 32);
+                point_list[start + i] = idx;
+            }
             r0 = grec[3 * (size_t)idx + 0];
             r1 = grec[3 * (size_t)idx + 1];
             r2 = make_float4(grec[3 * (size_t)idx + 2].x, __uint_as_float(idx), __uint_as_float(i), 0.f);

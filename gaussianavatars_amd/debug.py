@@ -23,7 +23,7 @@ def forward_state(rs: GaussianRasterizationSettings, means3D, shs, colors_precom
     instance lists so that keys / point_list / ranges / n_contrib compare with the oracle index for index."""
     from . import rasterizer as _R
 
-    prev = _R.set_tile_culling(tile_culling)
+    prev = _R.set_tile_culling(2 if tile_culling else 0)   # 2: culled, but the sorted lists are still written for inspection
     try:
         return _forward_state(rs, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)
     finally:

@@ -44,17 +44,17 @@ class GaussianRasterizationSettings(NamedTuple):
 # On by default: instances that cannot reach a tile are not binned (same image / radii / gradients, about a third
 # fewer keys to sort).  GSR_TILE_CULLING=0 or set_tile_culling(False) keeps the reference's rect-based lists, which is
 # what the parity tests compare with the oracle index for index.
-_tile_culling = os.environ.get("GSR_TILE_CULLING", "1") != "0"
+_tile_culling = int(os.environ.get("GSR_TILE_CULLING", "1"))
 
 
 def set_tile_culling(enabled: bool) -> bool:
     """Process-wide switch; returns the previous value."""
     global _tile_culling
-    prev, _tile_culling = _tile_culling, bool(enabled)
+    prev, _tile_culling = _tile_culling, int(enabled)   # 0 off, 1 on (production), 2 on + sorted lists kept (debug)
     return prev
 
 
-def get_tile_culling() -> bool:
+def get_tile_culling() -> int:
     return _tile_culling
 
 

@@ -59,8 +59,11 @@ typedef struct GsrSettings {
                                  !=0: only the tiles the splat's {alpha >= 1/255} ellipse can reach get one.  The dropped
                                  instances can never contribute to a pixel, so image, radii and gradients are the same
                                  bits; the binning state is the culled subsequence of the reference's and num_rendered
-                                 counts it (about 1/3 fewer instances to sort).  The rect-based count stays available at
-                                 byte 8 of the binning buffer. */
+                                 counts it (20-26 % fewer instances to sort).  The rect-based count stays available at
+                                 byte 8 of the binning buffer.
+                                 1: production -- additionally the reference-format sorted `keys` / `point_list` arrays are
+                                    not written (nothing downstream reads them; the blend walks the quadrant streams);
+                                 2: culled, lists written (what the subsequence parity tests inspect). */
 } GsrSettings;
 
 /* Byte offsets of the arrays inside the three opaque state buffers.  The state buffers play the
