@@ -42,7 +42,8 @@ __device__ __forceinline__ float row_sum(float v)
 
 __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
                                                      const uint32_t* __restrict__ qcount,
-                                                     const float4* __restrict__ qrecords, const float* __restrict__ final_T,
+                                                     const float4* __restrict__ qrecords, const uint32_t* __restrict__ qpos,
+                                                     const float* __restrict__ final_T,
                                                      const uint32_t* __restrict__ n_contrib_q, const float* __restrict__ dL_dpix,
                                                      float* __restrict__ acc /* [P][GSR_ACC_STRIDE] */)
 {
@@ -59,7 +60,8 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
     const uint2 range = ranges[tile];
     const uint32_t nt = range.y - range.x;
     const int nq = (int)qcount[4 * tile + wave];
-    const float4* __restrict__ rec = qrecords + (size_t)3 * ((size_t)4 * range.x + (size_t)wave * nt);
+    const float4* __restrict__ rec = qrecords + (size_t)3 * range.x;                         // the tile's records (sorted)
+    const uint32_t* __restrict__ qp = qpos + (size_t)4 * range.x + (size_t)wave * nt;       // this quadrant's positions into them
 
     const int pix_id = W * pyi + pxi;
     const size_t HW = (size_t)H * W;
@@ -85,10 +87,15 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
     else if (jmax > 1024) __builtin_amdgcn_s_setprio(2);
     else if (jmax > 512) __builtin_amdgcn_s_setprio(1);   // deepest contributor of any pixel of this wave
     struct Rec2 { float rx[2], ry[2], ca[2], cb[2], cc[2], op[2], cr[2], cg[2], cbl[2]; uint32_t id[2]; };
-    auto load2 = [&](int jp, Rec2& R) {
+    struct Pos2 { uint32_t p[2]; };
+    auto loadp = [&](int jp, Pos2& P) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) P.p[u] = qp[max(0, min(jp + u, nq - 1))];
+    };
+    auto load2 = [&](const Pos2& P, Rec2& R) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int j = min(jp + u, nq - 1);
+            const size_t j = (size_t)P.p[u];
             const float4 r0 = rec[3 * j + 0];
             const float4 r1 = rec[3 * j + 1];
             const float4 r2 = rec[3 * j + 2];
@@ -163,13 +170,20 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
     int jb = ((jmax + RB - 1) / RB) * RB - RB;
     if (jb >= 0) {
         Rec2 A, B;
-        load2(jb + 2, A);
+        Pos2 PA, PB;
+        // two-level scalar fetch (as the forward): positions two pairs ahead, records one pair ahead
+        loadp(jb + 2, PA);
+        loadp(jb, PB);
+        asm volatile("" ::"s"(PA.p[0]), "s"(PB.p[0]) : "memory");
+        load2(PA, A);
         for (; jb >= 0; jb -= RB) {
-            asm volatile("" ::"s"(A.rx[0]) : "memory");
-            load2(jb, B);
+            asm volatile("" ::"s"(A.rx[0]), "s"(PB.p[0]) : "memory");
+            load2(PB, B);
+            loadp(jb - RB + 2, PA);          // clamped inside loadp when the walk is about to end
             const bool h1 = grad2(jb + 2, A, 2);
-            asm volatile("" ::"s"(B.rx[0]) : "memory");
-            if (jb - RB >= 0) load2(jb - RB + 2, A);
+            asm volatile("" ::"s"(B.rx[0]), "s"(PA.p[0]) : "memory");
+            if (jb - RB >= 0) load2(PA, A);
+            loadp(jb - RB, PB);
             const bool h0 = grad2(jb, B, 0);
             if (!(h0 || h1)) continue;
             // transposed reduction: rows 0..3 of t[c] <- records 0, 2, 1, 3

@@ -548,7 +548,7 @@ __device__ __forceinline__ uint32_t quadrant_mask(float2 p, float4 co, float ox,
 template <int THREADS, int EPT>
 __device__ __forceinline__ void epilogue_striped(const u64 (&key)[EPT], uint32_t n, uint32_t tile, uint32_t start, float ox, float oy,
                                                  u64* __restrict__ seg, uint32_t* __restrict__ point_list, float4* __restrict__ qbase,
-                                                 uint32_t* __restrict__ qcount, const float4* __restrict__ grec,
+                                                 uint32_t* __restrict__ qpbase, uint32_t* __restrict__ qcount, const float4* __restrict__ grec,
                                                  u64* __restrict__ sk, uint32_t (*__restrict__ cntw)[EPT * (THREADS / 64) + 1], int tid)
 {
     constexpr int NW = THREADS / 64, NE = EPT * NW;   // waves, (chunk, wave) counters per quadrant
@@ -636,17 +636,17 @@ __device__ __forceinline__ void epilogue_striped(const u64 (&key)[EPT], uint32_t
                     point_list[start + i] = idx;
                 }
                 const uint32_t m = msk[c];
-                const float4 r0 = g0[k];
-                const float4 r1 = g1[k];
-                const float4 r2 = make_float4(g2x[k], __uint_as_float(idx), __uint_as_float(i), 0.f);
+                // the tile's record array, sorted order, written ONCE per instance (consecutive lanes -> consecutive 48-byte
+                // records); the quadrant streams carry 4-byte positions into it
+                float4* dst = qbase + (size_t)3 * i;
+                dst[0] = g0[k];
+                dst[1] = g1[k];
+                dst[2] = make_float4(g2x[k], __uint_as_float(idx), 0.f, 0.f);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if ((m >> q) & 1u) {
                         const uint32_t pos = cntw[q][c * NW + wid] + ((rank[c] >> (8 * q)) & 0xFFu);
-                        float4* dst = qbase + (size_t)3 * ((size_t)q * n + pos);
-                        dst[0] = r0;
-                        dst[1] = r1;
-                        dst[2] = r2;
+                        qpbase[(size_t)q * n + pos] = i;
                     }
                 }
             }
@@ -719,7 +719,8 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
                                                         const uint32_t* __restrict__ tile_count,
                                                     const uint32_t* __restrict__ tile_start, unsigned long long* __restrict__ keys,
                                                     uint32_t* __restrict__ point_list, float4* __restrict__ qrecords,
-                                                    uint32_t* __restrict__ qcount, const float4* __restrict__ grec,
+                                                    uint32_t* __restrict__ qpos, uint32_t* __restrict__ qcount,
+                                                    const float4* __restrict__ grec,
                                                     unsigned long long capacity, const unsigned long long* __restrict__ total_dev)
 {
     __shared__ unsigned long long skeys[KEYS];
@@ -738,16 +739,19 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
     unsigned long long* seg = keys + start;
     const bool in_lds = n <= (uint32_t)KEYS;
     const float ox = (float)((tile % (uint32_t)gx) * GSR_BLOCK_X), oy = (float)((tile / (uint32_t)gx) * GSR_BLOCK_Y);
-    float4* const qbase = qrecords + (size_t)3 * 4 * start;
+    float4* const qbase = qrecords + (size_t)3 * start;     // the tile's record array (one 48-byte record per instance, sorted)
+    uint32_t* const qpbase = qpos + (size_t)4 * start;      // four quadrant streams of positions into it, n slots each
     if (in_lds) {
         static_assert(EPT == 8 || EPT == 16, "register sort holds 8 or 16 keys per thread");
         u64 key[EPT];
         block_sort_regs<THREADS, EPT>(key, skeys, seg, n, tid);
-        epilogue_striped<THREADS, EPT>(key, n, tile, start, ox, oy, seg, point_list, qbase, qcount, grec, skeys, cntw, tid);
+        epilogue_striped<THREADS, EPT>(key, n, tile, start, ox, oy, seg, point_list, qbase, qpbase, qcount, grec, skeys, cntw, tid);
         return;
     } else {
-        // more entries than this class holds in LDS: chunked register sorts + global merge passes
+        // more entries than this class holds in LDS: chunked register sorts + global merge passes (scratch: the tile's
+        // still-unwritten record array, 48 n bytes for n 8-byte keys)
         oversize_sort<THREADS, EPT>(seg, reinterpret_cast<u64*>(qbase), skeys, n, tid);
+        __syncthreads();
     }
     // ---- epilogue: reference-format keys / point list, and the four 8x8-quadrant record streams --------
     // A record goes to quadrant q only if the exact ellipse {alpha >= 1/255} of the splat can reach a pixel
@@ -770,7 +774,10 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
             }
             r0 = grec[3 * (size_t)idx + 0];
             r1 = grec[3 * (size_t)idx + 1];
-            r2 = make_float4(grec[3 * (size_t)idx + 2].x, __uint_as_float(idx), __uint_as_float(i), 0.f);
+            r2 = make_float4(grec[3 * (size_t)idx + 2].x, __uint_as_float(idx), 0.f, 0.f);
+            qbase[(size_t)3 * i + 0] = r0;
+            qbase[(size_t)3 * i + 1] = r1;
+            qbase[(size_t)3 * i + 2] = r2;
             const uint32_t m = quadrant_mask(make_float2(r0.x, r0.y), make_float4(r0.z, r0.w, r1.x, r1.y), ox, oy);
 #pragma unroll
             for (int q = 0; q < 4; ++q) f[q] = (m >> q) & 1u;
@@ -792,12 +799,7 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
                 if (w < wid) off += cw;
                 tot += cw;
             }
-            if (f[q]) {
-                float4* dst = qbase + (size_t)3 * ((size_t)q * n + off + prefix[q]);
-                dst[0] = r0;
-                dst[1] = r1;
-                dst[2] = r2;
-            }
+            if (f[q]) qpbase[(size_t)q * n + off + prefix[q]] = i;
             running[q] += tot;
         }
         __syncthreads();
@@ -806,13 +808,13 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
 }
 
 template __global__ void k_tile_sort<GSR_SORT_SMALL_KEYS, 256>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
-                                                                float4*, uint32_t*, const float4*, unsigned long long,
+                                                                float4*, uint32_t*, uint32_t*, const float4*, unsigned long long,
                                                                 const unsigned long long*);
 template __global__ void k_tile_sort<GSR_SORT_LDS_KEYS, 1024>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
-                                                               float4*, uint32_t*, const float4*, unsigned long long,
+                                                               float4*, uint32_t*, uint32_t*, const float4*, unsigned long long,
                                                                const unsigned long long*);
 template __global__ void k_tile_sort<GSR_SORT_XL_KEYS, 1024>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
-                                                              float4*, uint32_t*, const float4*, unsigned long long,
+                                                              float4*, uint32_t*, uint32_t*, const float4*, unsigned long long,
                                                               const unsigned long long*);
 
 // ------------------------------------------------------------------------------------------
@@ -823,7 +825,8 @@ template __global__ void k_tile_sort<GSR_SORT_XL_KEYS, 1024>(uint32_t, uint32_t,
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
                                                  const uint32_t* __restrict__ qcount,
-                                                 const float4* __restrict__ qrecords, float* __restrict__ final_T,
+                                                 const float4* __restrict__ qrecords, const uint32_t* __restrict__ qpos,
+                                                 float* __restrict__ final_T,
                                                  uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ n_contrib_q,
                                                  float* __restrict__ out_color, unsigned long long capacity,
                                                  const unsigned long long* __restrict__ total_dev)
@@ -843,7 +846,8 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     const uint2 range = ranges[tile];
     const uint32_t nt = range.y - range.x;
     const int n = (int)qcount[4 * tile + wave];
-    const float4* __restrict__ rec = qrecords + (size_t)3 * ((size_t)4 * range.x + (size_t)wave * nt);
+    const float4* __restrict__ rec = qrecords + (size_t)3 * range.x;                         // the tile's records (sorted)
+    const uint32_t* __restrict__ qp = qpos + (size_t)4 * range.x + (size_t)wave * nt;       // this quadrant's positions into them
 
     float T = 1.0f;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
@@ -861,10 +865,16 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     constexpr int RB = 3;
     constexpr int TAIL_LANES = 8;     // switch to record-parallel mode when this few pixels are still open
     struct Rec4 { float rx[RB], ry[RB], ca[RB], cb[RB], cc[RB], op[RB], cr[RB], cg[RB], cbl[RB]; };
-    auto load4 = [&](int jb, Rec4& R) {
+    struct Pos4 { uint32_t p[RB]; };
+    // two-level scalar fetch: stream positions (4 bytes each) two batches ahead, the records they point at one batch ahead
+    auto loadp = [&](int jb, Pos4& P) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) P.p[u] = qp[min(jb + u, n - 1)];   // past the end: re-read the last one, masked out in blend4
+    };
+    auto load4 = [&](const Pos4& P, Rec4& R) {
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
-            const int j = min(jb + u, n - 1);   // past the end: re-read the last record, masked out in blend4
+            const size_t j = (size_t)P.p[u];
             const float4 r0 = rec[3 * j + 0];
             const float4 r1 = rec[3 * j + 1];
             const float r2x = rec[3 * j + 2].x;
@@ -910,15 +920,22 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     int j0 = 0;
     if (n > 0) {
         Rec4 A, B;
-        load4(0, A);
+        Pos4 PA, PB;
+        loadp(0, PA);
+        loadp(RB, PB);
+        asm volatile("" ::"s"(PA.p[0]), "s"(PB.p[0]) : "memory");
+        load4(PA, A);
         while (j0 < n && keep_going(j0)) {
-            asm volatile("" ::"s"(A.rx[0]) : "memory");
-            if (j0 + RB < n) load4(j0 + RB, B);
+            // A holds batch j0 (issued a batch ago), PB the positions of batch j0+RB (issued two batches ago)
+            asm volatile("" ::"s"(A.rx[0]), "s"(PB.p[0]) : "memory");
+            if (j0 + RB < n) load4(PB, B);
+            if (j0 + 2 * RB < n) loadp(j0 + 2 * RB, PA);
             blend4(j0, A);
             j0 += RB;
             if (!(j0 < n && keep_going(j0))) break;
-            asm volatile("" ::"s"(B.rx[0]) : "memory");
-            if (j0 + RB < n) load4(j0 + RB, A);
+            asm volatile("" ::"s"(B.rx[0]), "s"(PA.p[0]) : "memory");
+            if (j0 + RB < n) load4(PA, A);
+            if (j0 + 2 * RB < n) loadp(j0 + 2 * RB, PB);
             blend4(j0, B);
             j0 += RB;
         }
@@ -946,7 +963,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
             for (int c0 = j0; c0 < n && !donep; c0 += GSR_WAVE) {
                 const int j = c0 + lane;
                 const bool valid = j < n;
-                const int jc = valid ? j : n - 1;
+                const size_t jc = (size_t)qp[valid ? j : n - 1];
                 const float4 r0 = rec[3 * jc + 0];
                 const float4 r1 = rec[3 * jc + 1];
                 const float4 r2 = rec[3 * jc + 2];
@@ -974,8 +991,8 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     }
     if (inside) {
         const int pix_id = W * pyi + pxi;
-        // the reference's n_contrib counts positions in the TILE list: look it up from the last record used
-        const uint32_t last_contributor = last_q ? __float_as_uint(rec[3 * (last_q - 1) + 2].z) + 1u : 0u;
+        // the reference's n_contrib counts positions in the TILE list: that is what the stream holds
+        const uint32_t last_contributor = last_q ? qp[last_q - 1] + 1u : 0u;
         final_T[pix_id] = T;
         n_contrib[pix_id] = last_contributor;
         n_contrib_q[pix_id] = last_q;

@@ -18,14 +18,13 @@ for wl in ("cfg3", "cfg5"):
                                            cam.camera_center, False, False)
         hs = forward_state(rs, g.get_xyz, g.get_features, None, g.get_opacity, g.get_scaling, g.get_rotation, None)
     I = hs["num_rendered"]
-    qrec = hs["qrecords"].cpu().numpy(); qcnt = hs["qcount"].cpu().numpy().astype(np.int64); rng = hs["ranges"].cpu().numpy().astype(np.int64)
+    qpos = hs["qpos"].cpu().numpy().astype(np.int64); qcnt = hs["qcount"].cpu().numpy().astype(np.int64); rng = hs["ranges"].cpu().numpy().astype(np.int64)
     surv = 0; pairs = int(qcnt.sum())
     for t in range(rng.shape[0]):
         n, start = rng[t, 1] - rng[t, 0], rng[t, 0]
         if n == 0: continue
         seen = np.zeros(n, bool)
         for q in range(4):
-            r = qrec[4 * start + q * n: 4 * start + q * n + qcnt[t, q]]
-            seen[r[:, 10].view(np.uint32)] = True
+            seen[qpos[4 * start + q * n: 4 * start + q * n + qcnt[t, q]]] = True
         surv += int(seen.sum())
     print(wl, "I", I, "tile-level survivors", surv, "%.3f" % (surv / I), "quadrant pairs", pairs, "%.3f" % (pairs / (4 * I)))
