@@ -558,20 +558,38 @@ __device__ __forceinline__ void epilogue_striped(const u64 (&key)[EPT], uint32_t
     for (int k = 0; k < EPT; ++k) sk[tid * EPT + k] = key[k];
     __syncthreads();
     uint32_t msk[EPT], rank[EPT];   // rank: 4 x 8-bit in-wave exclusive ranks (0..63)
+    const u64 tile_hi = (u64)tile << 32;
+    // pass 1: gather each instance's record ONCE, write it to the tile's record array (consecutive lanes -> consecutive
+    // 48-byte records) and the reference-format lists, and evaluate its quadrant mask / in-wave ranks
 #pragma unroll
     for (int h = 0; h < EPT / 4; ++h) {
         float4 g0[4], g1[4];
+        float g2x[4];
+        u64 kk[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t i = (uint32_t)(4 * h + k) * THREADS + (uint32_t)tid;
-            const uint32_t idx = i < n ? (uint32_t)sk[i] : 0u;
+            kk[k] = i < n ? sk[i] : 0ull;
+            const uint32_t idx = (uint32_t)kk[k];
             g0[k] = grec[3 * (size_t)idx + 0];
             g1[k] = grec[3 * (size_t)idx + 1];
+            g2x[k] = grec[3 * (size_t)idx + 2].x;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = 4 * h + k;
             const uint32_t i = (uint32_t)c * THREADS + (uint32_t)tid;
+            if (i < n) {
+                const uint32_t idx = (uint32_t)kk[k];
+                if (point_list) {   // the reference-format lists are a parity/debug artefact: nothing downstream reads them
+                    seg[i] = tile_hi | (kk[k] >> 32);   // reference-format key: tile id | depth bits
+                    point_list[start + i] = idx;
+                }
+                float4* dst = qbase + (size_t)3 * i;
+                dst[0] = g0[k];
+                dst[1] = g1[k];
+                dst[2] = make_float4(g2x[k], __uint_as_float(idx), 0.f, 0.f);
+            }
             const uint32_t m = i < n ? quadrant_mask(make_float2(g0[k].x, g0[k].y), make_float4(g0[k].z, g0[k].w, g1[k].x, g1[k].y), ox, oy) : 0u;
             msk[c] = m;
             uint32_t r = 0;
@@ -610,45 +628,16 @@ __device__ __forceinline__ void epilogue_striped(const u64 (&key)[EPT], uint32_t
         if (lane == 63) cntw[wid][NE] = incl;   // total
     }
     __syncthreads();
-    const u64 tile_hi = (u64)tile << 32;
+    // pass 2: the quadrant streams get the positions (4 bytes per (instance, quadrant) pair), stable order
 #pragma unroll
-    for (int h = 0; h < EPT / 4; ++h) {
-        float4 g0[4], g1[4];
-        float g2x[4];
-        u64 kk[4];
+    for (int c = 0; c < EPT; ++c) {
+        const uint32_t i = (uint32_t)c * THREADS + (uint32_t)tid;
+        const uint32_t m = msk[c];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t i = (uint32_t)(4 * h + k) * THREADS + (uint32_t)tid;
-            kk[k] = i < n ? sk[i] : 0ull;
-            const uint32_t idx = (uint32_t)kk[k];
-            g0[k] = grec[3 * (size_t)idx + 0];
-            g1[k] = grec[3 * (size_t)idx + 1];
-            g2x[k] = grec[3 * (size_t)idx + 2].x;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = 4 * h + k;
-            const uint32_t i = (uint32_t)c * THREADS + (uint32_t)tid;
-            if (i < n) {
-                const uint32_t idx = (uint32_t)kk[k];
-                if (point_list) {   // the reference-format lists are a parity/debug artefact: nothing downstream reads them
-                    seg[i] = tile_hi | (kk[k] >> 32);   // reference-format key: tile id | depth bits
-                    point_list[start + i] = idx;
-                }
-                const uint32_t m = msk[c];
-                // the tile's record array, sorted order, written ONCE per instance (consecutive lanes -> consecutive 48-byte
-                // records); the quadrant streams carry 4-byte positions into it
-                float4* dst = qbase + (size_t)3 * i;
-                dst[0] = g0[k];
-                dst[1] = g1[k];
-                dst[2] = make_float4(g2x[k], __uint_as_float(idx), 0.f, 0.f);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if ((m >> q) & 1u) {
-                        const uint32_t pos = cntw[q][c * NW + wid] + ((rank[c] >> (8 * q)) & 0xFFu);
-                        qpbase[(size_t)q * n + pos] = i;
-                    }
-                }
+        for (int q = 0; q < 4; ++q) {
+            if ((m >> q) & 1u) {
+                const uint32_t pos = cntw[q][c * NW + wid] + ((rank[c] >> (8 * q)) & 0xFFu);
+                qpbase[(size_t)q * n + pos] = i;
             }
         }
     }
