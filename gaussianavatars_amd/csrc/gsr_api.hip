@@ -169,6 +169,7 @@ int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, GsrBinni
     o->tile_start = off;  off = align_up(off + tiles * 4, A);
     o->tile_cursor = off; off = align_up(off + tiles * 4, A);
     o->tile_order = off;  off = align_up(off + tiles * 4, A);
+    o->block_hist = off;  off = align_up(off + (tiles > (size_t)GSR_LDS_HIST_TILES ? 0 : (size_t)GSR_BIN_BLOCKS * tiles * 4), A);
     o->total = off + A;
     return 0;
 }
@@ -258,7 +259,8 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     }
 
     // binning workgroups: each owns a contiguous chunk of splats and an LDS histogram over the tiles
-    const int bin_blocks = pblocks < 256 ? pblocks : 256;
+    const int bin_blocks = pblocks < GSR_BIN_BLOCKS ? pblocks : GSR_BIN_BLOCKS;
+    uint32_t* block_hist = (uint32_t*)(b + bl.block_hist);
     // (grids beyond GSR_LDS_HIST_TILES tiles -- past ~3200x3200 px -- fall back to per-instance L2 atomics)
     const size_t hist_bytes = tiles > GSR_LDS_HIST_TILES ? 0 : (size_t)tiles * sizeof(uint32_t);
     if (hist_bytes > 48 * 1024) {
@@ -272,7 +274,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     if (pblocks > 0) {
         TIMED(GSR_K_COUNT, stream);
         hipLaunchKernelGGL(cull ? gsr::k_count<true> : gsr::k_count<false>, dim3(bin_blocks), dim3(256), hist_bytes, stream, P, gx, tiles,
-                           (const ushort4*)pa.rect, (const uint32_t*)pa.tiles_touched, (const float4*)pa.grec, tile_count, rect_total);
+                           (const ushort4*)pa.rect, (const uint32_t*)pa.tiles_touched, (const float4*)pa.grec, tile_count, rect_total, block_hist);
         KERNEL_CHECK("k_count", stream, dbg);
     }
 
@@ -305,7 +307,8 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
         TIMED(GSR_K_SCATTER, stream);
         hipLaunchKernelGGL(cull ? gsr::k_scatter<true> : gsr::k_scatter<false>, dim3(bin_blocks), dim3(256), hist_bytes, stream, P, gx, tiles,
                            (const float*)pa.depths, (const ushort4*)pa.rect, (const uint32_t*)pa.tiles_touched, (const float4*)pa.grec,
-                           (const uint32_t*)tile_start, tile_cursor, keys, cap, (const unsigned long long*)total_dev);
+                           (const uint32_t*)tile_start, tile_cursor, keys, cap, (const unsigned long long*)total_dev,
+                           (const uint32_t*)block_hist);
         KERNEL_CHECK("k_scatter", stream, dbg);
     }
     {

@@ -354,11 +354,11 @@ __global__ void k_tile_scan(int tiles, const uint32_t* tile_count, uint32_t* til
                             uint32_t* tile_order, unsigned long long* total_dev, unsigned long long* mailbox, unsigned long long seq);
 template <bool CULL>
 __global__ void k_count(int P, int gx, int tiles, const ushort4* rect, const uint32_t* tiles_touched, const float4* grec, uint32_t* tile_count,
-                        unsigned long long* rect_total);
+                        unsigned long long* rect_total, uint32_t* block_hist);
 template <bool CULL>
 __global__ void k_scatter(int P, int gx, int tiles, const float* depths, const ushort4* rect, const uint32_t* tiles_touched, const float4* grec,
                           const uint32_t* tile_start, uint32_t* tile_cursor, unsigned long long* keys,
-                          unsigned long long capacity, const unsigned long long* total_dev);
+                          unsigned long long capacity, const unsigned long long* total_dev, const uint32_t* block_hist);
 template <int KEYS, int THREADS>
 __global__ void k_tile_sort(uint32_t n_lo, uint32_t n_hi, int gx, const uint32_t* tile_order, const uint32_t* tile_count, const uint32_t* tile_start, unsigned long long* keys,
                             uint32_t* point_list, float4* qrecords, uint32_t* qpos, uint32_t* qcount, const float4* grec,

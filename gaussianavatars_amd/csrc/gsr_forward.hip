@@ -227,7 +227,8 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
 template <bool CULL>
 __global__ __launch_bounds__(256) void k_count(int P, int gx, int tiles, const ushort4* __restrict__ rect,
                                                 const uint32_t* __restrict__ tiles_touched, const float4* __restrict__ grec,
-                                                uint32_t* __restrict__ tile_count, unsigned long long* __restrict__ rect_total)
+                                                uint32_t* __restrict__ tile_count, unsigned long long* __restrict__ rect_total,
+                                                uint32_t* __restrict__ block_hist)
 {
     extern __shared__ uint32_t hist[];
     __shared__ unsigned long long rect_sum[4];
@@ -267,13 +268,15 @@ __global__ __launch_bounds__(256) void k_count(int P, int gx, int tiles, const u
     __syncthreads();
     if (tid == 0) atomicAdd(rect_total, rect_sum[0] + rect_sum[1] + rect_sum[2] + rect_sum[3]);
     if (direct) return;
+    uint32_t* __restrict__ mine = block_hist + (size_t)blockIdx.x * tiles;   // kept for k_scatter (same chunk, same histogram)
     for (int t = tid; t < tiles; t += 256) {
         const uint32_t v = hist[t];
+        mine[t] = v;
         if (v) atomicAdd(&tile_count[t], v);
     }
 }
-template __global__ void k_count<false>(int, int, int, const ushort4*, const uint32_t*, const float4*, uint32_t*, unsigned long long*);
-template __global__ void k_count<true>(int, int, int, const ushort4*, const uint32_t*, const float4*, uint32_t*, unsigned long long*);
+template __global__ void k_count<false>(int, int, int, const ushort4*, const uint32_t*, const float4*, uint32_t*, unsigned long long*, uint32_t*);
+template __global__ void k_count<true>(int, int, int, const ushort4*, const uint32_t*, const float4*, uint32_t*, unsigned long long*, uint32_t*);
 
 // ------------------------------------------------------------------------------------------
 // k_tile_scan: exclusive scan over the tile counters (single workgroup, 1024 threads)
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int tiles, const uint32_t* _
 
 // ------------------------------------------------------------------------------------------
 // k_scatter: one (depth bits << 32 | splat) entry into every touched tile's segment.  Same chunking
-// as k_count: the workgroup re-histograms its chunk in LDS, reserves one contiguous sub-range per
+// as k_count, whose per-workgroup histogram it re-uses: the workgroup reserves one contiguous sub-range per
 // touched tile with a single returning L2 atomic, then hands out slots with returning LDS atomics.
 // Order inside a tile segment is arbitrary here; k_tile_sort fixes it.
 // ------------------------------------------------------------------------------------------
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(256) void k_scatter(int P, int gx, int tiles, const
                                                   const ushort4* __restrict__ rect, const uint32_t* __restrict__ tiles_touched,
                                                   const float4* __restrict__ grec, const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
                                                   unsigned long long* __restrict__ keys, unsigned long long capacity,
-                                                  const unsigned long long* __restrict__ total_dev)
+                                                  const unsigned long long* __restrict__ total_dev, const uint32_t* __restrict__ block_hist)
 {
     extern __shared__ uint32_t hist[];
     if (*total_dev > capacity) return;  // the host will grow the buffer and replay the frame
@@ -385,26 +388,11 @@ __global__ __launch_bounds__(256) void k_scatter(int P, int gx, int tiles, const
         }
         return;
     }
-    for (int t = tid; t < tiles; t += 256) hist[t] = 0u;
-    __syncthreads();
-    for (int base = begin; base < end; base += 256) {
-        const int i = base + tid;
-        uint32_t n = 0;
-        int minx = 0, miny = 0, maxx = 0, maxy = 0;
-        if (i < end) {
-            n = tiles_touched[i];
-            const ushort4 r = rect[i];
-            minx = r.x; miny = r.y; maxx = r.z; maxy = r.w;
-            if (CULL && n) {
-                const float4 g0 = grec[3 * (size_t)i], g1 = grec[3 * (size_t)i + 1];
-                snug_rect(reach_of(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y), minx, miny, maxx, maxy, n);
-            }
-        }
-        for_each_tile(minx, miny, maxx, maxy, n, gx, [](uint32_t tile, uint32_t, uint32_t) { atomicAdd(&hist[tile], 1u); }, 0u, 0u);
-    }
-    __syncthreads();
+    // this workgroup's tile histogram was already built by k_count (same chunk): reserve one contiguous sub-range per touched
+    // tile with a single returning L2 atomic
+    const uint32_t* __restrict__ mine = block_hist + (size_t)blockIdx.x * tiles;
     for (int t = tid; t < tiles; t += 256) {
-        const uint32_t v = hist[t];
+        const uint32_t v = mine[t];
         hist[t] = v ? tile_start[t] + atomicAdd(&tile_cursor[t], v) : 0u;   // first slot of this workgroup in tile t
     }
     __syncthreads();
@@ -431,9 +419,9 @@ __global__ __launch_bounds__(256) void k_scatter(int P, int gx, int tiles, const
     }
 }
 template __global__ void k_scatter<false>(int, int, int, const float*, const ushort4*, const uint32_t*, const float4*, const uint32_t*, uint32_t*,
-                                          unsigned long long*, unsigned long long, const unsigned long long*);
+                                          unsigned long long*, unsigned long long, const unsigned long long*, const uint32_t*);
 template __global__ void k_scatter<true>(int, int, int, const float*, const ushort4*, const uint32_t*, const float4*, const uint32_t*, uint32_t*,
-                                         unsigned long long*, unsigned long long, const unsigned long long*);
+                                         unsigned long long*, unsigned long long, const unsigned long long*, const uint32_t*);
 
 // ------------------------------------------------------------------------------------------
 // Register-resident block sort for the in-LDS size classes: 8 keys per thread (index i = 8*tid + k).

@@ -29,6 +29,7 @@ extern "C" {
 #endif
 
 #define GSR_ABI_VERSION 1
+#define GSR_BIN_BLOCKS 256        /* workgroups of the two binning passes (each owns a contiguous chunk of splats) */
 #define GSR_BLOCK_X 16
 #define GSR_BLOCK_Y 16
 
@@ -101,6 +102,9 @@ typedef struct GsrBinningLayout {
     size_t tile_start;  /* uint32 [tiles]                                                            */
     size_t tile_cursor; /* uint32 [tiles]                                                            */
     size_t tile_order;  /* uint32 [tiles]  launch order of the per-tile kernels: heaviest tiles first         */
+    size_t block_hist;  /* uint32 [GSR_BIN_BLOCKS * tiles]  per-workgroup tile histograms of the counting pass, re-used by the
+                           scatter pass (same chunking) instead of histogramming again; absent (size 0) for tile grids
+                           beyond the LDS histogram                                                               */
     size_t total;
 } GsrBinningLayout;
 
