@@ -10,6 +10,37 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ---- host-side fast paths (the frame loop is ~0.7 ms of Python; these run a dozen times per frame) -----------------
+def raw_stream(dev):
+    """torch's current stream on `dev` as a c_void_p, without building a torch.cuda.Stream object."""
+    import torch
+
+    try:
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device()))
+    except AttributeError:   # very old / very new torch: the public route
+        return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class _NoCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOCTX = _NoCtx()
+
+
+def on_device(dev):
+    """Context that makes `dev` the current device for the native call; free when it already is (the usual case)."""
+    import torch
+
+    if dev.index is None or torch.cuda.current_device() == dev.index:
+        return _NOCTX
+    return torch.cuda.device(dev)
 GSR_LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
 
 GSR_OK = 0

@@ -19,7 +19,7 @@ def _p(t):
 
 
 def _stream(dev):
-    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return _lib.raw_stream(dev)
 
 
 def _chk(rc, what):
@@ -33,6 +33,8 @@ def _need_cuda(t, name):
 
 
 def _f32(t):
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return t          # inside an autograd Function the inputs already are plain tensors: no detach / copy needed
     return t.detach().float().contiguous()
 
 
@@ -87,7 +89,7 @@ class _FlameForward(torch.autograd.Function):
         verts = torch.empty((1, V, 3), dtype=torch.float32, device=dev)
         v_shaped = torch.empty((1, V, 3), dtype=torch.float32, device=dev)
         ws = torch.empty(_lib.GAB_FLAME_WS_FLOATS, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _chk(lib.gab_flame_forward(C.byref(rig), *[_p(t) for t in ins], _p(so), _p(verts), _p(v_shaped), _p(ws), _stream(dev)),
                  "gab_flame_forward")
         ctx.head = head
@@ -118,7 +120,7 @@ class _FlameForward(torch.autograd.Function):
         scratch = torch.empty(3 * V, **f32)
         gv = torch.zeros((V, 3), **f32) if g_verts is None else _f32(g_verts)
         gvs = None if g_vshaped is None else _f32(g_vshaped)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _chk(lib.gab_flame_backward(C.byref(rig), *[_p(t) for t in ins], _p(so), _p(v_shaped), _p(ws), _p(gv), _p(gvs),
                                         _p(d_shape), _p(d_expr), _p(d_rot), _p(d_neck), _p(d_jaw), _p(d_eyes), _p(d_trans), _p(d_so),
                                         _p(scratch), 0, None, None, _stream(dev)), "gab_flame_backward")
@@ -159,7 +161,7 @@ class _FlameForwardTimestep(torch.autograd.Function):
         verts = torch.empty((1, V, 3), dtype=torch.float32, device=dev)
         v_shaped = torch.empty((1, V, 3), dtype=torch.float32, device=dev)
         ws = torch.empty(_lib.GAB_FLAME_WS_FLOATS, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _chk(lib.gab_flame_forward(C.byref(rig), _p(sh), *rows, _p(so), _p(verts), _p(v_shaped), _p(ws), _stream(dev)),
                  "gab_flame_forward")
         ctx.head, ctx.t, ctx.T, ctx.widths = head, t, T, widths
@@ -193,7 +195,7 @@ class _FlameForwardTimestep(torch.autograd.Function):
         gv = torch.zeros((V, 3), **f32) if g_verts is None else _f32(g_verts)
         gvs = None if g_vshaped is None else _f32(g_vshaped)
         rows = [C.c_void_p(x.data_ptr() + 4 * t * w) for x, w in zip(tabs, widths)]
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             # the (T,k) tables are zero-filled by the backward's first kernel (no launch of their own)
             _chk(lib.gab_flame_backward(C.byref(rig), _p(sh), *rows, _p(so), _p(v_shaped), _p(ws), _p(gv), _p(gvs), _p(d_shape),
                                         *outp, _p(d_so), _p(scratch), len(tables), ptrs, sizes, _stream(dev)), "gab_flame_backward")
@@ -227,7 +229,7 @@ class _FaceFrames(torch.autograd.Function):
         scale, quat = torch.empty((F, 1), **f32), torch.empty((F, 4), **f32)
         # the backward scatters into a zeroed (V,3) buffer: let the forward kernel zero it on the side (no memset launch later)
         ctx.d_verts = torch.empty((V, 3), **f32) if ctx.needs_input_grad[0] else None
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _chk(lib.gab_face_frames_forward(V, F, _p(v), _p(fi), is64, _p(center), _p(R), _p(scale), _p(quat), _p(ctx.d_verts),
                                              _stream(dev)), "gab_face_frames_forward")
         ctx.save_for_backward(v, fi)
@@ -245,7 +247,7 @@ class _FaceFrames(torch.autograd.Function):
         if not prepared:
             d_verts = torch.empty((V, 3), dtype=torch.float32, device=dev)
         gs = [None if g is None else _f32(g) for g in (g_center, g_R, g_scale, g_quat)]
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _chk(lib.gab_face_frames_backward(V, F, _p(v), _p(fi), ctx.is64, _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(gs[3]), _p(d_verts),
                                               1 if prepared else 0, _stream(dev)), "gab_face_frames_backward")
         return d_verts, None
@@ -283,7 +285,7 @@ class _BindSplats(torch.autograd.Function):
         ox, osc, oq = torch.empty((N, 3), **f32), torch.empty((N, 3), **f32), torch.empty((N, 4), **f32)
         ol = None if opacity_logit is None else _f32(opacity_logit)
         oo = None if ol is None else torch.empty_like(ol)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _chk(lib.gab_bind_forward(N, F, _p(x), _p(ls), _p(q), _p(b), is64, _p(fc), _p(fR), _p(fs), _p(fq), _p(ox), _p(osc), _p(oq),
                                       _p(ol), _p(oo), _stream(dev)), "gab_bind_forward")
         ctx.save_for_backward(x, ls, q, b, fR, fs, fc, fq, oo)
@@ -305,7 +307,7 @@ class _BindSplats(torch.autograd.Function):
         gs = [None if g is None else _f32(g) for g in (g_xyz, g_scaling, g_rot)]
         go = None if (oo is None or g_opacity is None) else _f32(g_opacity)
         d_ol = None if oo is None else torch.empty_like(oo)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             if ctx.csr is not None:
                 order, face_begin = ctx.csr
                 _chk(lib.gab_bind_backward_csr(N, F, _p(x), _p(ls), _p(q), _p(fR), _p(fs), _p(fq), _p(gs[0]), _p(gs[1]), _p(gs[2]),

@@ -19,7 +19,7 @@ def _p(t):
 
 
 def _stream(dev):
-    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return _lib.raw_stream(dev)
 
 
 def _check(rc, what):

@@ -87,6 +87,8 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.is_cuda and t.dtype is torch.float32 and t.is_contiguous():
+        return t
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be a device tensor (got {t.device}); the MI355X rasterizer has no CPU path")
     if t.dtype != torch.float32:
@@ -107,6 +109,35 @@ def _make_settings(rs: GaussianRasterizationSettings, keep: list) -> _lib.GsrSet
         keep.append(t)
         setattr(s, field, t.data_ptr())
     return s
+
+
+_layout_cache: dict = {}
+
+
+def _layouts(lib, P, W, H):
+    """(geom, image) layouts: pure host arithmetic of the C ABI, cached per shape."""
+    key = (P, W, H)
+    hit = _layout_cache.get(key)
+    if hit is None:
+        gl, il = _lib.GsrGeomLayout(), _lib.GsrImageLayout()
+        lib.gsr_geom_layout(P, C.byref(gl))
+        lib.gsr_image_layout(W, H, C.byref(il))
+        if len(_layout_cache) > 64:
+            _layout_cache.clear()
+        hit = _layout_cache[key] = (gl, il)
+    return hit
+
+
+def _binning_layout(lib, cap, W, H):
+    key = ("b", cap, W, H)
+    hit = _layout_cache.get(key)
+    if hit is None:
+        hit = _lib.GsrBinningLayout()
+        lib.gsr_binning_layout(cap, W, H, C.byref(hit))
+        if len(_layout_cache) > 64:
+            _layout_cache.clear()
+        _layout_cache[key] = hit
+    return hit
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -137,9 +168,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             sh_rest = torch.empty(0, device=dev)
         M = (int(sh.shape[1]) + (int(sh_rest.shape[1]) if split else 0)) if sh.numel() else 0
 
-        gl, il = _lib.GsrGeomLayout(), _lib.GsrImageLayout()
-        lib.gsr_geom_layout(P, C.byref(gl))
-        lib.gsr_image_layout(W, H, C.byref(il))
+        gl, il = _layouts(lib, P, W, H)
         u8 = dict(dtype=torch.uint8, device=dev)
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
@@ -148,13 +177,12 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         key = (dev.index, H, W)
         cap = _capacity_hint.get(key) or _round_cap(8 * P)
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        stream = _lib.raw_stream(dev)
         n_host = C.c_int64(0)
         replays = 0
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             while True:
-                bl = _lib.GsrBinningLayout()
-                lib.gsr_binning_layout(cap, W, H, C.byref(bl))
+                bl = _binning_layout(lib, cap, W, H)
                 binning = torch.empty(bl.total, **u8)
                 rc = lib.gsr_forward_ex(C.byref(s), P, M, _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors_precomp), _ptr(opacities),
                                      _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(color), _ptr(radii),
@@ -209,8 +237,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         g_sh_rest = torch.empty((P, M - 1, 3), **f32) if ctx.split else None
         g_scales = torch.empty((P, 3), **f32) if use_sr else None
         g_rot = torch.empty((P, 4), **f32) if use_sr else None
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        with torch.cuda.device(dev):
+        stream = _lib.raw_stream(dev)
+        with _lib.on_device(dev):
             rc = lib.gsr_backward_ex(C.byref(s), P, M, _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors_precomp), _ptr(scales),
                                   _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(radii), _ptr(geom), _ptr(binning),
                                   ctx.capacity, _ptr(img), ctx.num_rendered, _ptr(grad_out_color),
@@ -241,8 +269,8 @@ class GaussianRasterizer(nn.Module):
             pos = _f32c(positions, "positions")
             vm, pm = _f32c(rs.viewmatrix, "viewmatrix"), _f32c(rs.projmatrix, "projmatrix")
             out = torch.empty((pos.shape[0],), dtype=torch.uint8, device=pos.device)
-            stream = C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
-            with torch.cuda.device(pos.device):
+            stream = _lib.raw_stream(pos.device)
+            with _lib.on_device(pos.device):
                 rc = _lib.gsr().gsr_mark_visible(pos.shape[0], _ptr(pos), _ptr(vm), _ptr(pm), _ptr(out), stream)
             if rc != _lib.GSR_OK:
                 raise RuntimeError(f"gsr_mark_visible failed ({rc}): {_lib.gsr_error()}")
