@@ -32,6 +32,10 @@ def scene(name):
     if name == "huge_grid":  # 207x207 = 42849 tiles: beyond the LDS tile histogram, the L2-atomic binning path
         sp = S.random_splats(1500, 1, 17, xyz_sigma=0.12, log_scale_mean=math.log(0.004), log_scale_sigma=0.6)
         return S.orbit_camera(3300, 3300), sp, [0.3, 0.3, 0.3], 1, 1.0
+    if name == "depth_ties":  # many splats at exactly the same depth: the (depth, index) tie order of the stable sort
+        sp = S.random_splats(4000, 0, 18, xyz_sigma=0.05, log_scale_mean=math.log(0.004))
+        sp["means3D"][:, 2] = np.round(sp["means3D"][:, 2] * 40.0) / 40.0   # the default camera looks down -z: depth = 1 - z
+        return S.orbit_camera(96, 96), sp, [0.5, 0.5, 0.5], 0, 1.0
     if name == "empty_view":  # nothing visible
         sp = S.random_splats(500, 0, 15)
         sp["means3D"][:, 2] += 3.0

@@ -97,7 +97,7 @@ def _check_forward(st, hs):
     assert checked or I == 0
 
 
-@pytest.mark.parametrize("name", ["cfg1", "sh3_small", "sh2_mod", "culls", "dense_tile", "dense_tile_xl", "empty_view", "huge_grid"])
+@pytest.mark.parametrize("name", ["cfg1", "sh3_small", "sh2_mod", "culls", "dense_tile", "dense_tile_xl", "depth_ties", "empty_view", "huge_grid"])
 def test_forward_bit_exact(oracle, name):
     s, st, hs, rs, _ = _run_both(oracle, name)
     _check_forward(st, hs)
