@@ -77,15 +77,17 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
     float T = T_final;
-    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f;      // colour accumulated behind the current splat
-    float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;      // colour of the previously visited splat
-    float last_alpha = 0.f;
+    float Sb = 0.f;                              // (colour accumulated behind the current splat) . dL/dpixel
+    float last_cg = 0.f;                         // (colour of the previously visited splat) . dL/dpixel
+    float last_alpha = 0.f, last_one_m = 1.f;
 
     constexpr int RB = 4;
     const int jmax = min((int)wave_max_u32((uint32_t)last), nq);
-    if (jmax > 2048) __builtin_amdgcn_s_setprio(3);
-    else if (jmax > 1024) __builtin_amdgcn_s_setprio(2);
-    else if (jmax > 512) __builtin_amdgcn_s_setprio(1);   // deepest contributor of any pixel of this wave
+    // The kernel ends when its longest walk ends (0.6 M wave-records in total, but the deepest quadrant walks ~500 of them
+    // strictly in order): let the deep walks win issue arbitration over the shallow ones sharing their SIMD.
+    if (jmax > 320) __builtin_amdgcn_s_setprio(3);
+    else if (jmax > 192) __builtin_amdgcn_s_setprio(2);
+    else if (jmax > 96) __builtin_amdgcn_s_setprio(1);   // deepest contributor of any pixel of this wave
     struct Rec2 { float rx[2], ry[2], ca[2], cb[2], cc[2], op[2], cr[2], cg[2], cbl[2]; uint32_t id[2]; };
     struct Pos2 { uint32_t p[2]; };
     auto loadp = [&](int jp, Pos2& P) {
@@ -127,40 +129,40 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
                 for (int c = 0; c < 9; ++c) v[uo + u][c] = 0.f;
             return false;
         }
+        // Select-free sequential part.  A record that does not touch this pixel gets G = 0: then alpha = 0, 1/(1-alpha) = 1,
+        // T is multiplied by exactly 1, every partial below is a product with G, alpha*T or dL/dG = 0, and the "colour behind"
+        // recurrence passes it by (its weight is the record's own alpha).  That recurrence is tracked as ONE scalar, the
+        // colour behind dotted with this pixel's dL/dpixel (the only way it is ever used), instead of three channels.
 #pragma unroll
         for (int u = 1; u >= 0; --u) {
-            const float one_m = 1.f - alpha[u];
+            const float Gh = hit[u] ? G[u] : 0.f;
+            const float al = sel_min(0.99f, R.op[u] * Gh);
+            const float one_m = 1.f - al;
             const float rinv = __builtin_amdgcn_rcpf(one_m);
             const float Tn = T * rinv;
-            const float w = alpha[u] * Tn;
-            const float n0 = last_alpha * lc0 + (1.f - last_alpha) * ar0;
-            const float n1 = last_alpha * lc1 + (1.f - last_alpha) * ar1;
-            const float n2 = last_alpha * lc2 + (1.f - last_alpha) * ar2;
-            float dL_dalpha = ((R.cr[u] - n0) * g0 + (R.cg[u] - n1) * g1 + (R.cbl[u] - n2) * g2) * Tn;
+            const float w = al * Tn;
+            const float cg = R.cr[u] * g0 + R.cg[u] * g1 + R.cbl[u] * g2;
+            Sb = last_alpha * last_cg + last_one_m * Sb;
+            float dL_dalpha = (cg - Sb) * Tn;
             dL_dalpha += (-T_final * rinv) * bg_dot;
             const float dL_dG = R.op[u] * dL_dalpha;
-            const float gdx = G[u] * dxs[u], gdy = G[u] * dys[u];
+            const float gdx = Gh * dxs[u], gdy = Gh * dys[u];
             const float dG_ddelx = -gdx * R.ca[u] - gdy * R.cb[u];
             const float dG_ddely = -gdy * R.cc[u] - gdx * R.cb[u];
-            const bool h = hit[u];
             float* vv = v[uo + u];
-            vv[0] = h ? w * g0 : 0.f;
-            vv[1] = h ? w * g1 : 0.f;
-            vv[2] = h ? w * g2 : 0.f;
-            vv[3] = h ? dL_dG * dG_ddelx * ddelx_dx : 0.f;
-            vv[4] = h ? dL_dG * dG_ddely * ddely_dy : 0.f;
-            vv[5] = h ? -0.5f * gdx * dxs[u] * dL_dG : 0.f;
-            vv[6] = h ? -0.5f * gdx * dys[u] * dL_dG : 0.f;
-            vv[7] = h ? -0.5f * gdy * dys[u] * dL_dG : 0.f;
-            vv[8] = h ? G[u] * dL_dalpha : 0.f;
-            T = h ? Tn : T;
-            ar0 = h ? n0 : ar0;
-            ar1 = h ? n1 : ar1;
-            ar2 = h ? n2 : ar2;
-            lc0 = h ? R.cr[u] : lc0;
-            lc1 = h ? R.cg[u] : lc1;
-            lc2 = h ? R.cbl[u] : lc2;
-            last_alpha = h ? alpha[u] : last_alpha;
+            vv[0] = w * g0;
+            vv[1] = w * g1;
+            vv[2] = w * g2;
+            vv[3] = dL_dG * dG_ddelx * ddelx_dx;
+            vv[4] = dL_dG * dG_ddely * ddely_dy;
+            vv[5] = -0.5f * gdx * dxs[u] * dL_dG;
+            vv[6] = -0.5f * gdx * dys[u] * dL_dG;
+            vv[7] = -0.5f * gdy * dys[u] * dL_dG;
+            vv[8] = Gh * dL_dalpha;
+            T = Tn;
+            last_alpha = al;
+            last_one_m = one_m;
+            last_cg = cg;
         }
         return true;
     };
