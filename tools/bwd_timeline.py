@@ -1,0 +1,33 @@
+"""Per-wave timeline of k_render_bwd (needs the -DGSR_EXPERIMENT_TIMELINE debug build copied over libgsr_hip.so)."""
+import ctypes as C, sys, numpy as np, torch
+sys.path.insert(0, '.')
+import bench
+from gaussianavatars_amd import _lib
+dev = torch.device('cuda:0')
+g, cam = bench.build_scene(dev, 100_000, 3, 550, 802, 4, "fused", True)
+bg = torch.ones(3, device=dev); target = torch.ones(3, 802, 550, device=dev)
+for i in range(12):
+    bench.zero_grads(g); bench.one_step(g, cam, bg, target, 0, True)
+torch.cuda.synchronize()
+lib = _lib.gsr()
+buf = (C.c_ulonglong * (4 * 16384))()
+lib.gsr_debug_read.restype = C.c_int
+assert lib.gsr_debug_read(buf, 4 * 16384) == 0
+a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4)[:7140].astype(np.int64)
+t0, t1, jm, hw = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+live = t1 > 0
+t0, t1, jm, hw = t0[live], t1[live], jm[live], hw[live]
+base = t0.min()
+dur = (t1 - t0) / 100.0            # wall_clock64 ticks at 100 MHz -> us
+print("waves", len(t0), "kernel span %.1f us" % ((t1.max() - base) / 100.0), "latest start %.1f us" % ((t0.max() - base) / 100.0))
+print("wave duration us: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % (dur.mean(), *np.percentile(dur, [50, 90, 99]), dur.max()))
+order = np.argsort(-(t1 - base))[:10]
+print("last finishers: (end us, start us, dur us, jmax, us per record)")
+for w in order:
+    print("   %.1f %.1f %.1f %d %.3f" % ((t1[w] - base) / 100.0, (t0[w] - base) / 100.0, dur[w], jm[w], dur[w] / max(jm[w], 1)))
+deep = np.argsort(-jm)[:10]
+print("deepest walks: (jmax, dur us, us per record, end us)")
+for w in deep:
+    print("   %d %.1f %.3f %.1f" % (jm[w], dur[w], dur[w] / max(jm[w], 1), (t1[w] - base) / 100.0))
+sel = jm > 50
+print("us per record vs depth: corr(dur, jmax) = %.3f;  median us/record (jmax>50) %.3f" % (np.corrcoef(dur, jm)[0, 1], np.median(dur[sel] / jm[sel])))
