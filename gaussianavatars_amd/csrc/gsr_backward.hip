@@ -40,6 +40,10 @@ __device__ __forceinline__ float row_sum(float v)
     return v;
 }
 
+#ifdef GSR_EXPERIMENT_TIMELINE   // `make timeline`: per-wave start/end stamps of k_render_bwd for tools/bwd_timeline.py
+__device__ unsigned long long gsr_dbg[4 * 16384];
+extern "C" int gsr_debug_read(unsigned long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gsr_dbg), (size_t)n * 8); }
+#endif
 __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
                                                      const uint32_t* __restrict__ qcount,
                                                      const float4* __restrict__ qrecords, const uint32_t* __restrict__ qpos,
@@ -47,6 +51,9 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
                                                      const uint32_t* __restrict__ n_contrib_q, const float* __restrict__ dL_dpix,
                                                      float* __restrict__ acc /* [P][GSR_ACC_STRIDE] */)
 {
+#ifdef GSR_EXPERIMENT_TIMELINE
+    const unsigned long long t_start = wall_clock64();
+#endif
     const int W = s.W, H = s.H;
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X;
     const int tile = (int)tile_order[blockIdx.x];
@@ -209,6 +216,15 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
             if (c_sel < 9 && (jb + rec_u) < nq && mine != 0.f) unsafeAtomicAdd(acc + (size_t)GSR_ACC_STRIDE * myid + c_sel, mine);
         }
     }
+#ifdef GSR_EXPERIMENT_TIMELINE
+    if (lane == 0 && (size_t)blockIdx.x * 4 + wave < 16384) {
+        unsigned long long* d = gsr_dbg + 4 * ((size_t)blockIdx.x * 4 + wave);
+        d[0] = t_start;
+        d[1] = wall_clock64();
+        d[2] = (unsigned long long)jmax;
+        d[3] = 0ull;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
