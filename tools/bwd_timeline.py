@@ -31,3 +31,19 @@ for w in deep:
     print("   %d %.1f %.3f %.1f" % (jm[w], dur[w], dur[w] / max(jm[w], 1), (t1[w] - base) / 100.0))
 sel = jm > 50
 print("us per record vs depth: corr(dur, jmax) = %.3f;  median us/record (jmax>50) %.3f" % (np.corrcoef(dur, jm)[0, 1], np.median(dur[sel] / jm[sel])))
+
+# ---- forward (k_render)
+lib.gsr_debug_read_fwd.restype = C.c_int
+assert lib.gsr_debug_read_fwd(buf, 4 * 16384) == 0
+a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4)[:7140].astype(np.int64)
+t0, t1, nj, tm = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+live = t1 > 0
+t0, t1, nj, tm = t0[live], t1[live], nj[live], tm[live]
+n, jmain = nj >> 32, nj & 0xFFFFFFFF
+base = t0.min(); dur = (t1 - t0) / 100.0; tail = (t1 - tm) / 100.0
+print("FORWARD waves", len(t0), "kernel span %.1f us" % ((t1.max() - base) / 100.0), "latest start %.1f us" % ((t0.max() - base) / 100.0))
+print("wave duration us: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f;  sum walked (pixel-parallel) %d;  waves entering tail mode %d, tail time total %.0f us" %
+      (dur.mean(), *np.percentile(dur, [50, 90, 99]), dur.max(), jmain.sum(), int((jmain < n).sum()), tail[jmain < n].sum()))
+print("last finishers: (end us, dur us, stream n, walked pixel-parallel, tail us, us per walked record)")
+for w in np.argsort(-(t1 - base))[:10]:
+    print("   %.1f %.1f %d %d %.1f %.3f" % ((t1[w] - base) / 100.0, dur[w], n[w], jmain[w], tail[w], (dur[w] - tail[w]) / max(jmain[w], 1)))
