@@ -800,6 +800,10 @@ template __global__ void k_tile_sort<GSR_SORT_XL_KEYS, 1024>(uint32_t, uint32_t,
 // wave-uniform, so the loads below are scalar-unit loads: one 48-byte fetch serves all 64 pixels
 // and the values sit in SGPRs -- no LDS staging, no barriers, each wave stops on its own.
 // ------------------------------------------------------------------------------------------
+#ifdef GSR_EXPERIMENT_TIMELINE   // `make timeline`: per-wave stamps of k_render for tools/bwd_timeline.py
+__device__ unsigned long long gsr_dbg_fwd[4 * 16384];
+extern "C" int gsr_debug_read_fwd(unsigned long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gsr_dbg_fwd), (size_t)n * 8); }
+#endif
 __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
                                                  const uint32_t* __restrict__ qcount,
                                                  const float4* __restrict__ qrecords, const uint32_t* __restrict__ qpos,
@@ -809,6 +813,9 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
                                                  const unsigned long long* __restrict__ total_dev)
 {
     if (*total_dev > capacity) return;
+#ifdef GSR_EXPERIMENT_TIMELINE
+    const unsigned long long t_start = wall_clock64();
+#endif
     const int W = s.W, H = s.H;
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X;
     const int tile = (int)tile_order[blockIdx.x];
@@ -918,6 +925,10 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         }
     }
 
+#ifdef GSR_EXPERIMENT_TIMELINE
+    const unsigned long long t_main = wall_clock64();
+    const int j_main = j0;
+#endif
     // ---- tail mode: record-parallel --------------------------------------------------------------
     // A few pixels that never saturate (silhouettes) would otherwise drag the whole wave through the
     // rest of a long stream with 60 idle lanes.  Here the roles flip: for one open pixel at a time the
@@ -966,6 +977,15 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
             if (lane == p) { T = Tp; C0 = A0; C1 = A1; C2 = A2; last_q = lastqp; }
         }
     }
+#ifdef GSR_EXPERIMENT_TIMELINE
+    if (lane == 0 && (size_t)blockIdx.x * 4 + wave < 16384) {
+        unsigned long long* d = gsr_dbg_fwd + 4 * ((size_t)blockIdx.x * 4 + wave);
+        d[0] = t_start;
+        d[1] = wall_clock64();
+        d[2] = ((unsigned long long)(uint32_t)n << 32) | (uint32_t)j_main;
+        d[3] = t_main;
+    }
+#endif
     if (inside) {
         const int pix_id = W * pyi + pxi;
         // the reference's n_contrib counts positions in the TILE list: that is what the stream holds
