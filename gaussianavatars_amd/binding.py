@@ -259,6 +259,53 @@ def face_frames(verts, faces):
 
 
 # -------------------------------------------------------------------------------------------------
+# select_mesh_by_timestep as ONE autograd node (FLAME forward + face frames)
+# -------------------------------------------------------------------------------------------------
+class _SubCtx:
+    """Stand-in for an autograd ctx so that one node can run two of the Functions above back to back (the frame loop is
+    ~0.6 ms of Python per step: every autograd node less is ~40 us of host time forward + backward)."""
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = needs_input_grad
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *t):
+        self.saved_tensors = t
+
+    def set_materialize_grads(self, flag):
+        pass
+
+
+class _MeshFramesTimestep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, head, t, faces, shape, expr, rotation, neck, jaw, eyes, translation, static_offset):
+        ctx.set_materialize_grads(False)
+        need = ctx.needs_input_grad
+        c1 = _SubCtx((False, False) + tuple(need[3:]))
+        verts, v_shaped = _FlameForwardTimestep.forward(c1, head, t, shape, expr, rotation, neck, jaw, eyes, translation, static_offset)
+        c2 = _SubCtx((any(need), False))
+        center, R, scale, quat = _FaceFrames.forward(c2, verts[0], faces)
+        ctx.c1, ctx.c2 = c1, c2
+        return verts, v_shaped, center, R, scale, quat
+
+    @staticmethod
+    def backward(ctx, g_verts, g_vshaped, g_center, g_R, g_scale, g_quat):
+        d_verts, _ = _FaceFrames.backward(ctx.c2, g_center, g_R, g_scale, g_quat)
+        if g_verts is not None:
+            d_verts = d_verts + g_verts.reshape(d_verts.shape)
+        grads = _FlameForwardTimestep.backward(ctx.c1, d_verts.view(1, -1, 3), g_vshaped)
+        return (None, None, None) + tuple(grads[2:])
+
+
+def mesh_frames_timestep(head, flame_param: dict, t: int, faces):
+    """select_mesh_by_timestep + update_mesh_properties in one autograd node:
+    -> (verts (1,V,3), verts_cano (1,V,3), face_center, face_orien_mat, face_scaling, face_orien_quat)."""
+    fp = flame_param
+    return _MeshFramesTimestep.apply(head, int(t), faces, fp["shape"], fp["expr"], fp["rotation"], fp["neck_pose"], fp["jaw_pose"],
+                                     fp["eyes_pose"], fp["translation"], fp.get("static_offset"))
+
+
+# -------------------------------------------------------------------------------------------------
 # per-splat local -> world
 # -------------------------------------------------------------------------------------------------
 def binding_csr(binding: torch.Tensor, num_faces: int):

@@ -266,8 +266,11 @@ class FlameGaussianModel(GaussianModel):
         fp = self.flame_param_orig if original and self.flame_param_orig is not None else self.flame_param
         if self.binding_impl == "fused":
             from . import binding as fused
-            verts, verts_cano = fused.flame_forward_timestep(self.flame_model, fp, timestep)
-            self.update_mesh_properties(verts, verts_cano)
+            faces = self.flame_model.faces
+            verts, verts_cano, c, R, s, q = fused.mesh_frames_timestep(self.flame_model, fp, timestep, faces)
+            self.face_center, self.face_orien_mat, self.face_scaling, self.face_orien_quat = c, R, s, q
+            self.verts, self.faces, self.verts_cano = verts, faces, verts_cano
+            self._mesh_version = self._mesh_version + 1
             return
         verts, verts_cano = self.flame_model(
             fp["shape"][None, ...], fp["expr"][[timestep]], fp["rotation"][[timestep]], fp["neck_pose"][[timestep]],
