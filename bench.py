@@ -133,10 +133,36 @@ def cpu_baseline(g, cam, bg, train, max_seconds=25.0):
         if el > max_seconds or frames >= 8:
             break
     cores = os.cpu_count() or 1
-    return dict(value=frames / el, unit="frames/s", cores=cores, kind="port",
-                sample=f"{frames} frame(s) of the bench workload, rasterizer half ({'fwd+bwd' if train else 'fwd'}), "
-                       f"oracle/gsr_oracle.c with OpenMP on {cores} threads (render backward is single-threaded)",
-                ), st.num_rendered, int((st.radii > 0).sum())
+    out = dict(value=frames / el, unit="frames/s", cores=cores, kind="port",
+               sample=f"{frames} frame(s) of the bench workload, rasterizer half ({'fwd+bwd' if train else 'fwd'}), "
+                      f"oracle/gsr_oracle.c with OpenMP on {cores} threads (render backward is single-threaded)")
+    if g.binding is not None:
+        out["binding_half"] = cpu_binding_baseline(g, train)
+    return out, st.num_rendered, int((st.radii > 0).sum())
+
+
+def cpu_binding_baseline(g, train, frames=5):
+    """The binding half on the host: the composed-torch formulation of the reference (select_mesh_by_timestep + the three
+    bound accessors, gaussianavatars_amd/unfused.py) on torch-CPU with torch's default thread count."""
+    cpu = torch.device("cpu")
+    n_frames = int(g.flame_param["expr"].shape[0])
+    gc, _ = build_scene(cpu, int(g._xyz.shape[0]), g.max_sh_degree, 64, 64, n_frames, "unfused", train)
+
+    def frame(t):
+        gc.select_mesh_by_timestep(t)
+        x, s, r = gc.get_xyz, gc.get_scaling, gc.get_rotation
+        if train:
+            (x.sum() + s.sum() + r.sum()).backward()
+            zero_grads(gc)
+
+    with torch.set_grad_enabled(train):
+        frame(0)
+        t0 = time.perf_counter()
+        for i in range(frames):
+            frame(i % n_frames)
+        ms = 1e3 * (time.perf_counter() - t0) / frames
+    return dict(ms_per_frame=round(ms, 2), threads=torch.get_num_threads(),
+                what="composed-torch FLAME + face frames + per-splat bind on torch-CPU (" + ("fwd+bwd" if train else "fwd") + ")")
 
 
 def main():
