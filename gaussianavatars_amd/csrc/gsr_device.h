@@ -21,6 +21,8 @@
 
 namespace gsr {
 
+typedef float f32x8 __attribute__((ext_vector_type(8)));   // eight consecutive scalar registers (one s_load_dwordx8)
+
 struct Settings {  // by-value kernel argument: scalars + the four device pointers of GsrSettings
     int H, W;
     float tanfovx, tanfovy;

@@ -18,6 +18,7 @@
 // submodule; call site gaussian_renderer/__init__.py:37-52,86-94).  This TU is built with
 // -ffp-contract=off: the arithmetic below is evaluated exactly as written.
 #include "gsr_device.h"
+#include <type_traits>
 
 namespace gsr {
 
@@ -833,10 +834,13 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     const float4* __restrict__ rec = qrecords + (size_t)3 * range.x;                         // the tile's records (sorted)
     const uint32_t* __restrict__ qp = qpos + (size_t)4 * range.x + (size_t)wave * nt;       // this quadrant's positions into them
 
+    // Two transmittances per pixel: T is the one the pixel ends with (the last accepted product), Tw the WORKING one, equal to
+    // T while the pixel is open and 0 once it is closed (saturated, or outside the image).  A closed pixel then needs no
+    // flag: Tw * (1 - alpha) == 0 fails the ">= 0.0001" acceptance test by itself, and c * alpha * Tw adds +0.
     float T = 1.0f;
+    float Tw = inside ? 1.0f : 0.0f;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last_q = 0;
-    bool done = !inside;
 
     // the kernel ends when its longest stream ends: let those waves win issue arbitration on their SIMD
     if (n > 2048) __builtin_amdgcn_s_setprio(3);
@@ -846,81 +850,101 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     // The stream is walked RB records at a time: the RB exponentials are independent (instruction-level
     // parallelism for a wave that is alone on its SIMD), only the short T/C update is sequential.
     // Skips are predicated (selects), so the arithmetic per contributing record is exactly A.3's.
+    // A wave on the critical path retires one instruction per ~6.6 cycles whatever its kind (measured: tools/pmc_kernel.sh,
+    // tools/bwd_timeline.py), so the loop is written for INSTRUCTION COUNT, scalar ones included: no per-record bounds
+    // tests (full batches take an unmasked body), 32-bit record offsets, no exec-mask branches around the exponential.
     constexpr int RB = 3;
     constexpr int TAIL_LANES = 8;     // switch to record-parallel mode when this few pixels are still open
-    struct Rec4 { float rx[RB], ry[RB], ca[RB], cb[RB], cc[RB], op[RB], cr[RB], cg[RB], cbl[RB]; };
+    struct Rec4 { f32x8 a[RB]; float cbl[RB]; };   // a = (x, y, conic a, conic b, conic c, opacity, red, green)
     struct Pos4 { uint32_t p[RB]; };
-    // two-level scalar fetch: stream positions (4 bytes each) two batches ahead, the records they point at one batch ahead
-    auto loadp = [&](int jb, Pos4& P) {
+    // Two-level scalar fetch: stream positions (4 bytes each) two batches ahead, the records they point at one batch ahead,
+    // every record address the base pointer plus a 32-bit byte offset (s_load with a register offset: no 64-bit address
+    // arithmetic on the scalar unit, which is on the critical path like everything else the wave issues).
+    // Both streams are read through the CONSTANT address space (nothing writes them while this kernel runs): a uniform load
+    // from it is a scalar-memory load by definition, whatever the compiler can or cannot prove about the pointer.
+    typedef const __attribute__((address_space(4))) char* cbytes;
+    const cbytes recb = (cbytes)(uintptr_t)rec;
+    const cbytes qpb = (cbytes)(uintptr_t)qp;
+    auto loadp = [&](int jb, Pos4& P, auto whole) {
 #pragma unroll
-        for (int u = 0; u < RB; ++u) P.p[u] = qp[min(jb + u, n - 1)];   // past the end: re-read the last one, masked out in blend4
+        for (int u = 0; u < RB; ++u) {   // past the end: re-read the last one, masked out in blend4<true>
+            const uint32_t j = decltype(whole)::value ? (uint32_t)(jb + u) : (uint32_t)min(jb + u, n - 1);
+            P.p[u] = *(const __attribute__((address_space(4))) uint32_t*)(qpb + j * 4u);
+        }
     };
     auto load4 = [&](const Pos4& P, Rec4& R) {
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
-            const size_t j = (size_t)P.p[u];
-            const float4 r0 = rec[3 * j + 0];
-            const float4 r1 = rec[3 * j + 1];
-            const float r2x = rec[3 * j + 2].x;
-            R.rx[u] = r0.x; R.ry[u] = r0.y; R.ca[u] = r0.z; R.cb[u] = r0.w;
-            R.cc[u] = r1.x; R.op[u] = r1.y; R.cr[u] = r1.z; R.cg[u] = r1.w; R.cbl[u] = r2x;
+            const uint32_t off = P.p[u] * 48u;   // byte offset inside the tile's records: < 4 GiB (a tile list of 89 M entries)
+            R.a[u] = *(const __attribute__((address_space(4))) f32x8*)(recb + off);
+            R.cbl[u] = *(const __attribute__((address_space(4))) float*)(recb + off + 32);
         }
     };
-    auto blend4 = [&](int jb, const Rec4& R) {
+    // Scalar loads return out of order, so the only wait is lgkmcnt(0); the empty asm pins that wait (first use of the current
+    // batch, whose loads were issued a whole batch ago) ahead of the next issue, instead of letting it land after it and
+    // stall on the fresh loads.
+    auto arrived = [&](Rec4& R, Pos4& P) { asm volatile("" ::"s"(R.a[0]), "s"(P.p[0]) : "memory"); };
+    auto blend4 = [&](int jb, const Rec4& R, auto masked) {
         float alpha[RB];
+        bool ok[RB];
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
-            const float dx = R.rx[u] - pixx;
-            const float dy = R.ry[u] - pixy;
-            const float power = -0.5f * (R.ca[u] * dx * dx + R.cc[u] * dy * dy) - R.cb[u] * dx * dy;
-            const float a = sel_min(0.99f, R.op[u] * gsr_expf_blend(power));
-            const bool ok = power <= 0.0f && (jb + u) < n && a >= 1.0f / 255.0f;
-            alpha[u] = ok ? a : 0.0f;
+            const float dx = R.a[u][0] - pixx;
+            const float dy = R.a[u][1] - pixy;
+            const float power = -0.5f * (R.a[u][2] * dx * dx + R.a[u][4] * dy * dy) - R.a[u][3] * dx * dy;
+            float a = sel_min(0.99f, R.a[u][5] * gsr_expf_blend(power));
+            asm volatile("" : "+v"(a));   // evaluated for every lane: power > 0 is too rare to pay an exec-mask branch per record
+            ok[u] = power <= 0.0f && a >= 1.0f / 255.0f;
+            if (decltype(masked)::value) ok[u] = ok[u] && (jb + u) < n;
+            alpha[u] = ok[u] ? a : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
-            const bool live = !done && alpha[u] > 0.0f;
-            const float test_T = T * (1.0f - alpha[u]);
-            const bool stop = live && test_T < 0.0001f;
-            const bool acc = live && !stop;
-            const float ae = acc ? alpha[u] : 0.0f;   // adding (c * 0) * T == +0 leaves C bit-identical: no selects on C
-            C0 = C0 + R.cr[u] * ae * T;
-            C1 = C1 + R.cg[u] * ae * T;
-            C2 = C2 + R.cbl[u] * ae * T;
-            T = acc ? test_T : T;
-            last_q = acc ? (uint32_t)(jb + u + 1) : last_q;
-            done = done || stop;
+            const float test_T = Tw * (1.0f - alpha[u]);      // alpha == 0 (skipped record): exactly Tw, accepted, nothing changes
+            const bool keep = test_T >= 0.0001f;              // false at the record that saturates the pixel, and forever after
+            const float ae = keep ? alpha[u] : 0.0f;          // adding (c * 0) * T == +0 leaves C bit-identical: no selects on C
+            C0 = C0 + R.a[u][6] * ae * Tw;
+            C1 = C1 + R.a[u][7] * ae * Tw;
+            C2 = C2 + R.cbl[u] * ae * Tw;
+            T = keep ? test_T : T;
+            Tw = keep ? test_T : 0.0f;
+            last_q = (keep && ok[u]) ? (uint32_t)(jb + u + 1) : last_q;
         }
+    };
+    auto blend = [&](int jb, const Rec4& R) {
+        if (jb + RB <= n) blend4(jb, R, std::false_type{});
+        else blend4(jb, R, std::true_type{});
     };
     auto keep_going = [&](int jb) {
-        const unsigned long long open_mask = __ballot(!done);
-        if (open_mask == 0ull) return false;
-        return !(__builtin_popcountll(open_mask) <= TAIL_LANES && n - jb > 2 * GSR_WAVE);   // few open pixels -> tail mode
+        const unsigned long long open_mask = __ballot(Tw > 0.0f);
+        if (__builtin_popcountll(open_mask) > TAIL_LANES) return true;
+        return open_mask != 0ull && n - jb <= 2 * GSR_WAVE;   // nothing open: stop; few open pixels and a long way to go: tail mode
     };
-    // Software-pipelined walk: the scalar loads of batch k+1 are issued BEFORE batch k is blended.  Scalar
-    // loads return out of order, so the only wait is lgkmcnt(0); the empty asm pins that wait (first use of
-    // the current batch, whose loads were issued a whole batch ago) ahead of the next issue, instead of
-    // letting it land after it and stall on the fresh loads.
+    // Software-pipelined walk: the scalar loads of batch k+1 are issued BEFORE batch k is blended, right after the wait for
+    // batch k's own loads (issued a whole batch ago) -- placed the other way round the wait would stall on the fresh loads.
     int j0 = 0;
     if (n > 0) {
         Rec4 A, B;
         Pos4 PA, PB;
-        loadp(0, PA);
-        loadp(RB, PB);
+        loadp(0, PA, std::false_type{});
+        loadp(RB, PB, std::false_type{});
         asm volatile("" ::"s"(PA.p[0]), "s"(PB.p[0]) : "memory");
         load4(PA, A);
+        // invariant at the top of both loops: A holds batch j0 (issued a batch ago), PB the positions of batch j0+RB (issued two
+        // batches ago).  Steady state: four whole batches ahead, so nothing in the body needs a bounds test; the open-pixel
+        // test runs once per two batches (a closed pixel ignores the extra records by construction).
+        // the last batches of the stream: the same walk with every fetch and the last batch bounds-tested
         while (j0 < n && keep_going(j0)) {
-            // A holds batch j0 (issued a batch ago), PB the positions of batch j0+RB (issued two batches ago)
-            asm volatile("" ::"s"(A.rx[0]), "s"(PB.p[0]) : "memory");
-            if (j0 + RB < n) load4(PB, B);
-            if (j0 + 2 * RB < n) loadp(j0 + 2 * RB, PA);
-            blend4(j0, A);
+            arrived(A, PB);
+            load4(PB, B);   // clamped positions are always valid: past the end these re-fetch the last record
+            loadp(j0 + 2 * RB, PA, std::false_type{});
+            blend(j0, A);
             j0 += RB;
-            if (!(j0 < n && keep_going(j0))) break;
-            asm volatile("" ::"s"(B.rx[0]), "s"(PA.p[0]) : "memory");
-            if (j0 + RB < n) load4(PA, A);
-            if (j0 + 2 * RB < n) loadp(j0 + 2 * RB, PB);
-            blend4(j0, B);
+            if (j0 >= n) break;   // the open-pixel test runs once per two batches: closed pixels ignore the extra records by construction
+            arrived(B, PA);
+            load4(PA, A);
+            loadp(j0 + 2 * RB, PB, std::false_type{});
+            blend(j0, B);
             j0 += RB;
         }
     }
@@ -936,13 +960,13 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     // (ballot) go through the sequential T/C update, in stream order -- the arithmetic per contributing
     // record and its order are unchanged, so results stay bit-identical.
     if (j0 < n) {
-        unsigned long long open_mask = __ballot(!done);
+        unsigned long long open_mask = __ballot(Tw > 0.0f);
         while (open_mask) {
             const int p = __builtin_ctzll(open_mask);
             open_mask &= open_mask - 1;
             const float ppx = (float)(tile_x * GSR_BLOCK_X + (wave & 1) * 8 + (p & 7));
             const float ppy = (float)(tile_y * GSR_BLOCK_Y + (wave >> 1) * 8 + (p >> 3));
-            float Tp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(T), p));
+            float Tp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tw), p));   // open: Tw == T
             float A0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C0), p));
             float A1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C1), p));
             float A2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C2), p));
