@@ -31,6 +31,29 @@ __device__ __forceinline__ float swap16_add(float a, float b)
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);   // rows 0,2: a's row pairs, rows 1,3: b's
 }
+// 16-lane sums of FOUR registers at once: bank b (lanes 4b..4b+3 of every row) of the result holds the row sum of register b.
+__device__ __forceinline__ float bank_merge(float keep, float take, const int bank_mask_sel)
+{
+    // lanes of the banks in the mask take `take`, the others keep `keep` (v_mov_b32_dpp with an identity quad_perm)
+    return bank_mask_sel == 0xA
+               ? __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(take), 0xE4, 0xf, 0xA, false))
+               : __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(take), 0xE4, 0xf, 0xC, false));
+}
+__device__ __forceinline__ float row_sum4(float a, float b, float c, float d)
+{
+    a += dpp_f<0x141, 0xf>(a);  // row_half_mirror: every bank now holds a half-row's partials (banks 0,1 the same total; 2,3 too)
+    b += dpp_f<0x141, 0xf>(b);
+    c += dpp_f<0x141, 0xf>(c);
+    d += dpp_f<0x141, 0xf>(d);
+    float ab = bank_merge(a, b, 0xA);   // banks 0,2: a    banks 1,3: b
+    float cd = bank_merge(c, d, 0xA);
+    ab += dpp_f<0x128, 0xf>(ab);        // row_ror:8: the other half-row's partials of the same register
+    cd += dpp_f<0x128, 0xf>(cd);
+    float r = bank_merge(ab, cd, 0xC);  // bank 0: a, 1: b, 2: c, 3: d
+    r += dpp_f<0xB1, 0xf>(r);           // quad_perm [1,0,3,2]
+    r += dpp_f<0x4E, 0xf>(r);           // quad_perm [2,3,0,1]
+    return r;
+}
 __device__ __forceinline__ float row_sum(float v)
 {
     v += dpp_f<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
@@ -81,7 +104,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
         g2 = dL_dpix[2 * HW + pix_id];
     }
     const float bg_dot = s.bg[0] * g0 + s.bg[1] * g1 + s.bg[2] * g2;
-    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+    const float neg_Tf_bg = -T_final * bg_dot;   // the background's share of dL/dalpha, times (1 - alpha) of the record
 
     float T = T_final;
     float Sb = 0.f;                              // (colour accumulated behind the current splat) . dL/dpixel
@@ -95,39 +118,46 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
     if (jmax > 320) __builtin_amdgcn_s_setprio(3);
     else if (jmax > 192) __builtin_amdgcn_s_setprio(2);
     else if (jmax > 96) __builtin_amdgcn_s_setprio(1);   // deepest contributor of any pixel of this wave
-    struct Rec2 { float rx[2], ry[2], ca[2], cb[2], cc[2], op[2], cr[2], cg[2], cbl[2]; uint32_t id[2]; };
+    struct Rec2 { f32x8 a[2]; float cbl[2]; uint32_t id[2]; };   // a = (x, y, conic a, conic b, conic c, opacity, red, green)
     struct Pos2 { uint32_t p[2]; };
+    // both streams through the CONSTANT address space with 32-bit byte offsets (as k_render): scalar loads, register-offset form
+    typedef const __attribute__((address_space(4))) char* cbytes;
+    const cbytes recb = (cbytes)(uintptr_t)rec;
+    const cbytes qpb = (cbytes)(uintptr_t)qp;
     auto loadp = [&](int jp, Pos2& P) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) P.p[u] = qp[max(0, min(jp + u, nq - 1))];
+        for (int u = 0; u < 2; ++u) P.p[u] = *(const __attribute__((address_space(4))) uint32_t*)(qpb + min((uint32_t)(jp + u), (uint32_t)(nq - 1)) * 4u);   // one unsigned clamp: a negative index (walk over) wraps high
     };
     auto load2 = [&](const Pos2& P, Rec2& R) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const size_t j = (size_t)P.p[u];
-            const float4 r0 = rec[3 * j + 0];
-            const float4 r1 = rec[3 * j + 1];
-            const float4 r2 = rec[3 * j + 2];
-            R.rx[u] = r0.x; R.ry[u] = r0.y; R.ca[u] = r0.z; R.cb[u] = r0.w;
-            R.cc[u] = r1.x; R.op[u] = r1.y; R.cr[u] = r1.z; R.cg[u] = r1.w; R.cbl[u] = r2.x;
-            R.id[u] = __float_as_uint(r2.y);
+            const uint32_t off = P.p[u] * 48u;
+            R.a[u] = *(const __attribute__((address_space(4))) f32x8*)(recb + off);
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 t = *(const __attribute__((address_space(4))) u32x2*)(recb + off + 32);
+            R.cbl[u] = __uint_as_float(t[0]);
+            R.id[u] = t[1];
         }
     };
     float v[RB][9];
     uint32_t id[RB];
+    // which component of which register a lane delivers to the accumulator after the reduction below
+    const int l16 = lane & 15;
+    const bool sel_v2 = (l16 & 3) == 1, sel_v3 = l16 == 2;
+    const int c_sel = sel_v3 ? 8 : ((l16 & 3) == 0 ? (l16 >> 2) : (sel_v2 ? 4 + (l16 >> 2) : -1));
     // records jp, jp+1 (visited jp+1 first: back to front) -> v[uo], v[uo+1]
     auto grad2 = [&](int jp, const Rec2& R, int uo) -> bool {
         float G[2], alpha[2], dxs[2], dys[2];
         bool hit[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            dxs[u] = R.rx[u] - pixx;
-            dys[u] = R.ry[u] - pixy;
-            const float power = -0.5f * (R.ca[u] * dxs[u] * dxs[u] + R.cc[u] * dys[u] * dys[u]) - R.cb[u] * dxs[u] * dys[u];
+            dxs[u] = R.a[u][0] - pixx;
+            dys[u] = R.a[u][1] - pixy;
+            const float power = -0.5f * (R.a[u][2] * dxs[u] * dxs[u] + R.a[u][4] * dys[u] * dys[u]) - R.a[u][3] * dxs[u] * dys[u];
             // hardware 2^x (v_exp_f32, ~1 ulp) instead of the forward's 13-instruction bit-reproducible polynomial: the backward
             // is compared with a tolerance, and a record whose alpha sits within an ulp of 1/255 flipping in or out is noise
             G[u] = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
-            alpha[u] = sel_min(0.99f, R.op[u] * G[u]);
+            alpha[u] = sel_min(0.99f, R.a[u][5] * G[u]);
             hit[u] = (jp + u) < last && power <= 0.0f && alpha[u] >= 1.0f / 255.0f;
             id[uo + u] = R.id[u];
         }
@@ -138,35 +168,34 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
                 for (int c = 0; c < 9; ++c) v[uo + u][c] = 0.f;
             return false;
         }
-        // Select-free sequential part.  A record that does not touch this pixel gets G = 0: then alpha = 0, 1/(1-alpha) = 1,
-        // T is multiplied by exactly 1, every partial below is a product with G, alpha*T or dL/dG = 0, and the "colour behind"
-        // recurrence passes it by (its weight is the record's own alpha).  That recurrence is tracked as ONE scalar, the
-        // colour behind dotted with this pixel's dL/dpixel (the only way it is ever used), instead of three channels.
+        // Sequential part, written for instruction count (this wave retires one instruction per ~6.6 cycles whatever its kind).
+        // A record that does not touch this pixel gets G = alpha = 0: then 1/(1-alpha) = 1, T is multiplied by exactly 1, every
+        // partial below is a product with G or alpha, and the "colour behind" recurrence passes it by (its weight is the
+        // record's own alpha).  That recurrence is tracked as ONE scalar, the colour behind dotted with this pixel's
+        // dL/dpixel (the only way it is ever used).  The partials leave here WITHOUT their constant factors (-W/2, -H/2 on the
+        // position pair, -1/2 on the conic triple): k_preprocess_bwd applies them once per splat instead of once per pixel.
 #pragma unroll
         for (int u = 1; u >= 0; --u) {
             const float Gh = hit[u] ? G[u] : 0.f;
-            const float al = sel_min(0.99f, R.op[u] * Gh);
+            const float al = hit[u] ? alpha[u] : 0.f;
             const float one_m = 1.f - al;
             const float rinv = __builtin_amdgcn_rcpf(one_m);
             const float Tn = T * rinv;
             const float w = al * Tn;
-            const float cg = R.cr[u] * g0 + R.cg[u] * g1 + R.cbl[u] * g2;
+            const float cg = R.a[u][6] * g0 + R.a[u][7] * g1 + R.cbl[u] * g2;
             Sb = last_alpha * last_cg + last_one_m * Sb;
-            float dL_dalpha = (cg - Sb) * Tn;
-            dL_dalpha += (-T_final * rinv) * bg_dot;
-            const float dL_dG = R.op[u] * dL_dalpha;
-            const float gdx = Gh * dxs[u], gdy = Gh * dys[u];
-            const float dG_ddelx = -gdx * R.ca[u] - gdy * R.cb[u];
-            const float dG_ddely = -gdy * R.cc[u] - gdx * R.cb[u];
+            const float dL_dalpha = (cg - Sb) * Tn + neg_Tf_bg * rinv;
+            const float q = Gh * (R.a[u][5] * dL_dalpha);     // G * dL/dG
+            const float ax = q * dxs[u], ay = q * dys[u];
             float* vv = v[uo + u];
             vv[0] = w * g0;
             vv[1] = w * g1;
             vv[2] = w * g2;
-            vv[3] = dL_dG * dG_ddelx * ddelx_dx;
-            vv[4] = dL_dG * dG_ddely * ddely_dy;
-            vv[5] = -0.5f * gdx * dxs[u] * dL_dG;
-            vv[6] = -0.5f * gdx * dys[u] * dL_dG;
-            vv[7] = -0.5f * gdy * dys[u] * dL_dG;
+            vv[3] = ax * R.a[u][2] + ay * R.a[u][3];          // x (-W/2) = dL/dmean2D.x
+            vv[4] = ay * R.a[u][4] + ax * R.a[u][3];          // x (-H/2) = dL/dmean2D.y
+            vv[5] = ax * dxs[u];                              // x (-1/2) = dL/dconic (a, b, c)
+            vv[6] = ax * dys[u];
+            vv[7] = ay * dys[u];
             vv[8] = Gh * dL_dalpha;
             T = Tn;
             last_alpha = al;
@@ -188,32 +217,39 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
         asm volatile("" ::"s"(PA.p[0]), "s"(PB.p[0]) : "memory");
         load2(PA, A);
         for (; jb >= 0; jb -= RB) {
-            asm volatile("" ::"s"(A.rx[0]), "s"(PB.p[0]) : "memory");
+            asm volatile("" ::"s"(A.a[0]), "s"(PB.p[0]) : "memory");
             load2(PB, B);
             loadp(jb - RB + 2, PA);          // clamped inside loadp when the walk is about to end
             const bool h1 = grad2(jb + 2, A, 2);
-            asm volatile("" ::"s"(B.rx[0]), "s"(PA.p[0]) : "memory");
+            asm volatile("" ::"s"(B.a[0]), "s"(PA.p[0]) : "memory");
             if (jb - RB >= 0) load2(PA, A);
             loadp(jb - RB, PB);
             const bool h0 = grad2(jb, B, 0);
             if (!(h0 || h1)) continue;
-            // transposed reduction: rows 0..3 of t[c] <- records 0, 2, 1, 3
-            float mine = 0.f;
-            const int c_sel = lane & 15;
+            // Transposed reduction.  Lane halves, then row pairs (permlane swaps): afterwards row r of t[c] holds 16 partial
+            // sums of component c of record kRowRec[r] = {0, 2, 1, 3}[r].  Inside the rows the transposition goes on at bank
+            // (4-lane) granularity: two registers share one after the half-row step, four after the row step, so the 16-lane
+            // sums of four components cost 11 DPP operations instead of 16, and bank b of the result holds component b.
+            float t[9];
 #pragma unroll
             for (int c = 0; c < 9; ++c) {
                 const float s01 = swap32_add(v[0][c], v[1][c]);
                 const float s23 = swap32_add(v[2][c], v[3][c]);
-                const float t = row_sum(swap16_add(s01, s23));
-                mine = (c_sel == c) ? t : mine;
+                t[c] = swap16_add(s01, s23);
             }
+            const float V1 = row_sum4(t[0], t[1], t[2], t[3]);
+            const float V2 = row_sum4(t[4], t[5], t[6], t[7]);
+            const float V3 = row_sum(t[8]);
+            float mine = V1;                       // lanes 0,4,8,12 of a row: components 0..3
+            mine = sel_v2 ? V2 : mine;             // lanes 1,5,9,13: components 4..7
+            mine = sel_v3 ? V3 : mine;             // lane 2: component 8
             const int row = lane >> 4;
             uint32_t myid = id[0];
             myid = (row == 1) ? id[2] : myid;
             myid = (row == 2) ? id[1] : myid;
             myid = (row == 3) ? id[3] : myid;
             const int rec_u = (row == 1) ? 2 : ((row == 2) ? 1 : row);
-            if (c_sel < 9 && (jb + rec_u) < nq && mine != 0.f) unsafeAtomicAdd(acc + (size_t)GSR_ACC_STRIDE * myid + c_sel, mine);
+            if (c_sel >= 0 && (jb + rec_u) < nq && mine != 0.f) unsafeAtomicAdd(acc + (size_t)GSR_ACC_STRIDE * myid + c_sel, mine);
         }
     }
 #ifdef GSR_EXPERIMENT_TIMELINE
@@ -266,8 +302,9 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
             ac4[0] = z; ac4[1] = z; ac4[2] = z;
         }
         gcol[0] = q0.x; gcol[1] = q0.y; gcol[2] = q0.z;
-        g2x = q0.w; g2y = q1.x;
-        const float gA = q1.y, gB = q1.z, gC = q1.w;
+        // k_render_bwd leaves the constant factors of these five to us (once per splat instead of once per pixel)
+        g2x = -0.5f * (float)s.W * q0.w; g2y = -0.5f * (float)s.H * q1.x;
+        const float gA = -0.5f * q1.y, gB = -0.5f * q1.z, gC = -0.5f * q1.w;
         gop = q2.x;
         const float* vm = s.viewmatrix;
         const float* proj = s.projmatrix;
