@@ -77,7 +77,7 @@ class GsrBinningLayout(C.Structure):
 
 
 class GsrImageLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("final_T", "n_contrib", "n_contrib_q", "total")]
+    _fields_ = [(n, C.c_size_t) for n in ("final_T", "n_contrib", "n_contrib_q", "c_final", "ck", "total")]
 
 
 #: every symbol include/gsr.h declares -> (restype, argtypes)

@@ -182,6 +182,8 @@ int gsr_image_layout(int32_t width, int32_t height, GsrImageLayout* o)
     o->final_T = off;   off = align_up(off + hw * 4, A);
     o->n_contrib = off; off = align_up(off + hw * 4, A);
     o->n_contrib_q = off; off = align_up(off + hw * 4, A);
+    o->c_final = off;   off = align_up(off + hw * 12, A);
+    o->ck = off;        off = align_up(off + hw * 16 * (GSR_BWD_SEGMENTS - 1), A);
     o->total = off + A;
     return 0;
 }
@@ -330,7 +332,8 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
         TIMED(GSR_K_RENDER, stream);
         hipLaunchKernelGGL(gsr::k_render, dim3(tiles), dim3(256), 0, stream, ds, (const uint32_t*)tile_order, (const uint2*)ranges,
                            (const uint32_t*)qcount, (const float4*)qrecords, (const uint32_t*)qpos, (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib),
-                           (uint32_t*)(im + il.n_contrib_q), out_color, cap, (const unsigned long long*)total_dev);
+                           (uint32_t*)(im + il.n_contrib_q), (float*)(im + il.c_final), (float4*)(im + il.ck), out_color, cap,
+                           (const unsigned long long*)total_dev);
         KERNEL_CHECK("k_render", stream, dbg);
     }
 
@@ -410,9 +413,10 @@ int gsr_backward_ex(const GsrSettings* settings, int32_t P, int32_t M, const flo
     float* grad_scratch = (float*)(g + gl.acc);   // zeroed by the forward (and by the previous backward)
     if (num_rendered > 0) {
         TIMED(GSR_K_RENDER_BWD, stream);
-        hipLaunchKernelGGL(gsr::k_render_bwd, dim3(gx * gy), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order),
+        hipLaunchKernelGGL(gsr::k_render_bwd, dim3(gx * gy * GSR_BWD_SEGMENTS), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order),
                            (const uint2*)(b + bl.ranges), (const uint32_t*)(b + bl.qcount), (const float4*)(b + bl.qrecords), (const uint32_t*)(b + bl.qpos),
-                           (const float*)(im + il.final_T), (const uint32_t*)(im + il.n_contrib_q), dL_dpix, grad_scratch);
+                           (const float*)(im + il.final_T), (const uint32_t*)(im + il.n_contrib_q), dL_dpix, grad_scratch,
+                           (const float*)(im + il.c_final), (const float4*)(im + il.ck), gx * gy);
         KERNEL_CHECK("k_render_bwd", stream, dbg);
     }
     gsr::PreBwdArgs pa;

@@ -72,14 +72,21 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
                                                      const float4* __restrict__ qrecords, const uint32_t* __restrict__ qpos,
                                                      const float* __restrict__ final_T,
                                                      const uint32_t* __restrict__ n_contrib_q, const float* __restrict__ dL_dpix,
-                                                     float* __restrict__ acc /* [P][GSR_ACC_STRIDE] */)
+                                                     float* __restrict__ acc /* [P][GSR_ACC_STRIDE] */,
+                                                     const float* __restrict__ c_final, const float4* __restrict__ ck, int tiles)
 {
 #ifdef GSR_EXPERIMENT_TIMELINE
     const unsigned long long t_start = wall_clock64();
 #endif
     const int W = s.W, H = s.H;
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X;
-    const int tile = (int)tile_order[blockIdx.x];
+    // Workgroup = (tile, segment): a quadrant's back-to-front walk is cut into GSR_BWD_SEGMENTS pieces of GSR_BWD_SEGMENT stream
+    // entries (the last piece takes the rest) and every piece runs on its own wave, starting from the (T, C) checkpoint the
+    // forward left at its upper end.  The walk is strictly serial per pixel, and the kernel used to end when the deepest
+    // quadrant (~600 records) ended while the average wave was done after a quarter of that.  Segment 0 of every tile is
+    // dispatched first, the (ever sparser) deeper segments behind them.
+    const int seg = (int)blockIdx.x / tiles;
+    const int tile = (int)tile_order[(int)blockIdx.x - seg * tiles];
     const int tile_x = tile % gx, tile_y = tile / gx;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
@@ -87,16 +94,22 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
     const int pyi = tile_y * GSR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = pxi < W && pyi < H;
     const float pixx = (float)pxi, pixy = (float)pyi;
+    const int nq = (int)qcount[4 * tile + wave];
+    const int seg_lo = seg * GSR_BWD_SEGMENT;
+    if (nq <= seg_lo) return;                    // the stream ends below this segment
     const uint2 range = ranges[tile];
     const uint32_t nt = range.y - range.x;
-    const int nq = (int)qcount[4 * tile + wave];
     const float4* __restrict__ rec = qrecords + (size_t)3 * range.x;                         // the tile's records (sorted)
     const uint32_t* __restrict__ qp = qpos + (size_t)4 * range.x + (size_t)wave * nt;       // this quadrant's positions into them
 
     const int pix_id = W * pyi + pxi;
     const size_t HW = (size_t)H * W;
     const float T_final = inside ? final_T[pix_id] : 0.f;
-    const int last = inside ? (int)n_contrib_q[pix_id] : 0;
+    const int last_pix = inside ? (int)n_contrib_q[pix_id] : 0;        // one past the pixel's last contributing stream entry
+    const int seg_hi = seg == GSR_BWD_SEGMENTS - 1 ? 0x7fffffff : seg_lo + GSR_BWD_SEGMENT;
+    const int last = last_pix > seg_lo ? min(last_pix, seg_hi) : 0;    // this wave handles entries seg_lo .. last-1 of the pixel
+    const int jmax = min((int)wave_max_u32((uint32_t)last), nq);
+    if (jmax == 0) return;                       // nothing of this segment in this quadrant
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (inside) {
         g0 = dL_dpix[0 * HW + pix_id];
@@ -110,14 +123,23 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
     float Sb = 0.f;                              // (colour accumulated behind the current splat) . dL/dpixel
     float last_cg = 0.f;                         // (colour of the previously visited splat) . dL/dpixel
     float last_alpha = 0.f, last_one_m = 1.f;
+    if (last_pix > seg_hi) {
+        // the pixel's walk continues above this segment: start from the forward's checkpoint at entry seg_hi.  T is the
+        // transmittance there; the colour behind it is what the pixel ended with minus what it had there, over T (the
+        // division by T cancels against the factor T of every use, so the cancellation error stays at fp32 round-off).
+        const float4 c = ck[(size_t)seg * HW + pix_id];
+        T = c.x;
+        const float b0 = c_final[0 * HW + pix_id] - c.y, b1 = c_final[1 * HW + pix_id] - c.z, b2 = c_final[2 * HW + pix_id] - c.w;
+        Sb = (b0 * g0 + b1 * g1 + b2 * g2) / T;
+    }
 
     constexpr int RB = 4;
-    const int jmax = min((int)wave_max_u32((uint32_t)last), nq);
     // The kernel ends when its longest walk ends (0.6 M wave-records in total, but the deepest quadrant walks ~500 of them
     // strictly in order): let the deep walks win issue arbitration over the shallow ones sharing their SIMD.
-    if (jmax > 320) __builtin_amdgcn_s_setprio(3);
-    else if (jmax > 192) __builtin_amdgcn_s_setprio(2);
-    else if (jmax > 96) __builtin_amdgcn_s_setprio(1);   // deepest contributor of any pixel of this wave
+    const int walk = jmax - seg_lo;              // only the open-ended last segment can be long
+    if (walk > 320) __builtin_amdgcn_s_setprio(3);
+    else if (walk > 192) __builtin_amdgcn_s_setprio(2);
+    else if (walk > 96) __builtin_amdgcn_s_setprio(1);
     struct Rec2 { f32x8 a[2]; float cbl[2]; uint32_t id[2]; };   // a = (x, y, conic a, conic b, conic c, opacity, red, green)
     struct Pos2 { uint32_t p[2]; };
     // both streams through the CONSTANT address space with 32-bit byte offsets (as k_render): scalar loads, register-offset form
@@ -208,7 +230,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
     // loads of the NEXT pair are issued before the current pair is processed (same lgkmcnt(0) pinning as
     // the forward kernel).
     int jb = ((jmax + RB - 1) / RB) * RB - RB;
-    if (jb >= 0) {
+    if (jb >= seg_lo) {   // seg_lo is a multiple of RB: batches never straddle a segment boundary
         Rec2 A, B;
         Pos2 PA, PB;
         // two-level scalar fetch (as the forward): positions two pairs ahead, records one pair ahead
@@ -216,13 +238,13 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
         loadp(jb, PB);
         asm volatile("" ::"s"(PA.p[0]), "s"(PB.p[0]) : "memory");
         load2(PA, A);
-        for (; jb >= 0; jb -= RB) {
+        for (; jb >= seg_lo; jb -= RB) {
             asm volatile("" ::"s"(A.a[0]), "s"(PB.p[0]) : "memory");
             load2(PB, B);
             loadp(jb - RB + 2, PA);          // clamped inside loadp when the walk is about to end
             const bool h1 = grad2(jb + 2, A, 2);
             asm volatile("" ::"s"(B.a[0]), "s"(PA.p[0]) : "memory");
-            if (jb - RB >= 0) load2(PA, A);
+            if (jb - RB >= seg_lo) load2(PA, A);
             loadp(jb - RB, PB);
             const bool h0 = grad2(jb, B, 0);
             if (!(h0 || h1)) continue;

@@ -810,6 +810,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
                                                  const float4* __restrict__ qrecords, const uint32_t* __restrict__ qpos,
                                                  float* __restrict__ final_T,
                                                  uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ n_contrib_q,
+                                                 float* __restrict__ c_final, float4* __restrict__ ck,
                                                  float* __restrict__ out_color, unsigned long long capacity,
                                                  const unsigned long long* __restrict__ total_dev)
 {
@@ -922,6 +923,24 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     };
     // Software-pipelined walk: the scalar loads of batch k+1 are issued BEFORE batch k is blended, right after the wait for
     // batch k's own loads (issued a whole batch ago) -- placed the other way round the wait would stall on the fresh loads.
+    // Blend checkpoints for the backward (include/gsr.h, GsrImageLayout.ck): the state (T, C) of every pixel just before
+    // stream entry s * GSR_BWD_SEGMENT, s = 1 .. GSR_BWD_SEGMENTS-1.  GSR_BWD_SEGMENT is a multiple of the two batches one
+    // iteration of the walk takes, so the test sits at the top of the loop only.  The store is unconditional: lanes outside
+    // the image aim at the spare slot behind the array (the layout's tail padding), closed pixels rewrite slots nobody reads.
+    static_assert(GSR_BWD_SEGMENT % (2 * RB) == 0, "checkpoints sit on iteration boundaries of the walk");
+    const size_t HWs = (size_t)H * W;
+    float4* ck_ptr = ck + (inside ? (size_t)(W * pyi + pxi) : (size_t)(GSR_BWD_SEGMENTS - 1) * HWs);
+    const size_t ck_step = inside ? HWs : 0;
+    int next_ck = GSR_BWD_SEGMENT;
+    auto checkpoint = [&](int jtop) {
+        if (jtop == next_ck) {
+            if (next_ck <= (GSR_BWD_SEGMENTS - 1) * GSR_BWD_SEGMENT) {
+                *ck_ptr = make_float4(T, C0, C1, C2);
+                ck_ptr += ck_step;
+            }
+            next_ck += GSR_BWD_SEGMENT;
+        }
+    };
     int j0 = 0;
     if (n > 0) {
         Rec4 A, B;
@@ -935,6 +954,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         // test runs once per two batches (a closed pixel ignores the extra records by construction).
         // the last batches of the stream: the same walk with every fetch and the last batch bounds-tested
         while (j0 < n && keep_going(j0)) {
+            checkpoint(j0);
             arrived(A, PB);
             load4(PB, B);   // clamped positions are always valid: past the end these re-fetch the last record
             loadp(j0 + 2 * RB, PA, std::false_type{});
@@ -949,6 +969,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         }
     }
 
+    if (j0 < n) checkpoint(j0);   // the walk stopped exactly on a checkpoint entry (tail mode takes over from here)
 #ifdef GSR_EXPERIMENT_TIMELINE
     const unsigned long long t_main = wall_clock64();
     const int j_main = j0;
@@ -972,6 +993,8 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
             float A2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(C2), p));
             uint32_t lastqp = (uint32_t)__builtin_amdgcn_readlane((int)last_q, p);
             bool donep = false;
+            int e_ck = next_ck;                               // this pixel's next checkpoint (the main loop stored the earlier ones)
+            float4* at_ck = ck + (size_t)(e_ck / GSR_BWD_SEGMENT - 1) * HWs + (size_t)(W * (int)ppy + (int)ppx);
             for (int c0 = j0; c0 < n && !donep; c0 += GSR_WAVE) {
                 const int j = c0 + lane;
                 const bool valid = j < n;
@@ -988,6 +1011,11 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
                 while (hits) {
                     const int k = __builtin_ctzll(hits);
                     hits &= hits - 1;
+                    while (c0 + k >= e_ck && e_ck <= (GSR_BWD_SEGMENTS - 1) * GSR_BWD_SEGMENT) {   // state before entry e_ck = after every hit below it
+                        if (lane == 0) *at_ck = make_float4(Tp, A0, A1, A2);
+                        e_ck += GSR_BWD_SEGMENT;
+                        at_ck += HWs;
+                    }
                     const float ak = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), k));
                     const float test_T = Tp * (1.0f - ak);
                     if (test_T < 0.0001f) { donep = true; break; }
@@ -1018,6 +1046,9 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         n_contrib[pix_id] = last_contributor;
         n_contrib_q[pix_id] = last_q;
         const size_t HW = (size_t)H * W;
+        c_final[0 * HW + pix_id] = C0;
+        c_final[1 * HW + pix_id] = C1;
+        c_final[2 * HW + pix_id] = C2;
         out_color[0 * HW + pix_id] = C0 + T * s.bg[0];
         out_color[1 * HW + pix_id] = C1 + T * s.bg[1];
         out_color[2 * HW + pix_id] = C2 + T * s.bg[2];

@@ -29,6 +29,8 @@ extern "C" {
 #endif
 
 #define GSR_ABI_VERSION 1
+#define GSR_BWD_SEGMENT 132       /* stream entries per backward segment (a multiple of both blend kernels' batches)  */
+#define GSR_BWD_SEGMENTS 6        /* segments per quadrant stream; the last one takes whatever is left                */
 #define GSR_BIN_BLOCKS 256        /* workgroups of the two binning passes (each owns a contiguous chunk of splats) */
 #define GSR_BLOCK_X 16
 #define GSR_BLOCK_Y 16
@@ -112,6 +114,10 @@ typedef struct GsrImageLayout {
     size_t final_T;    /* float  [H*W] */
     size_t n_contrib;  /* uint32 [H*W] last contributor, index+1 in the TILE list (== the reference's n_contrib) */
     size_t n_contrib_q;/* uint32 [H*W] the same position inside the pixel's quadrant stream (what the backward walks) */
+    size_t c_final;    /* float  [3*H*W] the composited colour WITHOUT the background term (planar)               */
+    size_t ck;         /* float4 [(GSR_BWD_SEGMENTS-1)*H*W] blend checkpoints: slot s-1 of a pixel = (T, C) before entry
+                          s*GSR_BWD_SEGMENT of its quadrant stream.  The backward walks each segment of a pixel's stream on
+                          its own wave, starting from the checkpoint (the serial walk was the kernel's critical path). */
     size_t total;
 } GsrImageLayout;
 
