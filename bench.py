@@ -212,8 +212,9 @@ def main():
 
     from gaussianavatars_amd import _lib
     from gaussianavatars_amd import rasterizer as R
-    from gaussianavatars_amd.frame_parallel import frames_for_rank
+    from gaussianavatars_amd.frame_parallel import frames_for_rank, pin_to_gpu_numa_node
 
+    pinned = pin_to_gpu_numa_node(local_rank)   # host launch latency: stay on the GPU's socket
     if args.workload == "cfg5":
         g, cam = build_unbound_scene(device, args.splats, 3, args.width, args.height)
     else:
@@ -357,7 +358,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             # the frame's single host wait (for the instance count): ~0 would mean the host paces the loop, not the GPU
-            "host": {"scan_wait_ms_per_step": round(wait_ms / max(waits, 1), 4)},
+            "host": {"scan_wait_ms_per_step": round(wait_ms / max(waits, 1), 4), "pinned_cpus": len(pinned) if pinned else None},
         }
         print(json.dumps(out))
     if dist is not None:

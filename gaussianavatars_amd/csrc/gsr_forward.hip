@@ -495,12 +495,15 @@ __device__ __forceinline__ void cx_tail(u64 (&key)[EPT], u64* __restrict__ sk, i
     }
 }
 template <int SIZE, int N, int THREADS, int EPT>
-__device__ __forceinline__ void cx_stage(u64 (&key)[EPT], u64* __restrict__ sk, int tid)
+__device__ __forceinline__ void cx_stage(u64 (&key)[EPT], u64* __restrict__ sk, int tid, uint32_t n)
 {
     if constexpr (SIZE <= N) {
+        // a merge of blocks of SIZE/2 has nothing to do once the first block holds every real key (the rest is +inf padding):
+        // the network stops at the first power of two >= n instead of at the class size (workgroup-uniform test)
+        if ((uint32_t)(SIZE / 2) >= n) return;
         cx_step<SIZE - 1, THREADS, EPT>(key, sk, tid);            // first step of a merge: partner = i ^ (size - 1)
         cx_tail<(SIZE >> 2), THREADS, EPT>(key, sk, tid);         // then i ^ j for j = size/4 ... 1
-        cx_stage<(SIZE << 1), N, THREADS, EPT>(key, sk, tid);
+        cx_stage<(SIZE << 1), N, THREADS, EPT>(key, sk, tid, n);
     }
 }
 
@@ -513,7 +516,7 @@ __device__ __forceinline__ void block_sort_regs(u64 (&key)[EPT], u64* __restrict
         const uint32_t i = (uint32_t)tid * (uint32_t)EPT + (uint32_t)k;
         key[k] = i < n ? seg[i] : ~0ull;
     }
-    cx_stage<2, EPT * THREADS, THREADS, EPT>(key, sk, tid);
+    cx_stage<2, EPT * THREADS, THREADS, EPT>(key, sk, tid, n);
 }
 
 // Which of the tile's four 8x8 quadrants can the splat's {alpha >= 1/255} ellipse reach?  (bit q set = keep)

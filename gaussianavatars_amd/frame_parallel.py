@@ -22,6 +22,34 @@ def frames_for_rank(num_frames: int, rank: int, world_size: int) -> List[int]:
     return list(range(rank, num_frames, world_size))
 
 
+def pin_to_gpu_numa_node(device_index: int = 0) -> Optional[List[int]]:
+    """Restrict this process to the CPU cores of the NUMA node the GPU hangs off (one process per GPU: each rank calls it
+    with its LOCAL_RANK).  The frame loop launches ~45 small kernels and polls one mapped-pinned word per frame; from the
+    far socket of a two-socket host every doorbell write and every poll crosses the inter-socket link and the same loop
+    measured 0.75 ms instead of 0.55 ms of host time per frame.  Returns the core list, or None when the topology cannot be
+    read (then nothing is changed)."""
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            spec = f.read().strip()
+        cpus: List[int] = []
+        for part in spec.split(","):
+            lo, _, hi = part.partition("-")
+            cpus.extend(range(int(lo), int(hi or lo) + 1))
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return allowed
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None
+
+
 def init_process_group(backend: Optional[str] = None):
     """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment (torchrun contract).
     backend: 'nccl' (= RCCL on ROCm) on GPUs, 'gloo' on CPU."""

@@ -36,6 +36,14 @@ def scene(name):
         sp = S.random_splats(4000, 0, 18, xyz_sigma=0.05, log_scale_mean=math.log(0.004))
         sp["means3D"][:, 2] = np.round(sp["means3D"][:, 2] * 40.0) / 40.0   # the default camera looks down -z: depth = 1 - z
         return S.orbit_camera(96, 96), sp, [0.5, 0.5, 0.5], 0, 1.0
+    if name == "deep_stack":  # ~1500 faint splats over the same few tiles: every pixel's blend walks through all the backward's
+        # segments (GSR_BWD_SEGMENT entries each, the last one open-ended), many pixels never saturate (tail mode, and the
+        # checkpoints it writes), the opaque sixth closes others mid-stream
+        sp = S.random_splats(1500, 1, 19, xyz_sigma=0.012, log_scale_mean=math.log(0.012), log_scale_sigma=0.3)
+        sp["opacities"][:] = 0.006 + 0.01 * np.random.default_rng(20).random((1500, 1), dtype=np.float32)
+        sp["opacities"][::6] = 0.2
+        sp["means3D"][::6, :2] += 0.02
+        return S.orbit_camera(48, 40), sp, [0.4, 0.1, 0.6], 1, 1.0
     if name == "empty_view":  # nothing visible
         sp = S.random_splats(500, 0, 15)
         sp["means3D"][:, 2] += 3.0

@@ -97,7 +97,7 @@ def _check_forward(st, hs):
     assert checked or I == 0
 
 
-@pytest.mark.parametrize("name", ["cfg1", "sh3_small", "sh2_mod", "culls", "dense_tile", "dense_tile_xl", "depth_ties", "empty_view", "huge_grid"])
+@pytest.mark.parametrize("name", ["cfg1", "sh3_small", "sh2_mod", "culls", "dense_tile", "dense_tile_xl", "depth_ties", "deep_stack", "empty_view", "huge_grid"])
 def test_forward_bit_exact(oracle, name):
     s, st, hs, rs, _ = _run_both(oracle, name)
     _check_forward(st, hs)
@@ -140,7 +140,7 @@ def _grad_check(oracle, name, use_precomp_color=False, use_precomp_cov=False, rt
     assert float(m2.grad[:, 2].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("name", ["cfg1", "sh3_small", "sh2_mod", "culls", "huge_grid"])
+@pytest.mark.parametrize("name", ["cfg1", "sh3_small", "sh2_mod", "culls", "deep_stack", "huge_grid"])
 def test_backward_matches_oracle(oracle, name):
     # huge_grid: screen-filling splats sum ~10^7 per-pixel terms through fp32 atomics; the run-to-run spread of the most
     # cancellation-prone gradient (rotations) reaches 3e-4 of its max, so that scene gets 1e-3
