@@ -22,30 +22,55 @@ def frames_for_rank(num_frames: int, rank: int, world_size: int) -> List[int]:
     return list(range(rank, num_frames, world_size))
 
 
-def pin_to_gpu_numa_node(device_index: int = 0) -> Optional[List[int]]:
-    """Restrict this process to the CPU cores of the NUMA node the GPU hangs off (one process per GPU: each rank calls it
-    with its LOCAL_RANK).  The frame loop launches ~45 small kernels and polls one mapped-pinned word per frame; from the
-    far socket of a two-socket host every doorbell write and every poll crosses the inter-socket link and the same loop
-    measured 0.75 ms instead of 0.55 ms of host time per frame.  Returns the core list, or None when the topology cannot be
-    read (then nothing is changed)."""
+def _cpulist(spec: str) -> List[int]:
+    cpus: List[int] = []
+    for part in spec.strip().split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def _gpu_numa_node(device_index: int) -> int:
+    props = torch.cuda.get_device_properties(device_index)
+    bdf = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+    with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+        return int(f.read().strip())
+
+
+def pin_to_gpu_numa_node(device_index: int = 0, cores: int = 8) -> Optional[List[int]]:
+    """Restrict this process to `cores` neighbouring physical cores of the NUMA node the GPU hangs off (one process per GPU:
+    each rank calls it with its LOCAL_RANK; GPUs sharing a node get disjoint core groups).
+
+    The frame loop is host-paced: ~45 small kernel launches, one mapped-pinned word polled per frame, and a hand-off to the
+    autograd thread and back.  From the far socket of a two-socket host every doorbell write and every poll crosses the
+    inter-socket link (0.75 ms instead of 0.55 ms of host time per frame); with the two threads on different core complexes
+    of the right socket the hand-offs bounce between L3 slices (0.61 ms).  A group of 8 consecutive physical cores is one
+    core complex on the EPYC hosts of the MI355X boxes.  Returns the CPU list, or None when the topology cannot be read
+    (then nothing is changed)."""
     try:
-        props = torch.cuda.get_device_properties(device_index)
-        bdf = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
-        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
-            node = int(f.read().strip())
+        node = _gpu_numa_node(device_index)
         if node < 0:
             return None
         with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
-            spec = f.read().strip()
-        cpus: List[int] = []
-        for part in spec.split(","):
-            lo, _, hi = part.partition("-")
-            cpus.extend(range(int(lo), int(hi or lo) + 1))
-        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
-        if not allowed:
+            node_cpus = _cpulist(f.read())
+        # one logical CPU per physical core (drop SMT siblings), in core order
+        firsts = []
+        for c in node_cpus:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as f:
+                if min(_cpulist(f.read())) == c:
+                    firsts.append(c)
+        allowed_now = set(os.sched_getaffinity(0))
+        firsts = [c for c in sorted(firsts) if c in allowed_now]
+        if not firsts:
             return None
-        os.sched_setaffinity(0, allowed)
-        return allowed
+        # my slot among the GPUs of this node
+        peers = [d for d in range(torch.cuda.device_count()) if _gpu_numa_node(d) == node]
+        slot = peers.index(device_index) if device_index in peers else 0
+        cores = max(1, min(cores, len(firsts) // max(len(peers), 1)))
+        mine = firsts[slot * cores: slot * cores + cores] or firsts[:cores]
+        os.sched_setaffinity(0, mine)
+        return mine
     except (OSError, ValueError, AttributeError, RuntimeError):
         return None
 
