@@ -61,3 +61,16 @@ def test_two_rank_gloo_allreduce():
     expect = float(sum(t * t for t in range(21)))
     for rank, total, count, mx in res:
         assert total == expect and count == 21 and mx == 2.0
+
+
+def test_cpu_list_parsing_and_pinning_is_a_no_op_without_a_gpu():
+    import os
+
+    from gaussianavatars_amd.frame_parallel import _cpulist, pin_to_gpu_numa_node
+
+    assert _cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert _cpulist("") == []
+    before = os.sched_getaffinity(0)
+    if not torch.cuda.is_available():
+        assert pin_to_gpu_numa_node(0) is None       # topology unreadable: nothing changes
+        assert os.sched_getaffinity(0) == before
