@@ -317,7 +317,9 @@ def main():
             roofline = dict(kernel=dom, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(ach / HBM_PEAK_GBS, 5), traffic=pmc.get(dom),
                             algorithmic_bytes_per_launch=int(algo[dom]), avg_launch_us=round(per_kernel[dom]["avg_us"], 2),
-                            note="alpha-blend kernels are VALU/latency-bound (exp + per-wave critical path), HBM fraction reported as asked",
+                            note=("the tile sort is bound by its sorting network (instruction issue) and by the scattered 48-byte record gathers of "
+                                  "its epilogue, not by streaming bandwidth; HBM fraction reported as asked" if dom == "k_tile_sort" else
+                                  "alpha-blend kernels are VALU-bound (exp + per-wave instruction stream), HBM fraction reported as asked"),
                             all_kernels={k: dict(avg_us=round(v["avg_us"], 2),
                                                  algo_GBs=round(algo[k] / (v["avg_us"] * 1e-6) / 1e9, 1) if k in algo else None)
                                          for k, v in per_kernel.items()})
