@@ -73,7 +73,7 @@ class GsrGeomLayout(C.Structure):
 
 class GsrBinningLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
-                ("keys", "point_list", "qrecords", "qpos", "qcount", "ranges", "tile_count", "tile_start", "tile_cursor", "tile_order", "block_hist", "total")]
+                ("keys", "point_list", "qlist", "qpos", "qcount", "ranges", "tile_count", "tile_start", "tile_cursor", "tile_order", "block_hist", "total")]
 
 
 class GsrImageLayout(C.Structure):

@@ -161,7 +161,7 @@ int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, GsrBinni
     size_t off = 256;  // header: [0] = uint64 instance count of this frame
     o->keys = off;        off = align_up(off + cap * 8, A);
     o->point_list = off;  off = align_up(off + cap * 4, A);
-    o->qrecords = off;    off = align_up(off + cap * 48, A);
+    o->qlist = off;       off = align_up(off + cap * 4 * 4, A);
     o->qpos = off;        off = align_up(off + cap * 4 * 4, A);
     o->qcount = off;      off = align_up(off + tiles * 16, A);
     o->ranges = off;      off = align_up(off + tiles * 8, A);
@@ -302,7 +302,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     const unsigned long long cap = (unsigned long long)binning_capacity;
     unsigned long long* keys = (unsigned long long*)(b + bl.keys);
     uint32_t* point_list = (uint32_t*)(b + bl.point_list);
-    float4* qrecords = (float4*)(b + bl.qrecords);
+    uint32_t* qlist = (uint32_t*)(b + bl.qlist);
     uint32_t* qpos = (uint32_t*)(b + bl.qpos);
     uint32_t* qcount = (uint32_t*)(b + bl.qcount);
     if (pblocks > 0) {
@@ -319,7 +319,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
         TIMED(GSR_K_TILE_SORT, stream);
         auto sort_class = [&](auto kernel, int threads, uint32_t n_lo, uint32_t n_hi) {
             hipLaunchKernelGGL(kernel, dim3(tiles), dim3(threads), 0, stream, n_lo, n_hi, gx, (const uint32_t*)tile_order,
-                               (const uint32_t*)tile_count, (const uint32_t*)tile_start, keys, write_lists ? point_list : nullptr, qrecords, qpos, qcount,
+                               (const uint32_t*)tile_count, (const uint32_t*)tile_start, keys, write_lists ? point_list : nullptr, write_lists ? qlist : nullptr, qpos, qcount,
                                (const float4*)pa.grec, cap,
                                (const unsigned long long*)total_dev);
         };
@@ -331,7 +331,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     {
         TIMED(GSR_K_RENDER, stream);
         hipLaunchKernelGGL(gsr::k_render, dim3(tiles), dim3(256), 0, stream, ds, (const uint32_t*)tile_order, (const uint2*)ranges,
-                           (const uint32_t*)qcount, (const float4*)qrecords, (const uint32_t*)qpos, (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib),
+                           (const uint32_t*)qcount, (const float4*)pa.grec, (const uint32_t*)qpos, write_lists ? (const uint32_t*)qlist : nullptr, (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib),
                            (uint32_t*)(im + il.n_contrib_q), (float*)(im + il.c_final), (float4*)(im + il.ck), out_color, cap,
                            (const unsigned long long*)total_dev);
         KERNEL_CHECK("k_render", stream, dbg);
@@ -414,7 +414,7 @@ int gsr_backward_ex(const GsrSettings* settings, int32_t P, int32_t M, const flo
     if (num_rendered > 0) {
         TIMED(GSR_K_RENDER_BWD, stream);
         hipLaunchKernelGGL(gsr::k_render_bwd, dim3(gx * gy * GSR_BWD_SEGMENTS), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order),
-                           (const uint2*)(b + bl.ranges), (const uint32_t*)(b + bl.qcount), (const float4*)(b + bl.qrecords), (const uint32_t*)(b + bl.qpos),
+                           (const uint2*)(b + bl.ranges), (const uint32_t*)(b + bl.qcount), (const float4*)(g + gl.grec), (const uint32_t*)(b + bl.qpos),
                            (const float*)(im + il.final_T), (const uint32_t*)(im + il.n_contrib_q), dL_dpix, grad_scratch,
                            (const float*)(im + il.c_final), (const float4*)(im + il.ck), gx * gy);
         KERNEL_CHECK("k_render_bwd", stream, dbg);

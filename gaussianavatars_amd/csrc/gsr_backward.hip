@@ -69,7 +69,7 @@ extern "C" int gsr_debug_read(unsigned long long* host, int n) { return (int)hip
 #endif
 __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
                                                      const uint32_t* __restrict__ qcount,
-                                                     const float4* __restrict__ qrecords, const uint32_t* __restrict__ qpos,
+                                                     const float4* __restrict__ grec, const uint32_t* __restrict__ qpos,
                                                      const float* __restrict__ final_T,
                                                      const uint32_t* __restrict__ n_contrib_q, const float* __restrict__ dL_dpix,
                                                      float* __restrict__ acc /* [P][GSR_ACC_STRIDE] */,
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
     if (nq <= seg_lo) return;                    // the stream ends below this segment
     const uint2 range = ranges[tile];
     const uint32_t nt = range.y - range.x;
-    const float4* __restrict__ rec = qrecords + (size_t)3 * range.x;                         // the tile's records (sorted)
-    const uint32_t* __restrict__ qp = qpos + (size_t)4 * range.x + (size_t)wave * nt;       // this quadrant's positions into them
+    const float4* __restrict__ rec = grec;                                                   // the per-splat records (48 bytes each)
+    const uint32_t* __restrict__ qp = qpos + (size_t)4 * range.x + (size_t)wave * nt;       // this quadrant's stream of splat indices
 
     const int pix_id = W * pyi + pxi;
     const size_t HW = (size_t)H * W;
@@ -155,10 +155,8 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
         for (int u = 0; u < 2; ++u) {
             const uint32_t off = P.p[u] * 48u;
             R.a[u] = *(const __attribute__((address_space(4))) f32x8*)(recb + off);
-            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-            const u32x2 t = *(const __attribute__((address_space(4))) u32x2*)(recb + off + 32);
-            R.cbl[u] = __uint_as_float(t[0]);
-            R.id[u] = t[1];
+            R.cbl[u] = *(const __attribute__((address_space(4))) float*)(recb + off + 32);
+            R.id[u] = P.p[u];   // the stream entry IS the splat index
         }
     };
     float v[RB][9];

@@ -363,14 +363,14 @@ __global__ void k_scatter(int P, int gx, int tiles, const float* depths, const u
                           unsigned long long capacity, const unsigned long long* total_dev, const uint32_t* block_hist);
 template <int KEYS, int THREADS>
 __global__ void k_tile_sort(uint32_t n_lo, uint32_t n_hi, int gx, const uint32_t* tile_order, const uint32_t* tile_count, const uint32_t* tile_start, unsigned long long* keys,
-                            uint32_t* point_list, float4* qrecords, uint32_t* qpos, uint32_t* qcount, const float4* grec,
+                            uint32_t* point_list, uint32_t* qlist, uint32_t* qpos, uint32_t* qcount, const float4* grec,
                             unsigned long long capacity, const unsigned long long* total_dev);
-__global__ void k_render(Settings s, const uint32_t* tile_order, const uint2* ranges, const uint32_t* qcount, const float4* qrecords,
-                         const uint32_t* qpos, float* final_T,
+__global__ void k_render(Settings s, const uint32_t* tile_order, const uint2* ranges, const uint32_t* qcount, const float4* grec,
+                         const uint32_t* qpos, const uint32_t* qlist, float* final_T,
                          uint32_t* n_contrib, uint32_t* n_contrib_q, float* c_final, float4* ck, float* out_color, unsigned long long capacity,
                          const unsigned long long* total_dev);
 __global__ void k_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present);
-__global__ void k_render_bwd(Settings s, const uint32_t* tile_order, const uint2* ranges, const uint32_t* qcount, const float4* qrecords,
+__global__ void k_render_bwd(Settings s, const uint32_t* tile_order, const uint2* ranges, const uint32_t* qcount, const float4* grec,
                              const uint32_t* qpos, const float* final_T,
                              const uint32_t* n_contrib_q, const float* dL_dpix, float* acc, const float* c_final, const float4* ck, int tiles);
 __global__ void k_preprocess_bwd(Settings s, PreBwdArgs a);

@@ -539,7 +539,7 @@ __device__ __forceinline__ uint32_t quadrant_mask(float2 p, float4 co, float ox,
 // exclusive scan over the (chunk, wave) counters -- three barriers in total, gathers issued four chunks at a time.
 template <int THREADS, int EPT>
 __device__ __forceinline__ void epilogue_striped(const u64 (&key)[EPT], uint32_t n, uint32_t tile, uint32_t start, float ox, float oy,
-                                                 u64* __restrict__ seg, uint32_t* __restrict__ point_list, float4* __restrict__ qbase,
+                                                 u64* __restrict__ seg, uint32_t* __restrict__ point_list, uint32_t* __restrict__ qlbase,
                                                  uint32_t* __restrict__ qpbase, uint32_t* __restrict__ qcount, const float4* __restrict__ grec,
                                                  u64* __restrict__ sk, uint32_t (*__restrict__ cntw)[EPT * (THREADS / 64) + 1], int tid)
 {
@@ -551,12 +551,11 @@ __device__ __forceinline__ void epilogue_striped(const u64 (&key)[EPT], uint32_t
     __syncthreads();
     uint32_t msk[EPT], rank[EPT];   // rank: 4 x 8-bit in-wave exclusive ranks (0..63)
     const u64 tile_hi = (u64)tile << 32;
-    // pass 1: gather each instance's record ONCE, write it to the tile's record array (consecutive lanes -> consecutive
-    // 48-byte records) and the reference-format lists, and evaluate its quadrant mask / in-wave ranks
+    // pass 1: gather the geometry half of each instance's per-splat record (centre, conic, opacity: 32 of its 48 bytes),
+    // evaluate its quadrant mask / in-wave ranks, and write the reference-format lists in the parity modes
 #pragma unroll
     for (int h = 0; h < EPT / 4; ++h) {
         float4 g0[4], g1[4];
-        float g2x[4];
         u64 kk[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -565,22 +564,14 @@ __device__ __forceinline__ void epilogue_striped(const u64 (&key)[EPT], uint32_t
             const uint32_t idx = (uint32_t)kk[k];
             g0[k] = grec[3 * (size_t)idx + 0];
             g1[k] = grec[3 * (size_t)idx + 1];
-            g2x[k] = grec[3 * (size_t)idx + 2].x;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = 4 * h + k;
             const uint32_t i = (uint32_t)c * THREADS + (uint32_t)tid;
-            if (i < n) {
-                const uint32_t idx = (uint32_t)kk[k];
-                if (point_list) {   // the reference-format lists are a parity/debug artefact: nothing downstream reads them
-                    seg[i] = tile_hi | (kk[k] >> 32);   // reference-format key: tile id | depth bits
-                    point_list[start + i] = idx;
-                }
-                float4* dst = qbase + (size_t)3 * i;
-                dst[0] = g0[k];
-                dst[1] = g1[k];
-                dst[2] = make_float4(g2x[k], __uint_as_float(idx), 0.f, 0.f);
+            if (i < n && point_list) {   // the reference-format lists are a parity/debug artefact: nothing downstream reads them
+                seg[i] = tile_hi | (kk[k] >> 32);   // reference-format key: tile id | depth bits
+                point_list[start + i] = (uint32_t)kk[k];
             }
             const uint32_t m = i < n ? quadrant_mask(make_float2(g0[k].x, g0[k].y), make_float4(g0[k].z, g0[k].w, g1[k].x, g1[k].y), ox, oy) : 0u;
             msk[c] = m;
@@ -620,16 +611,19 @@ __device__ __forceinline__ void epilogue_striped(const u64 (&key)[EPT], uint32_t
         if (lane == 63) cntw[wid][NE] = incl;   // total
     }
     __syncthreads();
-    // pass 2: the quadrant streams get the positions (4 bytes per (instance, quadrant) pair), stable order
+    // pass 2: the quadrant streams get the SPLAT INDICES (4 bytes per (instance, quadrant) pair), stable order; in the parity
+    // modes a twin stream keeps each entry's position in the tile list (what the reference's n_contrib counts)
 #pragma unroll
     for (int c = 0; c < EPT; ++c) {
         const uint32_t i = (uint32_t)c * THREADS + (uint32_t)tid;
         const uint32_t m = msk[c];
+        const uint32_t idx = m ? (uint32_t)sk[i] : 0u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if ((m >> q) & 1u) {
                 const uint32_t pos = cntw[q][c * NW + wid] + ((rank[c] >> (8 * q)) & 0xFFu);
-                qpbase[(size_t)q * n + pos] = i;
+                qpbase[(size_t)q * n + pos] = idx;
+                if (qlbase) qlbase[(size_t)q * n + pos] = i;
             }
         }
     }
@@ -699,7 +693,7 @@ template <int KEYS, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n_hi, int gx, const uint32_t* __restrict__ tile_order,
                                                         const uint32_t* __restrict__ tile_count,
                                                     const uint32_t* __restrict__ tile_start, unsigned long long* __restrict__ keys,
-                                                    uint32_t* __restrict__ point_list, float4* __restrict__ qrecords,
+                                                    uint32_t* __restrict__ point_list, uint32_t* __restrict__ qlist,
                                                     uint32_t* __restrict__ qpos, uint32_t* __restrict__ qcount,
                                                     const float4* __restrict__ grec,
                                                     unsigned long long capacity, const unsigned long long* __restrict__ total_dev)
@@ -720,18 +714,18 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
     unsigned long long* seg = keys + start;
     const bool in_lds = n <= (uint32_t)KEYS;
     const float ox = (float)((tile % (uint32_t)gx) * GSR_BLOCK_X), oy = (float)((tile / (uint32_t)gx) * GSR_BLOCK_Y);
-    float4* const qbase = qrecords + (size_t)3 * start;     // the tile's record array (one 48-byte record per instance, sorted)
-    uint32_t* const qpbase = qpos + (size_t)4 * start;      // four quadrant streams of positions into it, n slots each
+    uint32_t* const qpbase = qpos + (size_t)4 * start;      // the tile's four quadrant streams of splat indices, n slots each
+    uint32_t* const qlbase = qlist ? qlist + (size_t)4 * start : nullptr;   // parity modes: the entries' positions in the tile list
     if (in_lds) {
         static_assert(EPT == 8 || EPT == 16, "register sort holds 8 or 16 keys per thread");
         u64 key[EPT];
         block_sort_regs<THREADS, EPT>(key, skeys, seg, n, tid);
-        epilogue_striped<THREADS, EPT>(key, n, tile, start, ox, oy, seg, point_list, qbase, qpbase, qcount, grec, skeys, cntw, tid);
+        epilogue_striped<THREADS, EPT>(key, n, tile, start, ox, oy, seg, point_list, qlbase, qpbase, qcount, grec, skeys, cntw, tid);
         return;
     } else {
         // more entries than this class holds in LDS: chunked register sorts + global merge passes (scratch: the tile's
-        // still-unwritten record array, 48 n bytes for n 8-byte keys)
-        oversize_sort<THREADS, EPT>(seg, reinterpret_cast<u64*>(qbase), skeys, n, tid);
+        // still-unwritten quadrant streams, 16 n bytes for n 8-byte keys)
+        oversize_sort<THREADS, EPT>(seg, reinterpret_cast<u64*>(qpbase), skeys, n, tid);
         __syncthreads();
     }
     // ---- epilogue: reference-format keys / point list, and the four 8x8-quadrant record streams --------
@@ -745,20 +739,16 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
         const uint32_t i = base + tid;
         const bool valid = i < n;
         bool f[4] = {false, false, false, false};
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+        uint32_t idx = 0u;
         if (valid) {
             const unsigned long long k = in_lds ? skeys[i] : seg[i];
-            const uint32_t idx = (uint32_t)k;
+            idx = (uint32_t)k;
             if (point_list) {
                 seg[i] = tile_hi | (k >> 32);
                 point_list[start + i] = idx;
             }
-            r0 = grec[3 * (size_t)idx + 0];
-            r1 = grec[3 * (size_t)idx + 1];
-            r2 = make_float4(grec[3 * (size_t)idx + 2].x, __uint_as_float(idx), 0.f, 0.f);
-            qbase[(size_t)3 * i + 0] = r0;
-            qbase[(size_t)3 * i + 1] = r1;
-            qbase[(size_t)3 * i + 2] = r2;
+            const float4 r0 = grec[3 * (size_t)idx + 0];
+            const float4 r1 = grec[3 * (size_t)idx + 1];
             const uint32_t m = quadrant_mask(make_float2(r0.x, r0.y), make_float4(r0.z, r0.w, r1.x, r1.y), ox, oy);
 #pragma unroll
             for (int q = 0; q < 4; ++q) f[q] = (m >> q) & 1u;
@@ -780,7 +770,10 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
                 if (w < wid) off += cw;
                 tot += cw;
             }
-            if (f[q]) qpbase[(size_t)q * n + off + prefix[q]] = i;
+            if (f[q]) {
+                qpbase[(size_t)q * n + off + prefix[q]] = idx;
+                if (qlbase) qlbase[(size_t)q * n + off + prefix[q]] = i;
+            }
             running[q] += tot;
         }
         __syncthreads();
@@ -789,13 +782,13 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
 }
 
 template __global__ void k_tile_sort<GSR_SORT_SMALL_KEYS, 256>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
-                                                                float4*, uint32_t*, uint32_t*, const float4*, unsigned long long,
+                                                                uint32_t*, uint32_t*, uint32_t*, const float4*, unsigned long long,
                                                                 const unsigned long long*);
 template __global__ void k_tile_sort<GSR_SORT_LDS_KEYS, 1024>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
-                                                               float4*, uint32_t*, uint32_t*, const float4*, unsigned long long,
+                                                               uint32_t*, uint32_t*, uint32_t*, const float4*, unsigned long long,
                                                                const unsigned long long*);
 template __global__ void k_tile_sort<GSR_SORT_XL_KEYS, 1024>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
-                                                              float4*, uint32_t*, uint32_t*, const float4*, unsigned long long,
+                                                              uint32_t*, uint32_t*, uint32_t*, const float4*, unsigned long long,
                                                               const unsigned long long*);
 
 // ------------------------------------------------------------------------------------------
@@ -810,8 +803,8 @@ extern "C" int gsr_debug_read_fwd(unsigned long long* host, int n) { return (int
 #endif
 __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
                                                  const uint32_t* __restrict__ qcount,
-                                                 const float4* __restrict__ qrecords, const uint32_t* __restrict__ qpos,
-                                                 float* __restrict__ final_T,
+                                                 const float4* __restrict__ grec, const uint32_t* __restrict__ qpos,
+                                                 const uint32_t* __restrict__ qlist, float* __restrict__ final_T,
                                                  uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ n_contrib_q,
                                                  float* __restrict__ c_final, float4* __restrict__ ck,
                                                  float* __restrict__ out_color, unsigned long long capacity,
@@ -835,8 +828,8 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     const uint2 range = ranges[tile];
     const uint32_t nt = range.y - range.x;
     const int n = (int)qcount[4 * tile + wave];
-    const float4* __restrict__ rec = qrecords + (size_t)3 * range.x;                         // the tile's records (sorted)
-    const uint32_t* __restrict__ qp = qpos + (size_t)4 * range.x + (size_t)wave * nt;       // this quadrant's positions into them
+    const float4* __restrict__ rec = grec;                                                   // the per-splat records (48 bytes each)
+    const uint32_t* __restrict__ qp = qpos + (size_t)4 * range.x + (size_t)wave * nt;       // this quadrant's stream of splat indices
 
     // Two transmittances per pixel: T is the one the pixel ends with (the last accepted product), Tw the WORKING one, equal to
     // T while the pixel is open and 0 once it is closed (saturated, or outside the image).  A closed pixel then needs no
@@ -879,7 +872,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     auto load4 = [&](const Pos4& P, Rec4& R) {
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
-            const uint32_t off = P.p[u] * 48u;   // byte offset inside the tile's records: < 4 GiB (a tile list of 89 M entries)
+            const uint32_t off = P.p[u] * 48u;   // byte offset of the splat's record: < 4 GiB (89 M splats)
             R.a[u] = *(const __attribute__((address_space(4))) f32x8*)(recb + off);
             R.cbl[u] = *(const __attribute__((address_space(4))) float*)(recb + off + 32);
         }
@@ -1043,8 +1036,9 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
 #endif
     if (inside) {
         const int pix_id = W * pyi + pxi;
-        // the reference's n_contrib counts positions in the TILE list: that is what the stream holds
-        const uint32_t last_contributor = last_q ? qp[last_q - 1] + 1u : 0u;
+        // the reference's n_contrib counts positions in the TILE list: the parity modes keep those in a twin stream; in
+        // production it is the position in the quadrant stream (nothing reads it: the backward walks n_contrib_q)
+        const uint32_t last_contributor = !qlist ? last_q : (last_q ? (qlist + (size_t)4 * range.x + (size_t)wave * nt)[last_q - 1] + 1u : 0u);
         final_T[pix_id] = T;
         n_contrib[pix_id] = last_contributor;
         n_contrib_q[pix_id] = last_q;

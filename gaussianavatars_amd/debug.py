@@ -73,8 +73,8 @@ def _forward_state(rs, means3D, shs, colors_precomp, opacities, scales, rotation
         clamped=_view(geom, gl.clamped, P, torch.uint8),
         keys=_view(binning, bl.keys, I, torch.int64),
         point_list=_view(binning, bl.point_list, I, u32),
-        qrecords=_view(binning, bl.qrecords, 12 * cap, f32).view(cap, 12),     # one record per instance, tile-sorted order
-        qpos=_view(binning, bl.qpos, 4 * cap, u32),                            # per tile at 4*start: 4 streams of n slots
+        qlist=_view(binning, bl.qlist, 4 * cap, u32),                          # parity modes: stream entries' positions in the tile list
+        qpos=_view(binning, bl.qpos, 4 * cap, u32),                            # per tile at 4*start: 4 streams of n splat indices
         qcount=_view(binning, bl.qcount, 4 * tiles, u32).view(tiles, 4),
         ranges=_view(binning, bl.ranges, 2 * tiles, u32).view(tiles, 2),
         tile_count=_view(binning, bl.tile_count, tiles, u32),

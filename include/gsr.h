@@ -94,10 +94,12 @@ typedef struct GsrGeomLayout {
 typedef struct GsrBinningLayout {
     size_t keys;        /* uint64 [cap]  sorted (tile << 32 | depth bits), upstream's point_list_keys */
     size_t point_list;  /* uint32 [cap]  sorted splat index, upstream's point_list                    */
-    size_t qrecords;    /* float4 [3*cap] the tile's instances in sorted order, ONE 48-byte record each (at 3*start):
-                           (x,y,A,B | C,opacity,r,g | b, splat idx, -, -)                                            */
-    size_t qpos;        /* uint32 [4*cap] per tile (at 4*start) four 8x8-quadrant streams of up to n POSITIONS each into
-                           the tile's records: quadrant q lists, in order, the instances whose ellipse can reach it  */
+    size_t qlist;       /* uint32 [4*cap] parity modes only (tile_culling 0 / 2): twin of qpos holding each stream entry's
+                           POSITION in the tile's sorted list (what the reference's n_contrib counts); not written in
+                           production (tile_culling 1)                                                                */
+    size_t qpos;        /* uint32 [4*cap] per tile (at 4*start) four 8x8-quadrant streams of up to n SPLAT INDICES each:
+                           quadrant q lists, in the tile's depth order, the splats whose ellipse can reach it.  The
+                           blend kernels fetch the 48-byte per-splat record (GsrGeomLayout.grec) of each entry        */
     size_t qcount;      /* uint32 [4*tiles] records in each quadrant stream                                       */
     size_t ranges;      /* uint32 [2*tiles]  [start,end) per tile, (0,0) when empty                   */
     size_t tile_count;  /* uint32 [tiles]                                                            */

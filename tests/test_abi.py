@@ -40,7 +40,7 @@ def test_layouts_are_disjoint_and_aligned():
     segs = [(gl.depths, 4 * P), (gl.grec, 48 * P), (gl.cov3D, 24 * P),
             (gl.rect, 8 * P), (gl.tiles_touched, 4 * P), (gl.clamped, P), (gl.visible, P), (gl.acc, 48 * P)]
     _check(segs, gl.total)
-    segs = [(bl.keys, 8 * cap), (bl.point_list, 4 * cap), (bl.qrecords, 48 * cap), (bl.qpos, 16 * cap), (bl.qcount, 16 * tiles), (bl.ranges, 8 * tiles),
+    segs = [(bl.keys, 8 * cap), (bl.point_list, 4 * cap), (bl.qlist, 16 * cap), (bl.qpos, 16 * cap), (bl.qcount, 16 * tiles), (bl.ranges, 8 * tiles),
             (bl.tile_count, 4 * tiles), (bl.tile_start, 4 * tiles), (bl.tile_cursor, 4 * tiles)]
     _check(segs, bl.total)
     _check([(il.final_T, 4 * HW), (il.n_contrib, 4 * HW), (il.n_contrib_q, 4 * HW), (il.c_final, 12 * HW), (il.ck, 80 * HW)], il.total)

@@ -76,23 +76,21 @@ def _check_forward(st, hs):
     assert np.array_equal(_np(hs["final_T"]).view(np.uint32), st.final_T.view(np.uint32))
     img = _np(hs["color"])
     assert np.array_equal(img.view(np.uint32), st.color.view(np.uint32)), f"image max abs diff {np.abs(img - st.color).max()}"
-    # tile records: the sorted list with its geometry, one 48-byte record per instance; quadrant streams: ordered
-    # sub-sequences of positions into it
-    qrec, qpos, qcnt, rng = _np(hs["qrecords"]), _np(hs["qpos"]).astype(np.int64), _np(hs["qcount"]).astype(np.int64), st.ranges.astype(np.int64)
+    # quadrant streams: ordered sub-sequences of the tile's sorted list -- splat indices in qpos, their positions in the
+    # tile list in the twin stream qlist (parity modes)
+    qpos, qlist, qcnt, rng = (_np(hs["qpos"]).astype(np.int64), _np(hs["qlist"]).astype(np.int64), _np(hs["qcount"]).astype(np.int64),
+                              st.ranges.astype(np.int64))
     assert (qcnt <= (rng[:, 1] - rng[:, 0])[:, None]).all()
-    r = qrec[:I]
-    np.testing.assert_array_equal(r[:, 9].view(np.uint32), st.point_list)
-    np.testing.assert_array_equal(r[:, 0:2], st.xy[st.point_list])
-    np.testing.assert_array_equal(r[:, 2:6], st.conic_opacity[st.point_list])
-    np.testing.assert_array_equal(r[:, 6:9], st.rgb[st.point_list])
     checked = 0
     for t in np.argsort(-(rng[:, 1] - rng[:, 0]))[:6]:
         n, start = rng[t, 1] - rng[t, 0], rng[t, 0]
         if n == 0:
             continue
         for q in range(4):
-            pos = qpos[4 * start + q * n: 4 * start + q * n + qcnt[t, q]]
+            sl = slice(4 * start + q * n, 4 * start + q * n + qcnt[t, q])
+            pos = qlist[sl]
             assert (np.diff(pos) > 0).all() and (pos < n).all() and (pos >= 0).all()
+            np.testing.assert_array_equal(qpos[sl], st.point_list[start + pos].astype(np.int64))
             checked += 1
     assert checked or I == 0
 
@@ -247,7 +245,7 @@ def test_tile_culling_changes_only_the_binning_state(oracle, name):
     rex, rcu = _np(ex["ranges"]).astype(np.int64), _np(cu["ranges"]).astype(np.int64)
     kex, kcu = _np(ex["keys"]).view(np.uint64), _np(cu["keys"]).view(np.uint64)
     pex, pcu = _np(ex["point_list"]).astype(np.int64), _np(cu["point_list"]).astype(np.int64)
-    qex, cex = _np(ex["qpos"]).astype(np.int64), _np(ex["qcount"]).astype(np.int64)
+    qex, cex = _np(ex["qlist"]).astype(np.int64), _np(ex["qcount"]).astype(np.int64)
     dropped = 0
     for tile in range(rex.shape[0]):
         e0, e1, c0, c1 = rex[tile, 0], rex[tile, 1], rcu[tile, 0], rcu[tile, 1]

@@ -18,7 +18,7 @@ for wl in ("cfg3", "cfg5"):
                                            cam.camera_center, False, False)
         hs = forward_state(rs, g.get_xyz, g.get_features, None, g.get_opacity, g.get_scaling, g.get_rotation, None)
     I = hs["num_rendered"]
-    qpos = hs["qpos"].cpu().numpy().astype(np.int64); qcnt = hs["qcount"].cpu().numpy().astype(np.int64); rng = hs["ranges"].cpu().numpy().astype(np.int64)
+    qpos = hs["qlist"].cpu().numpy().astype(np.int64); qcnt = hs["qcount"].cpu().numpy().astype(np.int64); rng = hs["ranges"].cpu().numpy().astype(np.int64)
     surv = 0; pairs = int(qcnt.sum())
     for t in range(rng.shape[0]):
         n, start = rng[t, 1] - rng[t, 0], rng[t, 0]
