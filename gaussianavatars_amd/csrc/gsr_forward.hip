@@ -7,12 +7,12 @@
 //                              host mailbox, and lists the tiles heaviest-first for the per-tile kernels
 //   k_scatter      same WGs  : drops (depth bits << 32 | splat) into its tiles' segments (LDS slot allocation)
 //   k_tile_sort    per tile  : register/cross-lane bitonic sort of the segment by (depth, splat) == the order a
-//                              stable radix sort of (tile << 32 | depth) produces; emits the reference-format
-//                              sorted keys / point list and, per 8x8 quadrant, a stream of packed 48-byte records
-//                              culled with the exact {alpha >= 1/255} ellipse (geometry gathered once, here)
-//   k_render       per tile  : 4 waves x 8x8 pixels; every wave walks its quadrant's record stream through the
-//                              scalar unit (wave-uniform s_loads, software-pipelined, no LDS, no barriers) and
-//                              composites front to back
+//                              stable radix sort of (tile << 32 | depth) produces; emits, per 8x8 quadrant, a stream
+//                              of splat indices culled with the exact {alpha >= 1/255} ellipse (and the
+//                              reference-format sorted keys / point list in the parity modes)
+//   k_render       per tile  : 4 waves x 8x8 pixels; every wave walks its quadrant's stream through the scalar unit
+//                              (wave-uniform s_loads of index, then of the splat's 48-byte record; software-pipelined,
+//                              no LDS, no barriers) and composites front to back
 //
 // Behavioural spec: SURVEY.md Appendix A.1-A.3 (the reference's rasterizer is an un-vendored
 // submodule; call site gaussian_renderer/__init__.py:37-52,86-94).  This TU is built with
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     constexpr int TAIL_LANES = 8;     // switch to record-parallel mode when this few pixels are still open
     struct Rec4 { f32x8 a[RB]; float cbl[RB]; };   // a = (x, y, conic a, conic b, conic c, opacity, red, green)
     struct Pos4 { uint32_t p[RB]; };
-    // Two-level scalar fetch: stream positions (4 bytes each) two batches ahead, the records they point at one batch ahead,
+    // Two-level scalar fetch: stream entries (4-byte splat indices) two batches ahead, the records they name one batch ahead,
     // every record address the base pointer plus a 32-bit byte offset (s_load with a register offset: no 64-bit address
     // arithmetic on the scalar unit, which is on the critical path like everything else the wave issues).
     // Both streams are read through the CONSTANT address space (nothing writes them while this kernel runs): a uniform load
