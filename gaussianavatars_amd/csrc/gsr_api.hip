@@ -196,6 +196,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     if (int rc = check_settings(settings)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0) return fail(GSR_E_ARG, "P must be >= 0");
+    if ((long long)P * 48 > 0xFFFFFFFFll) return fail(GSR_E_ARG, "P = %d exceeds 89478485 splats: the blend addresses the 48-byte per-splat records with 32-bit offsets", P);
     if (!out_color || !num_rendered_host) return fail(GSR_E_ARG, "out_color / num_rendered_host is NULL");
     if (P > 0) {   // with no splats there is nothing to point at: empty tensors legitimately arrive as NULL
         if ((shs == nullptr) == (colors_precomp == nullptr))

@@ -134,7 +134,8 @@ int gsr_image_layout(int32_t width, int32_t height, GsrImageLayout* out);
 /*
  * Forward pass.  Replaces `_C.rasterize_gaussians` (upstream rasterize_points.cu
  * RasterizeGaussiansCUDA -> CudaRasterizer::Rasterizer::forward).
- *   P splats, M SH coefficients per splat (shs is (P,M,3); 0 when colors_precomp is used).
+ *   P splats (at most 89 478 485: the blend addresses the 48-byte per-splat records with 32-bit byte offsets; GSR_E_ARG
+ *   beyond), M SH coefficients per splat (shs is (P,M,3); 0 when colors_precomp is used).
  *   Exactly one of shs / colors_precomp and exactly one of (scales,rotations) / cov3D_precomp
  *   must be non-NULL.
  *   out_color (3,H,W) and radii (P,) are fully written by the call.

@@ -74,6 +74,9 @@ def test_forward_argument_contract_without_gpu():
     s.sh_degree = 2
     rc = lib.gsr_forward(C.byref(s), 4, 4, one, one, None, one, one, one, None, one, one, one, one, 64, one, C.byref(n), None)
     assert rc < 0 and b"coefficients" in lib.gsr_last_error()
+    s.sh_degree = 0   # the splat-count ceiling of the 32-bit record offsets
+    rc = lib.gsr_forward(C.byref(s), 89_478_486, 1, one, one, None, one, one, one, None, one, one, one, one, 64, one, C.byref(n), None)
+    assert rc < 0 and b"89478485" in lib.gsr_last_error()
 
 
 def test_product_package_never_imports_the_oracle():
