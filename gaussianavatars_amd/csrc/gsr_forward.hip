@@ -851,7 +851,8 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     // tools/bwd_timeline.py), so the loop is written for INSTRUCTION COUNT, scalar ones included: no per-record bounds
     // tests (full batches take an unmasked body), 32-bit record offsets, no exec-mask branches around the exponential.
     constexpr int RB = 3;
-    constexpr int TAIL_LANES = 8;     // switch to record-parallel mode when this few pixels are still open
+    constexpr int TAIL_LANES = 4;     // switch to record-parallel mode when this few pixels are still open (swept 0..16 on the
+                                      // instruction-count build: 2-4 best, 8 costs 10 %, 16 costs 50 % of the kernel)
     struct Rec4 { f32x8 a[RB]; float cbl[RB]; };   // a = (x, y, conic a, conic b, conic c, opacity, red, green)
     struct Pos4 { uint32_t p[RB]; };
     // Two-level scalar fetch: stream entries (4-byte splat indices) two batches ahead, the records they name one batch ahead,

@@ -29,8 +29,8 @@ extern "C" {
 #endif
 
 #define GSR_ABI_VERSION 1
-#define GSR_BWD_SEGMENT 132       /* stream entries per backward segment (a multiple of both blend kernels' batches)  */
-#define GSR_BWD_SEGMENTS 6        /* segments per quadrant stream; the last one takes whatever is left                */
+#define GSR_BWD_SEGMENT 60        /* stream entries per backward segment (a multiple of both blend kernels' batches)  */
+#define GSR_BWD_SEGMENTS 10       /* segments per quadrant stream; the last one takes whatever is left                */
 #define GSR_BIN_BLOCKS 256        /* workgroups of the two binning passes (each owns a contiguous chunk of splats) */
 #define GSR_BLOCK_X 16
 #define GSR_BLOCK_Y 16

@@ -43,7 +43,7 @@ def test_layouts_are_disjoint_and_aligned():
     segs = [(bl.keys, 8 * cap), (bl.point_list, 4 * cap), (bl.qlist, 16 * cap), (bl.qpos, 16 * cap), (bl.qcount, 16 * tiles), (bl.ranges, 8 * tiles),
             (bl.tile_count, 4 * tiles), (bl.tile_start, 4 * tiles), (bl.tile_cursor, 4 * tiles)]
     _check(segs, bl.total)
-    _check([(il.final_T, 4 * HW), (il.n_contrib, 4 * HW), (il.n_contrib_q, 4 * HW), (il.c_final, 12 * HW), (il.ck, 80 * HW)], il.total)
+    _check([(il.final_T, 4 * HW), (il.n_contrib, 4 * HW), (il.n_contrib_q, 4 * HW), (il.c_final, 12 * HW), (il.ck, 144 * HW)], il.total)
     assert lib.gsr_geom_layout(-1, C.byref(gl)) < 0 and b"bad arguments" in lib.gsr_last_error()
 
 

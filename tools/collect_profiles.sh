@@ -18,8 +18,8 @@ for W in cfg3 cfg5; do
   rm -rf $OUT/${W}_fetch $OUT/${W}_write   # raw per-dispatch tables are large; the summaries are what is kept
   rm -f $OUT/${W}_stats/*/*kernel_trace.csv
 done
-python bench.py --steps 200 --warmup 30 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3.json
-python bench.py --workload cfg2 --steps 500 --warmup 50 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg2.json
-python bench.py --workload cfg4 --steps 150 --warmup 30 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg4.json
-python bench.py --workload cfg5 --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg5.json
+python bench.py --steps 150 --warmup 30 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3.json
+python bench.py --workload cfg2 --steps 300 --warmup 40 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg2.json
+python bench.py --workload cfg4 --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg4.json
+python bench.py --workload cfg5 --steps 40 --warmup 8 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg5.json
 ls -la $OUT
