@@ -75,8 +75,9 @@ typedef struct GsrSettings {
  * the oracle bit for bit. */
 typedef struct GsrGeomLayout {
     size_t depths;         /* float  [P]                                   */
-    size_t grec;           /* float4 [3P]  per-splat blend record, 48 B in ONE place so the binning gathers touch
-                              one line per instance:  (x, y, A, B | C, opacity, r, g | b, 0, 0, 0)
+    size_t grec;           /* float4 [3P]  per-splat blend record, 48 B in ONE place: what the quadrant test of the
+                              tile sort gathers per instance and what the two blend kernels fetch (scalar loads) per
+                              stream entry:  (x, y, A, B | C, opacity, r, g | b, 0, 0, 0)
                               x,y = pixel centre, A,B,C = conic                                         */
     size_t cov3D;          /* float  [6P]  xx xy xz yy yz zz                */
     size_t rect;           /* uint16 [4P]  tile rect min.x min.y max.x max.y */
@@ -114,7 +115,8 @@ typedef struct GsrBinningLayout {
 
 typedef struct GsrImageLayout {
     size_t final_T;    /* float  [H*W] */
-    size_t n_contrib;  /* uint32 [H*W] last contributor, index+1 in the TILE list (== the reference's n_contrib) */
+    size_t n_contrib;  /* uint32 [H*W] last contributor: index+1 in the TILE list (== the reference's n_contrib) in the
+                          parity modes (tile_culling 0 / 2); in production (1) the same value as n_contrib_q          */
     size_t n_contrib_q;/* uint32 [H*W] the same position inside the pixel's quadrant stream (what the backward walks) */
     size_t c_final;    /* float  [3*H*W] the composited colour WITHOUT the background term (planar)               */
     size_t ck;         /* float4 [(GSR_BWD_SEGMENTS-1)*H*W] blend checkpoints: slot s-1 of a pixel = (T, C) before entry
