@@ -431,7 +431,7 @@ template __global__ void k_scatter<true>(int, int, int, const float*, const usho
 // i ^ M differs only in the low 3 bits is done in registers, one that differs in lane bits goes through
 // the cross-lane network (ds_bpermute), and only masks reaching across waves (M >= 512) touch LDS with
 // a barrier: 10 barrier steps instead of 91 for 8192 keys.  Every mask is a compile-time constant, so
-// the key array stays in VGPRs.  Slots >= n hold ~0 (+inf) and sink to the end.
+// the key array stays in VGPRs.  Slots >= n hold the +inf pattern (GSR_SORT_PAD) and sink to the end.
 // ------------------------------------------------------------------------------------------
 typedef unsigned long long u64;
 __device__ __forceinline__ u64 shfl64(u64 v, int src_lane)
@@ -441,6 +441,24 @@ __device__ __forceinline__ u64 shfl64(u64 v, int src_lane)
     return ((u64)(uint32_t)hi << 32) | (u64)(uint32_t)lo;
 }
 constexpr int top_bit(int m) { int b = 1; while ((b << 1) <= m) b <<= 1; return b; }
+
+// Keys are compared as DOUBLES: a key is (depth bits << 32 | splat) with the depth a positive finite float, so its high word
+// is below 0x7F800000 and the 64-bit pattern is a positive finite (possibly denormal: FP64 denormals are never flushed)
+// double whose order is the order of the unsigned integers; padding slots hold +inf.  A compare-exchange is then
+// v_min_f64 + v_max_f64 (full-rate on CDNA4) instead of a 64-bit integer compare and four selects.
+__device__ __forceinline__ u64 kmin(u64 a, u64 b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(double, a)), "v"(__builtin_bit_cast(double, b)));
+    return __builtin_bit_cast(u64, r);
+}
+__device__ __forceinline__ u64 kmax(u64 a, u64 b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(double, a)), "v"(__builtin_bit_cast(double, b)));
+    return __builtin_bit_cast(u64, r);
+}
+#define GSR_SORT_PAD 0x7FF0000000000000ull   // +inf: sinks to the end
 
 template <int M, int THREADS, int EPT>
 __device__ __forceinline__ void cx_step(u64 (&key)[EPT], u64* __restrict__ sk, int tid)
@@ -454,14 +472,14 @@ __device__ __forceinline__ void cx_step(u64 (&key)[EPT], u64* __restrict__ sk, i
         for (int k = 0; k < EPT; ++k) {
             if ((k ^ KM) > k) {
                 const u64 a = key[k], b = key[k ^ KM];
-                const bool sw = a > b;
-                key[k] = sw ? b : a;
-                key[k ^ KM] = sw ? a : b;
+                key[k] = kmin(a, b);
+                key[k ^ KM] = kmax(a, b);
             }
         }
     } else {
         constexpr int TOP = top_bit(M);                  // >= EPT here: decided by the thread id alone
-        const bool keep_min = (tid & (TOP >> LE)) == 0;
+        // lanes that keep the larger key negate both operands (sign bit of the double), take the minimum and negate back
+        const u64 flip = (tid & (TOP >> LE)) ? 0x8000000000000000ull : 0ull;
         u64 other[EPT];
         if constexpr (WM == 0) {
             const int pl = (tid & 63) ^ LM;
@@ -478,11 +496,7 @@ __device__ __forceinline__ void cx_step(u64 (&key)[EPT], u64* __restrict__ sk, i
             __syncthreads();
         }
 #pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-            const u64 a = key[k], b = other[k];
-            const bool a_gt = a > b;
-            key[k] = (a_gt == keep_min) ? b : a;      // keep_min: take the smaller, else the larger
-        }
+        for (int k = 0; k < EPT; ++k) key[k] = kmin(key[k] ^ flip, other[k] ^ flip) ^ flip;
     }
 }
 
@@ -514,7 +528,7 @@ __device__ __forceinline__ void block_sort_regs(u64 (&key)[EPT], u64* __restrict
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
         const uint32_t i = (uint32_t)tid * (uint32_t)EPT + (uint32_t)k;
-        key[k] = i < n ? seg[i] : ~0ull;
+        key[k] = i < n ? seg[i] : GSR_SORT_PAD;
     }
     cx_stage<2, EPT * THREADS, THREADS, EPT>(key, sk, tid, n);
 }
