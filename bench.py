@@ -132,7 +132,7 @@ def cpu_baseline(g, cam, bg, train, max_seconds=25.0):
         el = time.perf_counter() - t0
         if el > max_seconds or frames >= 8:
             break
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0))
     out = dict(value=frames / el, unit="frames/s", cores=cores, kind="port",
                sample=f"{frames} frame(s) of the bench workload, rasterizer half ({'fwd+bwd' if train else 'fwd'}), "
                       f"oracle/gsr_oracle.c with OpenMP on {cores} threads (render backward is single-threaded)")
@@ -214,6 +214,7 @@ def main():
     from gaussianavatars_amd import rasterizer as R
     from gaussianavatars_amd.frame_parallel import frames_for_rank, pin_to_gpu_numa_node
 
+    all_cpus = os.sched_getaffinity(0)
     pinned = pin_to_gpu_numa_node(local_rank)   # host launch latency: stay on the GPU's socket
     if args.workload == "cfg5":
         g, cam = build_unbound_scene(device, args.splats, 3, args.width, args.height)
@@ -325,6 +326,7 @@ def main():
                                          for k, v in per_kernel.items()})
         cpu = None
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only
+            os.sched_setaffinity(0, all_cpus)   # the CPU legs get every host core back (the frame loop was pinned to 8)
             cpu, I_cpu, vis_cpu = cpu_baseline(g, cam, bg, train)
             vis = vis_cpu / N
         fps = n_gpus * args.steps / elapsed
