@@ -156,6 +156,7 @@ def gsr():
 # ------------------------------------------------------------------------------------------------
 GAB_LIB_PATH = os.path.join(_HERE, "libgab_hip.so")
 GAB_FLAME_WS_FLOATS = 512
+GAB_BIND_ROW_FLOATS = 20   # include/gab.h: floats per splat of the two-pass CSR backward's scratch
 _P = C.c_void_p
 
 
@@ -175,7 +176,7 @@ GAB_SYMBOLS = {
     "gab_face_frames_backward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "gab_bind_forward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gab_bind_backward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "gab_bind_backward_csr": (C.c_int, [C.c_int32, C.c_int32] + [_P] * 19),
+    "gab_bind_backward_csr": (C.c_int, [C.c_int32, C.c_int32] + [_P] * 22),
     "gab_zero_buffers": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _P]),
 }
 

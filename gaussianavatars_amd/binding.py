@@ -309,13 +309,17 @@ def mesh_frames_timestep(head, flame_param: dict, t: int, faces):
 # per-splat local -> world
 # -------------------------------------------------------------------------------------------------
 def binding_csr(binding: torch.Tensor, num_faces: int):
-    """(order int32 (N,), face_begin int32 (F+1,)) for gab_bind_backward_csr; depends on `binding` only."""
+    """(order int32 (N,), face_begin int32 (F+1,), splat_face int32 (N,), slot int32 (N,)) for gab_bind_backward_csr;
+    depends on `binding` only.  slot is the inverse permutation of order (the splat's position in the CSR)."""
     b = binding.detach().long()
-    order = torch.sort(b, stable=True).indices.to(torch.int32).contiguous()
+    order64 = torch.sort(b, stable=True).indices
+    order = order64.to(torch.int32).contiguous()
     counts = torch.bincount(b, minlength=num_faces)
     face_begin = torch.zeros(num_faces + 1, dtype=torch.int32, device=b.device)
     face_begin[1:] = torch.cumsum(counts, 0).to(torch.int32)
-    return order, face_begin
+    slot = torch.empty_like(order)
+    slot[order64] = torch.arange(order.numel(), dtype=torch.int32, device=b.device)
+    return order, face_begin, b.to(torch.int32).contiguous(), slot
 
 
 class _BindSplats(torch.autograd.Function):
@@ -356,10 +360,12 @@ class _BindSplats(torch.autograd.Function):
         d_ol = None if oo is None else torch.empty_like(oo)
         with _lib.on_device(dev):
             if ctx.csr is not None:
-                order, face_begin = ctx.csr
+                order, face_begin = ctx.csr[0], ctx.csr[1]
+                splat_face, slot = (ctx.csr[2], ctx.csr[3]) if len(ctx.csr) >= 4 else (None, None)
+                rows = torch.empty(_lib.GAB_BIND_ROW_FLOATS * N, **f32) if slot is not None else None   # two-pass scratch
                 _chk(lib.gab_bind_backward_csr(N, F, _p(x), _p(ls), _p(q), _p(fR), _p(fs), _p(fq), _p(gs[0]), _p(gs[1]), _p(gs[2]),
                                                _p(order), _p(face_begin), _p(d_x), _p(d_ls), _p(d_q), _p(d_face), _p(oo), _p(go), _p(d_ol),
-                                               _stream(dev)), "gab_bind_backward_csr")
+                                               _p(splat_face), _p(slot), _p(rows), _stream(dev)), "gab_bind_backward_csr")
             else:
                 _chk(lib.gab_bind_backward(N, F, _p(x), _p(ls), _p(q), _p(b), ctx.is64, _p(fc), _p(fR), _p(fs), _p(fq), _p(gs[0]),
                                            _p(gs[1]), _p(gs[2]), _p(d_x), _p(d_ls), _p(d_q), _p(d_face), _p(oo), _p(go), _p(d_ol),

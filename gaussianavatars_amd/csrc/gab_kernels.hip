@@ -901,6 +901,120 @@ __global__ __launch_bounds__(256) void k_bind_bwd_csr(int F, const float* __rest
     }
 }
 
+// Two-pass form of the CSR backward (what gab_bind_backward_csr runs when it is given splat_face / slot / rows).  The
+// one-pass kernel above visits the splats in FACE order, so each of its eight per-splat reads and four writes is a
+// scattered 4..16-byte access (12 sectors per splat: 78 MB of HBM transactions for 8 MB of data, and the kernel is bound
+// by exactly that).  Here pass 1 runs in SPLAT order -- every per-splat array is read and written coalesced, the small
+// per-face tables are gathered (L2-resident) -- and parks the splat's 17 contributions to its face as one 80-byte row at
+// the splat's CSR position; pass 2 sums each face's contiguous rows (16 lanes per face, coalesced) on the DPP network.
+// Deterministic like the one-pass kernel: the same values are added in the same CSR order.
+#define GAB_BIND_ROW 20   // floats per row: 17 used, padded to a multiple of 16 bytes
+__global__ __launch_bounds__(256) void k_bind_bwd_rows(int N, const float* __restrict__ xyz, const float* __restrict__ log_scaling,
+                                                        const float* __restrict__ rotation, const int* __restrict__ splat_face,
+                                                        const int* __restrict__ slot, const float* __restrict__ fR,
+                                                        const float* __restrict__ fs, const float* __restrict__ fq,
+                                                        const float* __restrict__ g_xyz, const float* __restrict__ g_scaling,
+                                                        const float* __restrict__ g_rot, float* __restrict__ d_xyz,
+                                                        float* __restrict__ d_log_scaling, float* __restrict__ d_rotation,
+                                                        float* __restrict__ rows, const float* __restrict__ out_opacity,
+                                                        const float* __restrict__ g_opacity, float* __restrict__ d_opacity_logit)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (d_opacity_logit) {
+        const float o = out_opacity[i];
+        d_opacity_logit[i] = (g_opacity ? g_opacity[i] : 0.f) * o * (1.f - o);
+    }
+    const int f = splat_face[i];
+    const float s = fs[f];
+    float R[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = fR[9 * f + k];
+    float acc[GAB_BIND_ROW];
+#pragma unroll
+    for (int k = 0; k < GAB_BIND_ROW; ++k) acc[k] = 0.f;
+    const float x[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    const float gx[3] = {g_xyz ? g_xyz[3 * i] : 0.f, g_xyz ? g_xyz[3 * i + 1] : 0.f, g_xyz ? g_xyz[3 * i + 2] : 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d_xyz[3 * i + c] = s * (R[c] * gx[0] + R[3 + c] * gx[1] + R[6 + c] * gx[2]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        acc[r] = gx[r];
+        acc[12] += gx[r] * (R[3 * r] * x[0] + R[3 * r + 1] * x[1] + R[3 * r + 2] * x[2]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[3 + 3 * r + c] = s * gx[r] * x[c];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float e = expf(log_scaling[3 * i + k]);
+        const float g = g_scaling ? g_scaling[3 * i + k] : 0.f;
+        d_log_scaling[3 * i + k] = g * e * s;
+        acc[12] += g * e;
+    }
+    const float4 qf = reinterpret_cast<const float4*>(fq)[f];
+    const float na = qnorm_clamped(qf);
+    const float4 a = make_float4(qf.x / na, qf.y / na, qf.z / na, qf.w / na);
+    const float4 q = reinterpret_cast<const float4*>(rotation)[i];
+    const float nb = qnorm_clamped(q);
+    const float4 b = make_float4(q.x / nb, q.y / nb, q.z / nb, q.w / nb);
+    const float4 g = g_rot ? reinterpret_cast<const float4*>(g_rot)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 da = qmul(g, qconj(b));
+    const float4 db = qmul(qconj(a), g);
+    const float ada = a.x * da.x + a.y * da.y + a.z * da.z + a.w * da.w;
+    const float bdb = b.x * db.x + b.y * db.y + b.z * db.z + b.w * db.w;
+    reinterpret_cast<float4*>(d_rotation)[i] =
+        make_float4((db.x - b.x * bdb) / nb, (db.y - b.y * bdb) / nb, (db.z - b.z * bdb) / nb, (db.w - b.w * bdb) / nb);
+    acc[13] = (da.x - a.x * ada) / na;
+    acc[14] = (da.y - a.y * ada) / na;
+    acc[15] = (da.z - a.z * ada) / na;
+    acc[16] = (da.w - a.w * ada) / na;
+    float4* row = reinterpret_cast<float4*>(rows + (size_t)GAB_BIND_ROW * slot[i]);
+#pragma unroll
+    for (int k = 0; k < GAB_BIND_ROW / 4; ++k) row[k] = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+}
+
+__global__ __launch_bounds__(256) void k_bind_bwd_faces(int F, const int* __restrict__ face_begin, const float* __restrict__ rows,
+                                                         float* __restrict__ d_face)
+{
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = gtid >> 4, sub = gtid & 15;
+    const bool okf = f < F;
+    float acc[GAB_BIND_ROW];
+#pragma unroll
+    for (int k = 0; k < GAB_BIND_ROW; ++k) acc[k] = 0.f;
+    if (okf) {
+        const int b0 = face_begin[f], b1 = face_begin[f + 1];
+        for (int j = b0 + sub; j < b1; j += 16) {
+            const float4* row = reinterpret_cast<const float4*>(rows + (size_t)GAB_BIND_ROW * j);
+#pragma unroll
+            for (int k = 0; k < GAB_BIND_ROW / 4; ++k) {
+                const float4 v = row[k];
+                acc[4 * k] += v.x; acc[4 * k + 1] += v.y; acc[4 * k + 2] += v.z; acc[4 * k + 3] += v.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 17; ++k) {
+        float v = acc[k];
+        v += dpp_f<0xB1, 0xf>(v);
+        v += dpp_f<0x4E, 0xf>(v);
+        v += dpp_f<0x141, 0xf>(v);
+        v += dpp_f<0x140, 0xf>(v);
+        acc[k] = v;
+    }
+    if (okf) {
+#pragma unroll
+        for (int k = 0; k < 17; ++k) {
+            if ((k & 15) != sub) continue;
+            float* dst = k < 3 ? d_face + 3 * f + k
+                       : k < 12 ? d_face + (size_t)3 * F + 9 * f + (k - 3)
+                       : k < 13 ? d_face + (size_t)12 * F + f
+                                : d_face + (size_t)13 * F + 4 * f + (k - 13);
+            *dst = acc[k];
+        }
+    }
+}
+
 // one launch that zero-fills up to 8 small buffers (the full-table gradients of the per-timestep FLAME rows)
 __global__ __launch_bounds__(256) void k_zero_many(ZeroSpec z)
 {
@@ -1093,7 +1207,8 @@ int gab_bind_backward_csr(int32_t N, int32_t F, const float* xyz, const float* l
                           const float* face_orien_mat, const float* face_scaling, const float* face_orien_quat,
                           const float* d_out_xyz, const float* d_out_scaling, const float* d_out_rotation, const int32_t* order,
                           const int32_t* face_begin, float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face,
-                          const float* out_opacity, const float* d_out_opacity, float* d_opacity_logit, void* stream_)
+                          const float* out_opacity, const float* d_out_opacity, float* d_opacity_logit,
+                          const int32_t* splat_face, const int32_t* slot, float* rows, void* stream_)
 {
     if (d_opacity_logit && !out_opacity) return fail(GAB_E_ARG, "d_opacity_logit needs out_opacity");
     if (N < 0 || F <= 0) return fail(GAB_E_ARG, "bad sizes");
@@ -1102,6 +1217,18 @@ int gab_bind_backward_csr(int32_t N, int32_t F, const float* xyz, const float* l
                   !d_rotation))
         return fail(GAB_E_ARG, "gab_bind_backward_csr: NULL buffer");
     const long long threads = 16ll * F;
+    if (splat_face && slot && rows) {   // two passes: splat order (coalesced), then face order over contiguous rows
+        if (N > 0) {
+            hipLaunchKernelGGL(gab::k_bind_bwd_rows, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, N, xyz, log_scaling,
+                               rotation, splat_face, slot, face_orien_mat, face_scaling, face_orien_quat, d_out_xyz, d_out_scaling,
+                               d_out_rotation, d_xyz, d_log_scaling, d_rotation, rows, out_opacity, d_out_opacity, d_opacity_logit);
+            LAUNCH_CHECK("k_bind_bwd_rows");
+        }
+        hipLaunchKernelGGL(gab::k_bind_bwd_faces, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, F, face_begin,
+                           (const float*)rows, d_face);
+        LAUNCH_CHECK("k_bind_bwd_faces");
+        return GAB_OK;
+    }
     hipLaunchKernelGGL(gab::k_bind_bwd_csr, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, F, xyz, log_scaling,
                        rotation, face_orien_mat, face_scaling, face_orien_quat, d_out_xyz, d_out_scaling, d_out_rotation, order, face_begin,
                        d_xyz, d_log_scaling, d_rotation, d_face, out_opacity, d_out_opacity, d_opacity_logit);

@@ -105,13 +105,20 @@ int gab_bind_backward(int32_t N, int32_t F, const float* xyz, const float* log_s
 
 /* Atomic-free, deterministic variant of gab_bind_backward.  `order` (int32 N): splat indices sorted by face;
  * `face_begin` (int32 F+1): CSR offsets into `order`.  Both depend only on `binding` (build them once per
- * densification step).  Every splat must appear exactly once; d_face needs no zero-fill. */
+ * densification step).  Every splat must appear exactly once; d_face needs no zero-fill.
+ * Optional two-pass form (all three non-NULL, else all NULL): `splat_face` (int32 N) = binding as int32, `slot` (int32 N)
+ * = the inverse permutation of `order` (slot[order[j]] == j), `rows` = caller scratch of GAB_BIND_ROW_FLOATS*N floats.
+ * Pass 1 visits the splats in splat order (every per-splat array coalesced) and parks each splat's 17 face
+ * contributions as one row at its CSR position, pass 2 sums each face's contiguous rows: same sums in the same order,
+ * half the time of the one-pass kernel, whose scattered per-splat accesses in face order bound it. */
+#define GAB_BIND_ROW_FLOATS 20
 int gab_bind_backward_csr(int32_t N, int32_t F, const float* xyz, const float* log_scaling, const float* rotation,
                           const float* face_orien_mat, const float* face_scaling, const float* face_orien_quat,
                           const float* d_out_xyz, const float* d_out_scaling, const float* d_out_rotation,
                           const int32_t* order, const int32_t* face_begin,
                           float* d_xyz, float* d_log_scaling, float* d_rotation, float* d_face /*17*F, same four blocks*/,
-                          const float* out_opacity, const float* d_out_opacity, float* d_opacity_logit, void* stream);
+                          const float* out_opacity, const float* d_out_opacity, float* d_opacity_logit,
+                          const int32_t* splat_face, const int32_t* slot, float* rows, void* stream);
 
 /* Utility: zero-fills up to 8 device buffers (sizes in floats) with ONE launch.  `buffers_host` / `sizes_host` are
  * HOST arrays of device pointers / element counts.  Used to build the full (T,k) gradient tables of the per-timestep

@@ -100,7 +100,8 @@ def test_face_frames_and_bind_forward_backward_vs_torch():
     g = np.random.default_rng(3)
     verts0 = verts0 + g.normal(0, 5e-4, verts0.shape).astype(np.float32)
     sp = S.bound_splats(30000, S.FLAME_F, 3, 2)
-    for idx_dtype in (torch.int64, torch.int32):
+    # three backward variants: atomics (no CSR), the two-pass CSR form (the model's), the one-pass CSR kernel
+    for idx_dtype, csr_form in ((torch.int64, None), (torch.int32, "two-pass"), (torch.int32, "one-pass")):
         t = lambda a: torch.as_tensor(a, device=dev).clone().requires_grad_(True)
         va, vb = t(verts0), t(verts0)
         fa = torch.as_tensor(faces, device=dev).to(idx_dtype)
@@ -111,7 +112,12 @@ def test_face_frames_and_bind_forward_backward_vs_torch():
         c2, R2, s2, q2 = U.face_frames(vb, fa.long())
         for n, x, y in (("center", c1, c2), ("R", R1, R2), ("scale", s1, s2), ("quat", q1, q2)):
             _close(x, y, 5e-5, f"face {n}")
-        csr = B.binding_csr(binding, fa.shape[0]) if idx_dtype == torch.int32 else None   # both backward variants
+        csr = B.binding_csr(binding, fa.shape[0]) if csr_form else None
+        if csr_form == "two-pass":
+            order, face_begin, splat_face, slot = csr
+            assert torch.equal(slot[order.long()].long(), torch.arange(order.numel(), device=dev)) and torch.equal(splat_face.long(), binding.long())
+        elif csr_form == "one-pass":
+            csr = csr[:2]
         o1 = B.bind_splats(xa, sa, ra, binding, R1, s1, c1, q1, csr=csr)
         o2 = (U.bind_xyz(xb, binding, R2, s2, c2), U.bind_scaling(sb, binding, s2), U.bind_rotation(rb, binding, q2))
         gen = torch.Generator(device="cpu").manual_seed(1)
@@ -124,7 +130,7 @@ def test_face_frames_and_bind_forward_backward_vs_torch():
         loss1.backward()
         loss2.backward()
         for n, x, y in (("_xyz", xa, xb), ("_scaling", sa, sb), ("_rotation", ra, rb), ("verts", va, vb)):
-            _close(x.grad, y.grad, 3e-4, f"d{n} ({idx_dtype})")
+            _close(x.grad, y.grad, 3e-4, f"d{n} ({idx_dtype}, {csr_form})")
 
 
 def test_model_fused_equals_unfused_end_to_end():
