@@ -93,3 +93,26 @@ def test_fused_path_refuses_cpu_tensors():
 
     with pytest.raises(RuntimeError, match="no CPU implementation"):
         B.face_frames(torch.zeros(4, 3), torch.zeros(2, 3, dtype=torch.long))
+
+
+def test_binding_csr_arrays_are_consistent():
+    """The four arrays gab_bind_backward_csr's two-pass form takes (include/gab.h) depend on `binding` only and are pure torch:
+    order groups the splats by face (stable), face_begin are its CSR offsets, slot inverts order, splat_face is the binding."""
+    import torch
+
+    from gaussianavatars_amd.binding import binding_csr
+
+    g = torch.Generator().manual_seed(7)
+    F, N = 37, 500
+    binding = torch.randint(0, F, (N,), generator=g)
+    binding[binding == 5] = 6                          # an empty face
+    order, face_begin, splat_face, slot = binding_csr(binding, F)
+    assert order.dtype == face_begin.dtype == splat_face.dtype == slot.dtype == torch.int32
+    assert face_begin.shape == (F + 1,) and int(face_begin[0]) == 0 and int(face_begin[-1]) == N
+    assert torch.equal(torch.sort(order.long()).values, torch.arange(N))           # a permutation
+    assert torch.equal(slot[order.long()].long(), torch.arange(N))                # slot is its inverse
+    assert torch.equal(splat_face.long(), binding)
+    for f in range(F):
+        seg = order[int(face_begin[f]): int(face_begin[f + 1])].long()
+        assert (binding[seg] == f).all() and (seg[1:] > seg[:-1]).all()            # grouped by face, stable inside a face
+    assert int(face_begin[6]) == int(face_begin[5])
