@@ -272,6 +272,35 @@ def test_tile_culling_changes_only_the_binning_state(oracle, name):
         assert dropped > 0
 
 
+def test_production_mode_state(oracle):
+    """tile_culling = 1 (what render() runs): same image / final_T / radii bits as the parity modes; the reference-format
+    lists are not written and n_contrib holds the quadrant-stream position (include/gsr.h)."""
+    from gaussianavatars_amd import debug as D
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd.rasterizer import GaussianRasterizationSettings
+
+    dev = _dev()
+    cam, sp, bg, deg, mod = scene("sh3_small")
+    a = settings_args(cam, bg, deg, mod)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    rs = GaussianRasterizationSettings(a["H"], a["W"], a["tanfovx"], a["tanfovy"], t(a["bg"]), mod, t(a["viewmatrix"]),
+                                       t(a["projmatrix"]), deg, t(a["campos"]), False, False)
+    args = (t(sp["means3D"]), t(sp["shs"]), None, t(sp["opacities"]), t(sp["scales"]), t(sp["rotations"]), None)
+    par = D.forward_state(rs, *args, tile_culling=True)
+    prev = R.set_tile_culling(1)
+    try:
+        pro = D._forward_state(rs, *args)
+    finally:
+        R.set_tile_culling(prev)
+    for k in ("color", "final_T"):
+        assert np.array_equal(_np(pro[k]).view(np.uint32), _np(par[k]).view(np.uint32)), k
+    np.testing.assert_array_equal(_np(pro["radii"]), _np(par["radii"]))
+    np.testing.assert_array_equal(_np(pro["n_contrib_q"]), _np(par["n_contrib_q"]))
+    np.testing.assert_array_equal(_np(pro["n_contrib"]), _np(pro["n_contrib_q"]))
+    np.testing.assert_array_equal(_np(pro["qcount"]), _np(par["qcount"]))
+    assert pro["num_rendered"] == par["num_rendered"]
+
+
 def test_tile_culling_gradients_equal_exact_mode(oracle):
     from gaussianavatars_amd import rasterizer as R
 
