@@ -44,6 +44,7 @@ def on_device(dev):
 GSR_LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
 
 GSR_OK = 0
+GSR_ABI_VERSION = 2
 GSR_E_CAPACITY = 1
 
 
@@ -63,6 +64,7 @@ class GsrSettings(C.Structure):
         ("prefiltered", C.c_int32),
         ("debug", C.c_int32),
         ("tile_culling", C.c_int32),
+        ("exact_scale_grad", C.c_int32),
     ]
 
 
@@ -145,8 +147,8 @@ def gsr():
             fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if lib.gsr_abi_version() != 1:
-            raise RuntimeError(f"gsr ABI version {lib.gsr_abi_version()} != 1")
+        if lib.gsr_abi_version() != GSR_ABI_VERSION:
+            raise RuntimeError(f"gsr ABI version {lib.gsr_abi_version()} != {GSR_ABI_VERSION}")
         _gsr = lib
     return _gsr
 

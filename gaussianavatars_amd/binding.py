@@ -45,6 +45,31 @@ def _idx(t):
     return t.contiguous(), int(t.dtype == torch.int64)
 
 
+class _Keep:
+    """Tensors a node needs in its backward, kept for the node's whole life (not freed by the first backward).
+
+    The accessors of a bound model hand the SAME node to every consumer of one mesh update (get_xyz / get_scaling /
+    get_rotation / get_opacity share one launch), so the node must survive being walked more than once -- two
+    render()+backward() passes at one timestep work in the reference, which recomputes the accessors per call.  What
+    autograd's saved-tensor machinery would still give us is done by hand: every entry is a detached alias (never an
+    output object, so no ctx -> output -> grad_fn -> ctx cycle keeps device memory until the cyclic GC runs) and the
+    version counter of each is recorded and re-checked, so an in-place update between forward and backward raises
+    like it does in stock autograd instead of yielding silently wrong gradients."""
+
+    __slots__ = ("tensors", "versions")
+
+    def __init__(self, *tensors):
+        self.tensors = tuple(None if t is None else t.detach() for t in tensors)
+        self.versions = tuple(None if t is None else t._version for t in tensors)
+
+    def get(self):
+        for t, v in zip(self.tensors, self.versions):
+            if t is not None and t._version != v:
+                raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation "
+                                   f"(a {tuple(t.shape)} tensor saved by the fused binding path is at version {t._version}, expected {v})")
+        return self.tensors
+
+
 # -------------------------------------------------------------------------------------------------
 # FLAME forward
 # -------------------------------------------------------------------------------------------------
@@ -168,14 +193,14 @@ class _FlameForwardTimestep(torch.autograd.Function):
         ctx.has_so = so is not None
         ctx.shape_shape = shape.shape
         ctx.so_shape = None if static_offset is None else static_offset.shape
-        ctx.save_for_backward(sh, *tabs, *([so] if so is not None else []), v_shaped, ws)
+        ctx.keep = _Keep(sh, *tabs, *([so] if so is not None else []), v_shaped, ws)
         return verts, v_shaped
 
     @staticmethod
     def backward(ctx, g_verts, g_vshaped):
         lib = _lib.gab()
         rig = _rig_struct(ctx.head)
-        saved = ctx.saved_tensors
+        saved = ctx.keep.get()
         sh, tabs = saved[0], list(saved[1:7])
         so = saved[7] if ctx.has_so else None
         v_shaped, ws = saved[-2], saved[-1]
@@ -232,14 +257,14 @@ class _FaceFrames(torch.autograd.Function):
         with _lib.on_device(dev):
             _chk(lib.gab_face_frames_forward(V, F, _p(v), _p(fi), is64, _p(center), _p(R), _p(scale), _p(quat), _p(ctx.d_verts),
                                              _stream(dev)), "gab_face_frames_forward")
-        ctx.save_for_backward(v, fi)
+        ctx.keep = _Keep(v, fi)
         ctx.is64 = is64
         return center, R, scale, quat
 
     @staticmethod
     def backward(ctx, g_center, g_R, g_scale, g_quat):
         lib = _lib.gab()
-        v, fi = ctx.saved_tensors
+        v, fi = ctx.keep.get()
         dev = v.device
         V, F = v.shape[0], fi.shape[0]
         d_verts, ctx.d_verts = ctx.d_verts, None    # the pre-zeroed buffer serves one backward; a repeat allocates + memsets
@@ -263,14 +288,11 @@ def face_frames(verts, faces):
 # -------------------------------------------------------------------------------------------------
 class _SubCtx:
     """Stand-in for an autograd ctx so that one node can run two of the Functions above back to back (the frame loop is
-    ~0.6 ms of Python per step: every autograd node less is ~40 us of host time forward + backward)."""
+    ~0.6 ms of Python per step: every autograd node less is ~40 us of host time forward + backward).  The two sub-functions
+    keep their tensors as detached aliases (_Keep), so nothing here refers back to the node's outputs."""
 
     def __init__(self, needs_input_grad):
         self.needs_input_grad = needs_input_grad
-        self.saved_tensors = ()
-
-    def save_for_backward(self, *t):
-        self.saved_tensors = t
 
     def set_materialize_grads(self, flag):
         pass
@@ -339,8 +361,11 @@ class _BindSplats(torch.autograd.Function):
         with _lib.on_device(dev):
             _chk(lib.gab_bind_forward(N, F, _p(x), _p(ls), _p(q), _p(b), is64, _p(fc), _p(fR), _p(fs), _p(fq), _p(ox), _p(osc), _p(oq),
                                       _p(ol), _p(oo), _stream(dev)), "gab_bind_forward")
-        ctx.save_for_backward(x, ls, q, b, fR, fs, fc, fq, oo)
+        ctx.keep = _Keep(x, ls, q, b, fR, fs, fc, fq, oo)
         ctx.is64 = is64
+        if csr is not None and (csr[0].numel() != N or csr[1].numel() != F + 1 or any(t.numel() != N for t in csr[2:4])):
+            raise RuntimeError(f"binding CSR does not match this call: {csr[0].numel()} ordered splats / {csr[1].numel() - 1} faces, "
+                               f"expected {N} / {F} (rebuild it with binding_csr after the binding changed)")
         ctx.csr = csr
         if oo is None:
             return ox, osc, oq
@@ -349,7 +374,7 @@ class _BindSplats(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_xyz, g_scaling, g_rot, g_opacity=None):
         lib = _lib.gab()
-        x, ls, q, b, fR, fs, fc, fq, oo = ctx.saved_tensors
+        x, ls, q, b, fR, fs, fc, fq, oo = ctx.keep.get()
         dev = x.device
         N, F = x.shape[0], fc.shape[0]
         f32 = dict(dtype=torch.float32, device=dev)

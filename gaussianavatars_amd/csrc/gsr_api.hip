@@ -112,6 +112,7 @@ gsr::Settings to_dev_settings(const GsrSettings* s)
     d.tanfovy = s->tanfovy;
     d.scale_modifier = s->scale_modifier;
     d.sh_degree = s->sh_degree;
+    d.exact_scale_grad = s->exact_scale_grad;
     d.bg = s->bg;
     d.viewmatrix = s->viewmatrix;
     d.projmatrix = s->projmatrix;

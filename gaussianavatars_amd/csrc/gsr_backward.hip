@@ -499,7 +499,8 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
                     dMk[j] = 2.0f * sc[k] * (R[0][k] * gS[0][j] + R[1][k] * gS[1][j] + R[2][k] * gS[2][j]);
-                dscale[k] = mod * (R[0][k] * dMk[0] + R[1][k] * dMk[1] + R[2][k] * dMk[2]);
+                // upstream returns the gradient w.r.t. (mod * scale); the modifier's own factor is the option (gsr.h)
+                dscale[k] = (s.exact_scale_grad ? mod : 1.0f) * (R[0][k] * dMk[0] + R[1][k] * dMk[1] + R[2][k] * dMk[2]);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) dR[j][k] = sc[k] * dMk[j];
             }

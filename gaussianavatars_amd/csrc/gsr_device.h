@@ -28,6 +28,7 @@ struct Settings {  // by-value kernel argument: scalars + the four device pointe
     float tanfovx, tanfovy;
     float scale_modifier;
     int sh_degree;
+    int exact_scale_grad;
     const float* __restrict__ bg;
     const float* __restrict__ viewmatrix;
     const float* __restrict__ projmatrix;

@@ -3,8 +3,14 @@ scene/gaussian_model.py:113-163 and the mesh update of scene/flame_gaussian_mode
 the same names, attributes and lazy-init behaviour, so a caller written against the reference
 (`render()`, train.py's inner loop, fps_benchmark_demo.py) reads the same.
 
-Only the per-frame path is mirrored.  Optimiser surgery, densification, PLY io and dataset loading
-are out of scope and stay with the reference's own files.
+The classes below state the per-frame methods in COMPOSED TORCH, the way the reference's own classes do, and then go
+through `gaussianavatars_amd.patch.patch_classes` at the bottom of this file -- the very call that rebinds the
+reference's classes in a checkout (`patch_reference()`).  `binding_impl="unfused"` on an instance opts out of the
+fused kernels (the A/B leg of bench.py and the parity tests).  /root/reference does not travel to the GPU box; these
+stand-ins are what the GPU tests and bench.py drive, through the same patched methods.
+
+Only the per-frame path is mirrored.  Optimiser surgery, densification and dataset loading are out of scope
+ and stay with the reference's own files.
 """
 from __future__ import annotations
 
@@ -75,14 +81,14 @@ class GaussianModel:
             arrs["binding"] = self.binding.detach().cpu().numpy()
         gio.save_ply(str(path), arrs)
 
-    # ---- accessors ------------------------------------------------------------------------------
+    # ---- accessors (scene/gaussian_model.py:113-160, composed torch; rebound to the fused kernels below) ----------
     @property
     def get_scaling(self):
         if self.binding is None:
             return torch.exp(self._scaling)
         if self.face_scaling is None:
             self.select_mesh_by_timestep(0)
-        return self._bound()[1]
+        return unfused.bind_scaling(self._scaling, self.binding, self.face_scaling)
 
     @property
     def get_rotation(self):
@@ -90,7 +96,7 @@ class GaussianModel:
             return torch.nn.functional.normalize(self._rotation)
         if self.face_orien_quat is None:
             self.select_mesh_by_timestep(0)
-        return self._bound()[2]
+        return unfused.bind_rotation(self._rotation, self.binding, self.face_orien_quat)
 
     @property
     def get_xyz(self):
@@ -98,21 +104,14 @@ class GaussianModel:
             return self._xyz
         if self.face_center is None:
             self.select_mesh_by_timestep(0)
-        return self._bound()[0]
+        return unfused.bind_xyz(self._xyz, self.binding, self.face_orien_mat, self.face_scaling, self.face_center)
 
     @property
     def get_features(self):
         return torch.cat((self._features_dc, self._features_rest), dim=1)
 
     @property
-    def get_features_split(self):
-        """(dc (N,1,3), rest (N,K,3)) for the rasterizer's split-SH entry; None when there is no rest block."""
-        return (self._features_dc, self._features_rest) if self._features_rest.shape[1] > 0 else None
-
-    @property
     def get_opacity(self):
-        if self.binding is not None and self.binding_impl == "fused" and self.face_center is not None:
-            return self._bound()[3]   # the activation rides along with the bound transform (one launch for all four accessors)
         return torch.sigmoid(self._opacity)
 
     def get_covariance(self, scaling_modifier=1):
@@ -146,34 +145,6 @@ class GaussianModel:
         if self.active_sh_degree < self.max_sh_degree:
             self.active_sh_degree += 1
 
-    # ---- bound transform: one evaluation per mesh update, shared by the three accessors -------
-    def _bound(self):
-        """(xyz_world, scaling_world, rotation_world) for the current mesh.  The reference recomputes
-        each accessor on every call (get_xyz twice per render(), gaussian_renderer/__init__.py:27,54);
-        the values only change when the mesh or a leaf does, so they are cached per (mesh version,
-        leaf versions) -- autograd connectivity to the leaves and the face tensors is unchanged."""
-        key = (self._mesh_version, self._xyz._version, self._scaling._version, self._rotation._version, self._opacity._version,
-               id(self._xyz), id(self._scaling), id(self._rotation), id(self._opacity), torch.is_grad_enabled())
-        if getattr(self, "_bound_key", None) != key:
-            if self.binding_impl == "unfused":
-                out = (unfused.bind_xyz(self._xyz, self.binding, self.face_orien_mat, self.face_scaling, self.face_center),
-                       unfused.bind_scaling(self._scaling, self.binding, self.face_scaling),
-                       unfused.bind_rotation(self._rotation, self.binding, self.face_orien_quat), torch.sigmoid(self._opacity))
-            else:
-                from . import binding as fused
-                ckey = (id(self.binding), self.binding._version, self.face_center.shape[0])
-                if getattr(self, "_csr_key", None) != ckey:   # rebuilt only when the binding changes (densification)
-                    self._csr = fused.binding_csr(self.binding, self.face_center.shape[0])
-                    self._csr_key = ckey
-                out = fused.bind_splats(self._xyz, self._scaling, self._rotation, self.binding, self.face_orien_mat,
-                                        self.face_scaling, self.face_center, self.face_orien_quat, csr=self._csr,
-                                        opacity_logit=self._opacity)
-            self._bound_cache = out
-            self._bound_key = key
-        return self._bound_cache
-
-    _mesh_version = 0
-
 
 class FlameHead(nn.Module):
     """Buffers + forward of the reference FlameHead (flame_model/flame.py:83-184, 485-558) on a rig given
@@ -195,13 +166,9 @@ class FlameHead(nn.Module):
         if zero_centered_at_root_node or return_landmarks:
             raise NotImplementedError("only the per-frame path of GaussianAvatars is mirrored "
                                       "(zero_centered_at_root_node=False, return_landmarks=False)")
-        if self.impl == "unfused":
-            rig = dict(v_template=self.v_template, shapedirs=self.shapedirs, posedirs=self.posedirs,
-                       J_regressor=self.J_regressor, lbs_weights=self.lbs_weights, parents=self.parents)
-            verts, v_shaped = unfused.flame_forward(rig, shape, expr, rotation, neck, jaw, eyes, translation, static_offset)
-        else:
-            from . import binding as fused
-            verts, v_shaped = fused.flame_forward(self, shape, expr, rotation, neck, jaw, eyes, translation, static_offset)
+        rig = dict(v_template=self.v_template, shapedirs=self.shapedirs, posedirs=self.posedirs,
+                   J_regressor=self.J_regressor, lbs_weights=self.lbs_weights, parents=self.parents)
+        verts, v_shaped = unfused.flame_forward(rig, shape, expr, rotation, neck, jaw, eyes, translation, static_offset)
         return [verts, v_shaped] if return_verts_cano else verts
 
 
@@ -264,14 +231,6 @@ class FlameGaussianModel(GaussianModel):
     def select_mesh_by_timestep(self, timestep, original=False):
         self.timestep = timestep
         fp = self.flame_param_orig if original and self.flame_param_orig is not None else self.flame_param
-        if self.binding_impl == "fused":
-            from . import binding as fused
-            faces = self.flame_model.faces
-            verts, verts_cano, c, R, s, q = fused.mesh_frames_timestep(self.flame_model, fp, timestep, faces)
-            self.face_center, self.face_orien_mat, self.face_scaling, self.face_orien_quat = c, R, s, q
-            self.verts, self.faces, self.verts_cano = verts, faces, verts_cano
-            self._mesh_version = self._mesh_version + 1
-            return
         verts, verts_cano = self.flame_model(
             fp["shape"][None, ...], fp["expr"][[timestep]], fp["rotation"][[timestep]], fp["neck_pose"][[timestep]],
             fp["jaw_pose"][[timestep]], fp["eyes_pose"][[timestep]], fp["translation"][[timestep]],
@@ -281,13 +240,14 @@ class FlameGaussianModel(GaussianModel):
 
     def update_mesh_properties(self, verts, verts_cano):
         faces = self.flame_model.faces
-        if self.binding_impl == "unfused":
-            c, R, s, q = unfused.face_frames(verts.squeeze(0), faces)
-        else:
-            from . import binding as fused
-            c, R, s, q = fused.face_frames(verts.squeeze(0), faces)
+        c, R, s, q = unfused.face_frames(verts.squeeze(0), faces)
         self.face_center, self.face_orien_mat, self.face_scaling, self.face_orien_quat = c, R, s, q
         self.verts = verts
         self.faces = faces
         self.verts_cano = verts_cano
-        self._mesh_version = self._mesh_version + 1
+
+
+# The same rebinding `patch_reference()` applies to the reference's classes (gaussianavatars_amd/patch.py).
+from .patch import patch_classes as _patch_classes  # noqa: E402
+
+_patch_classes(GaussianModel, FlameGaussianModel, FlameHead)

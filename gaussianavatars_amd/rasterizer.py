@@ -22,7 +22,7 @@ from torch import nn
 from . import _lib
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_forward_info", "set_tile_culling",
-           "get_tile_culling"]
+           "get_tile_culling", "set_exact_scale_grad"]
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -56,6 +56,18 @@ def set_tile_culling(enabled: bool) -> bool:
 
 def get_tile_culling() -> int:
     return _tile_culling
+
+
+# ---- dL/dscales convention (include/gsr.h: GsrSettings.exact_scale_grad) -------------------------
+# Default = upstream: the gradient w.r.t. (scale_modifier * scale), no factor for the modifier itself.
+_exact_scale_grad = int(os.environ.get("GSR_EXACT_SCALE_GRAD", "0"))
+
+
+def set_exact_scale_grad(enabled: bool) -> bool:
+    """Process-wide switch; True multiplies dL/dscales by scale_modifier (the exact chain rule).  Returns the previous value."""
+    global _exact_scale_grad
+    prev, _exact_scale_grad = bool(_exact_scale_grad), int(bool(enabled))
+    return prev
 
 
 # ---- per-device running estimate of the binning capacity (instances per frame) -----------------
@@ -104,6 +116,7 @@ def _make_settings(rs: GaussianRasterizationSettings, keep: list) -> _lib.GsrSet
     s.sh_degree = int(rs.sh_degree)
     s.prefiltered, s.debug = int(bool(rs.prefiltered)), int(bool(rs.debug))
     s.tile_culling = int(_tile_culling)
+    s.exact_scale_grad = int(_exact_scale_grad)
     for field in ("bg", "viewmatrix", "projmatrix", "campos"):
         t = _f32c(getattr(rs, field), field)
         keep.append(t)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 1
+#define GSR_ABI_VERSION 2
 #define GSR_BWD_SEGMENT 60        /* stream entries per backward segment (a multiple of both blend kernels' batches)  */
 #define GSR_BWD_SEGMENTS 10       /* segments per quadrant stream; the last one takes whatever is left                */
 #define GSR_BIN_BLOCKS 256        /* workgroups of the two binning passes (each owns a contiguous chunk of splats) */
@@ -67,6 +67,10 @@ typedef struct GsrSettings {
                                  1: production -- additionally the reference-format sorted `keys` / `point_list` arrays are
                                     not written (nothing downstream reads them; the blend walks the quadrant streams);
                                  2: culled, lists written (what the subsequence parity tests inspect). */
+    int32_t exact_scale_grad; /* 0 (default): dL/dscales as upstream's computeCov3D backward returns it -- the gradient
+                                 w.r.t. (scale_modifier * scale), WITHOUT the modifier's chain-rule factor;
+                                 !=0: multiplied by scale_modifier (the mathematically exact gradient).  The two agree at
+                                 the reference's scaling_modifier = 1.0 (gaussian_renderer/__init__.py:19). */
 } GsrSettings;
 
 /* Byte offsets of the arrays inside the three opaque state buffers.  The state buffers play the

@@ -51,6 +51,8 @@ typedef struct {
     float campos[3];
     int32_t prefiltered;
     int32_t debug;
+    int32_t exact_scale_grad; /* 0 (default): upstream's dL/dscale, i.e. the gradient w.r.t. (scale_modifier * scale);
+                                 1: the chain rule through the modifier as well (x scale_modifier) */
 } OraSettings;
 
 /* ---- SH constants: values of utils/sh_utils.py:26-43 rounded to fp32 ------------------ */
@@ -436,74 +438,119 @@ void ora_render_forward(const OraSettings* s, const uint32_t* ranges, const uint
 }
 
 /* =====================================================================================
- * A.4  backward.  Accumulation order is fixed (pixels row-major, then back-to-front) so
- * the oracle is deterministic; the device sums in a different order and is compared with
- * a tolerance.  Accumulators are double here on purpose: the oracle is the *reference
- * value* of the sum, the fp32 device result must land within tolerance of it.
+ * A.4  backward.  Accumulators are double on purpose: the oracle is the *reference value*
+ * of the sum, the fp32 device result must land within tolerance of it.
+ * Parallel over tiles (OpenMP) and still deterministic: a tile owns the instances [r0, r1) of
+ * the sorted list, so every (pixel, instance) term is added -- pixels row-major inside the
+ * tile, back to front per pixel -- into a per-INSTANCE partial row nobody else touches; a
+ * second, sequential pass folds the instance rows into the per-splat sums in list order.
+ * The summation order is therefore fixed whatever the thread count.
  * ===================================================================================== */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* threads used by the OpenMP loops of this file from now on (0 = leave the runtime's default); returns the count that will
+ * be used.  bench.py's cpu_baseline reports a 1-thread and an all-core figure with it. */
+int ora_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 void ora_render_backward(const OraSettings* s, int P, const uint32_t* ranges, const uint32_t* point_list,
                          const float* xy, const float* conic_opacity, const float* rgb, const float* final_T,
                          const uint32_t* n_contrib, const float* dL_dpix, double* dL_dmean2D /*2P*/,
                          double* dL_dconic /*3P: A,B,C*/, double* dL_dopacity /*P*/, double* dL_dcolor /*3P*/)
 {
     const int W = s->image_width, H = s->image_height;
-    const int gx = (W + ORA_BLOCK_X - 1) / ORA_BLOCK_X;
+    const int gx = (W + ORA_BLOCK_X - 1) / ORA_BLOCK_X, gy = (H + ORA_BLOCK_Y - 1) / ORA_BLOCK_Y;
     memset(dL_dmean2D, 0, sizeof(double) * 2 * (size_t)P);
     memset(dL_dconic, 0, sizeof(double) * 3 * (size_t)P);
     memset(dL_dopacity, 0, sizeof(double) * (size_t)P);
     memset(dL_dcolor, 0, sizeof(double) * 3 * (size_t)P);
     const float ddelx_dx = 0.5f * (float)W;
     const float ddely_dy = 0.5f * (float)H;
-    for (int py = 0; py < H; ++py) {
-        for (int px = 0; px < W; ++px) {
-            const int tile = (py / ORA_BLOCK_Y) * gx + (px / ORA_BLOCK_X);
-            const uint32_t r0 = ranges[2 * tile];
-            const int pix_id = W * py + px;
-            const float pixx = (float)px, pixy = (float)py;
-            const float T_final = final_T[pix_id];
-            float T = T_final;
-            const uint32_t last = n_contrib[pix_id];
-            float accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0}, last_alpha = 0.f;
-            float dpix[3];
-            for (int ch = 0; ch < 3; ++ch) dpix[ch] = dL_dpix[ch * H * W + pix_id];
-            float bg_dot = 0.f;
-            for (int ch = 0; ch < 3; ++ch) bg_dot += s->bg[ch] * dpix[ch];
-            for (uint32_t c = last; c-- > 0;) {
-                const uint32_t id = point_list[r0 + c];
-                const float dx = xy[2 * id] - pixx;
-                const float dy = xy[2 * id + 1] - pixy;
-                const float* co = conic_opacity + 4 * id;
-                const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                if (power > 0.0f) continue;
-                const float G = ora_expf(power);
-                const float alpha = fminf_(0.99f, co[3] * G);
-                if (alpha < 1.0f / 255.0f) continue;
-                T = T / (1.f - alpha);
-                const float dchannel_dcolor = alpha * T;
-                float dL_dalpha = 0.0f;
-                for (int ch = 0; ch < 3; ++ch) {
-                    const float col = rgb[3 * id + ch];
-                    accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
-                    last_color[ch] = col;
-                    dL_dalpha += (col - accum_rec[ch]) * dpix[ch];
-                    dL_dcolor[3 * id + ch] += (double)(dchannel_dcolor * dpix[ch]);
+    size_t I = 0;   /* instances = end of the last non-empty range */
+    for (int t = 0; t < gx * gy; ++t)
+        if (ranges[2 * t + 1] > I) I = ranges[2 * t + 1];
+    if (I == 0) return;
+    double* part = (double*)calloc(I * 9, sizeof(double));   /* per instance: mean2D 2, conic 3, opacity 1, colour 3 */
+    if (!part) return;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gx * gy; ++tile) {
+        const uint32_t r0 = ranges[2 * tile];
+        if (ranges[2 * tile + 1] == r0) continue;
+        const int ty = tile / gx, tx = tile - ty * gx;
+        const int y1 = imin(H, (ty + 1) * ORA_BLOCK_Y), x1 = imin(W, (tx + 1) * ORA_BLOCK_X);
+        for (int py = ty * ORA_BLOCK_Y; py < y1; ++py) {
+            for (int px = tx * ORA_BLOCK_X; px < x1; ++px) {
+                const int pix_id = W * py + px;
+                const float pixx = (float)px, pixy = (float)py;
+                const float T_final = final_T[pix_id];
+                float T = T_final;
+                const uint32_t last = n_contrib[pix_id];
+                float accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0}, last_alpha = 0.f;
+                float dpix[3];
+                for (int ch = 0; ch < 3; ++ch) dpix[ch] = dL_dpix[ch * H * W + pix_id];
+                float bg_dot = 0.f;
+                for (int ch = 0; ch < 3; ++ch) bg_dot += s->bg[ch] * dpix[ch];
+                for (uint32_t c = last; c-- > 0;) {
+                    const uint32_t id = point_list[r0 + c];
+                    double* acc = part + 9 * (size_t)(r0 + c);
+                    const float dx = xy[2 * id] - pixx;
+                    const float dy = xy[2 * id + 1] - pixy;
+                    const float* co = conic_opacity + 4 * id;
+                    const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > 0.0f) continue;
+                    const float G = ora_expf(power);
+                    const float alpha = fminf_(0.99f, co[3] * G);
+                    if (alpha < 1.0f / 255.0f) continue;
+                    T = T / (1.f - alpha);
+                    const float dchannel_dcolor = alpha * T;
+                    float dL_dalpha = 0.0f;
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float col = rgb[3 * id + ch];
+                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                        last_color[ch] = col;
+                        dL_dalpha += (col - accum_rec[ch]) * dpix[ch];
+                        acc[6 + ch] += (double)(dchannel_dcolor * dpix[ch]);
+                    }
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                    const float dL_dG = co[3] * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * co[0] - gdy * co[1];
+                    const float dG_ddely = -gdy * co[2] - gdx * co[1];
+                    acc[0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
+                    acc[1] += (double)(dL_dG * dG_ddely * ddely_dy);
+                    acc[2] += (double)(-0.5f * gdx * dx * dL_dG);
+                    acc[3] += (double)(-0.5f * gdx * dy * dL_dG);
+                    acc[4] += (double)(-0.5f * gdy * dy * dL_dG);
+                    acc[5] += (double)(G * dL_dalpha);
                 }
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                const float dL_dG = co[3] * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * co[0] - gdy * co[1];
-                const float dG_ddely = -gdy * co[2] - gdx * co[1];
-                dL_dmean2D[2 * id + 0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
-                dL_dmean2D[2 * id + 1] += (double)(dL_dG * dG_ddely * ddely_dy);
-                dL_dconic[3 * id + 0] += (double)(-0.5f * gdx * dx * dL_dG);
-                dL_dconic[3 * id + 1] += (double)(-0.5f * gdx * dy * dL_dG);
-                dL_dconic[3 * id + 2] += (double)(-0.5f * gdy * dy * dL_dG);
-                dL_dopacity[id] += (double)(G * dL_dalpha);
             }
         }
     }
+    for (size_t k = 0; k < I; ++k) {   /* sequential fold, list order: deterministic */
+        const uint32_t id = point_list[k];
+        const double* acc = part + 9 * k;
+        dL_dmean2D[2 * id + 0] += acc[0];
+        dL_dmean2D[2 * id + 1] += acc[1];
+        dL_dconic[3 * id + 0] += acc[2];
+        dL_dconic[3 * id + 1] += acc[3];
+        dL_dconic[3 * id + 2] += acc[4];
+        dL_dopacity[id] += acc[5];
+        dL_dcolor[3 * id + 0] += acc[6];
+        dL_dcolor[3 * id + 1] += acc[7];
+        dL_dcolor[3 * id + 2] += acc[8];
+    }
+    free(part);
 }
 
 /* K8 + K9: per visible splat.  Inputs are fp32 (the oracle driver rounds the double sums of
@@ -685,9 +732,13 @@ void ora_preprocess_backward(const OraSettings* s, int P, int M, const float* me
             for (int k = 0; k < 3; ++k)
                 for (int j = 0; j < 3; ++j)
                     dM[k][j] = 2.0f * (sc[k] * R[0][k] * gS[0][j] + sc[k] * R[1][k] * gS[1][j] + sc[k] * R[2][k] * gS[2][j]);
-            /* dL/ds_k = sum_j R[j][k] dM[k][j];  dL/dscale = mod * dL/ds */
+            /* dL/ds_k = sum_j R[j][k] dM[k][j] with s = mod * scale.  Upstream's computeCov3D backward returns THIS as
+             * dL/dscale (it differentiates w.r.t. the modified scale and never multiplies by the modifier); the exact
+             * chain rule (x mod) is the option.  Identical at the reference's scaling_modifier = 1.0
+             * (gaussian_renderer/__init__.py:19). */
+            const float smul = s->exact_scale_grad ? mod : 1.0f;
             for (int k = 0; k < 3; ++k)
-                dL_dscale[3 * i + k] = mod * (R[0][k] * dM[k][0] + R[1][k] * dM[k][1] + R[2][k] * dM[k][2]);
+                dL_dscale[3 * i + k] = smul * (R[0][k] * dM[k][0] + R[1][k] * dM[k][1] + R[2][k] * dM[k][2]);
             /* dL/dR[j][k] = s_k dM[k][j] */
             float dR[3][3];
             for (int j = 0; j < 3; ++j)

@@ -32,6 +32,7 @@ class OraSettings(C.Structure):
         ("campos", C.c_float * 3),
         ("prefiltered", C.c_int32),
         ("debug", C.c_int32),
+        ("exact_scale_grad", C.c_int32),
     ]
 
 
@@ -56,6 +57,8 @@ def lib():
         _lib.ora_expf.restype = C.c_float
         _lib.ora_expf.argtypes = [C.c_float]
         _lib.ora_scan.restype = C.c_int64
+        _lib.ora_set_threads.restype = C.c_int
+        _lib.ora_set_threads.argtypes = [C.c_int]
     return _lib
 
 
@@ -67,7 +70,7 @@ def _p(a: Optional[np.ndarray]):
 
 
 def make_settings(H, W, tanfovx, tanfovy, bg, scale_modifier, viewmatrix, projmatrix, sh_degree, campos,
-                  prefiltered=False, debug=False) -> OraSettings:
+                  prefiltered=False, debug=False, exact_scale_grad=False) -> OraSettings:
     s = OraSettings()
     s.image_height, s.image_width = int(H), int(W)
     s.tanfovx, s.tanfovy = float(tanfovx), float(tanfovy)
@@ -78,6 +81,7 @@ def make_settings(H, W, tanfovx, tanfovy, bg, scale_modifier, viewmatrix, projma
     s.sh_degree = int(sh_degree)
     s.campos[:] = [float(v) for v in np.asarray(campos, np.float32).reshape(3)]
     s.prefiltered, s.debug = int(prefiltered), int(debug)
+    s.exact_scale_grad = int(exact_scale_grad)   # default: upstream's dL/dscale (no scale_modifier factor)
     return s
 
 
@@ -206,6 +210,11 @@ def backward(settings: OraSettings, st: OracleState, dL_dpix) -> dict:
         _color=g_color32,
         _cov3D=g_cov3D,
     )
+
+
+def set_threads(n: int) -> int:
+    """OpenMP threads for the oracle's parallel loops from now on (0: keep the default); returns the count in use."""
+    return int(lib().ora_set_threads(int(n)))
 
 
 def expf(x: np.ndarray) -> np.ndarray:

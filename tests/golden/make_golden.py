@@ -15,6 +15,14 @@ Pins produced (the reference has no tests or golden vectors of i
   loss_pins.npz     utils/loss_utils.l1_loss / ssim (values + autograd gradients, fp32 torch-CPU)
                     scene/gaussian_model.GaussianModel.add_densification_stats + train.py:197
                                                                    -> densification statistics update
+  model_pins.npz    the reference's OWN classes at full rig size (V = 5143, F = 10144, 400 betas, 20 000 bound splats):
+                    scene/flame_gaussian_model.FlameGaussianModel.select_mesh_by_timestep / update_mesh_by_param_dict /
+                    update_mesh_properties, flame_model/flame.FlameHead.forward, flame_model/lbs.lbs,
+                    scene/gaussian_model.GaussianModel.get_xyz / get_scaling / get_rotation / get_opacity / get_covariance,
+                    and torch autograd through all of them down to the flame_param rows
+                    (inputs are regenerated from gaussianavatars_amd.synthetic seeds; only outputs are stored, the large
+                    ones at a fixed stride).  roma is absent: its four functions come from gaussianavatars_amd/shims/roma.py,
+                    which tests/test_binding_cpu.py pins to SciPy.
 """
 import math
 import os
@@ -185,9 +193,101 @@ def loss_pins():
     np.savez_compressed(os.path.join(HERE, "loss_pins.npz"), **out)
 
 
+from tests.model_pin_inputs import MODEL_PINS, model_pin_inputs  # noqa: E402  (shared with the tests that consume the pins)
+
+
+def model_pins():
+    from gaussianavatars_amd import shims
+
+    shims.install(stub_torchvision=True)   # roma / plyfile / simple_knn ...: absent third-party imports of scene/*.py
+    from flame_model.flame import FlameHead as RefHead
+    from scene.flame_gaussian_model import FlameGaussianModel as RefFGM
+    from scene.gaussian_model import GaussianModel as RefGM
+
+    assert not getattr(RefGM, "_gaa_patched", False), "pins must come from the UNPATCHED reference classes"
+    c = MODEL_PINS
+    rig, seq, sp, w, pd = model_pin_inputs()
+
+    def build(dt):
+        """The reference's FlameGaussianModel around the synthetic rig, in dtype dt."""
+        t = lambda a: torch.tensor(a, dtype=dt) if np.asarray(a).dtype.kind == "f" else torch.tensor(a)
+        # FlameHead without its asset files (flame2023.pkl is licence-gated): the buffers its __init__ would register
+        head = RefHead.__new__(RefHead)
+        torch.nn.Module.__init__(head)
+        head.n_shape_params, head.n_expr_params, head.dtype = S.N_SHAPE, S.N_EXPR, dt
+        for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights"):
+            head.register_buffer(k, t(rig[k]))
+        head.register_buffer("parents", t(rig["parents"]))
+        head.register_buffer("faces", t(rig["faces"]), persistent=False)
+        m = RefFGM.__new__(RefFGM)
+        RefGM.__init__(m, 3)                       # the reference constructor of the base class (activations, empty leaves)
+        m.disable_flame_static_offset = m.not_finetune_flame_params = False
+        m.n_shape, m.n_expr = S.N_SHAPE, S.N_EXPR
+        m.flame_model = head
+        m.flame_param = {k: t(v) for k, v in seq.items()}
+        for k in ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation"):
+            m.flame_param[k].requires_grad_(True)
+        m.flame_param_orig = None
+        for k in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest"):
+            setattr(m, k, torch.nn.Parameter(t(sp[k])))
+        m.binding = t(sp["binding"])
+        return m, t
+
+    m, t = build(torch.float32)
+    m64, t64 = build(torch.float64)   # the same reference code in double: the value the fp32 gradients of the FLAME rows are noisy around
+    out = {}
+    fs, ss = c["face_stride"], c["splat_stride"]
+    for ts in c["steps"]:
+        for p in (m._xyz, m._scaling, m._rotation, m._opacity, *m.flame_param.values()):
+            p.grad = None
+        m.select_mesh_by_timestep(ts)          # FlameHead.forward -> lbs -> update_mesh_properties (reference code)
+        x, sc, ro, op = m.get_xyz, m.get_scaling, m.get_rotation, m.get_opacity
+        loss = (x * t(w["xyz"])).sum() + (sc * t(w["scaling"])).sum() + (ro * t(w["rotation"])).sum() + (op * t(w["opacity"])).sum()
+        loss.backward()
+        pre = f"t{ts}_"
+        out.update({pre + "verts": m.verts.detach().numpy()[0], pre + "verts_cano": m.verts_cano.detach().numpy()[0],
+                    pre + "face_center": m.face_center.detach().numpy()[::fs], pre + "face_orien_mat": m.face_orien_mat.detach().numpy()[::fs],
+                    pre + "face_scaling": m.face_scaling.detach().numpy()[::fs], pre + "face_orien_quat": m.face_orien_quat.detach().numpy()[::fs],
+                    pre + "xyz": x.detach().numpy()[::ss], pre + "scaling": sc.detach().numpy()[::ss],
+                    pre + "rotation": ro.detach().numpy()[::ss], pre + "opacity": op.detach().numpy()[::ss],
+                    pre + "loss": np.float64(loss.item()),
+                    pre + "g_xyz": m._xyz.grad.numpy()[::ss], pre + "g_scaling": m._scaling.grad.numpy()[::ss],
+                    pre + "g_rotation": m._rotation.grad.numpy()[::ss], pre + "g_opacity": m._opacity.grad.numpy()[::ss]})
+        for k in ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation"):
+            gk = m.flame_param[k].grad.numpy()
+            assert np.abs(np.delete(gk, ts, axis=0)).max() == 0.0          # only row t receives gradient
+            out[pre + "gf_" + k] = gk[ts]
+        # The per-splat weights are white noise, so the FLAME-row gradients are sums with heavy cancellation through the
+        # ill-conditioned face frames (1/edge-length factors): the reference's own fp32 result sits up to 5e-4 away from the
+        # exact value.  Store the fp64 evaluation of the same reference code as the anchor, and the reference's fp32 deviation
+        # from it as the yardstick the tests scale their tolerance with.
+        for p in m64.flame_param.values():
+            p.grad = None
+        m64.select_mesh_by_timestep(ts)
+        l64 = ((m64.get_xyz * t64(w["xyz"])).sum() + (m64.get_scaling * t64(w["scaling"])).sum() +
+               (m64.get_rotation * t64(w["rotation"])).sum() + (m64.get_opacity * t64(w["opacity"])).sum())
+        l64.backward()
+        for k in ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation"):
+            g64 = m64.flame_param[k].grad.numpy()[ts]
+            out[pre + "gf64_" + k] = g64
+            out[pre + "gf_dev_" + k] = np.float64(np.abs(out[pre + "gf_" + k] - g64).max() / np.abs(g64).max())
+    # python cov3D path (pipe.compute_cov3D_python): get_covariance uses the LOCAL rotation (scene/gaussian_model.py:162-163)
+    with cpu_zeros():
+        out["cov3D_mod"] = m.get_covariance(c["cov_mod"]).detach().numpy()[::ss]
+    out["cov3D_timestep"] = np.int32(c["steps"][-1])
+    # viewer path: update_mesh_by_param_dict (the reference calls .cuda() on the dict entries: identity on this host)
+    with mock.patch.object(torch.Tensor, "cuda", lambda self, *a, **k: self):
+        with torch.no_grad():
+            m.update_mesh_by_param_dict({k: t(v) for k, v in pd.items()})
+    out.update(pd_verts=m.verts.numpy()[0], pd_face_center=m.face_center.numpy()[::fs], pd_face_orien_quat=m.face_orien_quat.numpy()[::fs],
+               pd_face_scaling=m.face_scaling.numpy()[::fs])
+    np.savez_compressed(os.path.join(HERE, "model_pins.npz"), **out)
+
+
 if __name__ == "__main__":
     raster_pins()
     binding_pins()
     loss_pins()
-    for f in ("raster_pins.npz", "binding_pins.npz", "loss_pins.npz"):
+    model_pins()
+    for f in ("raster_pins.npz", "binding_pins.npz", "loss_pins.npz", "model_pins.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

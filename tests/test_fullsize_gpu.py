@@ -86,6 +86,8 @@ def test_config2_100k_bound_forward_backward_vs_oracle(oracle):
     m2 = torch.zeros_like(t["means3D"], requires_grad=True)
     color, _ = GaussianRasterizer(rs)(means3D=t["means3D"], means2D=m2, shs=t["shs"], opacities=t["opacities"], scales=t["scales"],
                                       rotations=t["rotations"])
+    # production mode (tile_culling = 1, what render() and bench.py run): the image is the oracle's, bit for bit
+    assert np.array_equal(_np(color).view(np.uint32), st.color.view(np.uint32))
     (color - 1.0).abs().mean().backward()
     gpix = (np.sign(st.color - 1.0) / st.color.size).astype(np.float32)
     ref = oracle.backward(s, st, gpix)
@@ -101,6 +103,54 @@ def test_config2_100k_bound_forward_backward_vs_oracle(oracle):
     (2.0 * (color2 - 1.0).abs().mean()).backward()
     err = (t2["means3D"].grad - 2 * t["means3D"].grad).abs().max() / (2 * t["means3D"].grad.abs().max())
     assert float(err) < 1e-4
+
+
+def test_config4_200k_rigged_sequence_vs_oracle(oracle):
+    """BASELINE configs[3]: 200 000 splats bound to the 5143-vertex synthetic FLAME rig, 300-frame expression sequence.
+    Three timesteps through the model path the benchmark runs (select_mesh_by_timestep -> render -> L1 vs white -> backward,
+    production mode): image bit-exact against the oracle fed the SAME world-space splats, screen-space and per-splat
+    gradients within 5e-4 of each tensor's max (the oracle sums in double)."""
+    import bench
+    from gaussianavatars_amd.gaussian_renderer import l1_loss, render
+
+    dev = _dev()
+    H, W, N, T = 802, 550, 200_000, 300
+    g, cam = bench.build_scene(dev, N, 3, W, H, T, "fused", True)
+    bg = torch.ones(3, device=dev)
+    target = torch.ones((3, H, W), device=dev)
+    tfx, tfy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    s = oracle.make_settings(H, W, tfx, tfy, [1, 1, 1], 1.0, _np(cam.world_view_transform), _np(cam.full_proj_transform), 3,
+                             _np(cam.camera_center))
+    for ts in (0, 137, 299):
+        bench.zero_grads(g)
+        g.select_mesh_by_timestep(ts)
+        world = dict(means3D=g.get_xyz, opacities=g.get_opacity, scales=g.get_scaling, rotations=g.get_rotation)
+        for v in world.values():
+            v.retain_grad()                      # what the rasterizer's backward hands to the binding backward
+        pkg = render(cam, g, bench.Pipe, bg)
+        loss = l1_loss(pkg["render"], target)
+        loss.backward()
+        a = {k: _np(v) for k, v in world.items()}
+        shs = _np(g.get_features)
+        st = oracle.forward(s, a["means3D"], shs, None, a["opacities"], a["scales"], a["rotations"], None)
+        img = _np(pkg["render"])
+        assert np.array_equal(img.view(np.uint32), st.color.view(np.uint32)), f"t={ts}: image max abs diff {np.abs(img - st.color).max()}"
+        np.testing.assert_array_equal(_np(pkg["radii"]), st.radii)
+        np.testing.assert_array_equal(_np(pkg["visibility_filter"]), st.radii > 0)
+        gpix = (np.sign(st.color - 1.0) / st.color.size).astype(np.float32)
+        ref = oracle.backward(s, st, gpix)
+        got = dict(means3D=world["means3D"].grad, means2D=pkg["viewspace_points"].grad, opacities=world["opacities"].grad,
+                   scales=world["scales"].grad, rotations=world["rotations"].grad,
+                   shs=torch.cat([g._features_dc.grad, g._features_rest.grad], 1))
+        for k, v in got.items():
+            r = ref[k]
+            err = np.abs(_np(v).reshape(r.shape) - r).max() / (np.abs(r).max() + 1e-30)
+            assert err < 5e-4, f"t={ts} {k}: rel err {err:.2e}"
+        for k in ("expr", "jaw_pose", "rotation", "translation"):
+            gk = g.flame_param[k].grad
+            other = torch.ones(gk.shape[0], dtype=torch.bool, device=gk.device)
+            other[ts] = False
+            assert float(gk[ts].abs().max()) > 0 and float(gk[other].abs().max()) == 0.0   # row ts only
 
 
 def test_config5_2m_stress_forward(oracle):

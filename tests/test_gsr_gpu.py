@@ -22,14 +22,14 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _run_both(oracle, name, use_precomp_color=False, use_precomp_cov=False):
+def _run_both(oracle, name, use_precomp_color=False, use_precomp_cov=False, exact_scale_grad=False):
     from gaussianavatars_amd.debug import forward_state
     from gaussianavatars_amd.rasterizer import GaussianRasterizationSettings
 
     dev = _dev()
     cam, sp, bg, deg, mod = scene(name)
     a = settings_args(cam, bg, deg, mod)
-    s = oracle.make_settings(**a)
+    s = oracle.make_settings(**a, exact_scale_grad=exact_scale_grad)
     shs = None if use_precomp_color else sp["shs"]
     colors = np.ascontiguousarray(np.abs(sp["shs"][:, 0, :])) if use_precomp_color else None
     st0 = None
@@ -106,11 +106,11 @@ def test_forward_precomputed_inputs(oracle):
     _check_forward(st, hs)
 
 
-def _grad_check(oracle, name, use_precomp_color=False, use_precomp_cov=False, rtol=2e-4):
+def _grad_check(oracle, name, use_precomp_color=False, use_precomp_cov=False, rtol=2e-4, exact_scale_grad=False):
     from gaussianavatars_amd.rasterizer import GaussianRasterizer
 
     dev = _dev()
-    s, st, hs, rs, inp = _run_both(oracle, name, use_precomp_color, use_precomp_cov)
+    s, st, hs, rs, inp = _run_both(oracle, name, use_precomp_color, use_precomp_cov, exact_scale_grad)
     H, W = rs.image_height, rs.image_width
     gpix = np.random.default_rng(5).normal(0, 1, (3, H, W)).astype(np.float32)
     ref = oracle.backward(s, st, gpix)
@@ -136,6 +136,7 @@ def _grad_check(oracle, name, use_precomp_color=False, use_precomp_cov=False, rt
         err = np.abs(g - r).max() / scale
         assert err < rtol, f"{name}/{k}: rel err {err:.3e} (max |ref| {scale:.3e})"
     assert float(m2.grad[:, 2].abs().max()) == 0.0
+    return got
 
 
 @pytest.mark.parametrize("name", ["cfg1", "sh3_small", "sh2_mod", "culls", "deep_stack", "huge_grid"])
@@ -143,6 +144,23 @@ def test_backward_matches_oracle(oracle, name):
     # huge_grid: screen-filling splats sum ~10^7 per-pixel terms through fp32 atomics; the run-to-run spread of the most
     # cancellation-prone gradient (rotations) reaches 3e-4 of its max, so that scene gets 1e-3
     _grad_check(oracle, name, rtol=1e-3 if name == "huge_grid" else 2e-4)
+
+
+def test_scale_gradient_conventions(oracle):
+    """scale_modifier = 1.4 (sh2_mod).  Default: dL/dscales is upstream's -- the gradient w.r.t. (modifier * scale), no
+    factor for the modifier.  set_exact_scale_grad(True): the exact chain rule, = default x modifier.  Both against the
+    oracle in the same mode (oracle exact mode is pinned to fp64 autograd, tests/test_oracle_pins.py)."""
+    from gaussianavatars_amd import rasterizer as R
+
+    up = _grad_check(oracle, "sh2_mod")
+    prev = R.set_exact_scale_grad(True)
+    try:
+        ex = _grad_check(oracle, "sh2_mod", exact_scale_grad=True)
+    finally:
+        R.set_exact_scale_grad(prev)
+    assert prev is False
+    a, b = _np(up["scales"]) * np.float32(1.4), _np(ex["scales"])
+    assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max()
 
 
 def test_backward_precomputed_inputs(oracle):

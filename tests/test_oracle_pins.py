@@ -128,10 +128,19 @@ def test_oracle_backward_matches_fp64_autograd(oracle, deg, mod):
     sp["means3D"][:3, 0] += 0.4  # outside the 1.3x frustum: clamp branch
     tfx, tfy = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
     bg = [0.3, 0.9, 0.5]
-    s = oracle.make_settings(H, W, tfx, tfy, bg, mod, cam.world_view_transform, cam.full_proj_transform, deg, cam.camera_center)
+    # exact_scale_grad: the chain rule through scale_modifier, which is what autograd of the restatement computes
+    s = oracle.make_settings(H, W, tfx, tfy, bg, mod, cam.world_view_transform, cam.full_proj_transform, deg, cam.camera_center,
+                             exact_scale_grad=True)
     st = oracle.forward(s, sp["means3D"], sp["shs"], None, sp["opacities"], sp["scales"], sp["rotations"], None)
     gpix = np.random.default_rng(3).normal(0, 1, (3, H, W)).astype(np.float32)
     g = oracle.backward(s, st, gpix)
+    # default mode = upstream's computeCov3D backward: dL/dscale is the gradient w.r.t. (scale_modifier * scale), i.e. the
+    # exact one divided by the modifier; every other gradient is the same
+    s_up = oracle.make_settings(H, W, tfx, tfy, bg, mod, cam.world_view_transform, cam.full_proj_transform, deg, cam.camera_center)
+    g_up = oracle.backward(s_up, st, gpix)
+    np.testing.assert_allclose(g_up["scales"] * np.float32(mod), g["scales"], rtol=2e-6, atol=1e-30)
+    for k in ("means3D", "means2D", "shs", "opacities", "rotations"):
+        np.testing.assert_array_equal(g_up[k], g[k])
     t = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
     m3, m2, sh, op, sc, ro = (t(sp["means3D"]), t(np.zeros((N, 3))), t(sp["shs"]), t(sp["opacities"]), t(sp["scales"]),
                               t(sp["rotations"]))

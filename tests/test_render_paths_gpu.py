@@ -1,0 +1,77 @@
+"""The two optional Python paths of render() (gaussian_renderer/__init__.py:63-67,73-79): `pipe.compute_cov3D_python`
+(3D covariance from GaussianModel.get_covariance, scene/gaussian_model.py:162-163) and `pipe.convert_SHs_python` (colours
+from utils/sh_utils.eval_sh).  Both feed the rasterizer's precomputed-input entries; the result must agree with the default
+path, where the kernel evaluates the same formulas -- up to fp32 evaluation-order differences (a handful of pixels may sit on
+the other side of the 1/255 or 1e-4 thresholds, bounded below)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class _Pipe:
+    debug = False
+    compute_cov3D_python = False
+    convert_SHs_python = False
+
+
+def _scene(dev):
+    from gaussianavatars_amd import synthetic as S
+    from gaussianavatars_amd.gaussian_model import GaussianModel
+
+    sp = S.random_splats(20000, 3, 31, xyz_sigma=0.05, log_scale_mean=math.log(0.004))
+    op = np.clip(sp["opacities"], 1e-6, 1 - 1e-6)
+    arrs = dict(_xyz=sp["means3D"], _scaling=np.log(sp["scales"]), _rotation=sp["rotations"], _opacity=np.log(op / (1 - op)),
+                _features_dc=sp["shs"][:, :1], _features_rest=sp["shs"][:, 1:])
+    g = GaussianModel(3)     # un-bound: get_covariance uses the local rotation, right only here (reference quirk, kept)
+    g.load_arrays(arrs, device=dev, requires_grad=True)
+    cam = S.orbit_camera(208, 176, yaw_deg=15, pitch_deg=-8)
+    for k in ("world_view_transform", "full_proj_transform", "camera_center"):
+        setattr(cam, k, torch.as_tensor(getattr(cam, k), device=dev))
+    return g, cam
+
+
+def _step(g, cam, pipe, dev):
+    from gaussianavatars_amd.gaussian_renderer import render
+
+    leaves = (g._xyz, g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity)
+    for p in leaves:
+        p.grad = None
+    pkg = render(cam, g, pipe, torch.tensor([0.1, 0.3, 0.2], device=dev))
+    w = torch.randn(pkg["render"].shape, generator=torch.Generator().manual_seed(2)).to(dev)
+    (pkg["render"] * w).sum().backward()
+    return pkg["render"].detach(), pkg["radii"], [p.grad.clone() for p in leaves], pkg["viewspace_points"].grad.clone()
+
+
+@pytest.mark.parametrize("flag", ["compute_cov3D_python", "convert_SHs_python"])
+def test_python_path_agrees_with_the_kernel_path(flag):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda:0")
+    g, cam = _scene(dev)
+    with torch.no_grad():    # the rasterizer takes the quaternion raw, get_covariance normalises it: feed unit quaternions
+        g._rotation.div_(g._rotation.norm(dim=1, keepdim=True))
+    base = _step(g, cam, _Pipe, dev)
+
+    class P(_Pipe):
+        pass
+
+    setattr(P, flag, True)
+    alt = _step(g, cam, P, dev)
+    diff = (alt[0] - base[0]).abs()
+    assert float(diff.mean()) < 2e-6 and float(diff.max()) < 2.0 / 255.0, (float(diff.mean()), float(diff.max()))
+    assert int((alt[1] != base[1]).sum()) <= 2                      # radii: ceil(3 sigma) may flip on a rounding boundary
+    names = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
+    for n, a, b in zip(names, alt[2], base[2]):
+        scale = float(b.abs().max()) + 1e-30
+        # _rotation: the python path differentiates through the normalisation, the kernel path does not (raw quaternion);
+        # for unit quaternions the two differ by the radial component only -- compare the tangential part
+        if n == "_rotation":
+            q = g._rotation.detach()
+            a = a - (a * q).sum(1, keepdim=True) * q
+            b = b - (b * q).sum(1, keepdim=True) * q
+        assert float((a - b).abs().max()) / scale < 2e-3, n
+    assert float((alt[3] - base[3]).abs().max()) / (float(base[3].abs().max()) + 1e-30) < 2e-3
