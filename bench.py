@@ -103,10 +103,10 @@ def zero_grads(g):
                 v.grad = None
 
 
-def cpu_baseline(g, cam, bg, train, max_seconds=25.0):
-    """The CPU oracle (oracle/, a port -- the reference has no CPU rasterizer) timed on
-    this box's host cores on the same frame (rasterizer half only: world-space splats in, image and
-    gradients out)."""
+def cpu_baseline(g, cam, bg, train, max_seconds=12.0):
+    """The CPU oracle (oracle/, a port -- the reference has no CPU rasterizer) timed on this box's host cores on
+    the same frame (rasterizer half only: world-space splats in, image and gradients out), once on every core (OpenMP over
+    splats / pixel rows / tiles) and once on ONE thread."""
     import math
 
     from oracle import gsr_oracle as O
@@ -123,19 +123,27 @@ def cpu_baseline(g, cam, bg, train, max_seconds=25.0):
                         g.active_sh_degree, cam.camera_center.cpu().numpy())
     H, W = cam.image_height, cam.image_width
     gpix = np.full((3, H, W), -1.0 / (3 * H * W), np.float32)  # d l1(image, white)/d image where image < 1
-    frames, t0 = 0, time.perf_counter()
-    while True:
-        st = O.forward(s, arrs["means3D"], arrs["shs"], None, arrs["opacities"], arrs["scales"], arrs["rotations"], None)
-        if train:
-            O.backward(s, st, gpix)
-        frames += 1
-        el = time.perf_counter() - t0
-        if el > max_seconds or frames >= 8:
-            break
     cores = len(os.sched_getaffinity(0))
-    out = dict(value=frames / el, unit="frames/s", cores=cores, kind="port",
-               sample=f"{frames} frame(s) of the bench workload, rasterizer half ({'fwd+bwd' if train else 'fwd'}), "
-                      f"oracle/gsr_oracle.c with OpenMP on {cores} threads (render backward is single-threaded)")
+
+    def timed(threads, max_frames, budget):
+        used = O.set_threads(threads)
+        frames, t0 = 0, time.perf_counter()
+        while True:
+            st = O.forward(s, arrs["means3D"], arrs["shs"], None, arrs["opacities"], arrs["scales"], arrs["rotations"], None)
+            if train:
+                O.backward(s, st, gpix)
+            frames += 1
+            el = time.perf_counter() - t0
+            if el > budget or frames >= max_frames:
+                return frames / el, frames, used, st
+
+    fps_all, n_all, used_all, st = timed(cores, 16, max_seconds)
+    fps_one, n_one, _, _ = timed(1, 2, max_seconds)
+    O.set_threads(cores)
+    what = "fwd+bwd" if train else "fwd"
+    out = dict(value=fps_all, unit="frames/s", cores=used_all, kind="port",
+               sample=f"{n_all} frame(s) of the bench workload, rasterizer half ({what}), oracle/gsr_oracle.c with OpenMP on {used_all} threads",
+               single_thread=dict(value=fps_one, unit="frames/s", cores=1, sample=f"{n_one} frame(s), same workload, one thread"))
     if g.binding is not None:
         out["binding_half"] = cpu_binding_baseline(g, train)
     return out, st.num_rendered, int((st.radii > 0).sum())
@@ -165,6 +173,59 @@ def cpu_binding_baseline(g, train, frames=5):
                 what="composed-torch FLAME + face frames + per-splat bind on torch-CPU (" + ("fwd+bwd" if train else "fwd") + ")")
 
 
+def make_runner(step_fn, my_frames, dist, device, post_step=None):
+    """run(n, offset): n steps over this rank's frames (wrapping around); returns the sum of the per-step scalars as a device
+    tensor.  The scalar all-reduce of step k is issued asynchronously (RCCL runs it on its own stream) and only waited for after
+    step k+1 has been enqueued, so its latency never idles the compute stream.  `step_fn(t) -> 0-d tensor`."""
+
+    def run(n, offset):
+        losses = []   # per-step device scalars; summed once at the end of the run (still inside the timed region)
+        pending = None
+        for i in range(n):
+            t = my_frames[(offset + i) % len(my_frames)]
+            l = step_fn(t)
+            if dist is not None:
+                buf = l.reshape(1).clone()
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)  # the one collective of the path: a scalar
+                if pending is not None:
+                    pending[0].wait()
+                    losses.append(pending[1][0])
+                pending = (work, buf)
+            else:
+                losses.append(l)
+            if post_step is not None:
+                post_step()
+        if pending is not None:
+            pending[0].wait()
+            losses.append(pending[1][0])
+        return torch.stack(losses).sum() if losses else torch.zeros((), device=device)
+
+    return run
+
+
+def timed_rounds(run, fence, steps, warmup, dist, device, min_rounds=3, min_seconds=0.5, max_rounds=64):
+    """The reference's timing protocol (fps_benchmark_demo.py:53-66: rounds of n iterations, FPS per round): W untimed warm-up
+    steps, then rounds of EXACTLY `steps` steps each, bracketed by barrier + device sync on both sides, the MAX over ranks
+    taken per round.  At least `min_rounds` rounds and at least `min_seconds` of timed work in total, whatever `steps` is (the
+    stopping rule reads the MAX-reduced times, so every rank runs the same number of rounds)."""
+    run(warmup, 0)
+    fence()
+    rounds, total, offset = [], 0.0, warmup
+    while len(rounds) < min_rounds or (total < min_seconds and len(rounds) < max_rounds):
+        t0 = time.perf_counter()
+        run(steps, offset)
+        fence()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            te = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        rounds.append(el)
+        total += el
+        offset += steps
+    return rounds
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,6 +240,8 @@ def main():
     ap.add_argument("--workload", choices=["cfg3", "cfg2", "cfg4", "cfg5", "train"], default="cfg3",
                     help="BASELINE.json configs: cfg3 = configs[2] fwd+bwd 100k (the metric, default); cfg2 = configs[1] forward; "
                          "cfg4 = configs[3] 200k-splat 300-frame sequence fwd+bwd; cfg5 = configs[4] 2M-splat 1600x1100 forward stress")
+    ap.add_argument("--rounds", type=int, default=3, help="minimum number of timed rounds of --steps steps each (the median round is reported)")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="minimum total timed duration: rounds are added until it is reached")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     args = ap.parse_args()
@@ -224,48 +287,21 @@ def main():
     target = torch.ones((3, args.height, args.width), dtype=torch.float32, device=device)
     my_frames = frames_for_rank(args.frames, rank, world)
 
-    def run(n, offset):
-        """n steps.  The scalar all-reduce of step k is issued asynchronously (RCCL runs it on its own stream)
-        and only waited for after step k+1 has been enqueued, so its latency never idles the compute stream."""
-        losses = []   # per-step device scalars; summed once at the end of the run (still inside the timed region)
-        pending = None
-        for i in range(n):
-            t = my_frames[(offset + i) % len(my_frames)]
-            with torch.set_grad_enabled(train):
-                l = one_step(g, cam, bg, target, t, train)
-            if dist is not None:
-                buf = l.reshape(1).clone()
-                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)  # the one collective of the path: a scalar
-                if pending is not None:
-                    pending[0].wait()
-                    losses.append(pending[1][0])
-                pending = (work, buf)
-            else:
-                losses.append(l)
-            if train:
-                zero_grads(g)
-        if pending is not None:
-            pending[0].wait()
-            losses.append(pending[1][0])
-        return torch.stack(losses).sum() if losses else torch.zeros((), device=device)
+    def step_fn(t):
+        with torch.set_grad_enabled(train):
+            return one_step(g, cam, bg, target, t, train)
+
+    run = make_runner(step_fn, my_frames, dist, device, post_step=(lambda: zero_grads(g)) if train else None)
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    run(args.warmup, 0)
-    fence()
     _lib.gsr_wait_stats()   # reset
-    t0 = time.perf_counter()
-    run(args.steps, args.warmup)
-    fence()
-    elapsed = time.perf_counter() - t0
+    rounds = timed_rounds(run, fence, args.steps, args.warmup, dist, device, min_rounds=args.rounds, min_seconds=args.min_seconds)
+    elapsed = float(np.median(rounds))   # the median round: exactly args.steps steps
     wait_ms, waits = _lib.gsr_wait_stats()
-    if dist is not None:
-        te = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
     info = R.last_forward_info()
 
     # ---- per-kernel durations: HIP events on the launch stream (recorded by the C ABI around every kernel).
@@ -283,46 +319,62 @@ def main():
 
     if rank == 0:
         N, HW = args.splats, args.width * args.height
-        I_binned = info.get("num_rendered", 0)
-        # the unit count of the algorithmic-bytes model is the reference's instance count (sum of tiles_touched); with
-        # tile culling on, fewer instances are actually binned (num_binned below)
-        I = info.get("rect_instances", I_binned)
+        I_binned = info.get("num_rendered", 0)            # instances actually binned (tile culling on: the culled lists)
+        I_rect = info.get("rect_instances", I_binned)     # the reference's count: sum of tiles_touched
         with torch.no_grad():
             vis = 1.0
         per_kernel = {k: dict(avg_us=1e3 * ms / max(n, 1), launches=n) for k, (ms, n) in kern.items() if n}
-        # algorithmic bytes per launch: SURVEY.md 8(d)'s per-unit figures x the units of one frame;
-        # v (visible fraction) = 1 for this scene (measured by the oracle leg below)
-        sort_bytes = 12 * I + 12 * I + 8 * I      # keys+idx written, one ideal sort pass read, range scan
-        algo = {
-            "k_preprocess": 236 * N + (44 + (27 if train else 0)) * N,
-            "k_scatter": 12 * I,
-            "k_tile_sort": sort_bytes - 12 * I,
-            "k_render": 40 * I + (12 + (8 if train else 0)) * HW,
-            "k_render_bwd": 20 * HW + 40 * I + 36 * N,
-            "k_preprocess_bwd": 300 * N + 256 * N,
-        }
-        pmc = {}
+        # Algorithmic bytes per launch: SURVEY.md 8(d)'s per-unit figures x the units of one frame; v (visible
+        # fraction) = 1 for this scene (measured by the oracle leg below).  The kernels downstream of the binning stream the CULLED
+        # instance lists, so their unit count is I_binned; the same figures with the reference's rect-based count are kept beside
+        # them (`algorithmic_bytes_rect_based`) -- those are what an implementation without tile culling would have to move.
+        def algo_for(I):
+            return {
+                "k_preprocess": 236 * N + (44 + (27 if train else 0)) * N,
+                "k_scatter": 12 * I,
+                "k_tile_sort": 12 * I + 8 * I,              # one ideal sort pass read + range scan (the 12 I key/idx write is k_scatter's)
+                "k_render": 40 * I + (12 + (8 if train else 0)) * HW,
+                "k_render_bwd": 20 * HW + 40 * I + 36 * N,
+                "k_preprocess_bwd": 300 * N + 256 * N,
+            }
+        algo, algo_rect = algo_for(I_binned), algo_for(I_rect)
+        # Coalesced-read component of each kernel (bytes per launch), for the PMC calibration rule of profiles/r02_pmc_calibration.json:
+        # FETCH_SIZE tallies 64 B per request; coalesced streams issue 128-byte requests (reported at half), per-lane gathers and
+        # scalar loads issue 64-byte ones (face value).  The blend kernels' 2-D tile accesses (32-128 B runs) lie between the
+        # calibrated patterns and are taken at face value (a lower bound); `traffic_bounds` brackets every kernel.
+        stream = {"k_preprocess": 236 * N, "k_count": 44 * N, "k_scatter": 48 * N, "k_tile_sort": 8 * I_binned, "k_render": 0,
+                  "k_render_bwd": 0, "k_preprocess_bwd": 300 * N + 48 * N}
+        pmc, pmc_raw = {}, {}
         pmc_tag = "cfg5" if args.workload == "cfg5" else ("cfg3" if args.workload in ("cfg3", "cfg2") else None)
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{pmc_tag}_pmc_fetch_write_per_launch.json"))) if pmc_tag else []
         pmc_path = cands[-1] if cands else ""   # the newest committed PMC summary of this workload
         if pmc_path:   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/README.md)
             for k, v in json.load(open(pmc_path)).items():
-                name = k.replace("void ", "").split("::")[-1].split("<")[0]   # the two k_tile_sort classes add up
-                # FETCH_SIZE/WRITE_SIZE are KB; gfx950 FETCH_SIZE counts half of a wide streaming read (MI355X_MICROARCH.md)
-                pmc[name] = pmc.get(name, 0) + int((2 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024)
+                name = k.replace("void ", "").split("::")[-1].split("<")[0]   # the k_tile_sort classes add up
+                f, w = pmc_raw.get(name, (0.0, 0.0))
+                pmc_raw[name] = (f + 1024.0 * v["FETCH_SIZE_KB_per_launch"], w + 1024.0 * v["WRITE_SIZE_KB_per_launch"])
+            for name, (f, w) in pmc_raw.items():
+                pmc[name] = int(f + min(f, 0.5 * stream.get(name, 0)) + w)
         roofline = None
         if per_kernel:
             dom = max((k for k in per_kernel if k in algo), key=lambda k: per_kernel[k]["avg_us"] * per_kernel[k]["launches"])
             ach = algo[dom] / (per_kernel[dom]["avg_us"] * 1e-6) / 1e9
+            notes = {"k_tile_sort": "bound by its sorting network (instruction issue) and the scattered record gathers of its epilogue, not by "
+                                    "streaming bandwidth; HBM fraction reported as asked",
+                     "k_render": "alpha-blend kernels are issue-bound (exp + per-wave instruction stream), HBM fraction reported as asked",
+                     "k_render_bwd": "alpha-blend kernels are issue-bound (exp + per-wave instruction stream), HBM fraction reported as asked"}
             roofline = dict(kernel=dom, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(ach / HBM_PEAK_GBS, 5), traffic=pmc.get(dom),
-                            algorithmic_bytes_per_launch=int(algo[dom]), avg_launch_us=round(per_kernel[dom]["avg_us"], 2),
-                            note=("the tile sort is bound by its sorting network (instruction issue) and by the scattered 48-byte record gathers of "
-                                  "its epilogue, not by streaming bandwidth; HBM fraction reported as asked" if dom == "k_tile_sort" else
-                                  "alpha-blend kernels are VALU-bound (exp + per-wave instruction stream), HBM fraction reported as asked"),
+                            traffic_bounds=[int(sum(pmc_raw[dom])), int(2 * pmc_raw[dom][0] + pmc_raw[dom][1])] if dom in pmc_raw else None,
+                            traffic_source=os.path.basename(pmc_path) if pmc_path else None,
+                            algorithmic_bytes_per_launch=int(algo[dom]), algorithmic_bytes_rect_based=int(algo_rect[dom]),
+                            instances=dict(binned=int(I_binned), rect_based=int(I_rect)),
+                            avg_launch_us=round(per_kernel[dom]["avg_us"], 2), note=notes.get(dom, "HBM-bound streaming kernel"),
                             all_kernels={k: dict(avg_us=round(v["avg_us"], 2),
-                                                 algo_GBs=round(algo[k] / (v["avg_us"] * 1e-6) / 1e9, 1) if k in algo else None)
+                                                 algo_GBs=round(algo[k] / (v["avg_us"] * 1e-6) / 1e9, 1) if k in algo else None,
+                                                 frac=round(algo[k] / (v["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if k in algo else None,
+                                                 traffic=pmc.get(k))
                                          for k, v in per_kernel.items()})
         cpu = None
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only
@@ -330,6 +382,7 @@ def main():
             cpu, I_cpu, vis_cpu = cpu_baseline(g, cam, bg, train)
             vis = vis_cpu / N
         fps = n_gpus * args.steps / elapsed
+        counts = [len(frames_for_rank(args.frames, r, world)) for r in range(world)]
         out = {
             "metric": ("frames/sec fwd+bwd" if train else "frames/sec fwd") + (" (L1+SSIM loss, densification stats)" if SSIM_STEP else "") +
                       " @%dk SH-3 splats %dx%d" % (N // 1000, args.height, args.width),
@@ -355,10 +408,15 @@ def main():
                                       "target, backward, densification statistics; no optimiser step"}[
                                  args.workload] % (N, args.height, args.width),
                 "splats": N, "width": args.width, "height": args.height, "sh_degree": 3,
-                "num_rendered": I, "num_binned": I_binned, "tile_culling": bool(info.get("tile_culling", False)),
+                "num_rendered": I_rect, "num_binned": I_binned, "tile_culling": bool(info.get("tile_culling", False)),
                 "visible_fraction": round(vis, 4), "binding": args.binding,
-                "parallelism": f"frame-parallel x{n_gpus}, scalar loss all-reduce",
+                "parallelism": (f"frame-parallel x{n_gpus}: {dist.get_world_size() if dist is not None else 1} "
+                                f"{'RCCL (torch nccl)' if dist is not None else 'single-process'} rank(s), frames per rank {counts}, "
+                                "one asynchronous scalar all-reduce (loss) per step"),
             },
+            # every timed round is exactly `steps` steps (barrier + device sync on both sides, MAX over ranks); value = median round
+            "rounds": {"n": len(rounds), "frames_per_s": [round(n_gpus * args.steps / r, 2) for r in rounds],
+                       "timed_seconds": round(float(sum(rounds)), 4)},
             "roofline": roofline,
             "cpu_baseline": cpu,
             # the frame's single host wait (for the instance count): ~0 would mean the host paces the loop, not the GPU

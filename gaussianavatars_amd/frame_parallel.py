@@ -103,49 +103,138 @@ def allreduce_scalar(value: torch.Tensor, op: str = "sum") -> torch.Tensor:
     return value
 
 
-def run_frames(step_fn, num_frames: int, rank: int, world_size: int):
+def _collective_device(device=None) -> torch.device:
+    """Where a rank's collective buffers must live: the rank's GPU under nccl/RCCL (a CPU tensor there fails on this rank
+    while the others block in the collective), the host under gloo."""
+    import torch.distributed as dist
+
+    if device is not None:
+        return torch.device(device)
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def run_frames(step_fn, num_frames: int, rank: int, world_size: int, device=None):
     """Calls step_fn(t) -> scalar tensor for every frame of this rank and returns the all-reduced sum
-    together with the global frame count (every rank gets the same pair)."""
+    together with the global frame count (every rank gets the same pair).  A rank that owns no frame (num_frames <
+    world_size) still takes part in both collectives, with zeros on its own device."""
     mine = frames_for_rank(num_frames, rank, world_size)
-    acc = None
+    dev = _collective_device(device)
+    acc = torch.zeros((), dtype=torch.float32, device=dev)
     for t in mine:
-        v = step_fn(t).detach().reshape(())
-        acc = v.clone() if acc is None else acc + v
-    if acc is None:
-        acc = torch.zeros(())
-    count = torch.tensor(float(len(mine)), device=acc.device)
+        acc = acc + step_fn(t).detach().reshape(()).to(device=dev, dtype=torch.float32)
+    count = torch.tensor(float(len(mine)), device=dev)
     allreduce_scalar(acc)
     allreduce_scalar(count)
     return acc, int(count.item())
 
 
-def allreduce_gradients(params, average: bool = True, bucket_bytes: int = 64 << 20) -> None:
+def replica_fingerprint(tensors) -> torch.Tensor:
+    """A few integers that must agree on every rank before gradients are exchanged: number of tensors, total element count,
+    a shape hash, and the checksum of every integer tensor (the `binding` of a mesh-bound model)."""
+    n, total, h, chk = 0, 0, 0, 0
+    for t in tensors:
+        if t is None:
+            continue
+        n += 1
+        total += t.numel()
+        for d in t.shape:
+            h = (h * 1000003 + int(d) + 1) % 2147483629
+        h = (h * 1000003 + 7) % 2147483629
+        if not t.is_floating_point():
+            chk = (chk + int(t.detach().long().sum().item())) % 2147483629
+    return torch.tensor([n, total % 2147483629, h, chk], dtype=torch.int64)
+
+
+def check_replica_consistency(tensors, device=None) -> None:
+    """Raises on every rank if the replicas differ in shape (one rank densified differently) -- BEFORE an all-reduce over
+    mismatched buffers corrupts gradients or hangs."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    fp = replica_fingerprint(tensors).to(_collective_device(device))
+    lo, hi = fp.clone(), fp.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if not torch.equal(lo, hi):
+        raise RuntimeError(f"replicas diverged: rank {dist.get_rank()} holds fingerprint {fp.tolist()}, ranks span {lo.tolist()} .. {hi.tolist()} "
+                           "(tensor count, elements, shape hash, integer checksum)")
+
+
+def sync_densification_stats(model) -> None:
+    """Rank-consistent densification.  The reference decides clone / split / prune from statistics each
+    process accumulates over the frames IT rendered (scene/gaussian_model.py:426-519: xyz_gradient_accum / denom /
+    max_radii2D); replicas that see different frames would diverge at the first densify_and_prune.  Summing the two
+    accumulators and taking the maximum of the radii over all ranks right before that call gives every rank the statistics of
+    the whole frame set, hence identical decisions (together with seed_all_ranks for the split sampling)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    dist.all_reduce(model.xyz_gradient_accum, op=dist.ReduceOp.SUM)
+    dist.all_reduce(model.denom, op=dist.ReduceOp.SUM)
+    dist.all_reduce(model.max_radii2D, op=dist.ReduceOp.MAX)
+
+
+def seed_all_ranks(iteration: int, base_seed: int = 0) -> int:
+    """The same RNG state on every rank for the sampling inside densify_and_split (scene/gaussian_model.py:462-466
+    draws torch.normal): a function of the iteration only.  Returns the seed."""
+    seed = (int(base_seed) * 1000003 + int(iteration)) % (2 ** 31 - 1)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    return seed
+
+
+def allreduce_gradients(params, average: bool = True, bucket_bytes: int = 64 << 20, method: str = "allreduce", check: bool = True) -> None:
     """Data-parallel training on top of frame-parallel rendering: sums (or averages) the
     `.grad` of the given leaf tensors over all ranks.  Gradients are packed into flat buckets so that 100k
     splats (236 B each, ~24 MB) travel as ONE collective: xGMI is point-to-point (7 links x ~153 GB/s per GPU),
-    so a few large all-reduces amortise the per-collective latency that dozens of per-tensor calls would pay.
-    Ranks must hold identical parameter shapes (replicated splats, consistent densification)."""
+    so a few large collectives amortise the per-collective latency that dozens of per-tensor calls would pay.
+
+    method="reduce_scatter": every bucket goes through reduce-scatter + all-gather (each rank reduces 1/N of the bucket, all
+    7 links of every GPU carry traffic in both phases) instead of one all-reduce; same result.
+    A parameter whose .grad is None on this rank (it rendered no frame touching it) contributes zeros, so every rank builds
+    the same bucket layout; with `check`, the replicas' shapes are compared first (check_replica_consistency)."""
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
     world = dist.get_world_size()
-    grads = [p.grad for p in params if p is not None and p.grad is not None]
+    params = [p for p in params if p is not None]
+    if check:
+        check_replica_consistency(params)
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    grads = [p.grad for p in params]
     bucket, size = [], 0
 
     def flush():
         nonlocal bucket, size
         if not bucket:
             return
-        flat = torch.cat([g.reshape(-1) for g in bucket])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        if average:
-            flat /= world
+        n = sum(g.numel() for g in bucket)
+        if method == "reduce_scatter":
+            pad = (-n) % world
+            flat = torch.cat([g.reshape(-1) for g in bucket] + ([bucket[0].new_zeros(pad)] if pad else []))
+            shard = torch.empty(flat.numel() // world, dtype=flat.dtype, device=flat.device)
+            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
+            if average:
+                shard /= world
+            dist.all_gather_into_tensor(flat, shard)
+        else:
+            flat = torch.cat([g.reshape(-1) for g in bucket])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            if average:
+                flat /= world
         off = 0
         for g in bucket:
-            n = g.numel()
-            g.copy_(flat[off: off + n].view_as(g))
-            off += n
+            k = g.numel()
+            g.copy_(flat[off: off + k].view_as(g))
+            off += k
         bucket, size = [], 0
 
     for g in grads:

@@ -27,6 +27,13 @@ def _check(rc, what):
         raise RuntimeError(f"{what} failed ({rc}): {_lib.gls_error()}")
 
 
+def _launch(dev, what, fn, *args):
+    """One native call with `dev` as the current device (the stream argument belongs to it: with several GPUs in one process
+    a launch against another device's stream is an invalid-handle error, or lands on the wrong GPU)."""
+    with _lib.on_device(dev):
+        _check(fn(*args), what)
+
+
 def _as_input(t: torch.Tensor, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be a device tensor (the HIP kernels are the only implementation)")
@@ -47,8 +54,8 @@ class _L1Ssim(torch.autograd.Function):
         sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
         partial = torch.empty(int(lib.gls_partial_floats(B, Cc, H, W)), dtype=torch.float32, device=dev)
         maps = torch.empty((3, B, Cc, H, W), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
-        _check(lib.gls_l1_ssim_forward(B, Cc, H, W, _p(img1), _p(img2), 1.0 / float(Cc * H * W), _p(sums), _p(maps), _p(partial),
-                                       _stream(dev)), "gls_l1_ssim_forward")
+        _launch(dev, "gls_l1_ssim_forward", lib.gls_l1_ssim_forward, B, Cc, H, W, _p(img1), _p(img2), 1.0 / float(Cc * H * W), _p(sums), _p(maps), _p(partial),
+                                       _stream(dev))
         if need:
             ctx.save_for_backward(img1, img2, maps)
         return sums
@@ -64,19 +71,16 @@ class _L1Ssim(torch.autograd.Function):
         d1 = d2 = None
         if ctx.needs_input_grad[0]:
             d1 = torch.empty_like(img1)
-            _check(lib.gls_l1_ssim_backward(B, Cc, H, W, _p(img1), _p(img2), _p(maps), _p(gs), scale, _p(d1), _stream(dev)),
-                   "gls_l1_ssim_backward")
+            _launch(dev, "gls_l1_ssim_backward", lib.gls_l1_ssim_backward, B, Cc, H, W, _p(img1), _p(img2), _p(maps), _p(gs), scale, _p(d1), _stream(dev))
         if ctx.needs_input_grad[1]:
             # both statistics are symmetric in their arguments: the gradient w.r.t. the second image is the gradient
             # w.r.t. the first of the swapped pair (rare: the ground truth is data)
             partial = torch.empty(int(lib.gls_partial_floats(B, Cc, H, W)), dtype=torch.float32, device=dev)
             sums = torch.empty((B, 2), dtype=torch.float32, device=dev)
             maps2 = torch.empty((3, B, Cc, H, W), dtype=torch.float32, device=dev)
-            _check(lib.gls_l1_ssim_forward(B, Cc, H, W, _p(img2), _p(img1), scale, _p(sums), _p(maps2), _p(partial), _stream(dev)),
-                   "gls_l1_ssim_forward")
+            _launch(dev, "gls_l1_ssim_forward", lib.gls_l1_ssim_forward, B, Cc, H, W, _p(img2), _p(img1), scale, _p(sums), _p(maps2), _p(partial), _stream(dev))
             d2 = torch.empty_like(img2)
-            _check(lib.gls_l1_ssim_backward(B, Cc, H, W, _p(img2), _p(img1), _p(maps2), _p(gs), scale, _p(d2), _stream(dev)),
-                   "gls_l1_ssim_backward")
+            _launch(dev, "gls_l1_ssim_backward", lib.gls_l1_ssim_backward, B, Cc, H, W, _p(img2), _p(img1), _p(maps2), _p(gs), scale, _p(d2), _stream(dev))
         return d1, d2
 
 
@@ -118,7 +122,7 @@ class _L1(torch.autograd.Function):
         n = a.numel()
         out = torch.empty((), dtype=torch.float32, device=dev)
         partial = torch.empty(int(lib.gls_partial_floats(1, 1, 1, 1)), dtype=torch.float32, device=dev)
-        _check(lib.gls_l1_forward(n, _p(a), _p(b), 1.0 / float(max(n, 1)), _p(out), _p(partial), _stream(dev)), "gls_l1_forward")
+        _launch(dev, "gls_l1_forward", lib.gls_l1_forward, n, _p(a), _p(b), 1.0 / float(max(n, 1)), _p(out), _p(partial), _stream(dev))
         ctx.save_for_backward(a, b)
         return out
 
@@ -133,10 +137,10 @@ class _L1(torch.autograd.Function):
         da = db = None
         if ctx.needs_input_grad[0]:
             da = torch.empty_like(a)
-            _check(lib.gls_l1_backward(n, _p(a), _p(b), _p(gs), scale, _p(da), _stream(dev)), "gls_l1_backward")
+            _launch(dev, "gls_l1_backward", lib.gls_l1_backward, n, _p(a), _p(b), _p(gs), scale, _p(da), _stream(dev))
         if ctx.needs_input_grad[1]:
             db = torch.empty_like(b)
-            _check(lib.gls_l1_backward(n, _p(b), _p(a), _p(gs), scale, _p(db), _stream(dev)), "gls_l1_backward")
+            _launch(dev, "gls_l1_backward", lib.gls_l1_backward, n, _p(b), _p(a), _p(gs), scale, _p(db), _stream(dev))
         return da, db
 
 
@@ -162,5 +166,6 @@ def densification_stats(radii: torch.Tensor, viewspace_grad: torch.Tensor, max_r
     if tuple(viewspace_grad.shape) != (P, 3) or viewspace_grad.dtype != torch.float32:
         raise ValueError("viewspace_grad must be (P,3) float32")
     vg = viewspace_grad.contiguous()
-    _check(_lib.gls().gls_densification_stats(P, _p(radii.contiguous()), _p(vg), _p(max_radii2D), _p(xyz_gradient_accum), _p(denom),
-                                              _stream(radii.device)), "gls_densification_stats")
+    dev = radii.device
+    _launch(dev, "gls_densification_stats", _lib.gls().gls_densification_stats, P, _p(radii.contiguous()), _p(vg), _p(max_radii2D), _p(xyz_gradient_accum), _p(denom),
+                                              _stream(radii.device))

@@ -331,22 +331,61 @@ int64_t ora_scan(int P, const uint32_t* tiles_touched, uint32_t* offsets)
     return P > 0 ? (int64_t)offsets[P - 1] : 0;
 }
 
-static void radix_sort_pairs(uint64_t* keys, uint32_t* vals, uint64_t* tk, uint32_t* tv, int64_t n, int bits)
+/* Stable sort of the (key, value) pairs by key = tile << 32 | depth bits -- what one stable radix sort over the low
+ * 32 + bits(tiles) key bits produces (A.2) -- organised so that the host cores can share it: one stable counting-sort pass
+ * by tile (serial; the order inside a tile stays the emission order, i.e. ascending splat index), then every tile's segment is
+ * sorted on its own by the 32 depth bits with a stable LSD radix (8 bits a pass; short segments by stable insertion), OpenMP
+ * over tiles. */
+static void sort_segment(uint64_t* k, uint32_t* v, uint64_t* tk, uint32_t* tv, int64_t n)
 {
-    /* stable LSD radix sort, 8 bits a pass, over the low `bits` bits */
-    for (int shift = 0; shift < bits; shift += 8) {
+    if (n < 48) {
+        for (int64_t i = 1; i < n; ++i) {
+            const uint64_t kk = k[i];
+            const uint32_t vv = v[i];
+            int64_t j = i - 1;
+            while (j >= 0 && (uint32_t)k[j] > (uint32_t)kk) { k[j + 1] = k[j]; v[j + 1] = v[j]; --j; }
+            k[j + 1] = kk;
+            v[j + 1] = vv;
+        }
+        return;
+    }
+    uint64_t *sk = k, *dk = tk;
+    uint32_t *sv = v, *dv = tv;
+    for (int shift = 0; shift < 32; shift += 8) {
         int64_t cnt[257];
         memset(cnt, 0, sizeof(cnt));
-        for (int64_t i = 0; i < n; ++i) cnt[((keys[i] >> shift) & 0xFF) + 1]++;
+        for (int64_t i = 0; i < n; ++i) cnt[((sk[i] >> shift) & 0xFF) + 1]++;
         for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
         for (int64_t i = 0; i < n; ++i) {
-            int64_t dst = cnt[(keys[i] >> shift) & 0xFF]++;
-            tk[dst] = keys[i];
-            tv[dst] = vals[i];
+            const int64_t dst = cnt[(sk[i] >> shift) & 0xFF]++;
+            dk[dst] = sk[i];
+            dv[dst] = sv[i];
         }
-        memcpy(keys, tk, (size_t)n * sizeof(uint64_t));
-        memcpy(vals, tv, (size_t)n * sizeof(uint32_t));
+        uint64_t* t1 = sk; sk = dk; dk = t1;
+        uint32_t* t2 = sv; sv = dv; dv = t2;
     }
+    /* four passes: the result is back in (k, v) */
+}
+
+static void sort_pairs_by_tile_then_depth(uint64_t* keys, uint32_t* vals, uint64_t* tk, uint32_t* tv, int64_t n, int tiles)
+{
+    int64_t* start = (int64_t*)calloc((size_t)tiles + 1, sizeof(int64_t));
+    for (int64_t i = 0; i < n; ++i) start[(keys[i] >> 32) + 1]++;
+    for (int t = 0; t < tiles; ++t) start[t + 1] += start[t];
+    int64_t* cur = (int64_t*)malloc((size_t)tiles * sizeof(int64_t));
+    memcpy(cur, start, (size_t)tiles * sizeof(int64_t));
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t dst = cur[keys[i] >> 32]++;
+        tk[dst] = keys[i];
+        tv[dst] = vals[i];
+    }
+    memcpy(keys, tk, (size_t)n * sizeof(uint64_t));
+    memcpy(vals, tv, (size_t)n * sizeof(uint32_t));
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int t = 0; t < tiles; ++t)
+        sort_segment(keys + start[t], vals + start[t], tk + start[t], tv + start[t], start[t + 1] - start[t]);
+    free(cur);
+    free(start);
 }
 
 /* keys[I], vals[I] come back sorted; ranges[2*tiles] */
@@ -355,6 +394,7 @@ void ora_bin(const OraSettings* s, int P, const float* depths, const int32_t* ra
 {
     const int W = s->image_width, H = s->image_height;
     const int gx = (W + ORA_BLOCK_X - 1) / ORA_BLOCK_X, gy = (H + ORA_BLOCK_Y - 1) / ORA_BLOCK_Y;
+#pragma omp parallel for schedule(dynamic, 256)   /* every splat writes its own [offsets[i-1], offsets[i]) */
     for (int i = 0; i < P; ++i) {
         if (radii[i] > 0) {
             uint32_t off = (i == 0) ? 0 : offsets[i - 1];
@@ -372,11 +412,9 @@ void ora_bin(const OraSettings* s, int P, const float* depths, const int32_t* ra
         }
     }
     int tiles = gx * gy;
-    int bit = 0;
-    while ((1 << bit) < tiles && bit < 31) bit++; /* msb(tiles) style: enough bits for any tile id */
     uint64_t* tk = (uint64_t*)malloc((size_t)(I > 0 ? I : 1) * sizeof(uint64_t));
     uint32_t* tv = (uint32_t*)malloc((size_t)(I > 0 ? I : 1) * sizeof(uint32_t));
-    radix_sort_pairs(keys, vals, tk, tv, I, 32 + bit + 1);
+    sort_pairs_by_tile_then_depth(keys, vals, tk, tv, I, tiles);
     free(tk);
     free(tv);
     memset(ranges, 0, (size_t)tiles * 2 * sizeof(uint32_t));

@@ -42,6 +42,55 @@ def _worker(rank, world, port, out):
     a.grad, b.grad = torch.full((5, 3), float(rank + 1)), torch.arange(7.0) * (rank + 1)
     fp.allreduce_gradients([a, b], average=True, bucket_bytes=32)
     assert torch.allclose(a.grad, torch.full((5, 3), 1.5)) and torch.allclose(b.grad, torch.arange(7.0) * 1.5)
+    # reduce-scatter + all-gather form (element count not a multiple of the world size: padded), and a parameter without a
+    # gradient on one rank (it contributes zeros; both ranks build the same bucket layout)
+    c, d = torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(4))
+    c.grad = torch.full((5, 3), float(rank + 1))
+    if rank == 0:
+        d.grad = torch.arange(4.0)
+    fp.allreduce_gradients([c, d], average=False, method="reduce_scatter")
+    assert torch.allclose(c.grad, torch.full((5, 3), 3.0)) and torch.allclose(d.grad, torch.arange(4.0))
+    # a rank that owns no frame still takes part in the collectives (its accumulator lives on its own device)
+    t1, n1 = fp.run_frames(lambda t: torch.tensor(5.0), 1, r, w)
+    assert float(t1) == 5.0 and n1 == 1
+    # replicas that diverged (one rank densified differently) are detected before gradients are exchanged
+    fp.check_replica_consistency([a, b, torch.arange(6)])
+    try:
+        fp.check_replica_consistency([torch.zeros(5 + rank, 3)])
+        diverged = False
+    except RuntimeError as e:
+        diverged = "replicas diverged" in str(e)
+    assert diverged
+    # rank-consistent densification statistics + RNG
+    class M:
+        pass
+    m = M()
+    m.xyz_gradient_accum, m.denom, m.max_radii2D = torch.full((4, 1), float(rank + 1)), torch.full((4, 1), 1.0), torch.tensor([1.0, 5.0, 2.0, 0.0]) * (rank + 1)
+    fp.sync_densification_stats(m)
+    assert torch.equal(m.xyz_gradient_accum, torch.full((4, 1), 3.0)) and torch.equal(m.denom, torch.full((4, 1), 2.0))
+    assert torch.equal(m.max_radii2D, torch.tensor([2.0, 10.0, 4.0, 0.0]))
+    fp.seed_all_ranks(1234)
+    draw = torch.rand(3)
+    both = [torch.zeros(3) for _ in range(w)]
+    dist.all_gather(both, draw)
+    assert torch.equal(both[0], both[1])
+    # bench.py's frame loop: asynchronous scalar all-reduce ordering, frame wrap-around, MAX-reduced round times
+    import bench
+    mine = fp.frames_for_rank(7, r, w)                      # rank 0: 0 2 4 6, rank 1: 1 3 5
+    seen = []
+    def step(t):
+        seen.append(t)
+        return torch.tensor(float(t))
+    run = bench.make_runner(step, mine, dist, torch.device("cpu"), post_step=None)
+    total5 = run(5, 2)                                      # 5 steps starting at offset 2: wraps around this rank's list
+    exp0 = [[0, 2, 4, 6][(2 + i) % 4] for i in range(5)]
+    exp1 = [[1, 3, 5][(2 + i) % 3] for i in range(5)]
+    assert seen == (exp0 if r == 0 else exp1)
+    assert float(total5) == float(sum(exp0) + sum(exp1))    # every step's scalar was all-reduced exactly once
+    rounds = bench.timed_rounds(run, lambda: dist.barrier(), 3, 1, dist, torch.device("cpu"), min_rounds=2, min_seconds=0.0)
+    both_r = [None, None]
+    dist.all_gather_object(both_r, rounds)
+    assert len(rounds) == 2 and both_r[0] == both_r[1]      # MAX over ranks: identical on every rank
     out.put((rank, float(total), count, float(one)))
     dist.barrier()
     dist.destroy_process_group()
