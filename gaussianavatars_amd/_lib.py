@@ -41,7 +41,9 @@ def on_device(dev):
     if dev.index is None or torch.cuda.current_device() == dev.index:
         return _NOCTX
     return torch.cuda.device(dev)
-GSR_LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+# GSR_LIB overrides the library file (kernel experiments build variants side by side: tools/exp_build.sh); the product default is
+# the in-tree build.  An override that does not exist is an error, never a fallback.
+GSR_LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr_hip.so")
 
 GSR_OK = 0
 GSR_ABI_VERSION = 2
