@@ -72,12 +72,14 @@ class GsrSettings(C.Structure):
 
 class GsrGeomLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
-                ("depths", "grec", "cov3D", "rect", "tiles_touched", "clamped", "visible", "acc", "total")]
+                ("depths", "grec", "cov3D", "rect", "tiles_touched", "clamped", "visible", "brec", "acc", "total")]
 
 
 class GsrBinningLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
-                ("keys", "point_list", "qlist", "qpos", "qcount", "ranges", "tile_count", "tile_start", "tile_cursor", "tile_order", "block_hist", "total")]
+                ("keys", "point_list", "qlist", "qpos", "qcount", "qstart", "ranges", "tile_count", "tile_start", "tile_cursor", "tile_order",
+                 "block_hist", "dkeys", "dtmp", "order", "bcount", "bstart", "bcursor", "border", "bhist", "qhist", "qprefix", "qmask", "path", "chunks", "nb",
+                 "total")]
 
 
 class GsrImageLayout(C.Structure):
@@ -89,7 +91,7 @@ GSR_SYMBOLS = {
     "gsr_abi_version": (C.c_int, []),
     "gsr_last_error": (C.c_char_p, []),
     "gsr_geom_layout": (C.c_int, [C.c_int32, C.POINTER(GsrGeomLayout)]),
-    "gsr_binning_layout": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(GsrBinningLayout)]),
+    "gsr_binning_layout": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GsrBinningLayout)]),
     "gsr_image_layout": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(GsrImageLayout)]),
     "gsr_forward": (C.c_int, [C.POINTER(GsrSettings), C.c_int32, C.c_int32] + [C.c_void_p] * 7 +
                     [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
@@ -109,7 +111,7 @@ GSR_SYMBOLS = {
     "gsr_kernel_name": (C.c_char_p, [C.c_int]),
     "gsr_wait_stats": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
-GSR_NUM_KERNELS = 8
+GSR_NUM_KERNELS = 12
 
 
 def gsr_profile_enable(on: bool) -> None:

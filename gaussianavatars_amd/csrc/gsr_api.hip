@@ -149,28 +149,68 @@ int gsr_geom_layout(int32_t P, GsrGeomLayout* o)
     o->tiles_touched = off; off = align_up(off + n * 4, A);
     o->clamped = off;       off = align_up(off + n, A);
     o->visible = off;       off = align_up(off + n, A);
+    o->brec = off;          off = align_up(off + n * 48, A);
     o->acc = off;           off = align_up(off + n * GSR_ACC_STRIDE * 4, A);
     o->total = off + A;
     return 0;
 }
 
-int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, GsrBinningLayout* o)
+// Production binning parameters for (P, grid): chunks of the ordered walk (one wave each, S = ceil(P / chunks) <= 255 splats so
+// that the per-quadrant counters of a chunk fit a byte) and depth buckets (about 512 splats each).  Returns false when the
+// depth-ordered scatter does not apply (then the per-tile sort path is used).
+static bool production_params(int32_t P, size_t tiles, int32_t tile_culling, size_t* chunks, size_t* nb)
 {
-    if (!o || capacity < 0 || width <= 0 || height <= 0) return fail(GSR_E_ARG, "gsr_binning_layout: bad arguments");
+    *chunks = 0; *nb = 0;
+    // below ~140 k splats the per-tile sort path is the faster one (its cost grows faster than linearly with the splat count: 169 us at
+    // 100 k, 403 us at 200 k against 195 / 323 us for the depth-ordered scatter on the same box)
+    if (tile_culling == 4 ? P <= 0 : (tile_culling != 1 || P < GSR_PRODUCTION_MIN_SPLATS)) return false;   // 4: whenever it applies (tests, A/B)
+    const size_t Q = 4 * tiles;
+    if (Q > 16384) return false;                                   // the scatter wave keeps a 4-byte cursor per quadrant in LDS: <= 64 KB
+    size_t c = ((size_t)P + 127) / 128;                           // ~128 splats per chunk: each of the chunk's 4 band waves walks them
+    c = c < 64 ? 64 : (c > 4096 ? 4096 : c);
+    if (((size_t)P + c - 1) / c > 255) return false;               // byte counters
+    if (c * Q * 4 > ((size_t)1 << 30)) return false;               // qprefix table
+    size_t b = 16;
+    while (b < 8192 && b * 512 < (size_t)P) b <<= 1;
+    *chunks = c; *nb = b;
+    return true;
+}
+
+int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, int32_t P, int32_t tile_culling, GsrBinningLayout* o)
+{
+    if (!o || capacity < 0 || width <= 0 || height <= 0 || P < 0) return fail(GSR_E_ARG, "gsr_binning_layout: bad arguments");
     const size_t tiles = (size_t)((width + GSR_BLOCK_X - 1) / GSR_BLOCK_X) * (size_t)((height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y);
-    const size_t cap = (size_t)capacity, A = 256;
-    size_t off = 256;  // header: [0] = uint64 instance count of this frame
-    o->keys = off;        off = align_up(off + cap * 8, A);
-    o->point_list = off;  off = align_up(off + cap * 4, A);
-    o->qlist = off;       off = align_up(off + cap * 4 * 4, A);
-    o->qpos = off;        off = align_up(off + cap * 4 * 4, A);
+    const size_t cap = (size_t)capacity, A = 256, n = (size_t)P;
+    size_t chunks, nb;
+    const bool prod = production_params(P, tiles, tile_culling, &chunks, &nb);
+    const size_t Q = 4 * tiles, qw = (Q + 3) / 4;
+    size_t off = align_up(sizeof(gsr::BinHeader), A);  // header + statistics slots (gsr_device.h: BinHeader)
+    o->keys = off;        off = align_up(off + (prod ? 0 : cap * 8), A);
+    o->point_list = off;  off = align_up(off + (prod ? 0 : cap * 4), A);
+    o->qlist = off;       off = align_up(off + (prod ? 0 : cap * 4 * 4), A);
+    o->qpos = off;        off = align_up(off + (prod ? cap * 4 : cap * 4 * 4), A);
     o->qcount = off;      off = align_up(off + tiles * 16, A);
-    o->ranges = off;      off = align_up(off + tiles * 8, A);
-    o->tile_count = off;  off = align_up(off + tiles * 4, A);
-    o->tile_start = off;  off = align_up(off + tiles * 4, A);
-    o->tile_cursor = off; off = align_up(off + tiles * 4, A);
+    o->qstart = off;      off = align_up(off + tiles * 16, A);
+    o->ranges = off;      off = align_up(off + (prod ? 0 : tiles * 8), A);
+    o->tile_count = off;  off = align_up(off + (prod ? 0 : tiles * 4), A);
+    o->tile_start = off;  off = align_up(off + (prod ? 0 : tiles * 4), A);
+    o->tile_cursor = off; off = align_up(off + (prod ? 0 : tiles * 4), A);
     o->tile_order = off;  off = align_up(off + tiles * 4, A);
-    o->block_hist = off;  off = align_up(off + (tiles > (size_t)GSR_LDS_HIST_TILES ? 0 : (size_t)GSR_BIN_BLOCKS * tiles * 4), A);
+    o->block_hist = off;  off = align_up(off + (prod || tiles > (size_t)GSR_LDS_HIST_TILES ? 0 : (size_t)GSR_BIN_BLOCKS * tiles * 4), A);
+    o->dkeys = off;       off = align_up(off + (prod ? n * 8 : 0), A);
+    o->dtmp = off;        off = align_up(off + (prod ? n * 8 : 0), A);
+    o->order = off;       off = align_up(off + (prod ? n * 4 : 0), A);
+    o->bcount = off;      off = align_up(off + (prod ? nb * 4 : 0), A);
+    o->bstart = off;      off = align_up(off + (prod ? nb * 4 : 0), A);
+    o->bcursor = off;     off = align_up(off + (prod ? nb * 4 : 0), A);
+    o->border = off;      off = align_up(off + (prod ? nb * 4 : 0), A);
+    o->bhist = off;       off = align_up(off + (prod ? (size_t)GSR_BIN_BLOCKS * nb * 4 : 0), A);
+    o->qhist = off;       off = align_up(off + (prod ? chunks * qw * 4 : 0), A);
+    o->qprefix = off;     off = align_up(off + (prod ? chunks * Q * 4 : 0), A);
+    o->qmask = off;       off = align_up(off + (prod ? n * GSR_WALK_MASKS * 8 : 0), A);
+    o->path = prod ? 1 : 0;
+    o->chunks = chunks;
+    o->nb = nb;
     o->total = off + A;
     return 0;
 }
@@ -224,17 +264,21 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     GsrBinningLayout bl;
     GsrImageLayout il;
     gsr_geom_layout(P, &gl);
-    gsr_binning_layout(binning_capacity, W, H, &bl);
+    gsr_binning_layout(binning_capacity, W, H, P, settings->tile_culling, &bl);
     gsr_image_layout(W, H, &il);
     char* g = (char*)geom;
     char* b = (char*)binning;
     char* im = (char*)img;
     unsigned long long* total_dev = (unsigned long long*)b;
+    gsr::BinHeader* hdr = (gsr::BinHeader*)b;
     uint32_t* tile_count = (uint32_t*)(b + bl.tile_count);
     unsigned long long* rect_total = total_dev + 1;   // header word 1: sum of tiles_touched (the reference's num_rendered)
+    const bool prod = bl.path == 1;                   // depth-ordered scatter into the quadrant streams (gsr_binning.hip)
 
     gsr::Settings ds = to_dev_settings(settings);
-    if (P == 0) {   // otherwise k_preprocess zeroes both
+    if (prod) {
+        HIP_TRY(hipMemsetAsync(hdr, 0, sizeof(gsr::BinHeader), stream));   // k_preprocess accumulates the frame statistics into it
+    } else if (P == 0) {   // otherwise k_preprocess zeroes both
         HIP_TRY(hipMemsetAsync(tile_count, 0, (size_t)tiles * 4, stream));
         HIP_TRY(hipMemsetAsync(rect_total, 0, 8, stream));
     }
@@ -255,6 +299,10 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     pa.tile_count = tile_count;
     pa.rect_total = rect_total;
     pa.tiles = tiles;
+    pa.brec = prod ? (float4*)(g + gl.brec) : nullptr;
+    pa.hdr = hdr;
+    pa.bcount = (uint32_t*)(b + bl.bcount);
+    pa.nb = (int)bl.nb;
     const int pblocks = (P + 255) / 256;
     if (pblocks > 0) {
         TIMED(GSR_K_PREPROCESS, stream);
@@ -262,6 +310,76 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
         KERNEL_CHECK("k_preprocess", stream, dbg);
     }
 
+    const unsigned long long seq = (g_mail.seq.fetch_add(1) % 0xFFFFFEull) + 1;  // 1 .. 2^24-2, never 0
+    volatile unsigned long long* slot = g_mail.host + (seq % Mailbox::kSlots);
+    *slot = 0;
+    unsigned long long* slot_dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void**)&slot_dev, (void*)slot, 0));
+    const unsigned long long cap = (unsigned long long)binning_capacity;
+    uint32_t* tile_order = (uint32_t*)(b + bl.tile_order);
+    uint32_t* qpos = (uint32_t*)(b + bl.qpos);
+    uint32_t* qcount = (uint32_t*)(b + bl.qcount);
+    uint32_t* qstart = (uint32_t*)(b + bl.qstart);
+    const bool write_lists = settings->tile_culling == 0 || settings->tile_culling == 2;   // production (1, 3, 4): the sorted key / point lists are not materialised
+    uint32_t* qlist = (uint32_t*)(b + bl.qlist);
+
+    if (prod) {
+        // ---- production: sort the SPLATS by depth, then append them in that order to the quadrant streams ----------------
+        const uint32_t nb = (uint32_t)bl.nb, chunks = (uint32_t)bl.chunks;
+        const int Q = 4 * tiles;
+        uint32_t* bcount = (uint32_t*)(b + bl.bcount);
+        uint32_t* bstart = (uint32_t*)(b + bl.bstart);
+        uint32_t* bcursor = (uint32_t*)(b + bl.bcursor);
+        uint32_t* border = (uint32_t*)(b + bl.border);
+        unsigned long long* dkeys = (unsigned long long*)(b + bl.dkeys);
+        unsigned long long* dtmp = (unsigned long long*)(b + bl.dtmp);
+        uint32_t* order = (uint32_t*)(b + bl.order);
+        const uint32_t* brec_rect = (const uint32_t*)(g + gl.brec);
+        {
+            TIMED(GSR_K_DEPTH_SORT, stream);
+            const int dblocks = pblocks < GSR_BIN_BLOCKS ? pblocks : GSR_BIN_BLOCKS;
+            uint32_t* bhist = (uint32_t*)(b + bl.bhist);
+            hipLaunchKernelGGL(gsr::k_dbucket, dim3(dblocks), dim3(256), (size_t)nb * 4, stream, P, brec_rect, (const float*)pa.depths, hdr, nb,
+                               bcount, bhist);
+            hipLaunchKernelGGL(gsr::k_dscan, dim3(1), dim3(1024), 0, stream, nb, (const uint32_t*)bcount, bstart, bcursor, border, hdr);
+            hipLaunchKernelGGL(gsr::k_dscatter, dim3(dblocks), dim3(256), (size_t)nb * 4, stream, P, brec_rect, (const float*)pa.depths,
+                               (const gsr::BinHeader*)hdr, nb, (const uint32_t*)bstart, bcursor, dkeys, (const uint32_t*)bhist);
+            // one class: 2048 keys in registers per workgroup, heavier buckets (rare: the bucket map is linear in this frame's own depth
+            // range) by chunked sorts + merges in global memory; heaviest buckets first
+            hipLaunchKernelGGL((gsr::k_dsort<GSR_SORT_SMALL_KEYS, 256>), dim3(nb), dim3(256), 0, stream, 0u, 0xFFFFFFFFu,
+                               (const uint32_t*)border, (const uint32_t*)bcount, (const uint32_t*)bstart, dkeys, dtmp, order);
+            KERNEL_CHECK("depth sort", stream, dbg);
+        }
+        gsr::QBinArgs qa;
+        qa.Q = Q; qa.gx = gx; qa.chunks = chunks;
+        qa.qmask = (unsigned long long*)(b + bl.qmask);
+        qa.hdr = hdr; qa.brec = (const float4*)(g + gl.brec); qa.order = order;
+        qa.qhist = (uint32_t*)(b + bl.qhist); qa.qprefix = (const uint32_t*)(b + bl.qprefix); qa.qstart = qstart; qa.qpos = qpos;
+        qa.capacity = cap;
+        const size_t count_lds = (((size_t)Q + 3) / 4) * 4;   // byte counters, four to a word
+        const size_t walk_lds = (size_t)Q * 4;               // absolute cursors
+        if (walk_lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_qscatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds));
+        const int walk_blocks = (int)chunks;   // one workgroup per chunk, one wave per band
+        {
+            TIMED(GSR_K_QCOUNT, stream);
+            hipLaunchKernelGGL(gsr::k_qcount, dim3(walk_blocks), dim3(256), count_lds, stream, qa);
+            KERNEL_CHECK("k_qcount", stream, dbg);
+        }
+        {
+            TIMED(GSR_K_QSCAN, stream);
+            hipLaunchKernelGGL(gsr::k_qscan, dim3(((Q + 3) / 4 + 31) / 32), dim3(1024), 0, stream, Q, chunks, (const uint8_t*)(b + bl.qhist),
+                               (uint32_t*)(b + bl.qprefix), qcount);
+            hipLaunchKernelGGL(gsr::k_qscan_glob, dim3(1), dim3(1024), 0, stream, tiles, (const uint32_t*)qcount, qstart, tile_order, hdr,
+                               slot_dev, seq);
+            KERNEL_CHECK("k_qscan", stream, dbg);
+        }
+        {
+            TIMED(GSR_K_QSCATTER, stream);
+            hipLaunchKernelGGL(gsr::k_qscatter, dim3(walk_blocks), dim3(64), walk_lds, stream, qa);
+            KERNEL_CHECK("k_qscatter", stream, dbg);
+        }
+    } else {
     // binning workgroups: each owns a contiguous chunk of splats and an LDS histogram over the tiles
     const int bin_blocks = pblocks < GSR_BIN_BLOCKS ? pblocks : GSR_BIN_BLOCKS;
     uint32_t* block_hist = (uint32_t*)(b + bl.block_hist);
@@ -274,22 +392,14 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
         HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
     }
     const bool cull = settings->tile_culling != 0;
-    const bool write_lists = settings->tile_culling != 1;   // 1 = production: the sorted key / point lists are not materialised
     if (pblocks > 0) {
         TIMED(GSR_K_COUNT, stream);
         hipLaunchKernelGGL(cull ? gsr::k_count<true> : gsr::k_count<false>, dim3(bin_blocks), dim3(256), hist_bytes, stream, P, gx, tiles,
                            (const ushort4*)pa.rect, (const uint32_t*)pa.tiles_touched, (const float4*)pa.grec, tile_count, rect_total, block_hist);
         KERNEL_CHECK("k_count", stream, dbg);
     }
-
-    const unsigned long long seq = (g_mail.seq.fetch_add(1) % 0xFFFFFEull) + 1;  // 1 .. 2^24-2, never 0
-    volatile unsigned long long* slot = g_mail.host + (seq % Mailbox::kSlots);
-    *slot = 0;
-    unsigned long long* slot_dev = nullptr;
-    HIP_TRY(hipHostGetDevicePointer((void**)&slot_dev, (void*)slot, 0));
     uint32_t* tile_start = (uint32_t*)(b + bl.tile_start);
     uint32_t* tile_cursor = (uint32_t*)(b + bl.tile_cursor);
-    uint32_t* tile_order = (uint32_t*)(b + bl.tile_order);
     uint2* ranges = (uint2*)(b + bl.ranges);
     {
         TIMED(GSR_K_TILE_SCAN, stream);
@@ -301,12 +411,8 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     // Optimistic launch: the rest of the frame is enqueued against the caller's capacity before the
     // host knows I; every kernel re-checks *total_dev <= capacity on the device and does nothing
     // otherwise.  The host then waits only for the scan (early in the frame), not for the frame.
-    const unsigned long long cap = (unsigned long long)binning_capacity;
     unsigned long long* keys = (unsigned long long*)(b + bl.keys);
     uint32_t* point_list = (uint32_t*)(b + bl.point_list);
-    uint32_t* qlist = (uint32_t*)(b + bl.qlist);
-    uint32_t* qpos = (uint32_t*)(b + bl.qpos);
-    uint32_t* qcount = (uint32_t*)(b + bl.qcount);
     if (pblocks > 0) {
         TIMED(GSR_K_SCATTER, stream);
         hipLaunchKernelGGL(cull ? gsr::k_scatter<true> : gsr::k_scatter<false>, dim3(bin_blocks), dim3(256), hist_bytes, stream, P, gx, tiles,
@@ -321,7 +427,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
         TIMED(GSR_K_TILE_SORT, stream);
         auto sort_class = [&](auto kernel, int threads, uint32_t n_lo, uint32_t n_hi) {
             hipLaunchKernelGGL(kernel, dim3(tiles), dim3(threads), 0, stream, n_lo, n_hi, gx, (const uint32_t*)tile_order,
-                               (const uint32_t*)tile_count, (const uint32_t*)tile_start, keys, write_lists ? point_list : nullptr, write_lists ? qlist : nullptr, qpos, qcount,
+                               (const uint32_t*)tile_count, (const uint32_t*)tile_start, keys, write_lists ? point_list : nullptr, write_lists ? qlist : nullptr, qpos, qcount, qstart,
                                (const float4*)pa.grec, cap,
                                (const unsigned long long*)total_dev);
         };
@@ -330,9 +436,10 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
         sort_class(gsr::k_tile_sort<GSR_SORT_SMALL_KEYS, 256>, 256, 0u, (uint32_t)GSR_SORT_SMALL_KEYS);
         KERNEL_CHECK("k_tile_sort", stream, dbg);
     }
+    }   // per-tile sort path
     {
         TIMED(GSR_K_RENDER, stream);
-        hipLaunchKernelGGL(gsr::k_render, dim3(tiles), dim3(256), 0, stream, ds, (const uint32_t*)tile_order, (const uint2*)ranges,
+        hipLaunchKernelGGL(gsr::k_render, dim3(tiles), dim3(256), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
                            (const uint32_t*)qcount, (const float4*)pa.grec, (const uint32_t*)qpos, write_lists ? (const uint32_t*)qlist : nullptr, (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib),
                            (uint32_t*)(im + il.n_contrib_q), (float*)(im + il.c_final), (float4*)(im + il.ck), out_color, cap,
                            (const unsigned long long*)total_dev);
@@ -406,7 +513,7 @@ int gsr_backward_ex(const GsrSettings* settings, int32_t P, int32_t M, const flo
     GsrBinningLayout bl;
     GsrImageLayout il;
     gsr_geom_layout(P, &gl);
-    gsr_binning_layout(binning_capacity, W, H, &bl);
+    gsr_binning_layout(binning_capacity, W, H, P, settings->tile_culling, &bl);
     gsr_image_layout(W, H, &il);
     char* g = (char*)geom;
     const char* b = (const char*)binning;
@@ -416,7 +523,7 @@ int gsr_backward_ex(const GsrSettings* settings, int32_t P, int32_t M, const flo
     if (num_rendered > 0) {
         TIMED(GSR_K_RENDER_BWD, stream);
         hipLaunchKernelGGL(gsr::k_render_bwd, dim3(gx * gy * GSR_BWD_SEGMENTS), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order),
-                           (const uint2*)(b + bl.ranges), (const uint32_t*)(b + bl.qcount), (const float4*)(g + gl.grec), (const uint32_t*)(b + bl.qpos),
+                           (const uint32_t*)(b + bl.qstart), (const uint32_t*)(b + bl.qcount), (const float4*)(g + gl.grec), (const uint32_t*)(b + bl.qpos),
                            (const float*)(im + il.final_T), (const uint32_t*)(im + il.n_contrib_q), dL_dpix, grad_scratch,
                            (const float*)(im + il.c_final), (const float4*)(im + il.ck), gx * gy);
         KERNEL_CHECK("k_render_bwd", stream, dbg);
@@ -487,7 +594,8 @@ int gsr_wait_stats(double* total_wait_ms, int64_t* waits)
 const char* gsr_kernel_name(int id)
 {
     static const char* names[GSR_NUM_KERNELS] = {"k_preprocess", "k_tile_scan", "k_scatter", "k_tile_sort",
-                                                 "k_render", "k_render_bwd", "k_preprocess_bwd", "k_count"};
+                                                 "k_render", "k_render_bwd", "k_preprocess_bwd", "k_count",
+                                                 "k_depth_sort", "k_qcount", "k_qscan", "k_qscatter"};
     return (id >= 0 && id < GSR_NUM_KERNELS) ? names[id] : "?";
 }
 

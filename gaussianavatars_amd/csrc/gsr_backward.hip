@@ -67,7 +67,7 @@ __device__ __forceinline__ float row_sum(float v)
 __device__ unsigned long long gsr_dbg[4 * 16384];
 extern "C" int gsr_debug_read(unsigned long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gsr_dbg), (size_t)n * 8); }
 #endif
-__global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ qstart,
                                                      const uint32_t* __restrict__ qcount,
                                                      const float4* __restrict__ grec, const uint32_t* __restrict__ qpos,
                                                      const float* __restrict__ final_T,
@@ -97,10 +97,8 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
     const int nq = (int)qcount[4 * tile + wave];
     const int seg_lo = seg * GSR_BWD_SEGMENT;
     if (nq <= seg_lo) return;                    // the stream ends below this segment
-    const uint2 range = ranges[tile];
-    const uint32_t nt = range.y - range.x;
-    const float4* __restrict__ rec = grec;                                                   // the per-splat records (48 bytes each)
-    const uint32_t* __restrict__ qp = qpos + (size_t)4 * range.x + (size_t)wave * nt;       // this quadrant's stream of splat indices
+    const float4* __restrict__ rec = grec;                            // the per-splat records (48 bytes each)
+    const uint32_t* __restrict__ qp = qpos + qstart[4 * tile + wave];   // this quadrant's stream of splat indices
 
     const int pix_id = W * pyi + pxi;
     const size_t HW = (size_t)H * W;

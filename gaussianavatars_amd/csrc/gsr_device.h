@@ -177,21 +177,24 @@ __device__ __forceinline__ Reach reach_of(float px, float py, float A, float B, 
     return r;
 }
 // rectangle of pixel centres [x0, x0 + w] x [y0, y0 + h]
+// Q is convex with its minimum (0) at the splat centre, so over a rectangle that does not hold the centre the minimum sits on
+// an edge that FACES the centre: at most one vertical and one horizontal edge need the 1-D minimisation (the two others can
+// only give larger values).
 __device__ __forceinline__ bool rect_reach(const Reach& r, float x0, float y0, float w, float h)
 {
     if (r.mode) return r.mode == 1;
     const float a0 = r.px - (x0 + w), a1 = r.px - x0;   // dx range over the rectangle
     const float b0 = r.py - (y0 + h), b1 = r.py - y0;
-    if (a0 <= 0.f && a1 >= 0.f && b0 <= 0.f && b1 >= 0.f) return true;
-    auto edge_x = [&](float a) {   // dx = a fixed, dy in [b0,b1]
-        const float dy = fminf(fmaxf(r.nBiC * a, b0), b1);
-        return 0.5f * (r.A * a * a + 2.f * r.B * a * dy + r.C * dy * dy);
-    };
-    auto edge_y = [&](float b) {   // dy = b fixed, dx in [a0,a1]
-        const float dx = fminf(fmaxf(r.nBiA * b, a0), a1);
-        return 0.5f * (r.A * dx * dx + 2.f * r.B * dx * b + r.C * b * b);
-    };
-    const float mn = fminf(fminf(edge_x(a0), edge_x(a1)), fminf(edge_y(b0), edge_y(b1)));
+    const bool in_x = a0 <= 0.f && a1 >= 0.f, in_y = b0 <= 0.f && b1 >= 0.f;
+    if (in_x && in_y) return true;
+    const float a = a0 > 0.f ? a0 : a1;                  // the facing vertical edge (dx = a) when the centre is left / right of the rect
+    const float b = b0 > 0.f ? b0 : b1;                  // the facing horizontal edge (dy = b) when it is above / below
+    const float dyv = fminf(fmaxf(r.nBiC * a, b0), b1);  // dx = a fixed, dy in [b0, b1]
+    const float qv = 0.5f * (r.A * a * a + 2.f * r.B * a * dyv + r.C * dyv * dyv);
+    const float dxh = fminf(fmaxf(r.nBiA * b, a0), a1);  // dy = b fixed, dx in [a0, a1]
+    const float qh = 0.5f * (r.A * dxh * dxh + 2.f * r.B * dxh * b + r.C * b * b);
+    const float big = 3.0e38f;
+    const float mn = fminf(in_x ? big : qv, in_y ? big : qh);
     return mn * 0.999f - 1e-3f <= r.tau;
 }
 
@@ -304,7 +307,43 @@ __device__ __forceinline__ void sh_rows_store(const float* __restrict__ lds, flo
     }
 }
 
-// ---- kernel argument blocks and entry points (gsr_forward.hip / gsr_backward.hip) ----------------
+// ---- kernel argument blocks and entry points (gsr_forward.hip / gsr_backward.hip / gsr_binning.hip) ----------------
+#define GSR_STAT_SLOTS 32         // k_preprocess spreads its per-block statistics over this many 64-byte slots (one hot line would
+                                  // serialise ~1600 L2 atomics per frame); the first binning kernel folds them into the header
+struct BinStatSlot {              // 64 bytes
+    uint32_t nvis, dmin_inv, dmax_bits, pad0;
+    unsigned long long binned_tiles, rect_total;
+    uint32_t pad1[8];
+};
+struct BinHeader {              // first bytes of the binning buffer (include/gsr.h: GsrBinningLayout); 256 bytes + the slots
+    unsigned long long total;       // instances of this frame (tile instances / quadrant-stream entries)
+    unsigned long long rect_total;  // sum of tiles_touched: the reference's num_rendered
+    uint32_t nvis;                  // production: splats that are binned (non-empty snug rect)
+    uint32_t dmin_inv;              // production: ~(bits of the smallest binned depth)  (so that a zeroed slot is +inf)
+    uint32_t dmax_bits;             // production: bits of the largest binned depth
+    uint32_t dmin_bits;             // = ~dmin_inv
+    unsigned long long binned_tiles;// production: tile instances after snug-rect culling (what the per-tile sort path would bin)
+    uint32_t pad[54];
+    BinStatSlot slot[GSR_STAT_SLOTS];
+};
+static_assert(sizeof(BinHeader) == 256 + 64 * GSR_STAT_SLOTS, "header layout is part of include/gsr.h");
+
+#define GSR_PRODUCTION_MIN_SPLATS 140000   // splat count from which production mode takes the depth-ordered scatter (gsr_binning.hip)
+#define GSR_WALK_MASKS 2           // saved hit masks per splat (rounds of 64 quadrants): rects beyond 128 quadrants are tested again by the scatter pass
+struct QBinArgs {               // k_qcount / k_qscatter
+    int Q, gx;                      // quadrants (4 * tiles), tile columns
+    uint32_t chunks;
+    BinHeader* __restrict__ hdr;
+    const float4* __restrict__ brec;
+    const uint32_t* __restrict__ order;
+    uint32_t* __restrict__ qhist;           // [chunks][ceil(Q/4)] words of 4 byte counters
+    const uint32_t* __restrict__ qprefix;   // [chunks][Q]
+    const uint32_t* __restrict__ qstart;
+    uint32_t* __restrict__ qpos;
+    unsigned long long* __restrict__ qmask; // [P][GSR_WALK_MASKS] hit masks of the counting pass (by position in order[]), replayed by the scatter
+    unsigned long long capacity;
+};
+
 struct PreprocessArgs {
     int P, M;
     const float* __restrict__ means3D;
@@ -327,6 +366,11 @@ struct PreprocessArgs {
     uint32_t* __restrict__ tile_count;    // [tiles] zeroed here (the binning histogram of this frame)
     unsigned long long* __restrict__ rect_total;   // zeroed here; k_count sums tiles_touched into it
     int tiles;
+    // production binning (gsr_binning.hip); brec == nullptr on the per-tile sort path
+    float4* __restrict__ brec;            // [P][3] binning record
+    BinHeader* __restrict__ hdr;          // zeroed by the API before this kernel; statistics accumulated here
+    uint32_t* __restrict__ bcount;        // [nb] depth-bucket histogram, zeroed here
+    int nb;
 };
 
 struct PreBwdArgs {
@@ -364,16 +408,29 @@ __global__ void k_scatter(int P, int gx, int tiles, const float* depths, const u
                           unsigned long long capacity, const unsigned long long* total_dev, const uint32_t* block_hist);
 template <int KEYS, int THREADS>
 __global__ void k_tile_sort(uint32_t n_lo, uint32_t n_hi, int gx, const uint32_t* tile_order, const uint32_t* tile_count, const uint32_t* tile_start, unsigned long long* keys,
-                            uint32_t* point_list, uint32_t* qlist, uint32_t* qpos, uint32_t* qcount, const float4* grec,
+                            uint32_t* point_list, uint32_t* qlist, uint32_t* qpos, uint32_t* qcount, uint32_t* qstart, const float4* grec,
                             unsigned long long capacity, const unsigned long long* total_dev);
-__global__ void k_render(Settings s, const uint32_t* tile_order, const uint2* ranges, const uint32_t* qcount, const float4* grec,
+__global__ void k_render(Settings s, const uint32_t* tile_order, const uint32_t* qstart, const uint32_t* qcount, const float4* grec,
                          const uint32_t* qpos, const uint32_t* qlist, float* final_T,
                          uint32_t* n_contrib, uint32_t* n_contrib_q, float* c_final, float4* ck, float* out_color, unsigned long long capacity,
                          const unsigned long long* total_dev);
 __global__ void k_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present);
-__global__ void k_render_bwd(Settings s, const uint32_t* tile_order, const uint2* ranges, const uint32_t* qcount, const float4* grec,
+__global__ void k_render_bwd(Settings s, const uint32_t* tile_order, const uint32_t* qstart, const uint32_t* qcount, const float4* grec,
                              const uint32_t* qpos, const float* final_T,
                              const uint32_t* n_contrib_q, const float* dL_dpix, float* acc, const float* c_final, const float4* ck, int tiles);
 __global__ void k_preprocess_bwd(Settings s, PreBwdArgs a);
+// production binning (gsr_binning.hip)
+__global__ void k_dbucket(int P, const uint32_t* brec_rect, const float* depths, BinHeader* hdr, uint32_t nb, uint32_t* bcount, uint32_t* bhist);
+__global__ void k_dscan(uint32_t nb, const uint32_t* bcount, uint32_t* bstart, uint32_t* bcursor, uint32_t* border, BinHeader* hdr);
+__global__ void k_dscatter(int P, const uint32_t* brec_rect, const float* depths, const BinHeader* hdr, uint32_t nb, const uint32_t* bstart,
+                           uint32_t* bcursor, unsigned long long* dkeys, const uint32_t* bhist);
+template <int KEYS, int THREADS>
+__global__ void k_dsort(uint32_t n_lo, uint32_t n_hi, const uint32_t* border, const uint32_t* bcount, const uint32_t* bstart,
+                        unsigned long long* dkeys, unsigned long long* tmp, uint32_t* order);
+__global__ void k_qcount(QBinArgs a);
+__global__ void k_qscatter(QBinArgs a);
+__global__ void k_qscan(int Q, uint32_t chunks, const uint8_t* qhist, uint32_t* qprefix, uint32_t* qcount);
+__global__ void k_qscan_glob(int tiles, const uint32_t* qcount, uint32_t* qstart, uint32_t* tile_order, BinHeader* hdr,
+                             unsigned long long* mailbox, unsigned long long seq);
 
 }  // namespace gsr

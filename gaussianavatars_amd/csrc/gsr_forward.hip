@@ -18,6 +18,7 @@
 // submodule; call site gaussian_renderer/__init__.py:37-52,86-94).  This TU is built with
 // -ffp-contract=off: the arithmetic below is evaluated exactly as written.
 #include "gsr_device.h"
+#include "gsr_sort.h"
 #include <type_traits>
 
 namespace gsr {
@@ -31,9 +32,15 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int W = s.W, H = s.H;
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
-    // this frame's tile histogram starts at zero (k_count runs after this kernel)
-    for (int t = i; t < a.tiles; t += (int)(gridDim.x * blockDim.x)) a.tile_count[t] = 0u;
-    if (i == 0) *a.rect_total = 0ull;
+    if (a.brec) {
+        // production binning: the depth-bucket histogram starts at zero (k_dbucket runs after this kernel); the header was
+        // zeroed by the API before this launch and collects this kernel's statistics
+        for (int t = i; t < a.nb; t += (int)(gridDim.x * blockDim.x)) a.bcount[t] = 0u;
+    } else {
+        // this frame's tile histogram starts at zero (k_count runs after this kernel)
+        for (int t = i; t < a.tiles; t += (int)(gridDim.x * blockDim.x)) a.tile_count[t] = 0u;
+        if (i == 0) *a.rect_total = 0ull;
+    }
 
     bool visible = false;
     float depth = 0.f, px = 0.f, py = 0.f;
@@ -216,6 +223,51 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         if (visible) {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             a.acc[3 * i + 0] = z; a.acc[3 * i + 1] = z; a.acc[3 * i + 2] = z;
+        }
+    }
+    if (a.brec) {
+        // ---- binning record: operands of the exact reach test and the quadrant rect to run it on (= 2 x the snug TILE rect, so that
+        // the streams hold exactly what the parity path's per-tile epilogue keeps), plus the frame statistics of the binned splats
+        uint32_t nt = 0, r0 = 0, r1 = 0;
+        if (visible) {
+            Reach r = reach_of(px, py, con0, con1, con2, opac);
+            nt = (uint32_t)((rmaxx - rminx) * (rmaxy - rminy));
+            int minx = rminx, miny = rminy, maxx = rmaxx, maxy = rmaxy;
+            snug_rect(r, minx, miny, maxx, maxy, nt);
+            if (nt) {
+                if (r.mode == 1) { r.A = 0.f; r.B = 0.f; r.C = 0.f; r.tau = 1.f; r.nBiC = 0.f; r.nBiA = 0.f; }   // never rejects
+                r0 = (uint32_t)(2 * minx) | ((uint32_t)(2 * miny) << 16);
+                r1 = (uint32_t)(2 * maxx) | ((uint32_t)(2 * maxy) << 16);
+                a.brec[3 * i + 0] = make_float4(r.px, r.py, r.A, r.B);
+                a.brec[3 * i + 1] = make_float4(r.C, r.tau, r.nBiC, r.nBiA);
+            }
+        }
+        if (i < a.P) a.brec[3 * i + 2] = make_float4(__uint_as_float(r0), __uint_as_float(r1), 0.f, 0.f);
+        // statistics of the binned splats: wave partials through LDS, ONE set of atomics per workgroup, spread over GSR_STAT_SLOTS lines
+        __shared__ uint32_t st_n[4], st_mx[4], st_mn[4];
+        __shared__ unsigned long long st_t[4], st_r[4];
+        const bool binned = nt != 0;
+        const unsigned long long bal = __ballot(binned);
+        const uint32_t dbits = binned ? __float_as_uint(depth) : 0u;
+        const uint32_t mx = wave_max_u32(dbits);
+        const uint32_t mn_inv = wave_max_u32(binned ? ~dbits : 0u);
+        unsigned long long tsum = nt, rsum = visible ? (unsigned long long)((rmaxx - rminx) * (rmaxy - rminy)) : 0ull;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { tsum += __shfl_xor(tsum, d, 64); rsum += __shfl_xor(rsum, d, 64); }
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { st_n[wv] = (uint32_t)__builtin_popcountll(bal); st_mx[wv] = mx; st_mn[wv] = mn_inv; st_t[wv] = tsum; st_r[wv] = rsum; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            BinStatSlot* sl = a.hdr->slot + (blockIdx.x & (GSR_STAT_SLOTS - 1));
+            const uint32_t n4 = st_n[0] + st_n[1] + st_n[2] + st_n[3];
+            const unsigned long long r4 = st_r[0] + st_r[1] + st_r[2] + st_r[3];
+            if (n4) {
+                atomicAdd(&sl->nvis, n4);
+                atomicMax(&sl->dmax_bits, max(max(st_mx[0], st_mx[1]), max(st_mx[2], st_mx[3])));
+                atomicMax(&sl->dmin_inv, max(max(st_mn[0], st_mn[1]), max(st_mn[2], st_mn[3])));
+                atomicAdd(&sl->binned_tiles, st_t[0] + st_t[1] + st_t[2] + st_t[3]);
+            }
+            if (r4) atomicAdd(&sl->rect_total, r4);
         }
     }
 }
@@ -424,115 +476,6 @@ template __global__ void k_scatter<false>(int, int, int, const float*, const ush
 template __global__ void k_scatter<true>(int, int, int, const float*, const ushort4*, const uint32_t*, const float4*, const uint32_t*, uint32_t*,
                                          unsigned long long*, unsigned long long, const unsigned long long*, const uint32_t*);
 
-// ------------------------------------------------------------------------------------------
-// Register-resident block sort for the in-LDS size classes: 8 keys per thread (index i = 8*tid + k).
-// Normalised bitonic network (every compare-exchange puts the smaller key at the lower index, first step
-// of a merge pairs i with i ^ (size-1), the rest with i ^ j), but a compare-exchange whose partner index
-// i ^ M differs only in the low 3 bits is done in registers, one that differs in lane bits goes through
-// the cross-lane network (ds_bpermute), and only masks reaching across waves (M >= 512) touch LDS with
-// a barrier: 10 barrier steps instead of 91 for 8192 keys.  Every mask is a compile-time constant, so
-// the key array stays in VGPRs.  Slots >= n hold the +inf pattern (GSR_SORT_PAD) and sink to the end.
-// ------------------------------------------------------------------------------------------
-typedef unsigned long long u64;
-__device__ __forceinline__ u64 shfl64(u64 v, int src_lane)
-{
-    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)v);
-    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)(v >> 32));
-    return ((u64)(uint32_t)hi << 32) | (u64)(uint32_t)lo;
-}
-constexpr int top_bit(int m) { int b = 1; while ((b << 1) <= m) b <<= 1; return b; }
-
-// Keys are compared as DOUBLES: a key is (depth bits << 32 | splat) with the depth a positive finite float, so its high word
-// is below 0x7F800000 and the 64-bit pattern is a positive finite (possibly denormal: FP64 denormals are never flushed)
-// double whose order is the order of the unsigned integers; padding slots hold +inf.  A compare-exchange is then
-// v_min_f64 + v_max_f64 (full-rate on CDNA4) instead of a 64-bit integer compare and four selects.
-__device__ __forceinline__ u64 kmin(u64 a, u64 b)
-{
-    double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(double, a)), "v"(__builtin_bit_cast(double, b)));
-    return __builtin_bit_cast(u64, r);
-}
-__device__ __forceinline__ u64 kmax(u64 a, u64 b)
-{
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(double, a)), "v"(__builtin_bit_cast(double, b)));
-    return __builtin_bit_cast(u64, r);
-}
-#define GSR_SORT_PAD 0x7FF0000000000000ull   // +inf: sinks to the end
-
-template <int M, int THREADS, int EPT>
-__device__ __forceinline__ void cx_step(u64 (&key)[EPT], u64* __restrict__ sk, int tid)
-{
-    constexpr int LE = EPT == 16 ? 4 : 3;                 // log2(keys per thread)
-    constexpr int KM = M & (EPT - 1);
-    constexpr int LM = (M >> LE) & 63;
-    constexpr int WM = M >> (LE + 6);
-    if constexpr (LM == 0 && WM == 0) {
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-            if ((k ^ KM) > k) {
-                const u64 a = key[k], b = key[k ^ KM];
-                key[k] = kmin(a, b);
-                key[k ^ KM] = kmax(a, b);
-            }
-        }
-    } else {
-        constexpr int TOP = top_bit(M);                  // >= EPT here: decided by the thread id alone
-        // lanes that keep the larger key negate both operands (sign bit of the double), take the minimum and negate back
-        const u64 flip = (tid & (TOP >> LE)) ? 0x8000000000000000ull : 0ull;
-        u64 other[EPT];
-        if constexpr (WM == 0) {
-            const int pl = (tid & 63) ^ LM;
-#pragma unroll
-            for (int k = 0; k < EPT; ++k) other[k] = shfl64(key[k ^ KM], pl);
-        } else {
-            // staging layout sk[k * THREADS + tid]: consecutive lanes hit consecutive banks
-#pragma unroll
-            for (int k = 0; k < EPT; ++k) sk[k * THREADS + tid] = key[k];
-            __syncthreads();
-            const int pt = tid ^ (M >> LE);
-#pragma unroll
-            for (int k = 0; k < EPT; ++k) other[k] = sk[(k ^ KM) * THREADS + pt];
-            __syncthreads();
-        }
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) key[k] = kmin(key[k] ^ flip, other[k] ^ flip) ^ flip;
-    }
-}
-
-template <int J, int THREADS, int EPT>
-__device__ __forceinline__ void cx_tail(u64 (&key)[EPT], u64* __restrict__ sk, int tid)
-{
-    if constexpr (J > 0) {
-        cx_step<J, THREADS, EPT>(key, sk, tid);
-        cx_tail<(J >> 1), THREADS, EPT>(key, sk, tid);
-    }
-}
-template <int SIZE, int N, int THREADS, int EPT>
-__device__ __forceinline__ void cx_stage(u64 (&key)[EPT], u64* __restrict__ sk, int tid, uint32_t n)
-{
-    if constexpr (SIZE <= N) {
-        // a merge of blocks of SIZE/2 has nothing to do once the first block holds every real key (the rest is +inf padding):
-        // the network stops at the first power of two >= n instead of at the class size (workgroup-uniform test)
-        if ((uint32_t)(SIZE / 2) >= n) return;
-        cx_step<SIZE - 1, THREADS, EPT>(key, sk, tid);            // first step of a merge: partner = i ^ (size - 1)
-        cx_tail<(SIZE >> 2), THREADS, EPT>(key, sk, tid);         // then i ^ j for j = size/4 ... 1
-        cx_stage<(SIZE << 1), N, THREADS, EPT>(key, sk, tid, n);
-    }
-}
-
-// sorts seg[0..n) (n <= EPT*THREADS); thread t ends up holding sorted positions EPT*t .. EPT*t+EPT-1 in key[]
-template <int THREADS, int EPT>
-__device__ __forceinline__ void block_sort_regs(u64 (&key)[EPT], u64* __restrict__ sk, const u64* __restrict__ seg, uint32_t n, int tid)
-{
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-        const uint32_t i = (uint32_t)tid * (uint32_t)EPT + (uint32_t)k;
-        key[k] = i < n ? seg[i] : GSR_SORT_PAD;
-    }
-    cx_stage<2, EPT * THREADS, THREADS, EPT>(key, sk, tid, n);
-}
-
 // Which of the tile's four 8x8 quadrants can the splat's {alpha >= 1/255} ellipse reach?  (bit q set = keep)
 // Same test as the tile-level one (rect_reach, gsr_device.h), on the quadrant's rectangle of pixel centres.
 __device__ __forceinline__ uint32_t quadrant_mask(float2 p, float4 co, float ox, float oy)
@@ -644,61 +587,6 @@ __device__ __forceinline__ void epilogue_striped(const u64 (&key)[EPT], uint32_t
     if (tid < 4) qcount[4 * tile + tid] = cntw[tid][NE];
 }
 
-// ------------------------------------------------------------------------------------------
-// Oversize tiles (more entries than the LDS class holds): sort KEYS-sized chunks with the register sort,
-// then merge the runs pairwise in global memory (merge path: every thread binary-searches its diagonal
-// and merges a private output slice).  `tmp` is scratch of at least n keys (the tile's still-unused
-// quadrant-record region); the sorted result always ends in seg[0..n).  Keys are unique per tile.
-// ------------------------------------------------------------------------------------------
-template <int THREADS, int EPT>
-__device__ __forceinline__ void oversize_sort(u64* __restrict__ seg, u64* __restrict__ tmp, u64* __restrict__ sk, uint32_t n, int tid)
-{
-    constexpr uint32_t CH = (uint32_t)(THREADS * EPT);
-    for (uint32_t c0 = 0; c0 < n; c0 += CH) {
-        const uint32_t m = min(CH, n - c0);
-        u64 key[EPT];
-        block_sort_regs<THREADS, EPT>(key, sk, seg + c0, m, tid);
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-            const uint32_t i = (uint32_t)tid * (uint32_t)EPT + (uint32_t)k;
-            if (i < m) tmp[c0 + i] = key[k];
-        }
-        __syncthreads();
-    }
-    u64* src = tmp;
-    u64* dst = seg;
-    for (uint32_t w = CH; w < n; w <<= 1) {
-        for (uint32_t p0 = 0; p0 < n; p0 += 2 * w) {
-            const u64* A = src + p0;
-            const uint32_t na = min(w, n - p0);
-            const u64* B = A + na;
-            const uint32_t nb = (p0 + na < n) ? min(w, n - p0 - na) : 0u;
-            const uint32_t total = na + nb;
-            const uint32_t S = (total + THREADS - 1) / THREADS;
-            const uint32_t d0 = min((uint32_t)tid * S, total), d1 = min(d0 + S, total);
-            // merge path: a = number of A elements among the first d0 outputs
-            uint32_t lo = d0 > nb ? d0 - nb : 0u, hi = min(d0, na);
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (A[mid] < B[d0 - 1 - mid]) lo = mid + 1; else hi = mid;
-            }
-            uint32_t a = lo, b = d0 - lo;
-            for (uint32_t o = d0; o < d1; ++o) {
-                const bool takeA = b >= nb || (a < na && A[a] < B[b]);
-                dst[p0 + o] = takeA ? A[a] : B[b];
-                a += takeA ? 1u : 0u;
-                b += takeA ? 0u : 1u;
-            }
-        }
-        __syncthreads();
-        u64* t = src; src = dst; dst = t;
-    }
-    if (src != seg) {   // odd number of passes (or none): bring the result home
-        for (uint32_t i = tid; i < n; i += THREADS) seg[i] = src[i];
-        __syncthreads();
-    }
-}
-
 // Three size classes share this body: tiles with n_lo < n <= n_hi are handled, the rest exit at once.
 //   small: <= 2048 entries, 256 threads x 8 keys, 16 KiB LDS (many workgroups per CU)
 //   large: <= 8192 entries, 1024 threads x 8 keys, 64 KiB LDS
@@ -708,7 +596,7 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
                                                         const uint32_t* __restrict__ tile_count,
                                                     const uint32_t* __restrict__ tile_start, unsigned long long* __restrict__ keys,
                                                     uint32_t* __restrict__ point_list, uint32_t* __restrict__ qlist,
-                                                    uint32_t* __restrict__ qpos, uint32_t* __restrict__ qcount,
+                                                    uint32_t* __restrict__ qpos, uint32_t* __restrict__ qcount, uint32_t* __restrict__ qstart,
                                                     const float4* __restrict__ grec,
                                                     unsigned long long capacity, const unsigned long long* __restrict__ total_dev)
 {
@@ -721,10 +609,11 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
     const uint32_t n = tile_count[tile];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (n <= n_lo || n > n_hi) {
-        if (n == 0 && n_lo == 0 && tid < 4) qcount[4 * tile + tid] = 0u;
+        if (n == 0 && n_lo == 0 && tid < 4) { qcount[4 * tile + tid] = 0u; qstart[4 * tile + tid] = 0u; }
         return;
     }
     const uint32_t start = tile_start[tile];
+    if (tid < 4) qstart[4 * tile + tid] = 4u * start + (uint32_t)tid * n;   // the tile's four n-slot streams
     unsigned long long* seg = keys + start;
     const bool in_lds = n <= (uint32_t)KEYS;
     const float ox = (float)((tile % (uint32_t)gx) * GSR_BLOCK_X), oy = (float)((tile / (uint32_t)gx) * GSR_BLOCK_Y);
@@ -795,13 +684,13 @@ __global__ __launch_bounds__(THREADS) void k_tile_sort(uint32_t n_lo, uint32_t n
     if (tid < 4) qcount[4 * tile + tid] = running[tid];
 }
 
-template __global__ void k_tile_sort<GSR_SORT_SMALL_KEYS, 256>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
+template __global__ void k_tile_sort<GSR_SORT_SMALL_KEYS, 256>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*, uint32_t*,
                                                                 uint32_t*, uint32_t*, uint32_t*, const float4*, unsigned long long,
                                                                 const unsigned long long*);
-template __global__ void k_tile_sort<GSR_SORT_LDS_KEYS, 1024>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
+template __global__ void k_tile_sort<GSR_SORT_LDS_KEYS, 1024>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*, uint32_t*,
                                                                uint32_t*, uint32_t*, uint32_t*, const float4*, unsigned long long,
                                                                const unsigned long long*);
-template __global__ void k_tile_sort<GSR_SORT_XL_KEYS, 1024>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*,
+template __global__ void k_tile_sort<GSR_SORT_XL_KEYS, 1024>(uint32_t, uint32_t, int, const uint32_t*, const uint32_t*, const uint32_t*, unsigned long long*, uint32_t*, uint32_t*,
                                                               uint32_t*, uint32_t*, uint32_t*, const float4*, unsigned long long,
                                                               const unsigned long long*);
 
@@ -815,7 +704,7 @@ template __global__ void k_tile_sort<GSR_SORT_XL_KEYS, 1024>(uint32_t, uint32_t,
 __device__ unsigned long long gsr_dbg_fwd[4 * 16384];
 extern "C" int gsr_debug_read_fwd(unsigned long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gsr_dbg_fwd), (size_t)n * 8); }
 #endif
-__global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __restrict__ tile_order, const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ qstart,
                                                  const uint32_t* __restrict__ qcount,
                                                  const float4* __restrict__ grec, const uint32_t* __restrict__ qpos,
                                                  const uint32_t* __restrict__ qlist, float* __restrict__ final_T,
@@ -839,11 +728,10 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     const bool inside = pxi < W && pyi < H;
     const float pixx = (float)pxi, pixy = (float)pyi;
 
-    const uint2 range = ranges[tile];
-    const uint32_t nt = range.y - range.x;
     const int n = (int)qcount[4 * tile + wave];
-    const float4* __restrict__ rec = grec;                                                   // the per-splat records (48 bytes each)
-    const uint32_t* __restrict__ qp = qpos + (size_t)4 * range.x + (size_t)wave * nt;       // this quadrant's stream of splat indices
+    const uint32_t qs = qstart[4 * tile + wave];
+    const float4* __restrict__ rec = grec;                      // the per-splat records (48 bytes each)
+    const uint32_t* __restrict__ qp = qpos + qs;                // this quadrant's stream of splat indices
 
     // Two transmittances per pixel: T is the one the pixel ends with (the last accepted product), Tw the WORKING one, equal to
     // T while the pixel is open and 0 once it is closed (saturated, or outside the image).  A closed pixel then needs no
@@ -1053,7 +941,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         const int pix_id = W * pyi + pxi;
         // the reference's n_contrib counts positions in the TILE list: the parity modes keep those in a twin stream; in
         // production it is the position in the quadrant stream (nothing reads it: the backward walks n_contrib_q)
-        const uint32_t last_contributor = !qlist ? last_q : (last_q ? (qlist + (size_t)4 * range.x + (size_t)wave * nt)[last_q - 1] + 1u : 0u);
+        const uint32_t last_contributor = !qlist ? last_q : (last_q ? (qlist + qs)[last_q - 1] + 1u : 0u);
         final_T[pix_id] = T;
         n_contrib[pix_id] = last_contributor;
         n_contrib_q[pix_id] = last_q;

@@ -56,7 +56,10 @@ def _forward_state(rs, means3D, shs, colors_precomp, opacities, scales, rotation
     I, cap = ctx.num_rendered, ctx.capacity
     gl, bl, il = _lib.GsrGeomLayout(), _lib.GsrBinningLayout(), _lib.GsrImageLayout()
     lib.gsr_geom_layout(P, C.byref(gl))
-    lib.gsr_binning_layout(cap, W, H, C.byref(bl))
+    from . import rasterizer as _R
+
+    lib.gsr_binning_layout(cap, W, H, P, int(_R.get_tile_culling()), C.byref(bl))
+    prod = bl.path == 1
     lib.gsr_image_layout(W, H, C.byref(il))
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     f32, u32, i16 = torch.float32, torch.int32, torch.int16
@@ -71,13 +74,15 @@ def _forward_state(rs, means3D, shs, colors_precomp, opacities, scales, rotation
         rect=_view(geom, gl.rect, 4 * P, i16).view(P, 4),
         tiles_touched=_view(geom, gl.tiles_touched, P, u32),
         clamped=_view(geom, gl.clamped, P, torch.uint8),
-        keys=_view(binning, bl.keys, I, torch.int64),
-        point_list=_view(binning, bl.point_list, I, u32),
-        qlist=_view(binning, bl.qlist, 4 * cap, u32),                          # parity modes: stream entries' positions in the tile list
-        qpos=_view(binning, bl.qpos, 4 * cap, u32),                            # per tile at 4*start: 4 streams of n splat indices
+        production_binning=prod,
+        keys=_view(binning, bl.keys, 0 if prod else I, torch.int64),
+        point_list=_view(binning, bl.point_list, 0 if prod else I, u32),
+        qlist=_view(binning, bl.qlist, 0 if prod else 4 * cap, u32),           # parity modes: stream entries' positions in the tile list
+        qpos=_view(binning, bl.qpos, cap if prod else 4 * cap, u32),           # the quadrant streams of splat indices (from qstart)
         qcount=_view(binning, bl.qcount, 4 * tiles, u32).view(tiles, 4),
-        ranges=_view(binning, bl.ranges, 2 * tiles, u32).view(tiles, 2),
-        tile_count=_view(binning, bl.tile_count, tiles, u32),
+        qstart=_view(binning, bl.qstart, 4 * tiles, u32).view(tiles, 4),
+        ranges=_view(binning, bl.ranges, 0 if prod else 2 * tiles, u32).view(-1, 2),
+        tile_count=_view(binning, bl.tile_count, 0 if prod else tiles, u32),
         final_T=_view(img, il.final_T, H * W, f32).view(H, W),
         n_contrib=_view(img, il.n_contrib, H * W, u32).view(H, W),
         n_contrib_q=_view(img, il.n_contrib_q, H * W, u32).view(H, W),

@@ -87,6 +87,9 @@ def last_forward_info() -> dict:
     b = _last_binning[0]
     if b is not None:
         info["rect_instances"] = int(b[8:16].view(torch.int64).item())
+        if info.get("production_binning"):   # header of the production path (csrc/gsr_device.h: BinHeader)
+            info["binned_splats"] = int(b[16:20].view(torch.int32).item())
+            info["tile_instances"] = int(b[32:40].view(torch.int64).item())   # after snug-rect culling: what the sort path would bin
     return info
 
 
@@ -141,12 +144,12 @@ def _layouts(lib, P, W, H):
     return hit
 
 
-def _binning_layout(lib, cap, W, H):
-    key = ("b", cap, W, H)
+def _binning_layout(lib, cap, W, H, P, mode):
+    key = ("b", cap, W, H, P, mode)
     hit = _layout_cache.get(key)
     if hit is None:
         hit = _lib.GsrBinningLayout()
-        lib.gsr_binning_layout(cap, W, H, C.byref(hit))
+        lib.gsr_binning_layout(cap, W, H, P, mode, C.byref(hit))
         if len(_layout_cache) > 64:
             _layout_cache.clear()
         _layout_cache[key] = hit
@@ -188,14 +191,17 @@ class _RasterizeGaussians(torch.autograd.Function):
         geom = torch.empty(gl.total, **u8)
         img = torch.empty(il.total, **u8)
 
-        key = (dev.index, H, W)
-        cap = _capacity_hint.get(key) or _round_cap(8 * P)
+        # the capacity counts what the binning path produces: tile instances on the per-tile sort path, quadrant-stream entries
+        # on the production path (include/gsr.h: gsr_binning_layout) -- one running estimate per path
+        prod = _binning_layout(lib, 0, W, H, P, int(s.tile_culling)).path == 1
+        key = (dev.index, H, W, prod)
+        cap = _capacity_hint.get(key) or _round_cap((24 if prod else 8) * P)
         stream = _lib.raw_stream(dev)
         n_host = C.c_int64(0)
         replays = 0
         with _lib.on_device(dev):
             while True:
-                bl = _binning_layout(lib, cap, W, H)
+                bl = _binning_layout(lib, cap, W, H, P, int(s.tile_culling))
                 binning = torch.empty(bl.total, **u8)
                 rc = lib.gsr_forward_ex(C.byref(s), P, M, _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors_precomp), _ptr(opacities),
                                      _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(color), _ptr(radii),
@@ -213,10 +219,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         I = int(n_host.value)
         # next frame: 25 % headroom over what this one needed, never shrinking below it
         _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
-        _last_info.update(num_rendered=I, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling))
+        _last_info.update(num_rendered=I, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod)
         _last_binning[0] = binning
 
         ctx.raster_settings = raster_settings
+        ctx.tile_culling = int(s.tile_culling)    # the state buffers are laid out for this mode
         ctx.num_rendered = I
         ctx.capacity = cap
         ctx.M = M
@@ -237,6 +244,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         dev = means3D.device
         keep: list = []
         s = _make_settings(rs, keep)
+        s.tile_culling = ctx.tile_culling
         P, M = means3D.shape[0], ctx.M
         f32 = dict(dtype=torch.float32, device=dev)
         grad_out_color = _f32c(grad_out_color, "grad_out_color")

@@ -66,7 +66,9 @@ typedef struct GsrSettings {
                                  byte 8 of the binning buffer.
                                  1: production -- additionally the reference-format sorted `keys` / `point_list` arrays are
                                     not written (nothing downstream reads them; the blend walks the quadrant streams);
-                                 2: culled, lists written (what the subsequence parity tests inspect). */
+                                 2: culled, lists written (what the subsequence parity tests inspect);
+                                 3: as 1 but always on the per-tile sort path, 4: as 1 but on the depth-ordered scatter whenever it
+                                    applies, whatever the splat count (A/B of the two production binnings, tests). */
     int32_t exact_scale_grad; /* 0 (default): dL/dscales as upstream's computeCov3D backward returns it -- the gradient
                                  w.r.t. (scale_modifier * scale), WITHOUT the modifier's chain-rule factor;
                                  !=0: multiplied by scale_modifier (the mathematically exact gradient).  The two agree at
@@ -89,6 +91,11 @@ typedef struct GsrGeomLayout {
     size_t clamped;        /* uint8  [P]   bit c set <=> channel c clamped  */
     size_t visible;        /* uint8  [P]   1 <=> radii > 0 (render()'s visibility_filter, written by the forward so that no
                               separate comparison kernel is needed)                                    */
+    size_t brec;           /* float  [12P] production binning only: the 48-byte binning record of a splat --
+                              (px, py, A, B | C, tau, -B/C, -B/A | quadrant rect: x0 | y0 << 16, x1 | y1 << 16, 0, 0) -- i.e. the
+                              operands of the exact {alpha >= 1/255} reach test (tau = ln(255 opacity), padded) and the rect of
+                              8x8 quadrants to run it on (= the splat's snug tile rect); an empty rect marks a splat that is
+                              not binned                                                                    */
     size_t acc;            /* float  [12P] backward accumulators of the screen-space gradients (dcolor 3, dmean2D 2,
                               dconic 3, dopacity 1, pad 3).  The forward zeroes the entries of visible splats and the
                               backward zeroes them again after consuming them, so a state is always ready for a
@@ -97,23 +104,42 @@ typedef struct GsrGeomLayout {
 } GsrGeomLayout;
 
 typedef struct GsrBinningLayout {
-    size_t keys;        /* uint64 [cap]  sorted (tile << 32 | depth bits), upstream's point_list_keys */
-    size_t point_list;  /* uint32 [cap]  sorted splat index, upstream's point_list                    */
+    /* header (2304 bytes) at byte 0: uint64 instances of this frame (what the capacity must hold: tile instances in the parity modes,
+       quadrant-stream entries in production), byte 8: uint64 sum of tiles_touched (the reference's num_rendered), byte 16:
+       uint32 binned splats, 20/24: depth range bits, byte 32: uint64 tile instances after snug-rect culling          */
+    size_t keys;        /* uint64 [cap]  parity modes: sorted (tile << 32 | depth bits), upstream's point_list_keys */
+    size_t point_list;  /* uint32 [cap]  parity modes: sorted splat index, upstream's point_list                    */
     size_t qlist;       /* uint32 [4*cap] parity modes only (tile_culling 0 / 2): twin of qpos holding each stream entry's
-                           POSITION in the tile's sorted list (what the reference's n_contrib counts); not written in
-                           production (tile_culling 1)                                                                */
-    size_t qpos;        /* uint32 [4*cap] per tile (at 4*start) four 8x8-quadrant streams of up to n SPLAT INDICES each:
-                           quadrant q lists, in the tile's depth order, the splats whose ellipse can reach it.  The
-                           blend kernels fetch the 48-byte per-splat record (GsrGeomLayout.grec) of each entry        */
-    size_t qcount;      /* uint32 [4*tiles] records in each quadrant stream                                       */
-    size_t ranges;      /* uint32 [2*tiles]  [start,end) per tile, (0,0) when empty                   */
-    size_t tile_count;  /* uint32 [tiles]                                                            */
-    size_t tile_start;  /* uint32 [tiles]                                                            */
-    size_t tile_cursor; /* uint32 [tiles]                                                            */
+                           POSITION in the tile's sorted list (what the reference's n_contrib counts)                 */
+    size_t qpos;        /* uint32: the 8x8-quadrant streams of SPLAT INDICES: quadrant q = 4 * tile + (row & 1) * 2 + (col & 1)
+                           lists, in depth order, the splats whose ellipse can reach it, qcount[q] entries from qstart[q].
+                           The blend kernels fetch the 48-byte per-splat record (GsrGeomLayout.grec) of each entry.
+                           Production: [cap] entries back to back; parity modes: [4*cap], four n-slot streams per tile  */
+    size_t qcount;      /* uint32 [4*tiles] entries in each quadrant stream                                       */
+    size_t qstart;      /* uint32 [4*tiles] first entry of each quadrant stream inside qpos (and qlist)            */
+    size_t ranges;      /* uint32 [2*tiles]  parity modes: [start,end) per tile, (0,0) when empty                 */
+    size_t tile_count;  /* uint32 [tiles]    parity modes                                                        */
+    size_t tile_start;  /* uint32 [tiles]    parity modes                                                        */
+    size_t tile_cursor; /* uint32 [tiles]    parity modes                                                        */
     size_t tile_order;  /* uint32 [tiles]  launch order of the per-tile kernels: heaviest tiles first         */
-    size_t block_hist;  /* uint32 [GSR_BIN_BLOCKS * tiles]  per-workgroup tile histograms of the counting pass, re-used by the
-                           scatter pass (same chunking) instead of histogramming again; absent (size 0) for tile grids
-                           beyond the LDS histogram                                                               */
+    size_t block_hist;  /* uint32 [GSR_BIN_BLOCKS * tiles]  parity modes: per-workgroup tile histograms of the counting pass,
+                           re-used by the scatter pass; absent (size 0) for tile grids beyond the LDS histogram        */
+    /* production binning (depth-ordered scatter into the quadrant streams, csrc/gsr_binning.hip): */
+    size_t dkeys;       /* uint64 [P]  (depth bits << 32 | splat) grouped by depth bucket, sorted inside the bucket  */
+    size_t dtmp;        /* uint64 [P]  merge scratch of buckets beyond the in-LDS classes                          */
+    size_t order;       /* uint32 [P]  the binned splats in (depth, index) order                                    */
+    size_t bcount;      /* uint32 [nb] depth buckets: count, start, fill cursor, launch order                       */
+    size_t bstart;
+    size_t bcursor;
+    size_t border;
+    size_t bhist;       /* uint32 [GSR_BIN_BLOCKS][nb]  per-workgroup bucket histograms of the bucket count, re-used by the scatter */
+    size_t qhist;       /* uint8  [chunks][4*ceil(Q/4)]  entries of chunk c (chunks consecutive runs of `order`) per quadrant */
+    size_t qprefix;     /* uint32 [chunks][Q]  exclusive prefix of qhist along the chunk axis                        */
+    size_t qmask;       /* uint64 [P][2]  hit masks of the counting pass (by position in `order`, first two rounds of 64 quadrants),
+                           replayed by the scatter pass                                                          */
+    size_t path;        /* 1: production binning is used for this (P, W, H, tile_culling); 0: the per-tile sort path     */
+    size_t chunks;      /* production: number of chunks (waves) of the ordered walk                                */
+    size_t nb;          /* production: number of depth buckets                                                     */
     size_t total;
 } GsrBinningLayout;
 
@@ -134,7 +160,12 @@ const char* gsr_last_error(void);
 
 /* sizes/layouts of the state buffers (pure host arithmetic, no device access) */
 int gsr_geom_layout(int32_t P, GsrGeomLayout* out);
-int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, GsrBinningLayout* out);
+/* P and tile_culling select the binning path (GsrBinningLayout.path): production (tile_culling 1) takes the depth-ordered
+ * scatter from 140 000 splats up (below that the per-tile sort is faster) when the grid has at most 16384 quadrants,
+ * P / chunks <= 255 and the chunk-prefix table stays below 1 GiB;
+ * otherwise (and always in the parity modes) the per-tile sort path of round 1.  `capacity` counts the instances the path
+ * produces: tile instances on the sort path, quadrant-stream entries on the production path.                          */
+int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, int32_t P, int32_t tile_culling, GsrBinningLayout* out);
 int gsr_image_layout(int32_t width, int32_t height, GsrImageLayout* out);
 
 /*
@@ -221,7 +252,11 @@ int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, c
 #define GSR_K_RENDER_BWD 5
 #define GSR_K_PREPROCESS_BWD 6
 #define GSR_K_COUNT 7
-#define GSR_NUM_KERNELS 8
+#define GSR_K_DEPTH_SORT 8    /* production binning: k_dbucket + k_dscan + k_dscatter + k_dsort, timed as one      */
+#define GSR_K_QCOUNT 9
+#define GSR_K_QSCAN 10        /* k_qscan + k_qscan_glob                                                            */
+#define GSR_K_QSCATTER 11
+#define GSR_NUM_KERNELS 12
 int gsr_profile_enable(int on);
 int gsr_profile_read(double* total_ms, int64_t* launches);
 const char* gsr_kernel_name(int id);

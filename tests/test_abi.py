@@ -34,15 +34,31 @@ def test_layouts_are_disjoint_and_aligned():
     lib = _lib.gsr()
     gl, bl, il = _lib.GsrGeomLayout(), _lib.GsrBinningLayout(), _lib.GsrImageLayout()
     assert lib.gsr_geom_layout(100_000, C.byref(gl)) == 0
-    assert lib.gsr_binning_layout(3_000_000, 550, 802, C.byref(bl)) == 0
+    assert lib.gsr_binning_layout(3_000_000, 550, 802, 100_000, 0, C.byref(bl)) == 0
     assert lib.gsr_image_layout(550, 802, C.byref(il)) == 0
     P, cap, tiles, HW = 100_000, 3_000_000, 35 * 51, 550 * 802
     segs = [(gl.depths, 4 * P), (gl.grec, 48 * P), (gl.cov3D, 24 * P),
-            (gl.rect, 8 * P), (gl.tiles_touched, 4 * P), (gl.clamped, P), (gl.visible, P), (gl.acc, 48 * P)]
+            (gl.rect, 8 * P), (gl.tiles_touched, 4 * P), (gl.clamped, P), (gl.visible, P), (gl.brec, 48 * P), (gl.acc, 48 * P)]
     _check(segs, gl.total)
-    segs = [(bl.keys, 8 * cap), (bl.point_list, 4 * cap), (bl.qlist, 16 * cap), (bl.qpos, 16 * cap), (bl.qcount, 16 * tiles), (bl.ranges, 8 * tiles),
-            (bl.tile_count, 4 * tiles), (bl.tile_start, 4 * tiles), (bl.tile_cursor, 4 * tiles)]
+    # parity modes: the per-tile sort path
+    assert bl.path == 0
+    segs = [(bl.keys, 8 * cap), (bl.point_list, 4 * cap), (bl.qlist, 16 * cap), (bl.qpos, 16 * cap), (bl.qcount, 16 * tiles), (bl.qstart, 16 * tiles),
+            (bl.ranges, 8 * tiles), (bl.tile_count, 4 * tiles), (bl.tile_start, 4 * tiles), (bl.tile_cursor, 4 * tiles), (bl.tile_order, 4 * tiles)]
     _check(segs, bl.total)
+    # production: depth-ordered scatter into the quadrant streams (capacity counts stream entries)
+    capq = 4_000_000
+    assert lib.gsr_binning_layout(capq, 550, 802, P, 1, C.byref(bl)) == 0 and bl.path == 0      # below 140 k splats: the sort path
+    assert lib.gsr_binning_layout(capq, 550, 802, 200_000, 1, C.byref(bl)) == 0 and bl.path == 1
+    assert lib.gsr_binning_layout(capq, 550, 802, P, 4, C.byref(bl)) == 0                        # 4: whenever it applies
+    assert bl.path == 1 and bl.chunks == 782 and bl.nb == 256 and (P + bl.chunks - 1) // bl.chunks <= 255
+    Q = 4 * tiles
+    segs = [(bl.qpos, 4 * capq), (bl.qcount, 4 * Q), (bl.qstart, 4 * Q), (bl.tile_order, 4 * tiles), (bl.dkeys, 8 * P), (bl.dtmp, 8 * P),
+            (bl.order, 4 * P), (bl.bcount, 4 * bl.nb), (bl.bstart, 4 * bl.nb), (bl.bcursor, 4 * bl.nb), (bl.border, 4 * bl.nb),
+            (bl.qhist, bl.chunks * Q), (bl.qprefix, 4 * bl.chunks * Q), (bl.qmask, 16 * P)]
+    _check(segs, bl.total)
+    # grids beyond 16384 quadrants and splat counts beyond 255 per chunk stay on the sort path
+    assert lib.gsr_binning_layout(capq, 1600, 1100, 2_000_000, 1, C.byref(bl)) == 0 and bl.path == 0
+    assert lib.gsr_binning_layout(capq, 550, 802, 2_000_000, 1, C.byref(bl)) == 0 and bl.path == 0
     _check([(il.final_T, 4 * HW), (il.n_contrib, 4 * HW), (il.n_contrib_q, 4 * HW), (il.c_final, 12 * HW), (il.ck, 144 * HW)], il.total)
     assert lib.gsr_geom_layout(-1, C.byref(gl)) < 0 and b"bad arguments" in lib.gsr_last_error()
 

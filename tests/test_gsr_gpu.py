@@ -227,13 +227,41 @@ def test_replay_on_capacity_overflow(oracle):
 
     R._capacity_hint.clear()
     s, st, hs, rs, _ = _run_both(oracle, "cfg1")
-    key = (0, rs.image_height, rs.image_width)
+    key = (0, rs.image_height, rs.image_width, False)    # (device, H, W, production path?)
     R._capacity_hint[key] = R._CAP_QUANTUM  # far below the 73k instances cfg1 needs? keep it honest:
     if st.num_rendered <= R._CAP_QUANTUM:
         pytest.skip("scene fits the minimum capacity")
     s, st, hs, rs, _ = _run_both(oracle, "cfg1")
     assert R.last_forward_info()["replays"] >= 1
     _check_forward(st, hs)
+
+
+def test_replay_on_capacity_overflow_production(oracle):
+    """The same on the production path, whose capacity counts quadrant-stream entries: an under-sized buffer is detected on the
+    device (k_qscatter and the blend do nothing), the host grows it and replays; the image is the oracle's."""
+    from gaussianavatars_amd import debug as D
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd.rasterizer import GaussianRasterizationSettings
+
+    dev = _dev()
+    cam, sp, bg, deg, mod = scene("cfg1")
+    a = settings_args(cam, bg, deg, mod)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    rs = GaussianRasterizationSettings(a["H"], a["W"], a["tanfovx"], a["tanfovy"], t(a["bg"]), mod, t(a["viewmatrix"]),
+                                       t(a["projmatrix"]), deg, t(a["campos"]), False, False)
+    args = (t(sp["means3D"]), t(sp["shs"]), None, t(sp["opacities"]), t(sp["scales"]), t(sp["rotations"]), None)
+    st = oracle.forward(oracle.make_settings(**a), sp["means3D"], sp["shs"], None, sp["opacities"], sp["scales"], sp["rotations"], None)
+    prev = R.set_tile_culling(4)
+    try:
+        R._capacity_hint[(0, a["H"], a["W"], True)] = R._CAP_QUANTUM
+        pro = D._forward_state(rs, *args)
+        info = R.last_forward_info()
+    finally:
+        R.set_tile_culling(prev)
+    if pro["num_rendered"] <= R._CAP_QUANTUM:
+        pytest.skip("scene fits the minimum capacity")
+    assert info["replays"] >= 1 and info["production_binning"]
+    assert np.array_equal(_np(pro["color"]).view(np.uint32), st.color.view(np.uint32))
 
 
 @pytest.mark.parametrize("name", ["cfg1", "sh3_small", "sh2_mod", "culls", "dense_tile", "empty_view"])
@@ -305,18 +333,68 @@ def test_production_mode_state(oracle):
                                        t(a["projmatrix"]), deg, t(a["campos"]), False, False)
     args = (t(sp["means3D"]), t(sp["shs"]), None, t(sp["opacities"]), t(sp["scales"]), t(sp["rotations"]), None)
     par = D.forward_state(rs, *args, tile_culling=True)
-    prev = R.set_tile_culling(1)
+    for mode in (1, 3, 4):     # 1: what render() runs (sort path at this size), 3 / 4: the two production binnings forced
+        prev = R.set_tile_culling(mode)
+        try:
+            pro = D._forward_state(rs, *args)
+        finally:
+            R.set_tile_culling(prev)
+        for k in ("color", "final_T"):
+            assert np.array_equal(_np(pro[k]).view(np.uint32), _np(par[k]).view(np.uint32)), k
+        np.testing.assert_array_equal(_np(pro["radii"]), _np(par["radii"]))
+        np.testing.assert_array_equal(_np(pro["n_contrib_q"]), _np(par["n_contrib_q"]))
+        np.testing.assert_array_equal(_np(pro["n_contrib"]), _np(pro["n_contrib_q"]))
+        _same_streams(pro, par, packed=mode == 4)
+        assert pro["production_binning"] == (mode == 4) and not par["production_binning"]
+        if mode == 4:
+            assert pro["num_rendered"] == int(_np(pro["qcount"]).astype(np.int64).sum())    # the scatter path counts stream entries
+        else:
+            assert pro["num_rendered"] == par["num_rendered"]
+        assert pro["rect_instances"] == par["rect_instances"]
+
+
+def _same_streams(pro, par, packed=True):
+    """The production binning (depth-ordered scatter, csrc/gsr_binning.hip) must produce the quadrant streams of the per-tile sort
+    path entry for entry: same membership, same (depth, index) order."""
+    np.testing.assert_array_equal(_np(pro["qcount"]), _np(par["qcount"]))
+    qc = _np(pro["qcount"]).astype(np.int64).reshape(-1)
+    a0, b0 = _np(pro["qstart"]).astype(np.int64).reshape(-1), _np(par["qstart"]).astype(np.int64).reshape(-1)
+    qa, qb = _np(pro["qpos"]).astype(np.int64), _np(par["qpos"]).astype(np.int64)
+    nz = np.nonzero(qc)[0]
+    if packed:
+        assert np.array_equal(a0[nz], np.concatenate([[0], np.cumsum(qc)[:-1]])[nz])          # the scatter path packs the streams back to back
+    ia = np.concatenate([np.arange(a0[q], a0[q] + qc[q]) for q in nz]) if len(nz) else np.zeros(0, np.int64)
+    ib = np.concatenate([np.arange(b0[q], b0[q] + qc[q]) for q in nz]) if len(nz) else np.zeros(0, np.int64)
+    np.testing.assert_array_equal(qa[ia], qb[ib])
+
+
+@pytest.mark.parametrize("name", ["cfg1", "sh2_mod", "culls", "dense_tile", "dense_tile_xl", "depth_ties", "deep_stack", "empty_view"])
+def test_production_binning_streams_equal_the_sort_path(oracle, name):
+    """Every scene of the parity set through the production binning: streams identical to the per-tile sort path's, image /
+    final_T / radii the oracle's bits."""
+    from gaussianavatars_amd import debug as D
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd.rasterizer import GaussianRasterizationSettings
+
+    dev = _dev()
+    cam, sp, bg, deg, mod = scene(name)
+    a = settings_args(cam, bg, deg, mod)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    rs = GaussianRasterizationSettings(a["H"], a["W"], a["tanfovx"], a["tanfovy"], t(a["bg"]), mod, t(a["viewmatrix"]),
+                                       t(a["projmatrix"]), deg, t(a["campos"]), False, False)
+    args = (t(sp["means3D"]), t(sp["shs"]), None, t(sp["opacities"]), t(sp["scales"]), t(sp["rotations"]), None)
+    par = D.forward_state(rs, *args, tile_culling=True)
+    prev = R.set_tile_culling(4)   # the depth-ordered scatter whatever the splat count (mode 1 takes it from 140 k splats up)
     try:
         pro = D._forward_state(rs, *args)
     finally:
         R.set_tile_culling(prev)
-    for k in ("color", "final_T"):
-        assert np.array_equal(_np(pro[k]).view(np.uint32), _np(par[k]).view(np.uint32)), k
-    np.testing.assert_array_equal(_np(pro["radii"]), _np(par["radii"]))
-    np.testing.assert_array_equal(_np(pro["n_contrib_q"]), _np(par["n_contrib_q"]))
-    np.testing.assert_array_equal(_np(pro["n_contrib"]), _np(pro["n_contrib_q"]))
-    np.testing.assert_array_equal(_np(pro["qcount"]), _np(par["qcount"]))
-    assert pro["num_rendered"] == par["num_rendered"]
+    assert pro["production_binning"]
+    _same_streams(pro, par)
+    st = oracle.forward(oracle.make_settings(**a), sp["means3D"], sp["shs"], None, sp["opacities"], sp["scales"], sp["rotations"], None)
+    assert np.array_equal(_np(pro["color"]).view(np.uint32), st.color.view(np.uint32))
+    assert np.array_equal(_np(pro["final_T"]).view(np.uint32), st.final_T.view(np.uint32))
+    np.testing.assert_array_equal(_np(pro["radii"]), st.radii)
 
 
 def test_tile_culling_gradients_equal_exact_mode(oracle):
