@@ -161,7 +161,7 @@ int gsr_geom_layout(int32_t P, GsrGeomLayout* o)
 static bool production_params(int32_t P, size_t tiles, int32_t tile_culling, size_t* chunks, size_t* nb)
 {
     *chunks = 0; *nb = 0;
-    // below ~140 k splats the per-tile sort path is the faster one (its cost grows faster than linearly with the splat count: 169 us at
+    // below ~125 k splats the per-tile sort path is the faster one (its cost grows faster than linearly with the splat count: 169 us at
     // 100 k, 403 us at 200 k against 195 / 323 us for the depth-ordered scatter on the same box)
     if (tile_culling == 4 ? P <= 0 : (tile_culling != 1 || P < GSR_PRODUCTION_MIN_SPLATS)) return false;   // 4: whenever it applies (tests, A/B)
     const size_t Q = 4 * tiles;

@@ -328,7 +328,7 @@ struct BinHeader {              // first bytes of the binning buffer (include/gs
 };
 static_assert(sizeof(BinHeader) == 256 + 64 * GSR_STAT_SLOTS, "header layout is part of include/gsr.h");
 
-#define GSR_PRODUCTION_MIN_SPLATS 140000   // splat count from which production mode takes the depth-ordered scatter (gsr_binning.hip)
+#define GSR_PRODUCTION_MIN_SPLATS 125000   // splat count from which production mode takes the depth-ordered scatter (gsr_binning.hip)
 #define GSR_WALK_MASKS 2           // saved hit masks per splat (rounds of 64 quadrants): rects beyond 128 quadrants are tested again by the scatter pass
 struct QBinArgs {               // k_qcount / k_qscatter
     int Q, gx;                      // quadrants (4 * tiles), tile columns

@@ -161,7 +161,7 @@ const char* gsr_last_error(void);
 /* sizes/layouts of the state buffers (pure host arithmetic, no device access) */
 int gsr_geom_layout(int32_t P, GsrGeomLayout* out);
 /* P and tile_culling select the binning path (GsrBinningLayout.path): production (tile_culling 1) takes the depth-ordered
- * scatter from 140 000 splats up (below that the per-tile sort is faster) when the grid has at most 16384 quadrants,
+ * scatter from 125 000 splats up (below that the per-tile sort is faster) when the grid has at most 16384 quadrants,
  * P / chunks <= 255 and the chunk-prefix table stays below 1 GiB;
  * otherwise (and always in the parity modes) the per-tile sort path of round 1.  `capacity` counts the instances the path
  * produces: tile instances on the sort path, quadrant-stream entries on the production path.                          */

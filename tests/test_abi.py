@@ -47,7 +47,7 @@ def test_layouts_are_disjoint_and_aligned():
     _check(segs, bl.total)
     # production: depth-ordered scatter into the quadrant streams (capacity counts stream entries)
     capq = 4_000_000
-    assert lib.gsr_binning_layout(capq, 550, 802, P, 1, C.byref(bl)) == 0 and bl.path == 0      # below 140 k splats: the sort path
+    assert lib.gsr_binning_layout(capq, 550, 802, P, 1, C.byref(bl)) == 0 and bl.path == 0      # below 125 k splats: the sort path
     assert lib.gsr_binning_layout(capq, 550, 802, 200_000, 1, C.byref(bl)) == 0 and bl.path == 1
     assert lib.gsr_binning_layout(capq, 550, 802, P, 4, C.byref(bl)) == 0                        # 4: whenever it applies
     assert bl.path == 1 and bl.chunks == 782 and bl.nb == 256 and (P + bl.chunks - 1) // bl.chunks <= 255

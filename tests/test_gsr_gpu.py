@@ -384,7 +384,7 @@ def test_production_binning_streams_equal_the_sort_path(oracle, name):
                                        t(a["projmatrix"]), deg, t(a["campos"]), False, False)
     args = (t(sp["means3D"]), t(sp["shs"]), None, t(sp["opacities"]), t(sp["scales"]), t(sp["rotations"]), None)
     par = D.forward_state(rs, *args, tile_culling=True)
-    prev = R.set_tile_culling(4)   # the depth-ordered scatter whatever the splat count (mode 1 takes it from 140 k splats up)
+    prev = R.set_tile_culling(4)   # the depth-ordered scatter whatever the splat count (mode 1 takes it from 125 k splats up)
     try:
         pro = D._forward_state(rs, *args)
     finally:
