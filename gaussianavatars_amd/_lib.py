@@ -46,7 +46,7 @@ def on_device(dev):
 GSR_LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr_hip.so")
 
 GSR_OK = 0
-GSR_ABI_VERSION = 2
+GSR_ABI_VERSION = 3
 GSR_E_CAPACITY = 1
 
 
@@ -66,6 +66,7 @@ class GsrSettings(C.Structure):
         ("prefiltered", C.c_int32),
         ("debug", C.c_int32),
         ("tile_culling", C.c_int32),
+        ("forward_only", C.c_int32),
         ("exact_scale_grad", C.c_int32),
     ]
 

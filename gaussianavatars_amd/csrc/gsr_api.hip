@@ -113,6 +113,7 @@ gsr::Settings to_dev_settings(const GsrSettings* s)
     d.scale_modifier = s->scale_modifier;
     d.sh_degree = s->sh_degree;
     d.exact_scale_grad = s->exact_scale_grad;
+    d.forward_only = s->forward_only;
     d.bg = s->bg;
     d.viewmatrix = s->viewmatrix;
     d.projmatrix = s->projmatrix;
@@ -496,6 +497,7 @@ int gsr_backward_ex(const GsrSettings* settings, int32_t P, int32_t M, const flo
     if (int rc = check_settings(settings)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0 || num_rendered < 0 || binning_capacity < num_rendered) return fail(GSR_E_ARG, "bad sizes");
+    if (settings->forward_only) return fail(GSR_E_ARG, "this state comes from a forward_only forward: its backward accumulators were never zeroed");
     if (P == 0) return GSR_OK;
     if (!means3D || !radii || !geom || !binning || !img || !dL_dpix || !dL_dmeans3D || !dL_dmeans2D ||
         !dL_dcolors || !dL_dopacity || !dL_dcov3D)

@@ -29,6 +29,7 @@ struct Settings {  // by-value kernel argument: scalars + the four device pointe
     float scale_modifier;
     int sh_degree;
     int exact_scale_grad;
+    int forward_only;
     const float* __restrict__ bg;
     const float* __restrict__ viewmatrix;
     const float* __restrict__ projmatrix;

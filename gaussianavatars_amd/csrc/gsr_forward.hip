@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         a.tiles_touched[i] = n;
         a.clamped[i] = (uint8_t)clampbits;
         a.visible[i] = radius > 0 ? (uint8_t)1 : (uint8_t)0;
-        if (visible) {
+        if (visible && !s.forward_only) {   // the backward's accumulators start at zero (skipped when no backward can follow)
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             a.acc[3 * i + 0] = z; a.acc[3 * i + 1] = z; a.acc[3 * i + 2] = z;
         }

@@ -38,6 +38,8 @@ def _forward_state(rs, means3D, shs, colors_precomp, opacities, scales, rotation
             e if cov3D_precomp is None else cov3D_precomp]
 
     class _Ctx:
+        needs_input_grad = (True,) * 10   # lay the state out as a training forward does
+
         def save_for_backward(self, *t):
             self.saved = t
 

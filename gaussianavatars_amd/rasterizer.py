@@ -164,6 +164,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         dev = means3D.device
         keep: list = []
         s = _make_settings(raster_settings, keep)
+        # no differentiable input (torch.no_grad, inference): no backward can follow, the forward skips preparing for one
+        s.forward_only = int(not any(ctx.needs_input_grad[:8]) and not (len(ctx.needs_input_grad) > 9 and ctx.needs_input_grad[9]))
         means3D = _f32c(means3D, "means3D")
         if means3D.dim() != 2 or means3D.shape[1] != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -245,6 +247,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         keep: list = []
         s = _make_settings(rs, keep)
         s.tile_culling = ctx.tile_culling
+        s.forward_only = 0
         P, M = means3D.shape[0], ctx.M
         f32 = dict(dtype=torch.float32, device=dev)
         grad_out_color = _f32c(grad_out_color, "grad_out_color")

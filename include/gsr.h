@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 2
+#define GSR_ABI_VERSION 3
 #define GSR_BWD_SEGMENT 60        /* stream entries per backward segment (a multiple of both blend kernels' batches)  */
 #define GSR_BWD_SEGMENTS 10       /* segments per quadrant stream; the last one takes whatever is left                */
 #define GSR_BIN_BLOCKS 256        /* workgroups of the two binning passes (each owns a contiguous chunk of splats) */
@@ -69,6 +69,9 @@ typedef struct GsrSettings {
                                  2: culled, lists written (what the subsequence parity tests inspect);
                                  3: as 1 but always on the per-tile sort path, 4: as 1 but on the depth-ordered scatter whenever it
                                     applies, whatever the splat count (A/B of the two production binnings, tests). */
+    int32_t forward_only;     /* !=0: no backward will follow this forward (inference, torch.no_grad): the forward skips zero-filling
+                                 the backward's per-splat accumulators (48 B per visible splat); gsr_backward on such a state is an
+                                 error                                                                                   */
     int32_t exact_scale_grad; /* 0 (default): dL/dscales as upstream's computeCov3D backward returns it -- the gradient
                                  w.r.t. (scale_modifier * scale), WITHOUT the modifier's chain-rule factor;
                                  !=0: multiplied by scale_modifier (the mathematically exact gradient).  The two agree at
