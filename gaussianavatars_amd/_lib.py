@@ -46,7 +46,7 @@ def on_device(dev):
 GSR_LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr_hip.so")
 
 GSR_OK = 0
-GSR_ABI_VERSION = 3
+GSR_ABI_VERSION = 4
 GSR_E_CAPACITY = 1
 
 
@@ -67,13 +67,14 @@ class GsrSettings(C.Structure):
         ("debug", C.c_int32),
         ("tile_culling", C.c_int32),
         ("forward_only", C.c_int32),
+        ("deterministic", C.c_int32),
         ("exact_scale_grad", C.c_int32),
     ]
 
 
 class GsrGeomLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
-                ("depths", "grec", "cov3D", "rect", "tiles_touched", "clamped", "visible", "brec", "acc", "total")]
+                ("depths", "grec", "cov3D", "rect", "tiles_touched", "clamped", "visible", "brec", "acc64", "acc", "total")]
 
 
 class GsrBinningLayout(C.Structure):
@@ -84,7 +85,7 @@ class GsrBinningLayout(C.Structure):
 
 
 class GsrImageLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("final_T", "n_contrib", "n_contrib_q", "c_final", "ck", "total")]
+    _fields_ = [(n, C.c_size_t) for n in ("final_T", "n_contrib", "n_contrib_q", "c_final", "ck", "gmax", "total")]
 
 
 #: every symbol include/gsr.h declares -> (restype, argtypes)

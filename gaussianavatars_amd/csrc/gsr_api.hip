@@ -114,6 +114,7 @@ gsr::Settings to_dev_settings(const GsrSettings* s)
     d.sh_degree = s->sh_degree;
     d.exact_scale_grad = s->exact_scale_grad;
     d.forward_only = s->forward_only;
+    d.deterministic = s->deterministic;
     d.bg = s->bg;
     d.viewmatrix = s->viewmatrix;
     d.projmatrix = s->projmatrix;
@@ -151,6 +152,7 @@ int gsr_geom_layout(int32_t P, GsrGeomLayout* o)
     o->clamped = off;       off = align_up(off + n, A);
     o->visible = off;       off = align_up(off + n, A);
     o->brec = off;          off = align_up(off + n * 48, A);
+    o->acc64 = off;         off = align_up(off + n * GSR_ACC64_STRIDE * 8, A);
     o->acc = off;           off = align_up(off + n * GSR_ACC_STRIDE * 4, A);
     o->total = off + A;
     return 0;
@@ -226,6 +228,7 @@ int gsr_image_layout(int32_t width, int32_t height, GsrImageLayout* o)
     o->n_contrib_q = off; off = align_up(off + hw * 4, A);
     o->c_final = off;   off = align_up(off + hw * 12, A);
     o->ck = off;        off = align_up(off + hw * 16 * (GSR_BWD_SEGMENTS - 1), A);
+    o->gmax = off;      off = align_up(off + 4, A);
     o->total = off + A;
     return 0;
 }
@@ -297,6 +300,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     pa.clamped = (uint8_t*)(g + gl.clamped);
     pa.visible = (uint8_t*)(g + gl.visible);
     pa.acc = (float4*)(g + gl.acc);
+    pa.acc64 = (float4*)(g + gl.acc64);
     pa.tile_count = tile_count;
     pa.rect_total = rect_total;
     pa.tiles = tiles;
@@ -522,12 +526,20 @@ int gsr_backward_ex(const GsrSettings* settings, int32_t P, int32_t M, const flo
     const char* im = (const char*)img;
     gsr::Settings ds = to_dev_settings(settings);
     float* grad_scratch = (float*)(g + gl.acc);   // zeroed by the forward (and by the previous backward)
+    long long* acc64 = (long long*)(g + gl.acc64);
+    uint32_t* gmax = (uint32_t*)(const_cast<char*>(im) + il.gmax);   // scratch word of the image state
+    const bool det = settings->deterministic != 0;
+    if (det) {   // the fixed-point scale of this backward: max |dL/dpixel|
+        HIP_TRY(hipMemsetAsync(gmax, 0, 4, stream));
+        hipLaunchKernelGGL(gsr::k_gmax, dim3(256), dim3(256), 0, stream, (size_t)3 * W * H, dL_dpix, gmax);
+        KERNEL_CHECK("k_gmax", stream, dbg);
+    }
     if (num_rendered > 0) {
         TIMED(GSR_K_RENDER_BWD, stream);
-        hipLaunchKernelGGL(gsr::k_render_bwd, dim3(gx * gy * GSR_BWD_SEGMENTS), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order),
+        hipLaunchKernelGGL(det ? gsr::k_render_bwd<true> : gsr::k_render_bwd<false>, dim3(gx * gy * GSR_BWD_SEGMENTS), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order),
                            (const uint32_t*)(b + bl.qstart), (const uint32_t*)(b + bl.qcount), (const float4*)(g + gl.grec), (const uint32_t*)(b + bl.qpos),
                            (const float*)(im + il.final_T), (const uint32_t*)(im + il.n_contrib_q), dL_dpix, grad_scratch,
-                           (const float*)(im + il.c_final), (const float4*)(im + il.ck), gx * gy);
+                           (const float*)(im + il.c_final), (const float4*)(im + il.ck), gx * gy, acc64, (const uint32_t*)gmax);
         KERNEL_CHECK("k_render_bwd", stream, dbg);
     }
     gsr::PreBwdArgs pa;
@@ -537,6 +549,9 @@ int gsr_backward_ex(const GsrSettings* settings, int32_t P, int32_t M, const flo
     pa.radii = radii;
     pa.clamped = (const uint8_t*)(g + gl.clamped);
     pa.acc = grad_scratch;
+    pa.acc64 = acc64;
+    pa.gmax = gmax;
+    pa.grec = (const float4*)(g + gl.grec);
     pa.use_precomp_cov = pre_cov ? 1 : 0;
     pa.use_precomp_color = pre_col ? 1 : 0;
     pa.dL_dmeans3D = dL_dmeans3D; pa.dL_dmeans2D = dL_dmeans2D; pa.dL_dsh = pre_col ? nullptr : dL_dsh; pa.dL_dsh_rest = shs_rest ? dL_dsh_rest : nullptr;

@@ -67,14 +67,29 @@ __device__ __forceinline__ float row_sum(float v)
 __device__ unsigned long long gsr_dbg[4 * 16384];
 extern "C" int gsr_debug_read(unsigned long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gsr_dbg), (size_t)n * 8); }
 #endif
+// max |dL/dpixel| for the deterministic mode's fixed-point scale (a maximum does not depend on the order it is taken in)
+__global__ __launch_bounds__(256) void k_gmax(size_t n, const float* __restrict__ dL_dpix, uint32_t* __restrict__ gmax)
+{
+    uint32_t m = 0u;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t b = __float_as_uint(dL_dpix[i]) & 0x7FFFFFFFu;
+        m = (b < 0x7F800000u && b > m) ? b : m;       // finite magnitudes order like their bit patterns
+    }
+    m = wave_max_u32(m);
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(gmax, m);
+}
+
+template <bool DET>
 __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ qstart,
                                                      const uint32_t* __restrict__ qcount,
                                                      const float4* __restrict__ grec, const uint32_t* __restrict__ qpos,
                                                      const float* __restrict__ final_T,
                                                      const uint32_t* __restrict__ n_contrib_q, const float* __restrict__ dL_dpix,
                                                      float* __restrict__ acc /* [P][GSR_ACC_STRIDE] */,
-                                                     const float* __restrict__ c_final, const float4* __restrict__ ck, int tiles)
+                                                     const float* __restrict__ c_final, const float4* __restrict__ ck, int tiles,
+                                                     long long* __restrict__ acc64, const uint32_t* __restrict__ gmax)
 {
+    const int e_g = DET ? gmax_exponent(*gmax) : 0;
 #ifdef GSR_EXPERIMENT_TIMELINE
     const unsigned long long t_start = wall_clock64();
 #endif
@@ -138,7 +153,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
     if (walk > 320) __builtin_amdgcn_s_setprio(3);
     else if (walk > 192) __builtin_amdgcn_s_setprio(2);
     else if (walk > 96) __builtin_amdgcn_s_setprio(1);
-    struct Rec2 { f32x8 a[2]; float cbl[2]; uint32_t id[2]; };   // a = (x, y, conic a, conic b, conic c, opacity, red, green)
+    struct Rec2 { f32x8 a[2]; float cbl[2]; int ex[2]; uint32_t id[2]; };   // a = (x, y, conic a, conic b, conic c, opacity, red, green)
     struct Pos2 { uint32_t p[2]; };
     // both streams through the CONSTANT address space with 32-bit byte offsets (as k_render): scalar loads, register-offset form
     typedef const __attribute__((address_space(4))) char* cbytes;
@@ -153,12 +168,21 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
         for (int u = 0; u < 2; ++u) {
             const uint32_t off = P.p[u] * 48u;
             R.a[u] = *(const __attribute__((address_space(4))) f32x8*)(recb + off);
-            R.cbl[u] = *(const __attribute__((address_space(4))) float*)(recb + off + 32);
+            if (DET) {   // blue and the splat's fixed-point exponent in one 8-byte load
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 be = *(const __attribute__((address_space(4))) f32x2*)(recb + off + 32);
+                R.cbl[u] = be[0];
+                R.ex[u] = __float_as_int(be[1]);
+            } else {
+                R.cbl[u] = *(const __attribute__((address_space(4))) float*)(recb + off + 32);
+                R.ex[u] = 0;
+            }
             R.id[u] = P.p[u];   // the stream entry IS the splat index
         }
     };
     float v[RB][9];
     uint32_t id[RB];
+    int ex[RB];
     // which component of which register a lane delivers to the accumulator after the reduction below
     const int l16 = lane & 15;
     const bool sel_v2 = (l16 & 3) == 1, sel_v3 = l16 == 2;
@@ -178,6 +202,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
             alpha[u] = sel_min(0.99f, R.a[u][5] * G[u]);
             hit[u] = (jp + u) < last && power <= 0.0f && alpha[u] >= 1.0f / 255.0f;
             id[uo + u] = R.id[u];
+            ex[uo + u] = R.ex[u];
         }
         if (__ballot(hit[0] || hit[1]) == 0ull) {      // no pixel of this wave touched these two splats
 #pragma unroll
@@ -266,8 +291,20 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
             myid = (row == 1) ? id[2] : myid;
             myid = (row == 2) ? id[1] : myid;
             myid = (row == 3) ? id[3] : myid;
+            int myex = ex[0];
+            if (DET) {
+                myex = (row == 1) ? ex[2] : myex;
+                myex = (row == 2) ? ex[1] : myex;
+                myex = (row == 3) ? ex[3] : myex;
+            }
             const int rec_u = (row == 1) ? 2 : ((row == 2) ? 1 : row);
-            if (c_sel >= 0 && (jb + rec_u) < nq && mine != 0.f) unsafeAtomicAdd(acc + (size_t)GSR_ACC_STRIDE * myid + c_sel, mine);
+            if (c_sel >= 0 && (jb + rec_u) < nq && mine != 0.f) {
+                if (DET)   // fixed point: integer adds commute, the sum is the same whatever order the waves arrive in
+                    atomicAdd((unsigned long long*)(acc64 + (size_t)GSR_ACC64_STRIDE * myid + c_sel),
+                              (unsigned long long)__builtin_llrintf(__builtin_ldexpf(mine, GSR_FIXED_BITS - e_g - ((c_sel >= 5 && c_sel <= 7) ? (myex >> 8) : (myex & 0xFF)))));
+                else
+                    unsafeAtomicAdd(acc + (size_t)GSR_ACC_STRIDE * myid + c_sel, mine);
+            }
         }
     }
 #ifdef GSR_EXPERIMENT_TIMELINE
@@ -280,6 +317,11 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
     }
 #endif
 }
+
+template __global__ void k_render_bwd<false>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const float*,
+                                             const uint32_t*, const float*, float*, const float*, const float4*, int, long long*, const uint32_t*);
+template __global__ void k_render_bwd<true>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const float*,
+                                            const uint32_t*, const float*, float*, const float*, const float4*, int, long long*, const uint32_t*);
 
 // ------------------------------------------------------------------------------------------
 
@@ -313,9 +355,18 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
     float* gsh = a.dL_dsh ? (sh_staged ? sh_lds + (int)threadIdx.x * sh_row_stride(M) : a.dL_dsh + (size_t)3 * M * i) : nullptr;
 
     if (vis) {
-        float4* ac4 = (float4*)(a.acc + (size_t)GSR_ACC_STRIDE * i);
-        const float4 q0 = ac4[0], q1 = ac4[1], q2 = ac4[2];
-        {   // leave the accumulators zeroed: the state is ready for another backward
+        float4 q0, q1, q2;
+        if (s.deterministic) {   // fixed-point sums -> fp32 (exact scaling by a power of two after the int -> float rounding)
+            long long* ai = a.acc64 + (size_t)GSR_ACC64_STRIDE * i;
+            const int ex = __float_as_int(a.grec[3 * (size_t)i + 2].y), back = gmax_exponent(*a.gmax) - GSR_FIXED_BITS;
+            float f[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { f[k] = __builtin_ldexpf((float)ai[k], back + ((k >= 5 && k <= 7) ? (ex >> 8) : (ex & 0xFF))); ai[k] = 0ll; }
+            q0 = make_float4(f[0], f[1], f[2], f[3]); q1 = make_float4(f[4], f[5], f[6], f[7]); q2 = make_float4(f[8], 0.f, 0.f, 0.f);
+        } else {
+            float4* ac4 = (float4*)(a.acc + (size_t)GSR_ACC_STRIDE * i);
+            q0 = ac4[0]; q1 = ac4[1]; q2 = ac4[2];
+            // leave the accumulators zeroed: the state is ready for another backward
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             ac4[0] = z; ac4[1] = z; ac4[2] = z;
         }

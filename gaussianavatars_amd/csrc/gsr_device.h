@@ -17,6 +17,13 @@
 #define GSR_SORT_XL_KEYS 16384  // 128 KiB of LDS, 16 keys per thread; beyond this the sort runs in global memory
 #define GSR_SORT_SMALL_KEYS 2048 // tiles up to this many entries take the 256-thread / 16 KiB class
 #define GSR_ACC_STRIDE 12        // floats per splat in the backward accumulator (48 B, one atomic burst)
+#define GSR_ACC64_STRIDE 10      // int64 per splat in the deterministic mode's fixed-point accumulator (9 sums + pad, 80 B)
+#define GSR_FIXED_BITS 58        // fixed point: a partial p of splat s is added as llrint(p * 2^(GSR_FIXED_BITS - e_s - e_g)) with
+                                 // 2^e_g > max |dL/dpixel| and 2^e_s >= the splat's own bound on the sum (two classes: conic sums, the rest) in units of
+                                 // max |dL/dpixel| (k_preprocess: pixels it can touch x 8 x max(1, largest 2-D variance)).  The bound is on the
+                                 // whole sum, so the only headroom needed is for what it leaves out (colours above 8/3): 5 bits below 2^63.
+                                 // Resolution 2^-58 of the bound: a screen-filling splat's 10^5 partials, whose sum is ~10^-6 of its bound,
+                                 // still come out at 10^-8 relative (at 46 bits the 3300 x 3300 test scene was off by 3e-3).
 #define GSR_LDS_HIST_TILES 40960 // 160 KB of LDS / 4 B: the largest tile grid k_count / k_scatter privatise
 
 namespace gsr {
@@ -30,6 +37,7 @@ struct Settings {  // by-value kernel argument: scalars + the four device pointe
     int sh_degree;
     int exact_scale_grad;
     int forward_only;
+    int deterministic;
     const float* __restrict__ bg;
     const float* __restrict__ viewmatrix;
     const float* __restrict__ projmatrix;
@@ -364,6 +372,7 @@ struct PreprocessArgs {
     uint8_t* __restrict__ clamped;
     uint8_t* __restrict__ visible;        // [P] radii > 0
     float4* __restrict__ acc;             // [P][3] backward accumulators, zeroed here for visible splats
+    float4* __restrict__ acc64;           // [P][5] the deterministic mode's (80 B per splat), zeroed instead when settings.deterministic
     uint32_t* __restrict__ tile_count;    // [tiles] zeroed here (the binning histogram of this frame)
     unsigned long long* __restrict__ rect_total;   // zeroed here; k_count sums tiles_touched into it
     int tiles;
@@ -385,6 +394,9 @@ struct PreBwdArgs {
     const int32_t* __restrict__ radii;
     const uint8_t* __restrict__ clamped;
     float* __restrict__ acc;              // [P][12]: dcolor(3) dmean2D(2) dconic(3) dopacity(1); re-zeroed after use
+    long long* __restrict__ acc64;        // deterministic mode: [P][10] the same sums in fixed point
+    const uint32_t* __restrict__ gmax;    // deterministic mode: bits of max |dL/dpixel| (the fixed-point scale)
+    const float4* __restrict__ grec;      // deterministic mode: the per-splat records (their fixed-point exponents)
     int use_precomp_cov, use_precomp_color;
     float* __restrict__ dL_dmeans3D;
     float* __restrict__ dL_dmeans2D;      // (P,3)
@@ -416,9 +428,27 @@ __global__ void k_render(Settings s, const uint32_t* tile_order, const uint32_t*
                          uint32_t* n_contrib, uint32_t* n_contrib_q, float* c_final, float4* ck, float* out_color, unsigned long long capacity,
                          const unsigned long long* total_dev);
 __global__ void k_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present);
+template <bool DET>
 __global__ void k_render_bwd(Settings s, const uint32_t* tile_order, const uint32_t* qstart, const uint32_t* qcount, const float4* grec,
                              const uint32_t* qpos, const float* final_T,
-                             const uint32_t* n_contrib_q, const float* dL_dpix, float* acc, const float* c_final, const float4* ck, int tiles);
+                             const uint32_t* n_contrib_q, const float* dL_dpix, float* acc, const float* c_final, const float4* ck, int tiles,
+                             long long* acc64, const uint32_t* gmax);
+__global__ void k_gmax(size_t n, const float* dL_dpix, uint32_t* gmax);
+// exponent e_g with 2^e_g > the float whose bits are given (0 for no gradient at all)
+__device__ __forceinline__ int gmax_exponent(uint32_t gmax_bits) { return gmax_bits ? (int)((gmax_bits >> 23) & 0xFFu) - 127 + 1 : 0; }
+// the splat's fixed-point exponents (see GSR_FIXED_BITS) from what the forward knows about it: low byte for the colour / position /
+// opacity sums (each partial stays below 8 |dL/dpixel| per pixel), next byte for the three conic sums, whose per-pixel factor
+// G dx^2 reaches 0.74 x the largest diagonal entry of the 2-D covariance = 0.74 max(A, C) / det(conic)
+__device__ __forceinline__ int splat_sum_exponents(uint32_t tiles, float conA, float conB, float conC, int W, int H)
+{
+    const float npix = fminf((float)tiles * (float)GSR_TILE_PIX, (float)W * (float)H);
+    const float det = conA * conC - conB * conB;
+    const float var = fmaxf(fabsf(conA), fabsf(conC)) / fmaxf(fabsf(det), 1e-30f);
+    int ea, eb;
+    (void)frexpf(npix * 8.0f, &ea);                       // bound < 2^e
+    (void)frexpf(npix * 8.0f * fmaxf(1.0f, var), &eb);
+    return min(max(ea, 0), 127) | (min(max(eb, 0), 127) << 8);
+}
 __global__ void k_preprocess_bwd(Settings s, PreBwdArgs a);
 // production binning (gsr_binning.hip)
 __global__ void k_dbucket(int P, const uint32_t* brec_rect, const float* depths, BinHeader* hdr, uint32_t nb, uint32_t* bcount, uint32_t* bhist);

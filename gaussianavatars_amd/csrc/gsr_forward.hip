@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         a.depths[i] = depth;
         a.grec[3 * i + 0] = make_float4(px, py, con0, con1);
         a.grec[3 * i + 1] = make_float4(con2, opac, col[0], col[1]);
-        a.grec[3 * i + 2] = make_float4(col[2], 0.f, 0.f, 0.f);
+        // .y: the splat's two fixed-point exponents for the deterministic backward (gsr_device.h: GSR_FIXED_BITS), as an integer in float bits
+        a.grec[3 * i + 2] = make_float4(col[2], __int_as_float(visible ? splat_sum_exponents(n, con0, con1, con2, W, H) : 0), 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < 6; ++k) a.cov3D[6 * i + k] = c6[k];
         a.rect[i] = make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy);
@@ -222,7 +223,12 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         a.visible[i] = radius > 0 ? (uint8_t)1 : (uint8_t)0;
         if (visible && !s.forward_only) {   // the backward's accumulators start at zero (skipped when no backward can follow)
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            a.acc[3 * i + 0] = z; a.acc[3 * i + 1] = z; a.acc[3 * i + 2] = z;
+            if (s.deterministic) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) a.acc64[5 * i + k] = z;   // 80 bytes of fixed-point sums
+            } else {
+                a.acc[3 * i + 0] = z; a.acc[3 * i + 1] = z; a.acc[3 * i + 2] = z;
+            }
         }
     }
     if (a.brec) {

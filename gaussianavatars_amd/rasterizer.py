@@ -22,7 +22,7 @@ from torch import nn
 from . import _lib
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_forward_info", "set_tile_culling",
-           "get_tile_culling", "set_exact_scale_grad"]
+           "get_tile_culling", "set_exact_scale_grad", "set_deterministic"]
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -61,6 +61,18 @@ def get_tile_culling() -> int:
 # ---- dL/dscales convention (include/gsr.h: GsrSettings.exact_scale_grad) -------------------------
 # Default = upstream: the gradient w.r.t. (scale_modifier * scale), no factor for the modifier itself.
 _exact_scale_grad = int(os.environ.get("GSR_EXACT_SCALE_GRAD", "0"))
+
+
+# ---- bit-reproducible backward (include/gsr.h: GsrSettings.deterministic) -------------------------
+_deterministic = int(os.environ.get("GSR_DETERMINISTIC", "0"))
+
+
+def set_deterministic(enabled: bool) -> bool:
+    """Process-wide switch; True makes the rasterizer's backward bit-reproducible run to run (fixed-point accumulation instead of fp32
+    atomics; ~the same speed).  Returns the previous value."""
+    global _deterministic
+    prev, _deterministic = bool(_deterministic), int(bool(enabled))
+    return prev
 
 
 def set_exact_scale_grad(enabled: bool) -> bool:
@@ -120,6 +132,7 @@ def _make_settings(rs: GaussianRasterizationSettings, keep: list) -> _lib.GsrSet
     s.prefiltered, s.debug = int(bool(rs.prefiltered)), int(bool(rs.debug))
     s.tile_culling = int(_tile_culling)
     s.exact_scale_grad = int(_exact_scale_grad)
+    s.deterministic = int(_deterministic)
     for field in ("bg", "viewmatrix", "projmatrix", "campos"):
         t = _f32c(getattr(rs, field), field)
         keep.append(t)
@@ -226,6 +239,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         ctx.raster_settings = raster_settings
         ctx.tile_culling = int(s.tile_culling)    # the state buffers are laid out for this mode
+        ctx.deterministic = int(s.deterministic)  # and the accumulators zero-filled for this one
         ctx.num_rendered = I
         ctx.capacity = cap
         ctx.M = M
@@ -247,6 +261,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         keep: list = []
         s = _make_settings(rs, keep)
         s.tile_culling = ctx.tile_culling
+        s.deterministic = ctx.deterministic
         s.forward_only = 0
         P, M = means3D.shape[0], ctx.M
         f32 = dict(dtype=torch.float32, device=dev)

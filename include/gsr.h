@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 3
+#define GSR_ABI_VERSION 4
 #define GSR_BWD_SEGMENT 60        /* stream entries per backward segment (a multiple of both blend kernels' batches)  */
 #define GSR_BWD_SEGMENTS 10       /* segments per quadrant stream; the last one takes whatever is left                */
 #define GSR_BIN_BLOCKS 256        /* workgroups of the two binning passes (each owns a contiguous chunk of splats) */
@@ -72,6 +72,12 @@ typedef struct GsrSettings {
     int32_t forward_only;     /* !=0: no backward will follow this forward (inference, torch.no_grad): the forward skips zero-filling
                                  the backward's per-splat accumulators (48 B per visible splat); gsr_backward on such a state is an
                                  error                                                                                   */
+    int32_t deterministic;    /* !=0: bit-reproducible backward.  The blend backward then adds its per-(wave, splat) partial sums as 64-bit
+                                 FIXED-POINT integers (integer addition is associative: the result does not depend on the order the
+                                 atomics land in), scaled by a power of two derived from max |dL/dpixel| (one extra reduction kernel);
+                                 resolution max|dL/dpixel| * 2^-34 per term, i.e. finer than the fp32 partials themselves.  Same
+                                 value in the forward and the backward call of a frame (the forward zero-fills the accumulators
+                                 of the mode).  Default 0: fp32 atomics (summation order varies run to run, like upstream's).    */
     int32_t exact_scale_grad; /* 0 (default): dL/dscales as upstream's computeCov3D backward returns it -- the gradient
                                  w.r.t. (scale_modifier * scale), WITHOUT the modifier's chain-rule factor;
                                  !=0: multiplied by scale_modifier (the mathematically exact gradient).  The two agree at
@@ -86,8 +92,9 @@ typedef struct GsrGeomLayout {
     size_t depths;         /* float  [P]                                   */
     size_t grec;           /* float4 [3P]  per-splat blend record, 48 B in ONE place: what the quadrant test of the
                               tile sort gathers per instance and what the two blend kernels fetch (scalar loads) per
-                              stream entry:  (x, y, A, B | C, opacity, r, g | b, 0, 0, 0)
-                              x,y = pixel centre, A,B,C = conic                                         */
+                              stream entry:  (x, y, A, B | C, opacity, r, g | b, e, 0, 0)
+                              x,y = pixel centre, A,B,C = conic, e = (int32 bits) the splat's fixed-point exponent of the
+                              deterministic backward                                                    */
     size_t cov3D;          /* float  [6P]  xx xy xz yy yz zz                */
     size_t rect;           /* uint16 [4P]  tile rect min.x min.y max.x max.y */
     size_t tiles_touched;  /* uint32 [P]                                   */
@@ -99,6 +106,7 @@ typedef struct GsrGeomLayout {
                               operands of the exact {alpha >= 1/255} reach test (tau = ln(255 opacity), padded) and the rect of
                               8x8 quadrants to run it on (= the splat's snug tile rect); an empty rect marks a splat that is
                               not binned                                                                    */
+    size_t acc64;          /* int64  [10P] deterministic mode's accumulators (same nine sums as `acc`, fixed point, one pad)     */
     size_t acc;            /* float  [12P] backward accumulators of the screen-space gradients (dcolor 3, dmean2D 2,
                               dconic 3, dopacity 1, pad 3).  The forward zeroes the entries of visible splats and the
                               backward zeroes them again after consuming them, so a state is always ready for a
@@ -155,6 +163,7 @@ typedef struct GsrImageLayout {
     size_t ck;         /* float4 [(GSR_BWD_SEGMENTS-1)*H*W] blend checkpoints: slot s-1 of a pixel = (T, C) before entry
                           s*GSR_BWD_SEGMENT of its quadrant stream.  The backward walks each segment of a pixel's stream on
                           its own wave, starting from the checkpoint (the serial walk was the kernel's critical path). */
+    size_t gmax;       /* uint32 [1]  deterministic backward: bits of max |dL/dpixel| of the current backward               */
     size_t total;
 } GsrImageLayout;
 

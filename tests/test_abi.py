@@ -25,7 +25,7 @@ def test_gsr_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"include/gsr.h declares {n} but libgsr_hip.so does not export it"
         assert n in _lib.GSR_SYMBOLS, f"{n} has no ctypes prototype in _lib.GSR_SYMBOLS"
-    assert lib.gsr_abi_version() == 3
+    assert lib.gsr_abi_version() == 4
 
 
 def test_layouts_are_disjoint_and_aligned():
@@ -38,7 +38,7 @@ def test_layouts_are_disjoint_and_aligned():
     assert lib.gsr_image_layout(550, 802, C.byref(il)) == 0
     P, cap, tiles, HW = 100_000, 3_000_000, 35 * 51, 550 * 802
     segs = [(gl.depths, 4 * P), (gl.grec, 48 * P), (gl.cov3D, 24 * P),
-            (gl.rect, 8 * P), (gl.tiles_touched, 4 * P), (gl.clamped, P), (gl.visible, P), (gl.brec, 48 * P), (gl.acc, 48 * P)]
+            (gl.rect, 8 * P), (gl.tiles_touched, 4 * P), (gl.clamped, P), (gl.visible, P), (gl.brec, 48 * P), (gl.acc64, 80 * P), (gl.acc, 48 * P)]
     _check(segs, gl.total)
     # parity modes: the per-tile sort path
     assert bl.path == 0

@@ -412,3 +412,23 @@ def test_tile_culling_gradients_equal_exact_mode(oracle):
         _grad_check(oracle, "culls")
     finally:
         R.set_tile_culling(prev)
+
+
+@pytest.mark.parametrize("name", ["sh3_small", "culls", "deep_stack", "huge_grid"])
+def test_deterministic_backward_is_bit_reproducible(oracle, name):
+    """GsrSettings.deterministic: the blend backward accumulates in 64-bit fixed point (integer adds commute), so two runs give the
+    same bits -- the default fp32 atomics do not -- and the values still match the oracle (the 3300x3300 scene, whose sums run over
+    10^7 pixels, at 5e-4: what is left there is the fp32 rounding of each 64-pixel partial and of the oracle's own running sums)."""
+    from gaussianavatars_amd import rasterizer as R
+
+    prev = R.set_deterministic(True)
+    try:
+        rtol = 5e-4 if name == "huge_grid" else 2e-4
+        a = _grad_check(oracle, name, rtol=rtol)
+        b = _grad_check(oracle, name, rtol=rtol)
+    finally:
+        R.set_deterministic(prev)
+    assert prev is False
+    for k in a:
+        if a[k] is not None:
+            assert torch.equal(a[k], b[k]), f"{name}/{k}: two deterministic backward passes differ"
