@@ -345,7 +345,7 @@ def main():
         stream = {"k_preprocess": 236 * N, "k_count": 44 * N, "k_scatter": 48 * N, "k_tile_sort": 8 * I_binned, "k_render": 0,
                   "k_render_bwd": 0, "k_preprocess_bwd": 300 * N + 48 * N}
         pmc, pmc_raw = {}, {}
-        pmc_tag = "cfg5" if args.workload == "cfg5" else ("cfg3" if args.workload in ("cfg3", "cfg2") else None)
+        pmc_tag = {"cfg5": "cfg5", "cfg4": "cfg4", "cfg3": "cfg3", "cfg2": "cfg3"}.get(args.workload)
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{pmc_tag}_pmc_fetch_write_per_launch.json"))) if pmc_tag else []
         pmc_path = cands[-1] if cands else ""   # the newest committed PMC summary of this workload

@@ -46,7 +46,7 @@ def on_device(dev):
 GSR_LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr_hip.so")
 
 GSR_OK = 0
-GSR_ABI_VERSION = 4
+GSR_ABI_VERSION = 5
 GSR_E_CAPACITY = 1
 
 
@@ -80,7 +80,7 @@ class GsrGeomLayout(C.Structure):
 class GsrBinningLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
                 ("keys", "point_list", "qlist", "qpos", "qcount", "qstart", "ranges", "tile_count", "tile_start", "tile_cursor", "tile_order",
-                 "block_hist", "dkeys", "dtmp", "order", "bcount", "bstart", "bcursor", "border", "bhist", "qhist", "qprefix", "qmask", "path", "chunks", "nb",
+                 "block_hist", "dkeys", "dtmp", "order", "bcount", "bstart", "bcursor", "border", "bhist", "qhist", "qprefix", "qmask", "ranks", "rank", "srect", "sspan", "pstat", "path", "chunks", "nb",
                  "total")]
 
 

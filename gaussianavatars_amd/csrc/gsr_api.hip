@@ -160,12 +160,11 @@ int gsr_geom_layout(int32_t P, GsrGeomLayout* o)
 
 // Production binning parameters for (P, grid): chunks of the ordered walk (one wave each, S = ceil(P / chunks) <= 255 splats so
 // that the per-quadrant counters of a chunk fit a byte) and depth buckets (about 512 splats each).  Returns false when the
-// depth-ordered scatter does not apply (then the per-tile sort path is used).
+// depth-ordered scatter does not apply (then the rank path is used).
 static bool production_params(int32_t P, size_t tiles, int32_t tile_culling, size_t* chunks, size_t* nb)
 {
     *chunks = 0; *nb = 0;
-    // below ~125 k splats the per-tile sort path is the faster one (its cost grows faster than linearly with the splat count: 169 us at
-    // 100 k, 403 us at 200 k against 195 / 323 us for the depth-ordered scatter on the same box)
+    // below ~125 k splats ordering the tile lists is the faster way (per-tile cost grows faster than linearly with the splat count)
     if (tile_culling == 4 ? P <= 0 : (tile_culling != 1 || P < GSR_PRODUCTION_MIN_SPLATS)) return false;   // 4: whenever it applies (tests, A/B)
     const size_t Q = 4 * tiles;
     if (Q > 16384) return false;                                   // the scatter wave keeps a 4-byte cursor per quadrant in LDS: <= 64 KB
@@ -178,6 +177,20 @@ static bool production_params(int32_t P, size_t tiles, int32_t tile_culling, siz
     *chunks = c; *nb = b;
     return true;
 }
+// Binning path of a frame: 1 production (depth-ordered scatter, gsr_binning.hip), 2 round 1's per-tile bitonic sort (tile_culling 5:
+// kept for A/B runs), 0 the rank path (gsr_rank.hip: splats ranked by depth once, tiles ordered through an LDS bitmap).
+static int binning_path(int32_t P, size_t tiles, int32_t tile_culling, size_t* chunks, size_t* nb)
+{
+    if (production_params(P, tiles, tile_culling, chunks, nb)) return 1;
+    if (tile_culling == 5) return 2;
+    // beyond GSR_RANK_MAX_SPLATS the tile bitmaps no longer hold every rank in one pass and the per-instance order[] / record gathers
+    // leave the caches (2 M splats: 1.67 ms against 0.88 ms): such frames keep round 1's per-tile sort
+    if (P > GSR_RANK_MAX_SPLATS) return 2;
+    size_t b = 16;
+    while (b < (size_t)GSR_RANK_MAX_BUCKETS && b * 256 < (size_t)P) b <<= 1;   // about 256 splats per depth bucket
+    *nb = b;
+    return 0;
+}
 
 int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, int32_t P, int32_t tile_culling, GsrBinningLayout* o)
 {
@@ -185,12 +198,16 @@ int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, int32_t 
     const size_t tiles = (size_t)((width + GSR_BLOCK_X - 1) / GSR_BLOCK_X) * (size_t)((height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y);
     const size_t cap = (size_t)capacity, A = 256, n = (size_t)P;
     size_t chunks, nb;
-    const bool prod = production_params(P, tiles, tile_culling, &chunks, &nb);
+    const int path = binning_path(P, tiles, tile_culling, &chunks, &nb);
+    const bool prod = path == 1, rankp = path == 0, old = path == 2;
+    const bool lists = tile_culling == 0 || tile_culling == 2;     // the reference-format key / point lists are materialised
+    const bool dsort = prod || rankp;                              // the splats are depth-sorted
     const size_t Q = 4 * tiles, qw = (Q + 3) / 4;
+    const size_t hist_tiles = rankp ? (size_t)GSR_RANK_HIST_TILES : (size_t)GSR_LDS_HIST_TILES;
     size_t off = align_up(sizeof(gsr::BinHeader), A);  // header + statistics slots (gsr_device.h: BinHeader)
-    o->keys = off;        off = align_up(off + (prod ? 0 : cap * 8), A);
-    o->point_list = off;  off = align_up(off + (prod ? 0 : cap * 4), A);
-    o->qlist = off;       off = align_up(off + (prod ? 0 : cap * 4 * 4), A);
+    o->keys = off;        off = align_up(off + (old || (rankp && lists) ? cap * 8 : 0), A);
+    o->point_list = off;  off = align_up(off + (old || rankp ? cap * 4 : 0), A);
+    o->qlist = off;       off = align_up(off + (!prod && lists ? cap * 4 * 4 : 0), A);
     o->qpos = off;        off = align_up(off + (prod ? cap * 4 : cap * 4 * 4), A);
     o->qcount = off;      off = align_up(off + tiles * 16, A);
     o->qstart = off;      off = align_up(off + tiles * 16, A);
@@ -199,19 +216,24 @@ int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, int32_t 
     o->tile_start = off;  off = align_up(off + (prod ? 0 : tiles * 4), A);
     o->tile_cursor = off; off = align_up(off + (prod ? 0 : tiles * 4), A);
     o->tile_order = off;  off = align_up(off + tiles * 4, A);
-    o->block_hist = off;  off = align_up(off + (prod || tiles > (size_t)GSR_LDS_HIST_TILES ? 0 : (size_t)GSR_BIN_BLOCKS * tiles * 4), A);
-    o->dkeys = off;       off = align_up(off + (prod ? n * 8 : 0), A);
-    o->dtmp = off;        off = align_up(off + (prod ? n * 8 : 0), A);
+    o->block_hist = off;  off = align_up(off + (prod || tiles > hist_tiles ? 0 : (size_t)GSR_BIN_BLOCKS * tiles * 4), A);
+    o->dkeys = off;       off = align_up(off + (dsort ? n * 8 : 0), A);
+    o->dtmp = off;        off = align_up(off + (dsort ? n * 8 : 0), A);
     o->order = off;       off = align_up(off + (prod ? n * 4 : 0), A);
-    o->bcount = off;      off = align_up(off + (prod ? nb * 4 : 0), A);
-    o->bstart = off;      off = align_up(off + (prod ? nb * 4 : 0), A);
-    o->bcursor = off;     off = align_up(off + (prod ? nb * 4 : 0), A);
+    o->bcount = off;      off = align_up(off + (dsort ? nb * 4 : 0), A);
+    o->bstart = off;      off = align_up(off + (dsort ? nb * 4 : 0), A);
+    o->bcursor = off;     off = align_up(off + (dsort ? nb * 4 : 0), A);
     o->border = off;      off = align_up(off + (prod ? nb * 4 : 0), A);
-    o->bhist = off;       off = align_up(off + (prod ? (size_t)GSR_BIN_BLOCKS * nb * 4 : 0), A);
+    o->bhist = off;       off = align_up(off + (dsort ? (size_t)GSR_BIN_BLOCKS * nb * 4 : 0), A);
     o->qhist = off;       off = align_up(off + (prod ? chunks * qw * 4 : 0), A);
     o->qprefix = off;     off = align_up(off + (prod ? chunks * Q * 4 : 0), A);
     o->qmask = off;       off = align_up(off + (prod ? n * GSR_WALK_MASKS * 8 : 0), A);
-    o->path = prod ? 1 : 0;
+    o->ranks = off;       off = align_up(off + (rankp ? cap * 8 : 0), A);
+    o->rank = off;        off = align_up(off + (rankp ? n * 4 : 0), A);
+    o->srect = off;       off = align_up(off + (rankp ? n * 8 : 0), A);
+    o->sspan = off;       off = align_up(off + (rankp ? n * 32 : 0), A);
+    o->pstat = off;       off = align_up(off + (rankp ? ((n + 255) / 256) * 8 : 0), A);
+    o->path = (size_t)path;
     o->chunks = chunks;
     o->nb = nb;
     o->total = off + A;
@@ -308,6 +330,12 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     pa.hdr = hdr;
     pa.bcount = (uint32_t*)(b + bl.bcount);
     pa.nb = (int)bl.nb;
+    const bool rankp = bl.path == 0;                  // tiles ordered by global depth rank (gsr_rank.hip)
+    pa.bcursor = (uint32_t*)(b + bl.bcursor);
+    pa.pstat = rankp ? (uint2*)(b + bl.pstat) : nullptr;
+    pa.srect = (ushort4*)(b + bl.srect);
+    pa.sspan = (float4*)(b + bl.sspan);
+    pa.cull = settings->tile_culling != 0;
     const int pblocks = (P + 255) / 256;
     if (pblocks > 0) {
         TIMED(GSR_K_PREPROCESS, stream);
@@ -384,8 +412,69 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
             hipLaunchKernelGGL(gsr::k_qscatter, dim3(walk_blocks), dim3(64), walk_lds, stream, qa);
             KERNEL_CHECK("k_qscatter", stream, dbg);
         }
+    } else if (rankp) {
+        // ---- rank path: depth-rank the splats once, order every tile's instances through an LDS bitmap (gsr_rank.hip) ----
+        const uint32_t nb = (uint32_t)bl.nb;
+        const int bin_blocks = pblocks < GSR_BIN_BLOCKS ? pblocks : GSR_BIN_BLOCKS;
+        const bool direct = tiles > GSR_RANK_HIST_TILES;
+        const size_t hist_bytes = direct ? 0 : (size_t)tiles * sizeof(uint32_t);
+        const size_t count_lds = (size_t)nb * 4 + hist_bytes;
+        if (count_lds > 48 * 1024) {
+            HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_rcount, hipFuncAttributeMaxDynamicSharedMemorySize, (int)count_lds));
+        }
+        if (hist_bytes > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_rscatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+        uint32_t* block_hist = (uint32_t*)(b + bl.block_hist);
+        uint32_t* bcount = (uint32_t*)(b + bl.bcount);
+        uint32_t* bstart = (uint32_t*)(b + bl.bstart);
+        uint32_t* bcursor = (uint32_t*)(b + bl.bcursor);
+        uint32_t* bhist = (uint32_t*)(b + bl.bhist);
+        unsigned long long* dkeys = (unsigned long long*)(b + bl.dkeys);
+        unsigned long long* dtmp = (unsigned long long*)(b + bl.dtmp);
+        uint32_t* rank = (uint32_t*)(b + bl.rank);
+        uint2* ranks = (uint2*)(b + bl.ranks);
+        ushort4* srect = (ushort4*)(b + bl.srect);
+        uint32_t* tile_start = (uint32_t*)(b + bl.tile_start);
+        uint32_t* tile_cursor = (uint32_t*)(b + bl.tile_cursor);
+        uint2* ranges = (uint2*)(b + bl.ranges);
+        if (pblocks > 0) {
+            TIMED(GSR_K_COUNT, stream);
+            hipLaunchKernelGGL(gsr::k_rcount, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), count_lds, stream, P, gx, tiles,
+                               pblocks, nb, (const ushort4*)srect, (const uint32_t*)pa.tiles_touched,
+                               (const float*)pa.depths, (const uint2*)pa.pstat, tile_count, rect_total, block_hist, bcount, bhist, hdr);
+            KERNEL_CHECK("k_rcount", stream, dbg);
+        }
+        {
+            TIMED(GSR_K_DEPTH_SORT, stream);
+            if (pblocks > 0)
+                hipLaunchKernelGGL(gsr::k_rdscatter, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), (size_t)nb * 4, stream, P, nb, (const ushort4*)srect,
+                                   (const float*)pa.depths, hdr, (const uint32_t*)bcount, bstart, bcursor, dkeys, (const uint32_t*)bhist);
+            // workgroup 0 scans the tile counters and posts the instance count; launched even when P == 0
+            hipLaunchKernelGGL(gsr::k_rdsort, dim3(1 + (pblocks > 0 ? nb : 0u)), dim3(256), 0, stream, (const uint32_t*)bcount,
+                               (const uint32_t*)bstart, dkeys, dtmp, rank, tiles, (const uint32_t*)tile_count, tile_start, tile_cursor,
+                               ranges, tile_order, total_dev, slot_dev, seq);
+            KERNEL_CHECK("k_rdsort", stream, dbg);
+        }
+        if (pblocks > 0) {
+            TIMED(GSR_K_SCATTER, stream);
+            hipLaunchKernelGGL(gsr::k_rscatter, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), hist_bytes, stream, P, gx, tiles, (const ushort4*)srect,
+                               (const uint32_t*)rank, (const float4*)pa.sspan, (const uint32_t*)tile_start, tile_cursor, ranks, cap,
+                               (const unsigned long long*)total_dev, (const uint32_t*)block_hist);
+            KERNEL_CHECK("k_rscatter", stream, dbg);
+        }
+        {
+            TIMED(GSR_K_TILE_SORT, stream);
+            // the bitmap holds every rank of the frame (P bounds the ranked splats; binning_path() keeps P <= GSR_RANK_MAX_SPLATS here)
+            const uint32_t words = (uint32_t)(((size_t)P + 2047) / 2048) * 64u;
+            hipLaunchKernelGGL(gsr::k_tile_rank, dim3(tiles), dim3(256), (size_t)words * 6, stream, words, (const uint32_t*)tile_order,
+                               (const uint32_t*)tile_count, (const uint32_t*)tile_start, (const uint2*)ranks, (const float*)pa.depths,
+                               (const gsr::BinHeader*)hdr, write_lists ? (unsigned long long*)(b + bl.keys) : nullptr,
+                               (uint32_t*)(b + bl.point_list), write_lists ? qlist : nullptr, qpos, qcount, qstart,
+                               cap, (const unsigned long long*)total_dev);
+            KERNEL_CHECK("k_tile_rank", stream, dbg);
+        }
     } else {
-    // binning workgroups: each owns a contiguous chunk of splats and an LDS histogram over the tiles
+    // round 1's per-tile bitonic sort (tile_culling 5).  Binning workgroups: each owns a contiguous chunk of splats and an LDS histogram over the tiles
     const int bin_blocks = pblocks < GSR_BIN_BLOCKS ? pblocks : GSR_BIN_BLOCKS;
     uint32_t* block_hist = (uint32_t*)(b + bl.block_hist);
     // (grids beyond GSR_LDS_HIST_TILES tiles -- past ~3200x3200 px -- fall back to per-instance L2 atomics)

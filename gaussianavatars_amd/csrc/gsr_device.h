@@ -25,6 +25,13 @@
                                  // Resolution 2^-58 of the bound: a screen-filling splat's 10^5 partials, whose sum is ~10^-6 of its bound,
                                  // still come out at 10^-8 relative (at 46 bits the 3300 x 3300 test scene was off by 3e-3).
 #define GSR_LDS_HIST_TILES 40960 // 160 KB of LDS / 4 B: the largest tile grid k_count / k_scatter privatise
+#define GSR_RANK_MAX_BUCKETS 4096 // depth buckets of the rank path (16 KB of LDS beside the tile histogram)
+#define GSR_RANK_HIST_TILES (GSR_LDS_HIST_TILES - GSR_RANK_MAX_BUCKETS)   // the largest tile grid k_rcount / k_rscatter privatise
+#define GSR_RANK_IDX_BITS 28      // a tile-list entry of the rank path is (rank, splat | quadrant mask << 28)
+#define GSR_RANK_MAX_SPLATS 262144 // splat count up to which the rank path is taken (8192 bitmap words per tile, one pass)
+#define GSR_RANK_WINDOW 4096     // k_tile_rank: entries of the sorted list per epilogue round (16 per thread)
+#define GSR_RANK_GROUP 16         // lanes that expand one splat's tile rect together in k_rcount / k_rscatter (4 splats per wave at a time)
+#define GSR_RANK_BIN_THREADS 1024 // threads per workgroup of k_rcount / k_rdscatter / k_rscatter (<= GSR_BIN_BLOCKS workgroups: 16 waves each keep the SIMDs busy)
 
 namespace gsr {
 
@@ -158,6 +165,19 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return mx(mx(a, b), mx(c, d));
 }
 
+// inclusive prefix sum across the 64 lanes in six DPP adds (row_shr inside the rows of 16, then the row totals broadcast to the
+// rows above): no LDS crossbar round trips (ds_bpermute), which is what __shfl_up costs per step
+__device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // ---- tile-rect expansion shared by the counting and the scatter pass ------------------------
 // Calls f(tile_id, k) for every tile of the rect.  Splats touching <= SMALL tiles are expanded by
 // their own lane; larger ones are expanded cooperatively by the whole wave (one splat at a time,
@@ -207,6 +227,45 @@ __device__ __forceinline__ bool rect_reach(const Reach& r, float x0, float y0, f
     return mn * 0.999f - 1e-3f <= r.tau;
 }
 
+// The same question per 8-pixel BAND, which is what the quadrant streams ask (one answer per band serves every quadrant of it):
+// the x-extent [xl, xr] of {Q <= T} over the rows of pixel centres y0 .. y0 + 7.  The extreme of dx over the band sits where the
+// ellipse's own extreme point (dx_m, dyr), dyr = -(B/C) dx_m, is clamped into the band: on the line dy = b,
+//     A dx^2 + 2 B b dx + C b^2 - 2 T = 0   =>   dx = (-B b +- sqrt(2 T A - det b^2)) / A,
+// real iff the line meets the ellipse.  T = (tau + 1e-3) / 0.999 carries rect_reach's padding, the interval another 1e-2 px.
+struct Span {
+    float px, py, B, det, twoTA, invA, dyr;
+    int mode;   // as Reach: 0 test, 1 keep everywhere, 2 never
+};
+__device__ __forceinline__ Span span_of(const Reach& r)
+{
+    Span s;
+    s.px = r.px; s.py = r.py; s.B = r.B; s.mode = r.mode;
+    s.det = 0.f; s.twoTA = 0.f; s.invA = 0.f; s.dyr = 0.f;
+    if (r.mode) return s;
+    const float T = (r.tau + 1e-3f) / 0.999f;
+    s.det = r.A * r.C - r.B * r.B;
+    s.twoTA = 2.f * T * r.A;
+    s.invA = 1.f / r.A;
+    s.dyr = r.nBiC * sqrtf(2.f * T * r.C / s.det);
+    if (!(fabsf(s.dyr) < 1e15f && s.twoTA < 1e30f && s.invA < 1e30f && s.det > 0.f)) s.mode = 1;   // degenerate: keep everywhere
+    return s;
+}
+struct Band { float xl, xr; };   // pixel centres x of the band the ellipse can reach: xl <= x <= xr (empty: xl > xr)
+__device__ __forceinline__ Band band_of(const Span& s, float y0)
+{
+    const float big = 3.0e38f;
+    Band e;
+    if (s.mode) { e.xl = s.mode == 1 ? -big : big; e.xr = s.mode == 1 ? big : -big; return e; }
+    const float b0 = y0 - s.py, b1 = b0 + 7.f;
+    const float br = fminf(fmaxf(s.dyr, b0), b1), bl = fminf(fmaxf(-s.dyr, b0), b1);
+    const float dr = s.twoTA - s.det * br * br, dl = s.twoTA - s.det * bl * bl;
+    const bool any = dr >= 0.f && dl >= 0.f;
+    e.xr = any ? s.px + (sqrtf(dr) - s.B * br) * s.invA + 1e-2f : -big;
+    e.xl = any ? s.px - (sqrtf(dl) + s.B * bl) * s.invA - 1e-2f : big;
+    return e;
+}
+__device__ __forceinline__ bool band_hit(const Band& e, float x0) { return e.xl <= x0 + 7.f && e.xr >= x0; }   // quadrant of pixel centres x0 .. x0 + 7
+
 // Snug tile rect (GsrSettings.tile_culling): the axis-aligned bounding box of the {alpha >= 1/255} ellipse
 //   |dx| <= sqrt(2 tau C / det),  |dy| <= sqrt(2 tau A / det),  det = A C - B^2
 // intersected with the reference's 3-sigma rect.  A tile column tx holds pixel centres 16 tx .. 16 tx + 15, so it is
@@ -225,6 +284,18 @@ __device__ __forceinline__ void snug_rect(const Reach& r, int& minx, int& miny, 
     minx = max(minx, lox); maxx = min(maxx, hix);
     miny = max(miny, loy); maxy = min(maxy, hiy);
     n = (maxx > minx && maxy > miny) ? (uint32_t)((maxx - minx) * (maxy - miny)) : 0u;
+}
+
+// Which of the tile's four 8x8 quadrants can the splat's {alpha >= 1/255} ellipse reach?  (bit q set = keep)
+// Same test as the tile-level one (rect_reach, gsr_device.h), on the quadrant's rectangle of pixel centres.
+__device__ __forceinline__ uint32_t quadrant_mask_of(const Span& s, float ox, float oy)
+{
+    const Band e0 = band_of(s, oy), e1 = band_of(s, oy + 8.f);
+    return (band_hit(e0, ox) ? 1u : 0u) | (band_hit(e0, ox + 8.f) ? 2u : 0u) | (band_hit(e1, ox) ? 4u : 0u) | (band_hit(e1, ox + 8.f) ? 8u : 0u);
+}
+__device__ __forceinline__ uint32_t quadrant_mask(float2 p, float4 co, float ox, float oy)
+{
+    return quadrant_mask_of(span_of(reach_of(p.x, p.y, co.x, co.y, co.z, co.w)), ox, oy);
 }
 
 template <typename F>
@@ -381,6 +452,12 @@ struct PreprocessArgs {
     BinHeader* __restrict__ hdr;          // zeroed by the API before this kernel; statistics accumulated here
     uint32_t* __restrict__ bcount;        // [nb] depth-bucket histogram, zeroed here
     int nb;
+    // rank path (gsr_rank.hip); pstat == nullptr otherwise
+    uint32_t* __restrict__ bcursor;       // [nb] bucket fill cursors, zeroed here
+    uint2* __restrict__ pstat;            // [workgroups] (min, max) depth bits of this workgroup's visible splats; (~0, 0) when it has none
+    ushort4* __restrict__ srect;          // [P] tile rect the splat is binned into (snug when cull != 0); zero area = not binned
+    float4* __restrict__ sspan;           // [P][2] the splat's Span (px, py, B, det | twoTA, invA, dyr, mode): operands of the quadrant test
+    int cull;                             // settings.tile_culling != 0
 };
 
 struct PreBwdArgs {
@@ -450,6 +527,21 @@ __device__ __forceinline__ int splat_sum_exponents(uint32_t tiles, float conA, f
     return min(max(ea, 0), 127) | (min(max(eb, 0), 127) << 8);
 }
 __global__ void k_preprocess_bwd(Settings s, PreBwdArgs a);
+// rank path (gsr_rank.hip)
+__global__ void k_rcount(int P, int gx, int tiles, int pblocks, uint32_t nb, const ushort4* srect, const uint32_t* tiles_touched,
+                         const float* depths, const uint2* pstat, uint32_t* tile_count, unsigned long long* rect_total, uint32_t* block_hist,
+                         uint32_t* bcount, uint32_t* bhist, BinHeader* hdr);
+__global__ void k_rdscatter(int P, uint32_t nb, const ushort4* srect, const float* depths, BinHeader* hdr, const uint32_t* bcount, uint32_t* bstart,
+                            uint32_t* bcursor, unsigned long long* dkeys, const uint32_t* bhist);
+__global__ void k_rdsort(const uint32_t* bcount, const uint32_t* bstart, unsigned long long* dkeys, unsigned long long* tmp,
+                         uint32_t* rank, int tiles, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, uint2* ranges,
+                         uint32_t* tile_order, unsigned long long* total_dev, unsigned long long* mailbox, unsigned long long seq);
+__global__ void k_rscatter(int P, int gx, int tiles, const ushort4* srect, const uint32_t* rank, const float4* sspan, const uint32_t* tile_start,
+                           uint32_t* tile_cursor, uint2* ranks, unsigned long long capacity, const unsigned long long* total_dev, const uint32_t* block_hist);
+__global__ void k_tile_rank(uint32_t words, const uint32_t* tile_order, const uint32_t* tile_count, const uint32_t* tile_start, const uint2* ranks,
+                            const float* depths, const BinHeader* hdr, unsigned long long* keys, uint32_t* point_list,
+                            uint32_t* qlist, uint32_t* qpos, uint32_t* qcount, uint32_t* qstart, unsigned long long capacity,
+                            const unsigned long long* total_dev);
 // production binning (gsr_binning.hip)
 __global__ void k_dbucket(int P, const uint32_t* brec_rect, const float* depths, BinHeader* hdr, uint32_t nb, uint32_t* bcount, uint32_t* bhist);
 __global__ void k_dscan(uint32_t nb, const uint32_t* bcount, uint32_t* bstart, uint32_t* bcursor, uint32_t* border, BinHeader* hdr);

@@ -40,6 +40,8 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         // this frame's tile histogram starts at zero (k_count runs after this kernel)
         for (int t = i; t < a.tiles; t += (int)(gridDim.x * blockDim.x)) a.tile_count[t] = 0u;
         if (i == 0) *a.rect_total = 0ull;
+        if (a.pstat)   // rank path: the depth-bucket histogram and its fill cursors start at zero as well
+            for (int t = i; t < a.nb; t += (int)(gridDim.x * blockDim.x)) { a.bcount[t] = 0u; a.bcursor[t] = 0u; }
     }
 
     bool visible = false;
@@ -231,6 +233,33 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
             }
         }
     }
+    if (a.pstat) {
+        // ---- rank path: this workgroup's depth range (plain stores, one pair per workgroup; k_rcount folds them)
+        __shared__ uint32_t ps_mn[4], ps_mx[4];
+        const uint32_t dbits = __float_as_uint(depth);
+        const uint32_t mn_inv = wave_max_u32(visible ? ~dbits : 0u), mx = wave_max_u32(visible ? dbits : 0u);
+        if ((threadIdx.x & 63) == 0) { ps_mn[threadIdx.x >> 6] = mn_inv; ps_mx[threadIdx.x >> 6] = mx; }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            a.pstat[blockIdx.x] = make_uint2(~max(max(ps_mn[0], ps_mn[1]), max(ps_mn[2], ps_mn[3])), max(max(ps_mx[0], ps_mx[1]), max(ps_mx[2], ps_mx[3])));
+        // the tile rect this splat is binned into (snug in the culling modes) and the operands of the per-quadrant reach test
+        // (gsr_device.h: band_of): computed here, once per splat, for the two binning passes that expand the rect
+        if (i < a.P) {
+            uint32_t nt = 0;
+            int minx = rminx, miny = rminy, maxx = rmaxx, maxy = rmaxy;
+            if (visible) {
+                nt = (uint32_t)((rmaxx - rminx) * (rmaxy - rminy));
+                const Reach r = reach_of(px, py, con0, con1, con2, opac);
+                if (a.cull) snug_rect(r, minx, miny, maxx, maxy, nt);
+                if (nt) {
+                    const Span sp = span_of(r);
+                    a.sspan[2 * i + 0] = make_float4(sp.px, sp.py, sp.B, sp.det);
+                    a.sspan[2 * i + 1] = make_float4(sp.twoTA, sp.invA, sp.dyr, __int_as_float(sp.mode));
+                }
+            }
+            a.srect[i] = nt ? make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy) : make_ushort4(0, 0, 0, 0);
+        }
+    }
     if (a.brec) {
         // ---- binning record: operands of the exact reach test and the quadrant rect to run it on (= 2 x the snug TILE rect, so that
         // the streams hold exactly what the parity path's per-tile epilogue keeps), plus the frame statistics of the binned splats
@@ -241,11 +270,11 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
             int minx = rminx, miny = rminy, maxx = rmaxx, maxy = rmaxy;
             snug_rect(r, minx, miny, maxx, maxy, nt);
             if (nt) {
-                if (r.mode == 1) { r.A = 0.f; r.B = 0.f; r.C = 0.f; r.tau = 1.f; r.nBiC = 0.f; r.nBiA = 0.f; }   // never rejects
+                const Span sp = span_of(r);   // what the per-quadrant test of the binning walk needs (gsr_device.h: band_of)
                 r0 = (uint32_t)(2 * minx) | ((uint32_t)(2 * miny) << 16);
                 r1 = (uint32_t)(2 * maxx) | ((uint32_t)(2 * maxy) << 16);
-                a.brec[3 * i + 0] = make_float4(r.px, r.py, r.A, r.B);
-                a.brec[3 * i + 1] = make_float4(r.C, r.tau, r.nBiC, r.nBiA);
+                a.brec[3 * i + 0] = make_float4(sp.px, sp.py, sp.B, sp.det);
+                a.brec[3 * i + 1] = make_float4(sp.twoTA, sp.invA, sp.dyr, __int_as_float(sp.mode));
             }
         }
         if (i < a.P) a.brec[3 * i + 2] = make_float4(__uint_as_float(r0), __uint_as_float(r1), 0.f, 0.f);
@@ -481,19 +510,6 @@ template __global__ void k_scatter<false>(int, int, int, const float*, const ush
                                           unsigned long long*, unsigned long long, const unsigned long long*, const uint32_t*);
 template __global__ void k_scatter<true>(int, int, int, const float*, const ushort4*, const uint32_t*, const float4*, const uint32_t*, uint32_t*,
                                          unsigned long long*, unsigned long long, const unsigned long long*, const uint32_t*);
-
-// Which of the tile's four 8x8 quadrants can the splat's {alpha >= 1/255} ellipse reach?  (bit q set = keep)
-// Same test as the tile-level one (rect_reach, gsr_device.h), on the quadrant's rectangle of pixel centres.
-__device__ __forceinline__ uint32_t quadrant_mask(float2 p, float4 co, float ox, float oy)
-{
-    const Reach r = reach_of(p.x, p.y, co.x, co.y, co.z, co.w);
-    if (r.mode) return r.mode == 1 ? 0xFu : 0u;
-    uint32_t m = 0u;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        m |= rect_reach(r, ox + (float)((q & 1) * 8), oy + (float)((q >> 1) * 8), 7.f, 7.f) ? (1u << q) : 0u;
-    return m;
-}
 
 // Epilogue for the register-sorted classes.  The sorted keys are first laid out in LDS in natural order so
 // that thread t handles entries c*THREADS + t (c = 0..7): consecutive lanes own consecutive entries and

@@ -1,0 +1,570 @@
+// gsr_rank.hip -- per-tile ordering by global depth RANK (gfx950, wave64): the per-tile sort path without a per-tile sort.
+//
+// The reference orders every (splat, tile) instance by (tile, depth) with one radix sort over all instances (A.2); round 1
+// sorted each tile's 64-bit (depth, splat) keys in LDS with a bitonic network.  The order inside a tile is only the SPLATS'
+// (depth, index) order restricted to the tile, so here the splats are ranked once (P keys, 17x fewer than instances) and a
+// tile orders its instances by setting bit `rank` in an LDS bitmap and reading the bitmap back in order -- no comparisons:
+//
+//   k_rcount    per chunk  : tile-instance histogram (as round 1's k_count) + depth-bucket histogram of the binned splats,
+//                            snug tile rect of every splat kept for the two scatters
+//   k_rdscatter per chunk  : bucket offsets (every workgroup scans the nb counters itself), (depth bits << 32 | splat) into buckets
+//   k_rdsort    per bucket : register bitonic sort (gsr_sort.h) -> rank[splat];
+//               + 1 WG     : exclusive scan of the tile counters, heavy-first tile order, instance count posted to the host
+//   k_rscatter  per chunk  : (rank[splat], splat) into every tile segment the splat's snug rect covers (8 bytes per instance)
+//   k_tile_rank per tile   : bitmap of the tile's ranks in LDS (ds_or), word popcounts scanned; an entry's position in the sorted
+//                            list is the number of set bits below its own; then the four 8x8-quadrant streams exactly as round
+//                            1's sort epilogue wrote them (stable compaction of the entries whose ellipse reaches the quadrant)
+//
+// Lists come out identical to a (depth, index) sort per tile: ranks are unique, and rank order IS (depth, index) order.
+#include "gsr_device.h"
+#include "gsr_sort.h"
+
+namespace gsr {
+
+__device__ __forceinline__ uint32_t rank_bucket(float depth, float lo, float scale, uint32_t nb)
+{
+    const int b = f2i_sat((depth - lo) * scale);
+    return (uint32_t)min(max(b, 0), (int)nb - 1);
+}
+__device__ __forceinline__ void rank_bucket_map(uint32_t dmin_bits, uint32_t dmax_bits, uint32_t nb, float& lo, float& scale)
+{
+    lo = __uint_as_float(dmin_bits);
+    const float span = __uint_as_float(dmax_bits) - lo;
+    scale = span > 0.f ? (float)nb * 0.99999f / span : 0.f;   // every depth of the frame lands in [0, nb); monotone in depth
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return ~wave_max_u32(~v); }
+
+// Expansion of a splat's tile rect shared by the counting and the scatter pass: GSR_RANK_GROUP lanes take one splat together
+// (lanes striding its tiles), i.e. 4 splats per wave at a time -- a splat per lane leaves 100 k splats at one wave per SIMD and the
+// pass latency-bound.  Rects beyond BIG tiles are expanded by the whole wave, one splat at a time, so that a screen-filling splat
+// does not serialise one group for thousands of iterations.  Must be called by all 64 lanes; every lane of a group passes the same
+// rect (n == 0 for idle groups).  f(x, y, src_lane): src_lane = the lane whose splat this tile belongs to (lane of its group).
+template <typename F>
+__device__ __forceinline__ void for_each_tile_grouped(int minx, int miny, int maxx, int maxy, uint32_t n, F f)
+{
+    constexpr uint32_t BIG = 256;
+    const int lane = lane_id(), sub = lane & (GSR_RANK_GROUP - 1);
+    if (n > 0 && n <= BIG) {
+        const uint32_t w = (uint32_t)(maxx - minx);
+        const float rw = __builtin_amdgcn_rcpf((float)w);      // k / w = floor((k + 0.5) * (1 / w)): exact for k < 2^15
+        for (uint32_t k = (uint32_t)sub; k < n; k += GSR_RANK_GROUP) {
+            const uint32_t row = (uint32_t)(((float)k + 0.5f) * rw);
+            f((uint32_t)minx + k - row * w, (uint32_t)miny + row, lane);
+        }
+    }
+    uint64_t big = __ballot(n > BIG && sub == 0);
+    while (big) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        const uint32_t bminx = (uint32_t)__builtin_amdgcn_readlane(minx, src), bminy = (uint32_t)__builtin_amdgcn_readlane(miny, src);
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane(maxx, src) - bminx, bn = (uint32_t)__builtin_amdgcn_readlane((int)n, src);
+        for (uint32_t k = (uint32_t)lane; k < bn; k += GSR_WAVE) f(bminx + k % w, bminy + k / w, src);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rcount: <= GSR_BIN_BLOCKS workgroups, each a contiguous chunk of splats.  Tile histogram and depth-bucket histogram in
+// LDS (ds_add, no return); only non-empty bins go to the global counters; both per-workgroup histograms are kept for the
+// scatters (same chunking).  The rect of every splat comes from k_preprocess (srect: snug in the culling modes).
+// The frame's depth range comes from k_preprocess's per-workgroup (min, max) pairs: no atomics, nothing to zero.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int P, int gx, int tiles, int pblocks, uint32_t nb, const ushort4* __restrict__ srect,
+                                                                  const uint32_t* __restrict__ tiles_touched, const float* __restrict__ depths,
+                                                                  const uint2* __restrict__ pstat, uint32_t* __restrict__ tile_count,
+                                                                  unsigned long long* __restrict__ rect_total, uint32_t* __restrict__ block_hist,
+                                                                  uint32_t* __restrict__ bcount, uint32_t* __restrict__ bhist,
+                                                                  BinHeader* __restrict__ hdr)
+{
+    extern __shared__ uint32_t lds[];
+    uint32_t* const dh = lds;            // [nb] depth buckets
+    uint32_t* const hist = lds + nb;     // [tiles] (absent beyond GSR_RANK_HIST_TILES)
+    constexpr int NT = GSR_RANK_BIN_THREADS, NWV = NT / 64, G = GSR_RANK_GROUP;
+    __shared__ unsigned long long rect_sum[NWV];
+    __shared__ uint32_t s_mn[NWV], s_mx[NWV];
+    const int tid = threadIdx.x;
+    const bool direct = tiles > GSR_RANK_HIST_TILES;
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    for (int j = tid; j < pblocks; j += NT) {
+        const uint2 v = pstat[j];
+        mn = min(mn, v.x);
+        mx = max(mx, v.y);
+    }
+    mn = wave_min_u32(mn);
+    mx = wave_max_u32(mx);
+    if ((tid & 63) == 0) { s_mn[tid >> 6] = mn; s_mx[tid >> 6] = mx; }
+    for (uint32_t t = tid; t < nb; t += NT) dh[t] = 0u;
+    if (!direct)
+        for (int t = tid; t < tiles; t += NT) hist[t] = 0u;
+    __syncthreads();
+    mn = s_mn[0]; mx = s_mx[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) { mn = min(mn, s_mn[w]); mx = max(mx, s_mx[w]); }
+    if (mn > mx) { mn = 0u; mx = 0u; }   // nothing visible
+    if (blockIdx.x == 0 && tid == 0) { hdr->dmin_bits = mn; hdr->dmax_bits = mx; }
+    float lo, scale;
+    rank_bucket_map(mn, mx, nb, lo, scale);
+
+    const int chunk = ((P + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
+    const int begin = blockIdx.x * chunk;
+    const int end = min(P, begin + chunk);
+    unsigned long long touched = 0;
+    for (int base = begin; base < end; base += NT / G) {
+        const int i = base + tid / G;
+        uint32_t n = 0;
+        int minx = 0, miny = 0, maxx = 0, maxy = 0;
+        if (i < end) {
+            const ushort4 r = srect[i];
+            minx = r.x; miny = r.y; maxx = r.z; maxy = r.w;
+            n = (uint32_t)((maxx - minx) * (maxy - miny));
+            if ((tid & (G - 1)) == 0) {
+                touched += tiles_touched[i];
+                if (n) atomicAdd(&dh[rank_bucket(depths[i], lo, scale, nb)], 1u);
+            }
+        }
+        if (direct)
+            for_each_tile_grouped(minx, miny, maxx, maxy, n, [=](uint32_t x, uint32_t y, int) { atomicAdd(&tile_count[y * (uint32_t)gx + x], 1u); });
+        else
+            for_each_tile_grouped(minx, miny, maxx, maxy, n, [=](uint32_t x, uint32_t y, int) { atomicAdd(&hist[y * (uint32_t)gx + x], 1u); });
+    }
+    // the rect-based instance count (the reference's num_rendered) is kept beside the culled one: sum of tiles_touched
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) touched += __shfl_xor(touched, d, 64);
+    if ((tid & 63) == 0) rect_sum[tid >> 6] = touched;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long tot = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) tot += rect_sum[w];
+        atomicAdd(rect_total, tot);
+    }
+    uint32_t* __restrict__ bmine = bhist + (size_t)blockIdx.x * nb;
+    for (uint32_t t = tid; t < nb; t += NT) {
+        const uint32_t v = dh[t];
+        bmine[t] = v;
+        if (v) atomicAdd(&bcount[t], v);
+    }
+    if (direct) return;
+    uint32_t* __restrict__ mine = block_hist + (size_t)blockIdx.x * tiles;
+    for (int t = tid; t < tiles; t += NT) {
+        const uint32_t v = hist[t];
+        mine[t] = v;
+        if (v) atomicAdd(&tile_count[t], v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rdscatter: same chunking.  Every workgroup scans the nb bucket counters itself (nb <= GSR_RANK_MAX_BUCKETS: a few
+// microseconds, no separate one-workgroup launch), reserves one sub-range per non-empty bucket of its own histogram with a
+// single returning L2 atomic, then hands out slots from LDS cursors.  Workgroup 0 publishes the bucket offsets and the number
+// of ranked splats.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rdscatter(int P, uint32_t nb, const ushort4* __restrict__ srect, const float* __restrict__ depths,
+                                                    BinHeader* __restrict__ hdr, const uint32_t* __restrict__ bcount,
+                                                    uint32_t* __restrict__ bstart, uint32_t* __restrict__ bcursor,
+                                                    unsigned long long* __restrict__ dkeys, const uint32_t* __restrict__ bhist)
+{
+    extern __shared__ uint32_t base[];   // [nb]
+    constexpr int NT = GSR_RANK_BIN_THREADS, NWV = NT / 64;
+    __shared__ uint32_t wave_tot[NWV];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t per = (nb + (uint32_t)NT - 1u) / (uint32_t)NT;   // consecutive counters per thread
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < per; ++k) {
+        const uint32_t t = (uint32_t)tid * per + k;
+        sum += t < nb ? bcount[t] : 0u;
+    }
+    const uint32_t incl = wave_scan_incl_u32(sum);
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wid; ++w) run += wave_tot[w];
+    const uint32_t* __restrict__ mine = bhist + (size_t)blockIdx.x * nb;
+    for (uint32_t k = 0; k < per; ++k) {
+        const uint32_t t = (uint32_t)tid * per + k;
+        if (t < nb) {
+            const uint32_t c = bcount[t];
+            if (blockIdx.x == 0) bstart[t] = run;
+            const uint32_t v = mine[t];
+            base[t] = v ? run + atomicAdd(&bcursor[t], v) : 0u;
+            run += c;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) tot += wave_tot[w];
+        hdr->nvis = tot;
+    }
+    __syncthreads();
+    float lo, scale;
+    rank_bucket_map(hdr->dmin_bits, hdr->dmax_bits, nb, lo, scale);
+    const int chunk = ((P + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
+    const int begin = blockIdx.x * chunk, end = min(P, begin + chunk);
+    for (int i = begin + tid; i < end; i += NT) {
+        const ushort4 r = srect[i];
+        if (r.z == r.x) continue;   // not binned
+        const float d = depths[i];
+        const uint32_t slot = atomicAdd(&base[rank_bucket(d, lo, scale, nb)], 1u);
+        dkeys[slot] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(uint32_t)i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rdsort: workgroup 0 scans the tile counters (independent of the depth sort: it rides along instead of taking a launch of
+// its own); workgroup 1 + b sorts bucket b by (depth, splat) and writes order[] / rank[].
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tile_scan_256(int tiles, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
+                                              uint32_t* __restrict__ tile_cursor, uint2* __restrict__ ranges,
+                                              uint32_t* __restrict__ tile_order, unsigned long long* __restrict__ total_dev,
+                                              unsigned long long* mailbox, unsigned long long seq)
+{
+    __shared__ uint32_t wave_tot[4];
+    __shared__ unsigned long long carry_s;
+    __shared__ uint32_t bucket[34];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < tiles; base += 1024) {
+        const int t0 = base + 4 * tid;   // four consecutive tiles per thread
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = (t0 + k < tiles) ? tile_count[t0 + k] : 0u;
+            sum += v[k];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wid; ++w) wave_off += wave_tot[w];
+        const unsigned long long carry = carry_s;
+        uint32_t excl = (uint32_t)carry + wave_off + incl - sum;   // offsets are 32-bit like upstream's
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (t0 + k < tiles) {
+                tile_start[t0 + k] = excl;
+                tile_cursor[t0 + k] = 0u;
+                if (ranges) ranges[t0 + k] = v[k] ? make_uint2(excl, excl + v[k]) : make_uint2(0u, 0u);
+            }
+            excl += v[k];
+        }
+        __syncthreads();
+        if (tid == 255) carry_s = carry + wave_off + incl;   // 64-bit running total: a frame past 2^32 instances is reported, not wrapped
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const unsigned long long grand = carry_s;
+        *total_dev = grand;
+        // post (seq, I) to the host: one 8-byte system-scope store into mapped pinned memory
+        __hip_atomic_store(mailbox, (seq << 40) | (grand & 0xFFFFFFFFFFull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // heavy-first launch order for the per-tile kernels (pure scheduling, see round 1's k_tile_scan)
+    if (tid < 34) bucket[tid] = 0u;
+    __syncthreads();
+    auto bucket_of = [](uint32_t c) { return c ? 32u - (uint32_t)(31 - __builtin_clz(c)) - 1u : 32u; };   // big counts first, empty last
+    for (int t = tid; t < tiles; t += 256) atomicAdd(&bucket[bucket_of(tile_count[t])], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < 33; ++b) { const uint32_t c = bucket[b]; bucket[b] = run; run += c; }
+    }
+    __syncthreads();
+    for (int t = tid; t < tiles; t += 256) tile_order[atomicAdd(&bucket[bucket_of(tile_count[t])], 1u)] = (uint32_t)t;
+}
+
+__global__ __launch_bounds__(256) void k_rdsort(const uint32_t* __restrict__ bcount, const uint32_t* __restrict__ bstart,
+                                                 unsigned long long* __restrict__ dkeys, unsigned long long* __restrict__ tmp,
+                                                 uint32_t* __restrict__ rank, int tiles,
+                                                 const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
+                                                 uint32_t* __restrict__ tile_cursor, uint2* __restrict__ ranges,
+                                                 uint32_t* __restrict__ tile_order, unsigned long long* __restrict__ total_dev,
+                                                 unsigned long long* mailbox, unsigned long long seq)
+{
+    if (blockIdx.x == 0) {
+        tile_scan_256(tiles, tile_count, tile_start, tile_cursor, ranges, tile_order, total_dev, mailbox, seq);
+        return;
+    }
+    constexpr int KEYS = GSR_SORT_SMALL_KEYS, THREADS = 256, EPT = KEYS / THREADS;
+    __shared__ unsigned long long skeys[KEYS];
+    const uint32_t b = blockIdx.x - 1u;
+    const uint32_t n = bcount[b];
+    if (n == 0) return;
+    const uint32_t start = bstart[b];
+    const int tid = threadIdx.x;
+    unsigned long long* seg = dkeys + start;
+    if (n <= (uint32_t)KEYS) {
+        u64 key[EPT];
+        block_sort_regs<THREADS, EPT>(key, skeys, seg, n, tid);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const uint32_t i = (uint32_t)tid * (uint32_t)EPT + (uint32_t)k;
+            if (i < n) {
+                rank[(uint32_t)key[k]] = start + i;
+            }
+        }
+    } else {
+        oversize_sort<THREADS, EPT>(seg, tmp + start, skeys, n, tid);
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += THREADS) {
+            rank[(uint32_t)seg[i]] = start + i;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rscatter: one entry (rank, splat | quadrant mask << 28) into every tile segment of the splat's rect.  Same chunking as
+// k_rcount, whose per-workgroup tile histogram it re-uses: one returning L2 atomic per (workgroup, touched tile) reserves a
+// contiguous sub-range, slots come from LDS cursors.  Order inside a tile segment is arbitrary; the bitmap in k_tile_rank does
+// not care.  The mask says which of the tile's four 8x8 quadrants the splat's {alpha >= 1/255} ellipse can reach: evaluated
+// here from the splat's Span (k_preprocess), so that the per-tile kernel never gathers a per-splat record.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx, int tiles, const ushort4* __restrict__ srect,
+                                                                    const uint32_t* __restrict__ rank, const float4* __restrict__ sspan,
+                                                                    const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
+                                                                    uint2* __restrict__ ranks, unsigned long long capacity,
+                                                                    const unsigned long long* __restrict__ total_dev,
+                                                                    const uint32_t* __restrict__ block_hist)
+{
+    extern __shared__ uint32_t hist[];
+    constexpr int NT = GSR_RANK_BIN_THREADS, G = GSR_RANK_GROUP;
+    if (*total_dev > capacity) return;  // the host will grow the buffer and replay the frame
+    const int tid = threadIdx.x;
+    const bool direct = tiles > GSR_RANK_HIST_TILES;
+    const int chunk = ((P + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
+    const int begin = blockIdx.x * chunk;
+    const int end = min(P, begin + chunk);
+    if (!direct) {
+        const uint32_t* __restrict__ mine = block_hist + (size_t)blockIdx.x * tiles;
+        for (int t = tid; t < tiles; t += NT) {
+            const uint32_t v = mine[t];
+            hist[t] = v ? tile_start[t] + atomicAdd(&tile_cursor[t], v) : 0u;   // first slot of this workgroup in tile t
+        }
+        __syncthreads();
+    }
+    for (int base = begin; base < end; base += NT / G) {
+        const int i = base + tid / G;
+        uint32_t n = 0, rk = 0;
+        int minx = 0, miny = 0, maxx = 0, maxy = 0;
+        Span sp;
+        sp.px = sp.py = sp.B = sp.det = sp.twoTA = sp.invA = sp.dyr = 0.f;
+        sp.mode = 2;
+        if (i < end) {
+            const ushort4 q = srect[i];
+            minx = q.x; miny = q.y; maxx = q.z; maxy = q.w;
+            n = (uint32_t)((maxx - minx) * (maxy - miny));
+            if (n) {
+                rk = rank[i];
+                const float4 s0 = sspan[2 * (size_t)i], s1 = sspan[2 * (size_t)i + 1];
+                sp.px = s0.x; sp.py = s0.y; sp.B = s0.z; sp.det = s0.w;
+                sp.twoTA = s1.x; sp.invA = s1.y; sp.dyr = s1.z; sp.mode = __float_as_int(s1.w);
+            }
+        }
+        for_each_tile_grouped(minx, miny, maxx, maxy, n, [&](uint32_t x, uint32_t y, int src) {
+            const int me = lane_id();
+            Span b = sp;
+            uint32_t brk = rk, bidx = (uint32_t)i;
+            if (src != me) {   // whole-wave expansion of a large rect: the owner's operands (src is wave-uniform there)
+                auto bf = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+                b.px = bf(sp.px); b.py = bf(sp.py); b.B = bf(sp.B); b.det = bf(sp.det); b.twoTA = bf(sp.twoTA); b.invA = bf(sp.invA); b.dyr = bf(sp.dyr);
+                b.mode = __builtin_amdgcn_readlane(sp.mode, src);
+                brk = (uint32_t)__builtin_amdgcn_readlane((int)rk, src);
+                bidx = (uint32_t)__builtin_amdgcn_readlane(i, src);
+            }
+            const uint32_t tile = y * (uint32_t)gx + x;
+            const uint32_t m = quadrant_mask_of(b, (float)(x * GSR_BLOCK_X), (float)(y * GSR_BLOCK_Y));
+            // tile grids beyond the LDS histogram: one returning L2 atomic per instance
+            const uint32_t slot = direct ? tile_start[tile] + atomicAdd(&tile_cursor[tile], 1u) : atomicAdd(&hist[tile], 1u);
+            ranks[slot] = make_uint2(brk, bidx | (m << GSR_RANK_IDX_BITS));
+        });
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_tile_rank: one workgroup per tile (heaviest first), one pass (the API takes this path only while every rank of the frame
+// fits the bitmap: WORDS * 32 >= P):
+//   1. bitmap[r >> 5] |= 1 << (r & 31) for the tile's (rank, splat) entries (ds_or)
+//   2. rows of 64 words go round-robin to the waves: a wave scan of the popcounts gives every word its offset inside the row
+//      (wprefix, 16 bit), the row totals are scanned by wave 0 -> rowoff[]
+//   3. every entry computes its own position in the sorted list -- rowoff[row] + wprefix[word] + popcount(bits below its own) --
+//      and drops its splat index there: sorted[position]; GSR_RANK_WINDOW positions at a time
+//   4. epilogue, GSR_RANK_WINDOW entries at a time (striped like round 1's): the entry carries the splat's quadrant mask
+//      (k_rscatter), so no per-splat record is gathered; stable compaction into the tile's four n-slot streams with
+//      ballots + one scan of the (chunk, wave) counters; the parity modes also write the reference-format key list
+// No comparison, no data-dependent loop, every step entry-parallel.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_rank(uint32_t words, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ tile_count,
+                                                    const uint32_t* __restrict__ tile_start, const uint2* __restrict__ ranks,
+                                                    const float* __restrict__ depths, const BinHeader* __restrict__ hdr,
+                                                    unsigned long long* __restrict__ keys, uint32_t* __restrict__ point_list,
+                                                    uint32_t* __restrict__ qlist, uint32_t* __restrict__ qpos, uint32_t* __restrict__ qcount,
+                                                    uint32_t* __restrict__ qstart, unsigned long long capacity,
+                                                    const unsigned long long* __restrict__ total_dev)
+{
+    constexpr int THREADS = 256, NW = THREADS / 64, EPT = GSR_RANK_WINDOW / THREADS, NE = EPT * NW;
+    constexpr int ROWS = GSR_RANK_MAX_SPLATS / 2048, RPL = (ROWS + 63) / 64;   // rows of 64 words = 2048 ranks
+    constexpr int UB = 8;   // entries per thread whose loads are in flight together
+    static_assert(NE <= 64, "one (chunk, wave) counter per lane in the epilogue's scan");
+    static_assert(EPT % 4 == 0, "the epilogue gathers four chunks at a time");
+    extern __shared__ uint32_t bitmap[];                                   // [words] (a multiple of 64: ceil(P / 2048) rows), then
+    uint16_t* const wprefix = reinterpret_cast<uint16_t*>(bitmap + words);  // [words] set bits before the word inside its row
+    __shared__ uint32_t cntw[4][NE + 1];
+    __shared__ uint32_t rowoff[ROWS + 1];
+    if (*total_dev > capacity) return;
+    const uint32_t tile = tile_order[blockIdx.x];
+    const uint32_t n = tile_count[tile];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (n == 0) {
+        if (tid < 4) { qcount[4 * tile + tid] = 0u; qstart[4 * tile + tid] = 0u; }
+        return;
+    }
+    const uint32_t start = tile_start[tile];
+    if (tid < 4) qstart[4 * tile + tid] = 4u * start + (uint32_t)tid * n;   // the tile's four n-slot streams
+    const uint2* __restrict__ rk = ranks + start;
+    uint32_t* const qpbase = qpos + (size_t)4 * start;
+    uint32_t* const qlbase = qlist ? qlist + (size_t)4 * start : nullptr;
+    const unsigned long long tile_hi = (unsigned long long)tile << 32;
+    const uint32_t Wn = min(words, (hdr->nvis + 31u) >> 5);
+    const uint32_t rows = (Wn + 63u) >> 6;
+
+    for (uint32_t w = tid; w < rows * 64u; w += THREADS) bitmap[w] = 0u;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += UB * THREADS) {
+        uint32_t r[UB];
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            const uint32_t i = base + (uint32_t)(k * THREADS + tid);
+            r[k] = i < n ? rk[i].x : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < UB; ++k)
+            if (r[k] < Wn * 32u) atomicOr(&bitmap[r[k] >> 5], 1u << (r[k] & 31u));
+    }
+    __syncthreads();
+    for (uint32_t row = wid; row < rows; row += NW) {
+        const uint32_t w = row * 64u + (uint32_t)lane;
+        const uint32_t v = (uint32_t)__builtin_popcount(bitmap[w]);
+        const uint32_t incl = wave_scan_incl_u32(v);
+        wprefix[w] = (uint16_t)(incl - v);
+        if (lane == 63) rowoff[row] = incl;   // the row's total, scanned in place below
+    }
+    __syncthreads();
+    if (wid == 0) {   // exclusive scan of the row totals (RPL consecutive rows per lane)
+        uint32_t a[RPL], sum = 0;
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const uint32_t rr = (uint32_t)(RPL * lane + j);
+            a[j] = rr < rows ? rowoff[rr] : 0u;
+            sum += a[j];
+        }
+        const uint32_t incl = wave_scan_incl_u32(sum);
+        uint32_t acc = incl - sum;
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const uint32_t rr = (uint32_t)(RPL * lane + j);
+            if (rr < rows) rowoff[rr] = acc;
+            acc += a[j];
+        }
+        if (lane == 63) rowoff[ROWS] = incl;
+    }
+    __syncthreads();
+    const uint32_t total = rowoff[ROWS];   // == n (ranks are unique)
+    uint32_t run[4] = {0u, 0u, 0u, 0u};
+
+    // ---- 3. every entry finds its position and drops its splat index there: the tile's sorted list, in global memory (the
+    //         reference's point_list; the same workgroup reads it back below, coalesced) ----
+    uint32_t* const sorted = point_list + start;
+    for (uint32_t base = 0; base < n; base += UB * THREADS) {
+        uint2 e[UB];
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            const uint32_t i = base + (uint32_t)(k * THREADS + tid);
+            e[k] = i < n ? rk[i] : make_uint2(0xFFFFFFFFu, 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            if (e[k].x < Wn * 32u) {
+                const uint32_t w = e[k].x >> 5;
+                const uint32_t below = bitmap[w] & ((1u << (e[k].x & 31u)) - 1u);
+                sorted[rowoff[w >> 6] + (uint32_t)wprefix[w] + (uint32_t)__builtin_popcount(below)] = e[k].y;
+            }
+        }
+    }
+    __syncthreads();   // (global stores of this workgroup are visible to it after the barrier)
+    for (uint32_t win_lo = 0; win_lo < total; win_lo += (uint32_t)GSR_RANK_WINDOW) {
+        const uint32_t m = min((uint32_t)GSR_RANK_WINDOW, total - win_lo);
+        // ---- 4. epilogue over entries i0 .. i0 + m of the tile's list ----
+        const uint32_t i0 = win_lo;
+        uint32_t msk[EPT], rnk[EPT], sid[EPT];
+#pragma unroll
+        for (int h = 0; h < EPT / 4; ++h) {
+            if ((uint32_t)(4 * h * THREADS) >= m) {   // workgroup-uniform: nothing left in this window
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    msk[4 * h + k] = 0u; rnk[4 * h + k] = 0u; sid[4 * h + k] = 0u;
+                    if (lane < 4) cntw[lane][(4 * h + k) * NW + wid] = 0u;
+                }
+                continue;
+            }
+            uint32_t ent[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t j = (uint32_t)(4 * h + k) * THREADS + (uint32_t)tid;
+                ent[k] = j < m ? sorted[i0 + j] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = 4 * h + k;
+                const uint32_t j = (uint32_t)c * THREADS + (uint32_t)tid;
+                const uint32_t idx = ent[k] & ((1u << GSR_RANK_IDX_BITS) - 1u);
+                if (j < m && keys) {   // the reference-format lists are a parity/debug artefact: nothing downstream reads them
+                    keys[start + i0 + j] = tile_hi | (unsigned long long)__float_as_uint(depths[idx]);
+                    sorted[i0 + j] = idx;   // point_list without the mask bits
+                }
+                const uint32_t mq = j < m ? ent[k] >> GSR_RANK_IDX_BITS : 0u;
+                msk[c] = mq;
+                sid[c] = idx;
+                uint32_t r = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned long long bal = __ballot((mq >> q) & 1u);
+                    r |= (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u)) << (8 * q);
+                    if (lane == 0) cntw[q][c * NW + wid] = (uint32_t)__builtin_popcountll(bal);
+                }
+                rnk[c] = r;
+            }
+        }
+        __syncthreads();
+        {   // wave q scans quadrant q's NE (chunk, wave) counters
+            const uint32_t a = lane < NE ? cntw[wid][lane] : 0u;
+            const uint32_t incl = wave_scan_incl_u32(a);
+            if (lane < NE) cntw[wid][lane] = incl - a;
+            if (lane == 63) cntw[wid][NE] = incl;   // total
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < EPT; ++c) {
+            const uint32_t mq = msk[c];
+            if (mq) {
+                const uint32_t j = (uint32_t)c * THREADS + (uint32_t)tid;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if ((mq >> q) & 1u) {
+                        const uint32_t pos = run[q] + cntw[q][c * NW + wid] + ((rnk[c] >> (8 * q)) & 0xFFu);
+                        qpbase[(size_t)q * n + pos] = sid[c];
+                        if (qlbase) qlbase[(size_t)q * n + pos] = i0 + j;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) run[q] += cntw[q][NE];
+        __syncthreads();   // cntw[] is rewritten by the next window
+    }
+    if (tid < 4) qcount[4 * tile + tid] = tid == 0 ? run[0] : tid == 1 ? run[1] : tid == 2 ? run[2] : run[3];
+}
+}  // namespace gsr

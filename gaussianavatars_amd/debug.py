@@ -62,6 +62,7 @@ def _forward_state(rs, means3D, shs, colors_precomp, opacities, scales, rotation
 
     lib.gsr_binning_layout(cap, W, H, P, int(_R.get_tile_culling()), C.byref(bl))
     prod = bl.path == 1
+    lists = int(_R.get_tile_culling()) in (0, 2) or bl.path == 2   # the reference-format key / point lists were written
     lib.gsr_image_layout(W, H, C.byref(il))
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     f32, u32, i16 = torch.float32, torch.int32, torch.int16
@@ -77,9 +78,10 @@ def _forward_state(rs, means3D, shs, colors_precomp, opacities, scales, rotation
         tiles_touched=_view(geom, gl.tiles_touched, P, u32),
         clamped=_view(geom, gl.clamped, P, torch.uint8),
         production_binning=prod,
-        keys=_view(binning, bl.keys, 0 if prod else I, torch.int64),
-        point_list=_view(binning, bl.point_list, 0 if prod else I, u32),
-        qlist=_view(binning, bl.qlist, 0 if prod else 4 * cap, u32),           # parity modes: stream entries' positions in the tile list
+        binning_path=int(bl.path),
+        keys=_view(binning, bl.keys, I if lists else 0, torch.int64),
+        point_list=_view(binning, bl.point_list, I if lists else 0, u32),
+        qlist=_view(binning, bl.qlist, 4 * cap if lists and not prod else 0, u32),           # parity modes: stream entries' positions in the tile list
         qpos=_view(binning, bl.qpos, cap if prod else 4 * cap, u32),           # the quadrant streams of splat indices (from qstart)
         qcount=_view(binning, bl.qcount, 4 * tiles, u32).view(tiles, 4),
         qstart=_view(binning, bl.qstart, 4 * tiles, u32).view(tiles, 4),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 4
+#define GSR_ABI_VERSION 5
 #define GSR_BWD_SEGMENT 60        /* stream entries per backward segment (a multiple of both blend kernels' batches)  */
 #define GSR_BWD_SEGMENTS 10       /* segments per quadrant stream; the last one takes whatever is left                */
 #define GSR_BIN_BLOCKS 256        /* workgroups of the two binning passes (each owns a contiguous chunk of splats) */
@@ -148,6 +148,13 @@ typedef struct GsrBinningLayout {
     size_t qprefix;     /* uint32 [chunks][Q]  exclusive prefix of qhist along the chunk axis                        */
     size_t qmask;       /* uint64 [P][2]  hit masks of the counting pass (by position in `order`, first two rounds of 64 quadrants),
                            replayed by the scatter pass                                                          */
+    /* rank path (csrc/gsr_rank.hip): splats ranked by depth once, every tile's instances ordered through an LDS bitmap */
+    size_t ranks;       /* uint32 [cap][2] (depth rank, splat) of every (splat, tile) instance, grouped by tile (unordered inside a tile) */
+    size_t rank;        /* uint32 [P]   rank of every binned splat in (depth, index) order                                     */
+    size_t srect;       /* uint16 [P][4] tile rect (minx, miny, maxx, maxy) every splat is binned into (snug in the culling modes);
+                           zero area = not binned                                                                          */
+    size_t sspan;       /* float  [P][8] operands of the per-quadrant reach test of a binned splat (csrc/gsr_device.h: Span)          */
+    size_t pstat;       /* uint32 [ceil(P/256)][2] (min, max) depth bits of each k_preprocess workgroup's visible splats       */
     size_t path;        /* 1: production binning is used for this (P, W, H, tile_culling); 0: the per-tile sort path     */
     size_t chunks;      /* production: number of chunks (waves) of the ordered walk                                */
     size_t nb;          /* production: number of depth buckets                                                     */

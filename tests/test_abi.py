@@ -25,7 +25,7 @@ def test_gsr_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"include/gsr.h declares {n} but libgsr_hip.so does not export it"
         assert n in _lib.GSR_SYMBOLS, f"{n} has no ctypes prototype in _lib.GSR_SYMBOLS"
-    assert lib.gsr_abi_version() == 4
+    assert lib.gsr_abi_version() == 5
 
 
 def test_layouts_are_disjoint_and_aligned():
@@ -40,14 +40,26 @@ def test_layouts_are_disjoint_and_aligned():
     segs = [(gl.depths, 4 * P), (gl.grec, 48 * P), (gl.cov3D, 24 * P),
             (gl.rect, 8 * P), (gl.tiles_touched, 4 * P), (gl.clamped, P), (gl.visible, P), (gl.brec, 48 * P), (gl.acc64, 80 * P), (gl.acc, 48 * P)]
     _check(segs, gl.total)
-    # parity modes: the per-tile sort path
-    assert bl.path == 0
-    segs = [(bl.keys, 8 * cap), (bl.point_list, 4 * cap), (bl.qlist, 16 * cap), (bl.qpos, 16 * cap), (bl.qcount, 16 * tiles), (bl.qstart, 16 * tiles),
+    # parity modes: the rank path (tile lists ordered by global depth rank), reference-format lists materialised
+    assert bl.path == 0 and bl.nb == 512
+    nblk = (P + 255) // 256
+    rank_segs = [(bl.qpos, 16 * cap), (bl.qcount, 16 * tiles), (bl.qstart, 16 * tiles),
+                 (bl.ranges, 8 * tiles), (bl.tile_count, 4 * tiles), (bl.tile_start, 4 * tiles), (bl.tile_cursor, 4 * tiles), (bl.tile_order, 4 * tiles),
+                 (bl.block_hist, 4 * 256 * tiles), (bl.dkeys, 8 * P), (bl.dtmp, 8 * P), (bl.bcount, 4 * bl.nb), (bl.bstart, 4 * bl.nb),
+                 (bl.bcursor, 4 * bl.nb), (bl.bhist, 4 * 256 * bl.nb), (bl.ranks, 8 * cap), (bl.rank, 4 * P), (bl.srect, 8 * P), (bl.sspan, 32 * P), (bl.pstat, 8 * nblk)]
+    _check(rank_segs + [(bl.keys, 8 * cap), (bl.point_list, 4 * cap), (bl.qlist, 16 * cap)], bl.total)
+    # production settings below 125 k splats: the same path without the reference-format lists
+    assert lib.gsr_binning_layout(cap, 550, 802, P, 3, C.byref(bl)) == 0 and bl.path == 0
+    assert bl.keys == bl.point_list and bl.qlist == bl.qpos
+    _check([(bl.qpos, 16 * cap), (bl.ranks, 8 * cap), (bl.point_list, 4 * cap), (bl.rank, 4 * P), (bl.srect, 8 * P), (bl.pstat, 8 * nblk)], bl.total)
+    # round 1's per-tile bitonic sort (tile_culling 5, A/B runs)
+    assert lib.gsr_binning_layout(cap, 550, 802, P, 5, C.byref(bl)) == 0 and bl.path == 2
+    segs = [(bl.keys, 8 * cap), (bl.point_list, 4 * cap), (bl.qpos, 16 * cap), (bl.qcount, 16 * tiles), (bl.qstart, 16 * tiles),
             (bl.ranges, 8 * tiles), (bl.tile_count, 4 * tiles), (bl.tile_start, 4 * tiles), (bl.tile_cursor, 4 * tiles), (bl.tile_order, 4 * tiles)]
     _check(segs, bl.total)
     # production: depth-ordered scatter into the quadrant streams (capacity counts stream entries)
     capq = 4_000_000
-    assert lib.gsr_binning_layout(capq, 550, 802, P, 1, C.byref(bl)) == 0 and bl.path == 0      # below 125 k splats: the sort path
+    assert lib.gsr_binning_layout(capq, 550, 802, P, 1, C.byref(bl)) == 0 and bl.path == 0      # below 125 k splats: the rank path
     assert lib.gsr_binning_layout(capq, 550, 802, 200_000, 1, C.byref(bl)) == 0 and bl.path == 1
     assert lib.gsr_binning_layout(capq, 550, 802, P, 4, C.byref(bl)) == 0                        # 4: whenever it applies
     assert bl.path == 1 and bl.chunks == 782 and bl.nb == 256 and (P + bl.chunks - 1) // bl.chunks <= 255
@@ -56,9 +68,11 @@ def test_layouts_are_disjoint_and_aligned():
             (bl.order, 4 * P), (bl.bcount, 4 * bl.nb), (bl.bstart, 4 * bl.nb), (bl.bcursor, 4 * bl.nb), (bl.border, 4 * bl.nb),
             (bl.qhist, bl.chunks * Q), (bl.qprefix, 4 * bl.chunks * Q), (bl.qmask, 16 * P)]
     _check(segs, bl.total)
-    # grids beyond 16384 quadrants and splat counts beyond 255 per chunk stay on the sort path
-    assert lib.gsr_binning_layout(capq, 1600, 1100, 2_000_000, 1, C.byref(bl)) == 0 and bl.path == 0
-    assert lib.gsr_binning_layout(capq, 550, 802, 2_000_000, 1, C.byref(bl)) == 0 and bl.path == 0
+    # grids beyond 16384 quadrants and splat counts beyond 255 per chunk do not take the scatter: the rank path up to 262144 splats
+    # (every rank of the frame in one tile bitmap), round 1's per-tile sort beyond
+    assert lib.gsr_binning_layout(capq, 1600, 1100, 250_000, 1, C.byref(bl)) == 0 and bl.path == 0
+    assert lib.gsr_binning_layout(capq, 1600, 1100, 2_000_000, 1, C.byref(bl)) == 0 and bl.path == 2
+    assert lib.gsr_binning_layout(capq, 550, 802, 2_000_000, 1, C.byref(bl)) == 0 and bl.path == 2
     _check([(il.final_T, 4 * HW), (il.n_contrib, 4 * HW), (il.n_contrib_q, 4 * HW), (il.c_final, 12 * HW), (il.ck, 144 * HW)], il.total)
     assert lib.gsr_geom_layout(-1, C.byref(gl)) < 0 and b"bad arguments" in lib.gsr_last_error()
 

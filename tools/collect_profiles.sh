@@ -1,21 +1,22 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence for profiles/ on a GPU box:  bash tools/collect_profiles.sh <tag>   (e.g. r01_e)
+# Collects the rocprofv3 evidence for profiles/ on a GPU box:  bash tools/collect_profiles.sh <tag>   (e.g. r02_a)
 # kernel stats and the two PMC counters are separate runs (PMC is never combined with other trace domains).
 set -u
-TAG=${1:-r01_x}
+TAG=${1:-r02_x}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-profile"
 cd $GRAFT_REPO_ROOT
-for W in cfg3 cfg5; do
-  if [ $W = cfg3 ]; then S="--steps 60 --warmup 15"; else S="--steps 30 --warmup 8"; fi
+for W in cfg3 cfg4 cfg5; do
+  if [ $W = cfg3 ]; then S="--steps 60 --warmup 15 --rounds 1 --min-seconds 0"; else S="--steps 30 --warmup 8 --rounds 1 --min-seconds 0"; fi
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${W}_stats -- $B --workload $W $S > $OUT/${W}_stats.log 2>&1
   timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${W}_fetch -- $B --workload $W $S > $OUT/${W}_fetch.log 2>&1
   timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${W}_write -- $B --workload $W $S > $OUT/${W}_write.log 2>&1
   python tools/pmc_per_launch.py $OUT/${TAG}_${W}_pmc_fetch_write_per_launch.json $OUT/${W}_fetch $OUT/${W}_write
   cp $(ls $OUT/${W}_stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_${W}_kernel_stats.csv
   rm -rf $OUT/${W}_fetch $OUT/${W}_write   # raw per-dispatch tables are large; the summaries are what is kept
+  python tools/trace_busy.py $OUT/${W}_stats > $OUT/${TAG}_${W}_busy.json
   rm -f $OUT/${W}_stats/*/*kernel_trace.csv
 done
 python bench.py --steps 150 --warmup 30 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3.json
