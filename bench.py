@@ -73,14 +73,20 @@ def build_unbound_scene(device, n_splats, sh_degree, width, height):
 SSIM_STEP = False   # --workload train: the loss and statistics lines of train.py:131-132,197-198 ride along
 
 
+_ZERO = {}
+
+
 def one_step(g, cam, bg, target, t, train):
     from gaussianavatars_amd.gaussian_renderer import l1_loss, render
 
     if g.binding is not None:
         g.select_mesh_by_timestep(t)
     pkg = render(cam, g, Pipe, bg)
-    if not train:
-        return pkg["render"].sum() * 0  # keep a device scalar for the (optional) all-reduce
+    if not train:   # forward-only workloads: a constant device scalar for the (optional) all-reduce, no reduction kernels in the timed loop
+        z = _ZERO.get(pkg["render"].device)
+        if z is None:
+            z = _ZERO[pkg["render"].device] = torch.zeros((), dtype=torch.float32, device=pkg["render"].device)
+        return z
     if SSIM_STEP:
         from gaussianavatars_amd.loss import l1_ssim
 

@@ -80,7 +80,7 @@ class GsrGeomLayout(C.Structure):
 class GsrBinningLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
                 ("keys", "point_list", "qlist", "qpos", "qcount", "qstart", "ranges", "tile_count", "tile_start", "tile_cursor", "tile_order",
-                 "block_hist", "dkeys", "dtmp", "order", "bcount", "bstart", "bcursor", "border", "bhist", "qhist", "qprefix", "qmask", "ranks", "rank", "srect", "sspan", "pstat", "path", "chunks", "nb",
+                 "block_hist", "dkeys", "dtmp", "order", "bcount", "bstart", "bcursor", "border", "bhist", "qhist", "qprefix", "qmask", "ranks", "rank", "srect", "sspan", "pstat", "tdesc", "path", "chunks", "nb",
                  "total")]
 
 

@@ -164,8 +164,9 @@ int gsr_geom_layout(int32_t P, GsrGeomLayout* o)
 static bool production_params(int32_t P, size_t tiles, int32_t tile_culling, size_t* chunks, size_t* nb)
 {
     *chunks = 0; *nb = 0;
-    // below ~125 k splats ordering the tile lists is the faster way (per-tile cost grows faster than linearly with the splat count)
-    if (tile_culling == 4 ? P <= 0 : (tile_culling != 1 || P < GSR_PRODUCTION_MIN_SPLATS)) return false;   // 4: whenever it applies (tests, A/B)
+    // up to GSR_RANK_MAX_SPLATS the rank path is the faster one (200 k splats, 550x802: 1565 against 1215 frames/s); beyond it the
+    // tile bitmaps no longer hold a frame's ranks and the depth-ordered scatter takes over where its tables fit
+    if (tile_culling == 4 ? P <= 0 : (tile_culling != 1 || P <= GSR_RANK_MAX_SPLATS)) return false;   // 4: whenever it applies (tests, A/B)
     const size_t Q = 4 * tiles;
     if (Q > 16384) return false;                                   // the scatter wave keeps a 4-byte cursor per quadrant in LDS: <= 64 KB
     size_t c = ((size_t)P + 127) / 128;                           // ~128 splats per chunk: each of the chunk's 4 band waves walks them
@@ -216,7 +217,8 @@ int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, int32_t 
     o->tile_start = off;  off = align_up(off + (prod ? 0 : tiles * 4), A);
     o->tile_cursor = off; off = align_up(off + (prod ? 0 : tiles * 4), A);
     o->tile_order = off;  off = align_up(off + tiles * 4, A);
-    o->block_hist = off;  off = align_up(off + (prod || tiles > hist_tiles ? 0 : (size_t)GSR_BIN_BLOCKS * tiles * 4), A);
+    const size_t blocks = rankp ? (size_t)GSR_RANK_BLOCKS : (size_t)GSR_BIN_BLOCKS;
+    o->block_hist = off;  off = align_up(off + (prod || tiles > hist_tiles ? 0 : blocks * tiles * 4), A);
     o->dkeys = off;       off = align_up(off + (dsort ? n * 8 : 0), A);
     o->dtmp = off;        off = align_up(off + (dsort ? n * 8 : 0), A);
     o->order = off;       off = align_up(off + (prod ? n * 4 : 0), A);
@@ -224,7 +226,7 @@ int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, int32_t 
     o->bstart = off;      off = align_up(off + (dsort ? nb * 4 : 0), A);
     o->bcursor = off;     off = align_up(off + (dsort ? nb * 4 : 0), A);
     o->border = off;      off = align_up(off + (prod ? nb * 4 : 0), A);
-    o->bhist = off;       off = align_up(off + (dsort ? (size_t)GSR_BIN_BLOCKS * nb * 4 : 0), A);
+    o->bhist = off;       off = align_up(off + (dsort ? blocks * nb * 4 : 0), A);
     o->qhist = off;       off = align_up(off + (prod ? chunks * qw * 4 : 0), A);
     o->qprefix = off;     off = align_up(off + (prod ? chunks * Q * 4 : 0), A);
     o->qmask = off;       off = align_up(off + (prod ? n * GSR_WALK_MASKS * 8 : 0), A);
@@ -233,6 +235,7 @@ int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, int32_t 
     o->srect = off;       off = align_up(off + (rankp ? n * 8 : 0), A);
     o->sspan = off;       off = align_up(off + (rankp ? n * 32 : 0), A);
     o->pstat = off;       off = align_up(off + (rankp ? ((n + 255) / 256) * 8 : 0), A);
+    o->tdesc = off;       off = align_up(off + (rankp ? tiles * 16 : 0), A);
     o->path = (size_t)path;
     o->chunks = chunks;
     o->nb = nb;
@@ -415,7 +418,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     } else if (rankp) {
         // ---- rank path: depth-rank the splats once, order every tile's instances through an LDS bitmap (gsr_rank.hip) ----
         const uint32_t nb = (uint32_t)bl.nb;
-        const int bin_blocks = pblocks < GSR_BIN_BLOCKS ? pblocks : GSR_BIN_BLOCKS;
+        const int bin_blocks = pblocks < GSR_RANK_BLOCKS ? pblocks : GSR_RANK_BLOCKS;
         const bool direct = tiles > GSR_RANK_HIST_TILES;
         const size_t hist_bytes = direct ? 0 : (size_t)tiles * sizeof(uint32_t);
         const size_t count_lds = (size_t)nb * 4 + hist_bytes;
@@ -452,7 +455,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
             // workgroup 0 scans the tile counters and posts the instance count; launched even when P == 0
             hipLaunchKernelGGL(gsr::k_rdsort, dim3(1 + (pblocks > 0 ? nb : 0u)), dim3(256), 0, stream, (const uint32_t*)bcount,
                                (const uint32_t*)bstart, dkeys, dtmp, rank, tiles, (const uint32_t*)tile_count, tile_start, tile_cursor,
-                               ranges, tile_order, total_dev, slot_dev, seq);
+                               ranges, tile_order, (uint4*)(b + bl.tdesc), total_dev, slot_dev, seq);
             KERNEL_CHECK("k_rdsort", stream, dbg);
         }
         if (pblocks > 0) {
@@ -466,8 +469,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
             TIMED(GSR_K_TILE_SORT, stream);
             // the bitmap holds every rank of the frame (P bounds the ranked splats; binning_path() keeps P <= GSR_RANK_MAX_SPLATS here)
             const uint32_t words = (uint32_t)(((size_t)P + 2047) / 2048) * 64u;
-            hipLaunchKernelGGL(gsr::k_tile_rank, dim3(tiles), dim3(256), (size_t)words * 6, stream, words, (const uint32_t*)tile_order,
-                               (const uint32_t*)tile_count, (const uint32_t*)tile_start, (const uint2*)ranks, (const float*)pa.depths,
+            hipLaunchKernelGGL(gsr::k_tile_rank, dim3(tiles), dim3(256), (size_t)words * 6, stream, words, (const uint4*)(b + bl.tdesc), (const uint2*)ranks, (const float*)pa.depths,
                                (const gsr::BinHeader*)hdr, write_lists ? (unsigned long long*)(b + bl.keys) : nullptr,
                                (uint32_t*)(b + bl.point_list), write_lists ? qlist : nullptr, qpos, qcount, qstart,
                                cap, (const unsigned long long*)total_dev);

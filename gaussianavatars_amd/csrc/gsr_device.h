@@ -408,7 +408,6 @@ struct BinHeader {              // first bytes of the binning buffer (include/gs
 };
 static_assert(sizeof(BinHeader) == 256 + 64 * GSR_STAT_SLOTS, "header layout is part of include/gsr.h");
 
-#define GSR_PRODUCTION_MIN_SPLATS 125000   // splat count from which production mode takes the depth-ordered scatter (gsr_binning.hip)
 #define GSR_WALK_MASKS 2           // saved hit masks per splat (rounds of 64 quadrants): rects beyond 128 quadrants are tested again by the scatter pass
 struct QBinArgs {               // k_qcount / k_qscatter
     int Q, gx;                      // quadrants (4 * tiles), tile columns
@@ -535,10 +534,10 @@ __global__ void k_rdscatter(int P, uint32_t nb, const ushort4* srect, const floa
                             uint32_t* bcursor, unsigned long long* dkeys, const uint32_t* bhist);
 __global__ void k_rdsort(const uint32_t* bcount, const uint32_t* bstart, unsigned long long* dkeys, unsigned long long* tmp,
                          uint32_t* rank, int tiles, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, uint2* ranges,
-                         uint32_t* tile_order, unsigned long long* total_dev, unsigned long long* mailbox, unsigned long long seq);
+                         uint32_t* tile_order, uint4* tdesc, unsigned long long* total_dev, unsigned long long* mailbox, unsigned long long seq);
 __global__ void k_rscatter(int P, int gx, int tiles, const ushort4* srect, const uint32_t* rank, const float4* sspan, const uint32_t* tile_start,
                            uint32_t* tile_cursor, uint2* ranks, unsigned long long capacity, const unsigned long long* total_dev, const uint32_t* block_hist);
-__global__ void k_tile_rank(uint32_t words, const uint32_t* tile_order, const uint32_t* tile_count, const uint32_t* tile_start, const uint2* ranks,
+__global__ void k_tile_rank(uint32_t words, const uint4* tdesc, const uint2* ranks,
                             const float* depths, const BinHeader* hdr, unsigned long long* keys, uint32_t* point_list,
                             uint32_t* qlist, uint32_t* qpos, uint32_t* qcount, uint32_t* qstart, unsigned long long capacity,
                             const unsigned long long* total_dev);

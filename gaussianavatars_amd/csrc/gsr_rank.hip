@@ -215,8 +215,8 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rdscatter(int P, uint3
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void tile_scan_256(int tiles, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
                                               uint32_t* __restrict__ tile_cursor, uint2* __restrict__ ranges,
-                                              uint32_t* __restrict__ tile_order, unsigned long long* __restrict__ total_dev,
-                                              unsigned long long* mailbox, unsigned long long seq)
+                                              uint32_t* __restrict__ tile_order, uint4* __restrict__ tdesc,
+                                              unsigned long long* __restrict__ total_dev, unsigned long long* mailbox, unsigned long long seq)
 {
     __shared__ uint32_t wave_tot[4];
     __shared__ unsigned long long carry_s;
@@ -274,7 +274,13 @@ __device__ __forceinline__ void tile_scan_256(int tiles, const uint32_t* __restr
         for (int b = 0; b < 33; ++b) { const uint32_t c = bucket[b]; bucket[b] = run; run += c; }
     }
     __syncthreads();
-    for (int t = tid; t < tiles; t += 256) tile_order[atomicAdd(&bucket[bucket_of(tile_count[t])], 1u)] = (uint32_t)t;
+    // (tile_start was written by other threads of this workgroup above: visible after the barriers in between)
+    for (int t = tid; t < tiles; t += 256) {
+        const uint32_t c = tile_count[t];
+        const uint32_t pos = atomicAdd(&bucket[bucket_of(c)], 1u);
+        tile_order[pos] = (uint32_t)t;
+        tdesc[pos] = make_uint4((uint32_t)t, c, tile_start[t], 0u);   // what the per-tile kernel needs, in one load
+    }
 }
 
 __global__ __launch_bounds__(256) void k_rdsort(const uint32_t* __restrict__ bcount, const uint32_t* __restrict__ bstart,
@@ -282,11 +288,11 @@ __global__ __launch_bounds__(256) void k_rdsort(const uint32_t* __restrict__ bco
                                                  uint32_t* __restrict__ rank, int tiles,
                                                  const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
                                                  uint32_t* __restrict__ tile_cursor, uint2* __restrict__ ranges,
-                                                 uint32_t* __restrict__ tile_order, unsigned long long* __restrict__ total_dev,
-                                                 unsigned long long* mailbox, unsigned long long seq)
+                                                 uint32_t* __restrict__ tile_order, uint4* __restrict__ tdesc,
+                                                 unsigned long long* __restrict__ total_dev, unsigned long long* mailbox, unsigned long long seq)
 {
     if (blockIdx.x == 0) {
-        tile_scan_256(tiles, tile_count, tile_start, tile_cursor, ranges, tile_order, total_dev, mailbox, seq);
+        tile_scan_256(tiles, tile_count, tile_start, tile_cursor, ranges, tile_order, tdesc, total_dev, mailbox, seq);
         return;
     }
     constexpr int KEYS = GSR_SORT_SMALL_KEYS, THREADS = 256, EPT = KEYS / THREADS;
@@ -397,8 +403,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
 //      ballots + one scan of the (chunk, wave) counters; the parity modes also write the reference-format key list
 // No comparison, no data-dependent loop, every step entry-parallel.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tile_rank(uint32_t words, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ tile_count,
-                                                    const uint32_t* __restrict__ tile_start, const uint2* __restrict__ ranks,
+__global__ __launch_bounds__(256) void k_tile_rank(uint32_t words, const uint4* __restrict__ tdesc, const uint2* __restrict__ ranks,
                                                     const float* __restrict__ depths, const BinHeader* __restrict__ hdr,
                                                     unsigned long long* __restrict__ keys, uint32_t* __restrict__ point_list,
                                                     uint32_t* __restrict__ qlist, uint32_t* __restrict__ qpos, uint32_t* __restrict__ qcount,
@@ -414,26 +419,37 @@ __global__ __launch_bounds__(256) void k_tile_rank(uint32_t words, const uint32_
     uint16_t* const wprefix = reinterpret_cast<uint16_t*>(bitmap + words);  // [words] set bits before the word inside its row
     __shared__ uint32_t cntw[4][NE + 1];
     __shared__ uint32_t rowoff[ROWS + 1];
+    __shared__ uint32_t lsorted[UB * THREADS];   // the sorted list of a tile whose entries fit the registers (the common case)
     if (*total_dev > capacity) return;
-    const uint32_t tile = tile_order[blockIdx.x];
-    const uint32_t n = tile_count[tile];
+    const uint4 td = tdesc[blockIdx.x];      // (tile, entries, first entry): launch order = heaviest tiles first
+    const uint32_t tile = td.x, n = td.y;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (n == 0) {
         if (tid < 4) { qcount[4 * tile + tid] = 0u; qstart[4 * tile + tid] = 0u; }
         return;
     }
-    const uint32_t start = tile_start[tile];
+    const uint32_t start = td.z;
     if (tid < 4) qstart[4 * tile + tid] = 4u * start + (uint32_t)tid * n;   // the tile's four n-slot streams
     const uint2* __restrict__ rk = ranks + start;
+    const bool fast = n <= (uint32_t)(UB * THREADS);   // every entry stays in a register between the two passes over them
     uint32_t* const qpbase = qpos + (size_t)4 * start;
     uint32_t* const qlbase = qlist ? qlist + (size_t)4 * start : nullptr;
     const unsigned long long tile_hi = (unsigned long long)tile << 32;
     const uint32_t Wn = min(words, (hdr->nvis + 31u) >> 5);
     const uint32_t rows = (Wn + 63u) >> 6;
 
+    uint2 e0[UB];
+#pragma unroll
+    for (int k = 0; k < UB; ++k) {   // the first UB * THREADS entries: issued before the bitmap is cleared
+        const uint32_t i = (uint32_t)(k * THREADS + tid);
+        e0[k] = i < n ? rk[i] : make_uint2(0xFFFFFFFFu, 0u);
+    }
     for (uint32_t w = tid; w < rows * 64u; w += THREADS) bitmap[w] = 0u;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += UB * THREADS) {
+#pragma unroll
+    for (int k = 0; k < UB; ++k)
+        if (e0[k].x < Wn * 32u) atomicOr(&bitmap[e0[k].x >> 5], 1u << (e0[k].x & 31u));
+    for (uint32_t base = UB * THREADS; base < n; base += UB * THREADS) {
         uint32_t r[UB];
 #pragma unroll
         for (int k = 0; k < UB; ++k) {
@@ -478,20 +494,25 @@ __global__ __launch_bounds__(256) void k_tile_rank(uint32_t words, const uint32_
     // ---- 3. every entry finds its position and drops its splat index there: the tile's sorted list, in global memory (the
     //         reference's point_list; the same workgroup reads it back below, coalesced) ----
     uint32_t* const sorted = point_list + start;
-    for (uint32_t base = 0; base < n; base += UB * THREADS) {
-        uint2 e[UB];
+    auto position = [&](uint32_t r) {
+        const uint32_t w = r >> 5;
+        return rowoff[w >> 6] + (uint32_t)wprefix[w] + (uint32_t)__builtin_popcount(bitmap[w] & ((1u << (r & 31u)) - 1u));
+    };
+    if (fast) {   // registers -> LDS: no second read of the entries, no global round trip for the list
 #pragma unroll
-        for (int k = 0; k < UB; ++k) {
-            const uint32_t i = base + (uint32_t)(k * THREADS + tid);
-            e[k] = i < n ? rk[i] : make_uint2(0xFFFFFFFFu, 0u);
-        }
+        for (int k = 0; k < UB; ++k)
+            if (e0[k].x < Wn * 32u) lsorted[position(e0[k].x)] = e0[k].y;
+    } else {
+        for (uint32_t base = 0; base < n; base += UB * THREADS) {
+            uint2 e[UB];
 #pragma unroll
-        for (int k = 0; k < UB; ++k) {
-            if (e[k].x < Wn * 32u) {
-                const uint32_t w = e[k].x >> 5;
-                const uint32_t below = bitmap[w] & ((1u << (e[k].x & 31u)) - 1u);
-                sorted[rowoff[w >> 6] + (uint32_t)wprefix[w] + (uint32_t)__builtin_popcount(below)] = e[k].y;
+            for (int k = 0; k < UB; ++k) {
+                const uint32_t i = base + (uint32_t)(k * THREADS + tid);
+                e[k] = i < n ? rk[i] : make_uint2(0xFFFFFFFFu, 0u);
             }
+#pragma unroll
+            for (int k = 0; k < UB; ++k)
+                if (e[k].x < Wn * 32u) sorted[position(e[k].x)] = e[k].y;
         }
     }
     __syncthreads();   // (global stores of this workgroup are visible to it after the barrier)
@@ -514,7 +535,7 @@ __global__ __launch_bounds__(256) void k_tile_rank(uint32_t words, const uint32_
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t j = (uint32_t)(4 * h + k) * THREADS + (uint32_t)tid;
-                ent[k] = j < m ? sorted[i0 + j] : 0u;
+                ent[k] = j < m ? (fast ? lsorted[j] : sorted[i0 + j]) : 0u;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {

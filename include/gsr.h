@@ -32,6 +32,7 @@ extern "C" {
 #define GSR_BWD_SEGMENT 60        /* stream entries per backward segment (a multiple of both blend kernels' batches)  */
 #define GSR_BWD_SEGMENTS 10       /* segments per quadrant stream; the last one takes whatever is left                */
 #define GSR_BIN_BLOCKS 256        /* workgroups of the two binning passes (each owns a contiguous chunk of splats) */
+#define GSR_RANK_BLOCKS 256       /* the same for the rank path (csrc/gsr_rank.hip), 1024 threads each: one per CU (swept 64..512)  */
 #define GSR_BLOCK_X 16
 #define GSR_BLOCK_Y 16
 
@@ -155,6 +156,7 @@ typedef struct GsrBinningLayout {
                            zero area = not binned                                                                          */
     size_t sspan;       /* float  [P][8] operands of the per-quadrant reach test of a binned splat (csrc/gsr_device.h: Span)          */
     size_t pstat;       /* uint32 [ceil(P/256)][2] (min, max) depth bits of each k_preprocess workgroup's visible splats       */
+    size_t tdesc;       /* uint32 [tiles][4] (tile, entries, first entry, 0) in launch order (heaviest tiles first)                       */
     size_t path;        /* 1: production binning is used for this (P, W, H, tile_culling); 0: the per-tile sort path     */
     size_t chunks;      /* production: number of chunks (waves) of the ordered walk                                */
     size_t nb;          /* production: number of depth buckets                                                     */

@@ -46,9 +46,9 @@ def test_layouts_are_disjoint_and_aligned():
     rank_segs = [(bl.qpos, 16 * cap), (bl.qcount, 16 * tiles), (bl.qstart, 16 * tiles),
                  (bl.ranges, 8 * tiles), (bl.tile_count, 4 * tiles), (bl.tile_start, 4 * tiles), (bl.tile_cursor, 4 * tiles), (bl.tile_order, 4 * tiles),
                  (bl.block_hist, 4 * 256 * tiles), (bl.dkeys, 8 * P), (bl.dtmp, 8 * P), (bl.bcount, 4 * bl.nb), (bl.bstart, 4 * bl.nb),
-                 (bl.bcursor, 4 * bl.nb), (bl.bhist, 4 * 256 * bl.nb), (bl.ranks, 8 * cap), (bl.rank, 4 * P), (bl.srect, 8 * P), (bl.sspan, 32 * P), (bl.pstat, 8 * nblk)]
+                 (bl.bcursor, 4 * bl.nb), (bl.bhist, 4 * 256 * bl.nb), (bl.ranks, 8 * cap), (bl.rank, 4 * P), (bl.srect, 8 * P), (bl.sspan, 32 * P), (bl.pstat, 8 * nblk), (bl.tdesc, 16 * tiles)]
     _check(rank_segs + [(bl.keys, 8 * cap), (bl.point_list, 4 * cap), (bl.qlist, 16 * cap)], bl.total)
-    # production settings below 125 k splats: the same path without the reference-format lists
+    # production settings up to 262144 splats: the same path without the reference-format lists
     assert lib.gsr_binning_layout(cap, 550, 802, P, 3, C.byref(bl)) == 0 and bl.path == 0
     assert bl.keys == bl.point_list and bl.qlist == bl.qpos
     _check([(bl.qpos, 16 * cap), (bl.ranks, 8 * cap), (bl.point_list, 4 * cap), (bl.rank, 4 * P), (bl.srect, 8 * P), (bl.pstat, 8 * nblk)], bl.total)
@@ -59,8 +59,9 @@ def test_layouts_are_disjoint_and_aligned():
     _check(segs, bl.total)
     # production: depth-ordered scatter into the quadrant streams (capacity counts stream entries)
     capq = 4_000_000
-    assert lib.gsr_binning_layout(capq, 550, 802, P, 1, C.byref(bl)) == 0 and bl.path == 0      # below 125 k splats: the rank path
-    assert lib.gsr_binning_layout(capq, 550, 802, 200_000, 1, C.byref(bl)) == 0 and bl.path == 1
+    assert lib.gsr_binning_layout(capq, 550, 802, P, 1, C.byref(bl)) == 0 and bl.path == 0      # up to 262144 splats: the rank path
+    assert lib.gsr_binning_layout(capq, 550, 802, 200_000, 1, C.byref(bl)) == 0 and bl.path == 0
+    assert lib.gsr_binning_layout(capq, 550, 802, 300_000, 1, C.byref(bl)) == 0 and bl.path == 1
     assert lib.gsr_binning_layout(capq, 550, 802, P, 4, C.byref(bl)) == 0                        # 4: whenever it applies
     assert bl.path == 1 and bl.chunks == 782 and bl.nb == 256 and (P + bl.chunks - 1) // bl.chunks <= 255
     Q = 4 * tiles

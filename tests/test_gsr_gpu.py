@@ -333,7 +333,7 @@ def test_production_mode_state(oracle):
                                        t(a["projmatrix"]), deg, t(a["campos"]), False, False)
     args = (t(sp["means3D"]), t(sp["shs"]), None, t(sp["opacities"]), t(sp["scales"]), t(sp["rotations"]), None)
     par = D.forward_state(rs, *args, tile_culling=True)
-    for mode in (1, 3, 4):     # 1: what render() runs (sort path at this size), 3 / 4: the two production binnings forced
+    for mode in (1, 3, 4, 5):  # 1: what render() runs (rank path at this size), 3 / 4 / 5: rank path, depth-ordered scatter, round 1's per-tile sort forced
         prev = R.set_tile_culling(mode)
         try:
             pro = D._forward_state(rs, *args)
@@ -384,7 +384,7 @@ def test_production_binning_streams_equal_the_sort_path(oracle, name):
                                        t(a["projmatrix"]), deg, t(a["campos"]), False, False)
     args = (t(sp["means3D"]), t(sp["shs"]), None, t(sp["opacities"]), t(sp["scales"]), t(sp["rotations"]), None)
     par = D.forward_state(rs, *args, tile_culling=True)
-    prev = R.set_tile_culling(4)   # the depth-ordered scatter whatever the splat count (mode 1 takes it from 125 k splats up)
+    prev = R.set_tile_culling(4)   # the depth-ordered scatter whatever the splat count (mode 1 takes it beyond 262144 splats)
     try:
         pro = D._forward_state(rs, *args)
     finally:
