@@ -74,6 +74,9 @@ SSIM_STEP = False   # --workload train: the loss and statistics lines of train.p
 
 
 _ZERO = {}
+# rocprofv3 kernel name -> the timing slot (include/gsr.h GSR_K_*) its launches are accounted under
+PMC_ALIAS = {"k_rcount": "k_count", "k_rscatter": "k_scatter", "k_tile_rank": "k_tile_sort", "k_rdscatter": "k_depth_sort", "k_rdsort": "k_depth_sort",
+             "k_dbucket": "k_depth_sort", "k_dscan": "k_depth_sort", "k_dscatter": "k_depth_sort", "k_dsort": "k_depth_sort", "k_qscan_glob": "k_qscan"}
 
 
 def one_step(g, cam, bg, target, t, train):
@@ -334,8 +337,9 @@ def main():
         # fraction) = 1 for this scene (measured by the oracle leg below).  The kernels downstream of the binning stream the CULLED
         # instance lists, so their unit count is I_binned; the same figures with the reference's rect-based count are kept beside
         # them (`algorithmic_bytes_rect_based`) -- those are what an implementation without tile culling would have to move.
+        path = int(info.get("binning_path", 2))           # 0 rank path, 1 depth-ordered scatter, 2 round 1's per-tile sort
         def algo_for(I):
-            return {
+            a = {
                 "k_preprocess": 236 * N + (44 + (27 if train else 0)) * N,
                 "k_scatter": 12 * I,
                 "k_tile_sort": 12 * I + 8 * I,              # one ideal sort pass read + range scan (the 12 I key/idx write is k_scatter's)
@@ -343,6 +347,15 @@ def main():
                 "k_render_bwd": 20 * HW + 40 * I + 36 * N,
                 "k_preprocess_bwd": 300 * N + 256 * N,
             }
+            if path == 0:   # rank path: bytes per splat N / per tile instance I of each pass
+                a.update({
+                    "k_preprocess": a["k_preprocess"] + 40 * N,   # + binned rect (8) and the quadrant-test operands (32)
+                    "k_count": 16 * N,                             # rect 8, tiles_touched 4, depth 4
+                    "k_depth_sort": 20 * N + 12 * N,               # bucket scatter: rect 8 + depth 4 read, key 8 written; bucket sort: key 8 read, rank 4 written
+                    "k_scatter": 44 * N + 8 * I,                   # rect 8 + rank 4 + operands 32 read per splat, one 8-byte entry written per instance
+                    "k_tile_sort": 8 * I + 4 * I,                  # entry read; at least one 4-byte stream entry written per instance
+                })
+            return a
         algo, algo_rect = algo_for(I_binned), algo_for(I_rect)
         # Coalesced-read component of each kernel (bytes per launch), for the PMC calibration rule of profiles/r02_pmc_calibration.json:
         # FETCH_SIZE tallies 64 B per request; coalesced streams issue 128-byte requests (reported at half), per-lane gathers and
@@ -350,6 +363,8 @@ def main():
         # calibrated patterns and are taken at face value (a lower bound); `traffic_bounds` brackets every kernel.
         stream = {"k_preprocess": 236 * N, "k_count": 44 * N, "k_scatter": 48 * N, "k_tile_sort": 8 * I_binned, "k_render": 0,
                   "k_render_bwd": 0, "k_preprocess_bwd": 300 * N + 48 * N}
+        if path == 0:
+            stream.update({"k_count": 16 * N, "k_depth_sort": 20 * N, "k_scatter": 44 * N, "k_tile_sort": 8 * I_binned})
         pmc, pmc_raw = {}, {}
         pmc_tag = {"cfg5": "cfg5", "cfg4": "cfg4", "cfg3": "cfg3", "cfg2": "cfg3"}.get(args.workload)
         import glob
@@ -358,6 +373,7 @@ def main():
         if pmc_path:   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/README.md)
             for k, v in json.load(open(pmc_path)).items():
                 name = k.replace("void ", "").split("::")[-1].split("<")[0]   # the k_tile_sort classes add up
+                name = PMC_ALIAS.get(name, name)                              # kernels that share one timing slot add up as well
                 f, w = pmc_raw.get(name, (0.0, 0.0))
                 pmc_raw[name] = (f + 1024.0 * v["FETCH_SIZE_KB_per_launch"], w + 1024.0 * v["WRITE_SIZE_KB_per_launch"])
             for name, (f, w) in pmc_raw.items():
@@ -366,8 +382,10 @@ def main():
         if per_kernel:
             dom = max((k for k in per_kernel if k in algo), key=lambda k: per_kernel[k]["avg_us"] * per_kernel[k]["launches"])
             ach = algo[dom] / (per_kernel[dom]["avg_us"] * 1e-6) / 1e9
-            notes = {"k_tile_sort": "bound by its sorting network (instruction issue) and the scattered record gathers of its epilogue, not by "
-                                    "streaming bandwidth; HBM fraction reported as asked",
+            notes = {"k_tile_sort": ("per-tile latency chain (bitmap, scans, compaction: six barriers), not streaming bandwidth; HBM fraction reported as asked"
+                                     if path == 0 else
+                                     "bound by its sorting network (instruction issue) and the scattered record gathers of its epilogue, not by "
+                                     "streaming bandwidth; HBM fraction reported as asked"),
                      "k_render": "alpha-blend kernels are issue-bound (exp + per-wave instruction stream), HBM fraction reported as asked",
                      "k_render_bwd": "alpha-blend kernels are issue-bound (exp + per-wave instruction stream), HBM fraction reported as asked"}
             roofline = dict(kernel=dom, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
@@ -415,6 +433,7 @@ def main():
                                  args.workload] % (N, args.height, args.width),
                 "splats": N, "width": args.width, "height": args.height, "sh_degree": 3,
                 "num_rendered": I_rect, "num_binned": I_binned, "tile_culling": bool(info.get("tile_culling", False)),
+                "binning_path": {0: "rank", 1: "depth-ordered scatter", 2: "per-tile sort"}[path],
                 "visible_fraction": round(vis, 4), "binding": args.binding,
                 "parallelism": (f"frame-parallel x{n_gpus}: {dist.get_world_size() if dist is not None else 1} "
                                 f"{'RCCL (torch nccl)' if dist is not None else 'single-process'} rank(s), frames per rank {counts}, "
