@@ -97,6 +97,28 @@ def _rig_struct(head) -> "_lib.GabRig":
     return r[1]
 
 
+def _prepared_rig(head, rig, shape_flat, so_flat):
+    """The per-(rig, shape, static_offset) part of the FLAME forward (include/gab.h: gab_flame_prepare), cached on the head and
+    re-made when any of them changes (identity + in-place version of the two tensors; the rig's own buffers key _rig_struct)."""
+    key = (id(rig), shape_flat.data_ptr(), shape_flat._version, None if so_flat is None else (so_flat.data_ptr(), so_flat._version))
+    c = getattr(head, "_gab_prepared", None)
+    if c is None or c[0] != key:
+        lib = _lib.gab()
+        dev = head.v_template.device
+        buf = torch.empty(int(lib.gab_flame_prepared_floats(C.byref(rig))), dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            _chk(lib.gab_flame_prepare(C.byref(rig), _p(shape_flat), _p(so_flat), _p(buf), _stream(dev)), "gab_flame_prepare")
+        head._gab_prepared = c = (key, buf, shape_flat, so_flat)   # the sources stay alive: their data_ptr is part of the key
+    return c[1]
+
+
+def _use_prepared(head, shape_needs_grad, so_needs_grad) -> bool:
+    """One launch forward / two backward (prepared rig) when neither shape nor static_offset is being optimised -- the
+    reference's training setup (scene/flame_gaussian_model.py:155-178 puts only the per-timestep parameters in the optimiser).
+    head.flame_impl = "classic" keeps the three-kernel forward and backward."""
+    return not shape_needs_grad and not so_needs_grad and getattr(head, "flame_impl", "prepared") != "classic"
+
+
 class _FlameForward(torch.autograd.Function):
     @staticmethod
     def forward(ctx, head, shape, expr, rotation, neck, jaw, eyes, translation, static_offset):
@@ -114,9 +136,15 @@ class _FlameForward(torch.autograd.Function):
         verts = torch.empty((1, V, 3), dtype=torch.float32, device=dev)
         v_shaped = torch.empty((1, V, 3), dtype=torch.float32, device=dev)
         ws = torch.empty(_lib.GAB_FLAME_WS_FLOATS, dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad
+        ctx.prepared = _prepared_rig(head, rig, ins[0], so) if _use_prepared(head, need[1], static_offset is not None and need[8]) else None
         with _lib.on_device(dev):
-            _chk(lib.gab_flame_forward(C.byref(rig), *[_p(t) for t in ins], _p(so), _p(verts), _p(v_shaped), _p(ws), _stream(dev)),
-                 "gab_flame_forward")
+            if ctx.prepared is not None:
+                _chk(lib.gab_flame_forward_prepared(C.byref(rig), _p(ctx.prepared), *[_p(t) for t in ins[1:]], _p(verts), _p(v_shaped),
+                                                    _p(ws), _stream(dev)), "gab_flame_forward_prepared")
+            else:
+                _chk(lib.gab_flame_forward(C.byref(rig), *[_p(t) for t in ins], _p(so), _p(verts), _p(v_shaped), _p(ws), _stream(dev)),
+                     "gab_flame_forward")
         ctx.head = head
         ctx.has_so = static_offset is not None
         ctx.shapes = [t.shape for t in (shape, expr, rotation, neck, jaw, eyes, translation)]
@@ -146,9 +174,14 @@ class _FlameForward(torch.autograd.Function):
         gv = torch.zeros((V, 3), **f32) if g_verts is None else _f32(g_verts)
         gvs = None if g_vshaped is None else _f32(g_vshaped)
         with _lib.on_device(dev):
-            _chk(lib.gab_flame_backward(C.byref(rig), *[_p(t) for t in ins], _p(so), _p(v_shaped), _p(ws), _p(gv), _p(gvs),
-                                        _p(d_shape), _p(d_expr), _p(d_rot), _p(d_neck), _p(d_jaw), _p(d_eyes), _p(d_trans), _p(d_so),
-                                        _p(scratch), 0, None, None, _stream(dev)), "gab_flame_backward")
+            if ctx.prepared is not None and gvs is None and d_shape is None and d_so is None:
+                _chk(lib.gab_flame_backward_prepared(C.byref(rig), _p(ctx.prepared), *[_p(t) for t in ins[2:6]], _p(v_shaped), _p(ws), _p(gv),
+                                                     _p(d_expr), _p(d_rot), _p(d_neck), _p(d_jaw), _p(d_eyes), _p(d_trans), _p(scratch),
+                                                     0, None, None, _stream(dev)), "gab_flame_backward_prepared")
+            else:
+                _chk(lib.gab_flame_backward(C.byref(rig), *[_p(t) for t in ins], _p(so), _p(v_shaped), _p(ws), _p(gv), _p(gvs),
+                                            _p(d_shape), _p(d_expr), _p(d_rot), _p(d_neck), _p(d_jaw), _p(d_eyes), _p(d_trans), _p(d_so),
+                                            _p(scratch), 0, None, None, _stream(dev)), "gab_flame_backward")
         sh = ctx.shapes
         outs = [None, None if d_shape is None else d_shape.view(sh[0]), d_expr.view(sh[1]), d_rot.view(sh[2]), d_neck.view(sh[3]),
                 d_jaw.view(sh[4]), d_eyes.view(sh[5]), d_trans.view(sh[6]), None if d_so is None else d_so.view(ctx.so_shape)]
@@ -186,9 +219,15 @@ class _FlameForwardTimestep(torch.autograd.Function):
         verts = torch.empty((1, V, 3), dtype=torch.float32, device=dev)
         v_shaped = torch.empty((1, V, 3), dtype=torch.float32, device=dev)
         ws = torch.empty(_lib.GAB_FLAME_WS_FLOATS, dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad  # (head, t, shape, expr, rotation, neck, jaw, eyes, translation, static_offset)
+        ctx.prepared = _prepared_rig(head, rig, sh, so) if _use_prepared(head, need[2], so is not None and need[9]) else None
         with _lib.on_device(dev):
-            _chk(lib.gab_flame_forward(C.byref(rig), _p(sh), *rows, _p(so), _p(verts), _p(v_shaped), _p(ws), _stream(dev)),
-                 "gab_flame_forward")
+            if ctx.prepared is not None:
+                _chk(lib.gab_flame_forward_prepared(C.byref(rig), _p(ctx.prepared), *rows, _p(verts), _p(v_shaped), _p(ws), _stream(dev)),
+                     "gab_flame_forward_prepared")
+            else:
+                _chk(lib.gab_flame_forward(C.byref(rig), _p(sh), *rows, _p(so), _p(verts), _p(v_shaped), _p(ws), _stream(dev)),
+                     "gab_flame_forward")
         ctx.head, ctx.t, ctx.T, ctx.widths = head, t, T, widths
         ctx.has_so = so is not None
         ctx.shape_shape = shape.shape
@@ -222,8 +261,12 @@ class _FlameForwardTimestep(torch.autograd.Function):
         rows = [C.c_void_p(x.data_ptr() + 4 * t * w) for x, w in zip(tabs, widths)]
         with _lib.on_device(dev):
             # the (T,k) tables are zero-filled by the backward's first kernel (no launch of their own)
-            _chk(lib.gab_flame_backward(C.byref(rig), _p(sh), *rows, _p(so), _p(v_shaped), _p(ws), _p(gv), _p(gvs), _p(d_shape),
-                                        *outp, _p(d_so), _p(scratch), len(tables), ptrs, sizes, _stream(dev)), "gab_flame_backward")
+            if ctx.prepared is not None and gvs is None and d_shape is None and d_so is None:
+                _chk(lib.gab_flame_backward_prepared(C.byref(rig), _p(ctx.prepared), *rows[1:5], _p(v_shaped), _p(ws), _p(gv), *outp,
+                                                     _p(scratch), len(tables), ptrs, sizes, _stream(dev)), "gab_flame_backward_prepared")
+            else:
+                _chk(lib.gab_flame_backward(C.byref(rig), _p(sh), *rows, _p(so), _p(v_shaped), _p(ws), _p(gv), _p(gvs), _p(d_shape),
+                                            *outp, _p(d_so), _p(scratch), len(tables), ptrs, sizes, _stream(dev)), "gab_flame_backward")
         grads = [tb if need[3 + i] else None for i, tb in enumerate(tables)]
         return (None, None, None if d_shape is None else d_shape.view(ctx.shape_shape), *grads,
                 None if d_so is None else d_so.view(ctx.so_shape))

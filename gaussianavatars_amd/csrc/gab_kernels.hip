@@ -309,6 +309,200 @@ __global__ __launch_bounds__(256) void k_skin(Rig rig, const float* __restrict__
         verts[3 * v + r] = T[4 * r] * vp[0] + T[4 * r + 1] * vp[1] + T[4 * r + 2] * vp[2] + T[4 * r + 3] + translation[r];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Prepared rig: everything of F1/F2 that does not depend on the per-frame parameters, folded once per (rig, shape, static_offset):
+//   v_static = v_template + shapedirs[:, :n_shape] . shape (+ static_offset)          (3V)
+//   J_static = J_regressor . v_static                                                  (15)
+//   M        = J_regressor . shapedirs[:, n_shape:]   =>  joints = J_static + M . expr (15 x n_expr)
+// With the joints a 15 x n_expr product instead of a regression over every vertex, nothing per-frame needs all the vertices any
+// more, and blend shapes + chain + skinning run as ONE launch (k_flame_fused) instead of three dependent ones.
+// Layout (floats): [0, 3V) v_static | [jo, jo + 16) J_static | [jo + 16, ...) M row-major, jo = 3V rounded up to 4.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline int prep_joint_offset(int V) { return (3 * V + 3) & ~3; }
+
+__global__ __launch_bounds__(256) void k_prep_rows(Rig rig, const float* __restrict__ shape, const float* __restrict__ static_offset,
+                                                    float* __restrict__ prepared)
+{
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= 3 * rig.V) return;
+    const float* row = rig.shapedirs + (size_t)e * (rig.n_shape + rig.n_expr);
+    float acc = 0.f;
+    for (int l = lane; l < rig.n_shape; l += 64) acc += row[l] * shape[l];
+    acc = wave_sum_hi(acc);
+    if (lane == 63) prepared[e] = rig.v_template[e] + acc + (static_offset ? static_offset[e] : 0.f);
+}
+// one wave per output: o < 15: J_static[o]; else M[k][l], o - 15 = k * n_expr + l
+__global__ __launch_bounds__(256) void k_prep_joints(Rig rig, float* __restrict__ prepared)
+{
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= 15 + 15 * rig.n_expr) return;
+    const int NB = rig.n_shape + rig.n_expr;
+    const int k = o < 15 ? o : (o - 15) / rig.n_expr, l = o < 15 ? 0 : (o - 15) % rig.n_expr;
+    const int j = k / 3, c = k - 3 * j;
+    float acc = 0.f;
+    for (int v = lane; v < rig.V; v += 64) {
+        const float w = rig.J_regressor[(size_t)j * rig.V + v];
+        if (w != 0.f) acc += w * (o < 15 ? prepared[3 * v + c] : rig.shapedirs[(size_t)(3 * v + c) * NB + rig.n_shape + l]);
+    }
+    acc = wave_sum_hi(acc);
+    const int jo = prep_joint_offset(rig.V);
+    if (lane == 63) prepared[o < 15 ? jo + o : jo + 16 + (o - 15)] = acc;
+}
+
+// F1+F2+F3 in one launch.  Workgroup = GAB_FUSED_VERTS vertices.  Every workgroup works the (tiny) joint / Rodrigues / chain
+// problem out for itself -- 15 x n_expr multiply-adds, five Rodrigues, one serial 5-joint chain -- while its blend-shape rows are
+// in flight: a half-wave per row of the expression block (25 float4 of the 400-byte run that starts at column n_shape), all
+// rows of a half-wave issued before the first is consumed.  Then 16 lanes per vertex gather the 36 pose-corrective rows and one
+// lane per vertex applies the blended rigid transform.  Workgroup 0 also leaves the workspace the backward reads.
+#define GAB_FUSED_VERTS 16
+template <bool FLAME_TREE>
+__global__ __launch_bounds__(256) void k_flame_fused(Rig rig, const float* __restrict__ prepared, const float* __restrict__ expr,
+                                                      const float* __restrict__ rotation, const float* __restrict__ neck,
+                                                      const float* __restrict__ jaw, const float* __restrict__ eyes,
+                                                      const float* __restrict__ translation, float* __restrict__ verts,
+                                                      float* __restrict__ v_shaped, float* __restrict__ ws)
+{
+    constexpr int VW = GAB_FUSED_VERTS, ROWS = 3 * VW, PER = ROWS / 8;   // rows per half-wave (8 half-waves)
+    __shared__ float out[WS_DA];        // the forward half of the workspace: J, R, pose features, A
+    __shared__ float vs[ROWS];          // this workgroup's rows of v_shaped
+    __shared__ float po[ROWS];          // pose-corrective offsets
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int E = 3 * rig.V, NB = rig.n_shape + rig.n_expr;
+    const int e0 = blockIdx.x * ROWS;
+    const int jo = prep_joint_offset(rig.V);
+    // ---- blend-shape rows: issue the loads first
+    const int hw = 2 * wid + (lane >> 5), hl = lane & 31;   // half-wave 0..7, lane inside it
+    const int nq = rig.n_expr >> 2;                          // float4 per row of the expression block
+    const bool vec = (rig.n_expr & 3) == 0 && (rig.n_shape & 3) == 0 && (NB & 3) == 0 && nq <= 32;
+    float acc[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) acc[r] = 0.f;
+    if (vec) {
+        float4 rw[PER];
+        const float4 b = hl < nq ? reinterpret_cast<const float4*>(expr)[hl] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            const int e = e0 + hw * PER + r;
+            rw[r] = (e < E && hl < nq) ? reinterpret_cast<const float4*>(rig.shapedirs + (size_t)e * NB + rig.n_shape)[hl]
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < PER; ++r) acc[r] = rw[r].x * b.x + rw[r].y * b.y + rw[r].z * b.z + rw[r].w * b.w;
+    } else {
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            const int e = e0 + hw * PER + r;
+            if (e < E)
+                for (int l = hl; l < rig.n_expr; l += 32) acc[r] += rig.shapedirs[(size_t)e * NB + rig.n_shape + l] * expr[l];
+        }
+    }
+    // ---- joints = J_static + M . expr: 16 lanes per output (240 threads), Rodrigues on five more lanes
+    if (tid < WS_DA) out[tid] = 0.f;
+    __syncthreads();
+    if (tid < 240) {
+        const int k = tid >> 4, q = tid & 15;
+        const float* mrow = prepared + jo + 16 + (size_t)k * rig.n_expr;
+        float a = 0.f;
+        for (int l = q; l < rig.n_expr; l += 16) a += mrow[l] * expr[l];
+        a += dpp_f<0xB1, 0xf>(a);
+        a += dpp_f<0x4E, 0xf>(a);
+        a += dpp_f<0x141, 0xf>(a);
+        a += dpp_f<0x140, 0xf>(a);   // every lane of the row of 16 holds the sum
+        if (q == 0) out[WS_J + k] = prepared[jo + k] + a;
+    } else if (tid < 240 + GAB_NUM_JOINTS) {
+        const int j = tid - 240;
+        const float* pj = j == 0 ? rotation : j == 1 ? neck : j == 2 ? jaw : eyes + 3 * (j - 3);
+        const float pose[3] = {pj[0], pj[1], pj[2]};
+        float R[9];
+        rodrigues(pose, R);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            out[WS_R + 9 * j + k] = R[k];
+            if (j >= 1) out[WS_PF + 9 * (j - 1) + k] = R[k] - ((k % 4) == 0 ? 1.f : 0.f);
+        }
+    }
+    // ---- finish the rows: 32-lane sums (rows of 16 by DPP, row 0 -> 1 and 2 -> 3 by row_bcast:15)
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        float a = acc[r];
+        a += dpp_f<0xB1, 0xf>(a);
+        a += dpp_f<0x4E, 0xf>(a);
+        a += dpp_f<0x141, 0xf>(a);
+        a += dpp_f<0x140, 0xf>(a);
+        a += dpp_f<0x142, 0xa>(a);   // lanes 16..31 / 48..63 now hold their half-wave's sum
+        const int e = e0 + hw * PER + r;
+        if (hl == 31 && e < E) {
+            const float x = prepared[e] + a;
+            vs[hw * PER + r] = x;
+            v_shaped[e] = x;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float J[15], R[45], Rg[45], tg[15];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) J[k] = out[WS_J + k];
+#pragma unroll
+        for (int k = 0; k < 45; ++k) R[k] = out[WS_R + k];
+        chain_forward<FLAME_TREE>(rig.parents, R, J, Rg, tg);
+#pragma unroll
+        for (int j = 0; j < GAB_NUM_JOINTS; ++j)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) out[WS_A + 12 * j + 4 * r + c] = Rg[9 * j + 3 * r + c];
+                out[WS_A + 12 * j + 4 * r + 3] = tg[3 * j + r] - (Rg[9 * j + 3 * r] * J[3 * j] + Rg[9 * j + 3 * r + 1] * J[3 * j + 1] +
+                                                                  Rg[9 * j + 3 * r + 2] * J[3 * j + 2]);
+            }
+    } else if (tid >= 64) {
+        // meanwhile: pose-corrective offsets, 16 lanes per vertex (lanes 64..255 = 12 vertices per pass)
+        for (int vl = (tid - 64) >> 4; vl < VW; vl += 12) {
+            const int v = blockIdx.x * VW + vl, q = tid & 15;
+            float o[3] = {0.f, 0.f, 0.f};
+            if (v < rig.V)
+                for (int p = q; p < GAB_POSE_FEATURES; p += 16) {
+                    const float f = out[WS_PF + p];
+                    const float* row = rig.posedirs + (size_t)p * E + 3 * v;
+                    o[0] += f * row[0]; o[1] += f * row[1]; o[2] += f * row[2];
+                }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float a = o[k];
+                a += dpp_f<0xB1, 0xf>(a);
+                a += dpp_f<0x4E, 0xf>(a);
+                a += dpp_f<0x141, 0xf>(a);
+                a += dpp_f<0x140, 0xf>(a);
+                if (q == 0) po[3 * vl + k] = a;
+            }
+        }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {   // the workspace the backward reads (and its accumulators, handed over zeroed)
+        if (tid < WS_DA) ws[tid] = out[tid];
+        for (int k = WS_DA + tid; k < GAB_FLAME_WS_FLOATS; k += 256) ws[k] = 0.f;
+    }
+    if (tid < VW) {
+        const int v = blockIdx.x * VW + tid;
+        if (v < rig.V) {
+            float T[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) T[k] = 0.f;
+#pragma unroll
+            for (int j = 0; j < GAB_NUM_JOINTS; ++j) {
+                const float w = rig.lbs_weights[(size_t)v * GAB_NUM_JOINTS + j];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) T[k] += w * out[WS_A + 12 * j + k];
+            }
+            const float vp[3] = {po[3 * tid] + vs[3 * tid], po[3 * tid + 1] + vs[3 * tid + 1], po[3 * tid + 2] + vs[3 * tid + 2]};
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                verts[3 * v + r] = T[4 * r] * vp[0] + T[4 * r + 1] * vp[1] + T[4 * r + 2] * vp[2] + T[4 * r + 3] + translation[r];
+        }
+    }
+}
+
 struct ZeroSpec { float* p[8]; int n[8]; int count; };   // up to 8 buffers a kernel zero-fills on the side
 
 // ---------------------------------------------------------------------------------------------
@@ -380,22 +574,29 @@ __global__ __launch_bounds__(256) void k_skin_bwd(Rig rig, float* __restrict__ w
 // ---------------------------------------------------------------------------------------------
 // B2  chain backward (one thread; 5 joints): dA, d pose_feature -> d pose (15), dJ (15)
 // ---------------------------------------------------------------------------------------------
-template <bool FLAME_TREE>
-__global__ __launch_bounds__(64) void k_chain_bwd(Rig rig, float* __restrict__ ws, const float* __restrict__ rotation, const float* __restrict__ neck,
+// NT threads run it (one workgroup).  Mmat == nullptr: the classic three-kernel backward -- d_expr / d_shape are zeroed here and
+// k_blend_bwd (next launch) adds J_regressor^T dJ through the vertices.  Mmat != nullptr (prepared rig): dJ reaches d_expr as
+// M^T dJ right here, d_expr was zeroed by k_skin_bwd, and the blend workgroups of the same launch never look at dJ.
+template <bool FLAME_TREE, int NT>
+__device__ __forceinline__ void chain_bwd_body(Rig rig, float* __restrict__ ws, const float* __restrict__ rotation, const float* __restrict__ neck,
                             const float* __restrict__ jaw, const float* __restrict__ eyes, float* __restrict__ d_rotation,
                             float* __restrict__ d_neck, float* __restrict__ d_jaw, float* __restrict__ d_eyes,
-                            float* __restrict__ d_translation, float* __restrict__ d_expr, float* __restrict__ d_shape)
+                            float* __restrict__ d_translation, float* __restrict__ d_expr, float* __restrict__ d_shape,
+                            const float* __restrict__ Mmat)
 {
     // stage the whole workspace through LDS with one coalesced pass, then a single lane runs the
     // (inherently serial, 5-joint) chain out of LDS instead of ~250 dependent global loads
     __shared__ float sw[GAB_FLAME_WS_FLOATS];
-    for (int kk = threadIdx.x; kk < GAB_FLAME_WS_FLOATS; kk += 64) sw[kk] = ws[kk];
+    __shared__ float sdJ[16];
+    for (int kk = threadIdx.x; kk < GAB_FLAME_WS_FLOATS; kk += NT) sw[kk] = ws[kk];
     __syncthreads();
     // consumed: leave the accumulators zeroed for the next backward, and zero the targets k_blend_bwd adds into
-    for (int kk = WS_DA + (int)threadIdx.x; kk < WS_DJ; kk += 64) ws[kk] = 0.f;
-    for (int kk = threadIdx.x; kk < rig.n_expr; kk += 64) d_expr[kk] = 0.f;
-    if (d_shape)
-        for (int kk = threadIdx.x; kk < rig.n_shape; kk += 64) d_shape[kk] = 0.f;
+    for (int kk = WS_DA + (int)threadIdx.x; kk < WS_DJ; kk += NT) ws[kk] = 0.f;
+    if (!Mmat) {
+        for (int kk = threadIdx.x; kk < rig.n_expr; kk += NT) d_expr[kk] = 0.f;
+        if (d_shape)
+            for (int kk = threadIdx.x; kk < rig.n_shape; kk += NT) d_shape[kk] = 0.f;
+    }
     __shared__ float sdR[45];
     if (threadIdx.x == 0) {
     float J[15], R[45], Rg[45], tg[15];
@@ -466,9 +667,16 @@ __global__ __launch_bounds__(64) void k_chain_bwd(Rig rig, float* __restrict__ w
 #pragma unroll
     for (int k = 0; k < 45; ++k) sdR[k] = dR[k];
 #pragma unroll
-    for (int k = 0; k < 15; ++k) ws[WS_DJ + k] = dJ[k];
+    for (int k = 0; k < 15; ++k) { ws[WS_DJ + k] = dJ[k]; sdJ[k] = dJ[k]; }
     }
     __syncthreads();
+    if (Mmat)   // d_expr += M^T dJ (the joints' dependence on the expression coefficients)
+        for (int l = threadIdx.x; l < rig.n_expr; l += NT) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) a += Mmat[(size_t)k * rig.n_expr + l] * sdJ[k];
+            unsafeAtomicAdd(&d_expr[l], a);
+        }
     // Rodrigues backward: one lane per joint
     const int j = threadIdx.x;
     if (j < GAB_NUM_JOINTS) {
@@ -484,27 +692,37 @@ __global__ __launch_bounds__(64) void k_chain_bwd(Rig rig, float* __restrict__ w
         d_translation[j - 8] = sw[WS_DT + j - 8];
     }
 }
+template <bool FLAME_TREE>
+__global__ __launch_bounds__(64) void k_chain_bwd(Rig rig, float* __restrict__ ws, const float* __restrict__ rotation, const float* __restrict__ neck,
+                            const float* __restrict__ jaw, const float* __restrict__ eyes, float* __restrict__ d_rotation,
+                            float* __restrict__ d_neck, float* __restrict__ d_jaw, float* __restrict__ d_eyes,
+                            float* __restrict__ d_translation, float* __restrict__ d_expr, float* __restrict__ d_shape)
+{
+    chain_bwd_body<FLAME_TREE, 64>(rig, ws, rotation, neck, jaw, eyes, d_rotation, d_neck, d_jaw, d_eyes, d_translation, d_expr, d_shape, nullptr);
+}
 
 // ---------------------------------------------------------------------------------------------
 // B3  blend backward: g_total = dL/dv_posed + J_regressor^T dJ (+ external dL/dv_shaped);
 //     d static_offset = g_total; d betas = shapedirs^T g_total (128 rows per workgroup)
 // ---------------------------------------------------------------------------------------------
 #define GAB_BLEND_BWD_ROWS 128   // swept 64 / 128 / 256: 11.0 / 8.7 / 9.7 us (fewer, less contended atomics vs parallelism)
-__global__ __launch_bounds__(256) void k_blend_bwd(Rig rig, const float* __restrict__ ws, const float* __restrict__ g_vs,
-                                                    const float* __restrict__ dL_dv_shaped, float* __restrict__ d_static_offset,
-                                                    float* __restrict__ d_shape, float* __restrict__ d_expr)
+// ws == nullptr: no J_regressor^T dJ term (prepared rig: it went into d_expr as M^T dJ)
+__device__ __forceinline__ void blend_bwd_body(Rig rig, const float* __restrict__ ws, const float* __restrict__ g_vs,
+                                               const float* __restrict__ dL_dv_shaped, float* __restrict__ d_static_offset,
+                                               float* __restrict__ d_shape, float* __restrict__ d_expr, int block)
 {
     __shared__ float g[GAB_BLEND_BWD_ROWS];
     const int tid = threadIdx.x;
     const int E = 3 * rig.V;
-    const int e0 = blockIdx.x * GAB_BLEND_BWD_ROWS;
+    const int e0 = block * GAB_BLEND_BWD_ROWS;
     if (tid < GAB_BLEND_BWD_ROWS) {
         const int e = e0 + tid;
         float x = 0.f;
         if (e < E) {
             const int v = e / 3, k = e - 3 * v;
             x = g_vs[e];
-            for (int j = 0; j < GAB_NUM_JOINTS; ++j) x += rig.J_regressor[(size_t)j * rig.V + v] * ws[WS_DJ + 3 * j + k];
+            if (ws)
+                for (int j = 0; j < GAB_NUM_JOINTS; ++j) x += rig.J_regressor[(size_t)j * rig.V + v] * ws[WS_DJ + 3 * j + k];
             if (dL_dv_shaped) x += dL_dv_shaped[e];
             if (d_static_offset) d_static_offset[e] = x;
         }
@@ -544,6 +762,26 @@ __global__ __launch_bounds__(256) void k_blend_bwd(Rig rig, const float* __restr
         }
         __syncthreads();
     }
+}
+__global__ __launch_bounds__(256) void k_blend_bwd(Rig rig, const float* __restrict__ ws, const float* __restrict__ g_vs,
+                                                    const float* __restrict__ dL_dv_shaped, float* __restrict__ d_static_offset,
+                                                    float* __restrict__ d_shape, float* __restrict__ d_expr)
+{
+    blend_bwd_body(rig, ws, g_vs, dL_dv_shaped, d_static_offset, d_shape, d_expr, (int)blockIdx.x);
+}
+// prepared rig: B2 and B3 side by side in one launch -- workgroup 0 runs the chain (and adds M^T dJ), the others the
+// expression block of shapedirs^T g; neither waits for the other
+template <bool FLAME_TREE>
+__global__ __launch_bounds__(256) void k_chain_blend_bwd(Rig rig, float* __restrict__ ws, const float* __restrict__ g_vs, const float* __restrict__ Mmat,
+                                                          const float* __restrict__ rotation, const float* __restrict__ neck,
+                                                          const float* __restrict__ jaw, const float* __restrict__ eyes,
+                                                          float* __restrict__ d_rotation, float* __restrict__ d_neck, float* __restrict__ d_jaw,
+                                                          float* __restrict__ d_eyes, float* __restrict__ d_translation, float* __restrict__ d_expr)
+{
+    if (blockIdx.x == 0)
+        chain_bwd_body<FLAME_TREE, 256>(rig, ws, rotation, neck, jaw, eyes, d_rotation, d_neck, d_jaw, d_eyes, d_translation, d_expr, nullptr, Mmat);
+    else
+        blend_bwd_body(rig, nullptr, g_vs, nullptr, nullptr, nullptr, d_expr, (int)blockIdx.x - 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1129,6 +1367,84 @@ int gab_flame_backward(const GabRig* rig_, const float* shape, const float* expr
     hipLaunchKernelGGL(gab::k_blend_bwd, dim3((E + GAB_BLEND_BWD_ROWS - 1) / GAB_BLEND_BWD_ROWS), dim3(256), 0, st, rig, (const float*)ws,
                        (const float*)scratch, dL_dv_shaped, d_static_offset, d_shape, d_expr);
     LAUNCH_CHECK("k_blend_bwd");
+    return GAB_OK;
+}
+
+int64_t gab_flame_prepared_floats(const GabRig* rig_)
+{
+    if (!rig_ || rig_->V <= 0 || rig_->n_expr < 0) return -1;
+    return (int64_t)gab::prep_joint_offset(rig_->V) + 16 + 15 * (int64_t)rig_->n_expr;
+}
+
+int gab_flame_prepare(const GabRig* rig_, const float* shape, const float* static_offset, float* prepared, void* stream_)
+{
+    gab::Rig rig;
+    if (int rc = to_rig(rig_, &rig)) return rc;
+    if ((rig.n_shape && !shape) || !prepared) return fail(GAB_E_ARG, "gab_flame_prepare: NULL buffer");
+    hipStream_t st = (hipStream_t)stream_;
+    const int E = 3 * rig.V, outs = 15 + 15 * rig.n_expr;
+    hipLaunchKernelGGL(gab::k_prep_rows, dim3((E + 3) / 4), dim3(256), 0, st, rig, shape, static_offset, prepared);
+    LAUNCH_CHECK("k_prep_rows");
+    hipLaunchKernelGGL(gab::k_prep_joints, dim3((outs + 3) / 4), dim3(256), 0, st, rig, prepared);
+    LAUNCH_CHECK("k_prep_joints");
+    return GAB_OK;
+}
+
+int gab_flame_forward_prepared(const GabRig* rig_, const float* prepared, const float* expr, const float* rotation, const float* neck,
+                               const float* jaw, const float* eyes, const float* translation, float* verts, float* v_shaped, float* ws,
+                               void* stream_)
+{
+    gab::Rig rig;
+    if (int rc = to_rig(rig_, &rig)) return rc;
+    if (!prepared || (rig.n_expr && !expr) || !rotation || !neck || !jaw || !eyes || !translation || !verts || !v_shaped || !ws)
+        return fail(GAB_E_ARG, "gab_flame_forward_prepared: NULL buffer");
+    hipStream_t st = (hipStream_t)stream_;
+    const int blocks = (rig.V + GAB_FUSED_VERTS - 1) / GAB_FUSED_VERTS;
+    const bool flame_tree = rig.parents[1] == 0 && rig.parents[2] == 1 && rig.parents[3] == 1 && rig.parents[4] == 1;
+    if (flame_tree)
+        hipLaunchKernelGGL(gab::k_flame_fused<true>, dim3(blocks), dim3(256), 0, st, rig, prepared, expr, rotation, neck, jaw, eyes, translation, verts, v_shaped, ws);
+    else
+        hipLaunchKernelGGL(gab::k_flame_fused<false>, dim3(blocks), dim3(256), 0, st, rig, prepared, expr, rotation, neck, jaw, eyes, translation, verts, v_shaped, ws);
+    LAUNCH_CHECK("k_flame_fused");
+    return GAB_OK;
+}
+
+int gab_flame_backward_prepared(const GabRig* rig_, const float* prepared, const float* rotation, const float* neck, const float* jaw,
+                                const float* eyes, const float* v_shaped, float* ws, const float* dL_dverts, float* d_expr,
+                                float* d_rotation, float* d_neck, float* d_jaw, float* d_eyes, float* d_translation, float* scratch,
+                                int32_t zero_count, float* const* zero_buffers_host, const int32_t* zero_sizes_host, void* stream_)
+{
+    if (zero_count < 0 || zero_count > 7 || (zero_count > 0 && (!zero_buffers_host || !zero_sizes_host)))
+        return fail(GAB_E_ARG, "gab_flame_backward_prepared: 0..7 zero-fill buffers");
+    gab::Rig rig;
+    if (int rc = to_rig(rig_, &rig)) return rc;
+    if (!prepared || !rotation || !neck || !jaw || !eyes || !v_shaped || !ws || !dL_dverts || !d_expr || !d_rotation || !d_neck || !d_jaw ||
+        !d_eyes || !d_translation || !scratch)
+        return fail(GAB_E_ARG, "gab_flame_backward_prepared: NULL buffer");
+    gab::ZeroSpec zs;
+    bool covers_expr = false;   // d_expr is added into by both roles of the second launch: it must be zero before that launch
+    for (int i = 0; i < 8; ++i) {
+        zs.p[i] = i < zero_count ? zero_buffers_host[i] : nullptr;
+        zs.n[i] = i < zero_count ? zero_sizes_host[i] : 0;
+        if (i < zero_count && (zs.n[i] < 0 || (zs.n[i] > 0 && !zs.p[i]))) return fail(GAB_E_ARG, "gab_flame_backward_prepared: bad zero-fill buffer %d", i);
+        if (i < zero_count && d_expr >= zs.p[i] && d_expr + rig.n_expr <= zs.p[i] + zs.n[i]) covers_expr = true;
+    }
+    zs.count = zero_count;
+    if (!covers_expr) { zs.p[zs.count] = d_expr; zs.n[zs.count] = rig.n_expr; ++zs.count; }
+    hipStream_t st = (hipStream_t)stream_;
+    const int E = 3 * rig.V;
+    hipLaunchKernelGGL(gab::k_skin_bwd, dim3((rig.V + 255) / 256), dim3(256), 0, st, rig, ws, v_shaped, dL_dverts, scratch, zs);
+    LAUNCH_CHECK("k_skin_bwd");
+    const float* Mmat = prepared + gab::prep_joint_offset(rig.V) + 16;
+    const int blocks = 1 + (E + GAB_BLEND_BWD_ROWS - 1) / GAB_BLEND_BWD_ROWS;
+    const bool flame_tree = rig.parents[1] == 0 && rig.parents[2] == 1 && rig.parents[3] == 1 && rig.parents[4] == 1;
+    if (flame_tree)
+        hipLaunchKernelGGL(gab::k_chain_blend_bwd<true>, dim3(blocks), dim3(256), 0, st, rig, ws, (const float*)scratch, Mmat, rotation, neck, jaw, eyes,
+                           d_rotation, d_neck, d_jaw, d_eyes, d_translation, d_expr);
+    else
+        hipLaunchKernelGGL(gab::k_chain_blend_bwd<false>, dim3(blocks), dim3(256), 0, st, rig, ws, (const float*)scratch, Mmat, rotation, neck, jaw, eyes,
+                           d_rotation, d_neck, d_jaw, d_eyes, d_translation, d_expr);
+    LAUNCH_CHECK("k_chain_blend_bwd");
     return GAB_OK;
 }
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GAB_ABI_VERSION 1
+#define GAB_ABI_VERSION 2
 #define GAB_OK 0
 #define GAB_E_ARG (-1)
 #define GAB_E_HIP (-2)
@@ -72,6 +72,27 @@ int gab_flame_backward(const GabRig* rig, const float* shape, const float* expr,
                        float* d_shape, float* d_expr, float* d_rotation, float* d_neck, float* d_jaw, float* d_eyes,
                        float* d_translation, float* d_static_offset, float* scratch,
                        int32_t zero_count, float* const* zero_buffers_host, const int32_t* zero_sizes_host, void* stream);
+
+/* ---- FLAME with a PREPARED rig: the per-frame part only (what a training step runs) -----------------------------------------
+ * gab_flame_prepare folds everything that does not depend on the per-frame parameters -- the shape block of the blend shapes
+ * and static_offset (v_static), the joint regression of that (J_static) and M = J_regressor . shapedirs[:, n_shape:], so that
+ * joints = J_static + M . expr (flame_model/lbs.py:222-225 restated: J_regressor (v_template + S beta) is affine in beta) --
+ * into `prepared` (gab_flame_prepared_floats(rig) floats).  Call it again whenever shape, static_offset or the rig change.
+ * With it the forward is ONE launch (blend shapes of the expression block, chain, skinning) and the backward TWO (skinning; chain
+ * and shapedirs^T g side by side), against 3 + 3: same outputs, same `ws` contract as gab_flame_forward / gab_flame_backward
+ * (the two backward entries are interchangeable on a state either forward wrote).  The prepared backward produces the gradients
+ * of the per-frame parameters only: use gab_flame_backward when shape / static_offset / an external dL/dv_shaped take part. */
+int64_t gab_flame_prepared_floats(const GabRig* rig);
+int gab_flame_prepare(const GabRig* rig, const float* shape, const float* static_offset /*(V,3) or NULL*/, float* prepared, void* stream);
+int gab_flame_forward_prepared(const GabRig* rig, const float* prepared, const float* expr, const float* rotation, const float* neck,
+                               const float* jaw, const float* eyes /*6*/, const float* translation,
+                               float* verts /*(V,3)*/, float* v_shaped /*(V,3)*/, float* ws /*GAB_FLAME_WS_FLOATS*/, void* stream);
+/* zero_*: as gab_flame_backward, at most 7 buffers (d_expr is zero-filled by the first kernel as well unless one of them covers it) */
+int gab_flame_backward_prepared(const GabRig* rig, const float* prepared, const float* rotation, const float* neck, const float* jaw,
+                                const float* eyes, const float* v_shaped, float* ws, const float* dL_dverts,
+                                float* d_expr, float* d_rotation, float* d_neck, float* d_jaw, float* d_eyes, float* d_translation,
+                                float* scratch, int32_t zero_count, float* const* zero_buffers_host, const int32_t* zero_sizes_host,
+                                void* stream);
 
 /* ---- per-face frames ----------------------------------------------------------------------- */
 /* d_verts_zeroed: optional (V,3) buffer the forward zero-fills on the side, to be handed to the backward as its

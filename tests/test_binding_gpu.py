@@ -92,6 +92,47 @@ def test_flame_full_size_forward_backward_vs_torch(with_shape_grad):
             assert a[k].grad is None
 
 
+def test_flame_prepared_rig_path_vs_torch_and_classic():
+    """The training configuration (shape and static_offset not optimised, no gradient into v_shaped): one forward launch and two
+    backward launches on the prepared rig (include/gab.h: gab_flame_prepare).  Same values and gradients as composed torch and as the
+    classic three-kernel path; the prepared buffer is re-made when shape changes in place."""
+    from gaussianavatars_amd import binding as B
+
+    dev = _dev()
+    rig = S.flame_rig(4)
+    seq = S.flame_sequence(8, 4)
+    t = lambda a, g=True: torch.as_tensor(a, device=dev).clone().requires_grad_(g)
+    mk = lambda: dict(shape=t(seq["shape"][None], False), expr=t(seq["expr"][[5]]), rot=t(seq["rotation"][[5]]),
+                      neck=t(seq["neck_pose"][[5]]), jaw=t(seq["jaw_pose"][[5]]), eyes=t(seq["eyes_pose"][[5]]),
+                      trans=t(seq["translation"][[5]]), so=t(seq["static_offset"], False))
+    heads = [_Head(rig, dev, 300) for _ in range(2)]
+    heads[1].flame_impl = "classic"
+    a, b, c = mk(), mk(), mk()
+    v1, vs1 = B.flame_forward(heads[0], a["shape"], a["expr"], a["rot"], a["neck"], a["jaw"], a["eyes"], a["trans"], a["so"])
+    v3, vs3 = B.flame_forward(heads[1], c["shape"], c["expr"], c["rot"], c["neck"], c["jaw"], c["eyes"], c["trans"], c["so"])
+    v2, vs2 = U.flame_forward(heads[0].rigdict(), b["shape"], b["expr"], b["rot"], b["neck"], b["jaw"], b["eyes"], b["trans"], b["so"])
+    assert getattr(heads[0], "_gab_prepared", None) is not None and getattr(heads[1], "_gab_prepared", None) is None
+    _close(v1, v2, 2e-5, "verts (prepared) vs torch")
+    _close(vs1, vs2, 2e-5, "v_shaped (prepared) vs torch")
+    _close(v1, v3, 1e-5, "verts prepared vs classic")
+    w1 = torch.randn(v1.shape, generator=torch.Generator(device="cpu").manual_seed(1)).to(dev)
+    for v in (v1, v2, v3):
+        (v * w1).sum().backward()
+    for k in a:
+        if a[k].requires_grad:
+            _close(a[k].grad, b[k].grad, 3e-4, f"d{k} (prepared) vs torch")
+            _close(a[k].grad, c[k].grad, 1e-4, f"d{k} prepared vs classic")
+    # an in-place change of shape invalidates the prepared buffer
+    before = heads[0]._gab_prepared[1]
+    with torch.no_grad():
+        a["shape"].mul_(0.5)
+        b["shape"].mul_(0.5)
+    v1b, _ = B.flame_forward(heads[0], a["shape"], a["expr"], a["rot"], a["neck"], a["jaw"], a["eyes"], a["trans"], a["so"])
+    v2b, _ = U.flame_forward(heads[0].rigdict(), b["shape"], b["expr"], b["rot"], b["neck"], b["jaw"], b["eyes"], b["trans"], b["so"])
+    assert heads[0]._gab_prepared[1] is not before
+    _close(v1b, v2b, 2e-5, "verts after an in-place shape update")
+
+
 def test_face_frames_and_bind_forward_backward_vs_torch():
     from gaussianavatars_amd import binding as B
 
