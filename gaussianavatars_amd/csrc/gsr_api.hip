@@ -469,7 +469,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
             TIMED(GSR_K_TILE_SORT, stream);
             // the bitmap holds every rank of the frame (P bounds the ranked splats; binning_path() keeps P <= GSR_RANK_MAX_SPLATS here)
             const uint32_t words = (uint32_t)(((size_t)P + 2047) / 2048) * 64u;
-            hipLaunchKernelGGL(gsr::k_tile_rank, dim3(tiles), dim3(256), (size_t)words * 6, stream, words, (const uint4*)(b + bl.tdesc), (const uint2*)ranks, (const float*)pa.depths,
+            hipLaunchKernelGGL(gsr::k_tile_rank, dim3(tiles), dim3(GSR_RANK_TILE_THREADS), (size_t)words * 6, stream, words, (const uint4*)(b + bl.tdesc), (const uint2*)ranks, (const float*)pa.depths,
                                (const gsr::BinHeader*)hdr, write_lists ? (unsigned long long*)(b + bl.keys) : nullptr,
                                (uint32_t*)(b + bl.point_list), write_lists ? qlist : nullptr, qpos, qcount, qstart,
                                cap, (const unsigned long long*)total_dev);

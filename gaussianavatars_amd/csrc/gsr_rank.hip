@@ -403,14 +403,14 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
 //      ballots + one scan of the (chunk, wave) counters; the parity modes also write the reference-format key list
 // No comparison, no data-dependent loop, every step entry-parallel.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tile_rank(uint32_t words, const uint4* __restrict__ tdesc, const uint2* __restrict__ ranks,
+__global__ __launch_bounds__(GSR_RANK_TILE_THREADS) void k_tile_rank(uint32_t words, const uint4* __restrict__ tdesc, const uint2* __restrict__ ranks,
                                                     const float* __restrict__ depths, const BinHeader* __restrict__ hdr,
                                                     unsigned long long* __restrict__ keys, uint32_t* __restrict__ point_list,
                                                     uint32_t* __restrict__ qlist, uint32_t* __restrict__ qpos, uint32_t* __restrict__ qcount,
                                                     uint32_t* __restrict__ qstart, unsigned long long capacity,
                                                     const unsigned long long* __restrict__ total_dev)
 {
-    constexpr int THREADS = 256, NW = THREADS / 64, EPT = GSR_RANK_WINDOW / THREADS, NE = EPT * NW;
+    constexpr int THREADS = GSR_RANK_TILE_THREADS, NW = THREADS / 64, EPT = GSR_RANK_WINDOW / THREADS, NE = EPT * NW;
     constexpr int ROWS = GSR_RANK_MAX_SPLATS / 2048, RPL = (ROWS + 63) / 64;   // rows of 64 words = 2048 ranks
     constexpr int UB = 8;   // entries per thread whose loads are in flight together
     static_assert(NE <= 64, "one (chunk, wave) counter per lane in the epilogue's scan");
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256) void k_tile_rank(uint32_t words, const uint4* 
             }
         }
         __syncthreads();
-        {   // wave q scans quadrant q's NE (chunk, wave) counters
+        if (wid < 4) {   // wave q scans quadrant q's NE (chunk, wave) counters
             const uint32_t a = lane < NE ? cntw[wid][lane] : 0u;
             const uint32_t incl = wave_scan_incl_u32(a);
             if (lane < NE) cntw[wid][lane] = incl - a;
