@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_qcount(QBinArgs a)
             auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
             Span r;
             r.px = bc(m0.x); r.py = bc(m0.y); r.B = bc(m0.z); r.det = bc(m0.w);
-            r.twoTA = bc(m1.x); r.invA = bc(m1.y); r.dyr = bc(m1.z); r.mode = __float_as_int(bc(m1.w));
+            r.twoTA = bc(m1.x); r.A = bc(m1.y); r.dyr = bc(m1.z); r.mode = __float_as_int(bc(m1.w));
             const uint32_t r0 = __float_as_uint(bc(m2.x)), r1 = __float_as_uint(bc(m2.y));
             const int qx0 = (int)(r0 & 0xFFFFu), qy0 = (int)(r0 >> 16), qx1 = (int)(r1 & 0xFFFFu), qy1 = (int)(r1 >> 16);
             const int w = qx1 - qx0;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_qcount(QBinArgs a)
                 const int row = (int)(((float)k + 0.5f) * rw);
                 const int qx = qx0 + k - row * w, qy = qy0 + row;
                 bool hit = k < nq;
-                if (hit) hit = band_hit(band_of(r, (float)(qy * 8)), (float)(qx * 8));
+                if (hit) hit = band_hit(band_of(r, (float)(qy * 8)), r, (float)(qx * 8));
                 const unsigned long long m = __ballot(hit);
                 if (round < GSR_WALK_MASKS && lane == 0) mask_row[(size_t)l * GSR_WALK_MASKS + round] = m;
                 if (hit) {
@@ -316,11 +316,11 @@ __global__ __launch_bounds__(64) void k_qscatter(QBinArgs a)
                 if (!saved) {   // a rect of more than 64 * GSR_WALK_MASKS quadrants: test again
                     if (r.mode == 3) {
                         const float4 g0 = a.brec[3 * (size_t)sid], g1 = a.brec[3 * (size_t)sid + 1];
-                        r.px = g0.x; r.py = g0.y; r.B = g0.z; r.det = g0.w; r.twoTA = g1.x; r.invA = g1.y; r.dyr = g1.z;
+                        r.px = g0.x; r.py = g0.y; r.B = g0.z; r.det = g0.w; r.twoTA = g1.x; r.A = g1.y; r.dyr = g1.z;
                         r.mode = __float_as_int(g1.w);
                     }
                     bool hit = k < nq;
-                    if (hit) hit = band_hit(band_of(r, (float)(qy * 8)), (float)(qx * 8));
+                    if (hit) hit = band_hit(band_of(r, (float)(qy * 8)), r, (float)(qx * 8));
                     m = __ballot(hit);
                 }
                 if ((m >> lane) & 1ull) {

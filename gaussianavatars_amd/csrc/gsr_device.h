@@ -235,41 +235,55 @@ __device__ __forceinline__ bool rect_reach(const Reach& r, float x0, float y0, f
 // The same question per 8-pixel BAND, which is what the quadrant streams ask (one answer per band serves every quadrant of it):
 // the x-extent [xl, xr] of {Q <= T} over the rows of pixel centres y0 .. y0 + 7.  The extreme of dx over the band sits where the
 // ellipse's own extreme point (dx_m, dyr), dyr = -(B/C) dx_m, is clamped into the band: on the line dy = b,
-//     A dx^2 + 2 B b dx + C b^2 - 2 T = 0   =>   dx = (-B b +- sqrt(2 T A - det b^2)) / A,
-// real iff the line meets the ellipse.  T = (tau + 1e-3) / 0.999 carries rect_reach's padding, the interval another 1e-2 px.
+//     A dx^2 + 2 B b dx + C b^2 - 2 T = 0   =>   dx = (-B b +- sqrt(D)) / A,   D = 2 T A - det b^2,
+// real iff the line meets the ellipse.  A quadrant of pixel centres x0 .. x0 + 7 is reached iff xl <= x0 + 7 and xr >= x0, i.e.
+//     sqrt(Dl) >= (px - eps - x0 - 7) A - B bl     and     sqrt(Dr) >= (x0 - px - eps) A + B br
+// -- compared through the squares, so the test costs no square root.  T = (tau + 1e-3) / 0.999 carries rect_reach's padding,
+// eps = 1e-2 px another margin on the interval.
 struct Span {
-    float px, py, B, det, twoTA, invA, dyr;
+    float px, py, B, det, twoTA, A, dyr;
     int mode;   // as Reach: 0 test, 1 keep everywhere, 2 never
 };
 __device__ __forceinline__ Span span_of(const Reach& r)
 {
     Span s;
     s.px = r.px; s.py = r.py; s.B = r.B; s.mode = r.mode;
-    s.det = 0.f; s.twoTA = 0.f; s.invA = 0.f; s.dyr = 0.f;
+    s.det = 0.f; s.twoTA = 0.f; s.A = 0.f; s.dyr = 0.f;
     if (r.mode) return s;
     const float T = (r.tau + 1e-3f) / 0.999f;
     s.det = r.A * r.C - r.B * r.B;
     s.twoTA = 2.f * T * r.A;
-    s.invA = 1.f / r.A;
+    s.A = r.A;
     s.dyr = r.nBiC * sqrtf(2.f * T * r.C / s.det);
-    if (!(fabsf(s.dyr) < 1e15f && s.twoTA < 1e30f && s.invA < 1e30f && s.det > 0.f)) s.mode = 1;   // degenerate: keep everywhere
+    if (!(fabsf(s.dyr) < 1e15f && s.twoTA < 1e30f && s.A > 1e-30f && s.A < 1e30f && s.det > 0.f)) s.mode = 1;   // degenerate: keep everywhere
     return s;
 }
-struct Band { float xl, xr; };   // pixel centres x of the band the ellipse can reach: xl <= x <= xr (empty: xl > xr)
+struct Band {
+    float dl, dr, Bbl, Bbr;   // discriminants and B b on the two lines that carry the band's left / right extreme
+    int any;                  // 0: the ellipse does not reach the band, 1: test, 2: reaches everything (degenerate conic)
+};
 __device__ __forceinline__ Band band_of(const Span& s, float y0)
 {
-    const float big = 3.0e38f;
     Band e;
-    if (s.mode) { e.xl = s.mode == 1 ? -big : big; e.xr = s.mode == 1 ? big : -big; return e; }
+    e.dl = e.dr = e.Bbl = e.Bbr = 0.f;
+    if (s.mode) { e.any = s.mode == 1 ? 2 : 0; return e; }
     const float b0 = y0 - s.py, b1 = b0 + 7.f;
     const float br = fminf(fmaxf(s.dyr, b0), b1), bl = fminf(fmaxf(-s.dyr, b0), b1);
-    const float dr = s.twoTA - s.det * br * br, dl = s.twoTA - s.det * bl * bl;
-    const bool any = dr >= 0.f && dl >= 0.f;
-    e.xr = any ? s.px + (sqrtf(dr) - s.B * br) * s.invA + 1e-2f : -big;
-    e.xl = any ? s.px - (sqrtf(dl) + s.B * bl) * s.invA - 1e-2f : big;
+    e.dr = s.twoTA - s.det * br * br;
+    e.dl = s.twoTA - s.det * bl * bl;
+    e.Bbr = s.B * br;
+    e.Bbl = s.B * bl;
+    e.any = (e.dr >= 0.f && e.dl >= 0.f) ? 1 : 0;
     return e;
 }
-__device__ __forceinline__ bool band_hit(const Band& e, float x0) { return e.xl <= x0 + 7.f && e.xr >= x0; }   // quadrant of pixel centres x0 .. x0 + 7
+// quadrant of pixel centres x0 .. x0 + 7 of the band
+__device__ __forceinline__ bool band_hit(const Band& e, const Span& s, float x0)
+{
+    const float tl = (s.px - 1e-2f - (x0 + 7.f)) * s.A - e.Bbl;
+    const float tr = (x0 - s.px - 1e-2f) * s.A + e.Bbr;
+    const bool hit = (tl <= 0.f || e.dl >= tl * tl) && (tr <= 0.f || e.dr >= tr * tr);
+    return e.any == 2 || (e.any == 1 && hit);
+}
 
 // Snug tile rect (GsrSettings.tile_culling): the axis-aligned bounding box of the {alpha >= 1/255} ellipse
 //   |dx| <= sqrt(2 tau C / det),  |dy| <= sqrt(2 tau A / det),  det = A C - B^2
@@ -296,7 +310,8 @@ __device__ __forceinline__ void snug_rect(const Reach& r, int& minx, int& miny, 
 __device__ __forceinline__ uint32_t quadrant_mask_of(const Span& s, float ox, float oy)
 {
     const Band e0 = band_of(s, oy), e1 = band_of(s, oy + 8.f);
-    return (band_hit(e0, ox) ? 1u : 0u) | (band_hit(e0, ox + 8.f) ? 2u : 0u) | (band_hit(e1, ox) ? 4u : 0u) | (band_hit(e1, ox + 8.f) ? 8u : 0u);
+    return (band_hit(e0, s, ox) ? 1u : 0u) | (band_hit(e0, s, ox + 8.f) ? 2u : 0u) | (band_hit(e1, s, ox) ? 4u : 0u) |
+           (band_hit(e1, s, ox + 8.f) ? 8u : 0u);
 }
 __device__ __forceinline__ uint32_t quadrant_mask(float2 p, float4 co, float ox, float oy)
 {
@@ -460,7 +475,7 @@ struct PreprocessArgs {
     uint32_t* __restrict__ bcursor;       // [nb] bucket fill cursors, zeroed here
     uint2* __restrict__ pstat;            // [workgroups] (min, max) depth bits of this workgroup's visible splats; (~0, 0) when it has none
     ushort4* __restrict__ srect;          // [P] tile rect the splat is binned into (snug when cull != 0); zero area = not binned
-    float4* __restrict__ sspan;           // [P][2] the splat's Span (px, py, B, det | twoTA, invA, dyr, mode): operands of the quadrant test
+    float4* __restrict__ sspan;           // [P][2] the splat's Span (px, py, B, det | twoTA, A, dyr, mode): operands of the quadrant test
     int cull;                             // settings.tile_culling != 0
 };
 

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
                 if (nt) {
                     const Span sp = span_of(r);
                     a.sspan[2 * i + 0] = make_float4(sp.px, sp.py, sp.B, sp.det);
-                    a.sspan[2 * i + 1] = make_float4(sp.twoTA, sp.invA, sp.dyr, __int_as_float(sp.mode));
+                    a.sspan[2 * i + 1] = make_float4(sp.twoTA, sp.A, sp.dyr, __int_as_float(sp.mode));
                 }
             }
             a.srect[i] = nt ? make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy) : make_ushort4(0, 0, 0, 0);
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
                 r0 = (uint32_t)(2 * minx) | ((uint32_t)(2 * miny) << 16);
                 r1 = (uint32_t)(2 * maxx) | ((uint32_t)(2 * maxy) << 16);
                 a.brec[3 * i + 0] = make_float4(sp.px, sp.py, sp.B, sp.det);
-                a.brec[3 * i + 1] = make_float4(sp.twoTA, sp.invA, sp.dyr, __int_as_float(sp.mode));
+                a.brec[3 * i + 1] = make_float4(sp.twoTA, sp.A, sp.dyr, __int_as_float(sp.mode));
             }
         }
         if (i < a.P) a.brec[3 * i + 2] = make_float4(__uint_as_float(r0), __uint_as_float(r1), 0.f, 0.f);

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
         uint32_t n = 0, rk = 0;
         int minx = 0, miny = 0, maxx = 0, maxy = 0;
         Span sp;
-        sp.px = sp.py = sp.B = sp.det = sp.twoTA = sp.invA = sp.dyr = 0.f;
+        sp.px = sp.py = sp.B = sp.det = sp.twoTA = sp.A = sp.dyr = 0.f;
         sp.mode = 2;
         if (i < end) {
             const ushort4 q = srect[i];
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
                 rk = rank[i];
                 const float4 s0 = sspan[2 * (size_t)i], s1 = sspan[2 * (size_t)i + 1];
                 sp.px = s0.x; sp.py = s0.y; sp.B = s0.z; sp.det = s0.w;
-                sp.twoTA = s1.x; sp.invA = s1.y; sp.dyr = s1.z; sp.mode = __float_as_int(s1.w);
+                sp.twoTA = s1.x; sp.A = s1.y; sp.dyr = s1.z; sp.mode = __float_as_int(s1.w);
             }
         }
         for_each_tile_grouped(minx, miny, maxx, maxy, n, [&](uint32_t x, uint32_t y, int src) {
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
             uint32_t brk = rk, bidx = (uint32_t)i;
             if (src != me) {   // whole-wave expansion of a large rect: the owner's operands (src is wave-uniform there)
                 auto bf = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
-                b.px = bf(sp.px); b.py = bf(sp.py); b.B = bf(sp.B); b.det = bf(sp.det); b.twoTA = bf(sp.twoTA); b.invA = bf(sp.invA); b.dyr = bf(sp.dyr);
+                b.px = bf(sp.px); b.py = bf(sp.py); b.B = bf(sp.B); b.det = bf(sp.det); b.twoTA = bf(sp.twoTA); b.A = bf(sp.A); b.dyr = bf(sp.dyr);
                 b.mode = __builtin_amdgcn_readlane(sp.mode, src);
                 brk = (uint32_t)__builtin_amdgcn_readlane((int)rk, src);
                 bidx = (uint32_t)__builtin_amdgcn_readlane(i, src);
