@@ -137,25 +137,25 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int P, int gx, 
         for (int w = 0; w < NWV; ++w) tot += rect_sum[w];
         atomicAdd(rect_total, tot);
     }
+    // One RETURNING L2 atomic per (workgroup, non-empty bin) both counts the bin and reserves this workgroup's sub-range inside it
+    // (in arrival order): the offset is what the rows keep for the two scatters, which then need no atomics of their own.
     uint32_t* __restrict__ bmine = bhist + (size_t)blockIdx.x * nb;
     for (uint32_t t = tid; t < nb; t += NT) {
         const uint32_t v = dh[t];
-        bmine[t] = v;
-        if (v) atomicAdd(&bcount[t], v);
+        bmine[t] = v ? atomicAdd(&bcount[t], v) : 0u;
     }
     if (direct) return;
     uint32_t* __restrict__ mine = block_hist + (size_t)blockIdx.x * tiles;
     for (int t = tid; t < tiles; t += NT) {
         const uint32_t v = hist[t];
-        mine[t] = v;
-        if (v) atomicAdd(&tile_count[t], v);
+        mine[t] = v ? atomicAdd(&tile_count[t], v) : 0u;
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // k_rdscatter: same chunking.  Every workgroup scans the nb bucket counters itself (nb <= GSR_RANK_MAX_BUCKETS: a few
-// microseconds, no separate one-workgroup launch), reserves one sub-range per non-empty bucket of its own histogram with a
-// single returning L2 atomic, then hands out slots from LDS cursors.  Workgroup 0 publishes the bucket offsets and the number
+// microseconds, no separate one-workgroup launch) and hands out slots from LDS cursors that start at the sub-range k_rcount
+// reserved for it in every bucket.  Workgroup 0 publishes the bucket offsets and the number
 // of ranked splats.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rdscatter(int P, uint32_t nb, const ushort4* __restrict__ srect, const float* __restrict__ depths,
@@ -184,8 +184,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rdscatter(int P, uint3
         if (t < nb) {
             const uint32_t c = bcount[t];
             if (blockIdx.x == 0) bstart[t] = run;
-            const uint32_t v = mine[t];
-            base[t] = v ? run + atomicAdd(&bcursor[t], v) : 0u;
+            base[t] = run + mine[t];   // this workgroup's first slot in bucket t (k_rcount reserved it)
             run += c;
         }
     }
@@ -324,8 +323,7 @@ __global__ __launch_bounds__(256) void k_rdsort(const uint32_t* __restrict__ bco
 
 // ------------------------------------------------------------------------------------------
 // k_rscatter: one entry (rank, splat | quadrant mask << 28) into every tile segment of the splat's rect.  Same chunking as
-// k_rcount, whose per-workgroup tile histogram it re-uses: one returning L2 atomic per (workgroup, touched tile) reserves a
-// contiguous sub-range, slots come from LDS cursors.  Order inside a tile segment is arbitrary; the bitmap in k_tile_rank does
+// k_rcount, which reserved a contiguous sub-range per (workgroup, touched tile): slots come from LDS cursors started there.  Order inside a tile segment is arbitrary; the bitmap in k_tile_rank does
 // not care.  The mask says which of the tile's four 8x8 quadrants the splat's {alpha >= 1/255} ellipse can reach: evaluated
 // here from the splat's Span (k_preprocess), so that the per-tile kernel never gathers a per-splat record.
 // ------------------------------------------------------------------------------------------
@@ -346,10 +344,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
     const int end = min(P, begin + chunk);
     if (!direct) {
         const uint32_t* __restrict__ mine = block_hist + (size_t)blockIdx.x * tiles;
-        for (int t = tid; t < tiles; t += NT) {
-            const uint32_t v = mine[t];
-            hist[t] = v ? tile_start[t] + atomicAdd(&tile_cursor[t], v) : 0u;   // first slot of this workgroup in tile t
-        }
+        for (int t = tid; t < tiles; t += NT) hist[t] = tile_start[t] + mine[t];   // first slot of this workgroup in tile t (k_rcount reserved it)
         __syncthreads();
     }
     for (int base = begin; base < end; base += NT / G) {
