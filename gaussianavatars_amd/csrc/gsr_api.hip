@@ -204,7 +204,8 @@ int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, int32_t 
     const bool lists = tile_culling == 0 || tile_culling == 2;     // the reference-format key / point lists are materialised
     const bool dsort = prod || rankp;                              // the splats are depth-sorted
     const size_t Q = 4 * tiles, qw = (Q + 3) / 4;
-    const size_t hist_tiles = rankp ? (size_t)GSR_RANK_HIST_TILES : (size_t)GSR_LDS_HIST_TILES;
+    const int lgx = (width + GSR_BLOCK_X - 1) / GSR_BLOCK_X;
+    const bool no_hist = rankp ? gsr::rank_direct(lgx, (int)tiles) : tiles > (size_t)GSR_LDS_HIST_TILES;   // no per-workgroup histograms: L2 atomics
     size_t off = align_up(sizeof(gsr::BinHeader), A);  // header + statistics slots (gsr_device.h: BinHeader)
     o->keys = off;        off = align_up(off + (old || (rankp && lists) ? cap * 8 : 0), A);
     o->point_list = off;  off = align_up(off + (old || rankp ? cap * 4 : 0), A);
@@ -218,7 +219,7 @@ int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, int32_t 
     o->tile_cursor = off; off = align_up(off + (prod ? 0 : tiles * 4), A);
     o->tile_order = off;  off = align_up(off + tiles * 4, A);
     const size_t blocks = rankp ? (size_t)GSR_RANK_BLOCKS : (size_t)GSR_BIN_BLOCKS;
-    o->block_hist = off;  off = align_up(off + (prod || tiles > hist_tiles ? 0 : blocks * tiles * 4), A);
+    o->block_hist = off;  off = align_up(off + (prod || no_hist ? 0 : blocks * tiles * 4), A);
     o->dkeys = off;       off = align_up(off + (dsort ? n * 8 : 0), A);
     o->dtmp = off;        off = align_up(off + (dsort ? n * 8 : 0), A);
     o->order = off;       off = align_up(off + (prod ? n * 4 : 0), A);
@@ -419,9 +420,9 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
         // ---- rank path: depth-rank the splats once, order every tile's instances through an LDS bitmap (gsr_rank.hip) ----
         const uint32_t nb = (uint32_t)bl.nb;
         const int bin_blocks = pblocks < GSR_RANK_BLOCKS ? pblocks : GSR_RANK_BLOCKS;
-        const bool direct = tiles > GSR_RANK_HIST_TILES;
+        const bool direct = gsr::rank_direct(gx, tiles);
         const size_t hist_bytes = direct ? 0 : (size_t)tiles * sizeof(uint32_t);
-        const size_t count_lds = (size_t)nb * 4 + hist_bytes;
+        const size_t count_lds = (size_t)nb * 4 + (direct ? 0 : (size_t)(gx + 1) * (size_t)(gy + 1) * sizeof(uint32_t));   // corner grid of the tile rects
         if (count_lds > 48 * 1024) {
             HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_rcount, hipFuncAttributeMaxDynamicSharedMemorySize, (int)count_lds));
         }

@@ -26,7 +26,7 @@
                                  // still come out at 10^-8 relative (at 46 bits the 3300 x 3300 test scene was off by 3e-3).
 #define GSR_LDS_HIST_TILES 40960 // 160 KB of LDS / 4 B: the largest tile grid k_count / k_scatter privatise
 #define GSR_RANK_MAX_BUCKETS 4096 // depth buckets of the rank path (16 KB of LDS beside the tile histogram)
-#define GSR_RANK_HIST_TILES (GSR_LDS_HIST_TILES - GSR_RANK_MAX_BUCKETS)   // the largest tile grid k_rcount / k_rscatter privatise
+#define GSR_RANK_HIST_TILES (GSR_LDS_HIST_TILES - GSR_RANK_MAX_BUCKETS)   // the largest grid of tile CORNERS, (gx+1)(gy+1), k_rcount / k_rscatter privatise
 #define GSR_RANK_IDX_BITS 28      // a tile-list entry of the rank path is (rank, splat | quadrant mask << 28)
 #define GSR_RANK_MAX_SPLATS 262144 // splat count up to which the rank path is taken (8192 bitmap words per tile, one pass)
 #ifdef GSR_RANK_TILE_THREADS_EXP
@@ -547,6 +547,8 @@ __device__ __forceinline__ int splat_sum_exponents(uint32_t tiles, float conA, f
 }
 __global__ void k_preprocess_bwd(Settings s, PreBwdArgs a);
 // rank path (gsr_rank.hip)
+// true: the grid of tile corners does not fit the LDS histogram; instances are counted / placed with L2 atomics
+__host__ __device__ inline bool rank_direct(int gx, int tiles) { return (long long)(gx + 1) * (long long)(tiles / gx + 1) > (long long)GSR_RANK_HIST_TILES; }
 __global__ void k_rcount(int P, int gx, int tiles, int pblocks, uint32_t nb, const ushort4* srect, const uint32_t* tiles_touched,
                          const float* depths, const uint2* pstat, uint32_t* tile_count, unsigned long long* rect_total, uint32_t* block_hist,
                          uint32_t* bcount, uint32_t* bhist, BinHeader* hdr);

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int P, int gx, 
     __shared__ unsigned long long rect_sum[NWV];
     __shared__ uint32_t s_mn[NWV], s_mx[NWV];
     const int tid = threadIdx.x;
-    const bool direct = tiles > GSR_RANK_HIST_TILES;
+    const bool direct = rank_direct(gx, tiles);
     uint32_t mn = 0xFFFFFFFFu, mx = 0u;
     for (int j = tid; j < pblocks; j += NT) {
         const uint2 v = pstat[j];
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int P, int gx, 
     if ((tid & 63) == 0) { s_mn[tid >> 6] = mn; s_mx[tid >> 6] = mx; }
     for (uint32_t t = tid; t < nb; t += NT) dh[t] = 0u;
     if (!direct)
-        for (int t = tid; t < tiles; t += NT) hist[t] = 0u;
+        for (int t = tid; t < (gx + 1) * (tiles / gx + 1); t += NT) hist[t] = 0u;
     __syncthreads();
     mn = s_mn[0]; mx = s_mx[0];
 #pragma unroll
@@ -108,23 +108,61 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int P, int gx, 
     const int begin = blockIdx.x * chunk;
     const int end = min(P, begin + chunk);
     unsigned long long touched = 0;
-    for (int base = begin; base < end; base += NT / G) {
-        const int i = base + tid / G;
-        uint32_t n = 0;
-        int minx = 0, miny = 0, maxx = 0, maxy = 0;
-        if (i < end) {
+    const int gy = tiles / gx, sx = gx + 1;   // the LDS grid has one more column and row: rect corners lie on tile CORNERS
+    if (direct) {
+        for (int base = begin; base < end; base += NT / G) {
+            const int i = base + tid / G;
+            uint32_t n = 0;
+            int minx = 0, miny = 0, maxx = 0, maxy = 0;
+            if (i < end) {
+                const ushort4 r = srect[i];
+                minx = r.x; miny = r.y; maxx = r.z; maxy = r.w;
+                n = (uint32_t)((maxx - minx) * (maxy - miny));
+                if ((tid & (G - 1)) == 0) {
+                    touched += tiles_touched[i];
+                    if (n) atomicAdd(&dh[rank_bucket(depths[i], lo, scale, nb)], 1u);
+                }
+            }
+            for_each_tile_grouped(minx, miny, maxx, maxy, n, [=](uint32_t x, uint32_t y, int) { atomicAdd(&tile_count[y * (uint32_t)gx + x], 1u); });
+        }
+    } else {
+        // A rect adds 1 to every tile it covers = +1 / -1 / -1 / +1 at its four corners followed by a 2-D prefix sum over the grid:
+        // four LDS atomics per splat whatever its size (18 tiles on average), one splat per lane
+        for (int i = begin + tid; i < end; i += NT) {
             const ushort4 r = srect[i];
-            minx = r.x; miny = r.y; maxx = r.z; maxy = r.w;
-            n = (uint32_t)((maxx - minx) * (maxy - miny));
-            if ((tid & (G - 1)) == 0) {
-                touched += tiles_touched[i];
-                if (n) atomicAdd(&dh[rank_bucket(depths[i], lo, scale, nb)], 1u);
+            touched += tiles_touched[i];
+            if (r.z != r.x) {
+                atomicAdd(&dh[rank_bucket(depths[i], lo, scale, nb)], 1u);
+                atomicAdd(&hist[r.y * sx + r.x], 1u);
+                atomicSub(&hist[r.y * sx + r.z], 1u);
+                atomicSub(&hist[r.w * sx + r.x], 1u);
+                atomicAdd(&hist[r.w * sx + r.z], 1u);
             }
         }
-        if (direct)
-            for_each_tile_grouped(minx, miny, maxx, maxy, n, [=](uint32_t x, uint32_t y, int) { atomicAdd(&tile_count[y * (uint32_t)gx + x], 1u); });
-        else
-            for_each_tile_grouped(minx, miny, maxx, maxy, n, [=](uint32_t x, uint32_t y, int) { atomicAdd(&hist[y * (uint32_t)gx + x], 1u); });
+        __syncthreads();
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int y = wv; y <= gy; y += NWV) {            // along x: a wave per row, 64 columns at a time
+            uint32_t carry = 0;
+            for (int x0 = 0; x0 < sx; x0 += 64) {
+                const int x = x0 + lane;
+                const uint32_t v = x < sx ? hist[y * sx + x] : 0u;
+                const uint32_t incl = wave_scan_incl_u32(v) + carry;
+                if (x < sx) hist[y * sx + x] = incl;
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+        }
+        __syncthreads();
+        for (int x = wv; x < gx; x += NWV) {             // along y: a wave per column, 64 rows at a time
+            uint32_t carry = 0;
+            for (int y0 = 0; y0 <= gy; y0 += 64) {
+                const int y = y0 + lane;
+                const uint32_t v = y <= gy ? hist[y * sx + x] : 0u;
+                const uint32_t incl = wave_scan_incl_u32(v) + carry;
+                if (y <= gy) hist[y * sx + x] = incl;
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+        }
+        __syncthreads();   // hist[y * sx + x] = this workgroup's instances in tile (x, y)
     }
     // the rect-based instance count (the reference's num_rendered) is kept beside the culled one: sum of tiles_touched
 #pragma unroll
@@ -147,7 +185,8 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int P, int gx, 
     if (direct) return;
     uint32_t* __restrict__ mine = block_hist + (size_t)blockIdx.x * tiles;
     for (int t = tid; t < tiles; t += NT) {
-        const uint32_t v = hist[t];
+        const int y = t / gx;
+        const uint32_t v = hist[t + y];   // y * sx + x
         mine[t] = v ? atomicAdd(&tile_count[t], v) : 0u;
     }
 }
@@ -338,7 +377,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
     constexpr int NT = GSR_RANK_BIN_THREADS, G = GSR_RANK_GROUP;
     if (*total_dev > capacity) return;  // the host will grow the buffer and replay the frame
     const int tid = threadIdx.x;
-    const bool direct = tiles > GSR_RANK_HIST_TILES;
+    const bool direct = rank_direct(gx, tiles);
     const int chunk = ((P + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
     const int begin = blockIdx.x * chunk;
     const int end = min(P, begin + chunk);
