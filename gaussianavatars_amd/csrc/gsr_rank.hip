@@ -381,6 +381,16 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
     const int chunk = ((P + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
     const int begin = blockIdx.x * chunk;
     const int end = min(P, begin + chunk);
+    // a splat's inputs, fetched one round ahead of their use (all four loads are independent: rank / operands of a splat that is
+    // not binned are never looked at)
+    struct In { ushort4 q; uint32_t rk; float4 s0, s1; };
+    auto fetch = [&](int i) {
+        In v;
+        v.q = make_ushort4(0, 0, 0, 0); v.rk = 0u; v.s0 = v.s1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < end) { v.q = srect[i]; v.rk = rank[i]; v.s0 = sspan[2 * (size_t)i]; v.s1 = sspan[2 * (size_t)i + 1]; }
+        return v;
+    };
+    In nxt = fetch(begin + tid / G);
     if (!direct) {
         const uint32_t* __restrict__ mine = block_hist + (size_t)blockIdx.x * tiles;
         for (int t = tid; t < tiles; t += NT) hist[t] = tile_start[t] + mine[t];   // first slot of this workgroup in tile t (k_rcount reserved it)
@@ -388,22 +398,13 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
     }
     for (int base = begin; base < end; base += NT / G) {
         const int i = base + tid / G;
-        uint32_t n = 0, rk = 0;
-        int minx = 0, miny = 0, maxx = 0, maxy = 0;
+        const In cur = nxt;
+        nxt = fetch(i + NT / G);
+        const int minx = cur.q.x, miny = cur.q.y, maxx = cur.q.z, maxy = cur.q.w;
+        const uint32_t n = (uint32_t)((maxx - minx) * (maxy - miny)), rk = cur.rk;
         Span sp;
-        sp.px = sp.py = sp.B = sp.det = sp.twoTA = sp.A = sp.dyr = 0.f;
-        sp.mode = 2;
-        if (i < end) {
-            const ushort4 q = srect[i];
-            minx = q.x; miny = q.y; maxx = q.z; maxy = q.w;
-            n = (uint32_t)((maxx - minx) * (maxy - miny));
-            if (n) {
-                rk = rank[i];
-                const float4 s0 = sspan[2 * (size_t)i], s1 = sspan[2 * (size_t)i + 1];
-                sp.px = s0.x; sp.py = s0.y; sp.B = s0.z; sp.det = s0.w;
-                sp.twoTA = s1.x; sp.A = s1.y; sp.dyr = s1.z; sp.mode = __float_as_int(s1.w);
-            }
-        }
+        sp.px = cur.s0.x; sp.py = cur.s0.y; sp.B = cur.s0.z; sp.det = cur.s0.w;
+        sp.twoTA = cur.s1.x; sp.A = cur.s1.y; sp.dyr = cur.s1.z; sp.mode = __float_as_int(cur.s1.w);
         for_each_tile_grouped(minx, miny, maxx, maxy, n, [&](uint32_t x, uint32_t y, int src) {
             const int me = lane_id();
             Span b = sp;
