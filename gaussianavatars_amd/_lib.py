@@ -18,9 +18,9 @@ def raw_stream(dev):
     import torch
 
     try:
-        return C.c_void_p(torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device()))
+        return torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
     except AttributeError:   # very old / very new torch: the public route
-        return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        return torch.cuda.current_stream(dev).cuda_stream
 
 
 class _NoCtx:
@@ -38,15 +38,21 @@ def on_device(dev):
     """Context that makes `dev` the current device for the native call; free when it already is (the usual case)."""
     import torch
 
-    if dev.index is None or torch.cuda.current_device() == dev.index:
+    global _ONE_DEVICE
+    if _ONE_DEVICE is None:
+        _ONE_DEVICE = torch.cuda.device_count() == 1
+    if _ONE_DEVICE or dev.index is None or torch.cuda.current_device() == dev.index:
         return _NOCTX
     return torch.cuda.device(dev)
+
+
+_ONE_DEVICE = None   # a process that sees one GPU never switches devices
 # GSR_LIB overrides the library file (kernel experiments build variants side by side: tools/exp_build.sh); the product default is
 # the in-tree build.  An override that does not exist is an error, never a fallback.
 GSR_LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr_hip.so")
 
 GSR_OK = 0
-GSR_ABI_VERSION = 5
+GSR_ABI_VERSION = 6
 GSR_E_CAPACITY = 1
 
 
@@ -84,6 +90,12 @@ class GsrBinningLayout(C.Structure):
                  "total")]
 
 
+class GsrBound(C.Structure):
+    """include/gsr.h: GsrBound -- the per-face frames of a mesh-bound model for the rasterizer's bound entry"""
+    _fields_ = [("binding", C.c_void_p), ("binding_is_i64", C.c_int32), ("F", C.c_int32), ("face_R", C.c_void_p), ("face_scale", C.c_void_p),
+                ("face_center", C.c_void_p), ("face_quat", C.c_void_p), ("slot", C.c_void_p), ("rows", C.c_void_p)]
+
+
 class GsrImageLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("final_T", "n_contrib", "n_contrib_q", "c_final", "ck", "gmax", "total")]
 
@@ -107,6 +119,11 @@ GSR_SYMBOLS = {
     "gsr_backward_ex": (C.c_int, [C.POINTER(GsrSettings), C.c_int32, C.c_int32] + [C.c_void_p] * 7 +
                         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p] +
                         [C.c_void_p] * 9 + [C.c_void_p]),
+    "gsr_forward_bound": (C.c_int, [C.POINTER(GsrSettings), C.c_int32, C.c_int32, C.POINTER(GsrBound)] + [C.c_void_p] * 6 +
+                          [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
+    "gsr_backward_bound": (C.c_int, [C.POINTER(GsrSettings), C.c_int32, C.c_int32, C.POINTER(GsrBound)] + [C.c_void_p] * 6 +
+                           [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p] +
+                           [C.c_void_p] * 8 + [C.c_void_p]),
     "gsr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_profile_enable": (C.c_int, [C.c_int]),
     "gsr_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -190,6 +207,7 @@ GAB_SYMBOLS = {
     "gab_bind_forward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gab_bind_backward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gab_bind_backward_csr": (C.c_int, [C.c_int32, C.c_int32] + [_P] * 22),
+    "gab_bind_backward_faces": (C.c_int, [C.c_int32, _P, _P, _P, _P]),
     "gab_zero_buffers": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _P]),
 }
 

@@ -15,7 +15,7 @@ from . import _lib
 
 
 def _p(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()   # a plain int converts to the c_void_p argument without an intermediate object
 
 
 def _stream(dev):
@@ -215,7 +215,7 @@ class _FlameForwardTimestep(torch.autograd.Function):
             raise RuntimeError("flame_forward_timestep: expected (T,n_expr),(T,3),(T,3),(T,3),(T,6),(T,3) tables and 0 <= t < T")
         sh = _f32(shape).reshape(-1)
         so = None if static_offset is None else _f32(static_offset).reshape(-1)
-        rows = [C.c_void_p(x.data_ptr() + 4 * t * w) for x, w in zip(tabs, widths)]
+        rows = [x.data_ptr() + 4 * t * w for x, w in zip(tabs, widths)]
         verts = torch.empty((1, V, 3), dtype=torch.float32, device=dev)
         v_shaped = torch.empty((1, V, 3), dtype=torch.float32, device=dev)
         ws = torch.empty(_lib.GAB_FLAME_WS_FLOATS, dtype=torch.float32, device=dev)
@@ -252,13 +252,13 @@ class _FlameForwardTimestep(torch.autograd.Function):
         tables = [torch.empty((T, w), **f32) for w in widths]
         ptrs = (C.c_void_p * len(tables))(*[x.data_ptr() for x in tables])
         sizes = (C.c_int32 * len(tables))(*[T * w for w in widths])
-        outp = [C.c_void_p(x.data_ptr() + 4 * t * w) for x, w in zip(tables, widths)]
+        outp = [x.data_ptr() + 4 * t * w for x, w in zip(tables, widths)]
         d_shape = torch.empty(rig.n_shape, **f32) if need[2] else None
         d_so = torch.empty(3 * V, **f32) if (ctx.has_so and need[9]) else None
         scratch = torch.empty(3 * V, **f32)
         gv = torch.zeros((V, 3), **f32) if g_verts is None else _f32(g_verts)
         gvs = None if g_vshaped is None else _f32(g_vshaped)
-        rows = [C.c_void_p(x.data_ptr() + 4 * t * w) for x, w in zip(tabs, widths)]
+        rows = [x.data_ptr() + 4 * t * w for x, w in zip(tabs, widths)]
         with _lib.on_device(dev):
             # the (T,k) tables are zero-filled by the backward's first kernel (no launch of their own)
             if ctx.prepared is not None and gvs is None and d_shape is None and d_so is None:

@@ -16,6 +16,7 @@
 #include <cstdio>
 
 #include "../../include/gab.h"
+#include "bind_math.h"
 
 namespace gab {
 
@@ -950,15 +951,9 @@ __global__ __launch_bounds__(256) void k_face_frames_bwd(int F, const float* __r
 // ---------------------------------------------------------------------------------------------
 // per-splat mesh-local -> world (get_xyz, get_scaling, get_rotation in one pass)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 qmul(float4 a, float4 b)   // Hamilton product, WXYZ in .x.y.z.w
-{
-    return make_float4(a.x * b.x - a.y * b.y - a.z * b.z - a.w * b.w,
-                       a.x * b.y + b.x * a.y + (a.z * b.w - a.w * b.z),
-                       a.x * b.z + b.x * a.z + (a.w * b.y - a.y * b.w),
-                       a.x * b.w + b.x * a.w + (a.y * b.z - a.z * b.y));
-}
-__device__ __forceinline__ float4 qconj(float4 a) { return make_float4(a.x, -a.y, -a.z, -a.w); }
-__device__ __forceinline__ float qnorm_clamped(float4 q) { const float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w); return n > 1e-12f ? n : 1e-12f; }
+using bindm::qmul;            // the transform itself lives in bind_math.h, shared with the rasterizer's bound entry
+using bindm::qconj;
+using bindm::qnorm_clamped;
 
 __global__ __launch_bounds__(256) void k_bind(int N, const float* __restrict__ xyz, const float* __restrict__ log_scaling,
                                                const float* __restrict__ rotation, const void* __restrict__ binding, int is64,
@@ -969,19 +964,14 @@ __global__ __launch_bounds__(256) void k_bind(int N, const float* __restrict__ x
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    if (opacity_logit) out_opacity[i] = 1.f / (1.f + expf(-opacity_logit[i]));   // get_opacity (scene/gaussian_model.py:158-160) on the side
+    if (opacity_logit) out_opacity[i] = bindm::sigmoid(opacity_logit[i]);   // get_opacity (scene/gaussian_model.py:158-160) on the side
     const long long f = index_at(binding, is64, i);
     const float s = fs[f];
-    const float* R = fR + 9 * f;
-    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    for (int r = 0; r < 3; ++r) out_xyz[3 * i + r] = (R[3 * r] * x + R[3 * r + 1] * y + R[3 * r + 2] * z) * s + fc[3 * f + r];
-    for (int k = 0; k < 3; ++k) out_scaling[3 * i + k] = expf(log_scaling[3 * i + k]) * s;
-    const float4 qf = reinterpret_cast<const float4*>(fq)[f];
-    const float4 q = reinterpret_cast<const float4*>(rotation)[i];
-    const float na = 1.f / qnorm_clamped(qf), nb = 1.f / qnorm_clamped(q);
-    const float4 a = make_float4(qf.x * na, qf.y * na, qf.z * na, qf.w * na);
-    const float4 b = make_float4(q.x * nb, q.y * nb, q.z * nb, q.w * nb);
-    reinterpret_cast<float4*>(out_rotation)[i] = qmul(a, b);
+    float w[3];
+    bindm::world_xyz(fR + 9 * f, s, fc + 3 * f, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], w);
+    for (int r = 0; r < 3; ++r) out_xyz[3 * i + r] = w[r];
+    for (int k = 0; k < 3; ++k) out_scaling[3 * i + k] = bindm::world_scaling(log_scaling[3 * i + k], s);
+    reinterpret_cast<float4*>(out_rotation)[i] = bindm::world_rotation(reinterpret_cast<const float4*>(fq)[f], reinterpret_cast<const float4*>(rotation)[i]);
 }
 
 __global__ __launch_bounds__(256) void k_bind_bwd(int N, const float* __restrict__ xyz, const float* __restrict__ log_scaling,
@@ -1549,6 +1539,15 @@ int gab_bind_backward_csr(int32_t N, int32_t F, const float* xyz, const float* l
                        rotation, face_orien_mat, face_scaling, face_orien_quat, d_out_xyz, d_out_scaling, d_out_rotation, order, face_begin,
                        d_xyz, d_log_scaling, d_rotation, d_face, out_opacity, d_out_opacity, d_opacity_logit);
     LAUNCH_CHECK("k_bind_bwd_csr");
+    return GAB_OK;
+}
+
+int gab_bind_backward_faces(int32_t F, const int32_t* face_begin, const float* rows, float* d_face, void* stream_)
+{
+    if (F <= 0 || !face_begin || !rows || !d_face) return fail(GAB_E_ARG, "gab_bind_backward_faces: bad arguments");
+    const long long threads = 16ll * F;
+    hipLaunchKernelGGL(gab::k_bind_bwd_faces, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, F, face_begin, rows, d_face);
+    LAUNCH_CHECK("k_bind_bwd_faces");
     return GAB_OK;
 }
 

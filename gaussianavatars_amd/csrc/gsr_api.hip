@@ -259,10 +259,23 @@ int gsr_image_layout(int32_t width, int32_t height, GsrImageLayout* o)
     return 0;
 }
 
-int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs, const float* shs_rest,
-                   const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
-                const float* cov3D_precomp, float* out_color, int32_t* radii, void* geom, void* binning,
-                int64_t binning_capacity, void* img, int64_t* num_rendered_host, void* stream_)
+static int to_bound(const GsrBound* b, int32_t P, bool backward, gsr::BoundDev* o)
+{
+    o->binding = nullptr; o->is64 = 0; o->fR = o->fs = o->fc = o->fq = nullptr; o->slot = nullptr; o->rows = nullptr;
+    if (!b) return 0;
+    if (b->F <= 0 || (P > 0 && (!b->binding || !b->face_R || !b->face_scale || !b->face_center || !b->face_quat)))
+        return fail(GSR_E_ARG, "GsrBound: NULL face buffer / binding or F <= 0");
+    if (backward && P > 0 && (!b->slot || !b->rows)) return fail(GSR_E_ARG, "GsrBound: the backward needs slot and rows");
+    o->binding = b->binding; o->is64 = b->binding_is_i64;
+    o->fR = b->face_R; o->fs = b->face_scale; o->fc = b->face_center; o->fq = b->face_quat;
+    o->slot = b->slot; o->rows = b->rows;
+    return 0;
+}
+
+static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs, const float* shs_rest,
+                        const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
+                        const float* cov3D_precomp, float* out_color, int32_t* radii, void* geom, void* binning,
+                        int64_t binning_capacity, void* img, int64_t* num_rendered_host, void* stream_, const GsrBound* bound)
 {
     if (int rc = check_settings(settings)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
@@ -340,6 +353,7 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     pa.srect = (ushort4*)(b + bl.srect);
     pa.sspan = (float4*)(b + bl.sspan);
     pa.cull = settings->tile_culling != 0;
+    if (int rc = to_bound(bound, P, false, &pa.bound)) return rc;
     const int pblocks = (P + 255) / 256;
     if (pblocks > 0) {
         TIMED(GSR_K_PREPROCESS, stream);
@@ -574,6 +588,25 @@ int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const floa
     return GSR_OK;
 }
 
+int gsr_forward_ex(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs, const float* shs_rest,
+                   const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
+                   const float* cov3D_precomp, float* out_color, int32_t* radii, void* geom, void* binning,
+                   int64_t binning_capacity, void* img, int64_t* num_rendered_host, void* stream)
+{
+    return forward_impl(settings, P, M, means3D, shs, shs_rest, colors_precomp, opacities, scales, rotations, cov3D_precomp, out_color, radii,
+                        geom, binning, binning_capacity, img, num_rendered_host, stream, nullptr);
+}
+
+int gsr_forward_bound(const GsrSettings* settings, int32_t P, int32_t M, const GsrBound* bound, const float* xyz_local, const float* shs,
+                      const float* shs_rest, const float* opacity_logit, const float* log_scales, const float* rot_local,
+                      float* out_color, int32_t* radii, void* geom, void* binning, int64_t binning_capacity, void* img,
+                      int64_t* num_rendered_host, void* stream)
+{
+    if (!bound) return fail(GSR_E_ARG, "gsr_forward_bound: bound is NULL");
+    return forward_impl(settings, P, M, xyz_local, shs, shs_rest, nullptr, opacity_logit, log_scales, rot_local, nullptr, out_color, radii,
+                        geom, binning, binning_capacity, img, num_rendered_host, stream, bound);
+}
+
 int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs,
                 const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
                 const float* cov3D_precomp, float* out_color, int32_t* radii, void* geom, void* binning,
@@ -583,12 +616,12 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t M, const float* 
                           radii, geom, binning, binning_capacity, img, num_rendered_host, stream);
 }
 
-int gsr_backward_ex(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs, const float* shs_rest,
-                    const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
-                 const int32_t* radii, void* geom, const void* binning, int64_t binning_capacity, const void* img,
-                 int64_t num_rendered, const float* dL_dpix, float* dL_dmeans3D, float* dL_dmeans2D,
-                 float* dL_dsh, float* dL_dsh_rest, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
-                 float* dL_dcov3D, void* stream_)
+static int backward_impl(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs, const float* shs_rest,
+                         const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
+                         const int32_t* radii, void* geom, const void* binning, int64_t binning_capacity, const void* img,
+                         int64_t num_rendered, const float* dL_dpix, float* dL_dmeans3D, float* dL_dmeans2D,
+                         float* dL_dsh, float* dL_dsh_rest, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                         float* dL_dcov3D, void* stream_, const GsrBound* bound, const float* opacity_logit)
 {
     if (int rc = check_settings(settings)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
@@ -650,12 +683,41 @@ int gsr_backward_ex(const GsrSettings* settings, int32_t P, int32_t M, const flo
     pa.dL_dcolors = dL_dcolors; pa.dL_dopacity = dL_dopacity;
     pa.dL_dscales = pre_cov ? nullptr : dL_dscales; pa.dL_drotations = pre_cov ? nullptr : dL_drotations;
     pa.dL_dcov3D = dL_dcov3D;
+    if (int rc = to_bound(bound, P, true, &pa.bound)) return rc;
+    pa.opacities = opacity_logit;
+    if (bound && !opacity_logit) return fail(GSR_E_ARG, "gsr_backward_bound: opacity_logit is NULL");
     {
         TIMED(GSR_K_PREPROCESS_BWD, stream);
         hipLaunchKernelGGL(gsr::k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, stream, ds, pa);
         KERNEL_CHECK("k_preprocess_bwd", stream, dbg);
     }
     return GSR_OK;
+}
+
+int gsr_backward_ex(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs, const float* shs_rest,
+                    const float* colors_precomp, const float* scales, const float* rotations, const float* cov3D_precomp,
+                    const int32_t* radii, void* geom, const void* binning, int64_t binning_capacity, const void* img,
+                    int64_t num_rendered, const float* dL_dpix, float* dL_dmeans3D, float* dL_dmeans2D,
+                    float* dL_dsh, float* dL_dsh_rest, float* dL_dcolors, float* dL_dopacity, float* dL_dscales, float* dL_drotations,
+                    float* dL_dcov3D, void* stream)
+{
+    return backward_impl(settings, P, M, means3D, shs, shs_rest, colors_precomp, scales, rotations, cov3D_precomp, radii, geom, binning,
+                         binning_capacity, img, num_rendered, dL_dpix, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dsh_rest, dL_dcolors, dL_dopacity,
+                         dL_dscales, dL_drotations, dL_dcov3D, stream, nullptr, nullptr);
+}
+
+int gsr_backward_bound(const GsrSettings* settings, int32_t P, int32_t M, const GsrBound* bound, const float* xyz_local, const float* shs,
+                       const float* shs_rest, const float* opacity_logit, const float* log_scales, const float* rot_local,
+                       const int32_t* radii, void* geom, const void* binning, int64_t binning_capacity, const void* img,
+                       int64_t num_rendered, const float* dL_dpix, float* dL_dxyz_local, float* dL_dmeans2D, float* dL_dsh,
+                       float* dL_dsh_rest, float* dL_dopacity_logit, float* dL_dlog_scales, float* dL_drot_local, float* scratch9,
+                       void* stream)
+{
+    if (!bound) return fail(GSR_E_ARG, "gsr_backward_bound: bound is NULL");
+    if (P > 0 && !scratch9) return fail(GSR_E_ARG, "gsr_backward_bound: scratch9 (9 P floats) is NULL");
+    return backward_impl(settings, P, M, xyz_local, shs, shs_rest, nullptr, log_scales, rot_local, nullptr, radii, geom, binning,
+                         binning_capacity, img, num_rendered, dL_dpix, dL_dxyz_local, dL_dmeans2D, dL_dsh, dL_dsh_rest, scratch9 /*dL_dcolors*/,
+                         dL_dopacity_logit, dL_dlog_scales, dL_drot_local, scratch9 + 3 * (size_t)P /*dL_dcov3D*/, stream, bound, opacity_logit);
 }
 
 int gsr_backward(const GsrSettings* settings, int32_t P, int32_t M, const float* means3D, const float* shs,

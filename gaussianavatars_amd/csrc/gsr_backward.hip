@@ -379,7 +379,13 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
         const float* proj = s.projmatrix;
         const int W = s.W, H = s.H;
         const float fx = (float)W / (2.0f * s.tanfovx), fy = (float)H / (2.0f * s.tanfovy);
-        const float mx = a.means3D[3 * i], my = a.means3D[3 * i + 1], mz = a.means3D[3 * i + 2];
+        float mx = a.means3D[3 * i], my = a.means3D[3 * i + 1], mz = a.means3D[3 * i + 2];
+        if (a.bound.binding) {   // bound entry: recompute the world-space position from the local leaf (bind_math.h)
+            const long long bface = bound_face(a.bound, i);
+            float w[3];
+            bindm::world_xyz(a.bound.fR + 9 * bface, a.bound.fs[bface], a.bound.fc + 3 * bface, mx, my, mz, w);
+            mx = w[0]; my = w[1]; mz = w[2];
+        }
         const float* c6 = a.cov3D + 6 * i;
 
         // ---- conic -> cov2D -> (Sigma, mean) -------------------------------------------------
@@ -524,7 +530,15 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
 
         // ---- Sigma -> scale, raw quaternion --------------------------------------------------
         if (!a.use_precomp_cov) {
-            const float4 q = reinterpret_cast<const float4*>(a.rotations)[i];
+            float4 q = reinterpret_cast<const float4*>(a.rotations)[i];
+            float ws[3] = {a.scales[3 * i], a.scales[3 * i + 1], a.scales[3 * i + 2]};
+            if (a.bound.binding) {
+                const long long bface = bound_face(a.bound, i);
+                q = bindm::world_rotation(reinterpret_cast<const float4*>(a.bound.fq)[bface], q);
+                const float bscale = a.bound.fs[bface];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ws[k] = bindm::world_scaling(ws[k], bscale);
+            }
             const float r = q.x, x = q.y, y = q.z, z = q.w;
             float R[3][3];
             R[0][0] = 1.f - 2.f * (y * y + z * z);
@@ -537,7 +551,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
             R[2][1] = 2.f * (y * z + r * x);
             R[2][2] = 1.f - 2.f * (x * x + y * y);
             const float mod = s.scale_modifier;
-            const float sc[3] = {mod * a.scales[3 * i], mod * a.scales[3 * i + 1], mod * a.scales[3 * i + 2]};
+            const float sc[3] = {mod * ws[0], mod * ws[1], mod * ws[2]};
             const float gS[3][3] = {{gcov[0], 0.5f * gcov[1], 0.5f * gcov[2]},
                                     {0.5f * gcov[1], gcov[3], 0.5f * gcov[4]},
                                     {0.5f * gcov[2], 0.5f * gcov[4], gcov[5]}};
@@ -562,6 +576,29 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
         for (int k = 0; k < 3 * M; ++k) gsh[k] = 0.f;
     }
 
+    if (a.bound.binding) {
+        // bound entry: (dL/d world xyz, scaling, rotation, opacity) -> the gradients of the splat's own leaves, and its 17
+        // contributions to its face's gradients parked at its CSR position for the per-face reduction (gab_bind_backward_faces)
+        const long long bface = bound_face(a.bound, i);
+        float Rf[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rf[k] = a.bound.fR[9 * bface + k];
+        const float xl[3] = {a.means3D[3 * i], a.means3D[3 * i + 1], a.means3D[3 * i + 2]};
+        const float ls[3] = {a.scales ? a.scales[3 * i] : 0.f, a.scales ? a.scales[3 * i + 1] : 0.f, a.scales ? a.scales[3 * i + 2] : 0.f};
+        const float4 ql = a.rotations ? reinterpret_cast<const float4*>(a.rotations)[i] : make_float4(1.f, 0.f, 0.f, 0.f);
+        float dx[3], dls[3], acc[BINDM_ROW];
+        float4 dq;
+        bindm::bind_backward(Rf, a.bound.fs[bface], reinterpret_cast<const float4*>(a.bound.fq)[bface], xl, ls, ql, dmean, dscale,
+                             make_float4(drot[0], drot[1], drot[2], drot[3]), dx, dls, &dq, acc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { dmean[k] = dx[k]; dscale[k] = dls[k]; }
+        drot[0] = dq.x; drot[1] = dq.y; drot[2] = dq.z; drot[3] = dq.w;
+        const float o = bindm::sigmoid(a.opacities[i]);
+        gop = gop * o * (1.f - o);
+        float4* row = reinterpret_cast<float4*>(a.bound.rows + (size_t)BINDM_ROW * a.bound.slot[i]);
+#pragma unroll
+        for (int k = 0; k < BINDM_ROW / 4; ++k) row[k] = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) a.dL_dmeans3D[3 * i + k] = dmean[k];
     a.dL_dmeans2D[3 * i + 0] = g2x;

@@ -38,6 +38,8 @@
 #define GSR_RANK_GROUP 16         // lanes that expand one splat's tile rect together in k_rcount / k_rscatter (4 splats per wave at a time)
 #define GSR_RANK_BIN_THREADS 1024 // threads per workgroup of k_rcount / k_rdscatter / k_rscatter (<= GSR_BIN_BLOCKS workgroups: 16 waves each keep the SIMDs busy)
 
+#include "bind_math.h"
+
 namespace gsr {
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));   // eight consecutive scalar registers (one s_load_dwordx8)
@@ -443,6 +445,24 @@ struct QBinArgs {               // k_qcount / k_qscatter
     unsigned long long capacity;
 };
 
+// Bound entry (gsr_forward_bound / gsr_backward_bound, N1 of SURVEY.md 8(f)): the per-splat inputs are the model's mesh-LOCAL
+// leaves and every splat is carried into world space right where it is read (bind_math.h) -- no world-space tensors, no bind launch.
+// binding == nullptr: plain world-space inputs.
+struct BoundDev {
+    const void* __restrict__ binding;     // (P) face of every splat, int32 or int64
+    int is64;
+    const float* __restrict__ fR;         // (F,3,3) face_orien_mat
+    const float* __restrict__ fs;         // (F)     face_scaling
+    const float* __restrict__ fc;         // (F,3)   face_center
+    const float* __restrict__ fq;         // (F,4)   face_orien_quat (WXYZ)
+    const int* __restrict__ slot;         // backward: (P) the splat's position in the per-face CSR of the binding
+    float* __restrict__ rows;             // backward: (P, BINDM_ROW) its contributions to its face's gradients, parked at that position
+};
+__device__ __forceinline__ long long bound_face(const BoundDev& b, int i)
+{
+    return b.is64 ? reinterpret_cast<const long long*>(b.binding)[i] : (long long)reinterpret_cast<const int*>(b.binding)[i];
+}
+
 struct PreprocessArgs {
     int P, M;
     const float* __restrict__ means3D;
@@ -477,6 +497,7 @@ struct PreprocessArgs {
     ushort4* __restrict__ srect;          // [P] tile rect the splat is binned into (snug when cull != 0); zero area = not binned
     float4* __restrict__ sspan;           // [P][2] the splat's Span (px, py, B, det | twoTA, A, dyr, mode): operands of the quadrant test
     int cull;                             // settings.tile_culling != 0
+    BoundDev bound;                       // means3D / scales / rotations / opacities are _xyz / _scaling / _rotation / _opacity when bound.binding
 };
 
 struct PreBwdArgs {
@@ -503,6 +524,8 @@ struct PreBwdArgs {
     float* __restrict__ dL_dscales;       // (P,3) or null
     float* __restrict__ dL_drotations;    // (P,4) or null
     float* __restrict__ dL_dcov3D;        // (P,6)
+    BoundDev bound;                       // bound entry: the four inputs above are the local leaves, the gradients those of the leaves
+    const float* __restrict__ opacities;  // bound entry: the opacity logits (sigmoid' for dL_dopacity)
 };
 
 __global__ void k_preprocess(Settings s, PreprocessArgs a);

@@ -56,7 +56,16 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
     if (i < a.P) {
         const float* vm = s.viewmatrix;
         const float* pm = s.projmatrix;
-        const float mx = a.means3D[3 * i + 0], my = a.means3D[3 * i + 1], mz = a.means3D[3 * i + 2];
+        float mx = a.means3D[3 * i + 0], my = a.means3D[3 * i + 1], mz = a.means3D[3 * i + 2];
+        long long bface = 0;
+        float bscale = 1.f;
+        if (a.bound.binding) {   // bound entry: the mesh-local position goes to world space here
+            bface = bound_face(a.bound, i);
+            bscale = a.bound.fs[bface];
+            float w[3];
+            bindm::world_xyz(a.bound.fR + 9 * bface, bscale, a.bound.fc + 3 * bface, mx, my, mz, w);
+            mx = w[0]; my = w[1]; mz = w[2];
+        }
         // view space (3 rows of W2C) and clip space (4 rows of P*W2C); storage is transposed
         const float vx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
         const float vy = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
@@ -72,7 +81,13 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
             if (a.cov3D_precomp) {
                 for (int k = 0; k < 6; ++k) c6[k] = a.cov3D_precomp[6 * i + k];
             } else {
-                const float4 q = reinterpret_cast<const float4*>(a.rotations)[i];
+                float4 q = reinterpret_cast<const float4*>(a.rotations)[i];
+                float ws[3] = {a.scales[3 * i + 0], a.scales[3 * i + 1], a.scales[3 * i + 2]};
+                if (a.bound.binding) {
+                    q = bindm::world_rotation(reinterpret_cast<const float4*>(a.bound.fq)[bface], q);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) ws[k] = bindm::world_scaling(ws[k], bscale);
+                }
                 const float r = q.x, x = q.y, y = q.z, z = q.w;
                 float R[3][3];
                 R[0][0] = 1.f - 2.f * (y * y + z * z);
@@ -84,8 +99,7 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
                 R[2][0] = 2.f * (x * z - r * y);
                 R[2][1] = 2.f * (y * z + r * x);
                 R[2][2] = 1.f - 2.f * (x * x + y * y);
-                const float sc[3] = {s.scale_modifier * a.scales[3 * i + 0], s.scale_modifier * a.scales[3 * i + 1],
-                                     s.scale_modifier * a.scales[3 * i + 2]};
+                const float sc[3] = {s.scale_modifier * ws[0], s.scale_modifier * ws[1], s.scale_modifier * ws[2]};
                 float Mm[3][3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
@@ -152,7 +166,7 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
                     con0 = cyy * det_inv;
                     con1 = -cxy * det_inv;
                     con2 = cxx * det_inv;
-                    opac = a.opacities[i];
+                    opac = a.bound.binding ? bindm::sigmoid(a.opacities[i]) : a.opacities[i];
                     rminx = x0; rminy = y0; rmaxx = x1; rmaxy = y1;
 
                     // ---- colour

@@ -59,7 +59,44 @@ def _dev(t, device):
     return t if isinstance(t, torch.Tensor) and t.device == device else torch.as_tensor(t, device=device)
 
 
+def _bound_fast_path(pc, pipe, override_color) -> bool:
+    """A patched mesh-bound model rendered the default way: the rasterizer's bound entry takes the model's leaves and per-face frames
+    and evaluates get_xyz / get_scaling / get_rotation / get_opacity inside its first kernel -- one autograd
+    node instead of two, no world-space tensors.  Anything else (python SH / covariance paths, colour overrides, unbound or
+    "unfused" models, `pc.bound_render = False`) takes the reference-shaped path below."""
+    if override_color is not None or pipe.compute_cov3D_python or pipe.convert_SHs_python:
+        return False
+    if getattr(pc, "binding", None) is None or getattr(pc, "binding_impl", "fused") == "unfused" or not getattr(pc, "bound_render", True):
+        return False
+    if not getattr(type(pc), "_gaa_patched", False) or getattr(pc, "get_features_split", None) is None:
+        return False
+    return pc._xyz.is_cuda
+
+
+def _render_bound(viewpoint_camera, pc, pipe, bg_color, scaling_modifier):
+    from .patch import binding_csr_cached
+    from .rasterizer import rasterize_bound
+
+    if pc.face_center is None:          # same lazy initialisation as the reference's accessors (scene/gaussian_model.py:119-120)
+        pc.select_mesh_by_timestep(0)
+    device = pc._xyz.device
+    screenspace_points = _screenspace_leaf(pc._xyz)
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=_dev(viewpoint_camera.world_view_transform, device),
+        projmatrix=_dev(viewpoint_camera.full_proj_transform, device), sh_degree=pc.active_sh_degree,
+        campos=_dev(viewpoint_camera.camera_center, device), prefiltered=False, debug=pipe.debug)
+    dc, rest = pc.get_features_split
+    csr = binding_csr_cached(pc, pc.face_center.shape[0])
+    image, radii, visible = rasterize_bound(pc._xyz, screenspace_points, dc, rest, pc._opacity, pc._scaling, pc._rotation, pc.face_orien_mat,
+                                            pc.face_scaling, pc.face_center, pc.face_orien_quat, pc.binding, csr, raster_settings)
+    return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": visible, "radii": radii}
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
+    if _bound_fast_path(pc, pipe, override_color):
+        return _render_bound(viewpoint_camera, pc, pipe, bg_color, scaling_modifier)
     xyz = pc.get_xyz
     device = xyz.device
     screenspace_points = _screenspace_leaf(xyz)

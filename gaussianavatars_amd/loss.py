@@ -15,7 +15,7 @@ from . import _lib
 
 
 def _p(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()
 
 
 def _stream(dev):

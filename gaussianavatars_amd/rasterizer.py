@@ -21,7 +21,7 @@ from torch import nn
 
 from . import _lib
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_forward_info", "set_tile_culling",
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_bound", "last_forward_info", "set_tile_culling",
            "get_tile_culling", "set_exact_scale_grad", "set_deterministic"]
 
 
@@ -110,7 +110,7 @@ def _round_cap(n: int) -> int:
 
 
 def _ptr(t: Optional[torch.Tensor]):
-    return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
+    return None if t is None or t.numel() == 0 else t.data_ptr()   # a plain int converts to the c_void_p argument
 
 
 def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -235,7 +235,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # next frame: 25 % headroom over what this one needed, never shrinking below it
         _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
         _last_info.update(num_rendered=I, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod,
-                          binning_path=int(bl.path))   # 0 rank path, 1 depth-ordered scatter, 2 per-tile sort (include/gsr.h)
+                          binning_path=int(bl.path), bound=False)   # 0 rank path, 1 depth-ordered scatter, 2 per-tile sort (include/gsr.h)
         _last_binning[0] = binning
 
         ctx.raster_settings = raster_settings
@@ -288,6 +288,122 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise RuntimeError(f"gsr_backward failed ({rc}): {_lib.gsr_error()}")
         return (g_means3D, g_means2D, g_sh, g_colors if not use_sh else None, g_opacity, g_scales, g_rot,
                 g_cov3D if not use_sr else None, None, g_sh_rest)
+
+
+class _RasterizeBound(torch.autograd.Function):
+    """The rasterizer on a mesh-BOUND model's own leaves (include/gsr.h: gsr_forward_bound / gsr_backward_bound): get_xyz / get_scaling /
+    get_rotation / get_opacity (scene/gaussian_model.py:113-160) are evaluated inside the first kernel, the world-space tensors never
+    exist, and one autograd node replaces the accessor node + the rasterizer node.  Inputs: the leaves (_xyz, _scaling, _rotation,
+    _opacity, _features_dc, _features_rest), the screen-space dummy, the four per-face frame tensors, binding and its CSR."""
+
+    @staticmethod
+    def forward(ctx, xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, face_R, face_scale, face_center, face_quat,
+                binding, csr, raster_settings):
+        ctx.set_materialize_grads(False)
+        lib = _lib.gsr()
+        dev = xyz.device
+        keep: list = []
+        s = _make_settings(raster_settings, keep)
+        need = ctx.needs_input_grad
+        s.forward_only = int(not any(need[:11]))
+        xyz, sh_dc, sh_rest = _f32c(xyz, "_xyz"), _f32c(sh_dc, "_features_dc"), _f32c(sh_rest, "_features_rest")
+        opacity_logit, log_scaling, rotation = _f32c(opacity_logit, "_opacity"), _f32c(log_scaling, "_scaling"), _f32c(rotation, "_rotation")
+        fR, fs, fc, fq = (_f32c(t, n) for t, n in ((face_R, "face_orien_mat"), (face_scale, "face_scaling"), (face_center, "face_center"),
+                                                    (face_quat, "face_orien_quat")))
+        P, F = xyz.shape[0], fc.shape[0]
+        if binding.dtype not in (torch.int32, torch.int64) or not binding.is_contiguous() or binding.numel() != P:
+            raise RuntimeError("binding must be a contiguous int32 / int64 tensor with one face per splat")
+        if csr is None or csr[1].numel() != F + 1 or csr[3].numel() != P:
+            raise RuntimeError("the bound rasterizer needs the binding's per-face CSR (binding.binding_csr) for this binding and mesh")
+        H, W = s.image_height, s.image_width
+        M = 1 + int(sh_rest.shape[1])
+        b = _lib.GsrBound()
+        b.binding, b.binding_is_i64, b.F = binding.data_ptr(), int(binding.dtype == torch.int64), F
+        b.face_R, b.face_scale, b.face_center, b.face_quat = fR.data_ptr(), fs.data_ptr(), fc.data_ptr(), fq.data_ptr()
+        gl, il = _layouts(lib, P, W, H)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        geom = torch.empty(gl.total, **u8)
+        img = torch.empty(il.total, **u8)
+        prod = _binning_layout(lib, 0, W, H, P, int(s.tile_culling)).path == 1
+        key = (dev.index, H, W, prod)
+        cap = _capacity_hint.get(key) or _round_cap((24 if prod else 8) * P)
+        stream = _lib.raw_stream(dev)
+        n_host = C.c_int64(0)
+        replays = 0
+        with _lib.on_device(dev):
+            while True:
+                bl = _binning_layout(lib, cap, W, H, P, int(s.tile_culling))
+                binning = torch.empty(bl.total, **u8)
+                rc = lib.gsr_forward_bound(C.byref(s), P, M, C.byref(b), _ptr(xyz), _ptr(sh_dc), _ptr(sh_rest), _ptr(opacity_logit),
+                                           _ptr(log_scaling), _ptr(rotation), _ptr(color), _ptr(radii), _ptr(geom), _ptr(binning), cap,
+                                           _ptr(img), C.byref(n_host), stream)
+                if rc == _lib.GSR_E_CAPACITY:
+                    cap = _round_cap(int(n_host.value * 1.25) + 1)
+                    replays += 1
+                    continue
+                if rc != _lib.GSR_OK:
+                    raise RuntimeError(f"gsr_forward_bound failed ({rc}): {_lib.gsr_error()}")
+                break
+        I = int(n_host.value)
+        _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
+        _last_info.update(num_rendered=I, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod,
+                          binning_path=int(bl.path), bound=True)
+        _last_binning[0] = binning
+        ctx.raster_settings = raster_settings
+        ctx.tile_culling, ctx.deterministic = int(s.tile_culling), int(s.deterministic)
+        ctx.num_rendered, ctx.capacity, ctx.M, ctx.F = I, cap, M, F
+        ctx.is64 = b.binding_is_i64
+        ctx.csr = csr
+        ctx.save_for_backward(xyz, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, fR, fs, fc, fq, binding, radii, geom, binning, img)
+        visible = geom[gl.visible: gl.visible + P].view(torch.bool)
+        ctx.mark_non_differentiable(radii, visible)
+        return color, radii, visible
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii, _grad_visible=None):
+        if grad_out_color is None:
+            return (None,) * 14
+        lib, gab = _lib.gsr(), _lib.gab()
+        xyz, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, fR, fs, fc, fq, binding, radii, geom, binning, img = ctx.saved_tensors
+        dev = xyz.device
+        keep: list = []
+        s = _make_settings(ctx.raster_settings, keep)
+        s.tile_culling, s.deterministic, s.forward_only = ctx.tile_culling, ctx.deterministic, 0
+        P, M, F = xyz.shape[0], ctx.M, ctx.F
+        f32 = dict(dtype=torch.float32, device=dev)
+        grad_out_color = _f32c(grad_out_color, "grad_out_color")
+        g_xyz, g_means2D = torch.empty((P, 3), **f32), torch.empty((P, 3), **f32)
+        g_dc, g_rest = torch.empty((P, 1, 3), **f32), torch.empty((P, M - 1, 3), **f32)
+        g_op, g_ls, g_rot = torch.empty((P, 1), **f32), torch.empty((P, 3), **f32), torch.empty((P, 4), **f32)
+        scratch = torch.empty(9 * P + _lib.GAB_BIND_ROW_FLOATS * P, **f32)   # colour / covariance gradients, then the CSR rows
+        d_face = torch.empty(17 * F, **f32)                                  # four contiguous blocks: center | orien_mat | scaling | orien_quat
+        order, face_begin, _splat_face, slot = ctx.csr[:4]
+        b = _lib.GsrBound()
+        b.binding, b.binding_is_i64, b.F = binding.data_ptr(), ctx.is64, F
+        b.face_R, b.face_scale, b.face_center, b.face_quat = fR.data_ptr(), fs.data_ptr(), fc.data_ptr(), fq.data_ptr()
+        b.slot, b.rows = slot.data_ptr(), scratch.data_ptr() + 4 * 9 * P
+        stream = _lib.raw_stream(dev)
+        with _lib.on_device(dev):
+            rc = lib.gsr_backward_bound(C.byref(s), P, M, C.byref(b), _ptr(xyz), _ptr(sh_dc), _ptr(sh_rest), _ptr(opacity_logit), _ptr(log_scaling),
+                                        _ptr(rotation), _ptr(radii), _ptr(geom), _ptr(binning), ctx.capacity, _ptr(img), ctx.num_rendered,
+                                        _ptr(grad_out_color), _ptr(g_xyz), _ptr(g_means2D), _ptr(g_dc), _ptr(g_rest), _ptr(g_op), _ptr(g_ls),
+                                        _ptr(g_rot), _ptr(scratch), stream)
+            if rc != _lib.GSR_OK:
+                raise RuntimeError(f"gsr_backward_bound failed ({rc}): {_lib.gsr_error()}")
+            rc = gab.gab_bind_backward_faces(F, face_begin.data_ptr(), b.rows, d_face.data_ptr(), stream)
+            if rc != 0:
+                raise RuntimeError(f"gab_bind_backward_faces failed ({rc}): {_lib.gab_error()}")
+        return (g_xyz, g_means2D, g_dc, g_rest, g_op, g_ls, g_rot, d_face[3 * F: 12 * F].view(F, 3, 3), d_face[12 * F: 13 * F].view(F, 1),
+                d_face[: 3 * F].view(F, 3), d_face[13 * F:].view(F, 4), None, None, None)
+
+
+def rasterize_bound(xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, face_R, face_scale, face_center, face_quat, binding, csr,
+                    raster_settings):
+    """-> (color, radii, visibility_filter) of a mesh-bound model straight from its leaves and face frames (see _RasterizeBound)."""
+    return _RasterizeBound.apply(xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, face_R, face_scale, face_center, face_quat,
+                                 binding, csr, raster_settings)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,

@@ -144,6 +144,11 @@ int gab_bind_backward_csr(int32_t N, int32_t F, const float* xyz, const float* l
 /* Utility: zero-fills up to 8 device buffers (sizes in floats) with ONE launch.  `buffers_host` / `sizes_host` are
  * HOST arrays of device pointers / element counts.  Used to build the full (T,k) gradient tables of the per-timestep
  * FLAME parameters around the single row gab_flame_backward writes. */
+/* Pass 2 of the two-pass form alone: sums every face's contiguous rows (GAB_BIND_ROW_FLOATS floats each, written at the splats' CSR
+ * positions) into d_face (17*F).  For callers whose pass 1 runs elsewhere -- the rasterizer's bound entry writes the rows from its own
+ * preprocess backward (include/gsr.h: gsr_backward_bound). */
+int gab_bind_backward_faces(int32_t F, const int32_t* face_begin, const float* rows, float* d_face /*17*F*/, void* stream);
+
 int gab_zero_buffers(int32_t count, float* const* buffers_host, const int32_t* sizes_host, void* stream);
 
 #ifdef __cplusplus

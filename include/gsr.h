@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 5
+#define GSR_ABI_VERSION 6
 #define GSR_BWD_SEGMENT 60        /* stream entries per backward segment (a multiple of both blend kernels' batches)  */
 #define GSR_BWD_SEGMENTS 10       /* segments per quadrant stream; the last one takes whatever is left                */
 #define GSR_BIN_BLOCKS 256        /* workgroups of the two binning passes (each owns a contiguous chunk of splats) */
@@ -278,6 +278,38 @@ int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, c
 #define GSR_K_QSCAN 10        /* k_qscan + k_qscan_glob                                                            */
 #define GSR_K_QSCATTER 11
 #define GSR_NUM_KERNELS 12
+/* ---- bound entry: scene/gaussian_model.py:113-160 evaluated inside the rasterizer -----------------------
+ * For a mesh-bound model the rasterizer's inputs are get_xyz / get_scaling / get_rotation / get_opacity, i.e. the model's leaves
+ * carried into world space by the face each splat is bound to.  These two entries take the LEAVES (_xyz, _scaling = log scales,
+ * _rotation, _opacity = logits) plus the per-face frames and evaluate that transform where the first kernel reads its inputs
+ * (the same arithmetic, bit for bit, as libgab's gab_bind_forward: csrc/bind_math.h), so the world-space tensors are never
+ * materialised and the bind launch and its backward's first pass disappear.  Colours come from SH; covariances from scale/rotation.
+ * Backward: gradients of the leaves, and `rows` -- every splat's 17 contributions to its face's gradients (d_center 3, d_orien_mat 9,
+ * d_scaling 1, d_orien_quat 4, padded to 20 floats), written at the splat's position `slot` in the per-face CSR of the binding
+ * (what gab_bind_backward_csr builds) for libgab's per-face reduction gab_bind_backward_faces. */
+typedef struct GsrBound {
+    const void* binding;        /* (P) face index of every splat                                     */
+    int32_t binding_is_i64;     /* 0: int32, 1: int64                                                */
+    int32_t F;                  /* faces                                                             */
+    const float* face_R;        /* (F,3,3) face_orien_mat                                            */
+    const float* face_scale;    /* (F,1)   face_scaling                                              */
+    const float* face_center;   /* (F,3)   face_center                                               */
+    const float* face_quat;     /* (F,4)   face_orien_quat, WXYZ                                     */
+    const int32_t* slot;        /* backward: (P) position of every splat in the per-face CSR         */
+    float* rows;                /* backward: (P,20) floats, fully written                            */
+} GsrBound;
+int gsr_forward_bound(const GsrSettings* settings, int32_t P, int32_t M, const GsrBound* bound, const float* xyz_local, const float* shs,
+                      const float* shs_rest, const float* opacity_logit, const float* log_scales, const float* rot_local,
+                      float* out_color, int32_t* radii, void* geom, void* binning, int64_t binning_capacity, void* img,
+                      int64_t* num_rendered_host, void* stream);
+/* scratch9: 9 P floats (the colour / covariance gradients the world-space entry hands out, internal here) */
+int gsr_backward_bound(const GsrSettings* settings, int32_t P, int32_t M, const GsrBound* bound, const float* xyz_local, const float* shs,
+                       const float* shs_rest, const float* opacity_logit, const float* log_scales, const float* rot_local,
+                       const int32_t* radii, void* geom, const void* binning, int64_t binning_capacity, const void* img,
+                       int64_t num_rendered, const float* dL_dout_color, float* dL_dxyz_local, float* dL_dmeans2D, float* dL_dsh,
+                       float* dL_dsh_rest, float* dL_dopacity_logit, float* dL_dlog_scales, float* dL_drot_local, float* scratch9,
+                       void* stream);
+
 int gsr_profile_enable(int on);
 int gsr_profile_read(double* total_ms, int64_t* launches);
 const char* gsr_kernel_name(int id);

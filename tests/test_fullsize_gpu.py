@@ -122,6 +122,13 @@ def test_config4_200k_rigged_sequence_vs_oracle(oracle):
     s = oracle.make_settings(H, W, tfx, tfy, [1, 1, 1], 1.0, _np(cam.world_view_transform), _np(cam.full_proj_transform), 3,
                              _np(cam.camera_center))
     for ts in (0, 137, 299):
+        # what the benchmark runs: the rasterizer's bound entry on the model's leaves (no world-space tensors); same image bits
+        g.bound_render = True
+        g.select_mesh_by_timestep(ts)
+        with torch.no_grad():
+            img_bound = _np(render(cam, g, bench.Pipe, bg)["render"])
+        # the world-space gradients the oracle is compared on only exist on the accessor path
+        g.bound_render = False
         bench.zero_grads(g)
         g.select_mesh_by_timestep(ts)
         world = dict(means3D=g.get_xyz, opacities=g.get_opacity, scales=g.get_scaling, rotations=g.get_rotation)
@@ -135,6 +142,7 @@ def test_config4_200k_rigged_sequence_vs_oracle(oracle):
         st = oracle.forward(s, a["means3D"], shs, None, a["opacities"], a["scales"], a["rotations"], None)
         img = _np(pkg["render"])
         assert np.array_equal(img.view(np.uint32), st.color.view(np.uint32)), f"t={ts}: image max abs diff {np.abs(img - st.color).max()}"
+        assert np.array_equal(img_bound.view(np.uint32), st.color.view(np.uint32)), f"t={ts}: bound entry: image max abs diff {np.abs(img_bound - st.color).max()}"
         np.testing.assert_array_equal(_np(pkg["radii"]), st.radii)
         np.testing.assert_array_equal(_np(pkg["visibility_filter"]), st.radii > 0)
         gpix = (np.sign(st.color - 1.0) / st.color.size).astype(np.float32)

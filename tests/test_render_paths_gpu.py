@@ -75,3 +75,47 @@ def test_python_path_agrees_with_the_kernel_path(flag):
             b = b - (b * q).sum(1, keepdim=True) * q
         assert float((a - b).abs().max()) / scale < 2e-3, n
     assert float((alt[3] - base[3]).abs().max()) / (float(base[3].abs().max()) + 1e-30) < 2e-3
+
+
+def test_bound_entry_equals_accessors_plus_rasterizer():
+    """render() of a mesh-bound model through the rasterizer's bound entry (the leaves go to world space inside the
+    first kernel, include/gsr.h: gsr_forward_bound) against the reference-shaped path (get_xyz / get_scaling / get_rotation /
+    get_opacity from gab_bind_forward, then the world-space rasterizer).  The transform is the same arithmetic in both libraries
+    (csrc/bind_math.h), so image and radii must be the same BITS; gradients of the leaves and of the FLAME rows agree to fp32
+    summation order (the face gradients are reduced per face in both, from rows written by different kernels)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import bench
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd.gaussian_renderer import render
+
+    dev = torch.device("cuda:0")
+    H, W, N, T = 208, 176, 30000, 6
+    g, cam = bench.build_scene(dev, N, 3, W, H, T, "fused", True)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    wimg = torch.randn((3, H, W), generator=torch.Generator().manual_seed(4)).to(dev)
+    leaves = lambda: (g._xyz, g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity)
+    rows = ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation")
+    out = {}
+    for fast in (True, False):
+        g.bound_render = fast
+        bench.zero_grads(g)
+        g.select_mesh_by_timestep(3)
+        pkg = render(cam, g, bench.Pipe, bg)
+        assert bool(R.last_forward_info().get("bound", False)) == fast
+        (pkg["render"] * wimg).sum().backward()
+        out[fast] = dict(img=pkg["render"].detach().clone(), radii=pkg["radii"].clone(), vis=pkg["visibility_filter"].clone(),
+                         vsp=pkg["viewspace_points"].grad.clone(), leaves=[p.grad.clone() for p in leaves()],
+                         flame={k: g.flame_param[k].grad.clone() for k in rows})
+    a, b = out[True], out[False]
+    assert torch.equal(a["img"].view(torch.int32), b["img"].view(torch.int32))
+    assert torch.equal(a["radii"], b["radii"]) and torch.equal(a["vis"], b["vis"])
+
+    def close(x, y, tol, what):
+        err = float((x.double() - y.double()).abs().max()) / (float(y.double().abs().max()) + 1e-30)
+        assert err < tol, f"{what}: rel err {err:.3e}"
+    close(a["vsp"], b["vsp"], 1e-5, "viewspace gradient")
+    for name, x, y in zip(("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"), a["leaves"], b["leaves"]):
+        close(x, y, 2e-5, "d" + name)
+    for k in rows:
+        close(a["flame"][k], b["flame"][k], 2e-4, "d flame " + k)
