@@ -184,9 +184,6 @@ static int binning_path(int32_t P, size_t tiles, int32_t tile_culling, size_t* c
 {
     if (production_params(P, tiles, tile_culling, chunks, nb)) return 1;
     if (tile_culling == 5) return 2;
-    // beyond GSR_RANK_MAX_SPLATS the tile bitmaps no longer hold every rank in one pass and the per-instance order[] / record gathers
-    // leave the caches (2 M splats: 1.67 ms against 0.88 ms): such frames keep round 1's per-tile sort
-    if (P > GSR_RANK_MAX_SPLATS) return 2;
     size_t b = 16;
     while (b < (size_t)GSR_RANK_MAX_BUCKETS && b * 256 < (size_t)P) b <<= 1;   // about 256 splats per depth bucket
     *nb = b;
@@ -482,12 +479,22 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         }
         {
             TIMED(GSR_K_TILE_SORT, stream);
-            // the bitmap holds every rank of the frame (P bounds the ranked splats; binning_path() keeps P <= GSR_RANK_MAX_SPLATS here)
-            const uint32_t words = (uint32_t)(((size_t)P + 2047) / 2048) * 64u;
-            hipLaunchKernelGGL(gsr::k_tile_rank, dim3(tiles), dim3(GSR_RANK_TILE_THREADS), (size_t)words * 6, stream, words, (const uint4*)(b + bl.tdesc), (const uint2*)ranks, (const float*)pa.depths,
-                               (const gsr::BinHeader*)hdr, write_lists ? (unsigned long long*)(b + bl.keys) : nullptr,
-                               (uint32_t*)(b + bl.point_list), write_lists ? qlist : nullptr, qpos, qcount, qstart,
-                               cap, (const unsigned long long*)total_dev);
+            if (P <= GSR_RANK_MAX_SPLATS) {
+                // the bitmap holds every rank of the frame in one pass (P bounds the ranked splats)
+                const uint32_t words = (uint32_t)(((size_t)P + 2047) / 2048) * 64u;
+                hipLaunchKernelGGL(gsr::k_tile_rank, dim3(tiles), dim3(GSR_RANK_TILE_THREADS), (size_t)words * 6, stream, words, (const uint4*)(b + bl.tdesc), (const uint2*)ranks, (const float*)pa.depths,
+                                   (const gsr::BinHeader*)hdr, write_lists ? (unsigned long long*)(b + bl.keys) : nullptr,
+                                   (uint32_t*)(b + bl.point_list), write_lists ? qlist : nullptr, qpos, qcount, qstart,
+                                   cap, (const unsigned long long*)total_dev);
+            } else {
+                // larger frames: 1 M ranks per pass through a 128 KB bitmap
+                const size_t big_lds = ((size_t)GSR_RANK_BIG_WORDS + GSR_RANK_BIG_WORDS / 8) * 4;
+                HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_tile_rank_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
+                hipLaunchKernelGGL(gsr::k_tile_rank_big, dim3(tiles), dim3(GSR_RANK_BIG_THREADS), big_lds, stream, (const uint4*)(b + bl.tdesc),
+                                   (const uint2*)ranks, (const float*)pa.depths, (const gsr::BinHeader*)hdr,
+                                   write_lists ? (unsigned long long*)(b + bl.keys) : nullptr, (uint32_t*)(b + bl.point_list),
+                                   write_lists ? qlist : nullptr, qpos, qcount, qstart, cap, (const unsigned long long*)total_dev);
+            }
             KERNEL_CHECK("k_tile_rank", stream, dbg);
         }
     } else {

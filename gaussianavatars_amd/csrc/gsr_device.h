@@ -27,6 +27,8 @@
 #define GSR_LDS_HIST_TILES 40960 // 160 KB of LDS / 4 B: the largest tile grid k_count / k_scatter privatise
 #define GSR_RANK_MAX_BUCKETS 4096 // depth buckets of the rank path (16 KB of LDS beside the tile histogram)
 #define GSR_RANK_HIST_TILES (GSR_LDS_HIST_TILES - GSR_RANK_MAX_BUCKETS)   // the largest grid of tile CORNERS, (gx+1)(gy+1), k_rcount / k_rscatter privatise
+#define GSR_RANK_BIG_WORDS 32768   // k_tile_rank_big: bitmap words per pass (1 M ranks, 128 KB of LDS)
+#define GSR_RANK_BIG_THREADS 1024
 #define GSR_RANK_IDX_BITS 28      // a tile-list entry of the rank path is (rank, splat | quadrant mask << 28)
 #define GSR_RANK_MAX_SPLATS 262144 // splat count up to which the rank path is taken (8192 bitmap words per tile, one pass)
 #ifdef GSR_RANK_TILE_THREADS_EXP
@@ -586,6 +588,9 @@ __global__ void k_tile_rank(uint32_t words, const uint4* tdesc, const uint2* ran
                             const float* depths, const BinHeader* hdr, unsigned long long* keys, uint32_t* point_list,
                             uint32_t* qlist, uint32_t* qpos, uint32_t* qcount, uint32_t* qstart, unsigned long long capacity,
                             const unsigned long long* total_dev);
+__global__ void k_tile_rank_big(const uint4* tdesc, const uint2* ranks, const float* depths, const BinHeader* hdr, unsigned long long* keys,
+                                uint32_t* point_list, uint32_t* qlist, uint32_t* qpos, uint32_t* qcount, uint32_t* qstart,
+                                unsigned long long capacity, const unsigned long long* total_dev);
 // production binning (gsr_binning.hip)
 __global__ void k_dbucket(int P, const uint32_t* brec_rect, const float* depths, BinHeader* hdr, uint32_t nb, uint32_t* bcount, uint32_t* bhist);
 __global__ void k_dscan(uint32_t nb, const uint32_t* bcount, uint32_t* bstart, uint32_t* bcursor, uint32_t* border, BinHeader* hdr);

@@ -426,131 +426,24 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
 }
 
 // ------------------------------------------------------------------------------------------
-// k_tile_rank: one workgroup per tile (heaviest first), one pass (the API takes this path only while every rank of the frame
-// fits the bitmap: WORDS * 32 >= P):
-//   1. bitmap[r >> 5] |= 1 << (r & 31) for the tile's (rank, splat) entries (ds_or)
-//   2. rows of 64 words go round-robin to the waves: a wave scan of the popcounts gives every word its offset inside the row
-//      (wprefix, 16 bit), the row totals are scanned by wave 0 -> rowoff[]
-//   3. every entry computes its own position in the sorted list -- rowoff[row] + wprefix[word] + popcount(bits below its own) --
-//      and drops its splat index there: sorted[position]; GSR_RANK_WINDOW positions at a time
-//   4. epilogue, GSR_RANK_WINDOW entries at a time (striped like round 1's): the entry carries the splat's quadrant mask
-//      (k_rscatter), so no per-splat record is gathered; stable compaction into the tile's four n-slot streams with
-//      ballots + one scan of the (chunk, wave) counters; the parity modes also write the reference-format key list
-// No comparison, no data-dependent loop, every step entry-parallel.
+// The tile's sorted list -> its four quadrant streams, GSR_RANK_WINDOW entries at a time (striped like round 1's epilogue): every
+// entry carries its quadrant mask (k_rscatter), so no per-splat record is gathered; stable compaction with ballots + one scan of
+// the (chunk, wave) counters; the parity modes also write the reference-format key list.  `lsorted`: the list in LDS (tiles whose
+// entries stayed in registers), else `sorted` in global memory (written by this workgroup before the preceding barrier).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GSR_RANK_TILE_THREADS) void k_tile_rank(uint32_t words, const uint4* __restrict__ tdesc, const uint2* __restrict__ ranks,
-                                                    const float* __restrict__ depths, const BinHeader* __restrict__ hdr,
-                                                    unsigned long long* __restrict__ keys, uint32_t* __restrict__ point_list,
-                                                    uint32_t* __restrict__ qlist, uint32_t* __restrict__ qpos, uint32_t* __restrict__ qcount,
-                                                    uint32_t* __restrict__ qstart, unsigned long long capacity,
-                                                    const unsigned long long* __restrict__ total_dev)
+template <int THREADS>
+__device__ __forceinline__ void tile_streams(uint32_t total, uint32_t n, uint32_t tile, uint32_t start, uint32_t* __restrict__ sorted,
+                                             const uint32_t* __restrict__ lsorted, uint32_t (*__restrict__ cntw)[GSR_RANK_WINDOW / 64 + 1],
+                                             const float* __restrict__ depths, unsigned long long* __restrict__ keys,
+                                             uint32_t* __restrict__ qpbase, uint32_t* __restrict__ qlbase, uint32_t* __restrict__ qcount)
 {
-    constexpr int THREADS = GSR_RANK_TILE_THREADS, NW = THREADS / 64, EPT = GSR_RANK_WINDOW / THREADS, NE = EPT * NW;
-    constexpr int ROWS = GSR_RANK_MAX_SPLATS / 2048, RPL = (ROWS + 63) / 64;   // rows of 64 words = 2048 ranks
-    constexpr int UB = 8;   // entries per thread whose loads are in flight together
-    static_assert(NE <= 64, "one (chunk, wave) counter per lane in the epilogue's scan");
-    static_assert(EPT % 4 == 0, "the epilogue gathers four chunks at a time");
-    extern __shared__ uint32_t bitmap[];                                   // [words] (a multiple of 64: ceil(P / 2048) rows), then
-    uint16_t* const wprefix = reinterpret_cast<uint16_t*>(bitmap + words);  // [words] set bits before the word inside its row
-    __shared__ uint32_t cntw[4][NE + 1];
-    __shared__ uint32_t rowoff[ROWS + 1];
-    __shared__ uint32_t lsorted[UB * THREADS];   // the sorted list of a tile whose entries fit the registers (the common case)
-    if (*total_dev > capacity) return;
-    const uint4 td = tdesc[blockIdx.x];      // (tile, entries, first entry): launch order = heaviest tiles first
-    const uint32_t tile = td.x, n = td.y;
+    constexpr int NW = THREADS / 64, EPT = GSR_RANK_WINDOW / THREADS, NE = EPT * NW;
+    static_assert(NE == GSR_RANK_WINDOW / 64 && NE <= 64, "one (chunk, wave) counter per lane in the scan");
+    static_assert(EPT % 4 == 0, "four chunks at a time");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (n == 0) {
-        if (tid < 4) { qcount[4 * tile + tid] = 0u; qstart[4 * tile + tid] = 0u; }
-        return;
-    }
-    const uint32_t start = td.z;
-    if (tid < 4) qstart[4 * tile + tid] = 4u * start + (uint32_t)tid * n;   // the tile's four n-slot streams
-    const uint2* __restrict__ rk = ranks + start;
-    const bool fast = n <= (uint32_t)(UB * THREADS);   // every entry stays in a register between the two passes over them
-    uint32_t* const qpbase = qpos + (size_t)4 * start;
-    uint32_t* const qlbase = qlist ? qlist + (size_t)4 * start : nullptr;
+    const bool fast = lsorted != nullptr;
     const unsigned long long tile_hi = (unsigned long long)tile << 32;
-    const uint32_t Wn = min(words, (hdr->nvis + 31u) >> 5);
-    const uint32_t rows = (Wn + 63u) >> 6;
-
-    uint2 e0[UB];
-#pragma unroll
-    for (int k = 0; k < UB; ++k) {   // the first UB * THREADS entries: issued before the bitmap is cleared
-        const uint32_t i = (uint32_t)(k * THREADS + tid);
-        e0[k] = i < n ? rk[i] : make_uint2(0xFFFFFFFFu, 0u);
-    }
-    for (uint32_t w = tid; w < rows * 64u; w += THREADS) bitmap[w] = 0u;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < UB; ++k)
-        if (e0[k].x < Wn * 32u) atomicOr(&bitmap[e0[k].x >> 5], 1u << (e0[k].x & 31u));
-    for (uint32_t base = UB * THREADS; base < n; base += UB * THREADS) {
-        uint32_t r[UB];
-#pragma unroll
-        for (int k = 0; k < UB; ++k) {
-            const uint32_t i = base + (uint32_t)(k * THREADS + tid);
-            r[k] = i < n ? rk[i].x : 0xFFFFFFFFu;
-        }
-#pragma unroll
-        for (int k = 0; k < UB; ++k)
-            if (r[k] < Wn * 32u) atomicOr(&bitmap[r[k] >> 5], 1u << (r[k] & 31u));
-    }
-    __syncthreads();
-    for (uint32_t row = wid; row < rows; row += NW) {
-        const uint32_t w = row * 64u + (uint32_t)lane;
-        const uint32_t v = (uint32_t)__builtin_popcount(bitmap[w]);
-        const uint32_t incl = wave_scan_incl_u32(v);
-        wprefix[w] = (uint16_t)(incl - v);
-        if (lane == 63) rowoff[row] = incl;   // the row's total, scanned in place below
-    }
-    __syncthreads();
-    if (wid == 0) {   // exclusive scan of the row totals (RPL consecutive rows per lane)
-        uint32_t a[RPL], sum = 0;
-#pragma unroll
-        for (int j = 0; j < RPL; ++j) {
-            const uint32_t rr = (uint32_t)(RPL * lane + j);
-            a[j] = rr < rows ? rowoff[rr] : 0u;
-            sum += a[j];
-        }
-        const uint32_t incl = wave_scan_incl_u32(sum);
-        uint32_t acc = incl - sum;
-#pragma unroll
-        for (int j = 0; j < RPL; ++j) {
-            const uint32_t rr = (uint32_t)(RPL * lane + j);
-            if (rr < rows) rowoff[rr] = acc;
-            acc += a[j];
-        }
-        if (lane == 63) rowoff[ROWS] = incl;
-    }
-    __syncthreads();
-    const uint32_t total = rowoff[ROWS];   // == n (ranks are unique)
     uint32_t run[4] = {0u, 0u, 0u, 0u};
-
-    // ---- 3. every entry finds its position and drops its splat index there: the tile's sorted list, in global memory (the
-    //         reference's point_list; the same workgroup reads it back below, coalesced) ----
-    uint32_t* const sorted = point_list + start;
-    auto position = [&](uint32_t r) {
-        const uint32_t w = r >> 5;
-        return rowoff[w >> 6] + (uint32_t)wprefix[w] + (uint32_t)__builtin_popcount(bitmap[w] & ((1u << (r & 31u)) - 1u));
-    };
-    if (fast) {   // registers -> LDS: no second read of the entries, no global round trip for the list
-#pragma unroll
-        for (int k = 0; k < UB; ++k)
-            if (e0[k].x < Wn * 32u) lsorted[position(e0[k].x)] = e0[k].y;
-    } else {
-        for (uint32_t base = 0; base < n; base += UB * THREADS) {
-            uint2 e[UB];
-#pragma unroll
-            for (int k = 0; k < UB; ++k) {
-                const uint32_t i = base + (uint32_t)(k * THREADS + tid);
-                e[k] = i < n ? rk[i] : make_uint2(0xFFFFFFFFu, 0u);
-            }
-#pragma unroll
-            for (int k = 0; k < UB; ++k)
-                if (e[k].x < Wn * 32u) sorted[position(e[k].x)] = e[k].y;
-        }
-    }
-    __syncthreads();   // (global stores of this workgroup are visible to it after the barrier)
     for (uint32_t win_lo = 0; win_lo < total; win_lo += (uint32_t)GSR_RANK_WINDOW) {
         const uint32_t m = min((uint32_t)GSR_RANK_WINDOW, total - win_lo);
         // ---- 4. epilogue over entries i0 .. i0 + m of the tile's list ----
@@ -623,4 +516,234 @@ __global__ __launch_bounds__(GSR_RANK_TILE_THREADS) void k_tile_rank(uint32_t wo
     }
     if (tid < 4) qcount[4 * tile + tid] = tid == 0 ? run[0] : tid == 1 ? run[1] : tid == 2 ? run[2] : run[3];
 }
+
+// ------------------------------------------------------------------------------------------
+// k_tile_rank: one workgroup per tile (heaviest first), one pass (the API takes this path only while every rank of the frame
+// fits the bitmap: WORDS * 32 >= P):
+//   1. bitmap[r >> 5] |= 1 << (r & 31) for the tile's (rank, splat) entries (ds_or)
+//   2. rows of 64 words go round-robin to the waves: a wave scan of the popcounts gives every word its offset inside the row
+//      (wprefix, 16 bit), the row totals are scanned by wave 0 -> rowoff[]
+//   3. every entry computes its own position in the sorted list -- rowoff[row] + wprefix[word] + popcount(bits below its own) --
+//      and drops its splat index there: sorted[position]; GSR_RANK_WINDOW positions at a time
+//   4. epilogue, GSR_RANK_WINDOW entries at a time (striped like round 1's): the entry carries the splat's quadrant mask
+//      (k_rscatter), so no per-splat record is gathered; stable compaction into the tile's four n-slot streams with
+//      ballots + one scan of the (chunk, wave) counters; the parity modes also write the reference-format key list
+// No comparison, no data-dependent loop, every step entry-parallel.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GSR_RANK_TILE_THREADS) void k_tile_rank(uint32_t words, const uint4* __restrict__ tdesc, const uint2* __restrict__ ranks,
+                                                    const float* __restrict__ depths, const BinHeader* __restrict__ hdr,
+                                                    unsigned long long* __restrict__ keys, uint32_t* __restrict__ point_list,
+                                                    uint32_t* __restrict__ qlist, uint32_t* __restrict__ qpos, uint32_t* __restrict__ qcount,
+                                                    uint32_t* __restrict__ qstart, unsigned long long capacity,
+                                                    const unsigned long long* __restrict__ total_dev)
+{
+    constexpr int THREADS = GSR_RANK_TILE_THREADS, NW = THREADS / 64, EPT = GSR_RANK_WINDOW / THREADS, NE = EPT * NW;
+    constexpr int ROWS = GSR_RANK_MAX_SPLATS / 2048, RPL = (ROWS + 63) / 64;   // rows of 64 words = 2048 ranks
+    constexpr int UB = 8;   // entries per thread whose loads are in flight together
+    static_assert(NE <= 64, "one (chunk, wave) counter per lane in the epilogue's scan");
+    static_assert(EPT % 4 == 0, "the epilogue gathers four chunks at a time");
+    extern __shared__ uint32_t bitmap[];                                   // [words] (a multiple of 64: ceil(P / 2048) rows), then
+    uint16_t* const wprefix = reinterpret_cast<uint16_t*>(bitmap + words);  // [words] set bits before the word inside its row
+    __shared__ uint32_t cntw[4][NE + 1];
+    __shared__ uint32_t rowoff[ROWS + 1];
+    __shared__ uint32_t lsorted[UB * THREADS];   // the sorted list of a tile whose entries fit the registers (the common case)
+    if (*total_dev > capacity) return;
+    const uint4 td = tdesc[blockIdx.x];      // (tile, entries, first entry): launch order = heaviest tiles first
+    const uint32_t tile = td.x, n = td.y;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (n == 0) {
+        if (tid < 4) { qcount[4 * tile + tid] = 0u; qstart[4 * tile + tid] = 0u; }
+        return;
+    }
+    const uint32_t start = td.z;
+    if (tid < 4) qstart[4 * tile + tid] = 4u * start + (uint32_t)tid * n;   // the tile's four n-slot streams
+    const uint2* __restrict__ rk = ranks + start;
+    const bool fast = n <= (uint32_t)(UB * THREADS);   // every entry stays in a register between the two passes over them
+    uint32_t* const qpbase = qpos + (size_t)4 * start;
+    uint32_t* const qlbase = qlist ? qlist + (size_t)4 * start : nullptr;
+    const uint32_t Wn = min(words, (hdr->nvis + 31u) >> 5);
+    const uint32_t rows = (Wn + 63u) >> 6;
+
+    uint2 e0[UB];
+#pragma unroll
+    for (int k = 0; k < UB; ++k) {   // the first UB * THREADS entries: issued before the bitmap is cleared
+        const uint32_t i = (uint32_t)(k * THREADS + tid);
+        e0[k] = i < n ? rk[i] : make_uint2(0xFFFFFFFFu, 0u);
+    }
+    for (uint32_t w = tid; w < rows * 64u; w += THREADS) bitmap[w] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < UB; ++k)
+        if (e0[k].x < Wn * 32u) atomicOr(&bitmap[e0[k].x >> 5], 1u << (e0[k].x & 31u));
+    for (uint32_t base = UB * THREADS; base < n; base += UB * THREADS) {
+        uint32_t r[UB];
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            const uint32_t i = base + (uint32_t)(k * THREADS + tid);
+            r[k] = i < n ? rk[i].x : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < UB; ++k)
+            if (r[k] < Wn * 32u) atomicOr(&bitmap[r[k] >> 5], 1u << (r[k] & 31u));
+    }
+    __syncthreads();
+    for (uint32_t row = wid; row < rows; row += NW) {
+        const uint32_t w = row * 64u + (uint32_t)lane;
+        const uint32_t v = (uint32_t)__builtin_popcount(bitmap[w]);
+        const uint32_t incl = wave_scan_incl_u32(v);
+        wprefix[w] = (uint16_t)(incl - v);
+        if (lane == 63) rowoff[row] = incl;   // the row's total, scanned in place below
+    }
+    __syncthreads();
+    if (wid == 0) {   // exclusive scan of the row totals (RPL consecutive rows per lane)
+        uint32_t a[RPL], sum = 0;
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const uint32_t rr = (uint32_t)(RPL * lane + j);
+            a[j] = rr < rows ? rowoff[rr] : 0u;
+            sum += a[j];
+        }
+        const uint32_t incl = wave_scan_incl_u32(sum);
+        uint32_t acc = incl - sum;
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const uint32_t rr = (uint32_t)(RPL * lane + j);
+            if (rr < rows) rowoff[rr] = acc;
+            acc += a[j];
+        }
+        if (lane == 63) rowoff[ROWS] = incl;
+    }
+    __syncthreads();
+    const uint32_t total = rowoff[ROWS];   // == n (ranks are unique)
+
+    // ---- 3. every entry finds its position and drops its splat index there: the tile's sorted list, in global memory (the
+    //         reference's point_list; the same workgroup reads it back below, coalesced) ----
+    uint32_t* const sorted = point_list + start;
+    auto position = [&](uint32_t r) {
+        const uint32_t w = r >> 5;
+        return rowoff[w >> 6] + (uint32_t)wprefix[w] + (uint32_t)__builtin_popcount(bitmap[w] & ((1u << (r & 31u)) - 1u));
+    };
+    if (fast) {   // registers -> LDS: no second read of the entries, no global round trip for the list
+#pragma unroll
+        for (int k = 0; k < UB; ++k)
+            if (e0[k].x < Wn * 32u) lsorted[position(e0[k].x)] = e0[k].y;
+    } else {
+        for (uint32_t base = 0; base < n; base += UB * THREADS) {
+            uint2 e[UB];
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                const uint32_t i = base + (uint32_t)(k * THREADS + tid);
+                e[k] = i < n ? rk[i] : make_uint2(0xFFFFFFFFu, 0u);
+            }
+#pragma unroll
+            for (int k = 0; k < UB; ++k)
+                if (e[k].x < Wn * 32u) sorted[position(e[k].x)] = e[k].y;
+        }
+    }
+    __syncthreads();   // (global stores of this workgroup are visible to it after the barrier)
+    tile_streams<THREADS>(total, n, tile, start, sorted, fast ? lsorted : nullptr, cntw, depths, keys, qpbase, qlbase, qcount);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_tile_rank_big: the same for frames whose ranks do not fit one tile bitmap (more than GSR_RANK_MAX_SPLATS ranked splats):
+// 1024 threads, GSR_RANK_BIG_WORDS * 32 ranks per pass (128 KB of LDS), as many passes as the frame needs.  Rows are 8 words here
+// and the offset of a word inside its row is recounted on the fly (up to 7 popcounts), so the only table beside the bitmap is one
+// offset per row (16 KB); the sorted list always goes through global memory.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GSR_RANK_BIG_THREADS) void k_tile_rank_big(const uint4* __restrict__ tdesc, const uint2* __restrict__ ranks,
+                                                                         const float* __restrict__ depths, const BinHeader* __restrict__ hdr,
+                                                                         unsigned long long* __restrict__ keys, uint32_t* __restrict__ point_list,
+                                                                         uint32_t* __restrict__ qlist, uint32_t* __restrict__ qpos,
+                                                                         uint32_t* __restrict__ qcount, uint32_t* __restrict__ qstart,
+                                                                         unsigned long long capacity, const unsigned long long* __restrict__ total_dev)
+{
+    constexpr int THREADS = GSR_RANK_BIG_THREADS, NWV = THREADS / 64, WORDS = GSR_RANK_BIG_WORDS, ROWS = WORDS / 8, RPT = ROWS / THREADS;
+    constexpr int UB = 4;
+    static_assert(ROWS % THREADS == 0, "rows split evenly over the threads");
+    extern __shared__ uint32_t bitmap[];                 // [WORDS], then [ROWS] row offsets
+    uint32_t* const rowoff = bitmap + WORDS;
+    __shared__ uint32_t cntw[4][GSR_RANK_WINDOW / 64 + 1];
+    __shared__ uint32_t wave_tot[NWV];
+    if (*total_dev > capacity) return;
+    const uint4 td = tdesc[blockIdx.x];
+    const uint32_t tile = td.x, n = td.y, start = td.z;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (n == 0) {
+        if (tid < 4) { qcount[4 * tile + tid] = 0u; qstart[4 * tile + tid] = 0u; }
+        return;
+    }
+    if (tid < 4) qstart[4 * tile + tid] = 4u * start + (uint32_t)tid * n;
+    const uint2* __restrict__ rk = ranks + start;
+    uint32_t* const sorted = point_list + start;
+    const uint32_t nvis = hdr->nvis;
+    uint32_t pass_base = 0;   // entries of the list placed by earlier passes
+    for (uint32_t pass_lo = 0; pass_lo < nvis && pass_base < n; pass_lo += (uint32_t)WORDS * 32u) {
+        const uint32_t span = min((uint32_t)WORDS * 32u, nvis - pass_lo);   // ranks of this pass
+        for (uint32_t w = tid; w < (uint32_t)WORDS; w += THREADS) bitmap[w] = 0u;
+        __syncthreads();
+        for (uint32_t base = 0; base < n; base += UB * THREADS) {
+            uint32_t r[UB];
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                const uint32_t i = base + (uint32_t)(k * THREADS + tid);
+                r[k] = i < n ? rk[i].x - pass_lo : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int k = 0; k < UB; ++k)
+                if (r[k] < span) atomicOr(&bitmap[r[k] >> 5], 1u << (r[k] & 31u));
+        }
+        __syncthreads();
+        // row totals: a lane per word (consecutive lanes, consecutive words: no bank conflicts), the 8 words of a row summed on DPP
+        for (uint32_t w = tid; w < (uint32_t)WORDS; w += THREADS) {
+            uint32_t c = (uint32_t)__builtin_popcount(bitmap[w]);
+            c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+            c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+            c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x141, 0xf, 0xf, false);   // row_half_mirror: the other quad of the 8
+            if ((lane & 7) == 0) rowoff[w >> 3] = c;
+        }
+        __syncthreads();
+        // exclusive scan of the ROWS totals in place: RPT consecutive rows per thread
+        uint32_t a[RPT], sum = 0;
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) { a[j] = rowoff[RPT * tid + j]; sum += a[j]; }
+        const uint32_t incl = wave_scan_incl_u32(sum);
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        uint32_t off = incl - sum, pass_total = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) {
+            const uint32_t t = wave_tot[w];
+            if (w < wid) off += t;
+            pass_total += t;
+        }
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) { rowoff[RPT * tid + j] = off; off += a[j]; }
+        __syncthreads();
+        if (pass_total) {
+            for (uint32_t base = 0; base < n; base += UB * THREADS) {
+                uint2 e[UB];
+#pragma unroll
+                for (int k = 0; k < UB; ++k) {
+                    const uint32_t i = base + (uint32_t)(k * THREADS + tid);
+                    e[k] = i < n ? rk[i] : make_uint2(0xFFFFFFFFu, 0u);
+                }
+#pragma unroll
+                for (int k = 0; k < UB; ++k) {
+                    const uint32_t r = e[k].x - pass_lo;
+                    if (r < span) {
+                        const uint32_t w = r >> 5, w0 = w & ~7u;
+                        uint32_t pos = pass_base + rowoff[w >> 3] + (uint32_t)__builtin_popcount(bitmap[w] & ((1u << (r & 31u)) - 1u));
+                        for (uint32_t k2 = w0; k2 < w; ++k2) pos += (uint32_t)__builtin_popcount(bitmap[k2]);
+                        sorted[pos] = e[k].y;
+                    }
+                }
+            }
+        }
+        pass_base += pass_total;
+        __syncthreads();   // the bitmap is cleared by the next pass; (and: this workgroup's global stores are visible to it)
+    }
+    tile_streams<THREADS>(n, n, tile, start, sorted, nullptr, cntw, depths, keys, qpos + (size_t)4 * start,
+                          qlist ? qlist + (size_t)4 * start : nullptr, qcount);
+}
+
 }  // namespace gsr

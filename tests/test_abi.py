@@ -69,11 +69,12 @@ def test_layouts_are_disjoint_and_aligned():
             (bl.order, 4 * P), (bl.bcount, 4 * bl.nb), (bl.bstart, 4 * bl.nb), (bl.bcursor, 4 * bl.nb), (bl.border, 4 * bl.nb),
             (bl.qhist, bl.chunks * Q), (bl.qprefix, 4 * bl.chunks * Q), (bl.qmask, 16 * P)]
     _check(segs, bl.total)
-    # grids beyond 16384 quadrants and splat counts beyond 255 per chunk do not take the scatter: the rank path up to 262144 splats
-    # (every rank of the frame in one tile bitmap), round 1's per-tile sort beyond
+    # grids beyond 16384 quadrants and splat counts beyond 255 per chunk do not take the scatter: the rank path at any size
+    # (one tile bitmap up to 262144 splats, 1 M ranks per pass beyond); round 1's per-tile sort only on request (tile_culling 5)
     assert lib.gsr_binning_layout(capq, 1600, 1100, 250_000, 1, C.byref(bl)) == 0 and bl.path == 0
-    assert lib.gsr_binning_layout(capq, 1600, 1100, 2_000_000, 1, C.byref(bl)) == 0 and bl.path == 2
-    assert lib.gsr_binning_layout(capq, 550, 802, 2_000_000, 1, C.byref(bl)) == 0 and bl.path == 2
+    assert lib.gsr_binning_layout(capq, 1600, 1100, 2_000_000, 1, C.byref(bl)) == 0 and bl.path == 0 and bl.nb == 4096
+    assert lib.gsr_binning_layout(capq, 550, 802, 2_000_000, 1, C.byref(bl)) == 0 and bl.path == 0
+    assert lib.gsr_binning_layout(capq, 1600, 1100, 2_000_000, 5, C.byref(bl)) == 0 and bl.path == 2
     _check([(il.final_T, 4 * HW), (il.n_contrib, 4 * HW), (il.n_contrib_q, 4 * HW), (il.c_final, 12 * HW), (il.ck, 144 * HW)], il.total)
     assert lib.gsr_geom_layout(-1, C.byref(gl)) < 0 and b"bad arguments" in lib.gsr_last_error()
 
