@@ -10,7 +10,7 @@ which=${1:-forward}
 here=$(cd "$(dirname "$0")/../gaussianavatars_amd/csrc" && pwd)
 if [ "$which" = forward ]; then src=gsr_forward.hip; fp=off; kern=_ZN3gsr8k_renderE; r=${2:-6}; else src=gsr_backward.hip; fp=fast; kern=_ZN3gsr12k_render_bwdILb0E; r=${2:-4}; fi
 tmp=$(mktemp -d)
-(cd "$here" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=$fp -S --cuda-device-only $src -o $tmp/k.s 2>/dev/null)
+(cd "$here" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=$fp ${ISA_DEFS:-} -S --cuda-device-only $src -o $tmp/k.s 2>/dev/null)
 awk -v k="$kern" '$0 ~ "^"k".*:" {on=1} on && /s_endpgm/ {on=0} on {print}' $tmp/k.s > $tmp/kernel.s
 hdr=$(grep -m1 "Loop Header: Depth=1" $tmp/kernel.s | sed 's/:.*//; s/^\.L//')
 awk -v h="$hdr" -v r="$r" '
