@@ -68,15 +68,18 @@ typedef struct GsrSettings {
                                  1: production -- additionally the reference-format sorted `keys` / `point_list` arrays are
                                     not written (nothing downstream reads them; the blend walks the quadrant streams);
                                  2: culled, lists written (what the subsequence parity tests inspect);
-                                 3: as 1 but always on the per-tile sort path, 4: as 1 but on the depth-ordered scatter whenever it
-                                    applies, whatever the splat count (A/B of the two production binnings, tests). */
+                                 3: as 1 but always on the rank path (tiles ordered through bitmaps of global depth ranks: the default
+                                    wherever the depth-ordered scatter does not apply), 4: as 1 but on the depth-ordered scatter whenever it
+                                    applies, whatever the splat count, 5: as 1 but on round 1's per-tile bitonic sort (A/B of the three
+                                    binnings, tests).  The binning path of a call is GsrBinningLayout.path.                   */
     int32_t forward_only;     /* !=0: no backward will follow this forward (inference, torch.no_grad): the forward skips zero-filling
                                  the backward's per-splat accumulators (48 B per visible splat); gsr_backward on such a state is an
                                  error                                                                                   */
     int32_t deterministic;    /* !=0: bit-reproducible backward.  The blend backward then adds its per-(wave, splat) partial sums as 64-bit
                                  FIXED-POINT integers (integer addition is associative: the result does not depend on the order the
                                  atomics land in), scaled by a power of two derived from max |dL/dpixel| (one extra reduction kernel);
-                                 resolution max|dL/dpixel| * 2^-34 per term, i.e. finer than the fp32 partials themselves.  Same
+                                 and from the splat's own footprint; resolution 2^-58 of that bound per term, i.e. finer than the fp32
+                                 partials themselves.  Same
                                  value in the forward and the backward call of a frame (the forward zero-fills the accumulators
                                  of the mode).  Default 0: fp32 atomics (summation order varies run to run, like upstream's).    */
     int32_t exact_scale_grad; /* 0 (default): dL/dscales as upstream's computeCov3D backward returns it -- the gradient
