@@ -160,7 +160,7 @@ typedef struct GsrBinningLayout {
     size_t sspan;       /* float  [P][8] operands of the per-quadrant reach test of a binned splat (csrc/gsr_device.h: Span)          */
     size_t pstat;       /* uint32 [ceil(P/256)][2] (min, max) depth bits of each k_preprocess workgroup's visible splats       */
     size_t tdesc;       /* uint32 [tiles][4] (tile, entries, first entry, 0) in launch order (heaviest tiles first)                       */
-    size_t path;        /* 1: production binning is used for this (P, W, H, tile_culling); 0: the per-tile sort path     */
+    size_t path;        /* 0: rank path, 1: depth-ordered scatter, 2: round 1's per-tile sort (see gsr_binning_layout)       */
     size_t chunks;      /* production: number of chunks (waves) of the ordered walk                                */
     size_t nb;          /* production: number of depth buckets                                                     */
     size_t total;
@@ -184,11 +184,11 @@ const char* gsr_last_error(void);
 
 /* sizes/layouts of the state buffers (pure host arithmetic, no device access) */
 int gsr_geom_layout(int32_t P, GsrGeomLayout* out);
-/* P and tile_culling select the binning path (GsrBinningLayout.path): production (tile_culling 1) takes the depth-ordered
- * scatter from 125 000 splats up (below that the per-tile sort is faster) when the grid has at most 16384 quadrants,
- * P / chunks <= 255 and the chunk-prefix table stays below 1 GiB;
- * otherwise (and always in the parity modes) the per-tile sort path of round 1.  `capacity` counts the instances the path
- * produces: tile instances on the sort path, quadrant-stream entries on the production path.                          */
+/* P and tile_culling select the binning path (GsrBinningLayout.path): 0 = the rank path (the default: splats ranked by depth once,
+ * every tile ordered through an LDS bitmap of ranks -- one pass up to 262144 splats, 1 M ranks per pass beyond); 1 = the
+ * depth-ordered scatter, taken by production (tile_culling 1) beyond 262144 splats when the grid has at most 16384 quadrants,
+ * P / chunks <= 255 and the chunk-prefix table stays below 1 GiB; 2 = round 1's per-tile bitonic sort (tile_culling 5 only).
+ * `capacity` counts the instances the path produces: tile instances on paths 0 and 2, quadrant-stream entries on path 1.   */
 int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, int32_t P, int32_t tile_culling, GsrBinningLayout* out);
 int gsr_image_layout(int32_t width, int32_t height, GsrImageLayout* out);
 
