@@ -63,6 +63,20 @@ __device__ __forceinline__ float4 world_rotation(float4 face_quat, float4 local_
     return qmul(a, b);
 }
 __device__ __forceinline__ float sigmoid(float x) { return 1.f / (1.f + exp_(-x)); }
+// an UNBOUND model's activations (scene/gaussian_model.py:113-160 without a binding): exp, normalize, sigmoid
+__device__ __forceinline__ float4 unit_rotation(float4 q)
+{
+    const float nb = 1.f / qnorm_clamped(q);
+    return make_float4(q.x * nb, q.y * nb, q.z * nb, q.w * nb);
+}
+// backward of unit_rotation: g is the gradient w.r.t. the normalised quaternion
+__device__ __forceinline__ float4 unit_rotation_backward(float4 q, float4 g)
+{
+    const float nb = qnorm_clamped(q);
+    const float4 b = make_float4(q.x / nb, q.y / nb, q.z / nb, q.w / nb);
+    const float bg = b.x * g.x + b.y * g.y + b.z * g.z + b.w * g.w;
+    return make_float4((g.x - b.x * bg) / nb, (g.y - b.y * bg) / nb, (g.z - b.z * bg) / nb, (g.w - b.w * bg) / nb);
+}
 
 // ---- backward of the four, for one splat.  g_*: gradients w.r.t. the world-space values; outputs: gradients of the splat's own
 // leaves and `row`, its 17 contributions to its face's gradients (d_center 3 | d_orien_mat 9 | d_scaling 1 | d_orien_quat 4):

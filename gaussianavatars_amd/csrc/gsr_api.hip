@@ -258,10 +258,15 @@ int gsr_image_layout(int32_t width, int32_t height, GsrImageLayout* o)
 
 static int to_bound(const GsrBound* b, int32_t P, bool backward, gsr::BoundDev* o)
 {
-    o->binding = nullptr; o->is64 = 0; o->fR = o->fs = o->fc = o->fq = nullptr; o->slot = nullptr; o->rows = nullptr;
+    o->leaves = 0; o->binding = nullptr; o->is64 = 0; o->fR = o->fs = o->fc = o->fq = nullptr; o->slot = nullptr; o->rows = nullptr;
     if (!b) return 0;
-    if (b->F <= 0 || (P > 0 && (!b->binding || !b->face_R || !b->face_scale || !b->face_center || !b->face_quat)))
-        return fail(GSR_E_ARG, "GsrBound: NULL face buffer / binding or F <= 0");
+    o->leaves = 1;
+    if (!b->binding) {   // an unbound model's leaves: activations only
+        if (b->F != 0 || b->face_R || b->face_scale || b->face_center || b->face_quat) return fail(GSR_E_ARG, "GsrBound: face buffers without a binding");
+        return 0;
+    }
+    if (b->F <= 0 || (P > 0 && (!b->face_R || !b->face_scale || !b->face_center || !b->face_quat)))
+        return fail(GSR_E_ARG, "GsrBound: NULL face buffer or F <= 0");
     if (backward && P > 0 && (!b->slot || !b->rows)) return fail(GSR_E_ARG, "GsrBound: the backward needs slot and rows");
     o->binding = b->binding; o->is64 = b->binding_is_i64;
     o->fR = b->face_R; o->fs = b->face_scale; o->fc = b->face_center; o->fq = b->face_quat;

@@ -538,6 +538,10 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
                 const float bscale = a.bound.fs[bface];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) ws[k] = bindm::world_scaling(ws[k], bscale);
+            } else if (a.bound.leaves) {
+                q = bindm::unit_rotation(q);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ws[k] = bindm::world_scaling(ws[k], 1.f);
             }
             const float r = q.x, x = q.y, y = q.z, z = q.w;
             float R[3][3];
@@ -598,6 +602,19 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
         float4* row = reinterpret_cast<float4*>(a.bound.rows + (size_t)BINDM_ROW * a.bound.slot[i]);
 #pragma unroll
         for (int k = 0; k < BINDM_ROW / 4; ++k) row[k] = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+    }
+    else if (a.bound.leaves) {
+        // an unbound model's leaves: the activations' chain rule (exp, normalize, sigmoid); the position is the leaf itself
+        if (a.scales) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dscale[k] *= bindm::world_scaling(a.scales[3 * i + k], 1.f);
+        }
+        if (a.rotations) {
+            const float4 dq = bindm::unit_rotation_backward(reinterpret_cast<const float4*>(a.rotations)[i], make_float4(drot[0], drot[1], drot[2], drot[3]));
+            drot[0] = dq.x; drot[1] = dq.y; drot[2] = dq.z; drot[3] = dq.w;
+        }
+        const float o = bindm::sigmoid(a.opacities[i]);
+        gop = gop * o * (1.f - o);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) a.dL_dmeans3D[3 * i + k] = dmean[k];

@@ -449,8 +449,9 @@ struct QBinArgs {               // k_qcount / k_qscatter
 
 // Bound entry (gsr_forward_bound / gsr_backward_bound, N1 of SURVEY.md 8(f)): the per-splat inputs are the model's mesh-LOCAL
 // leaves and every splat is carried into world space right where it is read (bind_math.h) -- no world-space tensors, no bind launch.
-// binding == nullptr: plain world-space inputs.
+// binding == nullptr: plain world-space inputs, or (leaves != 0) an UNBOUND model's leaves: the activations only (exp, normalize, sigmoid).
 struct BoundDev {
+    int leaves;                           // the inputs are the model's leaves (bound when binding != nullptr)
     const void* __restrict__ binding;     // (P) face of every splat, int32 or int64
     int is64;
     const float* __restrict__ fR;         // (F,3,3) face_orien_mat

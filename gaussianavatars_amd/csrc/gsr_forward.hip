@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
             } else {
                 float4 q = reinterpret_cast<const float4*>(a.rotations)[i];
                 float ws[3] = {a.scales[3 * i + 0], a.scales[3 * i + 1], a.scales[3 * i + 2]};
-                if (a.bound.binding) {
-                    q = bindm::world_rotation(reinterpret_cast<const float4*>(a.bound.fq)[bface], q);
+                if (a.bound.leaves) {   // the model's leaves: activations here (bscale == 1 without a binding)
+                    q = a.bound.binding ? bindm::world_rotation(reinterpret_cast<const float4*>(a.bound.fq)[bface], q) : bindm::unit_rotation(q);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) ws[k] = bindm::world_scaling(ws[k], bscale);
                 }
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
                     con0 = cyy * det_inv;
                     con1 = -cxy * det_inv;
                     con2 = cxx * det_inv;
-                    opac = a.bound.binding ? bindm::sigmoid(a.opacities[i]) : a.opacities[i];
+                    opac = a.bound.leaves ? bindm::sigmoid(a.opacities[i]) : a.opacities[i];
                     rminx = x0; rminy = y0; rmaxx = x1; rmaxy = y1;
 
                     // ---- colour

@@ -66,18 +66,19 @@ def _bound_fast_path(pc, pipe, override_color) -> bool:
     "unfused" models, `pc.bound_render = False`) takes the reference-shaped path below."""
     if override_color is not None or pipe.compute_cov3D_python or pipe.convert_SHs_python:
         return False
-    if getattr(pc, "binding", None) is None or getattr(pc, "binding_impl", "fused") == "unfused" or not getattr(pc, "bound_render", True):
+    if getattr(pc, "binding_impl", "fused") == "unfused" or not getattr(pc, "bound_render", True):
         return False
     if not getattr(type(pc), "_gaa_patched", False) or getattr(pc, "get_features_split", None) is None:
         return False
-    return pc._xyz.is_cuda
+    return pc._xyz.is_cuda   # bound: the bound entry; unbound: the same entry without faces (the three activations in-kernel)
 
 
 def _render_bound(viewpoint_camera, pc, pipe, bg_color, scaling_modifier):
     from .patch import binding_csr_cached
-    from .rasterizer import rasterize_bound
+    from .rasterizer import rasterize_bound, rasterize_leaves
 
-    if pc.face_center is None:          # same lazy initialisation as the reference's accessors (scene/gaussian_model.py:119-120)
+    unbound = getattr(pc, "binding", None) is None
+    if not unbound and pc.face_center is None:          # same lazy initialisation as the reference's accessors (scene/gaussian_model.py:119-120)
         pc.select_mesh_by_timestep(0)
     device = pc._xyz.device
     screenspace_points = _screenspace_leaf(pc._xyz)
@@ -88,6 +89,9 @@ def _render_bound(viewpoint_camera, pc, pipe, bg_color, scaling_modifier):
         projmatrix=_dev(viewpoint_camera.full_proj_transform, device), sh_degree=pc.active_sh_degree,
         campos=_dev(viewpoint_camera.camera_center, device), prefiltered=False, debug=pipe.debug)
     dc, rest = pc.get_features_split
+    if unbound:
+        image, radii, visible = rasterize_leaves(pc._xyz, screenspace_points, dc, rest, pc._opacity, pc._scaling, pc._rotation, raster_settings)
+        return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": visible, "radii": radii}
     csr = binding_csr_cached(pc, pc.face_center.shape[0])
     image, radii, visible = rasterize_bound(pc._xyz, screenspace_points, dc, rest, pc._opacity, pc._scaling, pc._rotation, pc.face_orien_mat,
                                             pc.face_scaling, pc.face_center, pc.face_orien_quat, pc.binding, csr, raster_settings)

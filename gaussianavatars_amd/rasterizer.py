@@ -21,7 +21,7 @@ from torch import nn
 
 from . import _lib
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_bound", "last_forward_info", "set_tile_culling",
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_bound", "rasterize_leaves", "last_forward_info", "set_tile_culling",
            "get_tile_culling", "set_exact_scale_grad", "set_deterministic"]
 
 
@@ -308,18 +308,23 @@ class _RasterizeBound(torch.autograd.Function):
         s.forward_only = int(not any(need[:11]))
         xyz, sh_dc, sh_rest = _f32c(xyz, "_xyz"), _f32c(sh_dc, "_features_dc"), _f32c(sh_rest, "_features_rest")
         opacity_logit, log_scaling, rotation = _f32c(opacity_logit, "_opacity"), _f32c(log_scaling, "_scaling"), _f32c(rotation, "_rotation")
-        fR, fs, fc, fq = (_f32c(t, n) for t, n in ((face_R, "face_orien_mat"), (face_scale, "face_scaling"), (face_center, "face_center"),
-                                                    (face_quat, "face_orien_quat")))
-        P, F = xyz.shape[0], fc.shape[0]
-        if binding.dtype not in (torch.int32, torch.int64) or not binding.is_contiguous() or binding.numel() != P:
-            raise RuntimeError("binding must be a contiguous int32 / int64 tensor with one face per splat")
-        if csr is None or csr[1].numel() != F + 1 or csr[3].numel() != P:
-            raise RuntimeError("the bound rasterizer needs the binding's per-face CSR (binding.binding_csr) for this binding and mesh")
+        P = xyz.shape[0]
+        b = _lib.GsrBound()
+        if binding is None:   # an unbound model's leaves: the activations only (exp, normalize, sigmoid)
+            fR = fs = fc = fq = None
+            F = 0
+        else:
+            fR, fs, fc, fq = (_f32c(t, n) for t, n in ((face_R, "face_orien_mat"), (face_scale, "face_scaling"), (face_center, "face_center"),
+                                                        (face_quat, "face_orien_quat")))
+            F = fc.shape[0]
+            if binding.dtype not in (torch.int32, torch.int64) or not binding.is_contiguous() or binding.numel() != P:
+                raise RuntimeError("binding must be a contiguous int32 / int64 tensor with one face per splat")
+            if csr is None or csr[1].numel() != F + 1 or csr[3].numel() != P:
+                raise RuntimeError("the bound rasterizer needs the binding's per-face CSR (binding.binding_csr) for this binding and mesh")
+            b.binding, b.binding_is_i64, b.F = binding.data_ptr(), int(binding.dtype == torch.int64), F
+            b.face_R, b.face_scale, b.face_center, b.face_quat = fR.data_ptr(), fs.data_ptr(), fc.data_ptr(), fq.data_ptr()
         H, W = s.image_height, s.image_width
         M = 1 + int(sh_rest.shape[1])
-        b = _lib.GsrBound()
-        b.binding, b.binding_is_i64, b.F = binding.data_ptr(), int(binding.dtype == torch.int64), F
-        b.face_R, b.face_scale, b.face_center, b.face_quat = fR.data_ptr(), fs.data_ptr(), fc.data_ptr(), fq.data_ptr()
         gl, il = _layouts(lib, P, W, H)
         u8 = dict(dtype=torch.uint8, device=dev)
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
@@ -356,6 +361,7 @@ class _RasterizeBound(torch.autograd.Function):
         ctx.num_rendered, ctx.capacity, ctx.M, ctx.F = I, cap, M, F
         ctx.is64 = b.binding_is_i64
         ctx.csr = csr
+        ctx.unbound = binding is None
         ctx.save_for_backward(xyz, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, fR, fs, fc, fq, binding, radii, geom, binning, img)
         visible = geom[gl.visible: gl.visible + P].view(torch.bool)
         ctx.mark_non_differentiable(radii, visible)
@@ -365,7 +371,8 @@ class _RasterizeBound(torch.autograd.Function):
     def backward(ctx, grad_out_color, _grad_radii, _grad_visible=None):
         if grad_out_color is None:
             return (None,) * 14
-        lib, gab = _lib.gsr(), _lib.gab()
+        lib = _lib.gsr()
+        gab = None if ctx.unbound else _lib.gab()
         xyz, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, fR, fs, fc, fq, binding, radii, geom, binning, img = ctx.saved_tensors
         dev = xyz.device
         keep: list = []
@@ -377,13 +384,17 @@ class _RasterizeBound(torch.autograd.Function):
         g_xyz, g_means2D = torch.empty((P, 3), **f32), torch.empty((P, 3), **f32)
         g_dc, g_rest = torch.empty((P, 1, 3), **f32), torch.empty((P, M - 1, 3), **f32)
         g_op, g_ls, g_rot = torch.empty((P, 1), **f32), torch.empty((P, 3), **f32), torch.empty((P, 4), **f32)
-        scratch = torch.empty(9 * P + _lib.GAB_BIND_ROW_FLOATS * P, **f32)   # colour / covariance gradients, then the CSR rows
-        d_face = torch.empty(17 * F, **f32)                                  # four contiguous blocks: center | orien_mat | scaling | orien_quat
-        order, face_begin, _splat_face, slot = ctx.csr[:4]
         b = _lib.GsrBound()
-        b.binding, b.binding_is_i64, b.F = binding.data_ptr(), ctx.is64, F
-        b.face_R, b.face_scale, b.face_center, b.face_quat = fR.data_ptr(), fs.data_ptr(), fc.data_ptr(), fq.data_ptr()
-        b.slot, b.rows = slot.data_ptr(), scratch.data_ptr() + 4 * 9 * P
+        if ctx.unbound:
+            scratch = torch.empty(9 * P, **f32)                                  # colour / covariance gradients (internal)
+            d_face = face_begin = None
+        else:
+            scratch = torch.empty(9 * P + _lib.GAB_BIND_ROW_FLOATS * P, **f32)   # ... then the CSR rows
+            d_face = torch.empty(17 * F, **f32)                                  # four contiguous blocks: center | orien_mat | scaling | orien_quat
+            order, face_begin, _splat_face, slot = ctx.csr[:4]
+            b.binding, b.binding_is_i64, b.F = binding.data_ptr(), ctx.is64, F
+            b.face_R, b.face_scale, b.face_center, b.face_quat = fR.data_ptr(), fs.data_ptr(), fc.data_ptr(), fq.data_ptr()
+            b.slot, b.rows = slot.data_ptr(), scratch.data_ptr() + 4 * 9 * P
         stream = _lib.raw_stream(dev)
         with _lib.on_device(dev):
             rc = lib.gsr_backward_bound(C.byref(s), P, M, C.byref(b), _ptr(xyz), _ptr(sh_dc), _ptr(sh_rest), _ptr(opacity_logit), _ptr(log_scaling),
@@ -392,11 +403,22 @@ class _RasterizeBound(torch.autograd.Function):
                                         _ptr(g_rot), _ptr(scratch), stream)
             if rc != _lib.GSR_OK:
                 raise RuntimeError(f"gsr_backward_bound failed ({rc}): {_lib.gsr_error()}")
-            rc = gab.gab_bind_backward_faces(F, face_begin.data_ptr(), b.rows, d_face.data_ptr(), stream)
-            if rc != 0:
-                raise RuntimeError(f"gab_bind_backward_faces failed ({rc}): {_lib.gab_error()}")
+            if not ctx.unbound:
+                rc = gab.gab_bind_backward_faces(F, face_begin.data_ptr(), b.rows, d_face.data_ptr(), stream)
+                if rc != 0:
+                    raise RuntimeError(f"gab_bind_backward_faces failed ({rc}): {_lib.gab_error()}")
+        if ctx.unbound:
+            return (g_xyz, g_means2D, g_dc, g_rest, g_op, g_ls, g_rot, None, None, None, None, None, None, None)
         return (g_xyz, g_means2D, g_dc, g_rest, g_op, g_ls, g_rot, d_face[3 * F: 12 * F].view(F, 3, 3), d_face[12 * F: 13 * F].view(F, 1),
                 d_face[: 3 * F].view(F, 3), d_face[13 * F:].view(F, 4), None, None, None)
+
+
+def rasterize_leaves(xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, raster_settings):
+    """-> (color, radii, visibility_filter) of an UNBOUND model straight from its leaves: get_scaling = exp, get_rotation = normalize,
+    get_opacity = sigmoid (scene/gaussian_model.py:113-160) are evaluated inside the rasterizer's first kernel and their chain rule in
+    its last one -- no activation launches, no activated tensors."""
+    return _RasterizeBound.apply(xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, None, None, None, None, None, None,
+                                 raster_settings)
 
 
 def rasterize_bound(xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, face_R, face_scale, face_center, face_quat, binding, csr,

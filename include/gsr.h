@@ -289,7 +289,9 @@ int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, c
  * materialised and the bind launch and its backward's first pass disappear.  Colours come from SH; covariances from scale/rotation.
  * Backward: gradients of the leaves, and `rows` -- every splat's 17 contributions to its face's gradients (d_center 3, d_orien_mat 9,
  * d_scaling 1, d_orien_quat 4, padded to 20 floats), written at the splat's position `slot` in the per-face CSR of the binding
- * (what gab_bind_backward_csr builds) for libgab's per-face reduction gab_bind_backward_faces. */
+ * (what gab_bind_backward_csr builds) for libgab's per-face reduction gab_bind_backward_faces.
+ * binding == NULL (F = 0, face pointers NULL): an UNBOUND model's leaves -- only the three activations of scene/gaussian_model.py:
+ * 113-160 (scaling = exp, rotation = normalize, opacity = sigmoid) are applied, the position is the leaf itself, no rows. */
 typedef struct GsrBound {
     const void* binding;        /* (P) face index of every splat                                     */
     int32_t binding_is_i64;     /* 0: int32, 1: int64                                                */

@@ -136,3 +136,29 @@ def test_bound_entry_equals_accessors_plus_rasterizer():
         assert torch.equal(x, y)          # the leaves' gradients come straight from the fixed-point sums
     for name, x, y in zip(("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"), det[0][:6], a["leaves"]):
         close(x, y, 2e-5, "deterministic d" + name)
+
+
+def test_unbound_leaves_entry_equals_torch_activations_plus_rasterizer():
+    """An UNBOUND model through the same entry without faces (rasterizer.rasterize_leaves): exp / normalize / sigmoid of
+    scene/gaussian_model.py:113-160 evaluated in the first kernel instead of three torch launches.  Against the reference-shaped path
+    (torch activations, world-space rasterizer): the kernel's exp is its own fmaf polynomial (~1 ulp from torch's), so values agree to
+    rounding -- image within 2e-6, a handful of radii may differ by one where a 3-sigma extent sits on an integer, gradients within
+    5e-5 of each tensor's max."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gaussianavatars_amd import rasterizer as R
+
+    dev = torch.device("cuda:0")
+    g, cam = _scene(dev)
+    out = {}
+    for fast in (True, False):
+        g.bound_render = fast
+        out[fast] = _step(g, cam, _Pipe, dev)
+        assert bool(R.last_forward_info().get("bound", False)) == fast
+    (img_a, rad_a, gr_a, vs_a), (img_b, rad_b, gr_b, vs_b) = out[True], out[False]
+    assert float((img_a - img_b).abs().max()) < 2e-6
+    assert int((rad_a != rad_b).sum()) <= 3 and int((rad_a - rad_b).abs().max()) <= 1
+    for name, x, y in zip(("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"), gr_a, gr_b):
+        err = float((x - y).abs().max()) / (float(y.abs().max()) + 1e-30)
+        assert err < 5e-5, f"d{name}: rel err {err:.3e}"
+    assert float((vs_a - vs_b).abs().max()) / float(vs_b.abs().max()) < 5e-5
