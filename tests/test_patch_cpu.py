@@ -75,6 +75,78 @@ def test_patch_reference_rebinds_the_reference_classes_and_dispatches_to_the_fus
 
 
 @needs_ref
+def test_the_references_own_render_drives_the_drop_in_rasterizer_package():
+    """/root/reference/gaussian_renderer/__init__.py:19-101, unmodified, against the top-level
+    `diff_gaussian_rasterization` package of this repository.  No GPU here, so `.cuda()` / device="cuda" are neutralised and the
+    native call is replaced by a recorder at the autograd-Function boundary: the test checks everything on the way there -- the
+    12-field settings tuple built by keyword, the keyword call of GaussianRasterizer.forward, both Exceptions of the argument
+    contract, the (image, radii) pair coming back and `radii > 0` -- and that without the recorder the same call ends in the
+    rasterizer's "no CPU path" error (i.e. it really is the HIP entry that is reached)."""
+    out = _run("""
+        import math, types, torch
+        from unittest import mock
+        from gaussianavatars_amd import shims
+        shims.install(stub_torchvision=True)
+        import gaussian_renderer as gr                      # the reference's module, importing OUR diff_gaussian_rasterization
+        import diff_gaussian_rasterization as dgr, gaussianavatars_amd.rasterizer as R
+        assert gr.GaussianRasterizer is R.GaussianRasterizer and gr.render.__module__ == "gaussian_renderer"
+        from gaussianavatars_amd import synthetic as S
+        from scene.gaussian_model import GaussianModel
+        sp = S.random_splats(500, 3, 3)
+        pc = GaussianModel(3)
+        pc._xyz, pc._scaling, pc._rotation = torch.tensor(sp["means3D"]), torch.tensor(sp["scales"]).log(), torch.tensor(sp["rotations"])
+        pc._opacity = torch.logit(torch.tensor(sp["opacities"]).clamp(1e-4, 1 - 1e-4))
+        pc._features_dc, pc._features_rest = torch.tensor(sp["shs"][:, :1]), torch.tensor(sp["shs"][:, 1:])
+        pc.active_sh_degree = 3
+        cam = S.orbit_camera(64, 48)
+        for k in ("world_view_transform", "full_proj_transform", "camera_center"):
+            setattr(cam, k, torch.as_tensor(getattr(cam, k)))
+        pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+        seen = {}
+        def recorder(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, sh_rest=None):
+            seen.update(means3D=means3D, means2D=means2D, sh=sh, colors=colors_precomp, opacities=opacities, scales=scales, rotations=rotations,
+                        cov=cov3Ds_precomp, rs=rs)
+            P = means3D.shape[0]
+            radii = torch.arange(P, dtype=torch.int32) % 3
+            return torch.zeros(3, rs.image_height, rs.image_width), radii, radii > 0
+        zl = torch.zeros_like
+        with mock.patch.object(torch.Tensor, "cuda", lambda self, *a, **k: self), \
+             mock.patch("torch.zeros_like", lambda t, **k: zl(t, **{kk: v for kk, v in k.items() if kk != "device"})):
+            with mock.patch.object(R._RasterizeGaussians, "apply", staticmethod(recorder)):
+                pkg = gr.render(cam, pc, pipe, torch.ones(3))
+            rs = seen["rs"]
+            assert rs._fields == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+                                  "sh_degree", "campos", "prefiltered", "debug")
+            assert (rs.image_height, rs.image_width, rs.sh_degree, rs.scale_modifier) == (cam.image_height, cam.image_width, 3, 1.0)
+            assert abs(rs.tanfovx - math.tan(cam.FoVx * 0.5)) < 1e-12
+            assert seen["means3D"] is pc._xyz and tuple(seen["sh"].shape) == (500, 16, 3) and seen["colors"].numel() == 0 and seen["cov"].numel() == 0
+            assert tuple(seen["scales"].shape) == (500, 3) and tuple(seen["rotations"].shape) == (500, 4) and tuple(seen["opacities"].shape) == (500, 1)
+            assert seen["means2D"].requires_grad and tuple(seen["means2D"].shape) == (500, 3)
+            assert set(pkg) == {"render", "viewspace_points", "visibility_filter", "radii"} and pkg["visibility_filter"].dtype == torch.bool
+            assert tuple(pkg["render"].shape) == (3, cam.image_height, cam.image_width)
+            # without the recorder: the native entry is reached and refuses host tensors
+            try:
+                gr.render(cam, pc, pipe, torch.ones(3))
+            except RuntimeError as e:
+                assert "no CPU path" in str(e), e
+            else:
+                raise AssertionError("the rasterizer accepted host tensors")
+            # the argument contract's two Exceptions (rasterizer __init__.py of the upstream package), through the reference's call
+            rast = dgr.GaussianRasterizer(raster_settings=rs)
+            for kw, msg in ((dict(shs=None, colors_precomp=None, scales=seen["scales"], rotations=seen["rotations"]), "SHs or precomputed colors"),
+                            (dict(shs=seen["sh"], scales=None, rotations=None, cov3D_precomp=None), "scale/rotation pair or precomputed 3D covariance")):
+                try:
+                    rast(means3D=pc._xyz, means2D=seen["means2D"], opacities=seen["opacities"], **kw)
+                except Exception as e:
+                    assert msg in str(e), e
+                else:
+                    raise AssertionError("no exception")
+        print("OK")
+    """)
+    assert out.strip().endswith("OK")
+
+
+@needs_ref
 def test_entry_scripts_import_closure_is_complete():
     """Every module-level import of the reference's entry scripts resolves once the shims are installed."""
     out = _run("""
