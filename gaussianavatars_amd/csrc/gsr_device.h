@@ -30,12 +30,8 @@
 #define GSR_RANK_BIG_WORDS 32768   // k_tile_rank_big: bitmap words per pass (1 M ranks, 128 KB of LDS)
 #define GSR_RANK_BIG_THREADS 1024
 #define GSR_RANK_IDX_BITS 28      // a tile-list entry of the rank path is (rank, splat | quadrant mask << 28)
-#define GSR_RANK_MAX_SPLATS 262144 // splat count up to which the rank path is taken (8192 bitmap words per tile, one pass)
-#ifdef GSR_RANK_TILE_THREADS_EXP
-#define GSR_RANK_TILE_THREADS GSR_RANK_TILE_THREADS_EXP
-#else
-#define GSR_RANK_TILE_THREADS 512 // threads of a k_tile_rank workgroup (a tile)
-#endif
+#define GSR_RANK_MAX_SPLATS 262144 // splat count up to which one tile bitmap holds every rank of the frame (8192 words: k_tile_rank); beyond: k_tile_rank_big
+#define GSR_RANK_TILE_THREADS 512 // threads of a k_tile_rank workgroup (a tile); swept 256 / 512 / 1024: 29 / 21 / 31 us at cfg3
 #define GSR_RANK_WINDOW 4096     // k_tile_rank: entries of the sorted list per epilogue round (16 per thread)
 #define GSR_RANK_GROUP 16         // lanes that expand one splat's tile rect together in k_rcount / k_rscatter (4 splats per wave at a time)
 #define GSR_RANK_BIN_THREADS 1024 // threads per workgroup of k_rcount / k_rdscatter / k_rscatter (<= GSR_BIN_BLOCKS workgroups: 16 waves each keep the SIMDs busy)
