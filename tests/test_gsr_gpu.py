@@ -7,6 +7,8 @@ n_contrib, clamp flags) BIT-EXACT; forward floats bit-exact too (the forward TUs
 tolerance of 0 documented here; backward gradients within rel 2e-4 of the oracle (float atomics
 reorder the sums) measured against the per-tensor max magnitude.
 """
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -432,3 +434,46 @@ def test_deterministic_backward_is_bit_reproducible(oracle, name):
     for k in a:
         if a[k] is not None:
             assert torch.equal(a[k], b[k]), f"{name}/{k}: two deterministic backward passes differ"
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_rank_path_equals_the_per_tile_sort_on_random_scenes(seed):
+    """The rank path (tile lists ordered through bitmaps of global depth ranks, csrc/gsr_rank.hip) against round 1's per-tile bitonic
+    sort on scenes drawn at random: odd image sizes, splat counts around the wave / workgroup / chunk boundaries, tiny to
+    screen-filling splats, everything behind the camera.  Same quadrant streams entry for entry, same image / final_T / radii /
+    n_contrib bits, same instance counts."""
+    from gaussianavatars_amd import debug as D
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd import synthetic as S
+    from gaussianavatars_amd.rasterizer import GaussianRasterizationSettings
+
+    dev = _dev()
+    rng = np.random.default_rng(1000 + seed)
+    P = int(rng.choice([1, 2, 63, 64, 65, 255, 257, 1023, 4097, 20011]))
+    W, H = int(rng.integers(17, 400)), int(rng.integers(17, 300))
+    deg = int(rng.integers(0, 4))
+    sp = S.random_splats(P, deg, 500 + seed, xyz_sigma=float(rng.choice([0.01, 0.05, 0.3])),
+                         log_scale_mean=math.log(float(rng.choice([0.0005, 0.004, 0.03, 0.2]))), log_scale_sigma=float(rng.choice([0.1, 0.6, 1.2])))
+    if seed == 7:
+        sp["means3D"][:, 2] += 5.0      # everything behind the near plane
+    cam = S.orbit_camera(W, H, yaw_deg=float(rng.uniform(-40, 40)), pitch_deg=float(rng.uniform(-20, 20)))
+    a = settings_args(cam, [0.2, 0.5, 0.1], deg, 1.0)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    rs = GaussianRasterizationSettings(a["H"], a["W"], a["tanfovx"], a["tanfovy"], t(a["bg"]), 1.0, t(a["viewmatrix"]), t(a["projmatrix"]), deg,
+                                       t(a["campos"]), False, False)
+    args = (t(sp["means3D"]), t(sp["shs"]), None, t(sp["opacities"]), t(sp["scales"]), t(sp["rotations"]), None)
+    out = {}
+    for mode in (3, 5):
+        prev = R.set_tile_culling(mode)
+        try:
+            out[mode] = D._forward_state(rs, *args)
+        finally:
+            R.set_tile_culling(prev)
+    new, old = out[3], out[5]
+    assert new["binning_path"] == 0 and old["binning_path"] == 2
+    assert new["num_rendered"] == old["num_rendered"] and new["rect_instances"] == old["rect_instances"]
+    for k in ("color", "final_T"):
+        assert np.array_equal(_np(new[k]).view(np.uint32), _np(old[k]).view(np.uint32)), k
+    for k in ("radii", "n_contrib", "n_contrib_q", "tiles_touched"):
+        np.testing.assert_array_equal(_np(new[k]), _np(old[k]), err_msg=k)
+    _same_streams(new, old, packed=False)
