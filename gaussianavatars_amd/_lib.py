@@ -52,7 +52,7 @@ _ONE_DEVICE = None   # a process that sees one GPU never switches devices
 GSR_LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr_hip.so")
 
 GSR_OK = 0
-GSR_ABI_VERSION = 6
+GSR_ABI_VERSION = 7
 GSR_E_CAPACITY = 1
 
 
@@ -86,7 +86,7 @@ class GsrGeomLayout(C.Structure):
 class GsrBinningLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
                 ("keys", "point_list", "qlist", "qpos", "qcount", "qstart", "ranges", "tile_count", "tile_start", "tile_cursor", "tile_order",
-                 "block_hist", "dkeys", "dtmp", "order", "bcount", "bstart", "bcursor", "border", "bhist", "qhist", "qprefix", "qmask", "ranks", "rank", "srect", "sspan", "pstat", "tdesc", "path", "chunks", "nb",
+                 "block_hist", "dkeys", "dtmp", "order", "bcount", "bstart", "bcursor", "border", "bhist", "qhist", "qprefix", "qmask", "ranks", "rank", "rank_over", "srect", "sspan", "pstat", "tdesc", "obs", "bandcnt", "path", "chunks", "nb", "nbands", "band_rows",
                  "total")]
 
 

@@ -229,7 +229,14 @@ int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, int32_t 
     o->qprefix = off;     off = align_up(off + (prod ? chunks * Q * 4 : 0), A);
     o->qmask = off;       off = align_up(off + (prod ? n * GSR_WALK_MASKS * 8 : 0), A);
     o->ranks = off;       off = align_up(off + (rankp ? cap * 8 : 0), A);
-    o->rank = off;        off = align_up(off + (rankp ? n * 4 : 0), A);
+    int band_rows = 1;
+    const size_t nbands = rankp ? (size_t)gsr::rank_bands((long long)P, (int)(tiles / (size_t)lgx), tile_culling == 6, &band_rows) : 1;
+    const size_t nwc = (n + GSR_RANK_BAND_CHUNK - 1) / GSR_RANK_BAND_CHUNK;
+    const bool bands = rankp && nbands > 1;
+    o->rank = off;        off = align_up(off + (rankp ? n * (bands ? 16 : 4) : 0), A);
+    o->rank_over = off;   off = align_up(off + (bands ? n * nbands * 4 : 0), A);
+    o->obs = off;         off = align_up(off + (bands ? n * 8 : 0), A);
+    o->bandcnt = off;     off = align_up(off + (bands ? nbands * nwc * 4 : 0), A);
     o->srect = off;       off = align_up(off + (rankp ? n * 8 : 0), A);
     o->sspan = off;       off = align_up(off + (rankp ? n * 32 : 0), A);
     o->pstat = off;       off = align_up(off + (rankp ? ((n + 255) / 256) * 8 : 0), A);
@@ -237,6 +244,8 @@ int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, int32_t 
     o->path = (size_t)path;
     o->chunks = chunks;
     o->nb = nb;
+    o->nbands = nbands;
+    o->band_rows = (size_t)band_rows;
     o->total = off + A;
     return 0;
 }
@@ -453,6 +462,15 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         unsigned long long* dtmp = (unsigned long long*)(b + bl.dtmp);
         uint32_t* rank = (uint32_t*)(b + bl.rank);
         uint2* ranks = (uint2*)(b + bl.ranks);
+        const int nbands = (int)bl.nbands;
+        const float inv_band_rows = 1.0f / (float)bl.band_rows;
+        uint2* obs = nbands > 1 ? (uint2*)(b + bl.obs) : nullptr;
+        uint32_t* bandcnt = (uint32_t*)(b + bl.bandcnt);
+        const uint32_t nwc = (uint32_t)(((size_t)P + GSR_RANK_BAND_CHUNK - 1) / GSR_RANK_BAND_CHUNK);
+        gsr::BandTables bt;
+        bt.nbands = (uint32_t)nbands;
+        bt.inv_band_rows = inv_band_rows;
+        bt.over = (const uint32_t*)(b + bl.rank_over);
         ushort4* srect = (ushort4*)(b + bl.srect);
         uint32_t* tile_start = (uint32_t*)(b + bl.tile_start);
         uint32_t* tile_cursor = (uint32_t*)(b + bl.tile_cursor);
@@ -471,35 +489,38 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
                                    (const float*)pa.depths, hdr, (const uint32_t*)bcount, bstart, bcursor, dkeys, (const uint32_t*)bhist);
             // workgroup 0 scans the tile counters and posts the instance count; launched even when P == 0
             hipLaunchKernelGGL(gsr::k_rdsort, dim3(1 + (pblocks > 0 ? nb : 0u)), dim3(256), 0, stream, (const uint32_t*)bcount,
-                               (const uint32_t*)bstart, dkeys, dtmp, rank, tiles, (const uint32_t*)tile_count, tile_start, tile_cursor,
+                               (const uint32_t*)bstart, dkeys, dtmp, rank, obs, (const ushort4*)srect, (int)bl.band_rows, tiles,
+                               (const uint32_t*)tile_count, tile_start, tile_cursor,
                                ranges, tile_order, (uint4*)(b + bl.tdesc), total_dev, slot_dev, seq);
             KERNEL_CHECK("k_rdsort", stream, dbg);
+            if (nbands > 1 && pblocks > 0) {
+                // large frames: a rank per (splat, band of tile rows) -- see gsr_rank.hip
+                const uint32_t wgs = (nwc + 3u) / 4u;
+                hipLaunchKernelGGL(gsr::k_band_count, dim3(wgs), dim3(256), 0, stream, (const gsr::BinHeader*)hdr, (const uint2*)obs,
+                                   (uint32_t)nbands, nwc, bandcnt);
+                hipLaunchKernelGGL(gsr::k_band_scan, dim3(nbands), dim3(1024), 0, stream, hdr, nwc, bandcnt);
+                hipLaunchKernelGGL(gsr::k_band_rank, dim3(wgs), dim3(256), 0, stream, (const gsr::BinHeader*)hdr, (const uint2*)obs,
+                                   (uint32_t)nbands, nwc, (const uint32_t*)bandcnt, (uint4*)rank, (uint32_t*)(b + bl.rank_over));
+                KERNEL_CHECK("k_band_rank", stream, dbg);
+            }
         }
         if (pblocks > 0) {
             TIMED(GSR_K_SCATTER, stream);
-            hipLaunchKernelGGL(gsr::k_rscatter, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), hist_bytes, stream, P, gx, tiles, (const ushort4*)srect,
-                               (const uint32_t*)rank, (const float4*)pa.sspan, (const uint32_t*)tile_start, tile_cursor, ranks, cap,
+            hipLaunchKernelGGL(gsr::k_rscatter, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), hist_bytes, stream, P, gx, tiles, bt,
+                               (const ushort4*)srect, (const uint32_t*)rank, (const float4*)pa.sspan, (const uint32_t*)tile_start, tile_cursor, ranks, cap,
                                (const unsigned long long*)total_dev, (const uint32_t*)block_hist);
             KERNEL_CHECK("k_rscatter", stream, dbg);
         }
         {
             TIMED(GSR_K_TILE_SORT, stream);
-            if (P <= GSR_RANK_MAX_SPLATS) {
-                // the bitmap holds every rank of the frame in one pass (P bounds the ranked splats)
-                const uint32_t words = (uint32_t)(((size_t)P + 2047) / 2048) * 64u;
-                hipLaunchKernelGGL(gsr::k_tile_rank, dim3(tiles), dim3(GSR_RANK_TILE_THREADS), (size_t)words * 6, stream, words, (const uint4*)(b + bl.tdesc), (const uint2*)ranks, (const float*)pa.depths,
-                                   (const gsr::BinHeader*)hdr, write_lists ? (unsigned long long*)(b + bl.keys) : nullptr,
-                                   (uint32_t*)(b + bl.point_list), write_lists ? qlist : nullptr, qpos, qcount, qstart,
-                                   cap, (const unsigned long long*)total_dev);
-            } else {
-                // larger frames: 1 M ranks per pass through a 128 KB bitmap
-                const size_t big_lds = ((size_t)GSR_RANK_BIG_WORDS + GSR_RANK_BIG_WORDS / 8) * 4;
-                HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_tile_rank_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
-                hipLaunchKernelGGL(gsr::k_tile_rank_big, dim3(tiles), dim3(GSR_RANK_BIG_THREADS), big_lds, stream, (const uint4*)(b + bl.tdesc),
-                                   (const uint2*)ranks, (const float*)pa.depths, (const gsr::BinHeader*)hdr,
-                                   write_lists ? (unsigned long long*)(b + bl.keys) : nullptr, (uint32_t*)(b + bl.point_list),
-                                   write_lists ? qlist : nullptr, qpos, qcount, qstart, cap, (const unsigned long long*)total_dev);
-            }
+            // the bitmap holds a rank space (the frame's, or a band's) in one pass unless it exceeds GSR_RANK_MAX_SPLATS splats (then: several)
+            const size_t space = (size_t)P < (size_t)GSR_RANK_MAX_SPLATS ? (size_t)P : (size_t)GSR_RANK_MAX_SPLATS;
+            const uint32_t words = (uint32_t)((space + 2047) / 2048) * 64u;
+            hipLaunchKernelGGL(gsr::k_tile_rank, dim3(tiles), dim3(GSR_RANK_TILE_THREADS), (size_t)words * 6, stream, words, gx, nbands,
+                               inv_band_rows, (const uint4*)(b + bl.tdesc), (const uint2*)ranks, (const float*)pa.depths,
+                               (const gsr::BinHeader*)hdr, write_lists ? (unsigned long long*)(b + bl.keys) : nullptr,
+                               (uint32_t*)(b + bl.point_list), write_lists ? qlist : nullptr, qpos, qcount, qstart,
+                               cap, (const unsigned long long*)total_dev);
             KERNEL_CHECK("k_tile_rank", stream, dbg);
         }
     } else {

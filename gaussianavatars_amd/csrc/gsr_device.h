@@ -27,10 +27,11 @@
 #define GSR_LDS_HIST_TILES 40960 // 160 KB of LDS / 4 B: the largest tile grid k_count / k_scatter privatise
 #define GSR_RANK_MAX_BUCKETS 4096 // depth buckets of the rank path (16 KB of LDS beside the tile histogram)
 #define GSR_RANK_HIST_TILES (GSR_LDS_HIST_TILES - GSR_RANK_MAX_BUCKETS)   // the largest grid of tile CORNERS, (gx+1)(gy+1), k_rcount / k_rscatter privatise
-#define GSR_RANK_BIG_WORDS 32768   // k_tile_rank_big: bitmap words per pass (1 M ranks, 128 KB of LDS)
-#define GSR_RANK_BIG_THREADS 1024
+#define GSR_RANK_BANDS 24          // frames beyond GSR_RANK_MAX_SPLATS: horizontal bands of tile rows with a depth rank of their own (<= this many)
+#define GSR_RANK_MAX_BANDS 32      // slots of BinHeader::band_total
+#define GSR_RANK_BAND_CHUNK 256    // consecutive depth ranks one wave of k_band_count / k_band_rank walks
 #define GSR_RANK_IDX_BITS 28      // a tile-list entry of the rank path is (rank, splat | quadrant mask << 28)
-#define GSR_RANK_MAX_SPLATS 262144 // splat count up to which one tile bitmap holds every rank of the frame (8192 words: k_tile_rank); beyond: k_tile_rank_big
+#define GSR_RANK_MAX_SPLATS 262144 // ranks one tile bitmap holds (8192 words of LDS: k_tile_rank); frames with more splats rank them per band of tile rows
 #define GSR_RANK_TILE_THREADS 512 // threads of a k_tile_rank workgroup (a tile); swept 256 / 512 / 1024: 29 / 21 / 31 us at cfg3
 #define GSR_RANK_WINDOW 4096     // k_tile_rank: entries of the sorted list per epilogue round (16 per thread)
 #define GSR_RANK_GROUP 16         // lanes that expand one splat's tile rect together in k_rcount / k_rscatter (4 splats per wave at a time)
@@ -423,7 +424,8 @@ struct BinHeader {              // first bytes of the binning buffer (include/gs
     uint32_t dmax_bits;             // production: bits of the largest binned depth
     uint32_t dmin_bits;             // = ~dmin_inv
     unsigned long long binned_tiles;// production: tile instances after snug-rect culling (what the per-tile sort path would bin)
-    uint32_t pad[54];
+    uint32_t band_total[GSR_RANK_MAX_BANDS];   // rank path with bands: binned splats whose rect touches band b (= the band's rank space)
+    uint32_t pad[22];
     BinStatSlot slot[GSR_STAT_SLOTS];
 };
 static_assert(sizeof(BinHeader) == 256 + 64 * GSR_STAT_SLOTS, "header layout is part of include/gsr.h");
@@ -576,18 +578,31 @@ __global__ void k_rcount(int P, int gx, int tiles, int pblocks, uint32_t nb, con
                          uint32_t* bcount, uint32_t* bhist, BinHeader* hdr);
 __global__ void k_rdscatter(int P, uint32_t nb, const ushort4* srect, const float* depths, BinHeader* hdr, const uint32_t* bcount, uint32_t* bstart,
                             uint32_t* bcursor, unsigned long long* dkeys, const uint32_t* bhist);
+// bands of the rank path: 1 (the whole frame) up to GSR_RANK_MAX_SPLATS splats, else bands of *band_rows tile rows
+__host__ __device__ inline int rank_bands(long long P, int gy, bool force, int* band_rows)
+{
+    if ((P <= (long long)GSR_RANK_MAX_SPLATS && !force) || gy <= 1) { *band_rows = gy > 0 ? gy : 1; return 1; }
+    const int bt = (gy + GSR_RANK_BANDS - 1) / GSR_RANK_BANDS;
+    *band_rows = bt;
+    return (gy + bt - 1) / bt;
+}
+struct BandTables {              // rank path with bands (gsr_rank.hip)
+    uint32_t nbands;
+    float inv_band_rows;
+    const uint32_t* __restrict__ over;  // [P][nbands] ranks of a splat in the fifth band onwards of its rect (very tall rects only)
+};
+__global__ void k_band_count(const BinHeader* hdr, const uint2* obs, uint32_t nbands, uint32_t nwc, uint32_t* bandcnt);
+__global__ void k_band_scan(BinHeader* hdr, uint32_t nwc, uint32_t* bandcnt);
+__global__ void k_band_rank(const BinHeader* hdr, const uint2* obs, uint32_t nbands, uint32_t nwc, const uint32_t* bandcnt, uint4* rank4, uint32_t* over);
 __global__ void k_rdsort(const uint32_t* bcount, const uint32_t* bstart, unsigned long long* dkeys, unsigned long long* tmp,
-                         uint32_t* rank, int tiles, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, uint2* ranges,
+                         uint32_t* rank, uint2* obs, const ushort4* srect, int band_rows, int tiles, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, uint2* ranges,
                          uint32_t* tile_order, uint4* tdesc, unsigned long long* total_dev, unsigned long long* mailbox, unsigned long long seq);
-__global__ void k_rscatter(int P, int gx, int tiles, const ushort4* srect, const uint32_t* rank, const float4* sspan, const uint32_t* tile_start,
+__global__ void k_rscatter(int P, int gx, int tiles, BandTables bt, const ushort4* srect, const uint32_t* rank, const float4* sspan, const uint32_t* tile_start,
                            uint32_t* tile_cursor, uint2* ranks, unsigned long long capacity, const unsigned long long* total_dev, const uint32_t* block_hist);
-__global__ void k_tile_rank(uint32_t words, const uint4* tdesc, const uint2* ranks,
+__global__ void k_tile_rank(uint32_t words, int gx, int nbands, float inv_band_rows, const uint4* tdesc, const uint2* ranks,
                             const float* depths, const BinHeader* hdr, unsigned long long* keys, uint32_t* point_list,
                             uint32_t* qlist, uint32_t* qpos, uint32_t* qcount, uint32_t* qstart, unsigned long long capacity,
                             const unsigned long long* total_dev);
-__global__ void k_tile_rank_big(const uint4* tdesc, const uint2* ranks, const float* depths, const BinHeader* hdr, unsigned long long* keys,
-                                uint32_t* point_list, uint32_t* qlist, uint32_t* qpos, uint32_t* qcount, uint32_t* qstart,
-                                unsigned long long capacity, const unsigned long long* total_dev);
 // production binning (gsr_binning.hip)
 __global__ void k_dbucket(int P, const uint32_t* brec_rect, const float* depths, BinHeader* hdr, uint32_t nb, uint32_t* bcount, uint32_t* bhist);
 __global__ void k_dscan(uint32_t nb, const uint32_t* bcount, uint32_t* bstart, uint32_t* bcursor, uint32_t* border, BinHeader* hdr);

@@ -10,6 +10,7 @@
 //   k_rdscatter per chunk  : bucket offsets (every workgroup scans the nb counters itself), (depth bits << 32 | splat) into buckets
 //   k_rdsort    per bucket : register bitonic sort (gsr_sort.h) -> rank[splat];
 //               + 1 WG     : exclusive scan of the tile counters, heavy-first tile order, instance count posted to the host
+//   (k_band_*   frames beyond GSR_RANK_MAX_SPLATS splats only: the rank of a splat inside every band of tile rows it touches)
 //   k_rscatter  per chunk  : (rank[splat], splat) into every tile segment the splat's snug rect covers (8 bytes per instance)
 //   k_tile_rank per tile   : bitmap of the tile's ranks in LDS (ds_or), word popcounts scanned; an entry's position in the sorted
 //                            list is the number of set bits below its own; then the four 8x8-quadrant streams exactly as round
@@ -323,7 +324,8 @@ __device__ __forceinline__ void tile_scan_256(int tiles, const uint32_t* __restr
 
 __global__ __launch_bounds__(256) void k_rdsort(const uint32_t* __restrict__ bcount, const uint32_t* __restrict__ bstart,
                                                  unsigned long long* __restrict__ dkeys, unsigned long long* __restrict__ tmp,
-                                                 uint32_t* __restrict__ rank, int tiles,
+                                                 uint32_t* __restrict__ rank, uint2* __restrict__ obs,
+                                                 const ushort4* __restrict__ srect, int band_rows, int tiles,
                                                  const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
                                                  uint32_t* __restrict__ tile_cursor, uint2* __restrict__ ranges,
                                                  uint32_t* __restrict__ tile_order, uint4* __restrict__ tdesc,
@@ -341,22 +343,121 @@ __global__ __launch_bounds__(256) void k_rdsort(const uint32_t* __restrict__ bco
     const uint32_t start = bstart[b];
     const int tid = threadIdx.x;
     unsigned long long* seg = dkeys + start;
+    // one band: rank[splat]; bands: (splat, first band | last band << 8) by rank, for k_band_count / k_band_rank
+    auto put = [&](uint32_t splat, uint32_t r) {
+        if (obs) {
+            const ushort4 q = srect[splat];
+            obs[r] = make_uint2(splat, (uint32_t)q.y / (uint32_t)band_rows | ((uint32_t)(q.w - 1) / (uint32_t)band_rows) << 8);
+        } else {
+            rank[splat] = r;
+        }
+    };
     if (n <= (uint32_t)KEYS) {
         u64 key[EPT];
         block_sort_regs<THREADS, EPT>(key, skeys, seg, n, tid);
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
             const uint32_t i = (uint32_t)tid * (uint32_t)EPT + (uint32_t)k;
-            if (i < n) {
-                rank[(uint32_t)key[k]] = start + i;
-            }
+            if (i < n) put((uint32_t)key[k], start + i);
         }
     } else {
         oversize_sort<THREADS, EPT>(seg, tmp + start, skeys, n, tid);
         __syncthreads();
-        for (uint32_t i = tid; i < n; i += THREADS) {
-            rank[(uint32_t)seg[i]] = start + i;
+        for (uint32_t i = tid; i < n; i += THREADS) put((uint32_t)seg[i], start + i);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Bands (frames beyond GSR_RANK_MAX_SPLATS splats).  A tile only needs the ORDER of its own instances, and a tile bitmap over
+// the whole frame's ranks is almost empty there (2 M ranks, ~2500 instances).  So the tile rows are cut into <= GSR_RANK_BANDS
+// bands and a splat gets, for every band its rect touches, its rank among the splats of THAT band: the walk below goes over the
+// splats in global depth order (k_rdsort's obs[]), a wave per GSR_RANK_BAND_CHUNK consecutive ranks, one ballot per band.
+//   k_band_count: members of every band per chunk;  k_band_scan: exclusive prefix along the chunks, the band totals;
+//   k_band_rank : the same walk again, rank of the splat in band b = chunk base + members before the lane: the first four bands
+//                 of a rect go to rank4[splat] (what k_rscatter reads, coalesced), further ones (very tall rects) to over[splat][b].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_band_count(const BinHeader* __restrict__ hdr, const uint2* __restrict__ obs, uint32_t nbands,
+                                                     uint32_t nwc, uint32_t* __restrict__ bandcnt)
+{
+    const uint32_t nvis = hdr->nvis;
+    const int lane = lane_id();
+    const uint32_t wc = blockIdx.x * 4u + (threadIdx.x >> 6), r0 = wc * (uint32_t)GSR_RANK_BAND_CHUNK;
+    if (r0 >= nvis) return;
+    uint32_t cnt = 0;   // lane b: members of band b
+#pragma unroll
+    for (int k = 0; k < GSR_RANK_BAND_CHUNK / 64; ++k) {
+        const uint32_t r = r0 + (uint32_t)(k * 64 + lane);
+        const bool valid = r < nvis;
+        const uint32_t bb = valid ? obs[r].y : 0u, b0 = bb & 255u, b1 = bb >> 8;
+        for (uint32_t b = 0; b < nbands; ++b) {
+            const uint64_t m = __ballot(valid && b0 <= b && b <= b1);
+            if ((uint32_t)lane == b) cnt += (uint32_t)__builtin_popcountll(m);
         }
+    }
+    if ((uint32_t)lane < nbands) bandcnt[(size_t)lane * nwc + wc] = cnt;
+}
+
+__global__ __launch_bounds__(1024) void k_band_scan(BinHeader* __restrict__ hdr, uint32_t nwc, uint32_t* __restrict__ bandcnt)
+{
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t n = (hdr->nvis + (uint32_t)GSR_RANK_BAND_CHUNK - 1u) / (uint32_t)GSR_RANK_BAND_CHUNK;   // chunks the count pass filled
+    uint32_t* const c = bandcnt + (size_t)blockIdx.x * nwc;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0u;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 4096u) {
+        const uint32_t i0 = base + 4u * (uint32_t)tid;
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = i0 + k < n ? c[i0 + k] : 0u; sum += v[k]; }
+        const uint32_t incl = wave_scan_incl_u32(sum);
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        uint32_t off = carry_s + incl - sum, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const uint32_t t = wave_tot[w]; if (w < wid) off += t; all += t; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (i0 + k < n) c[i0 + k] = off; off += v[k]; }
+        __syncthreads();
+        if (tid == 0) carry_s += all;
+        __syncthreads();
+    }
+    if (tid == 0) hdr->band_total[blockIdx.x] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void k_band_rank(const BinHeader* __restrict__ hdr, const uint2* __restrict__ obs, uint32_t nbands,
+                                                    uint32_t nwc, const uint32_t* __restrict__ bandcnt, uint4* __restrict__ rank4,
+                                                    uint32_t* __restrict__ over)
+{
+    const uint32_t nvis = hdr->nvis;
+    const int lane = lane_id();
+    const uint32_t wc = blockIdx.x * 4u + (threadIdx.x >> 6), r0 = wc * (uint32_t)GSR_RANK_BAND_CHUNK;
+    if (r0 >= nvis) return;
+    uint32_t run = (uint32_t)lane < nbands ? bandcnt[(size_t)lane * nwc + wc] : 0u;   // lane b: the next rank of band b
+#pragma unroll
+    for (int k = 0; k < GSR_RANK_BAND_CHUNK / 64; ++k) {
+        const uint32_t r = r0 + (uint32_t)(k * 64 + lane);
+        const bool valid = r < nvis;
+        const uint2 e = valid ? obs[r] : make_uint2(0u, 0u);
+        const uint32_t b0 = e.y & 255u, b1 = e.y >> 8;
+        uint4 four = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t b = 0; b < nbands; ++b) {
+            const bool in = valid && b0 <= b && b <= b1;
+            const uint64_t m = __ballot(in);
+            if (m == 0) continue;
+            const uint32_t mine = (uint32_t)__builtin_amdgcn_readlane((int)run, (int)b) + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            if (in) {
+                const uint32_t k = b - b0;
+                if (k == 0u) four.x = mine;
+                else if (k == 1u) four.y = mine;
+                else if (k == 2u) four.z = mine;
+                else if (k == 3u) four.w = mine;
+                else over[(size_t)e.x * nbands + b] = mine;
+            }
+            if ((uint32_t)lane == b) run += (uint32_t)__builtin_popcountll(m);
+        }
+        if (valid) rank4[e.x] = four;
     }
 }
 
@@ -366,7 +467,7 @@ __global__ __launch_bounds__(256) void k_rdsort(const uint32_t* __restrict__ bco
 // not care.  The mask says which of the tile's four 8x8 quadrants the splat's {alpha >= 1/255} ellipse can reach: evaluated
 // here from the splat's Span (k_preprocess), so that the per-tile kernel never gathers a per-splat record.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx, int tiles, const ushort4* __restrict__ srect,
+__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx, int tiles, BandTables bt, const ushort4* __restrict__ srect,
                                                                     const uint32_t* __restrict__ rank, const float4* __restrict__ sspan,
                                                                     const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
                                                                     uint2* __restrict__ ranks, unsigned long long capacity,
@@ -378,16 +479,21 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
     if (*total_dev > capacity) return;  // the host will grow the buffer and replay the frame
     const int tid = threadIdx.x;
     const bool direct = rank_direct(gx, tiles);
+    const bool bands = bt.nbands > 1;
+    const uint4* __restrict__ rank4 = reinterpret_cast<const uint4*>(rank);   // bands: the ranks inside the first four bands of the rect
     const int chunk = ((P + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
     const int begin = blockIdx.x * chunk;
     const int end = min(P, begin + chunk);
     // a splat's inputs, fetched one round ahead of their use (all four loads are independent: rank / operands of a splat that is
     // not binned are never looked at)
-    struct In { ushort4 q; uint32_t rk; float4 s0, s1; };
+    struct In { ushort4 q; uint4 rk; float4 s0, s1; };
     auto fetch = [&](int i) {
         In v;
-        v.q = make_ushort4(0, 0, 0, 0); v.rk = 0u; v.s0 = v.s1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < end) { v.q = srect[i]; v.rk = rank[i]; v.s0 = sspan[2 * (size_t)i]; v.s1 = sspan[2 * (size_t)i + 1]; }
+        v.q = make_ushort4(0, 0, 0, 0); v.rk = make_uint4(0u, 0u, 0u, 0u); v.s0 = v.s1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < end) {
+            v.q = srect[i]; v.s0 = sspan[2 * (size_t)i]; v.s1 = sspan[2 * (size_t)i + 1];
+            if (bands) v.rk = rank4[i]; else v.rk.x = rank[i];
+        }
         return v;
     };
     In nxt = fetch(begin + tid / G);
@@ -401,22 +507,33 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
         const In cur = nxt;
         nxt = fetch(i + NT / G);
         const int minx = cur.q.x, miny = cur.q.y, maxx = cur.q.z, maxy = cur.q.w;
-        const uint32_t n = (uint32_t)((maxx - minx) * (maxy - miny)), rk = cur.rk;
+        const uint32_t n = (uint32_t)((maxx - minx) * (maxy - miny));
+        const uint4 rk = cur.rk;
+        // bands: y / band_rows = floor((y + 0.5) * (1 / band_rows)), exact at these sizes
+        const uint32_t fb = bands ? (uint32_t)(((float)miny + 0.5f) * bt.inv_band_rows) : 0u;
         Span sp;
         sp.px = cur.s0.x; sp.py = cur.s0.y; sp.B = cur.s0.z; sp.det = cur.s0.w;
         sp.twoTA = cur.s1.x; sp.A = cur.s1.y; sp.dyr = cur.s1.z; sp.mode = __float_as_int(cur.s1.w);
         for_each_tile_grouped(minx, miny, maxx, maxy, n, [&](uint32_t x, uint32_t y, int src) {
             const int me = lane_id();
             Span b = sp;
-            uint32_t brk = rk, bidx = (uint32_t)i;
+            uint4 brk4 = rk;
+            uint32_t bfb = fb, bidx = (uint32_t)i;
             if (src != me) {   // whole-wave expansion of a large rect: the owner's operands (src is wave-uniform there)
                 auto bf = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+                auto bu = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
                 b.px = bf(sp.px); b.py = bf(sp.py); b.B = bf(sp.B); b.det = bf(sp.det); b.twoTA = bf(sp.twoTA); b.A = bf(sp.A); b.dyr = bf(sp.dyr);
                 b.mode = __builtin_amdgcn_readlane(sp.mode, src);
-                brk = (uint32_t)__builtin_amdgcn_readlane((int)rk, src);
+                brk4 = make_uint4(bu(rk.x), bu(rk.y), bu(rk.z), bu(rk.w)); bfb = bu(fb);
                 bidx = (uint32_t)__builtin_amdgcn_readlane(i, src);
             }
             const uint32_t tile = y * (uint32_t)gx + x;
+            uint32_t brk = brk4.x;
+            if (bands) {   // the splat's rank inside the tile's band
+                const uint32_t band = (uint32_t)(((float)y + 0.5f) * bt.inv_band_rows), k = band - bfb;
+                brk = k == 0u ? brk4.x : k == 1u ? brk4.y : k == 2u ? brk4.z : brk4.w;
+                if (k > 3u) brk = bt.over[(size_t)bidx * bt.nbands + band];   // fifth band onwards of a very tall rect
+            }
             const uint32_t m = quadrant_mask_of(b, (float)(x * GSR_BLOCK_X), (float)(y * GSR_BLOCK_Y));
             // tile grids beyond the LDS histogram: one returning L2 atomic per instance
             const uint32_t slot = direct ? tile_start[tile] + atomicAdd(&tile_cursor[tile], 1u) : atomicAdd(&hist[tile], 1u);
@@ -530,7 +647,8 @@ __device__ __forceinline__ void tile_streams(uint32_t total, uint32_t n, uint32_
 //      ballots + one scan of the (chunk, wave) counters; the parity modes also write the reference-format key list
 // No comparison, no data-dependent loop, every step entry-parallel.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GSR_RANK_TILE_THREADS) void k_tile_rank(uint32_t words, const uint4* __restrict__ tdesc, const uint2* __restrict__ ranks,
+__global__ __launch_bounds__(GSR_RANK_TILE_THREADS) void k_tile_rank(uint32_t words, int gx, int nbands, float inv_band_rows,
+                                                    const uint4* __restrict__ tdesc, const uint2* __restrict__ ranks,
                                                     const float* __restrict__ depths, const BinHeader* __restrict__ hdr,
                                                     unsigned long long* __restrict__ keys, uint32_t* __restrict__ point_list,
                                                     uint32_t* __restrict__ qlist, uint32_t* __restrict__ qpos, uint32_t* __restrict__ qcount,
@@ -542,7 +660,7 @@ __global__ __launch_bounds__(GSR_RANK_TILE_THREADS) void k_tile_rank(uint32_t wo
     constexpr int UB = 8;   // entries per thread whose loads are in flight together
     static_assert(NE <= 64, "one (chunk, wave) counter per lane in the epilogue's scan");
     static_assert(EPT % 4 == 0, "the epilogue gathers four chunks at a time");
-    extern __shared__ uint32_t bitmap[];                                   // [words] (a multiple of 64: ceil(P / 2048) rows), then
+    extern __shared__ uint32_t bitmap[];                                   // [words] (a multiple of 64, at most 64 * ROWS), then
     uint16_t* const wprefix = reinterpret_cast<uint16_t*>(bitmap + words);  // [words] set bits before the word inside its row
     __shared__ uint32_t cntw[4][NE + 1];
     __shared__ uint32_t rowoff[ROWS + 1];
@@ -558,11 +676,14 @@ __global__ __launch_bounds__(GSR_RANK_TILE_THREADS) void k_tile_rank(uint32_t wo
     const uint32_t start = td.z;
     if (tid < 4) qstart[4 * tile + tid] = 4u * start + (uint32_t)tid * n;   // the tile's four n-slot streams
     const uint2* __restrict__ rk = ranks + start;
-    const bool fast = n <= (uint32_t)(UB * THREADS);   // every entry stays in a register between the two passes over them
     uint32_t* const qpbase = qpos + (size_t)4 * start;
     uint32_t* const qlbase = qlist ? qlist + (size_t)4 * start : nullptr;
-    const uint32_t Wn = min(words, (hdr->nvis + 31u) >> 5);
-    const uint32_t rows = (Wn + 63u) >> 6;
+    // the rank space of this tile's entries: the frame's binned splats, or those of the tile's band
+    const uint32_t space = nbands > 1 ? hdr->band_total[(uint32_t)(((float)(tile / (uint32_t)gx) + 0.5f) * inv_band_rows)] : hdr->nvis;
+    const uint32_t per_pass = words * 32u;
+    const bool single = space <= per_pass;   // (always, unless one band holds more than GSR_RANK_MAX_SPLATS splats)
+    const bool fast = single && n <= (uint32_t)(UB * THREADS);   // every entry stays in a register between the two passes over them
+    uint32_t* const sorted = point_list + start;   // the tile's sorted list in global memory (the reference's point_list)
 
     uint2 e0[UB];
 #pragma unroll
@@ -570,156 +691,67 @@ __global__ __launch_bounds__(GSR_RANK_TILE_THREADS) void k_tile_rank(uint32_t wo
         const uint32_t i = (uint32_t)(k * THREADS + tid);
         e0[k] = i < n ? rk[i] : make_uint2(0xFFFFFFFFu, 0u);
     }
-    for (uint32_t w = tid; w < rows * 64u; w += THREADS) bitmap[w] = 0u;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < UB; ++k)
-        if (e0[k].x < Wn * 32u) atomicOr(&bitmap[e0[k].x >> 5], 1u << (e0[k].x & 31u));
-    for (uint32_t base = UB * THREADS; base < n; base += UB * THREADS) {
-        uint32_t r[UB];
+    // one pass over the ranks [lo, lo + span): the tile's entries in there go to the list from position `placed`; returns their number
+    auto pass = [&](const uint32_t lo, const uint32_t span, const bool in_lds, const uint32_t placed) {
+        const uint32_t rows = (((span + 31u) >> 5) + 63u) >> 6;   // (0xFFFFFFFF - lo, the filler of missing entries, stays above any span)
+        for (uint32_t w = tid; w < rows * 64u; w += THREADS) bitmap[w] = 0u;
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < UB; ++k) {
-            const uint32_t i = base + (uint32_t)(k * THREADS + tid);
-            r[k] = i < n ? rk[i].x : 0xFFFFFFFFu;
+            const uint32_t r = e0[k].x - lo;
+            if (r < span) atomicOr(&bitmap[r >> 5], 1u << (r & 31u));
         }
-#pragma unroll
-        for (int k = 0; k < UB; ++k)
-            if (r[k] < Wn * 32u) atomicOr(&bitmap[r[k] >> 5], 1u << (r[k] & 31u));
-    }
-    __syncthreads();
-    for (uint32_t row = wid; row < rows; row += NW) {
-        const uint32_t w = row * 64u + (uint32_t)lane;
-        const uint32_t v = (uint32_t)__builtin_popcount(bitmap[w]);
-        const uint32_t incl = wave_scan_incl_u32(v);
-        wprefix[w] = (uint16_t)(incl - v);
-        if (lane == 63) rowoff[row] = incl;   // the row's total, scanned in place below
-    }
-    __syncthreads();
-    if (wid == 0) {   // exclusive scan of the row totals (RPL consecutive rows per lane)
-        uint32_t a[RPL], sum = 0;
-#pragma unroll
-        for (int j = 0; j < RPL; ++j) {
-            const uint32_t rr = (uint32_t)(RPL * lane + j);
-            a[j] = rr < rows ? rowoff[rr] : 0u;
-            sum += a[j];
-        }
-        const uint32_t incl = wave_scan_incl_u32(sum);
-        uint32_t acc = incl - sum;
-#pragma unroll
-        for (int j = 0; j < RPL; ++j) {
-            const uint32_t rr = (uint32_t)(RPL * lane + j);
-            if (rr < rows) rowoff[rr] = acc;
-            acc += a[j];
-        }
-        if (lane == 63) rowoff[ROWS] = incl;
-    }
-    __syncthreads();
-    const uint32_t total = rowoff[ROWS];   // == n (ranks are unique)
-
-    // ---- 3. every entry finds its position and drops its splat index there: the tile's sorted list, in global memory (the
-    //         reference's point_list; the same workgroup reads it back below, coalesced) ----
-    uint32_t* const sorted = point_list + start;
-    auto position = [&](uint32_t r) {
-        const uint32_t w = r >> 5;
-        return rowoff[w >> 6] + (uint32_t)wprefix[w] + (uint32_t)__builtin_popcount(bitmap[w] & ((1u << (r & 31u)) - 1u));
-    };
-    if (fast) {   // registers -> LDS: no second read of the entries, no global round trip for the list
-#pragma unroll
-        for (int k = 0; k < UB; ++k)
-            if (e0[k].x < Wn * 32u) lsorted[position(e0[k].x)] = e0[k].y;
-    } else {
-        for (uint32_t base = 0; base < n; base += UB * THREADS) {
-            uint2 e[UB];
-#pragma unroll
-            for (int k = 0; k < UB; ++k) {
-                const uint32_t i = base + (uint32_t)(k * THREADS + tid);
-                e[k] = i < n ? rk[i] : make_uint2(0xFFFFFFFFu, 0u);
-            }
-#pragma unroll
-            for (int k = 0; k < UB; ++k)
-                if (e[k].x < Wn * 32u) sorted[position(e[k].x)] = e[k].y;
-        }
-    }
-    __syncthreads();   // (global stores of this workgroup are visible to it after the barrier)
-    tile_streams<THREADS>(total, n, tile, start, sorted, fast ? lsorted : nullptr, cntw, depths, keys, qpbase, qlbase, qcount);
-}
-
-// ------------------------------------------------------------------------------------------
-// k_tile_rank_big: the same for frames whose ranks do not fit one tile bitmap (more than GSR_RANK_MAX_SPLATS ranked splats):
-// 1024 threads, GSR_RANK_BIG_WORDS * 32 ranks per pass (128 KB of LDS), as many passes as the frame needs.  Rows are 8 words here
-// and the offset of a word inside its row is recounted on the fly (up to 7 popcounts), so the only table beside the bitmap is one
-// offset per row (16 KB); the sorted list always goes through global memory.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GSR_RANK_BIG_THREADS) void k_tile_rank_big(const uint4* __restrict__ tdesc, const uint2* __restrict__ ranks,
-                                                                         const float* __restrict__ depths, const BinHeader* __restrict__ hdr,
-                                                                         unsigned long long* __restrict__ keys, uint32_t* __restrict__ point_list,
-                                                                         uint32_t* __restrict__ qlist, uint32_t* __restrict__ qpos,
-                                                                         uint32_t* __restrict__ qcount, uint32_t* __restrict__ qstart,
-                                                                         unsigned long long capacity, const unsigned long long* __restrict__ total_dev)
-{
-    constexpr int THREADS = GSR_RANK_BIG_THREADS, NWV = THREADS / 64, WORDS = GSR_RANK_BIG_WORDS, ROWS = WORDS / 8, RPT = ROWS / THREADS;
-    constexpr int UB = 4;
-    static_assert(ROWS % THREADS == 0, "rows split evenly over the threads");
-    extern __shared__ uint32_t bitmap[];                 // [WORDS], then [ROWS] row offsets
-    uint32_t* const rowoff = bitmap + WORDS;
-    __shared__ uint32_t cntw[4][GSR_RANK_WINDOW / 64 + 1];
-    __shared__ uint32_t wave_tot[NWV];
-    if (*total_dev > capacity) return;
-    const uint4 td = tdesc[blockIdx.x];
-    const uint32_t tile = td.x, n = td.y, start = td.z;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (n == 0) {
-        if (tid < 4) { qcount[4 * tile + tid] = 0u; qstart[4 * tile + tid] = 0u; }
-        return;
-    }
-    if (tid < 4) qstart[4 * tile + tid] = 4u * start + (uint32_t)tid * n;
-    const uint2* __restrict__ rk = ranks + start;
-    uint32_t* const sorted = point_list + start;
-    const uint32_t nvis = hdr->nvis;
-    uint32_t pass_base = 0;   // entries of the list placed by earlier passes
-    for (uint32_t pass_lo = 0; pass_lo < nvis && pass_base < n; pass_lo += (uint32_t)WORDS * 32u) {
-        const uint32_t span = min((uint32_t)WORDS * 32u, nvis - pass_lo);   // ranks of this pass
-        for (uint32_t w = tid; w < (uint32_t)WORDS; w += THREADS) bitmap[w] = 0u;
-        __syncthreads();
-        for (uint32_t base = 0; base < n; base += UB * THREADS) {
+        for (uint32_t base = UB * THREADS; base < n; base += UB * THREADS) {
             uint32_t r[UB];
 #pragma unroll
             for (int k = 0; k < UB; ++k) {
                 const uint32_t i = base + (uint32_t)(k * THREADS + tid);
-                r[k] = i < n ? rk[i].x - pass_lo : 0xFFFFFFFFu;
+                r[k] = i < n ? rk[i].x - lo : 0xFFFFFFFFu;
             }
 #pragma unroll
             for (int k = 0; k < UB; ++k)
                 if (r[k] < span) atomicOr(&bitmap[r[k] >> 5], 1u << (r[k] & 31u));
         }
         __syncthreads();
-        // row totals: a lane per word (consecutive lanes, consecutive words: no bank conflicts), the 8 words of a row summed on DPP
-        for (uint32_t w = tid; w < (uint32_t)WORDS; w += THREADS) {
-            uint32_t c = (uint32_t)__builtin_popcount(bitmap[w]);
-            c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
-            c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
-            c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x141, 0xf, 0xf, false);   // row_half_mirror: the other quad of the 8
-            if ((lane & 7) == 0) rowoff[w >> 3] = c;
+        for (uint32_t row = wid; row < rows; row += NW) {
+            const uint32_t w = row * 64u + (uint32_t)lane;
+            const uint32_t v = (uint32_t)__builtin_popcount(bitmap[w]);
+            const uint32_t incl = wave_scan_incl_u32(v);
+            wprefix[w] = (uint16_t)(incl - v);
+            if (lane == 63) rowoff[row] = incl;   // the row's total, scanned in place below
         }
         __syncthreads();
-        // exclusive scan of the ROWS totals in place: RPT consecutive rows per thread
-        uint32_t a[RPT], sum = 0;
+        if (wid == 0) {   // exclusive scan of the row totals (RPL consecutive rows per lane)
+            uint32_t a[RPL], sum = 0;
 #pragma unroll
-        for (int j = 0; j < RPT; ++j) { a[j] = rowoff[RPT * tid + j]; sum += a[j]; }
-        const uint32_t incl = wave_scan_incl_u32(sum);
-        if (lane == 63) wave_tot[wid] = incl;
-        __syncthreads();
-        uint32_t off = incl - sum, pass_total = 0;
+            for (int j = 0; j < RPL; ++j) {
+                const uint32_t rr = (uint32_t)(RPL * lane + j);
+                a[j] = rr < rows ? rowoff[rr] : 0u;
+                sum += a[j];
+            }
+            const uint32_t incl = wave_scan_incl_u32(sum);
+            uint32_t acc = incl - sum;
 #pragma unroll
-        for (int w = 0; w < NWV; ++w) {
-            const uint32_t t = wave_tot[w];
-            if (w < wid) off += t;
-            pass_total += t;
+            for (int j = 0; j < RPL; ++j) {
+                const uint32_t rr = (uint32_t)(RPL * lane + j);
+                if (rr < rows) rowoff[rr] = acc;
+                acc += a[j];
+            }
+            if (lane == 63) rowoff[ROWS] = incl;
         }
-#pragma unroll
-        for (int j = 0; j < RPT; ++j) { rowoff[RPT * tid + j] = off; off += a[j]; }
         __syncthreads();
-        if (pass_total) {
+        // every entry finds its position and drops its splat index there
+        auto position = [&](uint32_t r) {
+            const uint32_t w = r >> 5;
+            return rowoff[w >> 6] + (uint32_t)wprefix[w] + (uint32_t)__builtin_popcount(bitmap[w] & ((1u << (r & 31u)) - 1u));
+        };
+        if (in_lds) {   // registers -> LDS: no second read of the entries, no global round trip for the list
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                const uint32_t r = e0[k].x - lo;
+                if (r < span) lsorted[position(r)] = e0[k].y;
+            }
+        } else {
             for (uint32_t base = 0; base < n; base += UB * THREADS) {
                 uint2 e[UB];
 #pragma unroll
@@ -729,21 +761,25 @@ __global__ __launch_bounds__(GSR_RANK_BIG_THREADS) void k_tile_rank_big(const ui
                 }
 #pragma unroll
                 for (int k = 0; k < UB; ++k) {
-                    const uint32_t r = e[k].x - pass_lo;
-                    if (r < span) {
-                        const uint32_t w = r >> 5, w0 = w & ~7u;
-                        uint32_t pos = pass_base + rowoff[w >> 3] + (uint32_t)__builtin_popcount(bitmap[w] & ((1u << (r & 31u)) - 1u));
-                        for (uint32_t k2 = w0; k2 < w; ++k2) pos += (uint32_t)__builtin_popcount(bitmap[k2]);
-                        sorted[pos] = e[k].y;
-                    }
+                    const uint32_t r = e[k].x - lo;
+                    if (r < span) sorted[placed + position(r)] = e[k].y;
                 }
             }
         }
-        pass_base += pass_total;
-        __syncthreads();   // the bitmap is cleared by the next pass; (and: this workgroup's global stores are visible to it)
+        return rowoff[ROWS];
+    };
+    uint32_t placed = 0;
+    if (single) {
+        placed = pass(0u, space, fast, 0u);
+    } else {
+        for (uint32_t lo = 0; lo < space; lo += per_pass) {
+            placed += pass(lo, min(per_pass, space - lo), false, placed);
+            __syncthreads();   // the next pass clears the bitmap
+        }
     }
-    tile_streams<THREADS>(n, n, tile, start, sorted, nullptr, cntw, depths, keys, qpos + (size_t)4 * start,
-                          qlist ? qlist + (size_t)4 * start : nullptr, qcount);
+    __syncthreads();   // (global stores of this workgroup are visible to it after the barrier)
+    // placed == n (ranks are unique inside a rank space)
+    tile_streams<THREADS>(placed, n, tile, start, sorted, fast ? lsorted : nullptr, cntw, depths, keys, qpbase, qlbase, qcount);
 }
 
 }  // namespace gsr

@@ -79,6 +79,8 @@ def _forward_state(rs, means3D, shs, colors_precomp, opacities, scales, rotation
         clamped=_view(geom, gl.clamped, P, torch.uint8),
         production_binning=prod,
         binning_path=int(bl.path),
+        nbands=int(bl.nbands), band_rows=int(bl.band_rows),
+        band_total=_view(binning, 40, int(bl.nbands) if bl.path == 0 and bl.nbands > 1 else 0, u32),   # binned splats per band of tile rows
         keys=_view(binning, bl.keys, I if lists else 0, torch.int64),
         point_list=_view(binning, bl.point_list, I if lists else 0, u32),
         qlist=_view(binning, bl.qlist, 4 * cap if lists and not prod else 0, u32),           # parity modes: stream entries' positions in the tile list

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 6
+#define GSR_ABI_VERSION 7
 #define GSR_BWD_SEGMENT 60        /* stream entries per backward segment (a multiple of both blend kernels' batches)  */
 #define GSR_BWD_SEGMENTS 10       /* segments per quadrant stream; the last one takes whatever is left                */
 #define GSR_BIN_BLOCKS 256        /* workgroups of the two binning passes (each owns a contiguous chunk of splats) */
@@ -71,7 +71,8 @@ typedef struct GsrSettings {
                                  3: as 1 but always on the rank path (tiles ordered through bitmaps of global depth ranks: the default
                                     wherever the depth-ordered scatter does not apply), 4: as 1 but on the depth-ordered scatter whenever it
                                     applies, whatever the splat count, 5: as 1 but on round 1's per-tile bitonic sort (A/B of the three
-                                    binnings, tests).  The binning path of a call is GsrBinningLayout.path.                   */
+                                    binnings, tests), 6: as 3 with the per-band ranks of large frames at any splat count (tests).
+                                    The binning path of a call is GsrBinningLayout.path.                                       */
     int32_t forward_only;     /* !=0: no backward will follow this forward (inference, torch.no_grad): the forward skips zero-filling
                                  the backward's per-splat accumulators (48 B per visible splat); gsr_backward on such a state is an
                                  error                                                                                   */
@@ -121,7 +122,8 @@ typedef struct GsrGeomLayout {
 typedef struct GsrBinningLayout {
     /* header (2304 bytes) at byte 0: uint64 instances of this frame (what the capacity must hold: tile instances in the parity modes,
        quadrant-stream entries in production), byte 8: uint64 sum of tiles_touched (the reference's num_rendered), byte 16:
-       uint32 binned splats, 20/24: depth range bits, byte 32: uint64 tile instances after snug-rect culling          */
+       uint32 binned splats, 20/24: depth range bits, byte 32: uint64 tile instances after snug-rect culling, bytes 40..167:
+       uint32 [32] binned splats per band of tile rows (rank path with nbands > 1)                                    */
     size_t keys;        /* uint64 [cap]  parity modes: sorted (tile << 32 | depth bits), upstream's point_list_keys */
     size_t point_list;  /* uint32 [cap]  parity modes: sorted splat index, upstream's point_list                    */
     size_t qlist;       /* uint32 [4*cap] parity modes only (tile_culling 0 / 2): twin of qpos holding each stream entry's
@@ -154,15 +156,21 @@ typedef struct GsrBinningLayout {
                            replayed by the scatter pass                                                          */
     /* rank path (csrc/gsr_rank.hip): splats ranked by depth once, every tile's instances ordered through an LDS bitmap */
     size_t ranks;       /* uint32 [cap][2] (depth rank, splat) of every (splat, tile) instance, grouped by tile (unordered inside a tile) */
-    size_t rank;        /* uint32 [P]   rank of every binned splat in (depth, index) order                                     */
+    size_t rank;        /* uint32 [P]   rank of every binned splat in (depth, index) order; with bands (nbands > 1) uint32 [P][4]: its rank
+                           among the splats touching the first .. fourth band of tile rows of its rect                            */
+    size_t rank_over;   /* uint32 [P][nbands] bands only: the same for the fifth band onwards (only entries of rects that tall are written) */
     size_t srect;       /* uint16 [P][4] tile rect (minx, miny, maxx, maxy) every splat is binned into (snug in the culling modes);
                            zero area = not binned                                                                          */
     size_t sspan;       /* float  [P][8] operands of the per-quadrant reach test of a binned splat (csrc/gsr_device.h: Span)          */
     size_t pstat;       /* uint32 [ceil(P/256)][2] (min, max) depth bits of each k_preprocess workgroup's visible splats       */
     size_t tdesc;       /* uint32 [tiles][4] (tile, entries, first entry, 0) in launch order (heaviest tiles first)                       */
+    size_t obs;         /* uint32 [P][2] bands only: (splat, first band | last band << 8) of the binned splats in depth order         */
+    size_t bandcnt;     /* uint32 [nbands][ceil(P/256)] bands only: splats of band b before each run of 256 consecutive depth ranks  */
     size_t path;        /* 0: rank path, 1: depth-ordered scatter, 2: round 1's per-tile sort (see gsr_binning_layout)       */
     size_t chunks;      /* production: number of chunks (waves) of the ordered walk                                */
     size_t nb;          /* production: number of depth buckets                                                     */
+    size_t nbands;      /* rank path: 1 up to 262144 splats; beyond, the tile rows are cut into this many bands (<= 24) ...  */
+    size_t band_rows;   /* ... of this many tile rows, each with a depth rank of its own (header bytes 40..167: uint32 splats per band) */
     size_t total;
 } GsrBinningLayout;
 
@@ -185,7 +193,8 @@ const char* gsr_last_error(void);
 /* sizes/layouts of the state buffers (pure host arithmetic, no device access) */
 int gsr_geom_layout(int32_t P, GsrGeomLayout* out);
 /* P and tile_culling select the binning path (GsrBinningLayout.path): 0 = the rank path (the default: splats ranked by depth once,
- * every tile ordered through an LDS bitmap of ranks -- one pass up to 262144 splats, 1 M ranks per pass beyond); 1 = the
+ * every tile ordered through an LDS bitmap of ranks; beyond 262144 splats the ranks are taken per band of tile rows so that a
+ * band's ranks still fit the bitmap -- GsrBinningLayout.nbands / band_rows); 1 = the
  * depth-ordered scatter, taken by production (tile_culling 1) beyond 262144 splats when the grid has at most 16384 quadrants,
  * P / chunks <= 255 and the chunk-prefix table stays below 1 GiB; 2 = round 1's per-tile bitonic sort (tile_culling 5 only).
  * `capacity` counts the instances the path produces: tile instances on paths 0 and 2, quadrant-stream entries on path 1.   */

@@ -25,7 +25,7 @@ def test_gsr_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"include/gsr.h declares {n} but libgsr_hip.so does not export it"
         assert n in _lib.GSR_SYMBOLS, f"{n} has no ctypes prototype in _lib.GSR_SYMBOLS"
-    assert lib.gsr_abi_version() == 6
+    assert lib.gsr_abi_version() == 7
 
 
 def test_layouts_are_disjoint_and_aligned():
@@ -41,7 +41,7 @@ def test_layouts_are_disjoint_and_aligned():
             (gl.rect, 8 * P), (gl.tiles_touched, 4 * P), (gl.clamped, P), (gl.visible, P), (gl.brec, 48 * P), (gl.acc64, 80 * P), (gl.acc, 48 * P)]
     _check(segs, gl.total)
     # parity modes: the rank path (tile lists ordered by global depth rank), reference-format lists materialised
-    assert bl.path == 0 and bl.nb == 512
+    assert bl.path == 0 and bl.nb == 512 and bl.nbands == 1 and bl.band_rows == 51 and bl.obs == bl.bandcnt
     nblk = (P + 255) // 256
     rank_segs = [(bl.qpos, 16 * cap), (bl.qcount, 16 * tiles), (bl.qstart, 16 * tiles),
                  (bl.ranges, 8 * tiles), (bl.tile_count, 4 * tiles), (bl.tile_start, 4 * tiles), (bl.tile_cursor, 4 * tiles), (bl.tile_order, 4 * tiles),
@@ -70,9 +70,15 @@ def test_layouts_are_disjoint_and_aligned():
             (bl.qhist, bl.chunks * Q), (bl.qprefix, 4 * bl.chunks * Q), (bl.qmask, 16 * P)]
     _check(segs, bl.total)
     # grids beyond 16384 quadrants and splat counts beyond 255 per chunk do not take the scatter: the rank path at any size
-    # (one tile bitmap up to 262144 splats, 1 M ranks per pass beyond); round 1's per-tile sort only on request (tile_culling 5)
-    assert lib.gsr_binning_layout(capq, 1600, 1100, 250_000, 1, C.byref(bl)) == 0 and bl.path == 0
+    # (one tile bitmap up to 262144 splats; beyond, ranks per band of tile rows); round 1's per-tile sort only on request (tile_culling 5)
+    assert lib.gsr_binning_layout(capq, 1600, 1100, 250_000, 1, C.byref(bl)) == 0 and bl.path == 0 and bl.nbands == 1
     assert lib.gsr_binning_layout(capq, 1600, 1100, 2_000_000, 1, C.byref(bl)) == 0 and bl.path == 0 and bl.nb == 4096
+    Pb, tb = 2_000_000, 100 * 69
+    assert bl.band_rows == 3 and bl.nbands == 23          # 69 tile rows in bands of ceil(69 / 24)
+    _check([(bl.qpos, 16 * capq), (bl.ranks, 8 * capq), (bl.point_list, 4 * capq), (bl.rank, 16 * Pb), (bl.rank_over, 4 * 23 * Pb), (bl.obs, 8 * Pb),
+            (bl.bandcnt, 4 * 23 * ((Pb + 255) // 256)), (bl.srect, 8 * Pb), (bl.sspan, 32 * Pb), (bl.tdesc, 16 * tb)], bl.total)
+    assert lib.gsr_binning_layout(capq, 550, 802, P, 6, C.byref(bl)) == 0 and bl.path == 0     # 6: the bands at any splat count (tests)
+    assert bl.band_rows == 3 and bl.nbands == 17 and bl.rank + 16 * P <= bl.rank_over and bl.rank_over + 4 * P * 17 <= bl.srect
     assert lib.gsr_binning_layout(capq, 550, 802, 2_000_000, 1, C.byref(bl)) == 0 and bl.path == 0
     assert lib.gsr_binning_layout(capq, 1600, 1100, 2_000_000, 5, C.byref(bl)) == 0 and bl.path == 2
     _check([(il.final_T, 4 * HW), (il.n_contrib, 4 * HW), (il.n_contrib_q, 4 * HW), (il.c_final, 12 * HW), (il.ck, 144 * HW)], il.total)

@@ -463,6 +463,45 @@ def test_rank_path_equals_the_per_tile_sort_on_random_scenes(seed):
                                        t(a["campos"]), False, False)
     args = (t(sp["means3D"]), t(sp["shs"]), None, t(sp["opacities"]), t(sp["scales"]), t(sp["rotations"]), None)
     out = {}
+    for mode in (3, 6, 5):     # 6: the rank path with a rank per band of tile rows (what frames beyond 262144 splats use)
+        prev = R.set_tile_culling(mode)
+        try:
+            out[mode] = D._forward_state(rs, *args)
+        finally:
+            R.set_tile_culling(prev)
+    old = out[5]
+    assert old["binning_path"] == 2
+    for mode in (3, 6):
+        new = out[mode]
+        assert new["binning_path"] == 0
+        assert new["num_rendered"] == old["num_rendered"] and new["rect_instances"] == old["rect_instances"]
+        for k in ("color", "final_T"):
+            assert np.array_equal(_np(new[k]).view(np.uint32), _np(old[k]).view(np.uint32)), (mode, k)
+        for k in ("radii", "n_contrib", "n_contrib_q", "tiles_touched"):
+            np.testing.assert_array_equal(_np(new[k]), _np(old[k]), err_msg=f"{mode}/{k}")
+        _same_streams(new, old, packed=False)
+
+
+@pytest.mark.parametrize("W,H,nbands", [(96, 80, 5), (96, 16, 1)])
+def test_rank_bands_with_more_splats_than_one_bitmap_holds(W, H, nbands):
+    """300 000 splats crowded into the middle of a small image: past 262144 splats the rank path ranks per band of tile rows, and here
+    one band (or, 16 pixels high, the only one) holds more splats than a tile bitmap has bits, so the tile kernel takes several
+    passes over its rank space.  Same streams, image bits and counters as round 1's per-tile sort."""
+    from gaussianavatars_amd import debug as D
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd import synthetic as S
+    from gaussianavatars_amd.rasterizer import GaussianRasterizationSettings
+
+    dev = _dev()
+    P, deg = 300_000, 0
+    sp = S.random_splats(P, deg, 77, xyz_sigma=0.004, log_scale_mean=math.log(0.002), log_scale_sigma=0.3)
+    cam = S.orbit_camera(W, H)
+    a = settings_args(cam, [0.0, 0.0, 0.0], deg, 1.0)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    rs = GaussianRasterizationSettings(a["H"], a["W"], a["tanfovx"], a["tanfovy"], t(a["bg"]), 1.0, t(a["viewmatrix"]), t(a["projmatrix"]), deg,
+                                       t(a["campos"]), False, False)
+    args = (t(sp["means3D"]), t(sp["shs"]), None, t(sp["opacities"]), t(sp["scales"]), t(sp["rotations"]), None)
+    out = {}
     for mode in (3, 5):
         prev = R.set_tile_culling(mode)
         try:
@@ -471,9 +510,12 @@ def test_rank_path_equals_the_per_tile_sort_on_random_scenes(seed):
             R.set_tile_culling(prev)
     new, old = out[3], out[5]
     assert new["binning_path"] == 0 and old["binning_path"] == 2
-    assert new["num_rendered"] == old["num_rendered"] and new["rect_instances"] == old["rect_instances"]
+    assert new["nbands"] == nbands and new["band_rows"] == 1
+    if nbands > 1:
+        assert int(_np(new["band_total"]).max()) > 262144, "the scene is meant to overflow one band's bitmap"
+    assert new["num_rendered"] == old["num_rendered"] > 262144
     for k in ("color", "final_T"):
         assert np.array_equal(_np(new[k]).view(np.uint32), _np(old[k]).view(np.uint32)), k
-    for k in ("radii", "n_contrib", "n_contrib_q", "tiles_touched"):
+    for k in ("radii", "n_contrib", "n_contrib_q"):
         np.testing.assert_array_equal(_np(new[k]), _np(old[k]), err_msg=k)
     _same_streams(new, old, packed=False)
