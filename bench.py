@@ -76,6 +76,7 @@ SSIM_STEP = False   # --workload train: the loss and statistics lines of train.p
 _ZERO = {}
 # rocprofv3 kernel name -> the timing slot (include/gsr.h GSR_K_*) its launches are accounted under
 PMC_ALIAS = {"k_rcount": "k_count", "k_rscatter": "k_scatter", "k_tile_rank": "k_tile_sort", "k_rdscatter": "k_depth_sort", "k_rdsort": "k_depth_sort",
+             "k_band_count": "k_depth_sort", "k_band_scan": "k_depth_sort", "k_band_rank": "k_depth_sort",
              "k_dbucket": "k_depth_sort", "k_dscan": "k_depth_sort", "k_dscatter": "k_depth_sort", "k_dsort": "k_depth_sort", "k_qscan_glob": "k_qscan"}
 
 
@@ -338,6 +339,7 @@ def main():
         # instance lists, so their unit count is I_binned; the same figures with the reference's rect-based count are kept beside
         # them (`algorithmic_bytes_rect_based`) -- those are what an implementation without tile culling would have to move.
         path = int(info.get("binning_path", 2))           # 0 rank path, 1 depth-ordered scatter, 2 round 1's per-tile sort
+        bands = int(info.get("rank_bands", 1))            # rank path: bands of tile rows with a depth rank of their own (1 up to 262144 splats)
         def algo_for(I):
             a = {
                 "k_preprocess": 236 * N + (44 + (27 if train else 0)) * N,
@@ -355,6 +357,11 @@ def main():
                     "k_scatter": 44 * N + 8 * I,                   # rect 8 + rank 4 + operands 32 read per splat, one 8-byte entry written per instance
                     "k_tile_sort": 8 * I + 4 * I,                  # entry read; at least one 4-byte stream entry written per instance
                 })
+                if bands > 1:   # frames beyond 262144 splats: ranks per band of tile rows (k_band_count / k_band_scan / k_band_rank)
+                    a.update({
+                        "k_depth_sort": 20 * N + 24 * N + 8 * N + 24 * N,   # bucket sort: key 8 + rect 8 read, (splat, bands) 8 written; count pass: 8 read; rank pass: 8 read, four ranks 16 written
+                        "k_scatter": 56 * N + 8 * I,                         # rect 8 + four ranks 16 + operands 32 read per splat
+                    })
             return a
         algo, algo_rect = algo_for(I_binned), algo_for(I_rect)
         # Coalesced-read component of each kernel (bytes per launch), for the PMC calibration rule of profiles/r02_pmc_calibration.json:
@@ -433,7 +440,7 @@ def main():
                                  args.workload] % (N, args.height, args.width),
                 "splats": N, "width": args.width, "height": args.height, "sh_degree": 3,
                 "num_rendered": I_rect, "num_binned": I_binned, "tile_culling": bool(info.get("tile_culling", False)),
-                "binning_path": {0: "rank", 1: "depth-ordered scatter", 2: "per-tile sort"}[path],
+                "binning_path": {0: "rank", 1: "depth-ordered scatter", 2: "per-tile sort"}[path] + (f" ({bands} bands of tile rows)" if path == 0 and bands > 1 else ""),
                 "visible_fraction": round(vis, 4), "binding": args.binding,
                 "parallelism": (f"frame-parallel x{n_gpus}: {dist.get_world_size() if dist is not None else 1} "
                                 f"{'RCCL (torch nccl)' if dist is not None else 'single-process'} rank(s), frames per rank {counts}, "

@@ -231,11 +231,16 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         a.grec[3 * i + 1] = make_float4(con2, opac, col[0], col[1]);
         // .y: the splat's two fixed-point exponents for the deterministic backward (gsr_device.h: GSR_FIXED_BITS), as an integer in float bits
         a.grec[3 * i + 2] = make_float4(col[2], __int_as_float(visible ? splat_sum_exponents(n, con0, con1, con2, W, H) : 0), 0.f, 0.f);
+        // forward_only (no backward can follow): what only the backward reads -- cov3D, the clamp flags, and on the rank path (which
+        // bins by srect) the rect -- is not written: 33 of ~134 bytes per splat
+        if (!s.forward_only) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) a.cov3D[6 * i + k] = c6[k];
-        a.rect[i] = make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy);
+            for (int k = 0; k < 6; ++k) a.cov3D[6 * i + k] = c6[k];
+            a.clamped[i] = (uint8_t)clampbits;
+        }
+        if (!s.forward_only || !a.pstat)
+            a.rect[i] = make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy);
         a.tiles_touched[i] = n;
-        a.clamped[i] = (uint8_t)clampbits;
         a.visible[i] = radius > 0 ? (uint8_t)1 : (uint8_t)0;
         if (visible && !s.forward_only) {   // the backward's accumulators start at zero (skipped when no backward can follow)
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);

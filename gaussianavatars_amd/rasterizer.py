@@ -235,7 +235,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # next frame: 25 % headroom over what this one needed, never shrinking below it
         _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
         _last_info.update(num_rendered=I, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod,
-                          binning_path=int(bl.path), bound=False)   # 0 rank path, 1 depth-ordered scatter, 2 per-tile sort (include/gsr.h)
+                          binning_path=int(bl.path), rank_bands=int(bl.nbands), bound=False)   # 0 rank path, 1 depth-ordered scatter, 2 per-tile sort (include/gsr.h)
         _last_binning[0] = binning
 
         ctx.raster_settings = raster_settings
@@ -354,7 +354,7 @@ class _RasterizeBound(torch.autograd.Function):
         I = int(n_host.value)
         _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
         _last_info.update(num_rendered=I, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod,
-                          binning_path=int(bl.path), bound=True)
+                          binning_path=int(bl.path), rank_bands=int(bl.nbands), bound=True)
         _last_binning[0] = binning
         ctx.raster_settings = raster_settings
         ctx.tile_culling, ctx.deterministic = int(s.tile_culling), int(s.deterministic)

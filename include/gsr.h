@@ -74,7 +74,8 @@ typedef struct GsrSettings {
                                     binnings, tests), 6: as 3 with the per-band ranks of large frames at any splat count (tests).
                                     The binning path of a call is GsrBinningLayout.path.                                       */
     int32_t forward_only;     /* !=0: no backward will follow this forward (inference, torch.no_grad): the forward skips zero-filling
-                                 the backward's per-splat accumulators (48 B per visible splat); gsr_backward on such a state is an
+                                 the backward's per-splat accumulators (48 B per visible splat) and writing what only the backward reads
+                                 (GsrGeomLayout.cov3D, clamped; rect on the rank path); gsr_backward on such a state is an
                                  error                                                                                   */
     int32_t deterministic;    /* !=0: bit-reproducible backward.  The blend backward then adds its per-(wave, splat) partial sums as 64-bit
                                  FIXED-POINT integers (integer addition is associative: the result does not depend on the order the
