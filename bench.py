@@ -254,6 +254,9 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=0.5, help="minimum total timed duration: rounds are added until it is reached")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="record the frame step once and replay it as one hipGraph launch per step (gaussianavatars_amd.graphs.GraphedStep)")
+    ap.add_argument("--no-pin", action="store_true", help="do not pin the process next to its GPU (host-sensitivity runs)")
     args = ap.parse_args()
     if args.workload == "cfg3" and args.mode == "render":
         args.workload = "cfg2"
@@ -288,7 +291,7 @@ def main():
     from gaussianavatars_amd.frame_parallel import frames_for_rank, pin_to_gpu_numa_node
 
     all_cpus = os.sched_getaffinity(0)
-    pinned = pin_to_gpu_numa_node(local_rank)   # host launch latency: stay on the GPU's socket
+    pinned = None if args.no_pin else pin_to_gpu_numa_node(local_rank)   # host launch latency: stay on the GPU's socket
     if args.workload == "cfg5":
         g, cam = build_unbound_scene(device, args.splats, 3, args.width, args.height)
     else:
@@ -302,6 +305,39 @@ def main():
             return one_step(g, cam, bg, target, t, train)
 
     run = make_runner(step_fn, my_frames, dist, device, post_step=(lambda: zero_grads(g)) if train else None)
+    run_eager, graphed = run, None
+    if args.graph:
+        # the same step recorded once and replayed: the frame's FLAME parameters are fed into static one-row tables (one copy),
+        # the gradients land in static .grad tensors (no zero_grads: every replay rewrites them)
+        from gaussianavatars_amd.graphs import FlameRowFeeder, GraphedStep, release_mesh
+
+        feeder = None
+        if g.binding is not None:
+            feeder = FlameRowFeeder(g.flame_param, requires_grad=train)
+            g.flame_param = feeder.static_param
+
+        def fixed_step():
+            with torch.set_grad_enabled(train):
+                return one_step(g, cam, bg, target, 0, train)
+
+        def eager_fed(t):   # the per-kernel event pass stays eager (events are recorded around the launches)
+            if feeder is not None:
+                feeder.feed(t)
+            return fixed_step()
+
+        run_eager = make_runner(eager_fed, my_frames, dist, device, post_step=(lambda: zero_grads(g)) if train else None)
+        def fresh():   # no gradients and no autograd graph of an earlier frame when the step is recorded
+            zero_grads(g)
+            release_mesh(g)
+
+        graphed = GraphedStep(fixed_step, before_capture=fresh)
+
+        def graph_step(t):
+            if feeder is not None:
+                feeder.feed(t)
+            return graphed.replay().clone()   # the recorded scalar is overwritten by the next replay
+
+        run = make_runner(graph_step, my_frames, dist, device)
 
     def fence():
         if dist is not None:
@@ -313,6 +349,9 @@ def main():
     elapsed = float(np.median(rounds))   # the median round: exactly args.steps steps
     wait_ms, waits = _lib.gsr_wait_stats()
     info = R.last_forward_info()
+    if graphed is not None:
+        graphed.check()                                   # every replayed frame fitted the recorded binning capacity
+        info["num_rendered"] = max(graphed.instances())   # (the recording itself did not know its count)
 
     # ---- per-kernel durations: HIP events on the launch stream (recorded by the C ABI around every kernel).
     # Bracketing each launch with an event pair costs ~5 % of the frame rate (983 -> 933 frames/s measured),
@@ -320,7 +359,7 @@ def main():
     kern = {}
     if rank == 0 and not args.no_kernel_profile:
         _lib.gsr_profile_enable(True)
-        run(args.steps, args.warmup)
+        run_eager(args.steps, args.warmup)
         torch.cuda.synchronize(device)
         kern = _lib.gsr_profile_read()
         _lib.gsr_profile_enable(False)
@@ -452,7 +491,9 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             # the frame's single host wait (for the instance count): ~0 would mean the host paces the loop, not the GPU
-            "host": {"scan_wait_ms_per_step": round(wait_ms / max(waits, 1), 4), "pinned_cpus": len(pinned) if pinned else None},
+            "host": {"scan_wait_ms_per_step": round(wait_ms / max(waits, 1), 4), "pinned_cpus": len(pinned) if pinned else None,
+                     "step_launch": ("hipGraph replay (one launch per step; binning capacity %d for %d instances)" % (graphed.capacity, max(graphed.instances())))
+                                    if graphed is not None else "eager (one Python-driven launch per kernel)"},
         }
         print(json.dumps(out))
     if dist is not None:

@@ -52,8 +52,9 @@ _ONE_DEVICE = None   # a process that sees one GPU never switches devices
 GSR_LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr_hip.so")
 
 GSR_OK = 0
-GSR_ABI_VERSION = 7
+GSR_ABI_VERSION = 8
 GSR_E_CAPACITY = 1
+GSR_COUNT_SLOTS = 128   # include/gsr.h: persistent instance-count slots of the deferred forwards
 
 
 class GsrSettings(C.Structure):
@@ -75,6 +76,7 @@ class GsrSettings(C.Structure):
         ("forward_only", C.c_int32),
         ("deterministic", C.c_int32),
         ("exact_scale_grad", C.c_int32),
+        ("deferred_count", C.c_int32),
     ]
 
 
@@ -104,6 +106,7 @@ class GsrImageLayout(C.Structure):
 GSR_SYMBOLS = {
     "gsr_abi_version": (C.c_int, []),
     "gsr_last_error": (C.c_char_p, []),
+    "gsr_count_slot_read": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gsr_geom_layout": (C.c_int, [C.c_int32, C.POINTER(GsrGeomLayout)]),
     "gsr_binning_layout": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GsrBinningLayout)]),
     "gsr_image_layout": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(GsrImageLayout)]),

@@ -49,8 +49,10 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // ---- host mailbox: a small ring of 8-byte slots in mapped pinned memory -----------------------
 // k_tile_scan posts (seq << 40 | I) with one system-scope store; gsr_forward spins on the slot.
 struct Mailbox {
-    static constexpr int kSlots = 256;
+    static constexpr int kSlots = 256;        // ring of the waiting forwards
+    static constexpr int kPersistent = GSR_COUNT_SLOTS;   // slots of the deferred forwards (GsrSettings.deferred_count), after the ring
     unsigned long long* host = nullptr;
+    unsigned long long* dev = nullptr;        // the same memory as the device sees it
     std::atomic<unsigned long long> seq{1};
     std::mutex init_mu;
     bool ready = false;
@@ -58,8 +60,9 @@ struct Mailbox {
     {
         std::lock_guard<std::mutex> lk(init_mu);
         if (ready) return 0;
-        HIP_TRY(hipHostMalloc((void**)&host, kSlots * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocPortable));
-        memset(host, 0, kSlots * sizeof(unsigned long long));
+        HIP_TRY(hipHostMalloc((void**)&host, (kSlots + kPersistent) * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocPortable));
+        memset(host, 0, (kSlots + kPersistent) * sizeof(unsigned long long));
+        HIP_TRY(hipHostGetDevicePointer((void**)&dev, (void*)host, 0));
         ready = true;
         return 0;
     }
@@ -129,6 +132,26 @@ int check_settings(const GsrSettings* s)
     if (s->image_height > 65535 * 16 || s->image_width > 65535 * 16) return fail(GSR_E_ARG, "image too large for 16-bit tile rects");
     if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->campos) return fail(GSR_E_ARG, "bg/viewmatrix/projmatrix/campos must be device pointers");
     if (s->sh_degree < 0 || s->sh_degree > 3) return fail(GSR_E_ARG, "sh_degree must be in 0..3");
+    if (s->deferred_count < 0 || s->deferred_count > GSR_COUNT_SLOTS) return fail(GSR_E_ARG, "deferred_count must be 0 or a slot in 1..%d", GSR_COUNT_SLOTS);
+    return 0;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, size class): the attribute sticks, and the call is not
+// something to repeat per frame (nor inside a stream capture)
+int ensure_dynamic_lds(const void* fn, size_t bytes)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, size_t>> seen;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& e : seen)
+        if (e.first == fn) {
+            if (e.second >= bytes) return 0;
+            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            e.second = bytes;
+            return 0;
+        }
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    seen.emplace_back(fn, bytes);
     return 0;
 }
 
@@ -138,6 +161,16 @@ extern "C" {
 
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 const char* gsr_last_error(void) { return g_err; }
+
+int gsr_count_slot_read(int32_t slot, int64_t* count, int64_t* seq)
+{
+    if (slot < 0 || slot >= GSR_COUNT_SLOTS || !count) return fail(GSR_E_ARG, "gsr_count_slot_read: bad arguments");
+    if (int rc = g_mail.init()) return rc;
+    const unsigned long long v = __atomic_load_n(g_mail.host + Mailbox::kSlots + slot, __ATOMIC_ACQUIRE);
+    *count = v ? (int64_t)(v & 0xFFFFFFFFFFull) : -1;
+    if (seq) *seq = (int64_t)(v >> 40);
+    return GSR_OK;
+}
 
 int gsr_geom_layout(int32_t P, GsrGeomLayout* o)
 {
@@ -373,10 +406,13 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     }
 
     const unsigned long long seq = (g_mail.seq.fetch_add(1) % 0xFFFFFEull) + 1;  // 1 .. 2^24-2, never 0
-    volatile unsigned long long* slot = g_mail.host + (seq % Mailbox::kSlots);
-    *slot = 0;
-    unsigned long long* slot_dev = nullptr;
-    HIP_TRY(hipHostGetDevicePointer((void**)&slot_dev, (void*)slot, 0));
+    // where the scan posts (seq, I): a ring slot this call spins on, or -- deferred count -- the caller's persistent slot, read
+    // later through gsr_count_slot_read (nothing waits, so the call can sit inside a stream capture and be replayed as a hipGraph)
+    const bool deferred = settings->deferred_count != 0;
+    const size_t slot_index = deferred ? (size_t)Mailbox::kSlots + (size_t)(settings->deferred_count - 1) : (size_t)(seq % Mailbox::kSlots);
+    volatile unsigned long long* slot = g_mail.host + slot_index;
+    if (!deferred) *slot = 0;
+    unsigned long long* slot_dev = g_mail.dev + slot_index;
     const unsigned long long cap = (unsigned long long)binning_capacity;
     uint32_t* tile_order = (uint32_t*)(b + bl.tile_order);
     uint32_t* qpos = (uint32_t*)(b + bl.qpos);
@@ -421,7 +457,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         const size_t count_lds = (((size_t)Q + 3) / 4) * 4;   // byte counters, four to a word
         const size_t walk_lds = (size_t)Q * 4;               // absolute cursors
         if (walk_lds > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_qscatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds));
+            if (int rc = ensure_dynamic_lds((const void*)gsr::k_qscatter, (size_t)walk_lds)) return rc;
         const int walk_blocks = (int)chunks;   // one workgroup per chunk, one wave per band
         {
             TIMED(GSR_K_QCOUNT, stream);
@@ -449,10 +485,10 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         const size_t hist_bytes = direct ? 0 : (size_t)tiles * sizeof(uint32_t);
         const size_t count_lds = (size_t)nb * 4 + (direct ? 0 : (size_t)(gx + 1) * (size_t)(gy + 1) * sizeof(uint32_t));   // corner grid of the tile rects
         if (count_lds > 48 * 1024) {
-            HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_rcount, hipFuncAttributeMaxDynamicSharedMemorySize, (int)count_lds));
+            if (int rc = ensure_dynamic_lds((const void*)gsr::k_rcount, (size_t)count_lds)) return rc;
         }
         if (hist_bytes > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_rscatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+            if (int rc = ensure_dynamic_lds((const void*)gsr::k_rscatter, (size_t)hist_bytes)) return rc;
         uint32_t* block_hist = (uint32_t*)(b + bl.block_hist);
         uint32_t* bcount = (uint32_t*)(b + bl.bcount);
         uint32_t* bstart = (uint32_t*)(b + bl.bstart);
@@ -530,10 +566,10 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     // (grids beyond GSR_LDS_HIST_TILES tiles -- past ~3200x3200 px -- fall back to per-instance L2 atomics)
     const size_t hist_bytes = tiles > GSR_LDS_HIST_TILES ? 0 : (size_t)tiles * sizeof(uint32_t);
     if (hist_bytes > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
-        HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_count<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
-        HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
-        HIP_TRY(hipFuncSetAttribute((const void*)gsr::k_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes));
+        if (int rc = ensure_dynamic_lds((const void*)gsr::k_count<false>, (size_t)hist_bytes)) return rc;
+        if (int rc = ensure_dynamic_lds((const void*)gsr::k_count<true>, (size_t)hist_bytes)) return rc;
+        if (int rc = ensure_dynamic_lds((const void*)gsr::k_scatter<false>, (size_t)hist_bytes)) return rc;
+        if (int rc = ensure_dynamic_lds((const void*)gsr::k_scatter<true>, (size_t)hist_bytes)) return rc;
     }
     const bool cull = settings->tile_culling != 0;
     if (pblocks > 0) {
@@ -590,6 +626,10 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         KERNEL_CHECK("k_render", stream, dbg);
     }
 
+    if (deferred) {   // the count of this frame is not known yet: the caller checks its slot after the fact
+        *num_rendered_host = -1;
+        return GSR_OK;
+    }
     // wait for the scan's post
     const auto t0 = std::chrono::steady_clock::now();
     unsigned long long v;
@@ -697,7 +737,8 @@ static int backward_impl(const GsrSettings* settings, int32_t P, int32_t M, cons
         hipLaunchKernelGGL(det ? gsr::k_render_bwd<true> : gsr::k_render_bwd<false>, dim3(gx * gy * GSR_BWD_SEGMENTS), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order),
                            (const uint32_t*)(b + bl.qstart), (const uint32_t*)(b + bl.qcount), (const float4*)(g + gl.grec), (const uint32_t*)(b + bl.qpos),
                            (const float*)(im + il.final_T), (const uint32_t*)(im + il.n_contrib_q), dL_dpix, grad_scratch,
-                           (const float*)(im + il.c_final), (const float4*)(im + il.ck), gx * gy, acc64, (const uint32_t*)gmax);
+                           (const float*)(im + il.c_final), (const float4*)(im + il.ck), gx * gy, acc64, (const uint32_t*)gmax,
+                           (unsigned long long)binning_capacity, (const unsigned long long*)b);
         KERNEL_CHECK("k_render_bwd", stream, dbg);
     }
     gsr::PreBwdArgs pa;

@@ -87,8 +87,10 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
                                                      const uint32_t* __restrict__ n_contrib_q, const float* __restrict__ dL_dpix,
                                                      float* __restrict__ acc /* [P][GSR_ACC_STRIDE] */,
                                                      const float* __restrict__ c_final, const float4* __restrict__ ck, int tiles,
-                                                     long long* __restrict__ acc64, const uint32_t* __restrict__ gmax)
+                                                     long long* __restrict__ acc64, const uint32_t* __restrict__ gmax,
+                                                     unsigned long long capacity, const unsigned long long* __restrict__ total_dev)
 {
+    if (*total_dev > capacity) return;   // the forward of this state overflowed its binning capacity and skipped the frame (deferred count)
     const int e_g = DET ? gmax_exponent(*gmax) : 0;
 #ifdef GSR_EXPERIMENT_TIMELINE
     const unsigned long long t_start = wall_clock64();
@@ -319,9 +321,11 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
 }
 
 template __global__ void k_render_bwd<false>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const float*,
-                                             const uint32_t*, const float*, float*, const float*, const float4*, int, long long*, const uint32_t*);
+                                             const uint32_t*, const float*, float*, const float*, const float4*, int, long long*, const uint32_t*,
+                                             unsigned long long, const unsigned long long*);
 template __global__ void k_render_bwd<true>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const float*,
-                                            const uint32_t*, const float*, float*, const float*, const float4*, int, long long*, const uint32_t*);
+                                            const uint32_t*, const float*, float*, const float*, const float4*, int, long long*, const uint32_t*,
+                                            unsigned long long, const unsigned long long*);
 
 // ------------------------------------------------------------------------------------------
 

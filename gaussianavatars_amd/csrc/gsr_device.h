@@ -552,7 +552,7 @@ template <bool DET>
 __global__ void k_render_bwd(Settings s, const uint32_t* tile_order, const uint32_t* qstart, const uint32_t* qcount, const float4* grec,
                              const uint32_t* qpos, const float* final_T,
                              const uint32_t* n_contrib_q, const float* dL_dpix, float* acc, const float* c_final, const float4* ck, int tiles,
-                             long long* acc64, const uint32_t* gmax);
+                             long long* acc64, const uint32_t* gmax, unsigned long long capacity, const unsigned long long* total_dev);
 __global__ void k_gmax(size_t n, const float* dL_dpix, uint32_t* gmax);
 // exponent e_g with 2^e_g > the float whose bits are given (0 for no gradient at all)
 __device__ __forceinline__ int gmax_exponent(uint32_t gmax_bits) { return gmax_bits ? (int)((gmax_bits >> 23) & 0xFFu) - 127 + 1 : 0; }

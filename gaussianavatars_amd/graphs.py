@@ -1,0 +1,173 @@
+"""A whole frame step as ONE hipGraph launch.
+
+The frame loop of the hot path (select_mesh_by_timestep -> render -> loss -> backward) is ~30 kernel launches driven by ~0.3 ms
+of Python per step.  On a GPU that needs 0.4 ms for the kernels that is fine while the process runs next to its GPU and alone;
+it stops being fine on a slower, busier or unpinned host.  `GraphedStep` records the step once -- stream capture sees every
+launch the three native libraries make, they are plain hipLaunchKernel calls on torch's current stream -- and replays it with
+one hipGraphLaunch: the host cost of a step becomes a few microseconds.
+
+What makes the step capturable:
+  * the rasterizer forward does not wait for the frame's instance count (`rasterizer.deferred_count`, include/gsr.h
+    GsrSettings.deferred_count): the binning buffer is over-allocated (`headroom` x the count of the warm-up frames; 288 GB of
+    HBM make that free), the count goes to a persistent slot, and `check()` reads it after the fact.  A frame whose count
+    exceeds the capacity skips its binning and blend kernels (nothing is read or written out of bounds): `check()` raises
+    CapacityOverflow for it and `recapture()` doubles the headroom;
+  * every input that changes from frame to frame lives in a STATIC device tensor the caller refills before `replay()`:
+    camera matrices (the rasterizer reads them through pointers), the FLAME parameters of the frame (`FlameRowFeeder`:
+    one-row tables fed from the packed sequence by ONE device-to-device copy), the target image;
+  * scalars passed by value (image size, tan(fov), SH degree, splat count) are part of the recording: a graph is valid for one
+    model size and one camera geometry.  Densification changes the model: capture again afterwards.
+
+Gradients: parameters' .grad must be None when the step is captured; the recorded backward then allocates them inside the
+graph's memory pool and every replay rewrites the same tensors in place (torch's whole-network capture rules).
+
+Autograd state: a recording must not meet pieces of an OLDER autograd graph.  torch ties a leaf's AccumulateGrad node to the
+stream it was created on and keeps the node alive as long as any graph refers to it; a mesh-bound model holds such a graph
+between frames (`model.verts`, `model.face_center`, ... are outputs of the mesh node of the previous frame).  If that frame ran
+on another stream, the recorded backward would hop to that stream in the middle of the capture (observed: a segmentation fault
+inside hipStreamEndCapture).  So the warm-up frames and the recording share ONE stream, and `before_capture` -- called before
+every warm-up frame and before the recording -- should drop what the model keeps from the previous frame
+(`release_mesh(model)`) along with the gradients.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+
+from . import rasterizer as _R
+
+__all__ = ["GraphedStep", "CapacityOverflow", "FlameRowFeeder", "release_mesh"]
+
+
+def release_mesh(model) -> None:
+    """Drops the per-frame mesh tensors select_mesh_by_timestep left on the model (scene/flame_gaussian_model.py:137-154) and
+    with them the autograd graph of the previous frame."""
+    for k in ("verts", "verts_cano", "face_center", "face_orien_mat", "face_scaling", "face_orien_quat"):
+        if hasattr(model, k):
+            setattr(model, k, None)
+
+
+class CapacityOverflow(RuntimeError):
+    """A replayed frame produced more tile instances than the recorded binning capacity holds; that frame's image and
+    gradients are not valid."""
+
+
+class GraphedStep:
+    """step = GraphedStep(fn); step.replay() -> fn's recorded return value (static tensors), step.check().
+
+    `fn()` runs one frame step on static tensors (forward, loss, backward) and returns a tensor or a tuple of tensors.
+    It is run `warmup` times eagerly on a side stream first -- every lazy initialisation (library loads, rig preparation,
+    binding CSR, LDS attributes) happens there, and the rasterizer learns the frame's instance count -- then once more
+    under stream capture.  `before_capture()` (optional) runs right before the recording, e.g. to reset .grad to None."""
+
+    def __init__(self, fn: Callable[[], object], warmup: int = 3, headroom: float = 4.0, before_capture: Optional[Callable[[], None]] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("GraphedStep needs the GPU (hipGraph capture); there is no CPU path")
+        self.fn, self.before_capture = fn, before_capture
+        self.headroom = float(headroom)
+        self.warmup = max(1, int(warmup))
+        self.replays = 0
+        self._state = None
+        self._stream = torch.cuda.Stream()   # the warm-up frames and the recording run here (see the module docstring)
+        self._capture()
+
+    def _capture(self):
+        side = self._stream
+        side.wait_stream(torch.cuda.current_stream())
+        need = 0
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                if self.before_capture is not None:
+                    self.before_capture()
+                self.fn()
+                need = max(need, int(_R.last_forward_info().get("num_rendered", 0)))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if self._state is not None:
+            self._state.release()
+        self._state = _R._Deferred(int(self.headroom * max(need, 1)) + 1)
+        self.warm_instances = need
+        if self.before_capture is not None:
+            self.before_capture()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            with _R.deferred_count(self._state):
+                self.out = self.fn()
+        if not self._state.slots:
+            raise RuntimeError("GraphedStep: fn() issued no rasterizer forward")
+
+    @property
+    def capacity(self) -> int:
+        return self._state.capacity
+
+    def replay(self):
+        """One hipGraphLaunch on the current stream; returns the recorded outputs (valid once the stream gets there)."""
+        self.graph.replay()
+        self.replays += 1
+        return self.out
+
+    def instances(self) -> list:
+        """Instance count of the newest frame each recorded rasterizer forward has finished (-1: none yet).  No synchronisation:
+        call after a sync (or an event) when the count of a particular replay is wanted."""
+        return self._state.counts()
+
+    def check(self) -> None:
+        """Raises CapacityOverflow when the newest finished frame did not fit the recorded capacity."""
+        worst = max(self.instances())
+        if worst > self.capacity:
+            raise CapacityOverflow(f"{worst} tile instances exceed the recorded binning capacity {self.capacity} "
+                                   f"(captured at {self.warm_instances} with headroom {self.headroom}): that frame is not valid; recapture()")
+
+    def recapture(self, headroom: Optional[float] = None) -> None:
+        """Record again (after densification, a new camera geometry, or an overflow: the headroom doubles unless given)."""
+        self.headroom = float(headroom) if headroom is not None else 2.0 * self.headroom
+        torch.cuda.synchronize()
+        self._capture()
+
+    def close(self) -> None:
+        if self._state is not None:
+            self._state.release()
+            self._state = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FlameRowFeeder:
+    """Static one-row FLAME parameter tables for a recorded step.
+
+    select_mesh_by_timestep(t) addresses row t of the (T, k) tables of flame_param (scene/flame_gaussian_model.py:117-135);
+    a recording would freeze t.  The feeder packs the per-timestep tables into one (T, sum k) tensor, hands the model
+    one-row VIEWS of a single static row -- `model.flame_param = feeder.static_param`, `select_mesh_by_timestep(0)` inside the
+    recorded step -- and `feed(t)` refreshes that row with one device-to-device copy before a replay."""
+
+    ROWS = ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation")
+
+    def __init__(self, flame_param: Dict[str, torch.Tensor], requires_grad: bool = False):
+        tabs = [flame_param[k].detach() for k in self.ROWS]
+        self.T = int(tabs[0].shape[0])
+        self.packed = torch.cat([t.reshape(self.T, -1).float() for t in tabs], dim=1).contiguous()
+        self.row = self.packed[:1].clone()
+        self.static_param = {k: v for k, v in flame_param.items() if k not in self.ROWS and k != "dynamic_offset"}
+        off = 0
+        for k, t in zip(self.ROWS, tabs):
+            w = int(t.reshape(self.T, -1).shape[1])
+            view = self.row[:, off:off + w]
+            self.static_param[k] = view.requires_grad_(True) if requires_grad else view
+            off += w
+        if "dynamic_offset" in flame_param:   # (T, V, 3): fed the same way
+            self.dyn_all = flame_param["dynamic_offset"].detach()
+            self.static_param["dynamic_offset"] = self.dyn_all[:1].clone()
+        else:
+            self.dyn_all = None
+
+    def feed(self, t: int) -> None:
+        t = int(t) % self.T
+        with torch.no_grad():
+            self.row.copy_(self.packed[t:t + 1])
+            if self.dyn_all is not None:
+                self.static_param["dynamic_offset"].copy_(self.dyn_all[t:t + 1])

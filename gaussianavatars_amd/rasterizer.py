@@ -21,7 +21,7 @@ from torch import nn
 
 from . import _lib
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_bound", "rasterize_leaves", "last_forward_info", "set_tile_culling",
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_bound", "rasterize_leaves", "last_forward_info", "set_tile_culling", "deferred_count",
            "get_tile_culling", "set_exact_scale_grad", "set_deterministic"]
 
 
@@ -107,6 +107,62 @@ def last_forward_info() -> dict:
 
 def _round_cap(n: int) -> int:
     return max(_CAP_QUANTUM, (int(n) + _CAP_QUANTUM - 1) // _CAP_QUANTUM * _CAP_QUANTUM)
+
+
+# ---- deferred instance count (include/gsr.h: GsrSettings.deferred_count) -------------------------
+# A forward normally waits for the frame's instance count (to grow the binning buffer and replay the frame when it does not
+# fit).  Inside a `deferred_count` context it does not: the binning buffer has the context's fixed capacity, the count goes
+# to a persistent slot the caller reads after the fact, and the call contains no host synchronisation at all -- which is what
+# lets a whole frame step be stream-captured and replayed as a hipGraph (gaussianavatars_amd.graphs.GraphedStep).
+class _Deferred:
+    def __init__(self, capacity: int):
+        self.capacity = _round_cap(capacity)
+        self.slots: list = []      # one persistent slot per rasterizer forward issued inside the context
+
+    def take(self) -> int:
+        if not _free_slots:
+            raise RuntimeError(f"all {_lib.GSR_COUNT_SLOTS} deferred-count slots are in use (release GraphedStep objects that are no longer needed)")
+        slot = _free_slots.pop()
+        self.slots.append(slot)
+        return slot
+
+    def release(self):
+        _free_slots.extend(self.slots)
+        self.slots = []
+
+    def counts(self) -> list:
+        """The newest instance count posted to each slot (-1: nothing yet)."""
+        lib = _lib.gsr()
+        out = []
+        for slot in self.slots:
+            n = C.c_int64(0)
+            if lib.gsr_count_slot_read(slot, C.byref(n), None) != _lib.GSR_OK:
+                raise RuntimeError(_lib.gsr_error())
+            out.append(int(n.value))
+        return out
+
+
+_free_slots = list(range(_lib.GSR_COUNT_SLOTS - 1, -1, -1))
+_deferred: Optional[_Deferred] = None
+
+
+class deferred_count:
+    """with deferred_count(capacity) as d: ... -- every rasterizer forward inside enqueues without waiting for its instance count;
+    d.counts() afterwards (once the work has run) returns them; a count above d.capacity means that frame skipped its binning and
+    blend kernels: its image and gradients are not valid.  d.release() returns the slots."""
+
+    def __init__(self, capacity_or_state):
+        self.state = capacity_or_state if isinstance(capacity_or_state, _Deferred) else _Deferred(int(capacity_or_state))
+
+    def __enter__(self) -> _Deferred:
+        global _deferred
+        self.prev, _deferred = _deferred, self.state
+        return self.state
+
+    def __exit__(self, *exc):
+        global _deferred
+        _deferred = self.prev
+        return False
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -211,6 +267,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         prod = _binning_layout(lib, 0, W, H, P, int(s.tile_culling)).path == 1
         key = (dev.index, H, W, prod)
         cap = _capacity_hint.get(key) or _round_cap((24 if prod else 8) * P)
+        defer = _deferred
+        if defer is not None:   # fixed capacity, count posted to a persistent slot, nothing waits (see deferred_count)
+            cap, s.deferred_count = defer.capacity, defer.take() + 1
         stream = _lib.raw_stream(dev)
         n_host = C.c_int64(0)
         replays = 0
@@ -232,9 +291,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                     raise RuntimeError(f"gsr_forward failed ({rc}): {msg}")
                 break
         I = int(n_host.value)
-        # next frame: 25 % headroom over what this one needed, never shrinking below it
-        _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
-        _last_info.update(num_rendered=I, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod,
+        if defer is not None:
+            I = cap      # unknown until the kernels have run: the backward takes the capacity as the bound
+        else:   # next frame: 25 % headroom over what this one needed, never shrinking below it
+            _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
+        _last_info.update(num_rendered=I if defer is None else -1, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod,
                           binning_path=int(bl.path), rank_bands=int(bl.nbands), bound=False)   # 0 rank path, 1 depth-ordered scatter, 2 per-tile sort (include/gsr.h)
         _last_binning[0] = binning
 
@@ -334,6 +395,9 @@ class _RasterizeBound(torch.autograd.Function):
         prod = _binning_layout(lib, 0, W, H, P, int(s.tile_culling)).path == 1
         key = (dev.index, H, W, prod)
         cap = _capacity_hint.get(key) or _round_cap((24 if prod else 8) * P)
+        defer = _deferred
+        if defer is not None:   # fixed capacity, count posted to a persistent slot, nothing waits (see deferred_count)
+            cap, s.deferred_count = defer.capacity, defer.take() + 1
         stream = _lib.raw_stream(dev)
         n_host = C.c_int64(0)
         replays = 0
@@ -352,8 +416,11 @@ class _RasterizeBound(torch.autograd.Function):
                     raise RuntimeError(f"gsr_forward_bound failed ({rc}): {_lib.gsr_error()}")
                 break
         I = int(n_host.value)
-        _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
-        _last_info.update(num_rendered=I, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod,
+        if defer is not None:
+            I = cap      # unknown until the kernels have run: the backward takes the capacity as the bound
+        else:
+            _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
+        _last_info.update(num_rendered=I if defer is None else -1, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod,
                           binning_path=int(bl.path), rank_bands=int(bl.nbands), bound=True)
         _last_binning[0] = binning
         ctx.raster_settings = raster_settings

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 7
+#define GSR_ABI_VERSION 8
 #define GSR_BWD_SEGMENT 60        /* stream entries per backward segment (a multiple of both blend kernels' batches)  */
 #define GSR_BWD_SEGMENTS 10       /* segments per quadrant stream; the last one takes whatever is left                */
 #define GSR_BIN_BLOCKS 256        /* workgroups of the two binning passes (each owns a contiguous chunk of splats) */
@@ -41,6 +41,7 @@ extern "C" {
 #define GSR_E_ARG (-1)
 #define GSR_E_HIP (-2)
 #define GSR_E_TIMEOUT (-3)
+#define GSR_COUNT_SLOTS 128  /* persistent instance-count slots of the deferred forwards (GsrSettings.deferred_count) */
 
 /* Mirrors the 12-field GaussianRasterizationSettings NamedTuple the reference constructs at
  * gaussian_renderer/__init__.py:37-50.  bg / viewmatrix / projmatrix / campos stay on the device
@@ -88,6 +89,14 @@ typedef struct GsrSettings {
                                  w.r.t. (scale_modifier * scale), WITHOUT the modifier's chain-rule factor;
                                  !=0: multiplied by scale_modifier (the mathematically exact gradient).  The two agree at
                                  the reference's scaling_modifier = 1.0 (gaussian_renderer/__init__.py:19). */
+    int32_t deferred_count;   /* 0 (default): gsr_forward waits for the frame's instance count, returns it and reports GSR_E_CAPACITY when the
+                                 binning buffer is too small (the caller grows it and calls again).
+                                 k in 1..GSR_COUNT_SLOTS: nothing waits -- the call only enqueues, *num_rendered_host is -1, and the count is
+                                 posted to persistent slot k-1 (gsr_count_slot_read) whenever the kernels get there.  Such a call contains no
+                                 host synchronisation, so it can be stream-captured and replayed as a hipGraph.  A frame whose count exceeds
+                                 binning_capacity skips its binning, blend and backward blend kernels (image and gradients of that frame are
+                                 NOT valid): the caller over-allocates (288 GB of HBM) and checks the slot after the fact.  gsr_backward of
+                                 such a state takes num_rendered = binning_capacity.                                              */
 } GsrSettings;
 
 /* Byte offsets of the arrays inside the three opaque state buffers.  The state buffers play the
@@ -190,6 +199,9 @@ typedef struct GsrImageLayout {
 
 int gsr_abi_version(void);
 const char* gsr_last_error(void);
+/* the newest post to persistent count slot `slot` (0..GSR_COUNT_SLOTS-1): *count = the frame's instances (-1: nothing posted yet),
+ * *seq = the posting frame's sequence number.  A plain read of mapped host memory, no synchronisation.                        */
+int gsr_count_slot_read(int32_t slot, int64_t* count, int64_t* seq);
 
 /* sizes/layouts of the state buffers (pure host arithmetic, no device access) */
 int gsr_geom_layout(int32_t P, GsrGeomLayout* out);

@@ -25,7 +25,7 @@ def test_gsr_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"include/gsr.h declares {n} but libgsr_hip.so does not export it"
         assert n in _lib.GSR_SYMBOLS, f"{n} has no ctypes prototype in _lib.GSR_SYMBOLS"
-    assert lib.gsr_abi_version() == 7
+    assert lib.gsr_abi_version() == 8
 
 
 def test_layouts_are_disjoint_and_aligned():

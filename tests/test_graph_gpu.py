@@ -1,0 +1,157 @@
+"""The frame step recorded once and replayed as ONE hipGraph launch (gaussianavatars_amd/graphs.py) against the same step run
+eagerly: same image bits, and -- with the deterministic backward -- the same splat-gradient bits, for every replayed timestep.  The
+recorded forward does not wait for its instance count (include/gsr.h: GsrSettings.deferred_count): a frame that overflows the
+recorded binning capacity must be reported, must not fault, and must be recoverable by recording again."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class _Pipe:
+    debug = False
+    compute_cov3D_python = False
+    convert_SHs_python = False
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _scene(dev, n=20000, frames=12):
+    from gaussianavatars_amd import synthetic as S
+    from gaussianavatars_amd.gaussian_model import FlameGaussianModel
+
+    g = FlameGaussianModel(3, S.flame_rig(seed=4), device=dev)
+    g.load_arrays(S.bound_splats(n, S.FLAME_F, 3, seed=2), device=dev, requires_grad=True)
+    g.load_flame_param(S.flame_sequence(frames, seed=4), device=dev, requires_grad=True)
+    cam = S.orbit_camera(208, 176, r=1.0, fovy_deg=20.0)
+    for k in ("world_view_transform", "full_proj_transform", "camera_center"):
+        setattr(cam, k, torch.as_tensor(getattr(cam, k), device=dev))
+    return g, cam
+
+
+_LEAVES = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
+
+
+def _zero(g):
+    from gaussianavatars_amd.graphs import release_mesh
+
+    release_mesh(g)
+    for n in _LEAVES:
+        getattr(g, n).grad = None
+    for v in g.flame_param.values():
+        if v.requires_grad:
+            v.grad = None
+
+
+def _step(g, cam, bg, target, t):
+    from gaussianavatars_amd.gaussian_renderer import l1_loss, render
+
+    g.select_mesh_by_timestep(t)
+    pkg = render(cam, g, _Pipe, bg)
+    loss = l1_loss(pkg["render"], target)
+    loss.backward()
+    return loss.detach(), pkg["render"].detach(), pkg["radii"], pkg["viewspace_points"]
+
+
+def test_graphed_step_equals_the_eager_step_frame_by_frame():
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd.graphs import FlameRowFeeder, GraphedStep
+
+    dev = _dev()
+    g, cam = _scene(dev)
+    bg = torch.ones(3, device=dev)
+    target = torch.full((3, 176, 208), 0.5, device=dev)
+    prev = R.set_deterministic(True)
+    try:
+        want = {}
+        full = g.flame_param
+        for t in (3, 7, 0):
+            _zero(g)
+            loss, img, radii, vsp = _step(g, cam, bg, target, t)
+            want[t] = dict(loss=loss.clone(), img=img.clone(), radii=radii.clone(), vsp=vsp.grad.clone(),
+                           leaves=[getattr(g, n).grad.clone() for n in _LEAVES],
+                           expr=full["expr"].grad[t].clone(), jaw=full["jaw_pose"].grad[t].clone(), n=R.last_forward_info()["num_rendered"])
+        feeder = FlameRowFeeder(full, requires_grad=True)
+        g.flame_param = feeder.static_param
+        step = GraphedStep(lambda: _step(g, cam, bg, target, 0), before_capture=lambda: _zero(g))
+        for t in (3, 7, 0, 7):
+            feeder.feed(t)
+            loss, img, radii, vsp = step.replay()
+            torch.cuda.synchronize()
+            step.check()
+            w = want[t]
+            assert step.instances() == [w["n"]]
+            assert torch.equal(img, w["img"]) and torch.equal(radii, w["radii"]) and torch.equal(loss, w["loss"]), t
+            assert torch.equal(vsp.grad, w["vsp"]), t
+            for n, a in zip(_LEAVES, w["leaves"]):
+                assert torch.equal(getattr(g, n).grad, a), (t, n)
+            # (the FLAME backward sums with float atomics: equal up to summation order)
+            for k, ref in (("expr", w["expr"]), ("jaw_pose", w["jaw"])):
+                got = feeder.static_param[k].grad[0]
+                assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-12, (t, k)
+        assert step.replays == 4 and step.capacity >= 4 * max(v["n"] for v in want.values()) - (1 << 16)
+        step.close()
+    finally:
+        R.set_deterministic(prev)
+
+
+def test_overflowing_frame_is_reported_and_recapture_recovers():
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd.graphs import CapacityOverflow, FlameRowFeeder, GraphedStep
+
+    dev = _dev()
+    g, cam = _scene(dev, n=60000)
+    bg = torch.ones(3, device=dev)
+    target = torch.full((3, 176, 208), 0.5, device=dev)
+    feeder = FlameRowFeeder(g.flame_param, requires_grad=True)
+    g.flame_param = feeder.static_param
+    _zero(g)
+    _step(g, cam, bg, target, 0)
+    need = R.last_forward_info()["num_rendered"]
+    assert need > 2 * (1 << 16), "the scene must need more than the smallest capacity the library hands out"
+    step = GraphedStep(lambda: _step(g, cam, bg, target, 0), before_capture=lambda: _zero(g), headroom=0.2)
+    assert step.capacity < need
+    step.replay()
+    torch.cuda.synchronize()          # an overflowing frame skips its kernels: nothing faults
+    assert step.instances() == [need]
+    with pytest.raises(CapacityOverflow):
+        step.check()
+    step.recapture(headroom=2.0)
+    feeder.feed(5)
+    loss, img, _, _ = step.replay()
+    torch.cuda.synchronize()
+    step.check()
+    assert step.capacity >= need and float(loss) > 0 and bool(torch.isfinite(img).all())
+    g.flame_param = feeder.static_param
+    _zero(g)
+    feeder.feed(5)
+    eager = _step(g, cam, bg, target, 0)
+    assert torch.equal(eager[1], img)
+    step.close()
+
+
+def test_deferred_count_outside_a_graph():
+    """The deferred forward by itself (run-ahead without a recording): same image, the count arrives in the slot."""
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd.gaussian_renderer import render
+
+    dev = _dev()
+    g, cam = _scene(dev)
+    bg = torch.ones(3, device=dev)
+    free0 = len(R._free_slots)
+    with torch.no_grad():
+        g.select_mesh_by_timestep(2)
+        ref = render(cam, g, _Pipe, bg)["render"].clone()
+        need = R.last_forward_info()["num_rendered"]
+        with R.deferred_count(2 * need) as d:
+            img = render(cam, g, _Pipe, bg)["render"]
+        torch.cuda.synchronize()
+    assert d.counts() == [need] and torch.equal(img, ref)
+    assert R.last_forward_info()["num_rendered"] == -1
+    d.release()
+    assert len(R._free_slots) == free0
