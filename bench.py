@@ -316,9 +316,14 @@ def main():
             feeder = FlameRowFeeder(g.flame_param, requires_grad=train)
             g.flame_param = feeder.static_param
 
+        loss_sum = torch.zeros((), dtype=torch.float32, device=device)
+
         def fixed_step():
             with torch.set_grad_enabled(train):
-                return one_step(g, cam, bg, target, 0, train)
+                l = one_step(g, cam, bg, target, 0, train)
+            if dist is None and train:
+                loss_sum.add_(l)
+            return l
 
         def eager_fed(t):   # the per-kernel event pass stays eager (events are recorded around the launches)
             if feeder is not None:
@@ -337,7 +342,16 @@ def main():
                 feeder.feed(t)
             return graphed.replay().clone()   # the recorded scalar is overwritten by the next replay
 
-        run = make_runner(graph_step, my_frames, dist, device)
+        if dist is not None:
+            run = make_runner(graph_step, my_frames, dist, device)   # (the per-step all-reduce takes its copy of the scalar anyway)
+        else:
+            def run(n, offset):   # one rank: the recorded step adds its loss to a static accumulator, nothing else runs per step
+                loss_sum.zero_()
+                for i in range(n):
+                    if feeder is not None:
+                        feeder.feed(my_frames[(offset + i) % len(my_frames)])
+                    graphed.replay()
+                return loss_sum.clone()
 
     def fence():
         if dist is not None:

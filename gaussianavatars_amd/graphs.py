@@ -152,22 +152,17 @@ class FlameRowFeeder:
         self.T = int(tabs[0].shape[0])
         self.packed = torch.cat([t.reshape(self.T, -1).float() for t in tabs], dim=1).contiguous()
         self.row = self.packed[:1].clone()
-        self.static_param = {k: v for k, v in flame_param.items() if k not in self.ROWS and k != "dynamic_offset"}
+        # (shape, static_offset and dynamic_offset pass through: FlameHead.forward accepts dynamic_offset and never reads it,
+        #  flame_model/flame.py:498)
+        self.static_param = {k: v for k, v in flame_param.items() if k not in self.ROWS}
         off = 0
         for k, t in zip(self.ROWS, tabs):
             w = int(t.reshape(self.T, -1).shape[1])
             view = self.row[:, off:off + w]
             self.static_param[k] = view.requires_grad_(True) if requires_grad else view
             off += w
-        if "dynamic_offset" in flame_param:   # (T, V, 3): fed the same way
-            self.dyn_all = flame_param["dynamic_offset"].detach()
-            self.static_param["dynamic_offset"] = self.dyn_all[:1].clone()
-        else:
-            self.dyn_all = None
 
     def feed(self, t: int) -> None:
         t = int(t) % self.T
         with torch.no_grad():
             self.row.copy_(self.packed[t:t + 1])
-            if self.dyn_all is not None:
-                self.static_param["dynamic_offset"].copy_(self.dyn_all[t:t + 1])

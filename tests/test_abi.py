@@ -139,3 +139,27 @@ def test_rasterizer_refuses_cpu_tensors():
     rs = GaussianRasterizationSettings(16, 16, 0.5, 0.5, z(3), 1.0, torch.eye(4), torch.eye(4), 0, z(3), False, False)
     with pytest.raises(RuntimeError, match="no CPU path"):
         GaussianRasterizer(rs)(means3D=z(2, 3), means2D=z(2, 3), opacities=z(2, 1), shs=z(2, 1, 3), scales=z(2, 3), rotations=z(2, 4))
+
+
+def test_deferred_count_slots_are_a_finite_pool():
+    """rasterizer.deferred_count hands every forward inside it one of the GSR_COUNT_SLOTS persistent slots of include/gsr.h
+    (GsrSettings.deferred_count); release() returns them; running out is an error, not a silent reuse."""
+    import pytest
+
+    from gaussianavatars_amd import _lib
+    from gaussianavatars_amd import rasterizer as R
+
+    assert _lib.GSR_COUNT_SLOTS == 128 and "deferred_count" in [f[0] for f in _lib.GsrSettings._fields_]
+    free0 = len(R._free_slots)
+    with R.deferred_count(1000) as d:
+        assert R._deferred is d and d.capacity == 1 << 16        # capacities come in 64 K quanta
+        taken = [d.take() for _ in range(3)]
+    assert R._deferred is None and len(set(taken)) == 3 and len(R._free_slots) == free0 - 3
+    many = R._Deferred(1)
+    for _ in range(free0 - 3):
+        many.take()
+    with pytest.raises(RuntimeError, match="slots are in use"):
+        many.take()
+    many.release()
+    d.release()
+    assert sorted(R._free_slots) == list(range(128)) and len(R._free_slots) == free0
