@@ -107,7 +107,7 @@ def one_step(g, cam, bg, target, t, train):
 def zero_grads(g):
     for p in (g._xyz, g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity):
         p.grad = None
-    if g.flame_param is not None:
+    if getattr(g, "flame_param", None) is not None:
         for v in g.flame_param.values():
             if v.requires_grad:
                 v.grad = None
@@ -256,6 +256,11 @@ def main():
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="record the frame step once and replay it as one hipGraph launch per step (gaussianavatars_amd.graphs.GraphedStep)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="with --graph: this many recordings on this many streams, frames dealt to them in turn (frame parallelism inside one GPU)")
+    ap.add_argument("--frame-streams", type=int, default=4,
+                    help="N=1, eager default run only: after the timed rounds, the same workload again as this many recorded frame "
+                         "lanes (reported beside `value` as `frame_streams`); 0 skips the leg")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the process next to its GPU (host-sensitivity runs)")
     args = ap.parse_args()
     if args.workload == "cfg3" and args.mode == "render":
@@ -305,53 +310,86 @@ def main():
             return one_step(g, cam, bg, target, t, train)
 
     run = make_runner(step_fn, my_frames, dist, device, post_step=(lambda: zero_grads(g)) if train else None)
-    run_eager, graphed = run, None
-    if args.graph:
-        # the same step recorded once and replayed: the frame's FLAME parameters are fed into static one-row tables (one copy),
-        # the gradients land in static .grad tensors (no zero_grads: every replay rewrites them)
+    run_eager, graphed, lanes = run, None, []
+    if args.streams > 1 and not args.graph:
+        raise SystemExit("--streams needs --graph (two eager frame loops in one process are host-bound)")
+    if args.streams > 1 and dist is not None:
+        raise SystemExit("--streams > 1 is a single-rank experiment")
+
+    def build_lanes(n_lanes):
+        """The step recorded once per lane and replayed (gaussianavatars_amd.graphs): the frame's FLAME parameters are fed into
+        static one-row tables (one copy), the gradients land in static .grad tensors (no zero_grads: every replay rewrites
+        them).  More than one lane: one recording per stream, each with a replica of the model (its own static inputs and
+        gradients, as a second rank would have); consecutive frames go to the lanes in turn, so independent frames overlap
+        on the GPU the way they do across GPUs."""
         from gaussianavatars_amd.graphs import FlameRowFeeder, GraphedStep, release_mesh
 
-        feeder = None
-        if g.binding is not None:
-            feeder = FlameRowFeeder(g.flame_param, requires_grad=train)
-            g.flame_param = feeder.static_param
+        def make_lane(gm):
+            feeder = None
+            if gm.binding is not None:
+                feeder = FlameRowFeeder(gm.flame_param, requires_grad=train)
+                gm.flame_param = feeder.static_param
+            loss_sum = torch.zeros((), dtype=torch.float32, device=device)
 
-        loss_sum = torch.zeros((), dtype=torch.float32, device=device)
+            def fixed_step():
+                with torch.set_grad_enabled(train):
+                    l = one_step(gm, cam, bg, target, 0, train)
+                if dist is None and train:
+                    loss_sum.add_(l)
+                return l
 
-        def fixed_step():
-            with torch.set_grad_enabled(train):
-                l = one_step(g, cam, bg, target, 0, train)
-            if dist is None and train:
-                loss_sum.add_(l)
-            return l
+            def fresh():   # no gradients and no autograd graph of an earlier frame when the step is recorded
+                zero_grads(gm)
+                release_mesh(gm)
+
+            return dict(g=gm, feeder=feeder, loss_sum=loss_sum, fixed_step=fixed_step, stream=torch.cuda.Stream(device),
+                        graphed=GraphedStep(fixed_step, before_capture=fresh))
+
+        out = [make_lane(g)]
+        for _ in range(1, n_lanes):
+            if args.workload == "cfg5":
+                gk, _ = build_unbound_scene(device, args.splats, 3, args.width, args.height)
+            else:
+                gk, _ = build_scene(device, args.splats, 3, args.width, args.height, args.frames, args.binding, train)
+            out.append(make_lane(gk))
+        return out
+
+    def lane_runner(lanes):
+        def run(n, offset):   # one rank: the recorded step adds its loss to a static accumulator, nothing else runs per step
+            cur = torch.cuda.current_stream(device)
+            for ln in lanes:
+                ln["stream"].wait_stream(cur)
+                with torch.cuda.stream(ln["stream"]):
+                    ln["loss_sum"].zero_()
+            for i in range(n):
+                ln = lanes[i % len(lanes)]
+                with torch.cuda.stream(ln["stream"]):
+                    if ln["feeder"] is not None:
+                        ln["feeder"].feed(my_frames[(offset + i) % len(my_frames)])
+                    ln["graphed"].replay()
+            for ln in lanes:
+                cur.wait_stream(ln["stream"])
+            return torch.stack([ln["loss_sum"] for ln in lanes]).sum()
+
+        return run
+
+    if args.graph:
+        lanes = build_lanes(args.streams)
+        graphed = lanes[0]["graphed"]
 
         def eager_fed(t):   # the per-kernel event pass stays eager (events are recorded around the launches)
-            if feeder is not None:
-                feeder.feed(t)
-            return fixed_step()
+            if lanes[0]["feeder"] is not None:
+                lanes[0]["feeder"].feed(t)
+            return lanes[0]["fixed_step"]()
 
         run_eager = make_runner(eager_fed, my_frames, dist, device, post_step=(lambda: zero_grads(g)) if train else None)
-        def fresh():   # no gradients and no autograd graph of an earlier frame when the step is recorded
-            zero_grads(g)
-            release_mesh(g)
-
-        graphed = GraphedStep(fixed_step, before_capture=fresh)
 
         def graph_step(t):
-            if feeder is not None:
-                feeder.feed(t)
+            if lanes[0]["feeder"] is not None:
+                lanes[0]["feeder"].feed(t)
             return graphed.replay().clone()   # the recorded scalar is overwritten by the next replay
 
-        if dist is not None:
-            run = make_runner(graph_step, my_frames, dist, device)   # (the per-step all-reduce takes its copy of the scalar anyway)
-        else:
-            def run(n, offset):   # one rank: the recorded step adds its loss to a static accumulator, nothing else runs per step
-                loss_sum.zero_()
-                for i in range(n):
-                    if feeder is not None:
-                        feeder.feed(my_frames[(offset + i) % len(my_frames)])
-                    graphed.replay()
-                return loss_sum.clone()
+        run = make_runner(graph_step, my_frames, dist, device) if dist is not None else lane_runner(lanes)   # (the per-step all-reduce takes its copy of the scalar anyway)
 
     def fence():
         if dist is not None:
@@ -364,7 +402,8 @@ def main():
     wait_ms, waits = _lib.gsr_wait_stats()
     info = R.last_forward_info()
     if graphed is not None:
-        graphed.check()                                   # every replayed frame fitted the recorded binning capacity
+        for ln in lanes:
+            ln["graphed"].check()                         # every replayed frame fitted the recorded binning capacity
         info["num_rendered"] = max(graphed.instances())   # (the recording itself did not know its count)
 
     # ---- per-kernel durations: HIP events on the launch stream (recorded by the C ABI around every kernel).
@@ -379,6 +418,22 @@ def main():
         _lib.gsr_profile_enable(False)
     if dist is not None:
         dist.barrier()
+
+    # ---- frame parallelism INSIDE the GPU (reported beside `value`, never as `value`): the same workload as --frame-streams
+    # recorded lanes on as many streams.  Independent frames -- what the ranks of a multi-GPU run process side by side -- overlap
+    # on one GPU too: one frame's serial tails and 20-workgroup kernels leave most of the 256 CUs idle.
+    frame_streams = None
+    if rank == 0 and world == 1 and not args.graph and args.frame_streams > 1:
+        fs_lanes = build_lanes(args.frame_streams)
+        fs_rounds = timed_rounds(lane_runner(fs_lanes), fence, args.steps, args.warmup, None, device, min_rounds=args.rounds,
+                                 min_seconds=args.min_seconds)
+        for ln in fs_lanes:
+            ln["graphed"].check()
+        fs_el = float(np.median(fs_rounds))
+        frame_streams = {"streams": len(fs_lanes), "value": round(args.steps / fs_el, 2), "unit": "frames/s",
+                         "ms_per_step": round(1e3 * fs_el / args.steps, 4),
+                         "what": "the same steps dealt in turn to recorded (hipGraph) lanes on separate streams, one model replica per lane; "
+                                 "ms_per_step = elapsed / steps, not the latency of one frame"}
 
     if rank == 0:
         N, HW = args.splats, args.width * args.height
@@ -497,16 +552,19 @@ def main():
                 "visible_fraction": round(vis, 4), "binding": args.binding,
                 "parallelism": (f"frame-parallel x{n_gpus}: {dist.get_world_size() if dist is not None else 1} "
                                 f"{'RCCL (torch nccl)' if dist is not None else 'single-process'} rank(s), frames per rank {counts}, "
-                                "one asynchronous scalar all-reduce (loss) per step"),
+                                "one asynchronous scalar all-reduce (loss) per step"
+                                + (f"; {len(lanes)} frame streams inside the GPU (independent frames overlap; ms_per_step is elapsed / steps, "
+                                   f"not the latency of one frame)" if len(lanes) > 1 else "")),
             },
             # every timed round is exactly `steps` steps (barrier + device sync on both sides, MAX over ranks); value = median round
             "rounds": {"n": len(rounds), "frames_per_s": [round(n_gpus * args.steps / r, 2) for r in rounds],
                        "timed_seconds": round(float(sum(rounds)), 4)},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "frame_streams": frame_streams,
             # the frame's single host wait (for the instance count): ~0 would mean the host paces the loop, not the GPU
             "host": {"scan_wait_ms_per_step": round(wait_ms / max(waits, 1), 4), "pinned_cpus": len(pinned) if pinned else None,
-                     "step_launch": ("hipGraph replay (one launch per step; binning capacity %d for %d instances)" % (graphed.capacity, max(graphed.instances())))
+                     "step_launch": ("hipGraph replay (one launch per step; binning capacity %d for %d instances; %d frame stream(s))" % (graphed.capacity, max(graphed.instances()), len(lanes)))
                                     if graphed is not None else "eager (one Python-driven launch per kernel)"},
         }
         print(json.dumps(out))

@@ -6,7 +6,7 @@ TAG=${1:-r02_x}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-profile"
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-profile --frame-streams 0"
 cd $GRAFT_REPO_ROOT
 for W in cfg3 cfg4 cfg5; do
   if [ $W = cfg3 ]; then S="--steps 60 --warmup 15 --rounds 1 --min-seconds 0"; else S="--steps 30 --warmup 8 --rounds 1 --min-seconds 0"; fi
