@@ -424,16 +424,23 @@ def main():
     # on one GPU too: one frame's serial tails and 20-workgroup kernels leave most of the 256 CUs idle.
     frame_streams = None
     if rank == 0 and world == 1 and not args.graph and args.frame_streams > 1:
-        fs_lanes = build_lanes(args.frame_streams)
-        fs_rounds = timed_rounds(lane_runner(fs_lanes), fence, args.steps, args.warmup, None, device, min_rounds=args.rounds,
-                                 min_seconds=args.min_seconds)
-        for ln in fs_lanes:
-            ln["graphed"].check()
-        fs_el = float(np.median(fs_rounds))
-        frame_streams = {"streams": len(fs_lanes), "value": round(args.steps / fs_el, 2), "unit": "frames/s",
-                         "ms_per_step": round(1e3 * fs_el / args.steps, 4),
-                         "what": "the same steps dealt in turn to recorded (hipGraph) lanes on separate streams, one model replica per lane; "
-                                 "ms_per_step = elapsed / steps, not the latency of one frame"}
+        # in a process of its own: whatever happens to the recording cannot take the line above with it
+        import subprocess
+
+        cmd = [sys.executable, os.path.abspath(__file__), "--graph", "--streams", str(args.frame_streams), "--frame-streams", "0",
+               "--no-cpu-baseline", "--no-kernel-profile", "--workload", args.workload, "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--rounds", str(args.rounds), "--min-seconds", str(args.min_seconds), "--splats", str(args.splats), "--width", str(args.width),
+               "--height", str(args.height), "--frames", str(args.frames), "--binding", args.binding] + (["--no-pin"] if args.no_pin else [])
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            sub = json.loads(out.stdout.strip().splitlines()[-1])
+            frame_streams = {"streams": args.frame_streams, "value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"],
+                             "rounds": sub["rounds"]["n"],
+                             "what": "the same steps dealt in turn to recorded (hipGraph) lanes on separate streams, one model replica per lane "
+                                     "(`bench.py --graph --streams %d`, run as a child process after the timed rounds above); "
+                                     "ms_per_step = elapsed / steps, not the latency of one frame" % args.frame_streams}
+        except Exception as e:   # noqa: BLE001 -- the leg is extra evidence, never a reason to lose the line
+            frame_streams = {"streams": args.frame_streams, "error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
     if rank == 0:
         N, HW = args.splats, args.width * args.height
