@@ -159,6 +159,14 @@ def gsr_wait_stats():
 _gsr = None
 
 
+def _torch_first():
+    """The libraries take raw device pointers of torch tensors and launch on torch's streams, so they have to share torch's HIP
+    runtime: torch is imported before the first library is mapped.  (Mapped first -- e.g. build() followed by smoke() in one
+    process -- they pull in /opt/rocm's libamdhip64 ahead of the copy torch ships, and the first runtime call that needs the
+    device fails with 'no ROCm-capable device is detected'.)"""
+    import torch  # noqa: F401
+
+
 def gsr():
     """The rasterizer library; raises (never falls back) when it is not built."""
     global _gsr
@@ -168,6 +176,7 @@ def gsr():
                 f"{GSR_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
             )
+        _torch_first()
         lib = C.CDLL(GSR_LIB_PATH)
         for name, (res, args) in GSR_SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
@@ -223,6 +232,7 @@ def gab():
     if _gab is None:
         if not os.path.exists(GAB_LIB_PATH):
             raise RuntimeError(f"{GAB_LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950).  There is no CPU fallback.")
+        _torch_first()
         lib = C.CDLL(GAB_LIB_PATH)
         for name, (res, args) in GAB_SYMBOLS.items():
             fn = getattr(lib, name)
@@ -258,6 +268,7 @@ def gls():
     if _gls is None:
         if not os.path.exists(GLS_LIB_PATH):
             raise RuntimeError(f"{GLS_LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950).  There is no CPU fallback.")
+        _torch_first()
         lib = C.CDLL(GLS_LIB_PATH)
         for name, (res, args) in GLS_SYMBOLS.items():
             fn = getattr(lib, name)
