@@ -140,18 +140,21 @@ int check_settings(const GsrSettings* s)
 // something to repeat per frame (nor inside a stream capture)
 int ensure_dynamic_lds(const void* fn, size_t bytes)
 {
+    struct Seen { const void* fn; int device; size_t bytes; };
     static std::mutex mu;
-    static std::vector<std::pair<const void*, size_t>> seen;
+    static std::vector<Seen> seen;
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));   // the attribute belongs to the kernel's code object on ONE device
     std::lock_guard<std::mutex> lk(mu);
     for (auto& e : seen)
-        if (e.first == fn) {
-            if (e.second >= bytes) return 0;
+        if (e.fn == fn && e.device == device) {
+            if (e.bytes >= bytes) return 0;
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-            e.second = bytes;
+            e.bytes = bytes;
             return 0;
         }
     HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    seen.emplace_back(fn, bytes);
+    seen.push_back({fn, device, bytes});
     return 0;
 }
 
