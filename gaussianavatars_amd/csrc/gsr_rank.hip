@@ -635,8 +635,9 @@ __device__ __forceinline__ void tile_streams(uint32_t total, uint32_t n, uint32_
 }
 
 // ------------------------------------------------------------------------------------------
-// k_tile_rank: one workgroup per tile (heaviest first), one pass (the API takes this path only while every rank of the frame
-// fits the bitmap: WORDS * 32 >= P):
+// k_tile_rank: one workgroup per tile (heaviest first).  The tile's rank space is the frame's binned splats, or -- frames beyond
+// GSR_RANK_MAX_SPLATS splats -- those of the tile's band of tile rows; it fits the bitmap (`words` * 32 ranks) in one pass unless
+// a single band holds more than GSR_RANK_MAX_SPLATS splats, in which case the four steps below repeat per slice of the space:
 //   1. bitmap[r >> 5] |= 1 << (r & 31) for the tile's (rank, splat) entries (ds_or)
 //   2. rows of 64 words go round-robin to the waves: a wave scan of the popcounts gives every word its offset inside the row
 //      (wprefix, 16 bit), the row totals are scanned by wave 0 -> rowoff[]
