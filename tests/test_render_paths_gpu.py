@@ -138,6 +138,36 @@ def test_bound_entry_equals_accessors_plus_rasterizer():
         close(x, y, 2e-5, "deterministic d" + name)
 
 
+def test_bound_entry_on_a_frame_large_enough_for_band_ranks():
+    """300 000 bound splats at 1600 x 1100: past 262144 splats the rank path ranks per band of tile rows (csrc/gsr_rank.hip), and the
+    bound entry feeds it.  Same image / radii bits as the accessor path, gradients to summation order."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import bench
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd.gaussian_renderer import render
+
+    dev = torch.device("cuda:0")
+    H, W, N = 1100, 1600, 300_000
+    g, cam = bench.build_scene(dev, N, 3, W, H, 4, "fused", True)
+    bg = torch.ones(3, device=dev)
+    out = {}
+    for fast in (True, False):
+        g.bound_render = fast
+        bench.zero_grads(g)
+        g.select_mesh_by_timestep(1)
+        pkg = render(cam, g, bench.Pipe, bg)
+        info = R.last_forward_info()
+        assert bool(info.get("bound", False)) == fast and info["binning_path"] == 0 and info["rank_bands"] > 1, info
+        pkg["render"].mean().backward()
+        out[fast] = (pkg["render"].detach().clone(), pkg["radii"].clone(), g._xyz.grad.clone(), g._features_rest.grad.clone(), info["num_rendered"])
+    a, b = out[True], out[False]
+    assert a[4] == b[4] and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[1], b[1])
+    for x, y, what in ((a[2], b[2], "d_xyz"), (a[3], b[3], "d_features_rest")):
+        err = float((x.double() - y.double()).abs().max()) / (float(y.double().abs().max()) + 1e-30)
+        assert err < 5e-5, f"{what}: rel err {err:.3e}"
+
+
 def test_unbound_leaves_entry_equals_torch_activations_plus_rasterizer():
     """An UNBOUND model through the same entry without faces (rasterizer.rasterize_leaves): exp / normalize / sigmoid of
     scene/gaussian_model.py:113-160 evaluated in the first kernel instead of three torch launches.  Against the reference-shaped path
