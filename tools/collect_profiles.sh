@@ -23,4 +23,11 @@ python bench.py --steps 150 --warmup 30 --no-cpu-baseline 2>/dev/null | tail -1 
 python bench.py --workload cfg2 --steps 300 --warmup 40 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg2.json
 python bench.py --workload cfg4 --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg4.json
 python bench.py --workload cfg5 --steps 40 --warmup 8 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg5.json
+# the plain default line (cpu_baseline, frame_streams leg), the train workload, and the recorded step pinned / un-pinned beside the eager loop un-pinned
+python bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench_default.json
+python bench.py --workload train --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_train.json
+G="--steps 200 --warmup 30 --no-cpu-baseline --no-kernel-profile --frame-streams 0"
+python bench.py --graph $G 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3_graph.json
+python bench.py --graph --no-pin $G 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3_graph_unpinned.json
+python bench.py --no-pin $G 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3_eager_unpinned.json
 ls -la $OUT
