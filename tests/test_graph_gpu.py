@@ -204,3 +204,46 @@ def test_recorded_lanes_on_separate_streams_do_not_disturb_each_other():
             step.close()
     finally:
         R.set_deterministic(prev)
+
+
+def test_recorded_step_in_a_training_loop_with_an_optimiser():
+    """INTEGRATION.md 3c as written: feed, replay, optimizer.step() on the static .grad tensors.  Three Adam iterations through the
+    recorded step leave the parameters where three eager iterations leave them (deterministic backward: bit for bit for the
+    splat leaves)."""
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd.graphs import FlameRowFeeder, GraphedStep
+
+    dev = _dev()
+    bg = torch.ones(3, device=dev)
+    target = torch.full((3, 176, 208), 0.5, device=dev)
+    frames = (2, 5, 9)
+    prev = R.set_deterministic(True)
+    try:
+        def params(g):
+            return [getattr(g, n) for n in _LEAVES]
+
+        # eager
+        g, cam = _scene(dev)
+        opt = torch.optim.Adam(params(g), lr=1e-3)
+        for t in frames:
+            _zero(g)
+            _step(g, cam, bg, target, t)
+            opt.step()
+        want = [p.detach().clone() for p in params(g)]
+        # recorded
+        g, cam = _scene(dev)
+        feeder = FlameRowFeeder(g.flame_param, requires_grad=True)
+        g.flame_param = feeder.static_param
+        opt = torch.optim.Adam(params(g), lr=1e-3)
+        step = GraphedStep(lambda: _step(g, cam, bg, target, 0), before_capture=lambda: _zero(g))
+        for t in frames:
+            feeder.feed(t)
+            step.replay()
+            opt.step()              # reads the static .grad tensors the replay just rewrote
+        torch.cuda.synchronize()
+        step.check()
+        for n, p, w in zip(_LEAVES, params(g), want):
+            assert torch.equal(p.detach(), w), n
+        step.close()
+    finally:
+        R.set_deterministic(prev)
