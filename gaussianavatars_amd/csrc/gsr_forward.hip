@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
     uint32_t clampbits = 0;
     int radius = 0;
     int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
+    int sum_exp = 0;
 
     if (i < a.P) {
         const float* vm = s.viewmatrix;
@@ -227,29 +228,54 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         const uint32_t n = visible ? (uint32_t)((rmaxx - rminx) * (rmaxy - rminy)) : 0u;
         a.radii[i] = radius;
         a.depths[i] = depth;
-        a.grec[3 * i + 0] = make_float4(px, py, con0, con1);
-        a.grec[3 * i + 1] = make_float4(con2, opac, col[0], col[1]);
-        // .y: the splat's two fixed-point exponents for the deterministic backward (gsr_device.h: GSR_FIXED_BITS), as an integer in float bits
-        a.grec[3 * i + 2] = make_float4(col[2], __int_as_float(visible ? splat_sum_exponents(n, con0, con1, con2, W, H) : 0), 0.f, 0.f);
+        // .y of the third: the splat's two fixed-point exponents for the deterministic backward (gsr_device.h: GSR_FIXED_BITS), as an integer in float bits
+        sum_exp = visible ? splat_sum_exponents(n, con0, con1, con2, W, H) : 0;
         // forward_only (no backward can follow): what only the backward reads -- cov3D, the clamp flags, and on the rank path (which
         // bins by srect) the rect -- is not written: 33 of ~134 bytes per splat
-        if (!s.forward_only) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) a.cov3D[6 * i + k] = c6[k];
-            a.clamped[i] = (uint8_t)clampbits;
-        }
+        if (!s.forward_only) a.clamped[i] = (uint8_t)clampbits;
         if (!s.forward_only || !a.pstat)
             a.rect[i] = make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy);
         a.tiles_touched[i] = n;
         a.visible[i] = radius > 0 ? (uint8_t)1 : (uint8_t)0;
-        if (visible && !s.forward_only) {   // the backward's accumulators start at zero (skipped when no backward can follow)
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s.deterministic) {
+    }
+    // ---- the per-splat ROWS (48-byte record, 24-byte covariance, 32-byte span): a thread storing its own row writes 16 bytes into
+    // each of 64 different lines per instruction, and the lines leave L2 in pieces (PMC: 355 MB written for 202 MB at 2 M splats).
+    // The workgroup's rows are contiguous in memory, so they go through LDS and out as whole lines, a kilobyte per wave-instruction.
+    __shared__ float4 stage[256 * 3];
+    const int first = (int)(blockIdx.x * blockDim.x), rows = min(256, a.P - first), tix = (int)threadIdx.x;
+    auto put_rows = [&](auto* dst, const auto* mine, auto per_row) {   // dst: global array of the row elements, mine[per_row]: this thread's row
+        constexpr int K = decltype(per_row)::value;
+        using E = std::remove_cv_t<std::remove_reference_t<decltype(mine[0])>>;
+        E* lds = reinterpret_cast<E*>(stage);
 #pragma unroll
-                for (int k = 0; k < 5; ++k) a.acc64[5 * i + k] = z;   // 80 bytes of fixed-point sums
-            } else {
-                a.acc[3 * i + 0] = z; a.acc[3 * i + 1] = z; a.acc[3 * i + 2] = z;
-            }
+        for (int k = 0; k < K; ++k) lds[K * tix + k] = mine[k];
+        __syncthreads();
+        E* out = dst + (size_t)K * first;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int e = tix + 256 * k;
+            if (e < K * rows) out[e] = lds[e];
+        }
+        __syncthreads();
+    };
+    {
+        const float4 rec[3] = {make_float4(px, py, con0, con1), make_float4(con2, opac, col[0], col[1]),
+                               make_float4(col[2], __int_as_float(sum_exp), 0.f, 0.f)};
+        put_rows(a.grec, rec, std::integral_constant<int, 3>{});
+    }
+    if (!s.forward_only) {
+        const float2 cv[3] = {make_float2(c6[0], c6[1]), make_float2(c6[2], c6[3]), make_float2(c6[4], c6[5])};
+        put_rows(reinterpret_cast<float2*>(a.cov3D), cv, std::integral_constant<int, 3>{});
+        // the backward's accumulators start at zero (skipped when no backward can follow): every row of the workgroup, whole lines
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s.deterministic) {
+            float4* out = a.acc64 + (size_t)5 * first;   // 80 bytes of fixed-point sums per splat
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { const int e = tix + 256 * k; if (e < 5 * rows) out[e] = z; }
+        } else {
+            float4* out = a.acc + (size_t)3 * first;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const int e = tix + 256 * k; if (e < 3 * rows) out[e] = z; }
         }
     }
     if (a.pstat) {
@@ -263,6 +289,7 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
             a.pstat[blockIdx.x] = make_uint2(~max(max(ps_mn[0], ps_mn[1]), max(ps_mn[2], ps_mn[3])), max(max(ps_mx[0], ps_mx[1]), max(ps_mx[2], ps_mx[3])));
         // the tile rect this splat is binned into (snug in the culling modes) and the operands of the per-quadrant reach test
         // (gsr_device.h: band_of): computed here, once per splat, for the two binning passes that expand the rect
+        float4 span2[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};   // (rows of splats that are not binned are never read)
         if (i < a.P) {
             uint32_t nt = 0;
             int minx = rminx, miny = rminy, maxx = rmaxx, maxy = rmaxy;
@@ -272,12 +299,13 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
                 if (a.cull) snug_rect(r, minx, miny, maxx, maxy, nt);
                 if (nt) {
                     const Span sp = span_of(r);
-                    a.sspan[2 * i + 0] = make_float4(sp.px, sp.py, sp.B, sp.det);
-                    a.sspan[2 * i + 1] = make_float4(sp.twoTA, sp.A, sp.dyr, __int_as_float(sp.mode));
+                    span2[0] = make_float4(sp.px, sp.py, sp.B, sp.det);
+                    span2[1] = make_float4(sp.twoTA, sp.A, sp.dyr, __int_as_float(sp.mode));
                 }
             }
             a.srect[i] = nt ? make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy) : make_ushort4(0, 0, 0, 0);
         }
+        put_rows(a.sspan, span2, std::integral_constant<int, 2>{});
     }
     if (a.brec) {
         // ---- binning record: operands of the exact reach test and the quadrant rect to run it on (= 2 x the snug TILE rect, so that
