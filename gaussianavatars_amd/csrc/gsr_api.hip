@@ -414,7 +414,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     const bool deferred = settings->deferred_count != 0;
     const size_t slot_index = deferred ? (size_t)Mailbox::kSlots + (size_t)(settings->deferred_count - 1) : (size_t)(seq % Mailbox::kSlots);
     volatile unsigned long long* slot = g_mail.host + slot_index;
-    if (!deferred) *slot = 0;
+    *slot = 0;   // (a persistent slot may still hold what its previous owner's last frame posted)
     unsigned long long* slot_dev = g_mail.dev + slot_index;
     const unsigned long long cap = (unsigned long long)binning_capacity;
     uint32_t* tile_order = (uint32_t*)(b + bl.tile_order);

@@ -91,11 +91,16 @@ class GraphedStep:
         if self.before_capture is not None:
             self.before_capture()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
-            with _R.deferred_count(self._state):
-                self.out = self.fn()
-        if not self._state.slots:
-            raise RuntimeError("GraphedStep: fn() issued no rasterizer forward")
+        try:
+            with torch.cuda.graph(self.graph, stream=side):
+                with _R.deferred_count(self._state):
+                    self.out = self.fn()
+            if not self._state.slots:
+                raise RuntimeError("GraphedStep: fn() issued no rasterizer forward")
+        except BaseException:
+            self._state.release()   # the count slots go back to the pool whatever went wrong in the recording
+            self._state = None
+            raise
 
     @property
     def capacity(self) -> int:
