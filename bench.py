@@ -10,9 +10,16 @@ fps_benchmark_demo.py:21-33).  Inputs are resident in HBM before the timed regio
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|render] [--binding fused|unfused]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU): every rank holds a replica of the
-splats and renders its own frames (frame-parallel, weak scaling); the only collective is the
-all-reduce of the scalar loss (RCCL over xGMI).  Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU, every rank holds a replica of the splats and renders its own frames
+(frame-parallel, weak scaling); the only collective is the all-reduce of the scalar loss (RCCL over
+xGMI).  Rank 0 prints ONE JSON line.  Either an external `python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...` provides the ranks (RANK / LOCAL_RANK / WORLD_SIZE in the
+environment), or plain `python bench.py --gpus N` starts them itself (launch_ranks below: the same
+torch.distributed.run command on 127.0.0.1, refused loudly when fewer than N GPUs are visible).
+
+`--backend gloo` is the DRY path of the multi-rank plumbing for boxes without GPUs (tests/): the ranks,
+the frame sharding, the run loop, the collectives and the JSON line are the real ones, the rasterizer's
+autograd Function is replaced by a torch stub and the line says so in `data` -- never a measurement.
 """
 from __future__ import annotations
 
@@ -236,6 +243,60 @@ def timed_rounds(run, fence, steps, warmup, dist, device, min_rounds=3, min_seco
     return rounds
 
 
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, backend, argv):
+    """`python bench.py --gpus N` without a launcher around it: N ranks of this same script under torch.distributed.run (one
+    process per GPU, the reference forces `cuda:0` per process -- utils/general_utils.py:133 -- so a process never spans GPUs),
+    rendezvous on 127.0.0.1.  Returns the launcher's exit code; rank 0's JSON line goes to this process's stdout unchanged."""
+    import subprocess
+
+    if backend == "nccl":
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            raise SystemExit(f"bench.py --gpus {n}: {have} GPU(s) visible on this node -- refusing to report an n_gpus={n} line from fewer devices")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+class _DryRasterize(torch.autograd.Function):
+    """--backend gloo only: stands in for gaussianavatars_amd.rasterizer._RasterizeGaussians at the autograd-Function boundary (same ten
+    arguments, same three outputs, gradients for the same inputs) so that the frame loop above it -- mesh update, accessors, render(),
+    loss, backward, all-reduce -- runs on a box without a GPU.  The image is a smooth function of the inputs, nothing more."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, sh_rest=None):
+        P = means3D.shape[0]
+        ctx.shapes = (means2D.shape, sh.shape, None if sh_rest is None else sh_rest.shape)
+        ctx.save_for_backward(means3D, opacities, scales, rotations)
+        v = 0.5 * torch.tanh(means3D.mean() + opacities.mean() + scales.mean() + rotations.mean())
+        radii = (torch.arange(P, dtype=torch.int32) % 3)
+        ctx.mark_non_differentiable(radii)
+        return v.expand(3, int(rs.image_height), int(rs.image_width)).clone(), radii, radii > 0
+
+    @staticmethod
+    def backward(ctx, g, *_):
+        means3D, opacities, scales, rotations = ctx.saved_tensors
+        v = torch.tanh(means3D.mean() + opacities.mean() + scales.mean() + rotations.mean())
+        gs = 0.5 * (1 - v * v) * g.sum()
+        m2, shs, rest = ctx.shapes
+        return (gs.expand_as(means3D) / means3D.numel(), torch.zeros(m2), torch.zeros(shs) if shs.numel() else None, None,
+                gs.expand_as(opacities) / opacities.numel(), gs.expand_as(scales) / scales.numel(), gs.expand_as(rotations) / rotations.numel(),
+                None, None, None if rest is None else torch.zeros(rest))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,14 +312,17 @@ def main():
                     help="BASELINE.json configs: cfg3 = configs[2] fwd+bwd 100k (the metric, default); cfg2 = configs[1] forward; "
                          "cfg4 = configs[3] 200k-splat 300-frame sequence fwd+bwd; cfg5 = configs[4] 2M-splat 1600x1100 forward stress")
     ap.add_argument("--rounds", type=int, default=3, help="minimum number of timed rounds of --steps steps each (the median round is reported)")
-    ap.add_argument("--min-seconds", type=float, default=0.5, help="minimum total timed duration: rounds are added until it is reached")
+    ap.add_argument("--min-seconds", type=float, default=3.0, help="minimum total timed duration: rounds are added until it is reached")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl (= RCCL): the measured path.  gloo: DRY run of the multi-rank plumbing on CPU -- a few hundred splats, composed-torch "
+                         "binding, the rasterizer stubbed at its autograd Function; the line is marked as such and is not a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="record the frame step once and replay it as one hipGraph launch per step (gaussianavatars_amd.graphs.GraphedStep)")
     ap.add_argument("--streams", type=int, default=1,
                     help="with --graph: this many recordings on this many streams, frames dealt to them in turn (frame parallelism inside one GPU)")
-    ap.add_argument("--frame-streams", type=int, default=4,
+    ap.add_argument("--frame-streams", type=int, default=0,
                     help="N=1, eager default run only: after the timed rounds, the same workload again as this many recorded frame "
                          "lanes (reported beside `value` as `frame_streams`); 0 skips the leg")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the process next to its GPU (host-sensitivity runs)")
@@ -275,20 +339,40 @@ def main():
     elif args.workload == "cfg5":
         args.mode, args.splats, args.width, args.height = "render", 2_000_000, 1600, 1100
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:   # no launcher around this process: start the N ranks ourselves
+        raise SystemExit(launch_ranks(args.gpus, args.backend, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: there is no CPU path for the rasterizer")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} inside a launcher with WORLD_SIZE={world}: the two must agree "
+                         "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N)")
+    dry = args.backend == "gloo"
+    if dry:   # plumbing check without a GPU: tiny scene, reference-shaped composed-torch binding, stubbed rasterizer Function
+        device = torch.device("cpu")
+        args.splats, args.width, args.height, args.frames = min(args.splats, 12_000), 64, 48, min(args.frames, 16)
+        args.binding, args.no_cpu_baseline, args.no_kernel_profile, args.frame_streams, args.no_pin = "unfused", True, True, 0, True
+        if args.graph or args.workload == "cfg5":
+            raise SystemExit("--backend gloo covers the eager frame loop of the bound workloads only")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: there is no CPU path for the rasterizer (--backend gloo is the dry run of the multi-rank plumbing)")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but {torch.cuda.device_count()} GPU(s) visible")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    n_gpus = world
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    n_gpus = dist.get_world_size() if dist is not None else 1
     train = args.mode == "train"
 
     from gaussianavatars_amd import _lib
@@ -304,6 +388,12 @@ def main():
     bg = torch.ones(3, dtype=torch.float32, device=device)
     target = torch.ones((3, args.height, args.width), dtype=torch.float32, device=device)
     my_frames = frames_for_rank(args.frames, rank, world)
+
+    if dry:
+        R._RasterizeGaussians.apply = staticmethod(_DryRasterize.apply)
+        import gaussianavatars_amd.gaussian_renderer as GR
+
+        GR.l1_loss = lambda a, b: (a - b).abs().mean()   # one_step imports it from there
 
     def step_fn(t):
         with torch.set_grad_enabled(train):
@@ -394,13 +484,14 @@ def main():
     def fence():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        if not dry:
+            torch.cuda.synchronize(device)
 
     _lib.gsr_wait_stats()   # reset
-    rounds = timed_rounds(run, fence, args.steps, args.warmup, dist, device, min_rounds=args.rounds, min_seconds=args.min_seconds)
+    rounds = timed_rounds(run, fence, args.steps, args.warmup, dist, device, min_rounds=args.rounds, min_seconds=args.min_seconds, max_rounds=256)
     elapsed = float(np.median(rounds))   # the median round: exactly args.steps steps
     wait_ms, waits = _lib.gsr_wait_stats()
-    info = R.last_forward_info()
+    info = {"binning_path": 0} if dry else R.last_forward_info()
     if graphed is not None:
         for ln in lanes:
             ln["graphed"].check()                         # every replayed frame fitted the recorded binning capacity
@@ -542,7 +633,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not dry else "DRY RUN (--backend gloo, CPU): rasterizer stubbed at its autograd Function, composed-torch binding, "
+                                                "reduced scene -- checks the multi-rank plumbing, measures nothing",
             "config": {
                 "workload": {"cfg3": "BASELINE configs[2]: %d mesh-bound SH-3 splats (synthetic stand-in for media/306), %dx%d (HxW), "
                                      "select_mesh_by_timestep + render + L1-vs-white + backward, no optimiser step",
@@ -558,14 +650,15 @@ def main():
                 "binning_path": {0: "rank", 1: "depth-ordered scatter", 2: "per-tile sort"}[path] + (f" ({bands} bands of tile rows)" if path == 0 and bands > 1 else ""),
                 "visible_fraction": round(vis, 4), "binding": args.binding,
                 "parallelism": (f"frame-parallel x{n_gpus}: {dist.get_world_size() if dist is not None else 1} "
-                                f"{'RCCL (torch nccl)' if dist is not None else 'single-process'} rank(s), frames per rank {counts}, "
+                                f"{('gloo (dry run)' if dry else 'RCCL (torch nccl)') if dist is not None else 'single-process'} rank(s), one process per GPU, frames per rank {counts}, "
                                 "one asynchronous scalar all-reduce (loss) per step"
                                 + (f"; {len(lanes)} frame streams inside the GPU (independent frames overlap; ms_per_step is elapsed / steps, "
                                    f"not the latency of one frame)" if len(lanes) > 1 else "")),
             },
             # every timed round is exactly `steps` steps (barrier + device sync on both sides, MAX over ranks); value = median round
             "rounds": {"n": len(rounds), "frames_per_s": [round(n_gpus * args.steps / r, 2) for r in rounds],
-                       "timed_seconds": round(float(sum(rounds)), 4)},
+                       "min": round(n_gpus * args.steps / max(rounds), 2), "p10": round(n_gpus * args.steps / float(np.percentile(rounds, 90)), 2),
+                       "max": round(n_gpus * args.steps / min(rounds), 2), "timed_seconds": round(float(sum(rounds)), 4)},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "frame_streams": frame_streams,

@@ -123,3 +123,44 @@ def test_cpu_list_parsing_and_pinning_is_a_no_op_without_a_gpu():
     if not torch.cuda.is_available():
         assert pin_to_gpu_numa_node(0) is None       # topology unreadable: nothing changes
         assert os.sched_getaffinity(0) == before
+
+
+def _bench(*argv, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (what the driver's scaling run types): the flag itself starts two ranks
+    (torch.distributed.run on 127.0.0.1).  Dry path (--backend gloo): the rasterizer Function is a stub, everything around it -- rank
+    start-up, frame sharding, the run loop with its asynchronous scalar all-reduce, MAX-reduced rounds, the single JSON line -- is
+    the code the GPU run executes."""
+    r, lines = _bench("--gpus", "2", "--backend", "gloo", "--steps", "4", "--warmup", "1", "--rounds", "2", "--min-seconds", "0", "--frames", "7")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert len(lines) == 1                                   # ONE line, from rank 0
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert "2 gloo (dry run) rank(s)" in out["config"]["parallelism"] and "frames per rank [4, 3]" in out["config"]["parallelism"]
+    assert out["rounds"]["n"] == 2 and len(out["rounds"]["frames_per_s"]) == 2
+    assert out["data"].startswith("DRY RUN")                 # never mistaken for a measurement
+    assert out["roofline"] is None and out["cpu_baseline"] is None
+    # value = all ranks' frames / the MAX-reduced median round
+    assert abs(out["value"] - 2 * 4 / (out["ms_per_step"] * 4e-3)) / out["value"] < 1e-3
+
+
+def test_bench_gpus_flag_refuses_what_it_cannot_deliver():
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs present: the refusal does not apply")
+    r, lines = _bench("--gpus", "2", "--steps", "2")           # RCCL path on a box without two GPUs: loud, no line
+    assert r.returncode != 0 and not lines and "GPU(s) visible" in r.stderr
+    # a launcher whose world size contradicts the flag (the line would misreport n_gpus)
+    r, lines = _bench("--gpus", "1", "--backend", "gloo", "--steps", "2", env_extra=dict(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and not lines and "must agree" in r.stderr
