@@ -52,7 +52,7 @@ _ONE_DEVICE = None   # a process that sees one GPU never switches devices
 GSR_LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr_hip.so")
 
 GSR_OK = 0
-GSR_ABI_VERSION = 8
+GSR_ABI_VERSION = 9
 GSR_E_CAPACITY = 1
 GSR_COUNT_SLOTS = 128   # include/gsr.h: persistent instance-count slots of the deferred forwards
 
@@ -77,6 +77,7 @@ class GsrSettings(C.Structure):
         ("deterministic", C.c_int32),
         ("exact_scale_grad", C.c_int32),
         ("deferred_count", C.c_int32),
+        ("fast_blend", C.c_int32),
     ]
 
 

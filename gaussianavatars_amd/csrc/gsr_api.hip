@@ -118,6 +118,7 @@ gsr::Settings to_dev_settings(const GsrSettings* s)
     d.exact_scale_grad = s->exact_scale_grad;
     d.forward_only = s->forward_only;
     d.deterministic = s->deterministic;
+    d.fast_blend = 0;   // the callers set the effective mode once the binning path is known (fast_effective)
     d.bg = s->bg;
     d.viewmatrix = s->viewmatrix;
     d.projmatrix = s->projmatrix;
@@ -135,6 +136,11 @@ int check_settings(const GsrSettings* s)
     if (s->deferred_count < 0 || s->deferred_count > GSR_COUNT_SLOTS) return fail(GSR_E_ARG, "deferred_count must be 0 or a slot in 1..%d", GSR_COUNT_SLOTS);
     return 0;
 }
+
+// GsrSettings.fast_blend as it applies to a frame: the exact kernels serve the deterministic mode (whose fixed-point scales are
+// derived for the exact partial sums) and the per-tile sort path (whose binning kernels read the conic from the per-splat record,
+// where the fast mode keeps it pre-scaled).  The forward and the backward of a frame evaluate this on the same inputs.
+bool fast_effective(const GsrSettings* s, const GsrBinningLayout& bl) { return s->fast_blend != 0 && s->deterministic == 0 && bl.path != 2; }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, size class): the attribute sticks, and the call is not
 // something to repeat per frame (nor inside a stream capture)
@@ -366,6 +372,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     const bool prod = bl.path == 1;                   // depth-ordered scatter into the quadrant streams (gsr_binning.hip)
 
     gsr::Settings ds = to_dev_settings(settings);
+    ds.fast_blend = fast_effective(settings, bl) ? 1 : 0;
     if (prod) {
         HIP_TRY(hipMemsetAsync(hdr, 0, sizeof(gsr::BinHeader), stream));   // k_preprocess accumulates the frame statistics into it
     } else if (P == 0) {   // otherwise k_preprocess zeroes both
@@ -622,7 +629,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     }   // per-tile sort path
     {
         TIMED(GSR_K_RENDER, stream);
-        hipLaunchKernelGGL(gsr::k_render, dim3(tiles), dim3(256), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
+        hipLaunchKernelGGL(ds.fast_blend ? gsr::k_render<true> : gsr::k_render<false>, dim3(tiles), dim3(256), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
                            (const uint32_t*)qcount, (const float4*)pa.grec, (const uint32_t*)qpos, write_lists ? (const uint32_t*)qlist : nullptr, (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib),
                            (uint32_t*)(im + il.n_contrib_q), (float*)(im + il.c_final), (float4*)(im + il.ck), out_color, cap,
                            (const unsigned long long*)total_dev);
@@ -726,6 +733,7 @@ static int backward_impl(const GsrSettings* settings, int32_t P, int32_t M, cons
     const char* b = (const char*)binning;
     const char* im = (const char*)img;
     gsr::Settings ds = to_dev_settings(settings);
+    ds.fast_blend = fast_effective(settings, bl) ? 1 : 0;
     float* grad_scratch = (float*)(g + gl.acc);   // zeroed by the forward (and by the previous backward)
     long long* acc64 = (long long*)(g + gl.acc64);
     uint32_t* gmax = (uint32_t*)(const_cast<char*>(im) + il.gmax);   // scratch word of the image state
@@ -737,7 +745,8 @@ static int backward_impl(const GsrSettings* settings, int32_t P, int32_t M, cons
     }
     if (num_rendered > 0) {
         TIMED(GSR_K_RENDER_BWD, stream);
-        hipLaunchKernelGGL(det ? gsr::k_render_bwd<true> : gsr::k_render_bwd<false>, dim3(gx * gy * GSR_BWD_SEGMENTS), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order),
+        auto* const render_bwd = det ? &gsr::k_render_bwd<true, false> : (ds.fast_blend ? &gsr::k_render_bwd<false, true> : &gsr::k_render_bwd<false, false>);
+        hipLaunchKernelGGL(render_bwd, dim3(gx * gy * GSR_BWD_SEGMENTS), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order),
                            (const uint32_t*)(b + bl.qstart), (const uint32_t*)(b + bl.qcount), (const float4*)(g + gl.grec), (const uint32_t*)(b + bl.qpos),
                            (const float*)(im + il.final_T), (const uint32_t*)(im + il.n_contrib_q), dL_dpix, grad_scratch,
                            (const float*)(im + il.c_final), (const float4*)(im + il.ck), gx * gy, acc64, (const uint32_t*)gmax,

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_gmax(size_t n, const float* __restrict_
     if ((threadIdx.x & 63) == 0 && m) atomicMax(gmax, m);
 }
 
-template <bool DET>
+template <bool DET, bool FAST>
 __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ qstart,
                                                      const uint32_t* __restrict__ qcount,
                                                      const float4* __restrict__ grec, const uint32_t* __restrict__ qpos,
@@ -197,10 +197,16 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
         for (int u = 0; u < 2; ++u) {
             dxs[u] = R.a[u][0] - pixx;
             dys[u] = R.a[u][1] - pixy;
-            const float power = -0.5f * (R.a[u][2] * dxs[u] * dxs[u] + R.a[u][4] * dys[u] * dys[u]) - R.a[u][3] * dxs[u] * dys[u];
             // hardware 2^x (v_exp_f32, ~1 ulp) instead of the forward's 13-instruction bit-reproducible polynomial: the backward
             // is compared with a tolerance, and a record whose alpha sits within an ulp of 1/255 flipping in or out is noise
-            G[u] = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
+            float power;
+            if constexpr (FAST) {   // fast blend: the record's conic is pre-scaled by -log2(e)/2 (exactly the forward's expression)
+                power = __builtin_fmaf(__builtin_fmaf(R.a[u][3], dys[u], R.a[u][2] * dxs[u]), dxs[u], (R.a[u][4] * dys[u]) * dys[u]);
+                G[u] = __builtin_amdgcn_exp2f(power);
+            } else {
+                power = -0.5f * (R.a[u][2] * dxs[u] * dxs[u] + R.a[u][4] * dys[u] * dys[u]) - R.a[u][3] * dxs[u] * dys[u];
+                G[u] = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
+            }
             alpha[u] = sel_min(0.99f, R.a[u][5] * G[u]);
             hit[u] = (jp + u) < last && power <= 0.0f && alpha[u] >= 1.0f / 255.0f;
             id[uo + u] = R.id[u];
@@ -236,8 +242,13 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
             vv[0] = w * g0;
             vv[1] = w * g1;
             vv[2] = w * g2;
-            vv[3] = ax * R.a[u][2] + ay * R.a[u][3];          // x (-W/2) = dL/dmean2D.x
-            vv[4] = ay * R.a[u][4] + ax * R.a[u][3];          // x (-H/2) = dL/dmean2D.y
+            if constexpr (FAST) {   // the two position sums leave without the conic: k_preprocess_bwd, which has it, forms A sx + B sy, C sy + B sx per splat
+                vv[3] = ax;
+                vv[4] = ay;
+            } else {
+                vv[3] = ax * R.a[u][2] + ay * R.a[u][3];          // x (-W/2) = dL/dmean2D.x
+                vv[4] = ay * R.a[u][4] + ax * R.a[u][3];          // x (-H/2) = dL/dmean2D.y
+            }
             vv[5] = ax * dxs[u];                              // x (-1/2) = dL/dconic (a, b, c)
             vv[6] = ax * dys[u];
             vv[7] = ay * dys[u];
@@ -320,10 +331,13 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
 #endif
 }
 
-template __global__ void k_render_bwd<false>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const float*,
+template __global__ void k_render_bwd<false, true>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const float*,
+                                                   const uint32_t*, const float*, float*, const float*, const float4*, int, long long*, const uint32_t*,
+                                                   unsigned long long, const unsigned long long*);
+template __global__ void k_render_bwd<false, false>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const float*,
                                              const uint32_t*, const float*, float*, const float*, const float4*, int, long long*, const uint32_t*,
                                              unsigned long long, const unsigned long long*);
-template __global__ void k_render_bwd<true>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const float*,
+template __global__ void k_render_bwd<true, false>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const float*,
                                             const uint32_t*, const float*, float*, const float*, const float4*, int, long long*, const uint32_t*,
                                             unsigned long long, const unsigned long long*);
 
@@ -419,6 +433,12 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
         const float cb = AV[0][0] * A[1][0] + AV[0][1] * A[1][1] + AV[0][2] * A[1][2];
         const float cc = AV[1][0] * A[1][0] + AV[1][1] * A[1][1] + AV[1][2] * A[1][2] + 0.3f;
         const float denom = ca * cc - cb * cb;
+        if (s.fast_blend) {   // the blend handed over sum(q dx), sum(q dy): the conic (the forward's: x * det_inv) turns them into the position gradient
+            const float det_inv = 1.f / denom;
+            const float kA = cc * det_inv, kB = -cb * det_inv, kC = ca * det_inv;
+            g2x = -0.5f * (float)s.W * (kA * q0.w + kB * q1.x);
+            g2y = -0.5f * (float)s.H * (kC * q1.x + kB * q0.w);
+        }
         const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
         float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
         if (denom2inv != 0.f) {

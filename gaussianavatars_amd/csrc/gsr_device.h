@@ -51,6 +51,7 @@ struct Settings {  // by-value kernel argument: scalars + the four device pointe
     int exact_scale_grad;
     int forward_only;
     int deterministic;
+    int fast_blend;      // EFFECTIVE fast mode of this frame (gsr_api.hip: off with `deterministic` and on the per-tile sort path)
     const float* __restrict__ bg;
     const float* __restrict__ viewmatrix;
     const float* __restrict__ projmatrix;
@@ -543,12 +544,13 @@ template <int KEYS, int THREADS>
 __global__ void k_tile_sort(uint32_t n_lo, uint32_t n_hi, int gx, const uint32_t* tile_order, const uint32_t* tile_count, const uint32_t* tile_start, unsigned long long* keys,
                             uint32_t* point_list, uint32_t* qlist, uint32_t* qpos, uint32_t* qcount, uint32_t* qstart, const float4* grec,
                             unsigned long long capacity, const unsigned long long* total_dev);
+template <bool FAST>
 __global__ void k_render(Settings s, const uint32_t* tile_order, const uint32_t* qstart, const uint32_t* qcount, const float4* grec,
                          const uint32_t* qpos, const uint32_t* qlist, float* final_T,
                          uint32_t* n_contrib, uint32_t* n_contrib_q, float* c_final, float4* ck, float* out_color, unsigned long long capacity,
                          const unsigned long long* total_dev);
 __global__ void k_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present);
-template <bool DET>
+template <bool DET, bool FAST>
 __global__ void k_render_bwd(Settings s, const uint32_t* tile_order, const uint32_t* qstart, const uint32_t* qcount, const float4* grec,
                              const uint32_t* qpos, const float* final_T,
                              const uint32_t* n_contrib_q, const float* dL_dpix, float* acc, const float* c_final, const float4* ck, int tiles,

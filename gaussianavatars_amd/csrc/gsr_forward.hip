@@ -259,7 +259,9 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         __syncthreads();
     };
     {
-        const float4 rec[3] = {make_float4(px, py, con0, con1), make_float4(con2, opac, col[0], col[1]),
+        // fast blend (include/gsr.h: GsrSettings.fast_blend): the blend kernels evaluate opacity * 2^(A' dx^2 + B' dx dy + C' dy^2)
+        const float k2 = s.fast_blend ? -0.72134752044448170368f : 1.0f;   // -log2(e) / 2
+        const float4 rec[3] = {make_float4(px, py, con0 * k2, s.fast_blend ? con1 * (2.0f * k2) : con1), make_float4(con2 * k2, opac, col[0], col[1]),
                                make_float4(col[2], __int_as_float(sum_exp), 0.f, 0.f)};
         put_rows(a.grec, rec, std::integral_constant<int, 3>{});
     }
@@ -773,6 +775,7 @@ template __global__ void k_tile_sort<GSR_SORT_XL_KEYS, 1024>(uint32_t, uint32_t,
 __device__ unsigned long long gsr_dbg_fwd[4 * 16384];
 extern "C" int gsr_debug_read_fwd(unsigned long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gsr_dbg_fwd), (size_t)n * 8); }
 #endif
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ qstart,
                                                  const uint32_t* __restrict__ qcount,
                                                  const float4* __restrict__ grec, const uint32_t* __restrict__ qpos,
@@ -860,8 +863,14 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         for (int u = 0; u < RB; ++u) {
             const float dx = R.a[u][0] - pixx;
             const float dy = R.a[u][1] - pixy;
-            const float power = -0.5f * (R.a[u][2] * dx * dx + R.a[u][4] * dy * dy) - R.a[u][3] * dx * dy;
-            float a = sel_min(0.99f, R.a[u][5] * gsr_expf_blend(power));
+            float power, a;
+            if constexpr (FAST) {   // the record holds the conic scaled by -log2(e)/2: power = log2 of the Gaussian, five instructions
+                power = __builtin_fmaf(__builtin_fmaf(R.a[u][3], dy, R.a[u][2] * dx), dx, (R.a[u][4] * dy) * dy);
+                a = sel_min(0.99f, R.a[u][5] * __builtin_amdgcn_exp2f(power));
+            } else {
+                power = -0.5f * (R.a[u][2] * dx * dx + R.a[u][4] * dy * dy) - R.a[u][3] * dx * dy;
+                a = sel_min(0.99f, R.a[u][5] * gsr_expf_blend(power));
+            }
             asm volatile("" : "+v"(a));   // evaluated for every lane: power > 0 is too rare to pay an exec-mask branch per record
             ok[u] = power <= 0.0f && a >= 1.0f / 255.0f;
             if (decltype(masked)::value) ok[u] = ok[u] && (jb + u) < n;
@@ -869,12 +878,19 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         }
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
-            const float test_T = Tw * (1.0f - alpha[u]);      // alpha == 0 (skipped record): exactly Tw, accepted, nothing changes
+            const float test_T = FAST ? __builtin_fmaf(-alpha[u], Tw, Tw) : Tw * (1.0f - alpha[u]);      // alpha == 0 (skipped record): exactly Tw, accepted, nothing changes
             const bool keep = test_T >= 0.0001f;              // false at the record that saturates the pixel, and forever after
             const float ae = keep ? alpha[u] : 0.0f;          // adding (c * 0) * T == +0 leaves C bit-identical: no selects on C
-            C0 = C0 + R.a[u][6] * ae * Tw;
-            C1 = C1 + R.a[u][7] * ae * Tw;
-            C2 = C2 + R.cbl[u] * ae * Tw;
+            if constexpr (FAST) {
+                const float wgt = ae * Tw;
+                C0 = __builtin_fmaf(R.a[u][6], wgt, C0);
+                C1 = __builtin_fmaf(R.a[u][7], wgt, C1);
+                C2 = __builtin_fmaf(R.cbl[u], wgt, C2);
+            } else {
+                C0 = C0 + R.a[u][6] * ae * Tw;
+                C1 = C1 + R.a[u][7] * ae * Tw;
+                C2 = C2 + R.cbl[u] * ae * Tw;
+            }
             T = keep ? test_T : T;
             Tw = keep ? test_T : 0.0f;
             last_q = (keep && ok[u]) ? (uint32_t)(jb + u + 1) : last_q;
@@ -972,8 +988,14 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
                 const float4 r2 = rec[3 * jc + 2];
                 const float dx = r0.x - ppx;
                 const float dy = r0.y - ppy;
-                const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-                const float a = sel_min(0.99f, r1.y * gsr_expf(power));
+                float power, a;
+                if constexpr (FAST) {
+                    power = __builtin_fmaf(__builtin_fmaf(r0.w, dy, r0.z * dx), dx, (r1.x * dy) * dy);
+                    a = sel_min(0.99f, r1.y * __builtin_amdgcn_exp2f(power));
+                } else {
+                    power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+                    a = sel_min(0.99f, r1.y * gsr_expf(power));
+                }
                 const bool ok = valid && power <= 0.0f && a >= 1.0f / 255.0f;
                 unsigned long long hits = __ballot(ok);
                 while (hits) {
@@ -985,11 +1007,18 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
                         at_ck += HWs;
                     }
                     const float ak = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), k));
-                    const float test_T = Tp * (1.0f - ak);
+                    const float test_T = FAST ? __builtin_fmaf(-ak, Tp, Tp) : Tp * (1.0f - ak);   // (the same expression as the main walk: a pixel's result does not depend on where the tail took over)
                     if (test_T < 0.0001f) { donep = true; break; }
+                    if constexpr (FAST) {
+                        const float wgt = ak * Tp;
+                        A0 = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.z), k)), wgt, A0);
+                        A1 = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.w), k)), wgt, A1);
+                        A2 = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(r2.x), k)), wgt, A2);
+                    } else {
                     A0 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.z), k)) * ak * Tp;
                     A1 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1.w), k)) * ak * Tp;
                     A2 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r2.x), k)) * ak * Tp;
+                    }
                     Tp = test_T;
                     lastqp = (uint32_t)(c0 + k + 1);
                 }
@@ -1023,6 +1052,11 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         out_color[2 * HW + pix_id] = C2 + T * s.bg[2];
     }
 }
+
+template __global__ void k_render<false>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
+                                         uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*);
+template __global__ void k_render<true>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
+                                        uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*);
 
 // ------------------------------------------------------------------------------------------
 // k_mark_visible (upstream checkFrustum): present = view z > 0.2

@@ -17,17 +17,19 @@ def _view(buf: torch.Tensor, off: int, count: int, dtype: torch.dtype) -> torch.
 
 
 def forward_state(rs: GaussianRasterizationSettings, means3D, shs, colors_precomp, opacities, scales, rotations,
-                  cov3D_precomp, tile_culling: bool = False) -> dict:
+                  cov3D_precomp, tile_culling: bool = False, fast_blend: bool = False) -> dict:
     """Runs the forward through the autograd Function (same code path as render()) and unpacks the
     saved state.  Returns device tensors.  tile_culling=False (default here) keeps the reference's rect-based
     instance lists so that keys / point_list / ranges / n_contrib compare with the oracle index for index."""
     from . import rasterizer as _R
 
     prev = _R.set_tile_culling(2 if tile_culling else 0)   # 2: culled, but the sorted lists are still written for inspection
+    prev_fast = _R.set_fast_blend(fast_blend)               # default: the exact blend, whose every intermediate equals the oracle's bits
     try:
         return _forward_state(rs, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)
     finally:
         _R.set_tile_culling(prev)
+        _R.set_fast_blend(prev_fast)
 
 
 def _forward_state(rs, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp) -> dict:

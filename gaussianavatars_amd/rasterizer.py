@@ -22,7 +22,7 @@ from torch import nn
 from . import _lib
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_bound", "rasterize_leaves", "last_forward_info", "set_tile_culling", "deferred_count",
-           "get_tile_culling", "set_exact_scale_grad", "set_deterministic"]
+           "get_tile_culling", "set_exact_scale_grad", "set_deterministic", "set_fast_blend"]
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -72,6 +72,21 @@ def set_deterministic(enabled: bool) -> bool:
     atomics; ~the same speed).  Returns the previous value."""
     global _deterministic
     prev, _deterministic = bool(_deterministic), int(bool(enabled))
+    return prev
+
+
+# ---- fast blend (include/gsr.h: GsrSettings.fast_blend) --------------------------------------------
+# On by default: the two blend kernels work in the 2^x domain (pre-scaled conic, hardware exp2, fused products) -- a third fewer
+# instructions per record.  Integer outputs are unchanged; the image agrees with the exact mode to ~1e-6 except at the (counted, rare)
+# pixels where a record sits within an ulp of one of the two blend thresholds.  GSR_FAST_BLEND=0 or set_fast_blend(False) selects
+# the kernels whose image is bit-identical to the oracle's (what the bit-exact parity tests run).
+_fast_blend = int(os.environ.get("GSR_FAST_BLEND", "1"))
+
+
+def set_fast_blend(enabled: bool) -> bool:
+    """Process-wide switch; returns the previous value."""
+    global _fast_blend
+    prev, _fast_blend = bool(_fast_blend), int(bool(enabled))
     return prev
 
 
@@ -189,6 +204,7 @@ def _make_settings(rs: GaussianRasterizationSettings, keep: list) -> _lib.GsrSet
     s.tile_culling = int(_tile_culling)
     s.exact_scale_grad = int(_exact_scale_grad)
     s.deterministic = int(_deterministic)
+    s.fast_blend = int(_fast_blend)
     for field in ("bg", "viewmatrix", "projmatrix", "campos"):
         t = _f32c(getattr(rs, field), field)
         keep.append(t)
@@ -302,6 +318,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = raster_settings
         ctx.tile_culling = int(s.tile_culling)    # the state buffers are laid out for this mode
         ctx.deterministic = int(s.deterministic)  # and the accumulators zero-filled for this one
+        ctx.fast_blend = int(s.fast_blend)        # and the per-splat records written for this one
         ctx.num_rendered = I
         ctx.capacity = cap
         ctx.M = M
@@ -324,6 +341,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         s = _make_settings(rs, keep)
         s.tile_culling = ctx.tile_culling
         s.deterministic = ctx.deterministic
+        s.fast_blend = ctx.fast_blend
         s.forward_only = 0
         P, M = means3D.shape[0], ctx.M
         f32 = dict(dtype=torch.float32, device=dev)
@@ -424,7 +442,7 @@ class _RasterizeBound(torch.autograd.Function):
                           binning_path=int(bl.path), rank_bands=int(bl.nbands), bound=True)
         _last_binning[0] = binning
         ctx.raster_settings = raster_settings
-        ctx.tile_culling, ctx.deterministic = int(s.tile_culling), int(s.deterministic)
+        ctx.tile_culling, ctx.deterministic, ctx.fast_blend = int(s.tile_culling), int(s.deterministic), int(s.fast_blend)
         ctx.num_rendered, ctx.capacity, ctx.M, ctx.F = I, cap, M, F
         ctx.is64 = b.binding_is_i64
         ctx.csr = csr
@@ -444,7 +462,7 @@ class _RasterizeBound(torch.autograd.Function):
         dev = xyz.device
         keep: list = []
         s = _make_settings(ctx.raster_settings, keep)
-        s.tile_culling, s.deterministic, s.forward_only = ctx.tile_culling, ctx.deterministic, 0
+        s.tile_culling, s.deterministic, s.fast_blend, s.forward_only = ctx.tile_culling, ctx.deterministic, ctx.fast_blend, 0
         P, M, F = xyz.shape[0], ctx.M, ctx.F
         f32 = dict(dtype=torch.float32, device=dev)
         grad_out_color = _f32c(grad_out_color, "grad_out_color")

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 8
+#define GSR_ABI_VERSION 9
 #define GSR_BWD_SEGMENT 60        /* stream entries per backward segment (a multiple of both blend kernels' batches)  */
 #define GSR_BWD_SEGMENTS 10       /* segments per quadrant stream; the last one takes whatever is left                */
 #define GSR_BIN_BLOCKS 256        /* workgroups of the two binning passes (each owns a contiguous chunk of splats) */
@@ -97,6 +97,18 @@ typedef struct GsrSettings {
                                  binning_capacity skips its binning, blend and backward blend kernels (image and gradients of that frame are
                                  NOT valid): the caller over-allocates (288 GB of HBM) and checks the slot after the fact.  gsr_backward of
                                  such a state takes num_rendered = binning_capacity.                                              */
+    int32_t fast_blend;       /* 0: the two blend kernels evaluate the reference's arithmetic expression by expression (exp through a pure-fmaf
+                                 polynomial, no contraction): image, final_T and n_contrib are bit-identical to oracle/gsr_oracle.c -- the mode
+                                 every bit-exact parity test runs in.
+                                 !=0 (what render() passes): the blend works in the 2^x domain -- k_preprocess stores the conic pre-multiplied by
+                                 -log2(e)/2 (the record's A, B, C slots then hold A' = -A log2(e)/2, B' = -B log2(e), C' = -C log2(e)/2), the
+                                 exponential is the hardware's v_exp_f32 (~1 ulp), products are fused -- about a third fewer instructions per
+                                 record in both kernels.  Everything integer (radii, rects, tiles_touched, keys, lists, ranges) is unchanged;
+                                 the image agrees with the exact mode to ~1e-6 except where a record's alpha sits within an ulp of 1/255 or a
+                                 pixel's transmittance within an ulp of 1e-4 (the record is then taken on one side and skipped on the other: a
+                                 difference bounded by 1/255 resp. 1e-4 per such pixel; tests/test_fast_blend_gpu.py counts them).  Same value in
+                                 the forward and the backward call of a frame.  Ignored (exact kernels) with `deterministic` and on the per-tile
+                                 sort path (tile_culling 5), whose binning reads the conic from the record.                         */
 } GsrSettings;
 
 /* Byte offsets of the arrays inside the three opaque state buffers.  The state buffers play the

@@ -10,6 +10,24 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "fast_blend: runs the rasterizer in its default (fast blend) mode; every other test runs the exact blend")
+
+
+@pytest.fixture(autouse=True)
+def _exact_blend_unless_marked(request):
+    """The parity bar of this suite is bit-exactness against the oracle, which is the EXACT blend (GsrSettings.fast_blend = 0).  The
+    product default is the fast blend (same integers, image within a stated tolerance): tests marked `fast_blend` run that mode and
+    state their tolerance; everything else selects the exact kernels for its duration."""
+    if request.node.get_closest_marker("fast_blend") is not None:
+        yield
+        return
+    from gaussianavatars_amd import rasterizer
+
+    prev = rasterizer.set_fast_blend(False)
+    try:
+        yield
+    finally:
+        rasterizer.set_fast_blend(prev)
 
 
 @pytest.fixture(scope="session")

@@ -16,6 +16,10 @@ def _declared(header):
     return sorted(set(re.findall(r"\b(g(?:sr|ab|ls)_[a-z0-9_]+)\s*\(", txt)))
 
 
+def _header_abi(header):
+    return int(re.search(r"#define\s+G[A-Z]+_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", header)).read()).group(1))
+
+
 def test_gsr_library_exports_every_declared_symbol():
     from gaussianavatars_amd import _lib
 
@@ -25,7 +29,7 @@ def test_gsr_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"include/gsr.h declares {n} but libgsr_hip.so does not export it"
         assert n in _lib.GSR_SYMBOLS, f"{n} has no ctypes prototype in _lib.GSR_SYMBOLS"
-    assert lib.gsr_abi_version() == 8
+    assert lib.gsr_abi_version() == _lib.GSR_ABI_VERSION == _header_abi("gsr.h")
 
 
 def test_layouts_are_disjoint_and_aligned():

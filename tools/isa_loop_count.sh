@@ -3,12 +3,19 @@
 # (a wave on the critical path retires one instruction per ~6.6 cycles whatever its kind).
 #   bash tools/isa_loop_count.sh forward  [records_per_iteration=6]     k_render      (gsr_forward.hip, -ffp-contract=off)
 #   bash tools/isa_loop_count.sh backward [records_per_iteration=4]     k_render_bwd  (gsr_backward.hip, -ffp-contract=fast)
+#   ... forward_fast / backward_fast: the GsrSettings.fast_blend instances of the two kernels
 # Prints the static totals of the first depth-1 loop and one line per basic block (n = instructions, v = VALU, s = SALU,
 # m = scalar memory, then the block's branches); the hot path is read off the branch structure by hand.
 set -eu
 which=${1:-forward}
 here=$(cd "$(dirname "$0")/../gaussianavatars_amd/csrc" && pwd)
-if [ "$which" = forward ]; then src=gsr_forward.hip; fp=off; kern=_ZN3gsr8k_renderE; r=${2:-6}; else src=gsr_backward.hip; fp=fast; kern=_ZN3gsr12k_render_bwdILb0E; r=${2:-4}; fi
+case "$which" in
+  forward)       src=gsr_forward.hip;  fp=off;  kern=_ZN3gsr8k_renderILb0EE;            r=${2:-6};;
+  forward_fast)  src=gsr_forward.hip;  fp=off;  kern=_ZN3gsr8k_renderILb1EE;            r=${2:-6};;   # GsrSettings.fast_blend
+  backward)      src=gsr_backward.hip; fp=fast; kern=_ZN3gsr12k_render_bwdILb0ELb0EE;   r=${2:-4};;
+  backward_fast) src=gsr_backward.hip; fp=fast; kern=_ZN3gsr12k_render_bwdILb0ELb1EE;   r=${2:-4};;
+  *) echo "forward | forward_fast | backward | backward_fast"; exit 2;;
+esac
 tmp=$(mktemp -d)
 (cd "$here" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=$fp ${ISA_DEFS:-} -S --cuda-device-only $src -o $tmp/k.s 2>/dev/null)
 awk -v k="$kern" '$0 ~ "^"k".*:" {on=1} on && /s_endpgm/ {on=0} on {print}' $tmp/k.s > $tmp/kernel.s
