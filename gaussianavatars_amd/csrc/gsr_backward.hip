@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
             vv[5] = ax * dxs[u];                              // x (-1/2) = dL/dconic (a, b, c)
             vv[6] = ax * dys[u];
             vv[7] = ay * dys[u];
-            vv[8] = Gh * dL_dalpha;
+            vv[8] = FAST ? q : Gh * dL_dalpha;                // fast blend: times the opacity (k_preprocess_bwd divides once per splat)
             T = Tn;
             last_alpha = al;
             last_one_m = one_m;
@@ -340,6 +340,230 @@ template __global__ void k_render_bwd<false, false>(Settings, const uint32_t*, c
 template __global__ void k_render_bwd<true, false>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const float*,
                                             const uint32_t*, const float*, float*, const float*, const float4*, int, long long*, const uint32_t*,
                                             unsigned long long, const unsigned long long*);
+
+// ------------------------------------------------------------------------------------------
+// k_render_bwd_rp -- the fast blend's backward (GsrSettings.fast_blend), lanes = RECORDS.
+//
+// The walk above gives every lane a pixel and every record a turn: 64 pixels x (73 VALU + 19 scalar instructions) per record, a
+// third of them the 64-lane reduction of the nine per-splat sums.  Here the roles are swapped: a wave still owns (quadrant, 60-entry
+// segment of its stream), but its LANES hold the segment's 60 records (one 48-byte gather per lane and segment, highest entry in lane
+// 0: back to front in lane order), and the quadrant's pixels take turns, four at a time (half a pixel row).  What was a serial
+// recurrence over the records becomes two wave scans per pixel,
+//     T_k   = T_end * prod_{i<=k} 1/(1 - alpha_i)               (transmittance in front of record k: prefix product over lanes)
+//     S_k   = S_end + sum_{i<k} alpha_i T_i (c_i . dL/dC)       (what lies behind record k, dotted with the pixel's gradient)
+// started from the forward's checkpoint at the segment's upper end exactly as the pixel-parallel kernel starts its walk; what was a
+// 64-lane reduction per record disappears -- every lane keeps the nine sums of ITS record in registers and adds them to the splat's
+// accumulator once per segment.  Per-pixel operands are wave-uniform (one LDS table per wave, broadcast reads); two pixels share every
+// arithmetic instruction through packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), the scans of four pixels are issued
+// interleaved so that the DPP read-after-write distance is covered by useful instructions.
+// Same results as the pixel-parallel fast kernel up to summation order (tests/test_fast_blend_gpu.py holds both to the oracle).
+// ------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// inclusive prefix scans over the 64 lanes of FOUR registers at once (in place).  v_OP_dpp dst, dst, dst: dst = shifted(dst) OP dst where
+// the shift has a source lane, unchanged elsewhere (bound_ctrl off disables the write) -- one instruction per step and register, which
+// the compiler will not form from the builtin for a multiply (its "old" operand has to be the identity, re-materialised per step).
+// A DPP operand needs two wait states behind the VALU write of the same register: the four chains provide three.
+#define GSR_SCAN4_STEP(OP, CTRL)                                      \
+    OP " %0, %0, %0 " CTRL "\n\t" OP " %1, %1, %1 " CTRL "\n\t" OP " %2, %2, %2 " CTRL "\n\t" OP " %3, %3, %3 " CTRL "\n\t"
+#define GSR_SCAN4(OP, a, b, c, d)                                                                      \
+    asm volatile("s_nop 1\n\t" GSR_SCAN4_STEP(OP, "row_shr:1 row_mask:0xf bank_mask:0xf")              \
+                 GSR_SCAN4_STEP(OP, "row_shr:2 row_mask:0xf bank_mask:0xf")                            \
+                 GSR_SCAN4_STEP(OP, "row_shr:4 row_mask:0xf bank_mask:0xf")                            \
+                 GSR_SCAN4_STEP(OP, "row_shr:8 row_mask:0xf bank_mask:0xf")                            \
+                 GSR_SCAN4_STEP(OP, "row_bcast:15 row_mask:0xa bank_mask:0xf")                         \
+                 GSR_SCAN4_STEP(OP, "row_bcast:31 row_mask:0xc bank_mask:0xf")                         \
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+
+#ifdef GSR_EXP_RP_WAVES
+__attribute__((amdgpu_waves_per_eu(GSR_EXP_RP_WAVES, GSR_EXP_RP_WAVES)))
+#endif
+__global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ qstart,
+                                                        const uint32_t* __restrict__ qcount, const float4* __restrict__ grec,
+                                                        const uint32_t* __restrict__ qpos, const float* __restrict__ final_T,
+                                                        const uint32_t* __restrict__ n_contrib_q, const float* __restrict__ dL_dpix,
+                                                        float* __restrict__ acc /* [P][GSR_ACC_STRIDE] */, const float* __restrict__ c_final,
+                                                        const float4* __restrict__ ck, int tiles, unsigned long long capacity,
+                                                        const unsigned long long* __restrict__ total_dev)
+{
+    if (*total_dev > capacity) return;
+    __shared__ __attribute__((aligned(16))) float tab_all[4][32 * 12];   // per wave: the pixel table (below)
+    __shared__ float xpose_all[4][64 * 9];                                // per wave: the nine sums of every lane on their way out
+    constexpr int CH = GSR_BWD_SEGMENT;          // records per chunk = lanes in use (60 of 64)
+    static_assert(CH <= 64 && CH > 32, "a chunk of the stream has to fit the wave");
+    const int W = s.W, H = s.H;
+    const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X;
+    const int seg = (int)blockIdx.x / tiles;
+    const int tile = (int)tile_order[(int)blockIdx.x - seg * tiles];
+    const int tile_x = tile % gx, tile_y = tile / gx;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int nq = (int)qcount[4 * tile + wave];
+    const int seg_lo = seg * CH;
+    if (nq <= seg_lo) return;
+    const uint32_t* __restrict__ qp = qpos + qstart[4 * tile + wave];
+
+    // ---- this lane's PIXEL (lane = 8 * row + column of the quadrant): what the pixel contributes to the table below
+    const int qx0 = tile_x * GSR_BLOCK_X + (wave & 1) * 8, qy0 = tile_y * GSR_BLOCK_Y + (wave >> 1) * 8;
+    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const int pix_id = W * pyi + pxi;
+    const size_t HW = (size_t)H * W;
+    const int last_pix = inside ? (int)n_contrib_q[pix_id] : 0;        // one past the pixel's last contributing stream entry
+    const int jtop = (int)wave_max_u32((uint32_t)last_pix);
+    if (jtop <= seg_lo) return;                                        // nothing of this segment in this quadrant
+    const bool open_ended = seg == GSR_BWD_SEGMENTS - 1;               // the last segment takes whatever is left, a chunk at a time
+    int hi = open_ended ? seg_lo + ((jtop - seg_lo + CH - 1) / CH) * CH : seg_lo + CH;
+    {
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f, Tend = 0.f, Sx = 0.f;
+        if (inside) {
+            g0 = dL_dpix[0 * HW + pix_id];
+            g1 = dL_dpix[1 * HW + pix_id];
+            g2 = dL_dpix[2 * HW + pix_id];
+            Tend = final_T[pix_id];
+            Sx = Tend * (s.bg[0] * g0 + s.bg[1] * g1 + s.bg[2] * g2);   // the background's share of what lies behind every record
+            if (!open_ended && last_pix > hi) {
+                // the pixel's stream goes on above this segment: the forward's checkpoint at entry hi gives the transmittance there and, as
+                // (final colour - colour so far) . dL/dC, everything that lies behind it
+                const float4 c = ck[(size_t)seg * HW + pix_id];
+                Tend = c.x;
+                Sx += (c_final[0 * HW + pix_id] - c.y) * g0 + (c_final[1 * HW + pix_id] - c.z) * g1 + (c_final[2 * HW + pix_id] - c.w) * g2;
+            }
+        }
+        // ---- the wave's pixel table (LDS, 12 floats per PAIR of horizontally adjacent pixels, three broadcast ds_read_b128 per pair):
+        //      (T_end, T_end', S, S' | g0, g0', g1, g1' | g2, g2', last, last')
+        float* tw = tab_all[wave] + ((lane >> 3) * 4 + ((lane & 7) >> 1)) * 12 + (lane & 1);
+        tw[0] = Tend; tw[2] = Sx; tw[4] = g0; tw[6] = g1; tw[8] = g2; tw[10] = __int_as_float(last_pix);
+    }
+    float* const tab = tab_all[wave];
+    const float fqx0 = (float)qx0, fqy0 = (float)qy0;
+
+    for (;;) {
+        const int lo = hi - CH;
+        // ---- this lane's RECORD: entry hi - 1 - lane of the stream (lanes CH.. and entries past the end: opacity 0, never hit)
+        const int j = hi - 1 - lane;
+        const bool valid = lane < CH && j < nq;
+        const uint32_t idx = qp[valid ? j : nq - 1];
+        const float4 r0 = grec[3 * (size_t)idx + 0], r1 = grec[3 * (size_t)idx + 1], r2 = grec[3 * (size_t)idx + 2];
+        const float xq = r0.x - fqx0, yq = r0.y - fqy0;          // relative to the quadrant's first pixel
+        const float cA = r0.z, cB = r0.w, cC = r1.x;             // the conic, pre-scaled into the 2^x domain (k_preprocess)
+        const float op = valid ? r1.y : 0.f;
+        const float cr = r1.z, cgn = r1.w, cb = r2.x;
+        const int jrec = valid ? j : 0x7fffffff;                 // "last > jrec" is the pixel's range test
+        const unsigned long long act = __ballot(last_pix > lo);  // pixels with something in this chunk
+        const bool more = lo > seg_lo;                           // (open-ended segment) another chunk follows below this one
+        f2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0, a6 = a0, a7 = a0, a8 = a0;
+
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t rm = (uint32_t)(act >> (8 * r)) & 0xFFu;
+            if (!rm) continue;
+            const float dy = yq - (float)r;
+            const float Bdy = cB * dy, Cdy2 = (cC * dy) * dy;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (!((rm >> (4 * h)) & 0xFu)) continue;
+                const f4* tp = reinterpret_cast<const f4*>(tab + (r * 4 + 2 * h) * 12);
+                f4 t[2][3];
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) t[e][k] = tp[3 * e + k];
+                f2 dx[2], a0m[2], al[2], rv[2], R[2], Tj[2], cg[2], aT[2], Pw[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float c0 = (float)(4 * h + 2 * e);
+                    dx[e] = f2{xq - c0, xq - (c0 + 1.0f)};
+                    const f2 pw = (cA * dx[e] + Bdy) * dx[e] + Cdy2;
+                    const f2 G = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+                    const f2 araw = op * G;
+                    const int l0 = __float_as_int(t[e][2].z), l1 = __float_as_int(t[e][2].w);
+                    a0m[e].x = (l0 > jrec && pw.x <= 0.0f && araw.x >= 1.0f / 255.0f) ? araw.x : 0.0f;
+                    a0m[e].y = (l1 > jrec && pw.y <= 0.0f && araw.y >= 1.0f / 255.0f) ? araw.y : 0.0f;
+                    al[e] = f2{__builtin_fminf(0.99f, a0m[e].x), __builtin_fminf(0.99f, a0m[e].y)};
+                    const f2 om = 1.0f - al[e];
+                    rv[e] = f2{__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                    R[e] = rv[e];
+                }
+#ifndef GSR_EXP_RP_NOSCAN
+                GSR_SCAN4("v_mul_f32_dpp", R[0].x, R[0].y, R[1].x, R[1].y);
+#endif
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const f2 Te = {t[e][0].x, t[e][0].y};
+                    const f2 g0 = {t[e][1].x, t[e][1].y}, g1 = {t[e][1].z, t[e][1].w}, g2 = {t[e][2].x, t[e][2].y};
+                    Tj[e] = Te * R[e];
+                    cg[e] = cr * g0 + (cgn * g1 + cb * g2);
+                    aT[e] = al[e] * Tj[e];
+                    Pw[e] = aT[e] * cg[e];      // w = alpha T (c . dL/dC); scanned in place
+                }
+#ifndef GSR_EXP_RP_NOSCAN
+                GSR_SCAN4("v_add_f32_dpp", Pw[0].x, Pw[0].y, Pw[1].x, Pw[1].y);
+#endif
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const f2 Sx = {t[e][0].z, t[e][0].w};
+                    const f2 g0 = {t[e][1].x, t[e][1].y}, g1 = {t[e][1].z, t[e][1].w}, g2 = {t[e][2].x, t[e][2].y};
+                    // dL/dalpha = T c.g - S / (1 - alpha), S = what lies behind the record = (inclusive sum - w) + S_end; with w = alpha T c.g and
+                    // 1 + alpha / (1 - alpha) = 1 / (1 - alpha) that is (T c.g - inclusive sum - S_end) / (1 - alpha)
+                    const f2 dLda = ((Tj[e] * cg[e] - Pw[e]) - Sx) * rv[e];
+                    const f2 tq = a0m[e] * dLda;                        // opacity * G * dL/dalpha  (= G * dL/dG; the 0.99 clamp has no gradient)
+                    const f2 ax = tq * dx[e], ay = tq * dy;
+                    a0 += aT[e] * g0;
+                    a1 += aT[e] * g1;
+                    a2 += aT[e] * g2;
+                    a3 += ax;                                           // k_preprocess_bwd forms A sx + B sy, C sy + B sx and the constant factors
+                    a4 += ay;
+                    a5 += ax * dx[e];
+                    a6 += ax * dy;
+                    a7 += ay * dy;
+                    a8 += tq;                                           // / opacity, once per splat
+                    if (more) {
+                        // state at the chunk's lower end for the chunk below: lane CH-1 holds the lowest entry -- the transmittance in front of it
+                        // and, inclusive of it, the sum behind
+                        const float T0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tj[e].x), CH - 1));
+                        const float T1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tj[e].y), CH - 1));
+                        const float S0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Pw[e].x), CH - 1)) + Sx.x;
+                        const float S1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Pw[e].y), CH - 1)) + Sx.y;
+                        if (lane == 0) {
+                            float* up = tab + (r * 4 + 2 * h + e) * 12;
+                            up[0] = T0; up[1] = T1; up[2] = S0; up[3] = S1;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- nine sums per record.  A lane adding its own nine would send 60 different cache lines per instruction through the L2 atomic
+        // units (measured: the kernel three times slower than the walk it replaces); instead the sums cross the wave through LDS and leave
+        // record-major -- lane e of pass i carries element 64 i + e of the (record, component) matrix, so each record's nine floats are
+        // consecutive lanes of one instruction and reach its 48-byte accumulator as one burst.
+#ifndef GSR_EXP_RP_NOATOMIC
+        {
+            float* xs = xpose_all[wave];
+            const float v[9] = {a0.x + a0.y, a1.x + a1.y, a2.x + a2.y, a3.x + a3.y, a4.x + a4.y, a5.x + a5.y, a6.x + a6.y, a7.x + a7.y, a8.x + a8.y};
+#pragma unroll
+            for (int c = 0; c < 9; ++c) xs[9 * lane + c] = v[c];
+            // seven records (63 lanes) per pass: a record's nine floats never straddle two instructions
+#pragma unroll
+            for (int i = 0; i < (CH + 6) / 7; ++i) {
+                const int rl7 = (lane * 7282) >> 16;                             // lane / 9 (0..7)
+                const int c = lane - 9 * rl7;
+                const int rl = 7 * i + rl7;                                      // the lane whose record this is
+                const float val = xs[63 * i + lane];
+                const uint32_t rid = (uint32_t)__builtin_amdgcn_ds_bpermute(rl << 2, (int)idx);   // its splat
+                const bool live = lane < 63 && rl < CH && (hi - 1 - rl) < nq;
+#ifdef GSR_EXP_RP_PLAINSTORE    // timing experiment: the sums stay live, nothing is added (a store no value ever triggers)
+                if (live && val == 12345.678f) acc[(size_t)GSR_ACC_STRIDE * rid + c] = val;
+#else
+                if (live && val != 0.f) unsafeAtomicAdd(acc + (size_t)GSR_ACC_STRIDE * rid + c, val);
+#endif
+            }
+        }
+#endif
+        if (!more) break;
+        hi = lo;
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 
@@ -438,6 +662,8 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
             const float kA = cc * det_inv, kB = -cb * det_inv, kC = ca * det_inv;
             g2x = -0.5f * (float)s.W * (kA * q0.w + kB * q1.x);
             g2y = -0.5f * (float)s.H * (kC * q1.x + kB * q0.w);
+            const float opac = a.grec[3 * (size_t)i + 1].y;   // the blend summed opacity * G * dL/dalpha
+            gop = opac > 0.f ? q2.x / opac : 0.f;
         }
         const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
         float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;

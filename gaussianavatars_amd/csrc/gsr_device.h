@@ -16,7 +16,7 @@
 #define GSR_SORT_LDS_KEYS 8192   // 64 KiB of uint64 keys per workgroup in the tile sort
 #define GSR_SORT_XL_KEYS 16384  // 128 KiB of LDS, 16 keys per thread; beyond this the sort runs in global memory
 #define GSR_SORT_SMALL_KEYS 2048 // tiles up to this many entries take the 256-thread / 16 KiB class
-#define GSR_ACC_STRIDE 12        // floats per splat in the backward accumulator (48 B, one atomic burst)
+#define GSR_ACC_STRIDE 16        // floats per splat in the backward accumulator: nine sums in a 64-byte line of their own (an atomic burst never straddles two lines)
 #define GSR_ACC64_STRIDE 10      // int64 per splat in the deterministic mode's fixed-point accumulator (9 sums + pad, 80 B)
 #define GSR_FIXED_BITS 58        // fixed point: a partial p of splat s is added as llrint(p * 2^(GSR_FIXED_BITS - e_s - e_g)) with
                                  // 2^e_g > max |dL/dpixel| and 2^e_s >= the splat's own bound on the sum (two classes: conic sums, the rest) in units of
@@ -555,6 +555,9 @@ __global__ void k_render_bwd(Settings s, const uint32_t* tile_order, const uint3
                              const uint32_t* qpos, const float* final_T,
                              const uint32_t* n_contrib_q, const float* dL_dpix, float* acc, const float* c_final, const float4* ck, int tiles,
                              long long* acc64, const uint32_t* gmax, unsigned long long capacity, const unsigned long long* total_dev);
+__global__ void k_render_bwd_rp(Settings s, const uint32_t* tile_order, const uint32_t* qstart, const uint32_t* qcount, const float4* grec,
+                                const uint32_t* qpos, const float* final_T, const uint32_t* n_contrib_q, const float* dL_dpix, float* acc,
+                                const float* c_final, const float4* ck, int tiles, unsigned long long capacity, const unsigned long long* total_dev);
 __global__ void k_gmax(size_t n, const float* dL_dpix, uint32_t* gmax);
 // exponent e_g with 2^e_g > the float whose bits are given (0 for no gradient at all)
 __device__ __forceinline__ int gmax_exponent(uint32_t gmax_bits) { return gmax_bits ? (int)((gmax_bits >> 23) & 0xFFu) - 127 + 1 : 0; }

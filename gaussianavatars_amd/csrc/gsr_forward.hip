@@ -275,9 +275,10 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
 #pragma unroll
             for (int k = 0; k < 5; ++k) { const int e = tix + 256 * k; if (e < 5 * rows) out[e] = z; }
         } else {
-            float4* out = a.acc + (size_t)3 * first;
+            constexpr int Q = GSR_ACC_STRIDE / 4;
+            float4* out = a.acc + (size_t)Q * first;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { const int e = tix + 256 * k; if (e < 3 * rows) out[e] = z; }
+            for (int k = 0; k < Q; ++k) { const int e = tix + 256 * k; if (e < Q * rows) out[e] = z; }
         }
     }
     if (a.pstat) {
