@@ -746,7 +746,10 @@ static int backward_impl(const GsrSettings* settings, int32_t P, int32_t M, cons
     if (num_rendered > 0) {
         TIMED(GSR_K_RENDER_BWD, stream);
         if (ds.fast_blend && settings->fast_blend != 2) {   // fast blend: the record-parallel kernel (fast_blend == 2 keeps the pixel-parallel walk: A/B runs)
-            hipLaunchKernelGGL(gsr::k_render_bwd_rp, dim3(gx * gy * GSR_BWD_SEGMENTS), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order),
+#ifndef GSR_EXP_RP_SEGS
+#define GSR_EXP_RP_SEGS GSR_BWD_SEGMENTS
+#endif
+            hipLaunchKernelGGL(gsr::k_render_bwd_rp, dim3(gx * gy * GSR_EXP_RP_SEGS), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order),
                                (const uint32_t*)(b + bl.qstart), (const uint32_t*)(b + bl.qcount), (const float4*)(g + gl.grec), (const uint32_t*)(b + bl.qpos),
                                (const float*)(im + il.final_T), (const uint32_t*)(im + il.n_contrib_q), dL_dpix, grad_scratch,
                                (const float*)(im + il.c_final), (const float4*)(im + il.ck), gx * gy,
