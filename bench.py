@@ -494,7 +494,7 @@ def main():
     info = {"binning_path": 0} if dry else R.last_forward_info()
     if graphed is not None:
         for ln in lanes:
-            ln["graphed"].check()                         # every replayed frame fitted the recorded binning capacity
+            ln["graphed"].check()                         # the device marks a slot whose frame did not fit and only the host clears the mark: this covers every replay above
         info["num_rendered"] = max(graphed.instances())   # (the recording itself did not know its count)
 
     # ---- per-kernel durations: HIP events on the launch stream (recorded by the C ABI around every kernel).

@@ -108,6 +108,7 @@ GSR_SYMBOLS = {
     "gsr_abi_version": (C.c_int, []),
     "gsr_last_error": (C.c_char_p, []),
     "gsr_count_slot_read": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gsr_count_slot_overflow": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.c_int32]),
     "gsr_geom_layout": (C.c_int, [C.c_int32, C.POINTER(GsrGeomLayout)]),
     "gsr_binning_layout": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GsrBinningLayout)]),
     "gsr_image_layout": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(GsrImageLayout)]),

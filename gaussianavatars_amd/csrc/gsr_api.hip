@@ -50,7 +50,8 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // k_tile_scan posts (seq << 40 | I) with one system-scope store; gsr_forward spins on the slot.
 struct Mailbox {
     static constexpr int kSlots = 256;        // ring of the waiting forwards
-    static constexpr int kPersistent = GSR_COUNT_SLOTS;   // slots of the deferred forwards (GsrSettings.deferred_count), after the ring
+    static constexpr int kPersistent = 2 * GSR_COUNT_SLOTS;   // after the ring: the count slots of the deferred forwards (GsrSettings.deferred_count),
+                                                              // then one STICKY overflow word per slot (set by the device, cleared by the host only)
     unsigned long long* host = nullptr;
     unsigned long long* dev = nullptr;        // the same memory as the device sees it
     std::atomic<unsigned long long> seq{1};
@@ -178,6 +179,16 @@ int gsr_count_slot_read(int32_t slot, int64_t* count, int64_t* seq)
     const unsigned long long v = __atomic_load_n(g_mail.host + Mailbox::kSlots + slot, __ATOMIC_ACQUIRE);
     *count = v ? (int64_t)(v & 0xFFFFFFFFFFull) : -1;
     if (seq) *seq = (int64_t)(v >> 40);
+    return GSR_OK;
+}
+
+int gsr_count_slot_overflow(int32_t slot, int64_t* worst, int32_t reset)
+{
+    if (slot < 0 || slot >= GSR_COUNT_SLOTS) return fail(GSR_E_ARG, "gsr_count_slot_overflow: bad slot");
+    if (int rc = g_mail.init()) return rc;
+    unsigned long long* w = g_mail.host + Mailbox::kSlots + GSR_COUNT_SLOTS + slot;
+    if (worst) *worst = (int64_t)__atomic_load_n(w, __ATOMIC_ACQUIRE);
+    if (reset) __atomic_store_n(w, 0ull, __ATOMIC_RELEASE);
     return GSR_OK;
 }
 
@@ -313,7 +324,7 @@ static int to_bound(const GsrBound* b, int32_t P, bool backward, gsr::BoundDev* 
     if (!b) return 0;
     o->leaves = 1;
     if (!b->binding) {   // an unbound model's leaves: activations only
-        if (b->F != 0 || b->face_R || b->face_scale || b->face_center || b->face_quat) return fail(GSR_E_ARG, "GsrBound: face buffers without a binding");
+        if (P > 0 && (b->F != 0 || b->face_R || b->face_scale || b->face_center || b->face_quat)) return fail(GSR_E_ARG, "GsrBound: face buffers without a binding");   // (P == 0: an empty binding has no address)
         return 0;
     }
     if (b->F <= 0 || (P > 0 && (!b->face_R || !b->face_scale || !b->face_center || !b->face_quat)))
@@ -349,6 +360,12 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     if (P > 0 && (!means3D || !opacities || !radii || !geom)) return fail(GSR_E_ARG, "NULL splat buffer");
     if (!binning || !img) return fail(GSR_E_ARG, "NULL state buffer");
     if (binning_capacity < 0 || binning_capacity >= (1ll << 32)) return fail(GSR_E_ARG, "binning_capacity out of range");
+    {   // the rank and per-tile sort paths address the four quadrant streams of a tile as 32-bit ELEMENT offsets 4 * start + q * n into qpos
+        GsrBinningLayout probe;
+        gsr_binning_layout(0, settings->image_width, settings->image_height, P, settings->tile_culling, &probe);
+        if (probe.path != 1 && binning_capacity > (1ll << 30))
+            return fail(GSR_E_ARG, "binning_capacity %lld exceeds 2^30 tile instances (32-bit quadrant-stream offsets on this binning path)", (long long)binning_capacity);
+    }
 
     const int W = settings->image_width, H = settings->image_height;
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X, gy = (H + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y;
@@ -423,6 +440,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     volatile unsigned long long* slot = g_mail.host + slot_index;
     *slot = 0;   // (a persistent slot may still hold what its previous owner's last frame posted)
     unsigned long long* slot_dev = g_mail.dev + slot_index;
+    const unsigned long long post_cap = deferred ? (unsigned long long)binning_capacity : ~0ull;   // deferred: an overflowing frame marks the slot's sticky word
     const unsigned long long cap = (unsigned long long)binning_capacity;
     uint32_t* tile_order = (uint32_t*)(b + bl.tile_order);
     uint32_t* qpos = (uint32_t*)(b + bl.qpos);
@@ -479,7 +497,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
             hipLaunchKernelGGL(gsr::k_qscan, dim3(((Q + 3) / 4 + 31) / 32), dim3(1024), 0, stream, Q, chunks, (const uint8_t*)(b + bl.qhist),
                                (uint32_t*)(b + bl.qprefix), qcount);
             hipLaunchKernelGGL(gsr::k_qscan_glob, dim3(1), dim3(1024), 0, stream, tiles, (const uint32_t*)qcount, qstart, tile_order, hdr,
-                               slot_dev, seq);
+                               slot_dev, seq, post_cap);
             KERNEL_CHECK("k_qscan", stream, dbg);
         }
         {
@@ -537,7 +555,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
             hipLaunchKernelGGL(gsr::k_rdsort, dim3(1 + (pblocks > 0 ? nb : 0u)), dim3(256), 0, stream, (const uint32_t*)bcount,
                                (const uint32_t*)bstart, dkeys, dtmp, rank, obs, (const ushort4*)srect, (int)bl.band_rows, tiles,
                                (const uint32_t*)tile_count, tile_start, tile_cursor,
-                               ranges, tile_order, (uint4*)(b + bl.tdesc), total_dev, slot_dev, seq);
+                               ranges, tile_order, (uint4*)(b + bl.tdesc), total_dev, slot_dev, seq, post_cap);
             KERNEL_CHECK("k_rdsort", stream, dbg);
             if (nbands > 1 && pblocks > 0) {
                 // large frames: a rank per (splat, band of tile rows) -- see gsr_rank.hip
@@ -594,7 +612,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     {
         TIMED(GSR_K_TILE_SCAN, stream);
         hipLaunchKernelGGL(gsr::k_tile_scan, dim3(1), dim3(1024), 0, stream, tiles, (const uint32_t*)tile_count, tile_start, tile_cursor,
-                           ranges, tile_order, total_dev, slot_dev, seq);
+                           ranges, tile_order, total_dev, slot_dev, seq, post_cap);
         KERNEL_CHECK("k_tile_scan", stream, dbg);
     }
 

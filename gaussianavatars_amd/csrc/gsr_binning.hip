@@ -387,7 +387,7 @@ __global__ __launch_bounds__(1024) void k_qscan(int Q, uint32_t chunks, const ui
 // mailbox; tiles listed heaviest-first (by the sum of their four quadrants) as the launch order of the blend kernels
 __global__ __launch_bounds__(1024) void k_qscan_glob(int tiles, const uint32_t* __restrict__ qcount, uint32_t* __restrict__ qstart,
                                                       uint32_t* __restrict__ tile_order, BinHeader* __restrict__ hdr,
-                                                      unsigned long long* mailbox, unsigned long long seq)
+                                                      unsigned long long* mailbox, unsigned long long seq, unsigned long long post_capacity)
 {
     __shared__ uint32_t wave_tot[16];
     __shared__ unsigned long long carry_s;
@@ -419,6 +419,9 @@ __global__ __launch_bounds__(1024) void k_qscan_glob(int tiles, const uint32_t* 
         const unsigned long long grand = carry_s;
         hdr->total = grand;
         __hip_atomic_store(mailbox, (seq << 40) | (grand & 0xFFFFFFFFFFull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // deferred count (post_capacity = the binning capacity, else ~0): a frame that does not fit leaves a STICKY mark in the slot's second
+        // word -- later frames overwrite the count above, nothing but the host clears this one (gsr_count_slot_overflow)
+        if (grand > post_capacity) __hip_atomic_store(mailbox + GSR_COUNT_SLOTS, grand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (tid < 34) bucket[tid] = 0u;
     __syncthreads();

@@ -532,7 +532,7 @@ struct PreBwdArgs {
 
 __global__ void k_preprocess(Settings s, PreprocessArgs a);
 __global__ void k_tile_scan(int tiles, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, uint2* ranges,
-                            uint32_t* tile_order, unsigned long long* total_dev, unsigned long long* mailbox, unsigned long long seq);
+                            uint32_t* tile_order, unsigned long long* total_dev, unsigned long long* mailbox, unsigned long long seq, unsigned long long post_capacity);
 template <bool CULL>
 __global__ void k_count(int P, int gx, int tiles, const ushort4* rect, const uint32_t* tiles_touched, const float4* grec, uint32_t* tile_count,
                         unsigned long long* rect_total, uint32_t* block_hist);
@@ -601,7 +601,7 @@ __global__ void k_band_scan(BinHeader* hdr, uint32_t nwc, uint32_t* bandcnt);
 __global__ void k_band_rank(const BinHeader* hdr, const uint2* obs, uint32_t nbands, uint32_t nwc, const uint32_t* bandcnt, uint4* rank4, uint32_t* over);
 __global__ void k_rdsort(const uint32_t* bcount, const uint32_t* bstart, unsigned long long* dkeys, unsigned long long* tmp,
                          uint32_t* rank, uint2* obs, const ushort4* srect, int band_rows, int tiles, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, uint2* ranges,
-                         uint32_t* tile_order, uint4* tdesc, unsigned long long* total_dev, unsigned long long* mailbox, unsigned long long seq);
+                         uint32_t* tile_order, uint4* tdesc, unsigned long long* total_dev, unsigned long long* mailbox, unsigned long long seq, unsigned long long post_capacity);
 __global__ void k_rscatter(int P, int gx, int tiles, BandTables bt, const ushort4* srect, const uint32_t* rank, const float4* sspan, const uint32_t* tile_start,
                            uint32_t* tile_cursor, uint2* ranks, unsigned long long capacity, const unsigned long long* total_dev, const uint32_t* block_hist);
 __global__ void k_tile_rank(uint32_t words, int gx, int nbands, float inv_band_rows, const uint4* tdesc, const uint2* ranks,
@@ -620,6 +620,6 @@ __global__ void k_qcount(QBinArgs a);
 __global__ void k_qscatter(QBinArgs a);
 __global__ void k_qscan(int Q, uint32_t chunks, const uint8_t* qhist, uint32_t* qprefix, uint32_t* qcount);
 __global__ void k_qscan_glob(int tiles, const uint32_t* qcount, uint32_t* qstart, uint32_t* tile_order, BinHeader* hdr,
-                             unsigned long long* mailbox, unsigned long long seq);
+                             unsigned long long* mailbox, unsigned long long seq, unsigned long long post_capacity);
 
 }  // namespace gsr

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int tiles, const uint32_t* _
                                                      uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
                                                      uint2* __restrict__ ranges, uint32_t* __restrict__ tile_order,
                                                      unsigned long long* __restrict__ total_dev, unsigned long long* mailbox,
-                                                     unsigned long long seq)
+                                                     unsigned long long seq, unsigned long long post_capacity)
 {
     __shared__ uint32_t wave_tot[16];
     __shared__ unsigned long long carry_s;
@@ -462,6 +462,9 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int tiles, const uint32_t* _
         *total_dev = grand;
         // post (seq, I) to the host: one 8-byte system-scope store into mapped pinned memory
         __hip_atomic_store(mailbox, (seq << 40) | (grand & 0xFFFFFFFFFFull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // deferred count (post_capacity = the binning capacity, else ~0): a frame that does not fit leaves a STICKY mark in the slot's second
+        // word -- later frames overwrite the count above, nothing but the host clears this one (gsr_count_slot_overflow)
+        if (grand > post_capacity) __hip_atomic_store(mailbox + GSR_COUNT_SLOTS, grand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // ---- heavy-first launch order for the per-tile kernels --------------------------------------------
     // Per-tile work is heavy-tailed (a few tiles hold thousands of instances).  The dispatcher hands out

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rdscatter(int P, uint3
 __device__ __forceinline__ void tile_scan_256(int tiles, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
                                               uint32_t* __restrict__ tile_cursor, uint2* __restrict__ ranges,
                                               uint32_t* __restrict__ tile_order, uint4* __restrict__ tdesc,
-                                              unsigned long long* __restrict__ total_dev, unsigned long long* mailbox, unsigned long long seq)
+                                              unsigned long long* __restrict__ total_dev, unsigned long long* mailbox, unsigned long long seq, unsigned long long post_capacity)
 {
     __shared__ uint32_t wave_tot[4];
     __shared__ unsigned long long carry_s;
@@ -301,6 +301,9 @@ __device__ __forceinline__ void tile_scan_256(int tiles, const uint32_t* __restr
         *total_dev = grand;
         // post (seq, I) to the host: one 8-byte system-scope store into mapped pinned memory
         __hip_atomic_store(mailbox, (seq << 40) | (grand & 0xFFFFFFFFFFull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // deferred count (post_capacity = the binning capacity, else ~0): a frame that does not fit leaves a STICKY mark in the slot's second
+        // word -- later frames overwrite the count above, nothing but the host clears this one (gsr_count_slot_overflow)
+        if (grand > post_capacity) __hip_atomic_store(mailbox + GSR_COUNT_SLOTS, grand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // heavy-first launch order for the per-tile kernels (pure scheduling, see round 1's k_tile_scan)
     if (tid < 34) bucket[tid] = 0u;
@@ -329,10 +332,10 @@ __global__ __launch_bounds__(256) void k_rdsort(const uint32_t* __restrict__ bco
                                                  const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
                                                  uint32_t* __restrict__ tile_cursor, uint2* __restrict__ ranges,
                                                  uint32_t* __restrict__ tile_order, uint4* __restrict__ tdesc,
-                                                 unsigned long long* __restrict__ total_dev, unsigned long long* mailbox, unsigned long long seq)
+                                                 unsigned long long* __restrict__ total_dev, unsigned long long* mailbox, unsigned long long seq, unsigned long long post_capacity)
 {
     if (blockIdx.x == 0) {
-        tile_scan_256(tiles, tile_count, tile_start, tile_cursor, ranges, tile_order, tdesc, total_dev, mailbox, seq);
+        tile_scan_256(tiles, tile_count, tile_start, tile_cursor, ranges, tile_order, tdesc, total_dev, mailbox, seq, post_capacity);
         return;
     }
     constexpr int KEYS = GSR_SORT_SMALL_KEYS, THREADS = 256, EPT = KEYS / THREADS;

@@ -80,8 +80,9 @@ class GraphedStep:
             for _ in range(self.warmup):
                 if self.before_capture is not None:
                     self.before_capture()
+                _R._forward_peak[0] = 0
                 self.fn()
-                need = max(need, int(_R.last_forward_info().get("num_rendered", 0)))
+                need = max(need, int(_R._forward_peak[0]))   # the largest count of ANY rasterizer forward the step issued
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if self._state is not None:
@@ -118,8 +119,10 @@ class GraphedStep:
         return self._state.counts()
 
     def check(self) -> None:
-        """Raises CapacityOverflow when the newest finished frame did not fit the recorded capacity."""
-        worst = max(self.instances())
+        """Raises CapacityOverflow when ANY replay since the recording (or since the previous check that raised) did not fit the recorded
+        capacity: the device leaves a sticky mark per count slot (include/gsr.h: gsr_count_slot_overflow), so one call after a run of
+        replays -- once their work has finished -- covers all of them.  The mark is cleared when it is reported."""
+        worst = max(max(self.instances()), self._state.overflow(reset=True))
         if worst > self.capacity:
             raise CapacityOverflow(f"{worst} tile instances exceed the recorded binning capacity {self.capacity} "
                                    f"(captured at {self.warm_instances} with headroom {self.headroom}): that frame is not valid; recapture()")
@@ -132,6 +135,7 @@ class GraphedStep:
 
     def close(self) -> None:
         if self._state is not None:
+            torch.cuda.synchronize()   # a replay still in flight would post into a slot its next owner already holds
             self._state.release()
             self._state = None
 

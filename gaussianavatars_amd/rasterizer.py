@@ -104,6 +104,7 @@ _last_info: dict = {}
 
 
 _last_binning: list = [None]
+_forward_peak: list = [0]   # largest instance count of any forward since the caller last zeroed it (GraphedStep's warm-up sizes its capacity from it)
 
 
 def last_forward_info() -> dict:
@@ -142,8 +143,24 @@ class _Deferred:
         return slot
 
     def release(self):
+        """Returns the slots to the pool, their sticky overflow marks cleared (call with none of their frames in flight)."""
+        lib = _lib.gsr()
+        for slot in self.slots:
+            lib.gsr_count_slot_overflow(slot, None, 1)
         _free_slots.extend(self.slots)
         self.slots = []
+
+    def overflow(self, reset: bool = False) -> int:
+        """The STICKY overflow mark of the slots: the instance count of the most recent frame, since the last reset, that did not fit the
+        capacity (0: every frame fitted).  counts() only shows the newest frame of each slot; a replayed recording overwrites it."""
+        lib = _lib.gsr()
+        worst = 0
+        for slot in self.slots:
+            n = C.c_int64(0)
+            if lib.gsr_count_slot_overflow(slot, C.byref(n), int(reset)) != _lib.GSR_OK:
+                raise RuntimeError(_lib.gsr_error())
+            worst = max(worst, int(n.value))
+        return worst
 
     def counts(self) -> list:
         """The newest instance count posted to each slot (-1: nothing yet)."""
@@ -311,6 +328,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             I = cap      # unknown until the kernels have run: the backward takes the capacity as the bound
         else:   # next frame: 25 % headroom over what this one needed, never shrinking below it
             _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
+        if defer is None:
+            _forward_peak[0] = max(_forward_peak[0], I)
         _last_info.update(num_rendered=I if defer is None else -1, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod,
                           binning_path=int(bl.path), rank_bands=int(bl.nbands), bound=False)   # 0 rank path, 1 depth-ordered scatter, 2 per-tile sort (include/gsr.h)
         _last_binning[0] = binning
@@ -438,6 +457,8 @@ class _RasterizeBound(torch.autograd.Function):
             I = cap      # unknown until the kernels have run: the backward takes the capacity as the bound
         else:
             _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
+        if defer is None:
+            _forward_peak[0] = max(_forward_peak[0], I)
         _last_info.update(num_rendered=I if defer is None else -1, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod,
                           binning_path=int(bl.path), rank_bands=int(bl.nbands), bound=True)
         _last_binning[0] = binning
@@ -465,6 +486,12 @@ class _RasterizeBound(torch.autograd.Function):
         s.tile_culling, s.deterministic, s.fast_blend, s.forward_only = ctx.tile_culling, ctx.deterministic, ctx.fast_blend, 0
         P, M, F = xyz.shape[0], ctx.M, ctx.F
         f32 = dict(dtype=torch.float32, device=dev)
+        if P == 0:   # everything pruned: no splat, no gradient -- zeros of the right shapes (the native entries have nothing to point at)
+            z = lambda *shape: torch.zeros(shape, **f32)
+            leaves = (z(0, 3), z(0, 3), z(0, 1, 3), z(0, M - 1, 3), z(0, 1), z(0, 3), z(0, 4))
+            if ctx.unbound:
+                return leaves + (None,) * 7
+            return leaves + (z(F, 3, 3), z(F, 1), z(F, 3), z(F, 4), None, None, None)
         grad_out_color = _f32c(grad_out_color, "grad_out_color")
         g_xyz, g_means2D = torch.empty((P, 3), **f32), torch.empty((P, 3), **f32)
         g_dc, g_rest = torch.empty((P, 1, 3), **f32), torch.empty((P, M - 1, 3), **f32)
@@ -474,12 +501,13 @@ class _RasterizeBound(torch.autograd.Function):
             scratch = torch.empty(9 * P, **f32)                                  # colour / covariance gradients (internal)
             d_face = face_begin = None
         else:
-            scratch = torch.empty(9 * P + _lib.GAB_BIND_ROW_FLOATS * P, **f32)   # ... then the CSR rows
+            rows_at = (9 * P + 3) // 4 * 4                                       # the CSR rows are read and written as float4: 16-byte aligned whatever P is
+            scratch = torch.empty(rows_at + _lib.GAB_BIND_ROW_FLOATS * P, **f32)  # ... then the CSR rows
             d_face = torch.empty(17 * F, **f32)                                  # four contiguous blocks: center | orien_mat | scaling | orien_quat
             order, face_begin, _splat_face, slot = ctx.csr[:4]
             b.binding, b.binding_is_i64, b.F = binding.data_ptr(), ctx.is64, F
             b.face_R, b.face_scale, b.face_center, b.face_quat = fR.data_ptr(), fs.data_ptr(), fc.data_ptr(), fq.data_ptr()
-            b.slot, b.rows = slot.data_ptr(), scratch.data_ptr() + 4 * 9 * P
+            b.slot, b.rows = slot.data_ptr(), scratch.data_ptr() + 4 * rows_at
         stream = _lib.raw_stream(dev)
         with _lib.on_device(dev):
             rc = lib.gsr_backward_bound(C.byref(s), P, M, C.byref(b), _ptr(xyz), _ptr(sh_dc), _ptr(sh_rest), _ptr(opacity_logit), _ptr(log_scaling),

@@ -214,6 +214,11 @@ const char* gsr_last_error(void);
 /* the newest post to persistent count slot `slot` (0..GSR_COUNT_SLOTS-1): *count = the frame's instances (-1: nothing posted yet),
  * *seq = the posting frame's sequence number.  A plain read of mapped host memory, no synchronisation.                        */
 int gsr_count_slot_read(int32_t slot, int64_t* count, int64_t* seq);
+/* The slot's STICKY overflow mark: *worst = the instance count of the most recent frame posted to the slot that exceeded the binning
+ * capacity of its call (0: every frame since the last reset fitted).  gsr_count_slot_read only shows the newest frame -- a replayed
+ * recording overwrites it every launch -- so "did every replay fit" is asked here.  reset != 0 clears the mark (call it with no
+ * frame of the slot in flight: before handing the slot to a new recording).  Plain accesses of mapped host memory.             */
+int gsr_count_slot_overflow(int32_t slot, int64_t* worst, int32_t reset);
 
 /* sizes/layouts of the state buffers (pure host arithmetic, no device access) */
 int gsr_geom_layout(int32_t P, GsrGeomLayout* out);

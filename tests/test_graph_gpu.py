@@ -135,6 +135,39 @@ def test_overflowing_frame_is_reported_and_recapture_recovers():
     step.close()
 
 
+def test_an_overflow_in_an_earlier_replay_stays_reported():
+    """The count slot of a recording only shows its NEWEST replay; a frame that overflowed three replays ago skipped its binning and blend
+    (stale image, zero gradients) all the same.  The device leaves a sticky mark (include/gsr.h: gsr_count_slot_overflow): check() after a
+    run of replays reports it even though the last frame fitted, and clears it."""
+    from gaussianavatars_amd.graphs import CapacityOverflow, FlameRowFeeder, GraphedStep
+
+    dev = _dev()
+    g, cam = _scene(dev, n=60000)
+    bg = torch.ones(3, device=dev)
+    target = torch.full((3, 176, 208), 0.5, device=dev)
+    feeder = FlameRowFeeder(g.flame_param, requires_grad=True)
+    g.flame_param = feeder.static_param
+    step = GraphedStep(lambda: _step(g, cam, bg, target, 0), before_capture=lambda: _zero(g), headroom=1.5)
+    need = step.warm_instances
+    step.replay()
+    torch.cuda.synchronize()
+    step.check()                                    # fits
+    with torch.no_grad():
+        g._scaling.add_(1.0)                        # e-times larger splats: several times the tile instances (the recording reads the leaf in place)
+    step.replay()
+    with torch.no_grad():
+        g._scaling.sub_(1.0)
+    for _ in range(3):
+        step.replay()                               # three fitting frames on top
+    torch.cuda.synchronize()
+    assert max(step.instances()) <= step.capacity   # the newest count is innocent ...
+    assert abs(max(step.instances()) - need) <= need // 10
+    with pytest.raises(CapacityOverflow):
+        step.check()                                # ... the mark is not
+    step.check()                                    # reported once, then cleared
+    step.close()
+
+
 def test_deferred_count_outside_a_graph():
     """The deferred forward by itself (run-ahead without a recording): same image, the count arrives in the slot."""
     from gaussianavatars_amd import rasterizer as R

@@ -77,7 +77,8 @@ def test_python_path_agrees_with_the_kernel_path(flag):
     assert float((alt[3] - base[3]).abs().max()) / (float(base[3].abs().max()) + 1e-30) < 2e-3
 
 
-def test_bound_entry_equals_accessors_plus_rasterizer():
+@pytest.mark.parametrize("N", [30000, 30003])   # 30003: a splat count that is no multiple of four (the backward's scratch rows stay 16-byte aligned)
+def test_bound_entry_equals_accessors_plus_rasterizer(N):
     """render() of a mesh-bound model through the rasterizer's bound entry (the leaves go to world space inside the
     first kernel, include/gsr.h: gsr_forward_bound) against the reference-shaped path (get_xyz / get_scaling / get_rotation /
     get_opacity from gab_bind_forward, then the world-space rasterizer).  The transform is the same arithmetic in both libraries
@@ -90,7 +91,7 @@ def test_bound_entry_equals_accessors_plus_rasterizer():
     from gaussianavatars_amd.gaussian_renderer import render
 
     dev = torch.device("cuda:0")
-    H, W, N, T = 208, 176, 30000, 6
+    H, W, T = 208, 176, 6
     g, cam = bench.build_scene(dev, N, 3, W, H, T, "fused", True)
     bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
     wimg = torch.randn((3, H, W), generator=torch.Generator().manual_seed(4)).to(dev)
@@ -192,3 +193,32 @@ def test_unbound_leaves_entry_equals_torch_activations_plus_rasterizer():
         err = float((x - y).abs().max()) / (float(y.abs().max()) + 1e-30)
         assert err < 5e-5, f"d{name}: rel err {err:.3e}"
     assert float((vs_a - vs_b).abs().max()) / float(vs_b.abs().max()) < 5e-5
+
+
+def test_bound_entry_with_every_splat_pruned():
+    """A mesh-bound model whose splats have all been pruned (P == 0): render() gives the background, backward gives empty leaf gradients and
+    zero face gradients instead of an error from the native entries (they have nothing to point at)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import bench
+    from gaussianavatars_amd.gaussian_renderer import render
+
+    dev = torch.device("cuda:0")
+    g, cam = bench.build_scene(dev, 12000, 3, 96, 80, 3, "fused", True)
+    F = int(g.binding.max().item()) + 1
+    with torch.no_grad():
+        for k in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
+            setattr(g, k, torch.nn.Parameter(getattr(g, k)[:0].clone().requires_grad_(True)))
+        g.binding = g.binding[:0].clone()
+    if hasattr(g, "_binding_csr"):
+        g._binding_csr = None
+    g.select_mesh_by_timestep(1)
+    assert g.face_center.shape[0] == F
+    bg = torch.tensor([0.2, 0.5, 0.3], device=dev)
+    pkg = render(cam, g, bench.Pipe, bg)
+    assert pkg["radii"].numel() == 0 and torch.equal(pkg["render"], bg[:, None, None].expand_as(pkg["render"]))
+    (pkg["render"].sum() + g.face_center.sum() * 0).backward()
+    assert g._xyz.grad is None or g._xyz.grad.numel() == 0
+    for k in ("expr", "rotation", "translation"):
+        gr = g.flame_param[k].grad
+        assert gr is None or float(gr.abs().max()) == 0.0
