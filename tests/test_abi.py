@@ -167,3 +167,63 @@ def test_deferred_count_slots_are_a_finite_pool():
     many.release()
     d.release()
     assert sorted(R._free_slots) == list(range(128)) and len(R._free_slots) == free0
+
+
+def _header_struct_fields(header, name):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), txt, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            m = re.match(r"(.*?)(\w+)$", decl, flags=re.S)
+            out.append((m.group(2), " ".join(m.group(1).split())))
+    return out
+
+
+def test_integration_stub_matches_the_header():
+    """INTEGRATION.md section 2 prints the ctypes stub a maintainer would copy.  A stale stub hands the library a short GsrSettings (garbage in
+    the trailing switches): the field list of include/gsr.h, of the shipped ctypes structure and of the printed stub must be the same,
+    in order and in type, and the calls the stub makes must pass as many arguments as the prototypes take."""
+    from gaussianavatars_amd import _lib
+
+    ctype_of = {"int32_t": C.c_int32, "float": C.c_float, "const float*": C.c_void_p}
+    hdr = _header_struct_fields("gsr.h", "GsrSettings")
+    want = [(n, ctype_of[t]) for n, t in hdr]
+    shipped = [(n, t) for n, t in _lib.GsrSettings._fields_]
+    assert [n for n, _ in shipped] == [n for n, _ in want]
+    for (n, t), (_, w) in zip(shipped, want):
+        assert C.sizeof(t) == C.sizeof(w), n
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(import ctypes as C, torch\n.*?)```", doc, flags=re.S).group(1)
+    cls = re.search(r"(class GsrSettings\(C\.Structure\):.*?\n)\ndef ", block, flags=re.S).group(1)
+    ns = {"C": C}
+    exec(cls, ns)
+    stub = ns["GsrSettings"]._fields_
+    assert [n for n, _ in stub] == [n for n, _ in want], "INTEGRATION.md prints a GsrSettings that is not include/gsr.h's"
+    assert C.sizeof(ns["GsrSettings"]) == C.sizeof(_lib.GsrSettings)
+    for (n, t), (_, w) in zip(stub, want):
+        assert C.sizeof(t) == C.sizeof(w), n
+    assert "gsr_abi_version() == %d" % _header_abi("gsr.h") in block
+    # the positional GsrSettings(...) construction fills every field
+    ctor = re.search(r"s = GsrSettings\((.*?)\)\n    gl, bl", block, flags=re.S).group(1)
+    depth, nargs = 0, 1
+    for ch in ctor:
+        depth += ch in "([" 
+        depth -= ch in ")]"
+        nargs += ch == "," and depth == 0
+    assert nargs == len(want)
+    # argument counts of the calls against the prototypes
+    for fn in ("gsr_geom_layout", "gsr_image_layout", "gsr_binning_layout", "gsr_forward"):
+        call = re.search(r"lib\.%s\((.*?)\)\n" % fn, block, flags=re.S)
+        if fn == "gsr_forward":
+            call = re.search(r"lib\.gsr_forward\((.*?)\)\n        if rc == 1", block, flags=re.S)
+        if fn == "gsr_geom_layout":
+            call = re.search(r"lib\.gsr_geom_layout\((.*?)\);", block, flags=re.S)
+        args, depth, n = call.group(1), 0, 1
+        for ch in args:
+            depth += ch in "(["
+            depth -= ch in ")]"
+            n += ch == "," and depth == 0
+        assert n == len(_lib.GSR_SYMBOLS[fn][1]), f"{fn}: the stub passes {n} arguments, the prototype takes {len(_lib.GSR_SYMBOLS[fn][1])}"
