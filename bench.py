@@ -556,8 +556,8 @@ def main():
                 "k_preprocess_bwd": 300 * N + 256 * N,
             }
             if path == 0:   # rank path: bytes per splat N / per tile instance I of each pass
-                a.update({
-                    "k_preprocess": a["k_preprocess"] + 40 * N,   # + binned rect (8) and the quadrant-test operands (32)
+                a.update({   # (k_preprocess stays at SURVEY.md 8(d)'s design-independent 236 N + 44 vN (+27 vN): the rank path's own rows -- binned
+                    # rect 8 B, quadrant-test operands 32 B per splat -- are traffic of this design, they show up in `traffic`, not here)
                     "k_count": 16 * N,                             # rect 8, tiles_touched 4, depth 4
                     "k_depth_sort": 20 * N + 12 * N,               # bucket scatter: rect 8 + depth 4 read, key 8 written; bucket sort: key 8 read, rank 4 written
                     "k_scatter": 44 * N + 8 * I,                   # rect 8 + rank 4 + operands 32 read per splat, one 8-byte entry written per instance

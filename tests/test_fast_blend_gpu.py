@@ -135,3 +135,43 @@ def test_fast_and_exact_agree_on_the_benchmark_frame():
         a, b = out[True]["flame"][k], out[False]["flame"][k]
         assert np.abs(a - b).max() <= 2e-3 * (np.abs(b).max() + 1e-20), k
     print(f"cfg3: {n} threshold pixel(s), image max|diff| {np.abs(out[True]['img'] - out[False]['img']).max():.2e}")
+
+
+def test_fast_bound_entry_on_the_rigged_200k_frame_vs_oracle(oracle):
+    """BASELINE configs[3] (200 000 splats on the 5143-vertex rig) through what bench.py runs by default: the bound entry in fast-blend mode.
+    Image against the oracle (fed the world-space splats of the accessor path) within the stated tolerance, leaf gradients against the
+    oracle's world-space gradients carried to the leaves in fp64 (tests/test_fullsize_gpu.py: _leaf_gradients_fp64)."""
+    import bench
+    from gaussianavatars_amd.gaussian_renderer import l1_loss, render
+    from gaussianavatars_amd.rasterizer import set_fast_blend
+    from tests.test_fullsize_gpu import _leaf_gradients_fp64
+
+    dev = _dev()
+    H, W, N, T, ts = 802, 550, 200_000, 300, 137
+    g, cam = bench.build_scene(dev, N, 3, W, H, T, "fused", True)
+    bg = torch.ones(3, device=dev)
+    target = torch.ones((3, H, W), device=dev)
+    tfx, tfy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    s = oracle.make_settings(H, W, tfx, tfy, [1, 1, 1], 1.0, _np(cam.world_view_transform), _np(cam.full_proj_transform), 3, _np(cam.camera_center))
+    g.select_mesh_by_timestep(ts)
+    with torch.no_grad():
+        a = {k: _np(v) for k, v in dict(means3D=g.get_xyz, opacities=g.get_opacity, scales=g.get_scaling, rotations=g.get_rotation).items()}
+        shs = _np(g.get_features)
+    st = oracle.forward(s, a["means3D"], shs, None, a["opacities"], a["scales"], a["rotations"], None)
+    ref = oracle.backward(s, st, (np.sign(st.color - 1.0) / st.color.size).astype(np.float32))
+    want = _leaf_gradients_fp64(g, ts, ref)
+    assert set_fast_blend(True) is True
+    g.bound_render = True
+    bench.zero_grads(g)
+    g.select_mesh_by_timestep(ts)
+    pkg = render(cam, g, bench.Pipe, bg)
+    l1_loss(pkg["render"], target).backward()
+    np.testing.assert_array_equal(_np(pkg["radii"]), st.radii)
+    n = check_image(_np(pkg["render"]), st.color, float(st.rgb[st.radii > 0].max()), "cfg4")
+    got = dict(_xyz=g._xyz.grad, _scaling=g._scaling.grad, _rotation=g._rotation.grad, _opacity=g._opacity.grad,
+               _features_dc=g._features_dc.grad, _features_rest=g._features_rest.grad)
+    for k, v in got.items():
+        r = np.asarray(want[k], np.float64).reshape(tuple(v.shape))
+        err = np.abs(_np(v).astype(np.float64) - r).max() / (np.abs(r).max() + 1e-30)
+        assert err < 5e-4, f"bound entry, fast blend: d{k} rel err {err:.2e}"
+    print(f"cfg4 fast blend: {n} threshold pixel(s)")

@@ -105,6 +105,33 @@ def test_config2_100k_bound_forward_backward_vs_oracle(oracle):
     assert float(err) < 1e-4
 
 
+def _leaf_gradients_fp64(g, ts, ref):
+    """The oracle's world-space gradients `ref` (means3D, scales, rotations, opacities, shs) carried to the model's leaves and to row `ts`
+    of the FLAME tables by the composed-torch binding in double precision."""
+    from gaussianavatars_amd import unfused as U
+
+    dev = g._xyz.device
+    d = lambda t: t.detach().to(torch.float64)
+    fm = g.flame_model
+    rig = {k: d(getattr(fm, k)) for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights")}
+    rig["parents"] = fm.parents
+    fp = g.flame_param
+    rows = {k: d(fp[k][[ts]]).requires_grad_(True) for k in ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation")}
+    leaves = {k: d(getattr(g, k)).requires_grad_(True) for k in ("_xyz", "_scaling", "_rotation", "_opacity")}
+    verts, _ = U.flame_forward(rig, d(fp["shape"])[None], rows["expr"], rows["rotation"], rows["neck_pose"], rows["jaw_pose"], rows["eyes_pose"],
+                               rows["translation"], d(fp["static_offset"]))
+    c, R, sc, q = U.face_frames(verts[0], fm.faces)
+    world = [U.bind_xyz(leaves["_xyz"], g.binding, R, sc, c), U.bind_scaling(leaves["_scaling"], g.binding, sc),
+             U.bind_rotation(leaves["_rotation"], g.binding, q), torch.sigmoid(leaves["_opacity"])]
+    grads = [torch.as_tensor(ref[k], dtype=torch.float64, device=dev).reshape(w.shape) for k, w in zip(("means3D", "scales", "rotations", "opacities"), world)]
+    torch.autograd.backward(world, grads)
+    out = {k: v.grad.cpu().numpy() for k, v in leaves.items()}
+    out.update({"flame_" + k: v.grad[0].cpu().numpy() for k, v in rows.items()})
+    shs = np.asarray(ref["shs"], np.float64)
+    out["_features_dc"], out["_features_rest"] = shs[:, :1], shs[:, 1:]
+    return out
+
+
 def test_config4_200k_rigged_sequence_vs_oracle(oracle):
     """BASELINE configs[3]: 200 000 splats bound to the 5143-vertex synthetic FLAME rig, 300-frame expression sequence.
     Three timesteps through the model path the benchmark runs (select_mesh_by_timestep -> render -> L1 vs white -> backward,
@@ -159,6 +186,27 @@ def test_config4_200k_rigged_sequence_vs_oracle(oracle):
             other = torch.ones(gk.shape[0], dtype=torch.bool, device=gk.device)
             other[ts] = False
             assert float(gk[ts].abs().max()) > 0 and float(gk[other].abs().max()) == 0.0   # row ts only
+        # ---- what the benchmark actually runs, gradients included: the BOUND entry (leaves in, leaf gradients out, no world-space tensors).
+        # Anchor: the oracle's world-space gradients pushed through the binding in fp64 -- the composed-torch statement of
+        # scene/gaussian_model.py:113-150, utils/graphics_utils.py:116-135 and flame_model/lbs.py (gaussianavatars_amd/unfused.py, itself
+        # pinned to the reference's classes by tests/test_model_pins.py) under torch autograd.
+        want = _leaf_gradients_fp64(g, ts, ref)
+        g.bound_render = True
+        bench.zero_grads(g)
+        g.select_mesh_by_timestep(ts)
+        pkg = render(cam, g, bench.Pipe, bg)
+        l1_loss(pkg["render"], target).backward()
+        got = dict(_xyz=g._xyz.grad, _scaling=g._scaling.grad, _rotation=g._rotation.grad, _opacity=g._opacity.grad,
+                   _features_dc=g._features_dc.grad, _features_rest=g._features_rest.grad, means2D=pkg["viewspace_points"].grad)
+        want["means2D"] = ref["means2D"]
+        for k, v in got.items():
+            r = np.asarray(want[k], np.float64).reshape(tuple(v.shape))
+            err = np.abs(_np(v).astype(np.float64) - r).max() / (np.abs(r).max() + 1e-30)
+            assert err < 5e-4, f"t={ts} bound entry d{k}: rel err {err:.2e}"
+        for k in ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation"):
+            r = want["flame_" + k]
+            err = np.abs(_np(g.flame_param[k].grad[ts]).astype(np.float64) - r).max() / (np.abs(r).max() + 1e-30)
+            assert err < 2e-3, f"t={ts} bound entry d flame {k}: rel err {err:.2e}"    # (sums over 200 k splats of cancelling terms: the fp32 kernels' own noise, cf. test_model_pins)
 
 
 def test_config5_2m_stress_forward(oracle):
