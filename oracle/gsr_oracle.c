@@ -33,6 +33,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <omp.h>
 
 #define ORA_BLOCK_X 16
 #define ORA_BLOCK_Y 16
@@ -333,7 +334,7 @@ int64_t ora_scan(int P, const uint32_t* tiles_touched, uint32_t* offsets)
 
 /* Stable sort of the (key, value) pairs by key = tile << 32 | depth bits -- what one stable radix sort over the low
  * 32 + bits(tiles) key bits produces (A.2) -- organised so that the host cores can share it: one stable counting-sort pass
- * by tile (serial; the order inside a tile stays the emission order, i.e. ascending splat index), then every tile's segment is
+ * by tile (stable_group below; the order inside a tile stays the emission order, i.e. ascending splat index), then every tile's segment is
  * sorted on its own by the 32 depth bits with a stable LSD radix (8 bits a pass; short segments by stable insertion), OpenMP
  * over tiles. */
 static void sort_segment(uint64_t* k, uint32_t* v, uint64_t* tk, uint32_t* tv, int64_t n)
@@ -367,24 +368,60 @@ static void sort_segment(uint64_t* k, uint32_t* v, uint64_t* tk, uint32_t* tv, i
     /* four passes: the result is back in (k, v) */
 }
 
+/* perm[0..n) = the indices 0..n-1 grouped by bin[i] (ascending index inside a bin), start[0..nbins] = the groups' first positions:
+ * a STABLE counting sort whose two passes the host cores share -- the index range is cut into chunks, every chunk histograms its own
+ * stretch, a prefix over (bin, chunk) gives every chunk its private cursor per bin, and the chunks scatter in order.  The result does
+ * not depend on the number of chunks or threads. */
+static void stable_group(const uint32_t* bin, uint32_t shift_is_key_hi, const uint64_t* key64, int64_t n, int64_t nbins, int64_t* start,
+                         int64_t* perm)
+{
+    int chunks = omp_get_max_threads();
+    if (chunks > 64) chunks = 64;
+    while (chunks > 1 && (int64_t)chunks * nbins > (int64_t)(1 << 25)) chunks /= 2;
+    if (n < 4096) chunks = 1;
+    int64_t* hist = (int64_t*)calloc((size_t)chunks * (size_t)nbins + 1, sizeof(int64_t));
+    const int64_t per = (n + chunks - 1) / chunks;
+#define BIN_OF(i) (shift_is_key_hi ? (int64_t)(key64[i] >> 32) : (int64_t)bin[i])
+#pragma omp parallel for schedule(static, 1)
+    for (int c = 0; c < chunks; ++c) {
+        int64_t* h = hist + (size_t)c * (size_t)nbins;
+        const int64_t lo = c * per, hi = lo + per < n ? lo + per : n;
+        for (int64_t i = lo; i < hi; ++i) h[BIN_OF(i)]++;
+    }
+    int64_t run = 0;
+    for (int64_t b = 0; b < nbins; ++b) {
+        start[b] = run;
+        for (int c = 0; c < chunks; ++c) {
+            int64_t* h = hist + (size_t)c * (size_t)nbins + b;
+            const int64_t cnt = *h;
+            *h = run;
+            run += cnt;
+        }
+    }
+    start[nbins] = run;
+#pragma omp parallel for schedule(static, 1)
+    for (int c = 0; c < chunks; ++c) {
+        int64_t* h = hist + (size_t)c * (size_t)nbins;
+        const int64_t lo = c * per, hi = lo + per < n ? lo + per : n;
+        for (int64_t i = lo; i < hi; ++i) perm[h[BIN_OF(i)]++] = i;
+    }
+#undef BIN_OF
+    free(hist);
+}
+
 static void sort_pairs_by_tile_then_depth(uint64_t* keys, uint32_t* vals, uint64_t* tk, uint32_t* tv, int64_t n, int tiles)
 {
     int64_t* start = (int64_t*)calloc((size_t)tiles + 1, sizeof(int64_t));
-    for (int64_t i = 0; i < n; ++i) start[(keys[i] >> 32) + 1]++;
-    for (int t = 0; t < tiles; ++t) start[t + 1] += start[t];
-    int64_t* cur = (int64_t*)malloc((size_t)tiles * sizeof(int64_t));
-    memcpy(cur, start, (size_t)tiles * sizeof(int64_t));
-    for (int64_t i = 0; i < n; ++i) {
-        const int64_t dst = cur[keys[i] >> 32]++;
-        tk[dst] = keys[i];
-        tv[dst] = vals[i];
-    }
-    memcpy(keys, tk, (size_t)n * sizeof(uint64_t));
-    memcpy(vals, tv, (size_t)n * sizeof(uint32_t));
+    int64_t* perm = (int64_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int64_t));
+    stable_group(NULL, 1u, keys, n, tiles, start, perm);   /* by tile; inside a tile the emission order (ascending splat index) stays */
+#pragma omp parallel for schedule(static)
+    for (int64_t d = 0; d < n; ++d) { tk[d] = keys[perm[d]]; tv[d] = vals[perm[d]]; }
+#pragma omp parallel for schedule(static)
+    for (int64_t d = 0; d < n; ++d) { keys[d] = tk[d]; vals[d] = tv[d]; }
 #pragma omp parallel for schedule(dynamic, 8)
     for (int t = 0; t < tiles; ++t)
         sort_segment(keys + start[t], vals + start[t], tk + start[t], tv + start[t], start[t + 1] - start[t]);
-    free(cur);
+    free(perm);
     free(start);
 }
 
@@ -517,8 +554,11 @@ void ora_render_backward(const OraSettings* s, int P, const uint32_t* ranges, co
     for (int t = 0; t < gx * gy; ++t)
         if (ranges[2 * t + 1] > I) I = ranges[2 * t + 1];
     if (I == 0) return;
-    double* part = (double*)calloc(I * 9, sizeof(double));   /* per instance: mean2D 2, conic 3, opacity 1, colour 3 */
+    double* part = (double*)malloc((I > 0 ? I : 1) * 9 * sizeof(double));   /* per instance: mean2D 2, conic 3, opacity 1, colour 3 */
     if (!part) return;
+#pragma omp parallel for schedule(static)   /* zeroed (and first touched) by every core: 166 MB at 100 k splats */
+    for (int64_t k = 0; k < (int64_t)I; ++k)
+        for (int c = 0; c < 9; ++c) part[9 * k + c] = 0.0;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gx * gy; ++tile) {
         const uint32_t r0 = ranges[2 * tile];
@@ -575,18 +615,29 @@ void ora_render_backward(const OraSettings* s, int P, const uint32_t* ranges, co
             }
         }
     }
-    for (size_t k = 0; k < I; ++k) {   /* sequential fold, list order: deterministic */
-        const uint32_t id = point_list[k];
-        const double* acc = part + 9 * k;
-        dL_dmean2D[2 * id + 0] += acc[0];
-        dL_dmean2D[2 * id + 1] += acc[1];
-        dL_dconic[3 * id + 0] += acc[2];
-        dL_dconic[3 * id + 1] += acc[3];
-        dL_dconic[3 * id + 2] += acc[4];
-        dL_dopacity[id] += acc[5];
-        dL_dcolor[3 * id + 0] += acc[6];
-        dL_dcolor[3 * id + 1] += acc[7];
-        dL_dcolor[3 * id + 2] += acc[8];
+    /* fold per splat, in LIST order (ascending position): the sums are the same whatever the thread count.  The positions of every
+     * splat come from a stable grouping of the list by splat index (the host cores share it), then the splats are independent. */
+    {
+        int64_t* start = (int64_t*)calloc((size_t)P + 1, sizeof(int64_t));
+        int64_t* perm = (int64_t*)malloc((I > 0 ? I : 1) * sizeof(int64_t));
+        stable_group(point_list, 0u, NULL, (int64_t)I, (int64_t)P, start, perm);
+#pragma omp parallel for schedule(dynamic, 512)
+        for (int id = 0; id < P; ++id) {
+            for (int64_t d = start[id]; d < start[id + 1]; ++d) {
+                const double* acc = part + 9 * (size_t)perm[d];
+                dL_dmean2D[2 * id + 0] += acc[0];
+                dL_dmean2D[2 * id + 1] += acc[1];
+                dL_dconic[3 * id + 0] += acc[2];
+                dL_dconic[3 * id + 1] += acc[3];
+                dL_dconic[3 * id + 2] += acc[4];
+                dL_dopacity[id] += acc[5];
+                dL_dcolor[3 * id + 0] += acc[6];
+                dL_dcolor[3 * id + 1] += acc[7];
+                dL_dcolor[3 * id + 2] += acc[8];
+            }
+        }
+        free(perm);
+        free(start);
     }
     free(part);
 }
