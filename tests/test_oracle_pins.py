@@ -177,3 +177,27 @@ def test_fp64_restatement_gradient_is_a_gradient():
     t = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
     assert torch.autograd.gradcheck(f, (t(sp["means3D"]), t(sp["scales"]), t(sp["rotations"]), t(sp["opacities"])),
                                     eps=1e-7, atol=1e-5, rtol=1e-3, nondet_tol=0.0)
+
+
+def test_oracle_results_do_not_depend_on_the_thread_count(oracle):
+    """The oracle's sort (stable grouping by tile, per-tile radix sort) and backward (per-tile partial rows, folded per splat in list
+    order) are shared by the host cores -- bench.py's cpu_baseline times them on every core and on one -- with the same bits either way."""
+    import math
+
+    from tests.scenes import scene, settings_args
+
+    cam, sp, bg, deg, mod = scene("sh3_small")
+    s = oracle.make_settings(**settings_args(cam, bg, deg, mod))
+    gpix = np.random.default_rng(3).normal(0, 1, (3, cam.image_height, cam.image_width)).astype(np.float32)
+    out = {}
+    try:
+        for th in (1, 4):
+            oracle.set_threads(th)
+            st = oracle.forward(s, sp["means3D"], sp["shs"], None, sp["opacities"], sp["scales"], sp["rotations"], None)
+            g = oracle.backward(s, st, gpix)
+            out[th] = [st.keys, st.point_list, st.ranges, st.color, st.n_contrib] + [g[k] for k in ("means3D", "means2D", "shs", "opacities", "scales", "rotations")]
+    finally:
+        oracle.set_threads(0)
+    assert out[1][0].size > 4096                       # (the parallel grouping takes its multi-chunk path)
+    for a, b in zip(out[1], out[4]):
+        assert np.array_equal(a, b)
