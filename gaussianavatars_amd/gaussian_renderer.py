@@ -66,7 +66,9 @@ def _bound_fast_path(pc, pipe, override_color) -> bool:
     "unfused" models, `pc.bound_render = False`) takes the reference-shaped path below."""
     if override_color is not None or pipe.compute_cov3D_python or pipe.convert_SHs_python:
         return False
-    if getattr(pc, "binding_impl", "fused") == "unfused" or not getattr(pc, "bound_render", True):
+    from .patch import _default_impl
+
+    if getattr(pc, "binding_impl", _default_impl()) == "unfused" or not getattr(pc, "bound_render", True):
         return False
     if not getattr(type(pc), "_gaa_patched", False) or getattr(pc, "get_features_split", None) is None:
         return False

@@ -31,8 +31,13 @@ import torch
 _ORIG: dict = {}   # (class, attribute) -> the original attribute, for unpatch() and the "unfused" opt-out
 
 
+def _default_impl() -> str:
+    """GAA_BINDING_IMPL=unfused: objects that do not say otherwise keep the reference's composed-torch methods (CPU tensors, A/B runs)."""
+    return os.environ.get("GAA_BINDING_IMPL", "fused")
+
+
 def _fused(self) -> bool:
-    return getattr(self, "binding_impl", "fused") != "unfused"
+    return getattr(self, "binding_impl", _default_impl()) != "unfused"
 
 
 # ------------------------------------------------------------------------------------------------
@@ -162,7 +167,7 @@ def _make_flame_forward(cls):
 
     def forward(self, shape, expr, rotation, neck, jaw, eyes, translation, zero_centered_at_root_node=False,
                 return_landmarks=True, return_verts_cano=False, static_offset=None, dynamic_offset=None):
-        fusable = (getattr(self, "impl", "fused") != "unfused" and not zero_centered_at_root_node and not return_landmarks
+        fusable = (getattr(self, "impl", _default_impl()) != "unfused" and not zero_centered_at_root_node and not return_landmarks
                    and shape.shape[0] == 1)
         if not fusable:
             kw = dict(zero_centered_at_root_node=zero_centered_at_root_node, return_landmarks=return_landmarks,

@@ -207,3 +207,104 @@ def bound_splats(n: int, n_faces: int, sh_degree: int, seed: int) -> Dict[str, n
         binding=binding,
     )
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# assets in the REFERENCE's on-disk formats: what an unchanged entry script needs to start
+# --------------------------------------------------------------------------------------------
+
+
+def read_obj_topology(path: str) -> Tuple[np.ndarray, np.ndarray]:
+    """(verts (V,3) f32, faces (F,3) int64, 0-based) of a triangle OBJ with `f v/vt v/vt v/vt` records (the FLAME template's layout)."""
+    v, f = [], []
+    with open(path) as fh:
+        for ln in fh:
+            if ln.startswith("v "):
+                v.append([float(x) for x in ln.split()[1:4]])
+            elif ln.startswith("f "):
+                f.append([int(tok.split("/")[0]) - 1 for tok in ln.split()[1:4]])
+    return np.asarray(v, np.float32), np.asarray(f, np.int64)
+
+
+def flame_pickle_dict(v_template: np.ndarray, faces: np.ndarray, seed: int = 4) -> Dict[str, np.ndarray]:
+    """A dict with the keys and shapes FlameHead.__init__ reads from flame2023.pkl (flame_model/flame.py:98-129): `v_template (V,3)`,
+    `shapedirs (V,3,400)` (first 300 shape, then 100 expression directions), `posedirs (V,3,36)`, `J_regressor (5,V)`,
+    `kintree_table (2,5)`, `weights (V,5)`, `f (F,3)` -- synthetic values on the given topology (the licensed model cannot be shipped):
+    smooth blend directions, joints at neck base / neck / jaw / two eyes of the head's bounding box."""
+    g = np.random.default_rng(seed)
+    V = v_template.shape[0]
+    lo, hi = v_template.min(0), v_template.max(0)
+    c, ext = (lo + hi) / 2, float((hi - lo).max()) / 2
+    u = (v_template - c) / ext                                              # roughly [-1, 1]^3
+    basis = np.concatenate([u, np.sin(3.0 * u), np.cos(2.0 * u)], 1)        # (V,9)
+    mix = g.normal(0.0, 1.0, (9, 3 * (N_SHAPE + N_EXPR)))
+    shapedirs = (basis @ mix).reshape(V, 3, N_SHAPE + N_EXPR) * (ext * 2e-2 / 3.0)
+    posedirs = g.normal(0.0, ext * 8e-3, (V, 3, 36))
+    joints = c + ext * np.array([[0, -0.85, -0.1], [0, -0.45, -0.1], [0, -0.2, 0.25], [0.27, 0.3, 0.65], [-0.27, 0.3, 0.65]])
+    J_regressor = np.zeros((FLAME_J, V))
+    weights = np.zeros((V, FLAME_J))
+    for j in range(FLAME_J):
+        d2 = ((v_template - joints[j]) ** 2).sum(1)
+        near = np.argsort(d2)[:50]
+        w = np.exp(-d2[near] / (2 * (0.17 * ext) ** 2))
+        J_regressor[j, near] = w / w.sum()
+        weights[:, j] = np.exp(-d2 / (2 * ((0.5 if j < 3 else 0.12) * ext) ** 2))
+    weights[:, 0] += 1e-3
+    weights /= weights.sum(1, keepdims=True)
+    kintree = np.array([[4294967295, 0, 1, 1, 1], [0, 1, 2, 3, 4]], np.int64)    # row 0 = parents (the reader overwrites entry 0 with -1)
+    return dict(v_template=v_template.astype(np.float64), shapedirs=shapedirs.astype(np.float32), posedirs=posedirs.astype(np.float32), J_regressor=J_regressor,
+                kintree_table=kintree, weights=weights, f=faces.astype(np.uint32))
+
+
+def flame_masks_dict(v_template: np.ndarray) -> Dict[str, np.ndarray]:
+    """FLAME_masks.pkl's regions (flame_model/flame.py:625-637) cut geometrically from the head's bounding box: every region the
+    reference's FlameMask.create_custom_mask combines is present and non-empty, none claims to be anatomically right."""
+    lo, hi = v_template.min(0), v_template.max(0)
+    u = (v_template - (lo + hi) / 2) / ((hi - lo) / 2)      # [-1,1] per axis: x left/right, y up, z front
+    ids = np.arange(v_template.shape[0])
+    x, y, z = u[:, 0], u[:, 1], u[:, 2]
+    sel = lambda m: ids[m].astype(np.int64)
+    eye_l = (np.abs(x - 0.35) < 0.18) & (np.abs(y - 0.25) < 0.14) & (z > 0.3)
+    eye_r = (np.abs(x + 0.35) < 0.18) & (np.abs(y - 0.25) < 0.14) & (z > 0.3)
+    ball_l = (np.abs(x - 0.35) < 0.08) & (np.abs(y - 0.25) < 0.07) & (z > 0.3)
+    ball_r = (np.abs(x + 0.35) < 0.08) & (np.abs(y - 0.25) < 0.07) & (z > 0.3)
+    return dict(
+        face=sel((z > 0.0) & (y > -0.55) & (y < 0.6)), neck=sel(y < -0.45), scalp=sel((y > 0.45) | ((z < 0.0) & (y > -0.3))),
+        boundary=sel(y < -0.92), right_eyeball=sel(ball_r), left_eyeball=sel(ball_l), right_ear=sel((x < -0.8) & (np.abs(y) < 0.3)),
+        left_ear=sel((x > 0.8) & (np.abs(y) < 0.3)), forehead=sel((z > 0.2) & (y > 0.4) & (y < 0.75)), eye_region=sel(eye_l | eye_r),
+        nose=sel((np.abs(x) < 0.15) & (np.abs(y) < 0.2) & (z > 0.6)), lips=sel((np.abs(x) < 0.3) & (np.abs(y + 0.3) < 0.1) & (z > 0.5)),
+        right_eye_region=sel(eye_r), left_eye_region=sel(eye_l))
+
+
+def write_reference_assets(asset_dir: str, avatar_dir: str, template_obj: str, n_splats: int = FLAME_F, n_frames: int = 4, sh_degree: int = 3,
+                           seed: int = 4) -> Dict[str, str]:
+    """Everything an unchanged `fps_benchmark_demo.py` / `render.py` of the reference opens, in the reference's own formats:
+      asset_dir/flame2023.pkl, asset_dir/FLAME_masks.pkl   what FlameHead() unpickles (flame_model/flame.py:37-38,98-129,625-637);
+      avatar_dir/point_cloud.ply + avatar_dir/flame_param.npz   a mesh-bound avatar as GaussianModel.save_ply / FlameGaussianModel.save_ply
+                                                              write it (scene/gaussian_model.py:253-275, scene/flame_gaussian_model.py:219-224).
+    `template_obj` is the checkout's flame_model/assets/flame/head_template_mesh.obj (the pickle's `f` has to equal its faces,
+    flame.py:170).  The avatar is bound to the template + teeth topology the reference builds (10144 faces, 5143 vertices)."""
+    import os
+    import pickle
+
+    from . import io as gio
+
+    v, f = read_obj_topology(template_obj)
+    os.makedirs(asset_dir, exist_ok=True)
+    os.makedirs(avatar_dir, exist_ok=True)
+    out = dict(flame_model=os.path.join(asset_dir, "flame2023.pkl"), flame_masks=os.path.join(asset_dir, "FLAME_masks.pkl"),
+               point_cloud=os.path.join(avatar_dir, "point_cloud.ply"), flame_param=os.path.join(avatar_dir, "flame_param.npz"))
+    with open(out["flame_model"], "wb") as fh:
+        pickle.dump(flame_pickle_dict(v, f, seed), fh, protocol=2)
+    with open(out["flame_masks"], "wb") as fh:
+        pickle.dump(flame_masks_dict(v), fh, protocol=2)
+    arrs = bound_splats(max(n_splats, FLAME_F), FLAME_F, sh_degree, seed=2)
+    ext = float((v.max(0) - v.min(0)).max())
+    arrs["_scaling"] = arrs["_scaling"] - 0.5      # (smaller splats than the benchmark scene: this avatar is for starting scripts, not for timing)
+    gio.save_ply(out["point_cloud"], arrs)
+    seq = flame_sequence(n_frames, seed)
+    # the template sits where the FLAME fitting left it (its head around y = 1.5 m): the per-frame translation brings it in front of the
+    # benchmark's orbit camera, which looks at the origin (fps_benchmark_demo.py:21-33)
+    seq["translation"] = (seq["translation"] * (ext / 0.24) - (v.min(0) + v.max(0)) / 2).astype(np.float32)
+    gio.save_flame_param(out["flame_param"], seq)
+    return out
