@@ -168,7 +168,8 @@ def sync_densification_stats(model) -> None:
     process accumulates over the frames IT rendered (scene/gaussian_model.py:426-519: xyz_gradient_accum / denom /
     max_radii2D); replicas that see different frames would diverge at the first densify_and_prune.  Summing the two
     accumulators and taking the maximum of the radii over all ranks right before that call gives every rank the statistics of
-    the whole frame set, hence identical decisions (together with seed_all_ranks for the split sampling)."""
+    the whole frame set, hence identical decisions (together with seed_all_ranks for the split sampling and, for a mesh-bound model,
+    sync_mesh_for_densification: the decisions also read the current mesh)."""
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -176,6 +177,25 @@ def sync_densification_stats(model) -> None:
     dist.all_reduce(model.xyz_gradient_accum, op=dist.ReduceOp.SUM)
     dist.all_reduce(model.denom, op=dist.ReduceOp.SUM)
     dist.all_reduce(model.max_radii2D, op=dist.ReduceOp.MAX)
+
+
+def sync_mesh_for_densification(model, timestep: int, src: int = 0) -> int:
+    """densify_and_prune reads the CURRENT mesh: `get_scaling` (= exp(_scaling) * face_scaling of the last select_mesh_by_timestep) decides
+    clone vs split and the size prune, and the split writes `selected_scaling / face_scaling` into the new splats
+    (scene/gaussian_model.py:462-475, 498-515).  Every replica just rendered a DIFFERENT frame, so the decisions would differ (found by
+    check_replica_consistency in tests/test_dp_training_cpu.py): all ranks take rank `src`'s timestep for the densification.
+    Returns that timestep."""
+    import torch.distributed as dist
+
+    t = int(timestep)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        buf = torch.tensor([t], dtype=torch.int64, device=_collective_device())
+        dist.broadcast(buf, src=src)
+        t = int(buf.item())
+    if getattr(model, "binding", None) is not None:
+        with torch.no_grad():
+            model.select_mesh_by_timestep(t)
+    return t
 
 
 def seed_all_ranks(iteration: int, base_seed: int = 0) -> int:
