@@ -1,11 +1,11 @@
 #!/bin/bash
-# SQ counters of one kernel:  bash tools/pmc_kernel.sh <kernel substring> "<COUNTERS pass 1>" "<COUNTERS pass 2>" ...
+# SQ counters of one kernel:  [PMC_BENCH_ARGS="--workload cfg4"] bash tools/pmc_kernel.sh <kernel substring> "<COUNTERS pass 1>" "<COUNTERS pass 2>" ...
 K=$1; shift
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 i=0
 for C in "$@"; do
   i=$((i+1)); D=gpurun_out/pmck_$i; rm -rf $D
-  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-profile --frame-streams 0 > $D.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python bench.py ${PMC_BENCH_ARGS:-} --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-profile --frame-streams 0 > $D.log 2>&1
   python - "$D" "$K" <<'PY'
 import csv, glob, sys, collections
 d, k = sys.argv[1], sys.argv[2]
@@ -17,4 +17,5 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
 for c, v in sorted(per.items()):
     print(f"{c:28s} {v / max(1, len(disp[c])):16.1f} per launch  ({len(disp[c])} launches)")
 PY
+  rm -rf $D   # the raw per-dispatch tables are large (gpurun_out/ is capped at 64 MiB); the printed summary is what is kept
 done
