@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
             float power, a;
             if constexpr (FAST) {   // the record holds the conic scaled by -log2(e)/2: power = log2 of the Gaussian, five instructions
                 power = __builtin_fmaf(__builtin_fmaf(R.a[u][3], dy, R.a[u][2] * dx), dx, (R.a[u][4] * dy) * dy);
-                a = sel_min(0.99f, R.a[u][5] * __builtin_amdgcn_exp2f(power));
+                a = __builtin_fminf(0.99f, R.a[u][5] * __builtin_amdgcn_exp2f(power));   // (one v_min_f32; a NaN power fails the test below either way)
             } else {
                 power = -0.5f * (R.a[u][2] * dx * dx + R.a[u][4] * dy * dy) - R.a[u][3] * dx * dy;
                 a = sel_min(0.99f, R.a[u][5] * gsr_expf_blend(power));
@@ -995,7 +995,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
                 float power, a;
                 if constexpr (FAST) {
                     power = __builtin_fmaf(__builtin_fmaf(r0.w, dy, r0.z * dx), dx, (r1.x * dy) * dy);
-                    a = sel_min(0.99f, r1.y * __builtin_amdgcn_exp2f(power));
+                    a = __builtin_fminf(0.99f, r1.y * __builtin_amdgcn_exp2f(power));
                 } else {
                     power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
                     a = sel_min(0.99f, r1.y * gsr_expf(power));

@@ -2,7 +2,7 @@
 # Collects the rocprofv3 evidence for profiles/ on a GPU box:  bash tools/collect_profiles.sh <tag>   (e.g. r02_a)
 # kernel stats and the two PMC counters are separate runs (PMC is never combined with other trace domains).
 set -u
-TAG=${1:-r02_x}
+TAG=${1:-r03_x}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
