@@ -82,7 +82,7 @@ SSIM_STEP = False   # --workload train: the loss and statistics lines of train.p
 
 _ZERO = {}
 # rocprofv3 kernel name -> the timing slot (include/gsr.h GSR_K_*) its launches are accounted under
-PMC_ALIAS = {"k_rcount": "k_count", "k_rscatter": "k_scatter", "k_tile_rank": "k_tile_sort", "k_rdscatter": "k_depth_sort", "k_rdsort": "k_depth_sort",
+PMC_ALIAS = {"k_render_bwd_rp": "k_render_bwd", "k_rcount": "k_count", "k_rscatter": "k_scatter", "k_tile_rank": "k_tile_sort", "k_rdscatter": "k_depth_sort", "k_rdsort": "k_depth_sort",
              "k_band_count": "k_depth_sort", "k_band_scan": "k_depth_sort", "k_band_rank": "k_depth_sort",
              "k_dbucket": "k_depth_sort", "k_dscan": "k_depth_sort", "k_dscatter": "k_depth_sort", "k_dsort": "k_depth_sort", "k_qscan_glob": "k_qscan"}
 
@@ -120,34 +120,79 @@ def zero_grads(g):
                 v.grad = None
 
 
-def cpu_baseline(g, cam, bg, train, max_seconds=12.0):
+def cpu_baseline(g, cam, bg, train, args, max_seconds=12.0):
     """The CPU oracle (oracle/, a port -- the reference has no CPU rasterizer) timed on this box's host cores on
     the same frame (rasterizer half only: world-space splats in, image and gradients out), once on every core (OpenMP over
     splats / pixel rows / tiles; the tile bucketing of the sort and the per-splat fold of the backward are shared by the cores as well)
-    and once on ONE thread.  The first all-core frame is a warm-up (page faults of the 100+ MB intermediates) and is not timed."""
+    and once on ONE thread.  The first all-core frame is a warm-up (page faults of the 100+ MB intermediates) and is not timed.
+
+    Runs in a CHILD process: this process spent its life pinned to one core complex next to its GPU, and the OpenMP pools torch and
+    the oracle share were created under that mask -- 256 threads on 8 cores measured 0.49 frames/s against 0.46 on one thread, and the
+    torch leg 28 s per frame.  The child starts with every core and fresh pools; it gets the frame's world-space splats as a file."""
     import math
+    import subprocess
+    import tempfile
 
-    from oracle import gsr_oracle as O
-
-    O.build()
     with torch.no_grad():
         if g.binding is not None:
             g.select_mesh_by_timestep(0)
-        arrs = dict(means3D=g.get_xyz, shs=g.get_features, opacities=g.get_opacity, scales=g.get_scaling,
-                    rotations=g.get_rotation)
+        arrs = dict(means3D=g.get_xyz, shs=g.get_features, opacities=g.get_opacity, scales=g.get_scaling, rotations=g.get_rotation)
         arrs = {k: v.detach().float().cpu().numpy() for k, v in arrs.items()}
-    s = O.make_settings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
-                        bg.cpu().numpy(), 1.0, cam.world_view_transform.cpu().numpy(), cam.full_proj_transform.cpu().numpy(),
-                        g.active_sh_degree, cam.camera_center.cpu().numpy())
-    H, W = cam.image_height, cam.image_width
-    gpix = np.full((3, H, W), -1.0 / (3 * H * W), np.float32)  # d l1(image, white)/d image where image < 1
-    cores = len(os.sched_getaffinity(0))
+    arrs.update(bg=bg.cpu().numpy(), viewmatrix=cam.world_view_transform.cpu().numpy(), projmatrix=cam.full_proj_transform.cpu().numpy(),
+                campos=cam.camera_center.cpu().numpy(),
+                scalars=np.array([cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), g.active_sh_degree,
+                                  float(train), max_seconds, float(g.binding is not None), g.max_sh_degree,
+                                  int(g.flame_param["expr"].shape[0]) if g.binding is not None else 0], np.float64))
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "frame.npz")
+        np.savez(path, **arrs)
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("OMP_", "GOMP_", "KMP_", "MKL_")) and k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env["HIP_VISIBLE_DEVICES"] = ""     # the child is a host-only process
+        env["OMP_WAIT_POLICY"] = "passive"   # idle team members sleep instead of spinning the container's CPU quota away
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", path], capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError("cpu_baseline child failed: " + (r.stderr or r.stdout)[-2000:])
+    out = json.loads(lines[-1])
+    return out["cpu"], out["num_rendered"], out["visible"]
+
+
+def host_cores():
+    """Cores this process may really use: the affinity mask capped by the container's CPU quota (cgroup v2 cpu.max / v1 cfs_quota).  The MI355X
+    boxes report 256 CPUs in the mask of a container that is throttled to a fraction of them: 256 OpenMP threads there were slower than one."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline_child(path):
+    """(child process of cpu_baseline) times the oracle, and the composed-torch binding half, on every core this host has."""
+    from oracle import gsr_oracle as O
+
+    O.build()
+    a = dict(np.load(path))
+    H, W, tfx, tfy, deg, train, max_seconds, bound, max_deg, n_frames = a["scalars"].tolist()
+    train = bool(train)
+    s = O.make_settings(int(H), int(W), tfx, tfy, a["bg"], 1.0, a["viewmatrix"], a["projmatrix"], int(deg), a["campos"])
+    gpix = np.full((3, int(H), int(W)), -1.0 / (3 * H * W), np.float32)  # d l1(image, white)/d image where image < 1
+    cores = host_cores()
 
     def timed(threads, max_frames, budget):
         used = O.set_threads(threads)
         frames, t0 = 0, time.perf_counter()
         while True:
-            st = O.forward(s, arrs["means3D"], arrs["shs"], None, arrs["opacities"], arrs["scales"], arrs["rotations"], None)
+            st = O.forward(s, a["means3D"], a["shs"], None, a["opacities"], a["scales"], a["rotations"], None)
             if train:
                 O.backward(s, st, gpix)
             frames += 1
@@ -157,25 +202,34 @@ def cpu_baseline(g, cam, bg, train, max_seconds=12.0):
 
     timed(cores, 1, max_seconds)   # warm-up
     fps_all, n_all, used_all, st = timed(cores, 16, max_seconds)
+    tried = {used_all: fps_all}
+    for th in (32, 16, 8):          # a mask (or quota) larger than what the host really gives this container: a smaller team can be faster
+        if th < cores and (th >= cores // 8 or fps_all < 4 * tried.get(1, 0) or len(tried) < 2):
+            f, n, u, _ = timed(th, 4, max_seconds / 3)
+            tried[u] = f
+            if f > fps_all:
+                fps_all, n_all, used_all = f, n, u
     fps_one, n_one, _, _ = timed(1, 2, max_seconds)
+    tried[1] = fps_one
     O.set_threads(cores)
     what = "fwd+bwd" if train else "fwd"
-    out = dict(value=fps_all, unit="frames/s", cores=used_all, kind="port",
-               sample=f"{n_all} frame(s) of the bench workload, rasterizer half ({what}), oracle/gsr_oracle.c with OpenMP on {used_all} threads",
+    out = dict(value=fps_all, unit="frames/s", cores=used_all, kind="port", host_cores=cores, affinity_cpus=len(os.sched_getaffinity(0)),
+               tried_frames_per_s={str(k): round(v, 3) for k, v in sorted(tried.items())},
+               sample=f"{n_all} frame(s) of the bench workload, rasterizer half ({what}), oracle/gsr_oracle.c with OpenMP on {used_all} threads "
+                      "(child process: every host core, fresh thread pools)",
                single_thread=dict(value=fps_one, unit="frames/s", cores=1, sample=f"{n_one} frame(s), same workload, one thread"))
-    if g.binding is not None:
-        out["binding_half"] = cpu_binding_baseline(g, train)
-    return out, st.num_rendered, int((st.radii > 0).sum())
+    if bound:
+        out["binding_half"] = cpu_binding_baseline(int(a["means3D"].shape[0]), int(max_deg), int(n_frames), train)
+    print(json.dumps(dict(cpu=out, num_rendered=int(st.num_rendered), visible=int((st.radii > 0).sum()))))
 
 
-def cpu_binding_baseline(g, train, frames=5):
+def cpu_binding_baseline(n_splats, max_sh_degree, n_frames, train, frames=5):
     """The binding half on the host: the composed-torch formulation of the reference (select_mesh_by_timestep + the three
     bound accessors, gaussianavatars_amd/unfused.py) on torch-CPU.  These are ~200 small ATen ops per frame over
     (N,3) / (F,3,3) tensors: past one core complex more threads only add synchronisation (128 threads measured 60x slower than 8 on a
     256-core host), so the leg is timed at 8, 16 and all cores and the BEST is reported with its thread count."""
     cpu = torch.device("cpu")
-    n_frames = int(g.flame_param["expr"].shape[0])
-    gc, _ = build_scene(cpu, int(g._xyz.shape[0]), g.max_sh_degree, 64, 64, n_frames, "unfused", train)
+    gc, _ = build_scene(cpu, n_splats, max_sh_degree, 64, 64, n_frames, "unfused", train)
 
     def frame(t):
         gc.select_mesh_by_timestep(t)
@@ -184,7 +238,7 @@ def cpu_binding_baseline(g, train, frames=5):
             (x.sum() + s.sum() + r.sum()).backward()
             zero_grads(gc)
 
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     before, tried = torch.get_num_threads(), {}
     try:
         for th in sorted({min(8, cores), min(16, cores), cores}):
@@ -312,6 +366,8 @@ class _DryRasterize(torch.autograd.Function):
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-baseline-child":
+        return cpu_baseline_child(sys.argv[2])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -630,7 +686,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only
             os.sched_setaffinity(0, all_cpus)   # the CPU legs get every host core back (the frame loop was pinned to 8)
-            cpu, I_cpu, vis_cpu = cpu_baseline(g, cam, bg, train)
+            cpu, I_cpu, vis_cpu = cpu_baseline(g, cam, bg, train, args)
             vis = vis_cpu / N
         fps = n_gpus * args.steps / elapsed
         counts = [len(frames_for_rank(args.frames, r, world)) for r in range(world)]
