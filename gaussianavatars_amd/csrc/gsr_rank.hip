@@ -469,6 +469,12 @@ __global__ __launch_bounds__(256) void k_band_rank(const BinHeader* __restrict__
 // k_rcount, which reserved a contiguous sub-range per (workgroup, touched tile): slots come from LDS cursors started there.  Order inside a tile segment is arbitrary; the bitmap in k_tile_rank does
 // not care.  The mask says which of the tile's four 8x8 quadrants the splat's {alpha >= 1/255} ellipse can reach: evaluated
 // here from the splat's Span (k_preprocess), so that the per-tile kernel never gathers a per-splat record.
+// Where the time goes (round 3, same-box experiment builds): without its store the kernel runs 186 us of 394 at 2 M splats -- there the 17 M
+// scattered 8-byte stores (one 32-byte sector each: 468 MB written for 136 MB) cost as much as everything else -- but at 100 k / 200 k
+// splats the store is hidden and the per-instance instruction stream bounds it (quadrant_mask_of without branches: 30.5 -> 26 us).  A
+// variant that built the workgroup's entries in LDS grouped by tile and wrote them as runs (count pass, scan, placement, entry-parallel
+// copy) was SLOWER at those sizes (26 -> 34 us, 45 -> 58 us: the runs of one (workgroup, tile) pair are only ~4 entries long) and is not
+// kept; for the band mode of large frames the runs would have to come from splats grouped by band first.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx, int tiles, BandTables bt, const ushort4* __restrict__ srect,
                                                                     const uint32_t* __restrict__ rank, const float4* __restrict__ sspan,
@@ -540,7 +546,11 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
             const uint32_t m = quadrant_mask_of(b, (float)(x * GSR_BLOCK_X), (float)(y * GSR_BLOCK_Y));
             // tile grids beyond the LDS histogram: one returning L2 atomic per instance
             const uint32_t slot = direct ? tile_start[tile] + atomicAdd(&tile_cursor[tile], 1u) : atomicAdd(&hist[tile], 1u);
+#ifdef GSR_EXP_RSCATTER_NOSTORE   // timing experiment: everything but the store (the condition keeps the rank, the mask and the slot live; no frame meets it)
+            if (brk == 0xFFFFFFF0u && m == 15u && bidx == 0x0FFFFFFFu) ranks[slot] = make_uint2(brk, bidx);
+#else
             ranks[slot] = make_uint2(brk, bidx | (m << GSR_RANK_IDX_BITS));
+#endif
         });
     }
 }
