@@ -829,8 +829,14 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     // tools/bwd_timeline.py), so the loop is written for INSTRUCTION COUNT, scalar ones included: no per-record bounds
     // tests (full batches take an unmasked body), 32-bit record offsets, no exec-mask branches around the exponential.
     constexpr int RB = 3;
-    constexpr int TAIL_LANES = 4;     // switch to record-parallel mode when this few pixels are still open (swept 0..16 on the
-                                      // instruction-count build: 2-4 best, 8 costs 10 %, 16 costs 50 % of the kernel)
+#ifndef GSR_FAST_TAIL_LANES
+#define GSR_FAST_TAIL_LANES 12
+#endif
+    // switch to record-parallel mode when this few pixels are still open.  Exact walk: the tail's T/C update is serial over the hits (swept
+    // 0..16 on the instruction-count build: 2-4 best, 8 costs 10 %, 16 costs 50 % of the kernel).  Fast blend: the tail evaluates a pixel's
+    // 60 records with one wave scan (no serial loop), ~75 instructions per (pixel, chunk) against 60 x 42 for the walk, so it takes over
+    // much earlier (model on the cfg3 frame, tools/remap_model.py: 31.7 M -> 26.3 M instructions at 8..16 open pixels).
+    constexpr int TAIL_LANES = FAST ? GSR_FAST_TAIL_LANES : 4;
     struct Rec4 { f32x8 a[RB]; float cbl[RB]; };   // a = (x, y, conic a, conic b, conic c, opacity, red, green)
     struct Pos4 { uint32_t p[RB]; };
     // Two-level scalar fetch: stream entries (4-byte splat indices) two batches ahead, the records they name one batch ahead,
@@ -968,7 +974,101 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     // 64 lanes evaluate 64 *records* in parallel, and only the records that actually touch the pixel
     // (ballot) go through the sequential T/C update, in stream order -- the arithmetic per contributing
     // record and its order are unchanged, so results stay bit-identical.
-    if (j0 < n) {
+    if (FAST && j0 < n) {
+        // ---- fast blend: chunks of the stream up to the next checkpoint boundary, lanes = records, one open pixel at a time.
+        // T_j = T_p * prod_{i<=j} (1 - alpha_i) is one inclusive wave scan (transmittance only falls: "T >= 1e-4" is a prefix mask, the
+        // pixel closes at its first failing lane), the colour is three wave sums of c * alpha * T_before; no loop over the hits.
+        unsigned long long open_mask = __ballot(Tw > 0.0f);
+        int c0 = j0;
+        while (c0 < n && open_mask) {
+            const int c1 = min(n, (c0 / GSR_BWD_SEGMENT + 1) * GSR_BWD_SEGMENT);   // the chunk ends where the next checkpoint sits (<= 60 entries)
+            const int j = c0 + lane;
+            const bool valid = j < c1;
+            const size_t jc = (size_t)qp[valid ? j : c1 - 1];
+            const float4 r0 = rec[3 * jc + 0];
+            const float4 r1 = rec[3 * jc + 1];
+            const float4 r2 = rec[3 * jc + 2];
+            unsigned long long todo = open_mask;
+            while (todo) {
+                // two open pixels per pass (the second one a repeat of the first when only one is left): their scans and sums interleave,
+                // which covers the two wait states a DPP operand needs behind its producer
+                const int pa = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const bool two = todo != 0ull;
+                const int pb = two ? __builtin_ctzll(todo) : pa;
+                todo &= todo - 1;
+                const int pp[2] = {pa, pb};
+                float Tp[2], am[2], prod[2], okf[2];
+                bool ok[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float ppx = (float)(tile_x * GSR_BLOCK_X + (wave & 1) * 8 + (pp[e] & 7));
+                    const float ppy = (float)(tile_y * GSR_BLOCK_Y + (wave >> 1) * 8 + (pp[e] >> 3));
+                    Tp[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tw), pp[e]));   // open: Tw == T
+                    const float dx = r0.x - ppx, dy = r0.y - ppy;
+                    const float power = __builtin_fmaf(__builtin_fmaf(r0.w, dy, r0.z * dx), dx, (r1.x * dy) * dy);
+                    const float a = __builtin_fminf(0.99f, r1.y * __builtin_amdgcn_exp2f(power));
+                    ok[e] = valid && power <= 0.0f && a >= 1.0f / 255.0f;
+                    am[e] = ok[e] ? a : 0.0f;
+                    prod[e] = 1.0f - am[e];
+                    okf[e] = am[e] * __builtin_amdgcn_rcpf(prod[e]);   // alpha / (1 - alpha)
+                }
+                // inclusive prefix products over the lanes (v_mul_f32_dpp in place: lanes without a source keep theirs)
+#define GSR_TAIL_STEP(CTRL) "v_mul_f32_dpp %0, %0, %0 " CTRL "\n\tv_mul_f32_dpp %1, %1, %1 " CTRL "\n\ts_nop 0\n\t"
+                asm volatile("s_nop 1\n\t" GSR_TAIL_STEP("row_shr:1 row_mask:0xf bank_mask:0xf") GSR_TAIL_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+                             GSR_TAIL_STEP("row_shr:4 row_mask:0xf bank_mask:0xf") GSR_TAIL_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+                             GSR_TAIL_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") GSR_TAIL_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                             : "+v"(prod[0]), "+v"(prod[1]));
+#undef GSR_TAIL_STEP
+                float Tfull[2], s3[2][3];
+                bool keepl[2];
+                unsigned long long K[2], hits[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    Tfull[e] = Tp[e] * prod[e];                         // transmittance AFTER the lane's record
+                    keepl[e] = Tfull[e] >= 0.0001f;                      // false from the record that would saturate the pixel onwards
+                    K[e] = __ballot(keepl[e]);
+                    hits[e] = __ballot(ok[e] && keepl[e]);
+                    const float wgt = keepl[e] ? Tfull[e] * okf[e] : 0.0f;   // alpha * T_before = T_after * alpha / (1 - alpha)
+                    s3[e][0] = r1.z * wgt; s3[e][1] = r1.w * wgt; s3[e][2] = r2.x * wgt;
+                }
+                // the six colour sums: halves first (v_permlane32_swap: lanes 0-31 keep pixel a's, lanes 32-63 pixel b's), then 32-lane sums
+                float h3[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s3[0][c]), __float_as_uint(s3[1][c]), false, false);
+                    float v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                    v += dpp_f<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+                    v += dpp_f<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+                    v += dpp_f<0x141, 0xf>(v);  // row_half_mirror
+                    v += dpp_f<0x140, 0xf>(v);  // row_mirror
+                    v += dpp_f<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3: lane 31 holds pixel a's sum, lane 63 pixel b's
+                    h3[c] = v;
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (e == 1 && !two) break;
+                    const int src = e ? 63 : 31;
+                    const float A0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h3[0]), src));
+                    const float A1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h3[1]), src));
+                    const float A2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h3[2]), src));
+                    const bool closed = K[e] != ~0ull;
+                    const int f = closed ? __builtin_ctzll(~K[e]) : 64;   // first lane whose record does not fit any more
+                    const float Tlast = f == 0 ? Tp[e] : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tfull[e]), f - 1));
+                    if (lane == pp[e]) {
+                        T = Tlast;
+                        Tw = closed ? 0.0f : Tlast;
+                        C0 += A0; C1 += A1; C2 += A2;
+                        if (hits[e]) last_q = (uint32_t)(c0 + 64 - __builtin_clzll(hits[e]));
+                    }
+                    if (closed) open_mask &= ~(1ull << pp[e]);
+                }
+            }
+            c0 = c1;
+            if (c0 < n) checkpoint(c0);   // (every lane stores its own pixel's state; closed pixels rewrite slots nobody reads)
+        }
+    }
+    if (!FAST && j0 < n) {
         unsigned long long open_mask = __ballot(Tw > 0.0f);
         while (open_mask) {
             const int p = __builtin_ctzll(open_mask);
