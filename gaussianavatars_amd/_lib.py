@@ -100,7 +100,7 @@ class GsrBound(C.Structure):
 
 
 class GsrImageLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("final_T", "n_contrib", "n_contrib_q", "c_final", "ck", "gmax", "total")]
+    _fields_ = [(n, C.c_size_t) for n in ("final_T", "n_contrib", "n_contrib_q", "c_final", "ck", "gmax", "seg_need", "total")]
 
 
 #: every symbol include/gsr.h declares -> (restype, argtypes)

@@ -314,6 +314,8 @@ int gsr_image_layout(int32_t width, int32_t height, GsrImageLayout* o)
     o->c_final = off;   off = align_up(off + hw * 12, A);
     o->ck = off;        off = align_up(off + hw * 16 * (GSR_BWD_SEGMENTS - 1), A);
     o->gmax = off;      off = align_up(off + 4, A);
+    const size_t tiles = (size_t)((width + GSR_BLOCK_X - 1) / GSR_BLOCK_X) * (size_t)((height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y);
+    o->seg_need = off;  off = align_up(off + tiles * 4, A);
     o->total = off + A;
     return 0;
 }
@@ -395,6 +397,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     } else if (P == 0) {   // otherwise k_preprocess zeroes both
         HIP_TRY(hipMemsetAsync(tile_count, 0, (size_t)tiles * 4, stream));
         HIP_TRY(hipMemsetAsync(rect_total, 0, 8, stream));
+        HIP_TRY(hipMemsetAsync(im + il.seg_need, 0, (size_t)tiles * 4, stream));
     }
 
     gsr::PreprocessArgs pa;
@@ -412,6 +415,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     pa.acc = (float4*)(g + gl.acc);
     pa.acc64 = (float4*)(g + gl.acc64);
     pa.tile_count = tile_count;
+    pa.seg_need = (uint32_t*)(im + il.seg_need);
     pa.rect_total = rect_total;
     pa.tiles = tiles;
     pa.brec = prod ? (float4*)(g + gl.brec) : nullptr;
@@ -650,7 +654,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         hipLaunchKernelGGL(ds.fast_blend ? gsr::k_render<true> : gsr::k_render<false>, dim3(tiles), dim3(256), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
                            (const uint32_t*)qcount, (const float4*)pa.grec, (const uint32_t*)qpos, write_lists ? (const uint32_t*)qlist : nullptr, (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib),
                            (uint32_t*)(im + il.n_contrib_q), (float*)(im + il.c_final), (float4*)(im + il.ck), out_color, cap,
-                           (const unsigned long long*)total_dev);
+                           (const unsigned long long*)total_dev, (uint32_t*)(im + il.seg_need));
         KERNEL_CHECK("k_render", stream, dbg);
     }
 
@@ -771,7 +775,7 @@ static int backward_impl(const GsrSettings* settings, int32_t P, int32_t M, cons
                                (const uint32_t*)(b + bl.qstart), (const uint32_t*)(b + bl.qcount), (const float4*)(g + gl.grec), (const uint32_t*)(b + bl.qpos),
                                (const float*)(im + il.final_T), (const uint32_t*)(im + il.n_contrib_q), dL_dpix, grad_scratch,
                                (const float*)(im + il.c_final), (const float4*)(im + il.ck), gx * gy,
-                               (unsigned long long)binning_capacity, (const unsigned long long*)b);
+                               (unsigned long long)binning_capacity, (const unsigned long long*)b, (const uint32_t*)(im + il.seg_need));
         } else {
         auto* const render_bwd = det ? &gsr::k_render_bwd<true, false> : (ds.fast_blend ? &gsr::k_render_bwd<false, true> : &gsr::k_render_bwd<false, false>);
         hipLaunchKernelGGL(render_bwd, dim3(gx * gy * GSR_BWD_SEGMENTS), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order),

@@ -385,9 +385,13 @@ __global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_
                                                         const uint32_t* __restrict__ n_contrib_q, const float* __restrict__ dL_dpix,
                                                         float* __restrict__ acc /* [P][GSR_ACC_STRIDE] */, const float* __restrict__ c_final,
                                                         const float4* __restrict__ ck, int tiles, unsigned long long capacity,
-                                                        const unsigned long long* __restrict__ total_dev)
+                                                        const unsigned long long* __restrict__ total_dev, const uint32_t* __restrict__ seg_need)
 {
     if (*total_dev > capacity) return;
+    {   // four of five workgroups of the grid own a segment no quadrant of their tile reaches: the forward left the tile's need behind
+        const int seg_ = (int)blockIdx.x / tiles;
+        if (seg_ >= (int)seg_need[(int)blockIdx.x - seg_ * tiles]) return;
+    }
     __shared__ __attribute__((aligned(16))) float tab_all[4][32 * 12];   // per wave: the pixel table (below)
     __shared__ float xpose_all[4][64 * 9];                                // per wave: the nine sums of every lane on their way out
     constexpr int CH = GSR_BWD_SEGMENT;          // records per chunk = lanes in use (60 of 64)

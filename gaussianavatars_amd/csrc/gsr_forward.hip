@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         for (int t = i; t < a.nb; t += (int)(gridDim.x * blockDim.x)) a.bcount[t] = 0u;
     } else {
         // this frame's tile histogram starts at zero (k_count runs after this kernel)
-        for (int t = i; t < a.tiles; t += (int)(gridDim.x * blockDim.x)) a.tile_count[t] = 0u;
+        for (int t = i; t < a.tiles; t += (int)(gridDim.x * blockDim.x)) { a.tile_count[t] = 0u; a.seg_need[t] = 0u; }
         if (i == 0) *a.rect_total = 0ull;
         if (a.pstat)   // rank path: the depth-bucket histogram and its fill cursors start at zero as well
             for (int t = i; t < a.nb; t += (int)(gridDim.x * blockDim.x)) { a.bcount[t] = 0u; a.bcursor[t] = 0u; }
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
                                                  uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ n_contrib_q,
                                                  float* __restrict__ c_final, float4* __restrict__ ck,
                                                  float* __restrict__ out_color, unsigned long long capacity,
-                                                 const unsigned long long* __restrict__ total_dev)
+                                                 const unsigned long long* __restrict__ total_dev, uint32_t* __restrict__ seg_need)
 {
     if (*total_dev > capacity) return;
 #ifdef GSR_EXPERIMENT_TIMELINE
@@ -1139,6 +1139,10 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         d[3] = t_main;
     }
 #endif
+    if (FAST && !s.forward_only) {   // how many backward segments this tile needs (by launch position: what k_render_bwd_rp's workgroups index)
+        const uint32_t qmax = wave_max_u32(inside ? last_q : 0u);
+        if (lane == 0 && qmax) atomicMax(seg_need + blockIdx.x, min((qmax + GSR_BWD_SEGMENT - 1u) / GSR_BWD_SEGMENT, (uint32_t)GSR_BWD_SEGMENTS));
+    }
     if (inside) {
         const int pix_id = W * pyi + pxi;
         // the reference's n_contrib counts positions in the TILE list: the parity modes keep those in a twin stream; in
@@ -1158,9 +1162,9 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
 }
 
 template __global__ void k_render<false>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
-                                         uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*);
+                                         uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*);
 template __global__ void k_render<true>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
-                                        uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*);
+                                        uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*);
 
 // ------------------------------------------------------------------------------------------
 // k_mark_visible (upstream checkFrustum): present = view z > 0.2

@@ -206,6 +206,9 @@ typedef struct GsrImageLayout {
                           s*GSR_BWD_SEGMENT of its quadrant stream.  The backward walks each segment of a pixel's stream on
                           its own wave, starting from the checkpoint (the serial walk was the kernel's critical path). */
     size_t gmax;       /* uint32 [1]  deterministic backward: bits of max |dL/dpixel| of the current backward               */
+    size_t seg_need;   /* uint32 [tiles] fast blend: backward segments the tile needs (the deepest last contributor of its four quadrants
+                          / GSR_BWD_SEGMENT, rounded up), by the tile's position in the launch order: a backward workgroup beyond it exits
+                          on one load instead of finding out quadrant by quadrant                                                */
     size_t total;
 } GsrImageLayout;
 
