@@ -197,6 +197,17 @@ class deferred_count:
         return False
 
 
+def _debug_dump(path: str, args) -> None:
+    """Upstream's `debug=True` behaviour (diff_gaussian_rasterization/__init__.py: on an exception of the native call the arguments are
+    written with torch.save to snapshot_fw.dump / snapshot_bw.dump in the working directory, a note is printed, the error is re-raised)."""
+    try:
+        cpu_args = tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+        torch.save(cpu_args, path)
+        print(f"\nAn error occured in {'forward' if 'fw' in path else 'backward'}. Please forward {path} for debugging.")
+    except Exception as e:   # noqa: BLE001 -- the dump must never replace the error it documents
+        print(f"\n(debug snapshot {path} could not be written: {e})")
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None or t.numel() == 0 else t.data_ptr()   # a plain int converts to the c_void_p argument
 
@@ -321,6 +332,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                     msg = _lib.gsr_error()
                     if "provide" in msg:  # the two argument-contract errors are plain Exceptions upstream
                         raise Exception(msg)
+                    if raster_settings.debug:   # upstream's debug mode: the failing call's arguments go to a file before the error is raised
+                        _debug_dump("snapshot_fw.dump", (raster_settings.bg, means3D, colors_precomp, opacities, scales, rotations, raster_settings.scale_modifier,
+                                                         cov3Ds_precomp, raster_settings.viewmatrix, raster_settings.projmatrix, raster_settings.tanfovx,
+                                                         raster_settings.tanfovy, raster_settings.image_height, raster_settings.image_width, sh,
+                                                         raster_settings.sh_degree, raster_settings.campos, raster_settings.prefiltered))
                     raise RuntimeError(f"gsr_forward failed ({rc}): {msg}")
                 break
         I = int(n_host.value)
@@ -383,7 +399,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                                   _ptr(g_means3D), _ptr(g_means2D), _ptr(g_sh), _ptr(g_sh_rest), _ptr(g_colors), _ptr(g_opacity),
                                   _ptr(g_scales), _ptr(g_rot), _ptr(g_cov3D), stream)
         if rc != _lib.GSR_OK:
-            raise RuntimeError(f"gsr_backward failed ({rc}): {_lib.gsr_error()}")
+            msg = _lib.gsr_error()
+            if rs.debug:
+                _debug_dump("snapshot_bw.dump", (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+                                                 rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos, ctx.num_rendered))
+            raise RuntimeError(f"gsr_backward failed ({rc}): {msg}")
         return (g_means3D, g_means2D, g_sh, g_colors if not use_sh else None, g_opacity, g_scales, g_rot,
                 g_cov3D if not use_sr else None, None, g_sh_rest)
 

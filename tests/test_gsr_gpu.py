@@ -519,3 +519,24 @@ def test_rank_bands_with_more_splats_than_one_bitmap_holds(W, H, nbands):
     for k in ("radii", "n_contrib", "n_contrib_q"):
         np.testing.assert_array_equal(_np(new[k]), _np(old[k]), err_msg=k)
     _same_streams(new, old, packed=False)
+
+
+def test_debug_mode_dumps_the_failing_calls_arguments(tmp_path, monkeypatch):
+    """Upstream's `debug=True`: a native call that fails writes its arguments to snapshot_fw.dump in the working directory before the error
+    is raised (gaussian_renderer/__init__.py:50 passes pipe.debug)."""
+    from gaussianavatars_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+    dev = _dev()
+    monkeypatch.chdir(tmp_path)
+    cam, sp, bg, deg, mod = scene("cfg1")
+    a = settings_args(cam, bg, deg, mod)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    for debug in (False, True):
+        rs = GaussianRasterizationSettings(a["H"], a["W"], a["tanfovx"], a["tanfovy"], t(a["bg"]), mod, t(a["viewmatrix"]), t(a["projmatrix"]),
+                                           3, t(a["campos"]), False, debug)     # degree 3 asked of one coefficient per splat: the library refuses
+        with pytest.raises(RuntimeError, match="sh_degree 3 needs 16"):
+            GaussianRasterizer(rs)(means3D=t(sp["means3D"]), means2D=torch.zeros(len(sp["means3D"]), 3, device=dev), shs=t(sp["shs"]),
+                                   opacities=t(sp["opacities"]), scales=t(sp["scales"]), rotations=t(sp["rotations"]))
+        assert (tmp_path / "snapshot_fw.dump").exists() == debug
+    saved = torch.load(tmp_path / "snapshot_fw.dump")
+    assert len(saved) == 18 and torch.equal(saved[1], torch.from_numpy(sp["means3D"])) and saved[15] == 3
