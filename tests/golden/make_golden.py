@@ -237,6 +237,20 @@ def model_pins():
     m64, t64 = build(torch.float64)   # the same reference code in double: the value the fp32 gradients of the FLAME rows are noisy around
     out = {}
     fs, ss = c["face_stride"], c["splat_stride"]
+    # Faces that are slivers at one of the tested timesteps (height or first edge under a tenth of the median height, measured in fp64): the
+    # gradient through such a face's frame is amplified by 1 / height (> 1e4 here) and ANY fp32 evaluation of it is a lottery.  The smooth-weight
+    # check leaves the splats bound to them out (weight 0); the white-noise check above keeps them.
+    ok = np.ones(len(rig["faces"]), bool)
+    for ts in c["steps"]:
+        m64.select_mesh_by_timestep(ts)
+        v = m64.verts.detach().numpy()[0]
+        fa = np.asarray(rig["faces"])
+        e1, e2 = v[fa[:, 1]] - v[fa[:, 0]], v[fa[:, 2]] - v[fa[:, 0]]
+        l1 = np.linalg.norm(e1, axis=1)
+        h = np.linalg.norm(np.cross(e1, e2), axis=1) / l1
+        ok &= np.minimum(l1, h) > 0.1 * np.median(h)
+    out["smooth_face_ok"] = ok
+    print(f"model pins: {int((~ok).sum())} sliver faces of {ok.size} carry no smooth weight ({int((~ok)[np.asarray(sp['binding'])].sum())} splats)")
     for ts in c["steps"]:
         for p in (m._xyz, m._scaling, m._rotation, m._opacity, *m.flame_param.values()):
             p.grad = None
@@ -271,6 +285,28 @@ def model_pins():
             g64 = m64.flame_param[k].grad.numpy()[ts]
             out[pre + "gf64_" + k] = g64
             out[pre + "gf_dev_" + k] = np.float64(np.abs(out[pre + "gf_" + k] - g64).max() / np.abs(g64).max())
+        # the same once more with the SMOOTH weights (tests/model_pin_inputs.py): a well-conditioned loss, for which the tests hold the
+        # fused kernels to a tight bar
+        w2 = {k: v * ok[np.asarray(sp["binding"])][:, None].astype(v.dtype) for k, v in w["smooth"].items()}
+        grads = {}
+        for mm, tt, tag in ((m, t, "gfs_"), (m64, t64, "gfs64_")):
+            for p in (mm._xyz, mm._scaling, mm._rotation, mm._opacity, *mm.flame_param.values()):   # (the leaf pins above are VIEWS of the old .grad)
+                p.grad = None
+            mm.select_mesh_by_timestep(ts)
+            mm.verts.retain_grad()
+            ls = ((mm.get_xyz * tt(w2["xyz"])).sum() + (mm.get_scaling * tt(w2["scaling"])).sum() + (mm.get_rotation * tt(w2["rotation"])).sum() +
+                  (mm.get_opacity * tt(w2["opacity"])).sum())
+            ls.backward()
+            for k in ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation"):
+                grads[tag + k] = mm.flame_param[k].grad.numpy()[ts].copy()
+            grads[tag + "verts"] = mm.verts.grad.numpy()[0].copy()          # dL/d(posed vertices): where the two halves of the backward meet
+            if tag == "gfs64_":
+                out[pre + "verts64"] = mm.verts.detach().numpy()[0].copy()
+        out[pre + "gfs64_verts"] = grads["gfs64_verts"]
+        out[pre + "gfs_dev_verts"] = np.float64(np.abs(grads["gfs_verts"] - grads["gfs64_verts"]).max() / np.abs(grads["gfs64_verts"]).max())
+        for k in ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation"):
+            out[pre + "gfs64_" + k] = grads["gfs64_" + k]
+            out[pre + "gfs_dev_" + k] = np.float64(np.abs(grads["gfs_" + k] - grads["gfs64_" + k]).max() / np.abs(grads["gfs64_" + k]).max())
     # python cov3D path (pipe.compute_cov3D_python): get_covariance uses the LOCAL rotation (scene/gaussian_model.py:162-163)
     with cpu_zeros():
         out["cov3D_mod"] = m.get_covariance(c["cov_mod"]).detach().numpy()[::ss]
