@@ -216,6 +216,8 @@ GAB_SYMBOLS = {
     "gab_flame_forward_prepared": (C.c_int, [C.POINTER(GabRig), _P] + [_P] * 6 + [_P, _P, _P, _P]),
     "gab_flame_backward_prepared": (C.c_int, [C.POINTER(GabRig), _P] + [_P] * 4 + [_P, _P, _P] + [_P] * 6 + [_P] +
                                     [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _P]),
+    "gab_mesh_backward_prepared": (C.c_int, [C.POINTER(GabRig), _P] + [_P] * 4 + [_P, _P, _P, _P, _P] + [_P] * 5 + [_P] * 6 + [_P] +
+                                   [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _P]),
     "gab_face_frames_forward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "gab_face_frames_backward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "gab_bind_forward": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -240,8 +242,8 @@ def gab():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.gab_abi_version() != 2:
-            raise RuntimeError(f"gab ABI version {lib.gab_abi_version()} != 2")
+        if lib.gab_abi_version() != 3:
+            raise RuntimeError(f"gab ABI version {lib.gab_abi_version()} != 3")
         _gab = lib
     return _gab
 

@@ -341,6 +341,37 @@ class _SubCtx:
         pass
 
 
+_VF_CACHE: list = []
+
+
+def vertex_corner_csr(faces: torch.Tensor, num_verts: int):
+    """(vf_begin int32 (V+1,), vf_list int32 (3F, 4)) for gab_mesh_backward_prepared: one row (4 f + c, i0, i1, i2) per corner c of face
+    f = (i0, i1, i2), listed vertex by vertex (stable, so a vertex's corners come in face order).  Static per topology: cached on the
+    tensor's identity and version."""
+    for ent in _VF_CACHE:
+        if ent[0] is faces and ent[1] == faces._version and ent[2] == num_verts:
+            return ent[3]
+    f = faces.detach().long()
+    flat = f.reshape(-1)
+    order = torch.sort(flat, stable=True).indices          # flat corner index 3 f + c, by vertex
+    fo, co = order // 3, order % 3
+    vf_list = torch.cat([(4 * fo + co)[:, None], f[fo]], 1).to(torch.int32).contiguous()
+    vf_begin = torch.zeros(num_verts + 1, dtype=torch.int32, device=flat.device)
+    vf_begin[1:] = torch.cumsum(torch.bincount(flat, minlength=num_verts), 0).to(torch.int32)
+    if len(_VF_CACHE) >= 4:
+        _VF_CACHE.pop(0)
+    _VF_CACHE.append((faces, faces._version, num_verts, (vf_begin, vf_list)))
+    return vf_begin, vf_list
+
+
+def _mesh_backward_mode() -> str:
+    """"merged" (default): the face-frame backward and the skinning backward are one launch (gab_mesh_backward_prepared: corner gather,
+    no d_verts buffer); "split": the two launches it replaced -- kept for A/B tests and for what the merged entry does not cover."""
+    import os
+
+    return os.environ.get("GAA_MESH_BWD", "merged")
+
+
 class _MeshFramesTimestep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, head, t, faces, shape, expr, rotation, neck, jaw, eyes, translation, static_offset):
@@ -348,13 +379,46 @@ class _MeshFramesTimestep(torch.autograd.Function):
         need = ctx.needs_input_grad
         c1 = _SubCtx((False, False) + tuple(need[3:]))
         verts, v_shaped = _FlameForwardTimestep.forward(c1, head, t, shape, expr, rotation, neck, jaw, eyes, translation, static_offset)
-        c2 = _SubCtx((any(need), False))
+        ctx.merged = c1.prepared is not None and _mesh_backward_mode() == "merged"
+        c2 = _SubCtx((any(need) and not ctx.merged, False))   # merged: no scatter target to pre-zero
         center, R, scale, quat = _FaceFrames.forward(c2, verts[0], faces)
         ctx.c1, ctx.c2 = c1, c2
+        ctx.faces = faces
         return verts, v_shaped, center, R, scale, quat
 
     @staticmethod
+    def _backward_merged(ctx, g_verts, g_center, g_R, g_scale, g_quat):
+        c1, c2 = ctx.c1, ctx.c2
+        lib = _lib.gab()
+        rig = _rig_struct(c1.head)
+        saved = c1.keep.get()
+        tabs = list(saved[1:7])
+        v_shaped, ws = saved[-2], saved[-1]
+        v, fi = c2.keep.get()
+        dev = v.device
+        V, T, t, widths = rig.V, c1.T, c1.t, c1.widths
+        need = c1.needs_input_grad
+        f32 = dict(dtype=torch.float32, device=dev)
+        tables = [torch.empty((T, w), **f32) for w in widths]
+        ptrs = (C.c_void_p * len(tables))(*[x.data_ptr() for x in tables])
+        sizes = (C.c_int32 * len(tables))(*[T * w for w in widths])
+        outp = [x.data_ptr() + 4 * t * w for x, w in zip(tables, widths)]
+        rows = [x.data_ptr() + 4 * t * w for x, w in zip(tabs, widths)]
+        vf_begin, vf_list = vertex_corner_csr(ctx.faces, V)
+        scratch = torch.empty(3 * V, **f32)
+        gs = [None if g is None else _f32(g) for g in (g_center, g_R, g_scale, g_quat)]
+        gv = None if g_verts is None else _f32(g_verts)
+        with _lib.on_device(dev):
+            _chk(lib.gab_mesh_backward_prepared(C.byref(rig), _p(c1.prepared), *rows[1:5], _p(v_shaped), _p(ws), _p(v),
+                                                _p(vf_begin), _p(vf_list), _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(gs[3]), _p(gv), *outp,
+                                                _p(scratch), len(tables), ptrs, sizes, _stream(dev)), "gab_mesh_backward_prepared")
+        grads = [tb if need[3 + i] else None for i, tb in enumerate(tables)]
+        return (None, None, None, None, *grads, None)
+
+    @staticmethod
     def backward(ctx, g_verts, g_vshaped, g_center, g_R, g_scale, g_quat):
+        if ctx.merged and g_vshaped is None:
+            return _MeshFramesTimestep._backward_merged(ctx, g_verts, g_center, g_R, g_scale, g_quat)
         d_verts, _ = _FaceFrames.backward(ctx.c2, g_center, g_R, g_scale, g_quat)
         if g_verts is not None:
             d_verts = d_verts + g_verts.reshape(d_verts.shape)

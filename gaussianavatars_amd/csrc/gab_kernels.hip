@@ -881,15 +881,10 @@ __device__ __forceinline__ Vec3 unit_bwd(Vec3 g_unit, Vec3 unit, float len, bool
     return (g_unit - unit * dot(unit, g_unit)) * (1.f / len);
 }
 
-__global__ __launch_bounds__(256) void k_face_frames_bwd(int F, const float* __restrict__ verts, const void* __restrict__ faces, int is64,
-                                                          const float* __restrict__ d_center, const float* __restrict__ d_R,
-                                                          const float* __restrict__ d_scaling, const float* __restrict__ d_quat,
-                                                          float* __restrict__ d_verts)
+// gradients of one face's frame outputs -> gradients of its three corners (g0, g1, g2), the corners' vertices given
+__device__ __forceinline__ void face_frame_bwd(int f, Vec3 v0, Vec3 v1, Vec3 v2, const float* __restrict__ d_center, const float* __restrict__ d_R,
+                                               const float* __restrict__ d_scaling, const float* __restrict__ d_quat, Vec3& g0, Vec3& g1, Vec3& g2)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
-    const long long i0 = index_at(faces, is64, 3ll * f), i1 = index_at(faces, is64, 3ll * f + 1), i2 = index_at(faces, is64, 3ll * f + 2);
-    const Vec3 v0 = ld3(verts, i0), v1 = ld3(verts, i1), v2 = ld3(verts, i2);
     const Frame fr = make_frame(v0, v1, v2);
     const float R[9] = {fr.a0.x, fr.a1.x, fr.a2.x, fr.a0.y, fr.a1.y, fr.a2.y, fr.a0.z, fr.a1.z, fr.a2.z};
     float gR[9];
@@ -942,10 +937,126 @@ __global__ __launch_bounds__(256) void k_face_frames_bwd(int F, const float* __r
     if (!fr.c1) g_e1 = g_e1 + fr.a0 * g_l1;
     Vec3 gc = {0.f, 0.f, 0.f};
     if (d_center) gc = Vec3{d_center[3 * f], d_center[3 * f + 1], d_center[3 * f + 2]} * (1.f / 3.f);
-    const Vec3 g0 = gc - g_e1 - g_e2, g1 = gc + g_e1, g2 = gc + g_e2;
+    g0 = gc - g_e1 - g_e2; g1 = gc + g_e1; g2 = gc + g_e2;
+}
+
+__global__ __launch_bounds__(256) void k_face_frames_bwd(int F, const float* __restrict__ verts, const void* __restrict__ faces, int is64,
+                                                          const float* __restrict__ d_center, const float* __restrict__ d_R,
+                                                          const float* __restrict__ d_scaling, const float* __restrict__ d_quat,
+                                                          float* __restrict__ d_verts)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const long long i0 = index_at(faces, is64, 3ll * f), i1 = index_at(faces, is64, 3ll * f + 1), i2 = index_at(faces, is64, 3ll * f + 2);
+    Vec3 g0, g1, g2;
+    face_frame_bwd(f, ld3(verts, i0), ld3(verts, i1), ld3(verts, i2), d_center, d_R, d_scaling, d_quat, g0, g1, g2);
     unsafeAtomicAdd(&d_verts[3 * i0], g0.x); unsafeAtomicAdd(&d_verts[3 * i0 + 1], g0.y); unsafeAtomicAdd(&d_verts[3 * i0 + 2], g0.z);
     unsafeAtomicAdd(&d_verts[3 * i1], g1.x); unsafeAtomicAdd(&d_verts[3 * i1 + 1], g1.y); unsafeAtomicAdd(&d_verts[3 * i1 + 2], g1.z);
     unsafeAtomicAdd(&d_verts[3 * i2], g2.x); unsafeAtomicAdd(&d_verts[3 * i2 + 1], g2.y); unsafeAtomicAdd(&d_verts[3 * i2 + 2], g2.z);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gather_skin_bwd: k_face_frames_bwd + k_skin_bwd in one launch, for select_mesh_by_timestep + update_mesh_properties as one
+// autograd node.  The pair of launches it replaces pays two launch floors (4 us each), 91 k float atomics into the vertices and a
+// zero-fill of their target.  Here a workgroup owns GAB_MESH_VPB consecutive vertices and GATHERS instead: the (face, corner) pairs
+// of its vertices come from a vertex -> corner table of the (static) topology, 16 bytes per pair = (4 f + c, i0, i1, i2), so that a
+// pair costs two dependent loads (entry, then vertices and gradients); one thread per pair re-derives the face's frame backward (each
+// face three times over the grid: ~250 flops) and adds its corner's share into LDS -- no global atomics, no d_verts buffer.
+// Then the skinning backward of k_skin_bwd for those vertices, the four waves sharing the 99 block sums.
+// (One launch for the WHOLE mesh backward was built and measured first: the grid-wide hand-over it needs -- fence, ticket, fence, a
+// last workgroup summing 81 rows of partials -- cost 6 + 18 us against the 4 us launch floor it saved; see DESIGN.md.)
+// ---------------------------------------------------------------------------------------------
+#ifndef GAB_MESH_VPB
+#define GAB_MESH_VPB 32
+#endif
+struct GatherSkinArgs {
+    const float* v_shaped; float* ws;
+    const float* verts;
+    const int* vf_begin; const int4* vf_list;                       // vertex -> (4 f + c, i0, i1, i2), rows sorted by vertex
+    const float* d_center; const float* d_R; const float* d_scaling; const float* d_quat;
+    const float* g_verts;                                           // optional external dL/d(posed vertices), added in
+    float* g_vs;                                                    // (V,3) out, for k_chain_blend_bwd
+};
+__global__ __launch_bounds__(256) void k_gather_skin_bwd(Rig rig, GatherSkinArgs a, ZeroSpec zero)
+{
+    constexpr int VPB = GAB_MESH_VPB, ROWS = 3 * VPB;
+    static_assert(VPB == 32 || VPB == 64, "a wave holds the workgroup's vertices");
+    __shared__ float gv[ROWS];          // dL/d(posed vertex) of this workgroup's vertices
+    __shared__ float red[100];          // the 99 block sums
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gid = blockIdx.x * 256 + tid;
+    for (int b = 0; b < zero.count; ++b)
+        for (int i = gid; i < zero.n[b]; i += (int)(gridDim.x * 256)) zero.p[b][i] = 0.f;
+    const int vbase = blockIdx.x * VPB, vend = min(vbase + VPB, rig.V);
+    for (int k = tid; k < ROWS; k += 256) gv[k] = 0.f;
+    __syncthreads();
+    // ---- gather the corners
+    const int p0 = a.vf_begin[vbase], p1 = a.vf_begin[vend];
+    for (int p = p0 + tid; p < p1; p += 256) {
+        const int4 e = a.vf_list[p];
+        const int f = e.x >> 2, c = e.x & 3;
+        Vec3 g0, g1, g2;
+        face_frame_bwd(f, ld3(a.verts, e.y), ld3(a.verts, e.z), ld3(a.verts, e.w), a.d_center, a.d_R, a.d_scaling, a.d_quat, g0, g1, g2);
+        const Vec3 g = c == 0 ? g0 : (c == 1 ? g1 : g2);
+        const int vl = (c == 0 ? e.y : (c == 1 ? e.z : e.w)) - vbase;
+        atomicAdd(&gv[3 * vl], g.x); atomicAdd(&gv[3 * vl + 1], g.y); atomicAdd(&gv[3 * vl + 2], g.z);
+    }
+    __syncthreads();
+    // ---- skinning backward: every wave evaluates the workgroup's vertices (lane = vertex), each reduces a quarter of the sums
+    const int v = vbase + lane;
+    const bool ok = lane < VPB && v < rig.V;
+    const int E = 3 * rig.V;
+    float g[3] = {0.f, 0.f, 0.f}, vp[3] = {0.f, 0.f, 0.f}, T[12], gvp[3] = {0.f, 0.f, 0.f};
+    float w[GAB_NUM_JOINTS] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float pf[GAB_POSE_FEATURES];
+#pragma unroll
+    for (int p = 0; p < GAB_POSE_FEATURES; ++p) pf[p] = 0.f;
+    if (ok) {
+        vertex_posed_and_T<true>(rig, a.ws, a.v_shaped, v, vp, T);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g[k] = gv[3 * lane + k] + (a.g_verts ? a.g_verts[3 * v + k] : 0.f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gvp[c] = T[c] * g[0] + T[4 + c] * g[1] + T[8 + c] * g[2];
+#pragma unroll
+        for (int j = 0; j < GAB_NUM_JOINTS; ++j) w[j] = rig.lbs_weights[(size_t)v * GAB_NUM_JOINTS + j];
+#pragma unroll
+        for (int p = 0; p < GAB_POSE_FEATURES; ++p) {
+            const float* row = rig.posedirs + (size_t)p * E + 3 * v;
+            pf[p] = row[0] * gvp[0] + row[1] * gvp[1] + row[2] * gvp[2];
+        }
+        if (wid == 0) { a.g_vs[3 * v] = gvp[0]; a.g_vs[3 * v + 1] = gvp[1]; a.g_vs[3 * v + 2] = gvp[2]; }
+    }
+    const float vph[4] = {vp[0], vp[1], vp[2], ok ? 1.f : 0.f};
+    // wave 0: joints 0, 1; wave 1: joints 2, 3; wave 2: joint 4, d translation, pose features 0..8; wave 3: pose features 9..35
+#pragma unroll
+    for (int j = 0; j < GAB_NUM_JOINTS; ++j) {
+        if (wid != (j >> 1)) continue;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float s = wave_sum_hi(w[j] * g[r] * vph[c]);
+                if (lane == 63) red[12 * j + 4 * r + c] = s;
+            }
+    }
+    if (wid == 2) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float s = wave_sum_hi(g[r]);
+            if (lane == 63) red[60 + r] = s;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < GAB_POSE_FEATURES; ++p) {
+        if (wid != (p < 9 ? 2 : 3)) continue;
+        const float s = wave_sum_hi(pf[p]);
+        if (lane == 63) red[63 + p] = s;
+    }
+    __syncthreads();
+    if (tid < 99) {
+        float* dst = tid < 60 ? &a.ws[WS_DA + tid] : (tid < 63 ? &a.ws[WS_DT + tid - 60] : &a.ws[WS_DPF + tid - 63]);
+        unsafeAtomicAdd(dst, red[tid]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1425,6 +1536,52 @@ int gab_flame_backward_prepared(const GabRig* rig_, const float* prepared, const
     const int E = 3 * rig.V;
     hipLaunchKernelGGL(gab::k_skin_bwd, dim3((rig.V + 255) / 256), dim3(256), 0, st, rig, ws, v_shaped, dL_dverts, scratch, zs);
     LAUNCH_CHECK("k_skin_bwd");
+    const float* Mmat = prepared + gab::prep_joint_offset(rig.V) + 16;
+    const int blocks = 1 + (E + GAB_BLEND_BWD_ROWS - 1) / GAB_BLEND_BWD_ROWS;
+    const bool flame_tree = rig.parents[1] == 0 && rig.parents[2] == 1 && rig.parents[3] == 1 && rig.parents[4] == 1;
+    if (flame_tree)
+        hipLaunchKernelGGL(gab::k_chain_blend_bwd<true>, dim3(blocks), dim3(256), 0, st, rig, ws, (const float*)scratch, Mmat, rotation, neck, jaw, eyes,
+                           d_rotation, d_neck, d_jaw, d_eyes, d_translation, d_expr);
+    else
+        hipLaunchKernelGGL(gab::k_chain_blend_bwd<false>, dim3(blocks), dim3(256), 0, st, rig, ws, (const float*)scratch, Mmat, rotation, neck, jaw, eyes,
+                           d_rotation, d_neck, d_jaw, d_eyes, d_translation, d_expr);
+    LAUNCH_CHECK("k_chain_blend_bwd");
+    return GAB_OK;
+}
+
+int gab_mesh_backward_prepared(const GabRig* rig_, const float* prepared, const float* rotation, const float* neck, const float* jaw,
+                               const float* eyes, const float* v_shaped, float* ws, const float* verts, const int32_t* vf_begin,
+                               const int32_t* vf_list, const float* d_center, const float* d_orien_mat, const float* d_scaling,
+                               const float* d_orien_quat, const float* dL_dverts, float* d_expr, float* d_rotation, float* d_neck,
+                               float* d_jaw, float* d_eyes, float* d_translation, float* scratch, int32_t zero_count,
+                               float* const* zero_buffers_host, const int32_t* zero_sizes_host, void* stream_)
+{
+    if (zero_count < 0 || zero_count > 7 || (zero_count > 0 && (!zero_buffers_host || !zero_sizes_host)))
+        return fail(GAB_E_ARG, "gab_mesh_backward_prepared: 0..7 zero-fill buffers");
+    gab::Rig rig;
+    if (int rc = to_rig(rig_, &rig)) return rc;
+    if (!prepared || !rotation || !neck || !jaw || !eyes || !v_shaped || !ws || !verts || !vf_begin || !vf_list || !d_expr || !d_rotation ||
+        !d_neck || !d_jaw || !d_eyes || !d_translation || !scratch)
+        return fail(GAB_E_ARG, "gab_mesh_backward_prepared: NULL buffer");
+    gab::ZeroSpec zs;
+    bool covers_expr = false;   // d_expr is added into by both roles of the second launch: it must be zero before that launch
+    for (int i = 0; i < 8; ++i) {
+        zs.p[i] = i < zero_count ? zero_buffers_host[i] : nullptr;
+        zs.n[i] = i < zero_count ? zero_sizes_host[i] : 0;
+        if (i < zero_count && (zs.n[i] < 0 || (zs.n[i] > 0 && !zs.p[i]))) return fail(GAB_E_ARG, "gab_mesh_backward_prepared: bad zero-fill buffer %d", i);
+        if (i < zero_count && d_expr >= zs.p[i] && d_expr + rig.n_expr <= zs.p[i] + zs.n[i]) covers_expr = true;
+    }
+    zs.count = zero_count;
+    if (!covers_expr) { zs.p[zs.count] = d_expr; zs.n[zs.count] = rig.n_expr; ++zs.count; }
+    gab::GatherSkinArgs a;
+    a.v_shaped = v_shaped; a.ws = ws; a.verts = verts;
+    a.vf_begin = vf_begin; a.vf_list = reinterpret_cast<const int4*>(vf_list);
+    a.d_center = d_center; a.d_R = d_orien_mat; a.d_scaling = d_scaling; a.d_quat = d_orien_quat; a.g_verts = dL_dverts;
+    a.g_vs = scratch;
+    hipStream_t st = (hipStream_t)stream_;
+    hipLaunchKernelGGL(gab::k_gather_skin_bwd, dim3((rig.V + GAB_MESH_VPB - 1) / GAB_MESH_VPB), dim3(256), 0, st, rig, a, zs);
+    LAUNCH_CHECK("k_gather_skin_bwd");
+    const int E = 3 * rig.V;
     const float* Mmat = prepared + gab::prep_joint_offset(rig.V) + 16;
     const int blocks = 1 + (E + GAB_BLEND_BWD_ROWS - 1) / GAB_BLEND_BWD_ROWS;
     const bool flame_tree = rig.parents[1] == 0 && rig.parents[2] == 1 && rig.parents[3] == 1 && rig.parents[4] == 1;

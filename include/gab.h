@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GAB_ABI_VERSION 2
+#define GAB_ABI_VERSION 3
 #define GAB_OK 0
 #define GAB_E_ARG (-1)
 #define GAB_E_HIP (-2)
@@ -93,6 +93,20 @@ int gab_flame_backward_prepared(const GabRig* rig, const float* prepared, const 
                                 float* d_expr, float* d_rotation, float* d_neck, float* d_jaw, float* d_eyes, float* d_translation,
                                 float* scratch, int32_t zero_count, float* const* zero_buffers_host, const int32_t* zero_sizes_host,
                                 void* stream);
+
+/* ---- select_mesh_by_timestep + update_mesh_properties, backward in TWO launches (prepared rig) -----------------------------
+ * Replaces gab_face_frames_backward + gab_flame_backward_prepared (three launches; scene/flame_gaussian_model.py:117-154 under
+ * autograd): takes the gradients of the four per-face outputs (any of them NULL), optionally an external dL/d(posed vertices) to
+ * add, and writes row t of the six per-frame parameter tables.  vf_begin (V+1) / vf_list (3F x 4 int32): the vertex -> corner
+ * table of the topology, one row (4 f + c, i0, i1, i2) per corner c of face f = (i0, i1, i2), rows in vertex order -- static,
+ * built once by the caller.  `ws`, scratch (3V floats) and zero_* as gab_flame_backward_prepared. */
+int gab_mesh_backward_prepared(const GabRig* rig, const float* prepared, const float* rotation, const float* neck, const float* jaw,
+                               const float* eyes, const float* v_shaped, float* ws, const float* verts /*(V,3) posed*/,
+                               const int32_t* vf_begin, const int32_t* vf_list, const float* d_center, const float* d_orien_mat,
+                               const float* d_scaling, const float* d_orien_quat, const float* dL_dverts /*(V,3) or NULL*/,
+                               float* d_expr, float* d_rotation, float* d_neck, float* d_jaw, float* d_eyes, float* d_translation,
+                               float* scratch, int32_t zero_count, float* const* zero_buffers_host, const int32_t* zero_sizes_host,
+                               void* stream);
 
 /* ---- per-face frames ----------------------------------------------------------------------- */
 /* d_verts_zeroed: optional (V,3) buffer the forward zero-fills on the side, to be handed to the backward as its

@@ -133,6 +133,44 @@ def test_flame_prepared_rig_path_vs_torch_and_classic():
     _close(v1b, v2b, 2e-5, "verts after an in-place shape update")
 
 
+@pytest.mark.parametrize("with_verts_grad", [False, True])
+def test_mesh_backward_gather_equals_the_scatter_form(monkeypatch, with_verts_grad):
+    """select_mesh_by_timestep + update_mesh_properties as one autograd node (binding.mesh_frames_timestep): its backward with the face-frame
+    and skinning backward as ONE gathering launch (gab_mesh_backward_prepared: no d_verts buffer, no global atomics into the vertices)
+    against the scatter + skinning launches it replaces, full-size rig, every per-face output weighted, with and without a gradient
+    arriving at the posed vertices themselves; twice over the same forward.  Both are fp32 sums in different orders: 1e-4 of each row's max."""
+    from gaussianavatars_amd import binding as B
+
+    dev = _dev()
+    rig = S.flame_rig(4)
+    seq = S.flame_sequence(8, 4)
+    head = _Head(rig, dev, 300)
+    faces = torch.as_tensor(rig["faces"], device=dev)
+    F = faces.shape[0]
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    wts = [torch.randn(s, generator=gen).to(dev) for s in ((F, 3), (F, 3, 3), (F, 1), (F, 4), (1, rig["v_template"].shape[0], 3))]
+    keys = ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation")
+    res = {}
+    for mode in ("merged", "split"):
+        monkeypatch.setenv("GAA_MESH_BWD", mode)
+        fp = {k: torch.as_tensor(v, device=dev).clone().requires_grad_(k in keys) for k, v in seq.items()}
+        verts, cano, center, R, scale, quat = B.mesh_frames_timestep(head, fp, 5, faces)
+        loss = (center * wts[0]).sum() + (R * wts[1]).sum() + (scale * wts[2]).sum() + (quat * wts[3]).sum()
+        if with_verts_grad:
+            loss = loss + (verts * wts[4]).sum()
+        loss.backward(retain_graph=True)
+        first = {k: fp[k].grad.clone() for k in keys}
+        for k in keys:
+            fp[k].grad = None
+        loss.backward()
+        for k in keys:
+            assert float((fp[k].grad - first[k]).abs().max()) <= 1e-4 * float(first[k].abs().max()), f"{k}: a second backward over the same forward differs"
+            assert float(fp[k].grad[:5].abs().max()) == 0.0 and float(fp[k].grad[6:].abs().max()) == 0.0, f"{k}: gradient outside row 5"
+        res[mode] = first
+    for k in keys:
+        _close(res["merged"][k][5], res["split"][k][5], 1e-4, f"d_{k}: gather vs scatter")
+
+
 def test_face_frames_and_bind_forward_backward_vs_torch():
     from gaussianavatars_amd import binding as B
 
