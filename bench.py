@@ -388,6 +388,9 @@ def main():
                          "binding, the rasterizer stubbed at its autograd Function; the line is marked as such and is not a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--graph-frames", type=int, default=4,
+                    help="with --graph: frames per recording (the frame feed is a kernel inside it: gab_feed_row), so that the launch gap between two "
+                         "graphs is paid once per K frames; steps that do not fill a recording use a one-frame recording")
     ap.add_argument("--graph", action="store_true",
                     help="record the frame step once and replay it as one hipGraph launch per step (gaussianavatars_amd.graphs.GraphedStep)")
     ap.add_argument("--streams", type=int, default=1,
@@ -484,49 +487,74 @@ def main():
         on the GPU the way they do across GPUs."""
         from gaussianavatars_amd.graphs import FlameRowFeeder, GraphedStep, release_mesh
 
-        def make_lane(gm):
+        def make_lane(gm, lane, n_lanes):
             feeder = None
             if gm.binding is not None:
                 feeder = FlameRowFeeder(gm.flame_param, requires_grad=train)
                 gm.flame_param = feeder.static_param
+                # this lane's frames in the order the eager loop would hand them over: frame i of the run goes to lane i % n_lanes
+                feeder.set_schedule([my_frames[(lane + n_lanes * m) % len(my_frames)] for m in range(len(my_frames))])
             loss_sum = torch.zeros((), dtype=torch.float32, device=device)
 
-            def fixed_step():
+            def fixed_step():   # the eager per-kernel event pass: one frame, fed by the caller
                 with torch.set_grad_enabled(train):
-                    l = one_step(gm, cam, bg, target, 0, train)
-                if dist is None and train:
-                    loss_sum.add_(l)
-                return l
+                    return one_step(gm, cam, bg, target, 0, train)
+
+            def frames_step(k):
+                def fn():   # K frames back to back, each fed from the device-side schedule; what a frame loop does between frames included
+                    ls = []
+                    for j in range(k):
+                        if feeder is not None:
+                            feeder.feed_next()
+                        with torch.set_grad_enabled(train):
+                            ls.append(one_step(gm, cam, bg, target, 0, train))
+                        if train and j + 1 < k:
+                            zero_grads(gm)
+                            release_mesh(gm)
+                    l = ls[0] if k == 1 else torch.stack(ls).sum()
+                    if dist is None and train:
+                        loss_sum.add_(l)
+                    return l
+                return fn
 
             def fresh():   # no gradients and no autograd graph of an earlier frame when the step is recorded
                 zero_grads(gm)
                 release_mesh(gm)
 
-            return dict(g=gm, feeder=feeder, loss_sum=loss_sum, fixed_step=fixed_step, stream=torch.cuda.Stream(device),
-                        graphed=GraphedStep(fixed_step, before_capture=fresh))
+            K = max(1, int(args.graph_frames)) if dist is None else 1   # (ranks all-reduce every step's scalar: one frame per recording)
+            ln = dict(g=gm, feeder=feeder, loss_sum=loss_sum, fixed_step=fixed_step, stream=torch.cuda.Stream(device), K=K,
+                      graphed=GraphedStep(frames_step(1), before_capture=fresh))
+            ln["graphed_k"] = GraphedStep(frames_step(K), before_capture=fresh) if K > 1 else ln["graphed"]
+            return ln
 
-        out = [make_lane(g)]
-        for _ in range(1, n_lanes):
+        out = [make_lane(g, 0, n_lanes)]
+        for lane in range(1, n_lanes):
             if args.workload == "cfg5":
                 gk, _ = build_unbound_scene(device, args.splats, 3, args.width, args.height)
             else:
                 gk, _ = build_scene(device, args.splats, 3, args.width, args.height, args.frames, args.binding, train)
-            out.append(make_lane(gk))
+            out.append(make_lane(gk, lane, n_lanes))
         return out
 
     def lane_runner(lanes):
-        def run(n, offset):   # one rank: the recorded step adds its loss to a static accumulator, nothing else runs per step
+        def run(n, offset):   # one rank: the recordings add their losses to a static accumulator, nothing else runs per step
             cur = torch.cuda.current_stream(device)
-            for ln in lanes:
+            L = len(lanes)
+            for j, ln in enumerate(lanes):
                 ln["stream"].wait_stream(cur)
                 with torch.cuda.stream(ln["stream"]):
                     ln["loss_sum"].zero_()
-            for i in range(n):
-                ln = lanes[i % len(lanes)]
-                with torch.cuda.stream(ln["stream"]):
                     if ln["feeder"] is not None:
-                        ln["feeder"].feed(my_frames[(offset + i) % len(my_frames)])
-                    ln["graphed"].replay()
+                        ln["feeder"].seek((offset + L - 1 - j) // L)   # frames offset .. of the run: lane j gets those with index = j (mod L)
+            # frame i of the run belongs to lane (offset + i) % L; every lane replays K-frame recordings while it has K frames left
+            per_lane = [len(range((j - offset) % L, n, L)) for j in range(L)]
+            todo = [[ln["K"]] * (c // ln["K"]) + [1] * (c % ln["K"]) for ln, c in zip(lanes, per_lane)]
+            while any(todo):
+                for ln, td in zip(lanes, todo):
+                    if td:
+                        k = td.pop(0)
+                        with torch.cuda.stream(ln["stream"]):
+                            (ln["graphed_k"] if k > 1 else ln["graphed"]).replay()
             for ln in lanes:
                 cur.wait_stream(ln["stream"])
             return torch.stack([ln["loss_sum"] for ln in lanes]).sum()
@@ -546,7 +574,7 @@ def main():
 
         def graph_step(t):
             if lanes[0]["feeder"] is not None:
-                lanes[0]["feeder"].feed(t)
+                lanes[0]["feeder"].seek(my_frames.index(t) if t in my_frames else 0)
             return graphed.replay().clone()   # the recorded scalar is overwritten by the next replay
 
         run = make_runner(graph_step, my_frames, dist, device) if dist is not None else lane_runner(lanes)   # (the per-step all-reduce takes its copy of the scalar anyway)
@@ -564,8 +592,9 @@ def main():
     info = {"binning_path": 0} if dry else R.last_forward_info()
     if graphed is not None:
         for ln in lanes:
+            ln["graphed_k"].check()
             ln["graphed"].check()                         # the device marks a slot whose frame did not fit and only the host clears the mark: this covers every replay above
-        info["num_rendered"] = max(graphed.instances())   # (the recording itself did not know its count)
+        info["num_rendered"] = max(max(graphed.instances()), max(lanes[0]["graphed_k"].instances()))   # (the recording itself did not know its count)
 
     # ---- per-kernel durations: HIP events on the launch stream (recorded by the C ABI around every kernel).
     # Bracketing each launch with an event pair costs ~5 % of the frame rate (983 -> 933 frames/s measured),
@@ -734,7 +763,7 @@ def main():
             "frame_streams": frame_streams,
             # the frame's single host wait (for the instance count): ~0 would mean the host paces the loop, not the GPU
             "host": {"scan_wait_ms_per_step": round(wait_ms / max(waits, 1), 4), "pinned_cpus": len(pinned) if pinned else None,
-                     "step_launch": ("hipGraph replay (one launch per step; binning capacity %d for %d instances; %d frame stream(s))" % (graphed.capacity, max(graphed.instances()), len(lanes)))
+                     "step_launch": ("hipGraph replay (one launch per %d steps, the frame feed a kernel inside the recording; binning capacity %d for %d instances; %d frame stream(s))" % (lanes[0]["K"], graphed.capacity, info["num_rendered"], len(lanes)))
                                     if graphed is not None else "eager (one Python-driven launch per kernel)"},
         }
         print(json.dumps(out))

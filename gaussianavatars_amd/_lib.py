@@ -225,6 +225,7 @@ GAB_SYMBOLS = {
     "gab_bind_backward_csr": (C.c_int, [C.c_int32, C.c_int32] + [_P] * 22),
     "gab_bind_backward_faces": (C.c_int, [C.c_int32, _P, _P, _P, _P]),
     "gab_zero_buffers": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _P]),
+    "gab_feed_row": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
 }
 
 _gab = None

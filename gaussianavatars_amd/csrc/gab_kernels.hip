@@ -1355,6 +1355,19 @@ __global__ __launch_bounds__(256) void k_bind_bwd_faces(int F, const int* __rest
 }
 
 // one launch that zero-fills up to 8 small buffers (the full-table gradients of the per-timestep FLAME rows)
+// The frame feed of a recorded step (graphs.py): row schedule[cursor % n] of the packed per-timestep table -> the static one-row table the
+// recorded kernels read; then the cursor moves on.  One workgroup; every thread reads the cursor before thread 0 advances it.
+__global__ __launch_bounds__(256) void k_feed_row(const float* __restrict__ packed, int T, int width, const int* __restrict__ schedule, int n_sched,
+                                                   int* __restrict__ cursor, float* __restrict__ row)
+{
+    const int c = *cursor;
+    int t = schedule ? schedule[(unsigned)c % (unsigned)n_sched] : c;
+    t = (int)((unsigned)t % (unsigned)T);
+    for (int k = threadIdx.x; k < width; k += 256) row[k] = packed[(size_t)t * width + k];
+    __syncthreads();
+    if (threadIdx.x == 0) *cursor = c + 1;
+}
+
 __global__ __launch_bounds__(256) void k_zero_many(ZeroSpec z)
 {
     const int b = blockIdx.y;
@@ -1705,6 +1718,15 @@ int gab_bind_backward_faces(int32_t F, const int32_t* face_begin, const float* r
     const long long threads = 16ll * F;
     hipLaunchKernelGGL(gab::k_bind_bwd_faces, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, F, face_begin, rows, d_face);
     LAUNCH_CHECK("k_bind_bwd_faces");
+    return GAB_OK;
+}
+
+int gab_feed_row(const float* packed, int32_t T, int32_t width, const int32_t* schedule, int32_t n_sched, int32_t* cursor, float* row,
+                 void* stream_)
+{
+    if (T <= 0 || width <= 0 || !packed || !cursor || !row || (schedule && n_sched <= 0)) return fail(GAB_E_ARG, "gab_feed_row: bad arguments");
+    hipLaunchKernelGGL(gab::k_feed_row, dim3(1), dim3(256), 0, (hipStream_t)stream_, packed, T, width, schedule, n_sched, cursor, row);
+    LAUNCH_CHECK("k_feed_row");
     return GAB_OK;
 }
 

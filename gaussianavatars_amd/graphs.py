@@ -175,3 +175,29 @@ class FlameRowFeeder:
         t = int(t) % self.T
         with torch.no_grad():
             self.row.copy_(self.packed[t:t + 1])
+
+    # ---- the feed as a kernel INSIDE a recording: K frames per graph, each preceded by feed_next() -------------------------
+    def set_schedule(self, frames, start: int = 0) -> None:
+        """The timesteps successive feed_next() calls deliver, cyclically (a DEVICE table: replays of a recording that contains
+        feed_next() walk it on their own), and the position the next one starts from."""
+        dev = self.packed.device
+        self.schedule = torch.as_tensor([int(f) % self.T for f in frames], dtype=torch.int32, device=dev)
+        self.cursor = torch.full((1,), int(start), dtype=torch.int32, device=dev)
+
+    def seek(self, position: int) -> None:
+        """Next feed_next() delivers schedule[position % len] (host call between replays; one fill kernel)."""
+        self.cursor.fill_(int(position))
+
+    def feed_next(self) -> None:
+        """row <- packed[schedule[cursor]]; cursor += 1 -- one kernel on the current stream (include/gab.h: gab_feed_row), capturable."""
+        import ctypes as C
+
+        from . import _lib
+
+        dev = self.packed.device
+        with _lib.on_device(dev):
+            rc = _lib.gab().gab_feed_row(C.c_void_p(self.packed.data_ptr()), self.T, int(self.packed.shape[1]), C.c_void_p(self.schedule.data_ptr()),
+                                         int(self.schedule.numel()), C.c_void_p(self.cursor.data_ptr()), C.c_void_p(self.row.data_ptr()),
+                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"gab_feed_row: {_lib.gab().gab_last_error().decode()}")

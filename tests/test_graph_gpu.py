@@ -100,6 +100,63 @@ def test_graphed_step_equals_the_eager_step_frame_by_frame():
         R.set_deterministic(prev)
 
 
+def test_three_frames_per_recording_fed_from_a_device_side_schedule():
+    """K frames in ONE recording, each preceded by the feeder's kernel (include/gab.h: gab_feed_row) that takes the next timestep of a DEVICE
+    schedule: two replays walk six schedule entries on their own (no host call between frames), wrap around the schedule, and every frame has
+    the eager step's image bits and loss; seek() repositions the walk."""
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd.graphs import FlameRowFeeder, GraphedStep
+
+    dev = _dev()
+    g, cam = _scene(dev)
+    bg = torch.ones(3, device=dev)
+    target = torch.full((3, 176, 208), 0.5, device=dev)
+    prev = R.set_deterministic(True)
+    try:
+        full = g.flame_param
+        sched = [3, 7, 0, 11, 5]
+        want = {}
+        for t in sched:
+            _zero(g)
+            loss, img, _, _ = _step(g, cam, bg, target, t)
+            want[t] = (loss.clone(), img.clone(), [getattr(g, n).grad.clone() for n in _LEAVES])
+        feeder = FlameRowFeeder(full, requires_grad=True)
+        feeder.set_schedule(sched)
+        g.flame_param = feeder.static_param
+
+        def three():
+            out = []
+            for j in range(3):
+                if j:
+                    _zero(g)
+                feeder.feed_next()
+                loss, img, _, _ = _step(g, cam, bg, target, 0)
+                out += [loss, img]
+            return tuple(out)
+
+        step = GraphedStep(three, before_capture=lambda: _zero(g))
+        assert len(step.instances()) == 3          # one count slot per recorded forward
+        feeder.seek(0)
+        seen = []
+        for _ in range(2):
+            out = step.replay()
+            torch.cuda.synchronize()
+            step.check()
+            seen += [(out[2 * j].clone(), out[2 * j + 1].clone()) for j in range(3)]
+        for (loss, img), t in zip(seen, [3, 7, 0, 11, 5, 3]):
+            assert torch.equal(img, want[t][1]) and torch.equal(loss, want[t][0]), t
+        for n, a in zip(_LEAVES, want[3][2]):      # the gradients left behind are the last frame's
+            assert torch.equal(getattr(g, n).grad, a), n
+        assert int(feeder.cursor.item()) == 6
+        feeder.seek(3)
+        out = step.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out[1], want[11][1]) and torch.equal(out[5], want[3][1])
+        step.close()
+    finally:
+        R.set_deterministic(prev)
+
+
 def test_overflowing_frame_is_reported_and_recapture_recovers():
     from gaussianavatars_amd import rasterizer as R
     from gaussianavatars_amd.graphs import CapacityOverflow, FlameRowFeeder, GraphedStep
