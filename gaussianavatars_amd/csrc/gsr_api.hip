@@ -807,7 +807,7 @@ static int backward_impl(const GsrSettings* settings, int32_t P, int32_t M, cons
     if (bound && !opacity_logit) return fail(GSR_E_ARG, "gsr_backward_bound: opacity_logit is NULL");
     {
         TIMED(GSR_K_PREPROCESS_BWD, stream);
-        hipLaunchKernelGGL(gsr::k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, stream, ds, pa);
+        hipLaunchKernelGGL(gsr::k_preprocess_bwd, dim3((P + GSR_PREBWD_ROWS - 1) / GSR_PREBWD_ROWS), dim3(GSR_PREBWD_ROWS), 0, stream, ds, pa);
         KERNEL_CHECK("k_preprocess_bwd", stream, dbg);
     }
     return GSR_OK;

@@ -571,22 +571,22 @@ __global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_
 
 // ------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a)
+__global__ __launch_bounds__(GSR_PREBWD_ROWS) void k_preprocess_bwd(Settings s, PreBwdArgs a)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int M = a.M;
     // SH coefficients in, SH gradients out: both as one coalesced stream per workgroup through LDS
     // (gsr_device.h); each thread reads its coefficient row and then overwrites it with the gradient row.
-    __shared__ float sh_lds[GSR_SH_ROWS * GSR_SH_MAX_STRIDE];
+    __shared__ float sh_lds[GSR_PREBWD_ROWS * GSR_SH_MAX_STRIDE];
     const bool sh_staged = !a.use_precomp_color && a.dL_dsh != nullptr && M <= 16;
-    const int first = blockIdx.x * GSR_SH_ROWS, rows = min(GSR_SH_ROWS, a.P - first);
+    const int first = blockIdx.x * GSR_PREBWD_ROWS, rows = min(GSR_PREBWD_ROWS, a.P - first);
     const int sh_stride = sh_row_stride(M);
     if (sh_staged) {
         if (a.shs_rest) {   // the model's two leaf tensors: DC (P,1,3) and rest (P,M-1,3)
-            sh_rows_load(sh_lds, a.shs, first, rows, 3, sh_stride, 0, (int)threadIdx.x);
-            sh_rows_load(sh_lds, a.shs_rest, first, rows, 3 * (M - 1), sh_stride, 3, (int)threadIdx.x);
+            sh_rows_load<GSR_PREBWD_ROWS>(sh_lds, a.shs, first, rows, 3, sh_stride, 0, (int)threadIdx.x);
+            sh_rows_load<GSR_PREBWD_ROWS>(sh_lds, a.shs_rest, first, rows, 3 * (M - 1), sh_stride, 3, (int)threadIdx.x);
         } else {
-            sh_rows_load(sh_lds, a.shs, first, rows, 3 * M, sh_stride, 0, (int)threadIdx.x);
+            sh_rows_load<GSR_PREBWD_ROWS>(sh_lds, a.shs, first, rows, 3 * M, sh_stride, 0, (int)threadIdx.x);
         }
         __syncthreads();
     }
@@ -634,84 +634,8 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
         }
         const float* c6 = a.cov3D + 6 * i;
 
-        // ---- conic -> cov2D -> (Sigma, mean) -------------------------------------------------
-        float t0 = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
-        float t1 = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
-        const float t2 = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
-        const float limx = 1.3f * s.tanfovx, limy = 1.3f * s.tanfovy;
-        const float txtz = t0 / t2, tytz = t1 / t2;
-        t0 = sel_min(limx, sel_max(-limx, txtz)) * t2;
-        t1 = sel_min(limy, sel_max(-limy, tytz)) * t2;
-        const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
-        const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
-        const float J00 = fx / t2, J02 = -(fx * t0) / (t2 * t2), J11 = fy / t2, J12 = -(fy * t1) / (t2 * t2);
-        float A[2][3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            A[0][j] = J00 * vm[4 * j + 0] + J02 * vm[4 * j + 2];
-            A[1][j] = J11 * vm[4 * j + 1] + J12 * vm[4 * j + 2];
-        }
-        const float V[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
-        float AV[2][3];
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) AV[r][j] = A[r][0] * V[0][j] + A[r][1] * V[1][j] + A[r][2] * V[2][j];
-        const float ca = AV[0][0] * A[0][0] + AV[0][1] * A[0][1] + AV[0][2] * A[0][2] + 0.3f;
-        const float cb = AV[0][0] * A[1][0] + AV[0][1] * A[1][1] + AV[0][2] * A[1][2];
-        const float cc = AV[1][0] * A[1][0] + AV[1][1] * A[1][1] + AV[1][2] * A[1][2] + 0.3f;
-        const float denom = ca * cc - cb * cb;
-        if (s.fast_blend) {   // the blend handed over sum(q dx), sum(q dy): the conic (the forward's: x * det_inv) turns them into the position gradient
-            const float det_inv = 1.f / denom;
-            const float kA = cc * det_inv, kB = -cb * det_inv, kC = ca * det_inv;
-            g2x = -0.5f * (float)s.W * (kA * q0.w + kB * q1.x);
-            g2y = -0.5f * (float)s.H * (kC * q1.x + kB * q0.w);
-            const float opac = a.grec[3 * (size_t)i + 1].y;   // the blend summed opacity * G * dL/dalpha
-            gop = opac > 0.f ? q2.x / opac : 0.f;
-        }
-        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
-        if (denom2inv != 0.f) {
-            dL_da = denom2inv * (-cc * cc * gA + 2.f * cb * cc * gB + (denom - ca * cc) * gC);
-            dL_dc = denom2inv * (-ca * ca * gC + 2.f * ca * cb * gB + (denom - ca * cc) * gA);
-            dL_db = denom2inv * 2.f * (cb * cc * gA - (denom + 2.f * cb * cb) * gB + ca * cb * gC);
-            gcov[0] = A[0][0] * A[0][0] * dL_da + A[0][0] * A[1][0] * dL_db + A[1][0] * A[1][0] * dL_dc;
-            gcov[3] = A[0][1] * A[0][1] * dL_da + A[0][1] * A[1][1] * dL_db + A[1][1] * A[1][1] * dL_dc;
-            gcov[5] = A[0][2] * A[0][2] * dL_da + A[0][2] * A[1][2] * dL_db + A[1][2] * A[1][2] * dL_dc;
-            gcov[1] = 2.f * A[0][0] * A[0][1] * dL_da + (A[0][0] * A[1][1] + A[0][1] * A[1][0]) * dL_db + 2.f * A[1][0] * A[1][1] * dL_dc;
-            gcov[2] = 2.f * A[0][0] * A[0][2] * dL_da + (A[0][0] * A[1][2] + A[0][2] * A[1][0]) * dL_db + 2.f * A[1][0] * A[1][2] * dL_dc;
-            gcov[4] = 2.f * A[0][2] * A[0][1] * dL_da + (A[0][1] * A[1][2] + A[0][2] * A[1][1]) * dL_db + 2.f * A[1][1] * A[1][2] * dL_dc;
-        }
-        float dA[2][3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float a0v = A[0][0] * V[j][0] + A[0][1] * V[j][1] + A[0][2] * V[j][2];
-            const float a1v = A[1][0] * V[j][0] + A[1][1] * V[j][1] + A[1][2] * V[j][2];
-            dA[0][j] = 2.f * a0v * dL_da + a1v * dL_db;
-            dA[1][j] = 2.f * a1v * dL_dc + a0v * dL_db;
-        }
-        const float dJ00 = vm[0] * dA[0][0] + vm[4] * dA[0][1] + vm[8] * dA[0][2];
-        const float dJ02 = vm[2] * dA[0][0] + vm[6] * dA[0][1] + vm[10] * dA[0][2];
-        const float dJ11 = vm[1] * dA[1][0] + vm[5] * dA[1][1] + vm[9] * dA[1][2];
-        const float dJ12 = vm[2] * dA[1][0] + vm[6] * dA[1][1] + vm[10] * dA[1][2];
-        const float tz = 1.f / t2, tz2 = tz * tz, tz3 = tz2 * tz;
-        const float dtx = x_grad_mul * -fx * tz2 * dJ02;
-        const float dty = y_grad_mul * -fy * tz2 * dJ12;
-        const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * t0) * tz3 * dJ02 + (2.f * fy * t1) * tz3 * dJ12;
-        dmean[0] = vm[0] * dtx + vm[1] * dty + vm[2] * dtz;
-        dmean[1] = vm[4] * dtx + vm[5] * dty + vm[6] * dtz;
-        dmean[2] = vm[8] * dtx + vm[9] * dty + vm[10] * dtz;
-
-        // ---- projective divide: d(ndc.xy)/d(mean) --------------------------------------------
-        const float hw = proj[3] * mx + proj[7] * my + proj[11] * mz + proj[15];
-        const float m_w = 1.0f / (hw + 0.0000001f);
-        const float mul1 = (proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12]) * m_w * m_w;
-        const float mul2 = (proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13]) * m_w * m_w;
-        dmean[0] += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
-        dmean[1] += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
-        dmean[2] += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
-
-        // ---- SH: coefficients and view direction ---------------------------------------------
+        // ---- SH: coefficients and view direction (FIRST: its 48 coefficient registers are dead before the geometric chain below builds
+        // up its own -- 90 VGPRs instead of 130 with the two blocks the other way round) --------------------------------------------
         if (!a.use_precomp_color) {
             // the coefficient row is copied to registers first: in staged mode the gradient row overwrites it in LDS
             float shr[48];
@@ -781,6 +705,83 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
             dmean[1] += (-d0 * d1 * ddir[0] + (sum2 - d1 * d1) * ddir[1] - d2 * d1 * ddir[2]) * invsum32;
             dmean[2] += (-d0 * d2 * ddir[0] - d1 * d2 * ddir[1] + (sum2 - d2 * d2) * ddir[2]) * invsum32;
         }
+
+        // ---- conic -> cov2D -> (Sigma, mean) -------------------------------------------------
+        float t0 = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
+        float t1 = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
+        const float t2 = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+        const float limx = 1.3f * s.tanfovx, limy = 1.3f * s.tanfovy;
+        const float txtz = t0 / t2, tytz = t1 / t2;
+        t0 = sel_min(limx, sel_max(-limx, txtz)) * t2;
+        t1 = sel_min(limy, sel_max(-limy, tytz)) * t2;
+        const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+        const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+        const float J00 = fx / t2, J02 = -(fx * t0) / (t2 * t2), J11 = fy / t2, J12 = -(fy * t1) / (t2 * t2);
+        float A[2][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            A[0][j] = J00 * vm[4 * j + 0] + J02 * vm[4 * j + 2];
+            A[1][j] = J11 * vm[4 * j + 1] + J12 * vm[4 * j + 2];
+        }
+        const float V[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+        float AV[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) AV[r][j] = A[r][0] * V[0][j] + A[r][1] * V[1][j] + A[r][2] * V[2][j];
+        const float ca = AV[0][0] * A[0][0] + AV[0][1] * A[0][1] + AV[0][2] * A[0][2] + 0.3f;
+        const float cb = AV[0][0] * A[1][0] + AV[0][1] * A[1][1] + AV[0][2] * A[1][2];
+        const float cc = AV[1][0] * A[1][0] + AV[1][1] * A[1][1] + AV[1][2] * A[1][2] + 0.3f;
+        const float denom = ca * cc - cb * cb;
+        if (s.fast_blend) {   // the blend handed over sum(q dx), sum(q dy): the conic (the forward's: x * det_inv) turns them into the position gradient
+            const float det_inv = 1.f / denom;
+            const float kA = cc * det_inv, kB = -cb * det_inv, kC = ca * det_inv;
+            g2x = -0.5f * (float)s.W * (kA * q0.w + kB * q1.x);
+            g2y = -0.5f * (float)s.H * (kC * q1.x + kB * q0.w);
+            const float opac = a.grec[3 * (size_t)i + 1].y;   // the blend summed opacity * G * dL/dalpha
+            gop = opac > 0.f ? q2.x / opac : 0.f;
+        }
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        if (denom2inv != 0.f) {
+            dL_da = denom2inv * (-cc * cc * gA + 2.f * cb * cc * gB + (denom - ca * cc) * gC);
+            dL_dc = denom2inv * (-ca * ca * gC + 2.f * ca * cb * gB + (denom - ca * cc) * gA);
+            dL_db = denom2inv * 2.f * (cb * cc * gA - (denom + 2.f * cb * cb) * gB + ca * cb * gC);
+            gcov[0] = A[0][0] * A[0][0] * dL_da + A[0][0] * A[1][0] * dL_db + A[1][0] * A[1][0] * dL_dc;
+            gcov[3] = A[0][1] * A[0][1] * dL_da + A[0][1] * A[1][1] * dL_db + A[1][1] * A[1][1] * dL_dc;
+            gcov[5] = A[0][2] * A[0][2] * dL_da + A[0][2] * A[1][2] * dL_db + A[1][2] * A[1][2] * dL_dc;
+            gcov[1] = 2.f * A[0][0] * A[0][1] * dL_da + (A[0][0] * A[1][1] + A[0][1] * A[1][0]) * dL_db + 2.f * A[1][0] * A[1][1] * dL_dc;
+            gcov[2] = 2.f * A[0][0] * A[0][2] * dL_da + (A[0][0] * A[1][2] + A[0][2] * A[1][0]) * dL_db + 2.f * A[1][0] * A[1][2] * dL_dc;
+            gcov[4] = 2.f * A[0][2] * A[0][1] * dL_da + (A[0][1] * A[1][2] + A[0][2] * A[1][1]) * dL_db + 2.f * A[1][1] * A[1][2] * dL_dc;
+        }
+        float dA[2][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float a0v = A[0][0] * V[j][0] + A[0][1] * V[j][1] + A[0][2] * V[j][2];
+            const float a1v = A[1][0] * V[j][0] + A[1][1] * V[j][1] + A[1][2] * V[j][2];
+            dA[0][j] = 2.f * a0v * dL_da + a1v * dL_db;
+            dA[1][j] = 2.f * a1v * dL_dc + a0v * dL_db;
+        }
+        const float dJ00 = vm[0] * dA[0][0] + vm[4] * dA[0][1] + vm[8] * dA[0][2];
+        const float dJ02 = vm[2] * dA[0][0] + vm[6] * dA[0][1] + vm[10] * dA[0][2];
+        const float dJ11 = vm[1] * dA[1][0] + vm[5] * dA[1][1] + vm[9] * dA[1][2];
+        const float dJ12 = vm[2] * dA[1][0] + vm[6] * dA[1][1] + vm[10] * dA[1][2];
+        const float tz = 1.f / t2, tz2 = tz * tz, tz3 = tz2 * tz;
+        const float dtx = x_grad_mul * -fx * tz2 * dJ02;
+        const float dty = y_grad_mul * -fy * tz2 * dJ12;
+        const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * t0) * tz3 * dJ02 + (2.f * fy * t1) * tz3 * dJ12;
+        dmean[0] += vm[0] * dtx + vm[1] * dty + vm[2] * dtz;   // (+=: the SH block above has put the view direction's share there already)
+        dmean[1] += vm[4] * dtx + vm[5] * dty + vm[6] * dtz;
+        dmean[2] += vm[8] * dtx + vm[9] * dty + vm[10] * dtz;
+
+        // ---- projective divide: d(ndc.xy)/d(mean) --------------------------------------------
+        const float hw = proj[3] * mx + proj[7] * my + proj[11] * mz + proj[15];
+        const float m_w = 1.0f / (hw + 0.0000001f);
+        const float mul1 = (proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12]) * m_w * m_w;
+        const float mul2 = (proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13]) * m_w * m_w;
+        dmean[0] += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+        dmean[1] += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+        dmean[2] += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
 
         // ---- Sigma -> scale, raw quaternion --------------------------------------------------
         if (!a.use_precomp_cov) {
@@ -889,10 +890,10 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(Settings s, PreBwdArgs a
     if (sh_staged) {
         __syncthreads();
         if (a.shs_rest) {
-            sh_rows_store(sh_lds, a.dL_dsh, first, rows, 3, sh_stride, 0, (int)threadIdx.x);
-            sh_rows_store(sh_lds, a.dL_dsh_rest, first, rows, 3 * (M - 1), sh_stride, 3, (int)threadIdx.x);
+            sh_rows_store<GSR_PREBWD_ROWS>(sh_lds, a.dL_dsh, first, rows, 3, sh_stride, 0, (int)threadIdx.x);
+            sh_rows_store<GSR_PREBWD_ROWS>(sh_lds, a.dL_dsh_rest, first, rows, 3 * (M - 1), sh_stride, 3, (int)threadIdx.x);
         } else {
-            sh_rows_store(sh_lds, a.dL_dsh, first, rows, 3 * M, sh_stride, 0, (int)threadIdx.x);
+            sh_rows_store<GSR_PREBWD_ROWS>(sh_lds, a.dL_dsh, first, rows, 3 * M, sh_stride, 0, (int)threadIdx.x);
         }
     }
 }

@@ -377,10 +377,17 @@ __device__ __forceinline__ void for_each_tile(int minx, int miny, int maxx, int 
 // coalesced float4 stream to/from LDS and every thread works on its own LDS row.  Row stride (3M)|1 is odd,
 // so the per-thread dword accesses are bank-conflict free.
 #define GSR_SH_ROWS 256
+// k_preprocess_bwd: 208 splats per workgroup -- four workgroups' staged SH rows (208 x 49 floats each) fill the CU's 160 KB of LDS exactly: 16 waves
+// per CU instead of 12 (the kernel needs 90 VGPRs) and 212 992 splats resident at once instead of 196 608 (BASELINE configs[3], 200 k splats, was
+// 782 workgroups for 768 places).  Measured on one box, 256 -> 208: 29.5 -> 28.8 us at 100 k, 59.1 -> 48.6 us at 200 k; 192 and 128 are slower.
+#ifndef GSR_PREBWD_ROWS
+#define GSR_PREBWD_ROWS 208
+#endif
 #define GSR_SH_MAX_STRIDE 49
 __device__ __forceinline__ int sh_row_stride(int M) { return (3 * M) | 1; }
 
 // copies `rows` source rows of width w into LDS columns [col0, col0+w) of rows laid out with `stride`
+template <int NT = GSR_SH_ROWS>
 __device__ __forceinline__ void sh_rows_load(float* __restrict__ lds, const float* __restrict__ src, int first, int rows, int w, int stride,
                                              int col0, int tid)
 {
@@ -388,7 +395,7 @@ __device__ __forceinline__ void sh_rows_load(float* __restrict__ lds, const floa
     const float* base = src + (size_t)first * w;
     if ((total & 3) == 0 && ((((size_t)first * w) & 3) == 0)) {
         const float4* b4 = reinterpret_cast<const float4*>(base);
-        for (int f = tid * 4; f < total; f += GSR_SH_ROWS * 4) {
+        for (int f = tid * 4; f < total; f += NT * 4) {
             const float4 v = b4[f >> 2];
             int r = f / w, c = f - r * w;
             const float e[4] = {v.x, v.y, v.z, v.w};
@@ -399,13 +406,14 @@ __device__ __forceinline__ void sh_rows_load(float* __restrict__ lds, const floa
             }
         }
     } else {
-        for (int f = tid; f < total; f += GSR_SH_ROWS) {
+        for (int f = tid; f < total; f += NT) {
             const int r = f / w, c = f - r * w;
             lds[r * stride + col0 + c] = base[f];
         }
     }
 }
 
+template <int NT = GSR_SH_ROWS>
 __device__ __forceinline__ void sh_rows_store(const float* __restrict__ lds, float* __restrict__ dst, int first, int rows, int w, int stride,
                                               int col0, int tid)
 {
@@ -413,7 +421,7 @@ __device__ __forceinline__ void sh_rows_store(const float* __restrict__ lds, flo
     float* base = dst + (size_t)first * w;
     if ((total & 3) == 0 && ((((size_t)first * w) & 3) == 0)) {
         float4* b4 = reinterpret_cast<float4*>(base);
-        for (int f = tid * 4; f < total; f += GSR_SH_ROWS * 4) {
+        for (int f = tid * 4; f < total; f += NT * 4) {
             int r = f / w, c = f - r * w;
             float e[4];
 #pragma unroll
@@ -424,7 +432,7 @@ __device__ __forceinline__ void sh_rows_store(const float* __restrict__ lds, flo
             b4[f >> 2] = make_float4(e[0], e[1], e[2], e[3]);
         }
     } else {
-        for (int f = tid; f < total; f += GSR_SH_ROWS) {
+        for (int f = tid; f < total; f += NT) {
             const int r = f / w, c = f - r * w;
             base[f] = lds[r * stride + col0 + c];
         }
