@@ -116,3 +116,34 @@ def test_binding_csr_arrays_are_consistent():
         seg = order[int(face_begin[f]): int(face_begin[f + 1])].long()
         assert (binding[seg] == f).all() and (seg[1:] > seg[:-1]).all()            # grouped by face, stable inside a face
     assert int(face_begin[6]) == int(face_begin[5])
+
+
+def test_vertex_corner_table_lists_every_corner_once_by_vertex():
+    """The static table gab_mesh_backward_prepared gathers through (include/gab.h): one row (4 f + c, i0, i1, i2) per corner c of face
+    f = (i0, i1, i2), grouped by the corner's vertex (stable: a vertex's corners in face order), vf_begin its CSR offsets; pure torch,
+    cached on the faces tensor's identity and version."""
+    import torch
+
+    from gaussianavatars_amd import synthetic as S
+    from gaussianavatars_amd.binding import vertex_corner_csr
+
+    rig = S.flame_rig(4)
+    faces = torch.as_tensor(rig["faces"]).long()
+    V, F = rig["v_template"].shape[0], faces.shape[0]
+    vf_begin, vf_list = vertex_corner_csr(faces, V)
+    assert vf_begin.dtype == vf_list.dtype == torch.int32 and vf_begin.shape == (V + 1,) and vf_list.shape == (3 * F, 4)
+    assert int(vf_begin[0]) == 0 and int(vf_begin[-1]) == 3 * F
+    code = vf_list[:, 0].long()
+    f, c = code >> 2, code & 3
+    assert int(c.max()) <= 2
+    assert torch.equal(torch.sort(3 * f + c).values, torch.arange(3 * F))            # every corner exactly once
+    assert torch.equal(vf_list[:, 1:].long(), faces[f])                              # the row carries its face's three vertices
+    owner = faces[f, c]                                                              # the vertex the corner belongs to
+    assert (owner[1:] >= owner[:-1]).all()                                           # grouped by vertex ...
+    same = owner[1:] == owner[:-1]
+    assert ((3 * f + c)[1:][same] > (3 * f + c)[:-1][same]).all()                    # ... stable inside a vertex
+    counts = torch.bincount(faces.reshape(-1), minlength=V)
+    assert torch.equal((vf_begin[1:] - vf_begin[:-1]).long(), counts)
+    assert vertex_corner_csr(faces, V)[1] is vf_list                                 # cached
+    faces2 = faces.clone()
+    assert vertex_corner_csr(faces2, V)[1] is not vf_list                            # another tensor: another table
