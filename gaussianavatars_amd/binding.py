@@ -341,16 +341,15 @@ class _SubCtx:
         pass
 
 
-_VF_CACHE: list = []
-
-
 def vertex_corner_csr(faces: torch.Tensor, num_verts: int):
     """(vf_begin int32 (V+1,), vf_list int32 (3F, 4)) for gab_mesh_backward_prepared: one row (4 f + c, i0, i1, i2) per corner c of face
-    f = (i0, i1, i2), listed vertex by vertex (stable, so a vertex's corners come in face order).  Static per topology: cached on the
-    tensor's identity and version."""
-    for ent in _VF_CACHE:
-        if ent[0] is faces and ent[1] == faces._version and ent[2] == num_verts:
-            return ent[3]
+    f = (i0, i1, i2), listed vertex by vertex (stable, so a vertex's corners come in face order).  Static per topology: kept ON the faces
+    tensor (it lives exactly as long as the topology it describes -- a recorded step has the table's addresses baked in, so a shared cache
+    that evicts would pull memory from under a hipGraph: eight recorded lanes did exactly that to a four-entry cache) and rebuilt when
+    the tensor is modified in place."""
+    hit = getattr(faces, "_gaa_vertex_corners", None)
+    if hit is not None and hit[0] == faces._version and hit[1] == num_verts:
+        return hit[2]
     f = faces.detach().long()
     flat = f.reshape(-1)
     order = torch.sort(flat, stable=True).indices          # flat corner index 3 f + c, by vertex
@@ -358,9 +357,7 @@ def vertex_corner_csr(faces: torch.Tensor, num_verts: int):
     vf_list = torch.cat([(4 * fo + co)[:, None], f[fo]], 1).to(torch.int32).contiguous()
     vf_begin = torch.zeros(num_verts + 1, dtype=torch.int32, device=flat.device)
     vf_begin[1:] = torch.cumsum(torch.bincount(flat, minlength=num_verts), 0).to(torch.int32)
-    if len(_VF_CACHE) >= 4:
-        _VF_CACHE.pop(0)
-    _VF_CACHE.append((faces, faces._version, num_verts, (vf_begin, vf_list)))
+    faces._gaa_vertex_corners = (faces._version, num_verts, (vf_begin, vf_list))
     return vf_begin, vf_list
 
 

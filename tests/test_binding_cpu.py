@@ -121,7 +121,7 @@ def test_binding_csr_arrays_are_consistent():
 def test_vertex_corner_table_lists_every_corner_once_by_vertex():
     """The static table gab_mesh_backward_prepared gathers through (include/gab.h): one row (4 f + c, i0, i1, i2) per corner c of face
     f = (i0, i1, i2), grouped by the corner's vertex (stable: a vertex's corners in face order), vf_begin its CSR offsets; pure torch,
-    cached on the faces tensor's identity and version."""
+    kept on the faces tensor itself (no shared cache that could evict a table a recorded step still reads)."""
     import torch
 
     from gaussianavatars_amd import synthetic as S
@@ -145,5 +145,9 @@ def test_vertex_corner_table_lists_every_corner_once_by_vertex():
     counts = torch.bincount(faces.reshape(-1), minlength=V)
     assert torch.equal((vf_begin[1:] - vf_begin[:-1]).long(), counts)
     assert vertex_corner_csr(faces, V)[1] is vf_list                                 # cached
-    faces2 = faces.clone()
-    assert vertex_corner_csr(faces2, V)[1] is not vf_list                            # another tensor: another table
+    others = [faces.clone() for _ in range(9)]                                       # nine more topologies do not evict the first one's table
+    for o in others:
+        assert vertex_corner_csr(o, V)[1] is not vf_list
+    assert vertex_corner_csr(faces, V)[1] is vf_list
+    faces[0] = faces[0].flip(0)                                                      # modified in place: rebuilt
+    assert vertex_corner_csr(faces, V)[1] is not vf_list
