@@ -395,7 +395,7 @@ def main():
                     help="record the frame step once and replay it as one hipGraph launch per step (gaussianavatars_amd.graphs.GraphedStep)")
     ap.add_argument("--streams", type=int, default=1,
                     help="with --graph: this many recordings on this many streams, frames dealt to them in turn (frame parallelism inside one GPU)")
-    ap.add_argument("--frame-streams", type=int, default=0,
+    ap.add_argument("--frame-streams", type=int, default=4,
                     help="N=1, eager default run only: after the timed rounds, the same workload again as this many recorded frame "
                          "lanes (reported beside `value` as `frame_streams`); 0 skips the leg")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the process next to its GPU (host-sensitivity runs)")
@@ -619,10 +619,10 @@ def main():
 
         cmd = [sys.executable, os.path.abspath(__file__), "--graph", "--streams", str(args.frame_streams), "--frame-streams", "0",
                "--no-cpu-baseline", "--no-kernel-profile", "--workload", args.workload, "--steps", str(args.steps), "--warmup", str(args.warmup),
-               "--rounds", str(args.rounds), "--min-seconds", str(args.min_seconds), "--splats", str(args.splats), "--width", str(args.width),
+               "--rounds", str(args.rounds), "--min-seconds", str(min(args.min_seconds, 1.5)), "--splats", str(args.splats), "--width", str(args.width),
                "--height", str(args.height), "--frames", str(args.frames), "--binding", args.binding] + (["--no-pin"] if args.no_pin else [])
         try:
-            out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
             sub = json.loads(out.stdout.strip().splitlines()[-1])
             frame_streams = {"streams": args.frame_streams, "value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"],
                              "rounds": sub["rounds"]["n"],

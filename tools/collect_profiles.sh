@@ -10,24 +10,24 @@ B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-profile --fram
 cd $GRAFT_REPO_ROOT
 for W in cfg3 cfg4 cfg5; do
   if [ $W = cfg3 ]; then S="--steps 60 --warmup 15 --rounds 1 --min-seconds 0"; else S="--steps 30 --warmup 8 --rounds 1 --min-seconds 0"; fi
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${W}_stats -- $B --workload $W $S > $OUT/${W}_stats.log 2>&1
-  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${W}_fetch -- $B --workload $W $S > $OUT/${W}_fetch.log 2>&1
-  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${W}_write -- $B --workload $W $S > $OUT/${W}_write.log 2>&1
+  timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${W}_stats -- $B --workload $W $S > $OUT/${W}_stats.log 2>&1
+  timeout 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${W}_fetch -- $B --workload $W $S > $OUT/${W}_fetch.log 2>&1
+  timeout 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${W}_write -- $B --workload $W $S > $OUT/${W}_write.log 2>&1
   python tools/pmc_per_launch.py $OUT/${TAG}_${W}_pmc_fetch_write_per_launch.json $OUT/${W}_fetch $OUT/${W}_write
   cp $(ls $OUT/${W}_stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_${W}_kernel_stats.csv
   rm -rf $OUT/${W}_fetch $OUT/${W}_write   # raw per-dispatch tables are large; the summaries are what is kept
   python tools/trace_busy.py $OUT/${W}_stats > $OUT/${TAG}_${W}_busy.json
   rm -f $OUT/${W}_stats/*/*kernel_trace.csv
 done
-python bench.py --steps 150 --warmup 30 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3.json
-python bench.py --workload cfg2 --steps 300 --warmup 40 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg2.json
-python bench.py --workload cfg4 --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg4.json
-python bench.py --workload cfg5 --steps 40 --warmup 8 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg5.json
+timeout 200 python bench.py --steps 150 --warmup 30 --no-cpu-baseline --frame-streams 0 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3.json
+timeout 200 python bench.py --workload cfg2 --steps 300 --warmup 40 --no-cpu-baseline --frame-streams 0 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg2.json
+timeout 200 python bench.py --workload cfg4 --steps 100 --warmup 20 --no-cpu-baseline --frame-streams 0 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg4.json
+timeout 200 python bench.py --workload cfg5 --steps 40 --warmup 8 --no-cpu-baseline --frame-streams 0 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg5.json
 # the plain default line (cpu_baseline, frame_streams leg), the train workload, and the recorded step pinned / un-pinned beside the eager loop un-pinned
-python bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench_default.json
-python bench.py --workload train --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_train.json
+timeout 400 python bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench_default.json
+timeout 200 python bench.py --workload train --steps 100 --warmup 20 --no-cpu-baseline --frame-streams 0 2>/dev/null | tail -1 > $OUT/${TAG}_bench_train.json
 G="--steps 200 --warmup 30 --no-cpu-baseline --no-kernel-profile --frame-streams 0"
-python bench.py --graph $G 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3_graph.json
-python bench.py --graph --no-pin $G 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3_graph_unpinned.json
-python bench.py --no-pin $G 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3_eager_unpinned.json
+timeout 200 python bench.py --graph $G 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3_graph.json
+timeout 200 python bench.py --graph --no-pin $G 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3_graph_unpinned.json
+timeout 200 python bench.py --no-pin $G 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3_eager_unpinned.json
 ls -la $OUT

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/gtrace
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/gtrace -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-kernel-profile --min-seconds 0 --rounds 1 "$@" > /tmp/gtrace.log 2>&1 || tail -5 /tmp/gtrace.log
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/gtrace -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-kernel-profile --frame-streams 0 --min-seconds 0 --rounds 1 "$@" > /tmp/gtrace.log 2>&1 || tail -5 /tmp/gtrace.log
 python - <<'PY'
 import csv,glob
 f=glob.glob('/tmp/gtrace/**/*kernel_trace.csv', recursive=True)[0]
