@@ -391,7 +391,7 @@ class _MeshFramesTimestep(torch.autograd.Function):
         saved = c1.keep.get()
         tabs = list(saved[1:7])
         v_shaped, ws = saved[-2], saved[-1]
-        v, fi = c2.keep.get()
+        v, _ = c2.keep.get()
         dev = v.device
         V, T, t, widths = rig.V, c1.T, c1.t, c1.widths
         need = c1.needs_input_grad

@@ -1,7 +1,8 @@
 // gab_kernels.hip -- fused HIP kernels (gfx950, wave64) + C ABI (include/gab.h) for the FLAME-rigged
 // binding half of the GaussianAvatars hot path.  The reference executes this half as ~200 ATen
 // launches per frame; here it is 3 (FLAME) + 1 (face frames) + 1 (splats) launches forward and
-// 3 + 1 + 1 backward.  Every stage is HBM-/latency-bound (no GEMM-shaped work at batch 1 except
+// 3 + 1 + 1 backward; on the prepared rig (gab_flame_prepare) 1 + 1 forward and, for the mesh node, 2 backward
+// (k_gather_skin_bwd: face-frame gather + skinning; k_chain_blend_bwd), the splats riding in the rasterizer's own kernels.  Every stage is HBM-/latency-bound (no GEMM-shaped work at batch 1 except
 // the 24.7 MB blend-shape GEMV, which is a pure streaming read), so the kernels are plain
 // coalesced VALU code: one wave per blend-shape row, one thread per vertex / face / splat.
 //
