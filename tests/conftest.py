@@ -10,7 +10,18 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "timeout: per-test time limit (pytest-timeout)")
     config.addinivalue_line("markers", "fast_blend: runs the rasterizer in its default (fast blend) mode; every other test runs the exact blend")
+
+
+def pytest_collection_modifyitems(config, items):
+    """No test of this suite needs minutes: a kernel that never returns (an out-of-bounds write did that once: 25 GPU-minutes) must fail the
+    run, not hang it.  pytest-timeout is part of the image; without it the marker is inert."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600 if item.get_closest_marker("gpu") is None else 300, method="thread"))   # thread: a wait inside a native call never returns to the interpreter
 
 
 @pytest.fixture(autouse=True)
