@@ -44,13 +44,20 @@ class Pipe:
     convert_SHs_python = False
 
 
+SPATIAL_SORT = False   # --spatial-sort: the splats in Morton order of their positions (gaussianavatars_amd.io.spatial_sort), a loader-side layout choice
+
+
 def build_scene(device, n_splats, sh_degree, width, height, n_frames, binding_impl, requires_grad):
+    from gaussianavatars_amd import io as gio
     from gaussianavatars_amd import synthetic as S
     from gaussianavatars_amd.gaussian_model import FlameGaussianModel
 
     rig = S.flame_rig(seed=4)
     g = FlameGaussianModel(sh_degree, rig, binding_impl=binding_impl, device=device)
-    g.load_arrays(S.bound_splats(n_splats, S.FLAME_F, sh_degree, seed=2), device=device, requires_grad=requires_grad)
+    arrs = S.bound_splats(n_splats, S.FLAME_F, sh_degree, seed=2)
+    if SPATIAL_SORT:
+        arrs = gio.spatial_sort(arrs, rig["v_template"][rig["faces"]].mean(1))
+    g.load_arrays(arrs, device=device, requires_grad=requires_grad)
     g.load_flame_param(S.flame_sequence(n_frames, seed=4), device=device, requires_grad=requires_grad)
     cam = S.orbit_camera(width, height, r=1.0, fovy_deg=20.0)
     for k in ("world_view_transform", "full_proj_transform", "camera_center"):
@@ -69,6 +76,10 @@ def build_unbound_scene(device, n_splats, sh_degree, width, height):
     op = np.clip(sp["opacities"], 1e-6, 1 - 1e-6)
     arrs = dict(_xyz=sp["means3D"], _scaling=np.log(sp["scales"]), _rotation=sp["rotations"], _opacity=np.log(op / (1 - op)),
                 _features_dc=sp["shs"][:, :1], _features_rest=sp["shs"][:, 1:])
+    if SPATIAL_SORT:
+        from gaussianavatars_amd import io as gio
+
+        arrs = gio.spatial_sort(arrs)
     g = GaussianModel(sh_degree)
     g.load_arrays(arrs, device=device, requires_grad=False)
     cam = S.orbit_camera(width, height, r=1.0, fovy_deg=20.0)
@@ -388,6 +399,9 @@ def main():
                          "binding, the rasterizer stubbed at its autograd Function; the line is marked as such and is not a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--spatial-sort", action="store_true",
+                    help="load the synthetic splats in Morton order of their positions (io.spatial_sort): same image, gradients permuted with the splats; "
+                         "the layout a loader may choose freely, reported in config.splat_order")
     ap.add_argument("--graph-frames", type=int, default=4,
                     help="with --graph: frames per recording (the frame feed is a kernel inside it: gab_feed_row), so that the launch gap between two "
                          "graphs is paid once per K frames; steps that do not fill a recording use a one-frame recording")
@@ -400,6 +414,9 @@ def main():
                          "lanes (reported beside `value` as `frame_streams`); 0 skips the leg")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the process next to its GPU (host-sensitivity runs)")
     args = ap.parse_args()
+    if args.spatial_sort:
+        global SPATIAL_SORT
+        SPATIAL_SORT = True
     if args.workload == "cfg3" and args.mode == "render":
         args.workload = "cfg2"
     if args.workload == "train":   # not a BASELINE config: cfg3 plus the fused L1+SSIM loss and the densification statistics (N3)
@@ -620,7 +637,8 @@ def main():
         cmd = [sys.executable, os.path.abspath(__file__), "--graph", "--streams", str(args.frame_streams), "--frame-streams", "0",
                "--no-cpu-baseline", "--no-kernel-profile", "--workload", args.workload, "--steps", str(args.steps), "--warmup", str(args.warmup),
                "--rounds", str(args.rounds), "--min-seconds", str(min(args.min_seconds, 1.5)), "--splats", str(args.splats), "--width", str(args.width),
-               "--height", str(args.height), "--frames", str(args.frames), "--binding", args.binding] + (["--no-pin"] if args.no_pin else [])
+               "--height", str(args.height), "--frames", str(args.frames), "--binding", args.binding] + (["--no-pin"] if args.no_pin else []) + (
+                   ["--spatial-sort"] if args.spatial_sort else [])
         try:
             out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
             sub = json.loads(out.stdout.strip().splitlines()[-1])
@@ -745,6 +763,7 @@ def main():
                                       "target, backward, densification statistics; no optimiser step"}[
                                  args.workload] % (N, args.height, args.width),
                 "splats": N, "width": args.width, "height": args.height, "sh_degree": 3,
+                "splat_order": "morton (io.spatial_sort)" if SPATIAL_SORT else "as generated (random)",
                 "num_rendered": I_rect, "num_binned": I_binned, "tile_culling": bool(info.get("tile_culling", False)),
                 "binning_path": {0: "rank", 1: "depth-ordered scatter", 2: "per-tile sort"}[path] + (f" ({bands} bands of tile rows)" if path == 0 and bands > 1 else ""),
                 "visible_fraction": round(vis, 4), "binding": args.binding,

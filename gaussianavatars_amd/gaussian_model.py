@@ -66,11 +66,17 @@ class GaussianModel:
         self.xyz_gradient_accum = torch.zeros((self._xyz.shape[0], 1), device=device)
         self.denom = torch.zeros((self._xyz.shape[0], 1), device=device)
 
-    def load_ply(self, path, device="cuda", **kwargs):
-        """scene/gaussian_model.py:282-332: leaf tensors from the reference's PLY (binding -> int32)."""
+    def load_ply(self, path, device="cuda", spatial_sort: bool = False, face_centers=None, **kwargs):
+        """scene/gaussian_model.py:282-332: leaf tensors from the reference's PLY (binding -> int32).  `spatial_sort` (off by default: the
+        tensors then hold the file's rows in the file's order, as the reference's do): the splats in Morton order of their positions
+        (io.spatial_sort; a bound model passes the template's face centres) -- same images, per-splat tensors permuted, the binning pass of
+        large models ~1.6 x faster."""
         from . import io as gio
 
-        self.load_arrays(gio.load_ply(str(path), self.max_sh_degree), device=device)
+        arrs = gio.load_ply(str(path), self.max_sh_degree)
+        if spatial_sort:
+            arrs = gio.spatial_sort(arrs, face_centers)
+        self.load_arrays(arrs, device=device)
 
     def save_ply(self, path):
         """scene/gaussian_model.py:253-275"""

@@ -118,3 +118,38 @@ def load_flame_param(path: str) -> Dict[str, np.ndarray]:
     """flame_param.npz schema; only float32 arrays are taken, like the reference's motion loader (:239-258)."""
     z = np.load(path)
     return {k: z[k] for k in z.files if z[k].dtype == np.float32}
+
+
+# -------------------------------------------------------------------------------------------------
+# splat ORDER in memory (a loader-side layout choice: the rasterizer's outputs do not depend on it)
+# -------------------------------------------------------------------------------------------------
+def morton_order(points: np.ndarray, bits: int = 10) -> np.ndarray:
+    """Permutation that lists `points` (N,3) along a 3-D Morton (Z-order) curve of their bounding box, `bits` bits per axis.
+    Neighbours in memory are then neighbours in space -- and on screen, for every camera: a workgroup that takes a run of consecutive splats
+    touches a compact set of tiles, so the binning pass's scattered 8-byte entries of one tile are written close together in time (they
+    merge in L2 instead of leaving as one 32-byte sector each) and its LDS histograms see fewer distinct tiles."""
+    p = np.asarray(points, np.float64)
+    lo, hi = p.min(0), p.max(0)
+    q = np.clip(((p - lo) / np.maximum(hi - lo, 1e-30) * ((1 << bits) - 1)).astype(np.uint64), 0, (1 << bits) - 1)
+    code = np.zeros(len(p), np.uint64)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + a)
+    return np.argsort(code, kind="stable")
+
+
+def reorder_splats(arrs: Dict[str, np.ndarray], perm: np.ndarray) -> Dict[str, np.ndarray]:
+    """Every per-splat array of a leaf dict (reference names, `binding` included) permuted the same way."""
+    n = len(perm)
+    return {k: (np.ascontiguousarray(np.asarray(v)[perm]) if v is not None and hasattr(v, "shape") and len(v.shape) and v.shape[0] == n else v)
+            for k, v in arrs.items()}
+
+
+def spatial_sort(arrs: Dict[str, np.ndarray], face_centers: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
+    """The leaf dict with its splats in Morton order of their positions: `_xyz` for an unbound model; for a mesh-bound one (`binding` present)
+    the centre of the splat's face on the template mesh (`face_centers` (F,3)), the local offset breaking ties."""
+    if arrs.get("binding") is not None and face_centers is not None:
+        pos = np.asarray(face_centers, np.float64)[np.asarray(arrs["binding"]).astype(np.int64)] + 1e-3 * np.asarray(arrs["_xyz"], np.float64)
+    else:
+        pos = np.asarray(arrs["_xyz"], np.float64)
+    return reorder_splats(arrs, morton_order(pos))

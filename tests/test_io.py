@@ -46,3 +46,26 @@ def test_flame_param_npz_round_trip(tmp_path):
     for k in back:
         np.testing.assert_array_equal(back[k], seq[k])
     assert back["expr"].shape == (5, 100) and back["static_offset"].shape == (1, S.FLAME_V, 3)
+
+
+def test_morton_order_keeps_every_splat_whole_and_neighbours_close():
+    """io.spatial_sort (a loader-side layout choice): a permutation applied to every per-splat array alike -- a bound splat keeps its face --,
+    consecutive splats close in space (unbound: by position; bound: by the template centre of their face)."""
+    rng = np.random.default_rng(5)
+    sp = S.bound_splats(5000, 400, 2, seed=9)
+    sp["binding"] = sp["binding"] % 400
+    tag = np.arange(5000)
+    sp["tag"] = tag                                        # rides along like any per-splat array
+    centers = rng.normal(0, 1, (400, 3))
+    out = gio.spatial_sort(sp, centers)
+    perm = out["tag"]
+    assert sorted(perm.tolist()) == list(range(5000))
+    for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "binding"):
+        np.testing.assert_array_equal(out[k], np.asarray(sp[k])[perm])
+    where = centers[out["binding"]]
+    assert np.linalg.norm(np.diff(where, axis=0), axis=1).mean() < 0.2 * np.linalg.norm(np.diff(centers[sp["binding"]], axis=0), axis=1).mean()
+    un = dict(_xyz=rng.normal(0, 1, (20000, 3)).astype(np.float32), _opacity=rng.normal(0, 1, (20000, 1)).astype(np.float32))
+    o2 = gio.spatial_sort(un)
+    assert np.linalg.norm(np.diff(o2["_xyz"], axis=0), axis=1).mean() < 0.15 * np.linalg.norm(np.diff(un["_xyz"], axis=0), axis=1).mean()
+    np.testing.assert_array_equal(np.sort(o2["_opacity"], 0), np.sort(un["_opacity"], 0))
+    assert list(gio.morton_order(np.array([[0., 0, 0], [1, 1, 1], [0, 0, 1e-3], [1, 1, 0.999]]))) == [0, 2, 3, 1]
