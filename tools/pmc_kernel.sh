@@ -5,7 +5,7 @@ cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 i=0
 for C in "$@"; do
   i=$((i+1)); D=gpurun_out/pmck_$i; rm -rf $D
-  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python bench.py ${PMC_BENCH_ARGS:-} --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-profile --frame-streams 0 > $D.log 2>&1
+  timeout 150 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python bench.py ${PMC_BENCH_ARGS:-} --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-profile --frame-streams 0 > $D.log 2>&1
   python - "$D" "$K" <<'PY'
 import csv, glob, sys, collections
 d, k = sys.argv[1], sys.argv[2]
