@@ -204,13 +204,14 @@ class FlameGaussianModel(GaussianModel):
         self.flame_param = fp
         self.num_timesteps = fp["expr"].shape[0]
 
-    def load_ply(self, path, device="cuda", **kwargs):
-        """scene/flame_gaussian_model.py:229-237: the PLY plus the flame_param.npz stored next to it."""
+    def load_ply(self, path, device="cuda", spatial_sort: bool = False, **kwargs):
+        """scene/flame_gaussian_model.py:229-237: the PLY plus the flame_param.npz stored next to it.  `spatial_sort`: as GaussianModel.load_ply,
+        by the template centre of each splat's face."""
         import os
 
         from . import io as gio
 
-        super().load_ply(path, device=device)
+        super().load_ply(path, device=device, spatial_sort=spatial_sort, face_centers=template_face_centers(self) if spatial_sort else None)
         if not kwargs.get("has_target", False):
             self.load_flame_param(gio.load_flame_param(os.path.join(os.path.dirname(str(path)), "flame_param.npz")), device=device)
 
@@ -257,3 +258,47 @@ class FlameGaussianModel(GaussianModel):
 from .patch import patch_classes as _patch_classes  # noqa: E402
 
 _patch_classes(GaussianModel, FlameGaussianModel, FlameHead)
+
+
+def template_face_centers(model):
+    """(F,3) numpy: centres of the faces of the model's template mesh (flame_model.v_template / .faces), None for a model without a mesh."""
+    fm = getattr(model, "flame_model", None)
+    if fm is None or not hasattr(fm, "v_template") or not hasattr(fm, "faces"):
+        return None
+    v = fm.v_template.detach().cpu().numpy().reshape(-1, 3)
+    f = fm.faces.detach().cpu().numpy().astype(np.int64).reshape(-1, 3)
+    return v[f].mean(1)
+
+
+def spatial_resort(model) -> torch.Tensor:
+    """Puts the splats of a LIVE model -- this package's classes or the reference's own -- into Morton order of their positions
+    (io.spatial_sort) and returns the permutation.  Densification appends its new splats (scene/gaussian_model.py:426-515), so a model that
+    was loaded in order drifts out of it; this is the re-sort.  Everything that is indexed by splat moves together: the six leaf
+    parameters, with an optimiser attached their Adam moments too -- through the reference's own `_prune_optimizer` (:349-371), which indexes
+    parameters and moments with whatever it is given: a permutation instead of a keep-mask --, the densification statistics
+    (xyz_gradient_accum, denom, max_radii2D) and the binding.  Recorded steps (graphs.py) must be captured again afterwards."""
+    from . import io as gio
+
+    with torch.no_grad():
+        binding = getattr(model, "binding", None)
+        arrs = {"_xyz": model._xyz.detach().cpu().numpy(), "binding": None if binding is None else binding.detach().cpu().numpy()}
+        centers = template_face_centers(model) if binding is not None else None
+        pos = arrs["_xyz"] if centers is None else centers[arrs["binding"].astype(np.int64)] + 1e-3 * arrs["_xyz"]
+        perm = torch.as_tensor(gio.morton_order(pos), dtype=torch.long, device=model._xyz.device)
+        names = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling", "rotation": "_rotation"}
+        if getattr(model, "optimizer", None) is not None and hasattr(model, "_prune_optimizer"):
+            moved = model._prune_optimizer(perm)
+            for group, attr in names.items():
+                setattr(model, attr, moved[group])
+        else:
+            for attr in names.values():
+                p = getattr(model, attr)
+                setattr(model, attr, nn.Parameter(p.detach()[perm].contiguous().requires_grad_(p.requires_grad)))
+        n = perm.shape[0]
+        for aux in ("xyz_gradient_accum", "denom", "max_radii2D"):
+            t = getattr(model, aux, None)
+            if isinstance(t, torch.Tensor) and t.dim() >= 1 and t.shape[0] == n:
+                setattr(model, aux, t[perm])
+        if binding is not None:
+            model.binding = binding[perm]
+    return perm

@@ -119,6 +119,34 @@ def _train(rank, world, port, farm, ply, q):
                 sizes.append(int(g._xyz.shape[0]))
             g.optimizer.step()
             g.optimizer.zero_grad(set_to_none=True)
+    # ---- after all that appending and pruning: the splats back into Morton order (gaussian_model.spatial_resort), parameters, Adam moments,
+    # statistics and binding moving together; then one more iteration on the re-sorted model
+    from gaussianavatars_amd.gaussian_model import spatial_resort
+
+    def rows():
+        grp = {gr["name"]: gr["params"][0] for gr in g.optimizer.param_groups if len(gr["params"]) == 1}
+        st = g.optimizer.state
+        cols = [g._xyz, g._opacity, g._scaling, g._rotation, g._features_dc.flatten(1), g._features_rest.flatten(1), st[grp["xyz"]]["exp_avg"],
+                st[grp["opacity"]]["exp_avg_sq"], st[grp["f_rest"]]["exp_avg"].flatten(1), g.binding[:, None], g.max_radii2D[:, None], g.denom, g.xyz_gradient_accum]
+        return torch.cat([c.detach().double().reshape(c.shape[0], -1) for c in cols], 1)
+
+    before = rows()
+    perm = spatial_resort(g)
+    assert sorted(perm.tolist()) == list(range(before.shape[0])) and not torch.equal(perm, torch.arange(before.shape[0]))
+    assert torch.equal(before[perm], rows()), "a per-splat quantity did not move with its splat"
+    assert all(g.optimizer.state.get(gr["params"][0]) is not None for gr in g.optimizer.param_groups if gr["name"] in ("xyz", "opacity", "f_rest"))
+    assert g._xyz is [gr["params"][0] for gr in g.optimizer.param_groups if gr["name"] == "xyz"][0]     # the model holds the optimiser's parameter objects
+    from gaussianavatars_amd.gaussian_model import template_face_centers
+    where = torch.as_tensor(template_face_centers(g))[g.binding]
+    spread = lambda w: float((w[1:] - w[:-1]).norm(dim=1).mean())
+    assert spread(where) < 0.5 * spread(torch.as_tensor(template_face_centers(g))[g.binding[torch.argsort(perm)]])   # neighbours in memory sit on neighbouring faces now
+    g.select_mesh_by_timestep(rank)
+    pkg = render(cam, g, pipe, bg)
+    l1_loss(pkg["render"], gt).backward()
+    with torch.no_grad():
+        fp.allreduce_gradients([p for grp in g.optimizer.param_groups for p in grp["params"]], average=True, method="reduce_scatter")
+        g.optimizer.step()
+        g.optimizer.zero_grad(set_to_none=True)
     state = {k: _digest(getattr(g, k)) for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "binding",
                                                    "binding_counter", "max_radii2D", "xyz_gradient_accum", "denom")}
     state.update({"flame_" + k: _digest(v) for k, v in g.flame_param.items()})
