@@ -23,6 +23,7 @@ timeout 200 python bench.py --steps 150 --warmup 30 --no-cpu-baseline --frame-st
 timeout 200 python bench.py --workload cfg2 --steps 300 --warmup 40 --no-cpu-baseline --frame-streams 0 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg2.json
 timeout 200 python bench.py --workload cfg4 --steps 100 --warmup 20 --no-cpu-baseline --frame-streams 0 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg4.json
 timeout 200 python bench.py --workload cfg5 --steps 40 --warmup 8 --no-cpu-baseline --frame-streams 0 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg5.json
+timeout 200 python bench.py --workload cfg5 --steps 40 --warmup 8 --no-cpu-baseline --frame-streams 0 --spatial-sort 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg5_morton.json
 # the plain default line (cpu_baseline, frame_streams leg), the train workload, and the recorded step pinned / un-pinned beside the eager loop un-pinned
 timeout 400 python bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench_default.json
 timeout 200 python bench.py --workload train --steps 100 --warmup 20 --no-cpu-baseline --frame-streams 0 2>/dev/null | tail -1 > $OUT/${TAG}_bench_train.json
