@@ -269,6 +269,22 @@ def cpu_binding_baseline(n_splats, max_sh_degree, n_frames, train, frames=5):
                 what="composed-torch FLAME + face frames + per-splat bind on torch-CPU (" + ("fwd+bwd" if train else "fwd") + "), best thread count")
 
 
+def lane_schedule(my_frames, lane, n_lanes):
+    """The frames lane `lane` of `n_lanes` recorded lanes renders, in its own order: frame i of a run goes to lane i % n_lanes, so the lane's
+    m-th frame is the run's frame lane + n_lanes * m (cyclic over the rank's frames, like the eager loop's `my_frames[i % len]`)."""
+    return [my_frames[(lane + n_lanes * m) % len(my_frames)] for m in range(len(my_frames))]
+
+
+def lane_plan(n, offset, n_lanes, frames_per_graph):
+    """For a run of n steps that starts at the run-global frame index `offset`: per lane, the position in its schedule it starts from and the
+    sizes of the recordings it replays (K-frame recordings while K frames are left, one-frame recordings for the rest)."""
+    plan = []
+    for j in range(n_lanes):
+        count = len(range((j - offset) % n_lanes, n, n_lanes))
+        plan.append(((offset + n_lanes - 1 - j) // n_lanes, [frames_per_graph] * (count // frames_per_graph) + [1] * (count % frames_per_graph)))
+    return plan
+
+
 def make_runner(step_fn, my_frames, dist, device, post_step=None):
     """run(n, offset): n steps over this rank's frames (wrapping around); returns the sum of the per-step scalars as a device
     tensor.  The scalar all-reduce of step k is issued asynchronously (RCCL runs it on its own stream) and only waited for after
@@ -510,7 +526,7 @@ def main():
                 feeder = FlameRowFeeder(gm.flame_param, requires_grad=train)
                 gm.flame_param = feeder.static_param
                 # this lane's frames in the order the eager loop would hand them over: frame i of the run goes to lane i % n_lanes
-                feeder.set_schedule([my_frames[(lane + n_lanes * m) % len(my_frames)] for m in range(len(my_frames))])
+                feeder.set_schedule(lane_schedule(my_frames, lane, n_lanes))
             loss_sum = torch.zeros((), dtype=torch.float32, device=device)
 
             def fixed_step():   # the eager per-kernel event pass: one frame, fed by the caller
@@ -556,16 +572,14 @@ def main():
     def lane_runner(lanes):
         def run(n, offset):   # one rank: the recordings add their losses to a static accumulator, nothing else runs per step
             cur = torch.cuda.current_stream(device)
-            L = len(lanes)
-            for j, ln in enumerate(lanes):
+            plan = lane_plan(n, offset, len(lanes), lanes[0]["K"])   # frame i of the run belongs to lane (offset + i) % L
+            for ln, (start, _) in zip(lanes, plan):
                 ln["stream"].wait_stream(cur)
                 with torch.cuda.stream(ln["stream"]):
                     ln["loss_sum"].zero_()
                     if ln["feeder"] is not None:
-                        ln["feeder"].seek((offset + L - 1 - j) // L)   # frames offset .. of the run: lane j gets those with index = j (mod L)
-            # frame i of the run belongs to lane (offset + i) % L; every lane replays K-frame recordings while it has K frames left
-            per_lane = [len(range((j - offset) % L, n, L)) for j in range(L)]
-            todo = [[ln["K"]] * (c // ln["K"]) + [1] * (c % ln["K"]) for ln, c in zip(lanes, per_lane)]
+                        ln["feeder"].seek(start)
+            todo = [list(sizes) for _, sizes in plan]
             while any(todo):
                 for ln, td in zip(lanes, todo):
                     if td:

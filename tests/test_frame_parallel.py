@@ -164,3 +164,30 @@ def test_bench_gpus_flag_refuses_what_it_cannot_deliver():
     # a launcher whose world size contradicts the flag (the line would misreport n_gpus)
     r, lines = _bench("--gpus", "1", "--backend", "gloo", "--steps", "2", env_extra=dict(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and not lines and "must agree" in r.stderr
+
+
+def test_recorded_lanes_walk_the_eager_loops_frames():
+    """bench.py --graph --streams L --graph-frames K: the device-side schedules of the lanes (lane_schedule) and the per-run plan
+    (lane_plan: where each lane's cursor starts, which recordings it replays) together render exactly the frames the eager loop renders,
+    my_frames[(offset + i) % len] for i < n, each once, whatever n, offset, L and K are."""
+    import bench
+
+    for frames in (list(range(12)), [3, 7, 0, 11, 5], list(range(0, 300, 8))):
+        for L in (1, 2, 3, 4, 8):
+            scheds = [bench.lane_schedule(frames, j, L) for j in range(L)]
+            for K in (1, 4, 5):
+                offset = 0
+                for n in (5, 20, 7, 40, 1):                      # consecutive runs, as timed_rounds issues them (warm-up first)
+                    plan = bench.lane_plan(n, offset, L, K)
+                    got = {}
+                    for j, (start, sizes) in enumerate(plan):
+                        assert all(s in (1, K) for s in sizes)
+                        cur = start
+                        for _ in range(sum(sizes)):
+                            g = j + L * cur                          # the run-global index of the lane's cur-th frame
+                            assert g not in got
+                            got[g] = scheds[j][cur % len(scheds[j])]
+                            cur += 1
+                    want = {offset + i: frames[(offset + i) % len(frames)] for i in range(n)}
+                    assert got == want, (frames[:4], L, K, n, offset)
+                    offset += n
