@@ -193,7 +193,7 @@ def gsr():
 # ------------------------------------------------------------------------------------------------
 # libgab_hip.so : FLAME / face-frame / splat binding kernels (include/gab.h)
 # ------------------------------------------------------------------------------------------------
-GAB_LIB_PATH = os.path.join(_HERE, "libgab_hip.so")
+GAB_LIB_PATH = os.environ.get("GAB_LIB") or os.path.join(_HERE, "libgab_hip.so")   # (GAB_LIB: experiment builds, as GSR_LIB)
 GAB_FLAME_WS_FLOATS = 512
 GAB_BIND_ROW_FLOATS = 20   # include/gab.h: floats per splat of the two-pass CSR backward's scratch
 _P = C.c_void_p
