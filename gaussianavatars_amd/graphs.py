@@ -161,6 +161,7 @@ class FlameRowFeeder:
         self.T = int(tabs[0].shape[0])
         self.packed = torch.cat([t.reshape(self.T, -1).float() for t in tabs], dim=1).contiguous()
         self.row = self.packed[:1].clone()
+        self.schedule = self.cursor = None   # set_schedule(): the device-side order of the frames for feed_next()
         # (shape, static_offset and dynamic_offset pass through: FlameHead.forward accepts dynamic_offset and never reads it,
         #  flame_model/flame.py:498)
         self.static_param = {k: v for k, v in flame_param.items() if k not in self.ROWS}
@@ -186,6 +187,8 @@ class FlameRowFeeder:
 
     def seek(self, position: int) -> None:
         """Next feed_next() delivers schedule[position % len] (host call between replays; one fill kernel)."""
+        if getattr(self, "cursor", None) is None:
+            raise RuntimeError("FlameRowFeeder.seek(): call set_schedule(frames) first")
         self.cursor.fill_(int(position))
 
     def feed_next(self) -> None:
@@ -194,6 +197,8 @@ class FlameRowFeeder:
 
         from . import _lib
 
+        if getattr(self, "schedule", None) is None:
+            raise RuntimeError("FlameRowFeeder.feed_next(): call set_schedule(frames) first (the order of the frames lives on the device)")
         dev = self.packed.device
         with _lib.on_device(dev):
             rc = _lib.gab().gab_feed_row(C.c_void_p(self.packed.data_ptr()), self.T, int(self.packed.shape[1]), C.c_void_p(self.schedule.data_ptr()),
