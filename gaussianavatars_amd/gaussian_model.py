@@ -54,7 +54,10 @@ class GaussianModel:
         """arrs uses the reference's leaf names (_xyz, _features_dc, _features_rest, _scaling, _rotation,
         _opacity, optional binding).  Like load_ply (:323) this activates the full SH degree."""
         for k in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
-            t = torch.as_tensor(arrs[k], dtype=torch.float32, device=device).contiguous()
+            src = arrs[k]
+            if isinstance(src, np.ndarray) and not src.flags.writeable:   # (io.load_ply maps the file read-only: a host tensor must not alias it)
+                src = np.array(src)
+            t = torch.as_tensor(src, dtype=torch.float32, device=device).contiguous()
             setattr(self, k, nn.Parameter(t.requires_grad_(requires_grad)))
         if arrs.get("binding") is not None:
             self.binding = torch.as_tensor(arrs["binding"], device=device)

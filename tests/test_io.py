@@ -69,3 +69,42 @@ def test_morton_order_keeps_every_splat_whole_and_neighbours_close():
     assert np.linalg.norm(np.diff(o2["_xyz"], axis=0), axis=1).mean() < 0.15 * np.linalg.norm(np.diff(un["_xyz"], axis=0), axis=1).mean()
     np.testing.assert_array_equal(np.sort(o2["_opacity"], 0), np.sort(un["_opacity"], 0))
     assert list(gio.morton_order(np.array([[0., 0, 0], [1, 1, 1], [0, 0, 1e-3], [1, 1, 0.999]]))) == [0, 2, 3, 1]
+
+
+def test_load_ply_spatial_sort_on_both_model_classes(tmp_path):
+    """GaussianModel.load_ply(spatial_sort=True): the file's splats in Morton order of their positions, a bound model's by the template centre
+    of their faces; off by default (row i of the tensors = row i of the file)."""
+    import torch
+
+    from gaussianavatars_amd.gaussian_model import FlameGaussianModel, GaussianModel, template_face_centers
+
+    sp = S.bound_splats(S.FLAME_F + 500, S.FLAME_F, 1, seed=3)
+    seq = S.flame_sequence(3, seed=4)
+    d = tmp_path / "point_cloud" / "iteration_1"
+    p = str(d / "point_cloud.ply")
+    gio.save_ply(p, sp)
+    gio.save_flame_param(str(d / "flame_param.npz"), seq)
+    rig = S.flame_rig(seed=4)
+    plain = FlameGaussianModel(1, rig, binding_impl="unfused", device="cpu")
+    plain.load_ply(p, device="cpu")
+    np.testing.assert_array_equal(plain._xyz.detach().numpy(), sp["_xyz"])
+    srt = FlameGaussianModel(1, rig, binding_impl="unfused", device="cpu")
+    srt.load_ply(p, device="cpu", spatial_sort=True)
+    centers = template_face_centers(srt)
+    assert centers.shape == (S.FLAME_F, 3)
+    b0, b1 = plain.binding.long().numpy(), srt.binding.long().numpy()
+    assert sorted(b0.tolist()) == sorted(b1.tolist()) and not np.array_equal(b0, b1)
+    spread = lambda b: np.linalg.norm(np.diff(centers[b], axis=0), axis=1).mean()
+    assert spread(b1) < 0.3 * spread(b0)
+    # every splat still carries its own data: match rows through (binding, xyz)
+    key = lambda m: {(int(b), tuple(np.round(x, 6))) for b, x in zip(m.binding.tolist(), m._xyz.detach().numpy().tolist())}
+    assert key(plain) == key(srt)
+    assert int(srt.binding_counter.sum()) == len(b1) and torch.equal(srt.binding_counter, plain.binding_counter)
+    un = dict(sp)
+    un.pop("binding")
+    q = str(tmp_path / "u.ply")
+    gio.save_ply(q, un)
+    g = GaussianModel(1)
+    g.load_ply(q, device="cpu", spatial_sort=True)
+    x = g._xyz.detach().numpy()
+    assert np.linalg.norm(np.diff(x, axis=0), axis=1).mean() < 0.5 * np.linalg.norm(np.diff(sp["_xyz"], axis=0), axis=1).mean()
