@@ -377,6 +377,12 @@ class _MeshFramesTimestep(torch.autograd.Function):
         c1 = _SubCtx((False, False) + tuple(need[3:]))
         verts, v_shaped = _FlameForwardTimestep.forward(c1, head, t, shape, expr, rotation, neck, jaw, eyes, translation, static_offset)
         ctx.merged = c1.prepared is not None and _mesh_backward_mode() == "merged"
+        if ctx.merged and faces.device != verts.device:
+            raise RuntimeError(f"select_mesh_by_timestep: faces live on {faces.device}, the vertices on {verts.device}")
+        if ctx.merged and any(need):
+            # the static vertex -> corner table of the merged backward is built HERE (a dozen torch ops on first use, then cached on the
+            # faces tensor): inside the first backward it would be recorded into a stream capture of the step
+            ctx.corners = vertex_corner_csr(faces, int(verts.shape[1]))
         c2 = _SubCtx((any(need) and not ctx.merged, False))   # merged: no scatter target to pre-zero
         center, R, scale, quat = _FaceFrames.forward(c2, verts[0], faces)
         ctx.c1, ctx.c2 = c1, c2
@@ -401,7 +407,7 @@ class _MeshFramesTimestep(torch.autograd.Function):
         sizes = (C.c_int32 * len(tables))(*[T * w for w in widths])
         outp = [x.data_ptr() + 4 * t * w for x, w in zip(tables, widths)]
         rows = [x.data_ptr() + 4 * t * w for x, w in zip(tabs, widths)]
-        vf_begin, vf_list = vertex_corner_csr(ctx.faces, V)
+        vf_begin, vf_list = ctx.corners
         scratch = torch.empty(3 * V, **f32)
         gs = [None if g is None else _f32(g) for g in (g_center, g_R, g_scale, g_quat)]
         gv = None if g_verts is None else _f32(g_verts)

@@ -1361,12 +1361,13 @@ __global__ __launch_bounds__(256) void k_bind_bwd_faces(int F, const int* __rest
 __global__ __launch_bounds__(256) void k_feed_row(const float* __restrict__ packed, int T, int width, const int* __restrict__ schedule, int n_sched,
                                                    int* __restrict__ cursor, float* __restrict__ row)
 {
-    const int c = *cursor;
-    int t = schedule ? schedule[(unsigned)c % (unsigned)n_sched] : c;
+    const unsigned c = (unsigned)*cursor;   // kept inside [0, period): a cursor that only grew would overflow after 2^31 feeds
+    const unsigned period = schedule ? (unsigned)n_sched : (unsigned)T;
+    int t = schedule ? schedule[c % period] : (int)c;
     t = (int)((unsigned)t % (unsigned)T);
     for (int k = threadIdx.x; k < width; k += 256) row[k] = packed[(size_t)t * width + k];
     __syncthreads();
-    if (threadIdx.x == 0) *cursor = c + 1;
+    if (threadIdx.x == 0) *cursor = (int)((c + 1u) % period);
 }
 
 __global__ __launch_bounds__(256) void k_zero_many(ZeroSpec z)

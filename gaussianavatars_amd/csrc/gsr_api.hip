@@ -187,8 +187,9 @@ int gsr_count_slot_overflow(int32_t slot, int64_t* worst, int32_t reset)
     if (slot < 0 || slot >= GSR_COUNT_SLOTS) return fail(GSR_E_ARG, "gsr_count_slot_overflow: bad slot");
     if (int rc = g_mail.init()) return rc;
     unsigned long long* w = g_mail.host + Mailbox::kSlots + GSR_COUNT_SLOTS + slot;
-    if (worst) *worst = (int64_t)__atomic_load_n(w, __ATOMIC_ACQUIRE);
-    if (reset) __atomic_store_n(w, 0ull, __ATOMIC_RELEASE);
+    // read-and-clear is ONE exchange: a frame still in flight that marks the slot between a load and a store would lose its report
+    const unsigned long long v = reset ? __atomic_exchange_n(w, 0ull, __ATOMIC_ACQ_REL) : __atomic_load_n(w, __ATOMIC_ACQUIRE);
+    if (worst) *worst = (int64_t)v;
     return GSR_OK;
 }
 

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_
     if (*total_dev > capacity) return;
     {   // four of five workgroups of the grid own a segment no quadrant of their tile reaches: the forward left the tile's need behind
         const int seg_ = (int)blockIdx.x / tiles;
-        if (seg_ >= (int)seg_need[(int)blockIdx.x - seg_ * tiles]) return;
+        if ((uint32_t)seg_ >= min(seg_need[(int)blockIdx.x - seg_ * tiles], (uint32_t)GSR_BWD_SEGMENTS)) return;   // (unsigned, clamped: a stray word can only cost time)
     }
     __shared__ __attribute__((aligned(16))) float tab_all[4][32 * 12];   // per wave: the pixel table (below)
     __shared__ float xpose_all[4][64 * 9];                                // per wave: the nine sums of every lane on their way out

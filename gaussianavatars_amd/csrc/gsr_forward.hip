@@ -36,6 +36,8 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         // production binning: the depth-bucket histogram starts at zero (k_dbucket runs after this kernel); the header was
         // zeroed by the API before this launch and collects this kernel's statistics
         for (int t = i; t < a.nb; t += (int)(gridDim.x * blockDim.x)) a.bcount[t] = 0u;
+        // the per-tile backward depth (k_render<true> raises it with atomicMax): the image state is a fresh, uninitialised allocation per forward
+        for (int t = i; t < a.tiles; t += (int)(gridDim.x * blockDim.x)) a.seg_need[t] = 0u;
     } else {
         // this frame's tile histogram starts at zero (k_count runs after this kernel)
         for (int t = i; t < a.tiles; t += (int)(gridDim.x * blockDim.x)) { a.tile_count[t] = 0u; a.seg_need[t] = 0u; }

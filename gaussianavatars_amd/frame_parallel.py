@@ -75,6 +75,51 @@ def pin_to_gpu_numa_node(device_index: int = 0, cores: int = 8) -> Optional[List
         return None
 
 
+_PIN: dict = {"original": None, "pinned": None, "hooked": False}
+
+
+def _restore_affinity_in_child() -> None:
+    original = _PIN["original"]
+    if original:
+        try:
+            os.sched_setaffinity(0, original)
+        except OSError:
+            pass
+
+
+def pin_host_process(device_index: Optional[int] = None, cores: int = 8) -> Optional[List[int]]:
+    """What `patch_reference()` / `python -m gaussianavatars_amd.run` do for an unchanged entry script by default: the frame loop's two
+    threads (main + autograd) go next to their GPU (pin_to_gpu_numa_node), exactly the host conditions bench.py measures under
+    (un-pinned, the same loop ran 1 930 instead of 3 044 frames/s on a two-socket box: profiles/r03_l_bench_cfg3_eager_unpinned.json).
+    `GAA_PIN=0` opts out.  The device is LOCAL_RANK's when several are visible, else 0 (utils/general_utils.py:133 pins cuda:0; one
+    process per GPU selects its device with HIP_VISIBLE_DEVICES).  Forked children -- the reference's DataLoader workers, train.py:55
+    -- get the ORIGINAL mask back (os.register_at_fork), so eight of them do not pile onto the trainer's eight cores.  Idempotent;
+    returns the CPU list, or None when nothing was changed (opt-out, no GPU, unreadable topology)."""
+    if os.environ.get("GAA_PIN", "1") == "0":
+        return None
+    if _PIN["pinned"] is not None:
+        return _PIN["pinned"]
+    try:
+        if not torch.cuda.is_available():
+            return None
+        n = torch.cuda.device_count()
+        if device_index is None:
+            device_index = int(os.environ.get("LOCAL_RANK", "0"))
+            if not (0 <= device_index < n):
+                device_index = 0
+        original = set(os.sched_getaffinity(0))
+    except (OSError, ValueError, AttributeError, RuntimeError, AssertionError):
+        return None
+    mine = pin_to_gpu_numa_node(device_index, cores)
+    if mine is None:
+        return None
+    _PIN["original"], _PIN["pinned"] = original, list(mine)
+    if not _PIN["hooked"]:
+        os.register_at_fork(after_in_child=_restore_affinity_in_child)
+        _PIN["hooked"] = True
+    return _PIN["pinned"]
+
+
 def init_process_group(backend: Optional[str] = None):
     """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment (torchrun contract).
     backend: 'nccl' (= RCCL on ROCm) on GPUs, 'gloo' on CPU."""

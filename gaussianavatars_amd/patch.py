@@ -223,7 +223,7 @@ def unpatch_classes(*classes) -> None:
             delattr(cls, "get_features_split")
 
 
-def patch_reference(reference_root: str | None = None, fast_render: bool = True, stub_torchvision: bool = True) -> dict:
+def patch_reference(reference_root: str | None = None, fast_render: bool = True, stub_torchvision: bool = True, pin: bool = True) -> dict:
     """Makes a checkout of the reference run on MI355X without editing it.
 
     1. registers the import shims the reference's unconditional imports need (gaussianavatars_amd.shims) and puts this
@@ -232,7 +232,10 @@ def patch_reference(reference_root: str | None = None, fast_render: bool = True,
        per-frame methods (patch_classes);
     3. with fast_render, replaces `gaussian_renderer.render` by the mirror with the same signature and return dict
        (split-SH read in place, screen-space leaf without the zeros_like + 0 + retain_grad round trip).
-    Returns {'shims': [...], 'classes': [...], 'render': bool}.  Call it before the entry script imports `render`."""
+    4. with pin (default; GAA_PIN=0 opts out), moves the process next to its GPU (frame_parallel.pin_host_process: the host conditions
+       bench.py measures under -- the frame loop is host-paced; forked DataLoader workers keep the original CPU mask).
+    Returns {'shims': [...], 'classes': [...], 'render': bool, 'pinned_cpus': [...] | None}.  Call it before the entry script imports
+    `render`."""
     from . import shims
 
     repo_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -256,4 +259,9 @@ def patch_reference(reference_root: str | None = None, fast_render: bool = True,
             _ORIG[(gr, "render")] = gr.render
             gr.render = fast
         did_render = True
-    return dict(shims=served, classes=[gm.GaussianModel, fgm.FlameGaussianModel, flame.FlameHead], render=did_render)
+    pinned = None
+    if pin:
+        from .frame_parallel import pin_host_process
+
+        pinned = pin_host_process()
+    return dict(shims=served, classes=[gm.GaussianModel, fgm.FlameGaussianModel, flame.FlameHead], render=did_render, pinned_cpus=pinned)

@@ -22,7 +22,7 @@ from torch import nn
 from . import _lib
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_bound", "rasterize_leaves", "last_forward_info", "set_tile_culling", "deferred_count",
-           "get_tile_culling", "set_exact_scale_grad", "set_deterministic", "set_fast_blend"]
+           "get_tile_culling", "set_exact_scale_grad", "set_deterministic", "set_fast_blend", "set_poison_state"]
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -83,10 +83,26 @@ def set_deterministic(enabled: bool) -> bool:
 _fast_blend = int(os.environ.get("GSR_FAST_BLEND", "1"))
 
 
-def set_fast_blend(enabled: bool) -> bool:
-    """Process-wide switch; returns the previous value."""
+def set_fast_blend(enabled) -> int:
+    """Process-wide switch; returns the previous value.  True / False (1 / 0) select the fast / exact kernels; the raw integer 2 (the A/B
+    mode of include/gsr.h: fast forward with the pixel-parallel fast backward) is kept as it is, so a save / restore pair
+    `prev = set_fast_blend(x); ...; set_fast_blend(prev)` restores every mode."""
     global _fast_blend
-    prev, _fast_blend = bool(_fast_blend), int(bool(enabled))
+    prev, _fast_blend = _fast_blend, int(enabled)
+    return prev
+
+
+# ---- poisoned state buffers (debugging aid, GSR_POISON_STATE=1) --------------------------------------
+# The three state buffers of a forward are fresh torch.empty allocations: whatever a kernel reads from them, an earlier kernel of the
+# same frame has to have written.  With this switch on they are filled with 0xFF bytes first (NaN as floats, 2^32 - 1 as counters), so
+# a word that is read before it is written shows up in the tests instead of depending on what the caching allocator recycled.
+_poison_state = int(os.environ.get("GSR_POISON_STATE", "0"))
+
+
+def set_poison_state(enabled: bool) -> bool:
+    """Process-wide debugging switch; returns the previous value."""
+    global _poison_state
+    prev, _poison_state = bool(_poison_state), int(bool(enabled))
     return prev
 
 
@@ -305,6 +321,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         geom = torch.empty(gl.total, **u8)
         img = torch.empty(il.total, **u8)
+        if _poison_state:
+            geom.fill_(0xFF), img.fill_(0xFF)
 
         # the capacity counts what the binning path produces: tile instances on the per-tile sort path, quadrant-stream entries
         # on the production path (include/gsr.h: gsr_binning_layout) -- one running estimate per path
@@ -321,6 +339,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             while True:
                 bl = _binning_layout(lib, cap, W, H, P, int(s.tile_culling))
                 binning = torch.empty(bl.total, **u8)
+                if _poison_state:
+                    binning.fill_(0xFF)
                 rc = lib.gsr_forward_ex(C.byref(s), P, M, _ptr(means3D), _ptr(sh), _ptr(sh_rest), _ptr(colors_precomp), _ptr(opacities),
                                      _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(color), _ptr(radii),
                                      _ptr(geom), _ptr(binning), cap, _ptr(img), C.byref(n_host), stream)
@@ -449,6 +469,8 @@ class _RasterizeBound(torch.autograd.Function):
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         geom = torch.empty(gl.total, **u8)
         img = torch.empty(il.total, **u8)
+        if _poison_state:
+            geom.fill_(0xFF), img.fill_(0xFF)
         prod = _binning_layout(lib, 0, W, H, P, int(s.tile_culling)).path == 1
         key = (dev.index, H, W, prod)
         cap = _capacity_hint.get(key) or _round_cap((24 if prod else 8) * P)
@@ -462,6 +484,8 @@ class _RasterizeBound(torch.autograd.Function):
             while True:
                 bl = _binning_layout(lib, cap, W, H, P, int(s.tile_culling))
                 binning = torch.empty(bl.total, **u8)
+                if _poison_state:
+                    binning.fill_(0xFF)
                 rc = lib.gsr_forward_bound(C.byref(s), P, M, C.byref(b), _ptr(xyz), _ptr(sh_dc), _ptr(sh_rest), _ptr(opacity_logit),
                                            _ptr(log_scaling), _ptr(rotation), _ptr(color), _ptr(radii), _ptr(geom), _ptr(binning), cap,
                                            _ptr(img), C.byref(n_host), stream)

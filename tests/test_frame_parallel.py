@@ -125,6 +125,74 @@ def test_cpu_list_parsing_and_pinning_is_a_no_op_without_a_gpu():
         assert os.sched_getaffinity(0) == before
 
 
+def test_pin_host_process_is_a_no_op_without_a_gpu_and_children_get_the_original_mask(monkeypatch):
+    """patch_reference() / `python -m gaussianavatars_amd.run` pin by default (frame_parallel.pin_host_process).  Here (no GPU): nothing
+    changes.  The fork hook is exercised with a stand-in for the topology: the parent narrows itself to one CPU, a forked child (a
+    DataLoader worker of the reference's train.py:55) must see the original mask again."""
+    import os
+
+    from gaussianavatars_amd import frame_parallel as FP
+
+    before = os.sched_getaffinity(0)
+    if not torch.cuda.is_available():
+        assert FP.pin_host_process() is None and os.sched_getaffinity(0) == before
+    monkeypatch.setenv("GAA_PIN", "0")
+    assert FP.pin_host_process() is None and os.sched_getaffinity(0) == before     # the opt-out
+    monkeypatch.delenv("GAA_PIN")
+    one = sorted(before)[:1]
+
+    def fake_pin(device_index=0, cores=8):
+        os.sched_setaffinity(0, one)
+        return one
+
+    monkeypatch.setattr(FP, "pin_to_gpu_numa_node", fake_pin)
+    monkeypatch.setattr(FP.torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(FP.torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setitem(FP._PIN, "pinned", None)
+    try:
+        assert FP.pin_host_process() == one and os.sched_getaffinity(0) == set(one)
+        assert FP.pin_host_process() == one                                         # idempotent
+        r, w = os.pipe()
+        pid = os.fork()
+        if pid == 0:
+            os.write(w, repr(sorted(os.sched_getaffinity(0))).encode())
+            os._exit(0)
+        os.waitpid(pid, 0)
+        child = eval(os.read(r, 1 << 16).decode())
+        assert set(child) == set(before), "a forked worker keeps the trainer's narrowed CPU mask"
+    finally:
+        os.sched_setaffinity(0, before)
+        FP._PIN["pinned"] = FP._PIN["original"] = None
+
+
+@pytest.mark.gpu
+def test_pin_host_process_moves_the_process_next_to_the_gpu():
+    """On a GPU box the default of patch_reference() narrows the CPU mask to (at most) eight physical cores of the GPU's NUMA node."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, json; before = sorted(os.sched_getaffinity(0));\n"
+            "from gaussianavatars_amd.frame_parallel import pin_host_process, _gpu_numa_node, _cpulist\n"
+            "got = pin_host_process(); node = _gpu_numa_node(0)\n"
+            "cpus = _cpulist(open('/sys/devices/system/node/node%d/cpulist' % node).read()) if node >= 0 else []\n"
+            "print(json.dumps(dict(before=before, got=got, after=sorted(os.sched_getaffinity(0)), node=node, node_cpus=cpus)))")
+    env = {k: v for k, v in os.environ.items() if k != "GAA_PIN"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    if d["node"] < 0:
+        pytest.skip("the GPU reports no NUMA node on this host")
+    assert d["got"] is not None and d["after"] == sorted(d["got"]) and 1 <= len(d["got"]) <= 8
+    assert set(d["got"]) <= set(d["node_cpus"]) and set(d["got"]) <= set(d["before"])
+    r0 = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, cwd=root, env=dict(env, GAA_PIN="0"))
+    d0 = json.loads(r0.stdout.strip().splitlines()[-1])
+    assert d0["got"] is None and d0["after"] == d0["before"]
+
+
 def _bench(*argv, env_extra=None, timeout=300):
     import json
     import subprocess
