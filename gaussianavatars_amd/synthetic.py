@@ -308,3 +308,83 @@ def write_reference_assets(asset_dir: str, avatar_dir: str, template_obj: str, n
     seq["translation"] = (seq["translation"] * (ext / 0.24) - (v.min(0) + v.max(0)) / 2).astype(np.float32)
     gio.save_flame_param(out["flame_param"], seq)
     return out
+
+
+def silhouette_image(verts: np.ndarray, cam: SynthCamera, radius: int = 2) -> np.ndarray:
+    """(H, W, 4) uint8 RGBA: a flat pseudo-render of a vertex cloud (a disc per projected vertex, coloured smoothly by the vertex's
+    position, alpha 255 where covered) -- a target a training script can fit, produced without any rasterizer."""
+    H, W = cam.image_height, cam.image_width
+    full = cam.full_proj_transform.astype(np.float64)          # (P W2C)^T : row-vector convention
+    hom = np.concatenate([verts.astype(np.float64), np.ones((len(verts), 1))], 1) @ full
+    ndc = hom[:, :2] / hom[:, 3:4]
+    px = ((ndc[:, 0] + 1.0) * W - 1.0) * 0.5                    # ndc2Pix
+    py = ((ndc[:, 1] + 1.0) * H - 1.0) * 0.5
+    lo, hi = verts.min(0), verts.max(0)
+    col = 0.15 + 0.7 * (verts - lo) / np.maximum(hi - lo, 1e-9)
+    img = np.zeros((H, W, 4), np.uint8)
+    order = np.argsort(-hom[:, 3])                              # far first, near vertices overwrite
+    ix, iy = np.rint(px[order]).astype(np.int64), np.rint(py[order]).astype(np.int64)
+    c8 = np.rint(col[order] * 255).astype(np.uint8)
+    for dy in range(-radius, radius + 1):
+        for dx in range(-radius, radius + 1):
+            if dx * dx + dy * dy > radius * radius:
+                continue
+            x, y = ix + dx, iy + dy
+            ok = (x >= 0) & (x < W) & (y >= 0) & (y < H)
+            img[y[ok], x[ok], :3] = c8[ok]
+            img[y[ok], x[ok], 3] = 255
+    return img
+
+
+def write_reference_dataset(data_dir: str, template_obj: str, n_timesteps: int = 4, yaws=(-25.0, 0.0, 25.0), width: int = 112, height: int = 160,
+                            seed: int = 4) -> Dict[str, object]:
+    """A dataset an unchanged `train.py -s <data_dir> --bind_to_mesh` / `render.py` / `fps_benchmark_dataset.py` of the reference opens
+    (scene/__init__.py:80-88 picks the "DynamicNerf" reader on `canonical_flame_param.npz`; scene/dataset_readers.py:189-352):
+
+      data_dir/canonical_flame_param.npz                the marker file (the reference only tests that it exists)
+      data_dir/transforms_{train,val,test}.json         {"frames": [{file_path, transform_matrix (camera-to-world, OpenGL axes),
+                                                         camera_angle_x, w, h, timestep_index, camera_index, flame_param_path}]}
+      data_dir/flame_param/<t>.npz                      per-timestep FLAME parameters, one row each: shape (300,), expr (1,100),
+                                                         rotation / neck_pose / jaw_pose / translation (1,3), eyes_pose (1,6),
+                                                         static_offset (1,5023,3) (FlameGaussianModel.load_meshes pads it to the
+                                                         5143 vertices with teeth, scene/flame_gaussian_model.py:52-60)
+      data_dir/images/<t>_<cam>.png                     RGBA targets (CameraDataset.__getitem__ composes them over the background)
+
+    Cameras: the benchmark's orbit camera (fps_benchmark_demo.py:21-33) at the given yaw angles; the last yaw is the validation view of
+    every timestep, the last timestep the test split.  The targets are flat pseudo-renders of the posed-by-translation template
+    (silhouette_image): no rasterizer is needed to write them, and a training run has something to fit.
+    Returns {'timesteps', 'cameras', 'train', 'val', 'test' (frame counts), 'flame_sequence'}."""
+    import json
+    import os
+
+    v, _f = read_obj_topology(template_obj)
+    os.makedirs(os.path.join(data_dir, "flame_param"), exist_ok=True)
+    os.makedirs(os.path.join(data_dir, "images"), exist_ok=True)
+    seq = flame_sequence(n_timesteps, seed)
+    ext = float((v.max(0) - v.min(0)).max())
+    seq["translation"] = (seq["translation"] * (ext / 0.24) - (v.min(0) + v.max(0)) / 2).astype(np.float32)   # in front of the orbit camera (as write_reference_assets)
+    static_offset = seq["static_offset"][:, : len(v)]            # the template's vertices: the reference pads the teeth
+    np.savez(os.path.join(data_dir, "canonical_flame_param.npz"), shape=seq["shape"], static_offset=static_offset,
+             **{k: np.zeros_like(seq[k][:1]) for k in ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation")})
+    for t in range(n_timesteps):
+        np.savez(os.path.join(data_dir, "flame_param", f"{t:05d}.npz"), shape=seq["shape"], static_offset=static_offset,
+                 **{k: seq[k][t: t + 1] for k in ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation")})
+    splits: Dict[str, list] = dict(train=[], val=[], test=[])
+    for t in range(n_timesteps):
+        for ci, yaw in enumerate(yaws):
+            cam = orbit_camera(width, height, yaw_deg=float(yaw))
+            w2c = cam.world_view_transform.T.astype(np.float64)      # OpenCV axes
+            c2w = np.linalg.inv(w2c)
+            c2w[:3, 1:3] *= -1                                        # back to the OpenGL axes transforms_*.json stores (the reader flips them: dataset_readers.py:205)
+            name = f"images/{t:05d}_{ci:02d}"
+            from PIL import Image
+
+            Image.fromarray(silhouette_image(v + seq["translation"][t], cam), "RGBA").save(os.path.join(data_dir, name + ".png"))
+            frame = dict(file_path=name, transform_matrix=c2w.tolist(), camera_angle_x=float(cam.FoVx), w=int(width), h=int(height),
+                         timestep_index=int(t), camera_index=int(ci), flame_param_path=f"flame_param/{t:05d}.npz")
+            split = "test" if (t == n_timesteps - 1 and n_timesteps > 1) else ("val" if (ci == len(yaws) - 1 and len(yaws) > 1) else "train")
+            splits[split].append(frame)
+    for split, frames in splits.items():
+        with open(os.path.join(data_dir, f"transforms_{split}.json"), "w") as fh:
+            json.dump(dict(frames=frames), fh)
+    return dict(timesteps=n_timesteps, cameras=len(yaws), train=len(splits["train"]), val=len(splits["val"]), test=len(splits["test"]), flame_sequence=seq)

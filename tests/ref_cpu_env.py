@@ -61,7 +61,9 @@ def _no_cuda():
 
 
 class _OracleRasterize(torch.autograd.Function):
-    """Same ten arguments and three outputs as gaussianavatars_amd.rasterizer._RasterizeGaussians, computed by the CPU oracle."""
+    """Same ten arguments and three outputs as gaussianavatars_amd.rasterizer._RasterizeGaussians, computed by the CPU oracle -- forward
+    (oracle.forward) and, since round 4, backward (oracle.backward: what lets the reference's train.py run its loss.backward(), the
+    densification statistics and the optimiser step on this box)."""
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, sh_rest=None):
@@ -69,23 +71,38 @@ class _OracleRasterize(torch.autograd.Function):
 
         n = lambda t: None if t is None or t.numel() == 0 else t.detach().cpu().numpy()
         shs = sh
-        if sh_rest is not None and sh_rest.numel():
+        split = sh_rest is not None and sh_rest.numel() > 0
+        if split:
             shs = torch.cat([sh, sh_rest], 1)
         s = O.make_settings(rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy, n(rs.bg), rs.scale_modifier, n(rs.viewmatrix), n(rs.projmatrix),
                             rs.sh_degree, n(rs.campos))
         st = O.forward(s, n(means3D), n(shs), n(colors_precomp), n(opacities), n(scales), n(rotations), n(cov3Ds_precomp))
-        ctx.mark_non_differentiable
         radii = torch.from_numpy(st.radii.copy())
+        visible = radii > 0
+        ctx.mark_non_differentiable(radii, visible)
+        ctx.set_materialize_grads(False)
+        ctx.oracle = (O, s, st, split, int(sh.shape[1]) if sh.numel() else 0)
         _OracleRasterize.calls += 1
         _OracleRasterize.last = st
-        return torch.from_numpy(st.color.copy()), radii, radii > 0
+        return torch.from_numpy(st.color.copy()), radii, visible
 
     @staticmethod
-    def backward(ctx, *g):
-        raise RuntimeError("the CPU stand-in of the rasterizer is forward-only")
+    def backward(ctx, g_color, _g_radii=None, _g_visible=None):
+        if g_color is None:
+            return (None,) * 10
+        O, s, st, split, m_dc = ctx.oracle
+        g = O.backward(s, st, g_color.detach().cpu().contiguous().numpy())
+        t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
+        g_sh, g_rest = t(g["shs"]), None
+        if split and g_sh is not None:
+            g_sh, g_rest = g_sh[:, :m_dc].contiguous(), g_sh[:, m_dc:].contiguous()
+        _OracleRasterize.backwards += 1
+        return (t(g["means3D"]), t(g["means2D"]), g_sh, t(g["colors_precomp"]), t(g["opacities"]), t(g["scales"]), t(g["rotations"]),
+                t(g["cov3D_precomp"]), None, g_rest)
 
 
 _OracleRasterize.calls = 0
+_OracleRasterize.backwards = 0
 _OracleRasterize.last = None
 
 

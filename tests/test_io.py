@@ -108,3 +108,64 @@ def test_load_ply_spatial_sort_on_both_model_classes(tmp_path):
     g.load_ply(q, device="cpu", spatial_sort=True)
     x = g._xyz.detach().numpy()
     assert np.linalg.norm(np.diff(x, axis=0), axis=1).mean() < 0.5 * np.linalg.norm(np.diff(sp["_xyz"], axis=0), axis=1).mean()
+
+
+def test_reference_dataset_layout(tmp_path):
+    """synthetic.write_reference_dataset: the "DynamicNerf" layout the reference's reader walks (scene/dataset_readers.py:189-352), checked
+    here without the reference: split files, per-frame keys, per-timestep FLAME rows, RGBA targets with a covered silhouette, and the
+    camera-to-world matrices in OpenGL axes (the reader flips columns 1 and 2 and inverts)."""
+    import json
+    import os
+
+    from PIL import Image
+
+    from gaussianavatars_amd import synthetic as S
+
+    obj = tmp_path / "t.obj"
+    g = np.random.default_rng(0)
+    v = g.normal(0, 0.06, (200, 3)) + np.array([0.0, 1.5, 0.0])
+    obj.write_text("".join(f"v {a:.6f} {b:.6f} {c:.6f}\n" for a, b, c in v) + "f 1/1 2/2 3/3\n")
+    info = S.write_reference_dataset(str(tmp_path / "d"), str(obj), n_timesteps=3, yaws=(-20.0, 20.0), width=64, height=96)
+    d = tmp_path / "d"
+    assert (info["train"], info["val"], info["test"]) == (2, 2, 2) and (d / "canonical_flame_param.npz").exists()
+    seen = set()
+    for split in ("train", "val", "test"):
+        frames = json.loads((d / f"transforms_{split}.json").read_text())["frames"]
+        for fr in frames:
+            assert {"file_path", "transform_matrix", "camera_angle_x", "w", "h", "timestep_index", "camera_index", "flame_param_path"} <= set(fr)
+            img = np.asarray(Image.open(d / (fr["file_path"] + ".png")))
+            assert img.shape == (96, 64, 4) and 0.01 < (img[..., 3] == 255).mean() < 0.9
+            fp = np.load(d / fr["flame_param_path"])
+            assert fp["shape"].shape == (300,) and fp["expr"].shape == (1, 100) and fp["eyes_pose"].shape == (1, 6)
+            assert fp["static_offset"].shape == (1, 200, 3) and fp["translation"].shape == (1, 3)
+            c2w = np.array(fr["transform_matrix"])
+            c2w[:3, 1:3] *= -1                                  # what readCamerasFromTransforms does
+            w2c = np.linalg.inv(c2w)
+            cam = S.orbit_camera(64, 96, yaw_deg=(-20.0, 20.0)[fr["camera_index"]])
+            np.testing.assert_allclose(w2c.T, cam.world_view_transform, atol=1e-6)
+            seen.add((fr["timestep_index"], fr["camera_index"]))
+    assert len(seen) == 6
+
+
+def test_pillow_compat_serves_the_references_int8_images():
+    """scene/__init__.py:51 builds its targets with np.byte data and an explicit mode; shims.pillow_compat keeps that call working on a
+    Pillow that type-checks it, and leaves every other call alone."""
+    from PIL import Image
+
+    from gaussianavatars_amd import shims
+
+    raw = np.array([[[255, 128, 0], [1, 2, 3]]], np.uint8)
+    try:
+        Image.fromarray(raw.view(np.int8), "RGB")
+        needed = False
+    except TypeError:
+        needed = True
+    assert shims.pillow_compat() == needed
+    try:
+        got = np.asarray(Image.fromarray(raw.view(np.int8), "RGB"))
+        np.testing.assert_array_equal(got, raw)
+        np.testing.assert_array_equal(np.asarray(Image.fromarray(raw)), raw)
+        assert shims.pillow_compat() is False                   # idempotent
+    finally:
+        shims.uninstall()
+    assert not getattr(Image.fromarray, "__gaussianavatars_amd_shim__", False)

@@ -76,3 +76,100 @@ def test_fps_benchmark_demo_runs_unchanged(tmp_path):
     assert int(tail[1]) == 6                               # three rounds of two frames reached the rasterizer boundary
     assert int(tail[3]) > 5000 and float(tail[5]) > 0.05   # ... with a visible avatar: most of the 10144 bound splats, >5 % of the pixels covered
     assert "fused model methods on GaussianModel, FlameGaussianModel, FlameHead" in r.stderr
+
+
+def _run_entry(farm, body, timeout=900):
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {ROOT!r})
+        from tests import ref_cpu_env
+        stand_in = ref_cpu_env.install()
+        import torch
+        losses = []
+        _orig_backward = torch.Tensor.backward
+        def _observed_backward(self, *a, **k):      # observation only: the scalar every loss.backward() of the script starts from
+            if self.dim() == 0:
+                losses.append(float(self.detach()))
+            return _orig_backward(self, *a, **k)
+        torch.Tensor.backward = _observed_backward
+        from gaussianavatars_amd import run
+    """) + textwrap.dedent(body)
+    env = dict(os.environ, GAA_BINDING_IMPL="unfused", PYTHONPATH=ROOT, MPLBACKEND="Agg")
+    r = subprocess.run([sys.executable, "-c", code], cwd=farm, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r
+
+
+@needs_ref
+def test_train_render_and_fps_benchmark_dataset_run_unchanged(tmp_path):
+    """/root/reference/train.py:36-214 (Scene -> DataLoader -> select_mesh_by_timestep -> render -> L1 + SSIM + the xyz / scale regularisers
+    -> backward -> densification statistics -> densify_and_prune -> optimiser step -> save), then render.py:53-135 and
+    fps_benchmark_dataset.py:14-60 on the model it wrote -- all three through `python -m gaussianavatars_amd.run`, the scripts themselves
+    symlinks into the read-only checkout.  The dataset is generated in the reference's "DynamicNerf" layout
+    (gaussianavatars_amd.synthetic.write_reference_dataset; scene/dataset_readers.py:283-352).  Stand-ins, as for the demo above: "cuda" is
+    the host, the CPU oracle (forward AND backward) serves the rasterizer Function, the binding runs composed-torch."""
+    from gaussianavatars_amd import io as gio
+    from gaussianavatars_amd import synthetic as S
+
+    farm = str(tmp_path / "checkout")
+    os.makedirs(farm)
+    asset_dir = symlink_farm(farm)
+    template = os.path.join(REF, "flame_model", "assets", "flame", "head_template_mesh.obj")
+    S.write_reference_assets(asset_dir, str(tmp_path / "avatar"), template, n_frames=2)     # the two FLAME pickles FlameHead() opens
+    data, model = str(tmp_path / "data"), str(tmp_path / "model")
+    info = S.write_reference_dataset(data, template, n_timesteps=4)
+    assert (info["train"], info["val"], info["test"]) == (6, 3, 3)
+    for script in ("train.py", "render.py", "fps_benchmark_dataset.py"):
+        assert os.path.islink(os.path.join(farm, script))
+
+    # ---- train.py: 30 iterations, densify_and_prune at 15 / 20 / 25, the model saved at 30 (no evaluation pass: LPIPS needs downloaded weights)
+    r = _run_entry(farm, f"""
+        run.main(["train.py", "-s", {data!r}, "-m", {model!r}, "--bind_to_mesh", "--white_background", "--eval", "--iterations", "30",
+                  "--densify_from_iter", "10", "--densification_interval", "5", "--densify_until_iter", "26",
+                  "--test_iterations", "100000", "--save_iterations", "30", "--checkpoint_iterations", "100000", "--port", "60123"])
+        print("LOSSES", " ".join(f"{{x:.6f}}" for x in losses))
+        print("CALLS", stand_in.calls, "BACKWARDS", stand_in.backwards)
+    """)
+    out = r.stdout.splitlines()
+    assert any(ln.startswith("Training complete.") for ln in out)
+    losses = [float(x) for x in [ln for ln in out if ln.startswith("LOSSES")][0].split()[1:31]]
+    assert len(losses) == 30 and np.isfinite(losses).all()
+    assert np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), f"the loss does not go down: {losses}"
+    tail = [ln for ln in out if ln.startswith("CALLS")][0].split()
+    assert (int(tail[1]), int(tail[3])) == (30, 30)          # every iteration went forward and backward through the rasterizer boundary
+    ply = os.path.join(model, "point_cloud", "iteration_30", "point_cloud.ply")
+    trained = gio.load_ply(ply)
+    F = 10144
+    assert trained["_xyz"].shape[0] > F, "densify_and_prune added no splat"      # the reference's own densification ran on our gradients / statistics
+    assert trained["binding"].min() >= 0 and trained["binding"].max() < F
+    fp = np.load(os.path.join(model, "point_cloud", "iteration_30", "flame_param.npz"))
+    assert fp["expr"].shape == (4, 100) and fp["static_offset"].shape == (1, 5143, 3) and fp["dynamic_offset"].shape == (4, 5143, 3)
+    seq = info["flame_sequence"]
+    assert not np.array_equal(fp["expr"], seq["expr"]) and np.abs(fp["expr"] - seq["expr"]).max() < 0.1   # fine-tuned by the optimiser, a little
+    assert "host CPUs: unchanged" in r.stderr                # (no GPU here: the default pinning is a no-op)
+
+    # ---- render.py on what train.py wrote (val + test splits: 3 + 3 frames, PNGs of renders and targets)
+    r = _run_entry(farm, f"""
+        run.main(["render.py", "-m", {model!r}, "--skip_train"])
+        print("CALLS", stand_in.calls)
+    """)
+    assert int([ln for ln in r.stdout.splitlines() if ln.startswith("CALLS")][0].split()[1]) == 6
+    from PIL import Image
+
+    for split in ("val", "test"):
+        for i in range(3):
+            img = np.asarray(Image.open(os.path.join(model, split, "ours_30", "renders", f"{i:05d}.png")))
+            gt = np.asarray(Image.open(os.path.join(model, split, "ours_30", "gt", f"{i:05d}.png")))
+            assert img.shape == gt.shape == (160, 112, 3)
+            assert (img < 250).mean() > 0.05                 # an avatar on the white background, not an empty frame
+
+    # ---- fps_benchmark_dataset.py: three timed rounds on the first test view
+    r = _run_entry(farm, f"""
+        run.main(["fps_benchmark_dataset.py", "-m", {model!r}, "--skip_train", "--skip_val", "--n_iter", "2"])
+        print("CALLS", stand_in.calls)
+    """)
+    lines = r.stdout.splitlines()
+    assert [ln.split(" [")[0] for ln in lines if ln.startswith("Round ")] == ["Round 1", "Round 2", "Round 3"]
+    fps = [float(ln.split(":")[1].split(" [")[0]) for ln in lines if ln.startswith("FPS:")]
+    assert len(fps) == 3 and all(f > 0 for f in fps)
+    assert int([ln for ln in lines if ln.startswith("CALLS")][0].split()[1]) == 6
