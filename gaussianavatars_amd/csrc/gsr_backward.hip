@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
     if (walk > 320) __builtin_amdgcn_s_setprio(3);
     else if (walk > 192) __builtin_amdgcn_s_setprio(2);
     else if (walk > 96) __builtin_amdgcn_s_setprio(1);
-    struct Rec2 { f32x8 a[2]; float cbl[2]; int ex[2]; uint32_t id[2]; };   // a = (x, y, conic a, conic b, conic c, opacity, red, green)
+    struct Rec2 { f32x8 a[2]; float cbl[2]; int ex[2]; uint32_t id[2]; float op[2]; };   // a = (x, y, conic a, conic b, conic c, opacity, red, green)
     struct Pos2 { uint32_t p[2]; };
     // both streams through the CONSTANT address space with 32-bit byte offsets (as k_render): scalar loads, register-offset form
     typedef const __attribute__((address_space(4))) char* cbytes;
@@ -179,6 +179,8 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
                 R.cbl[u] = *(const __attribute__((address_space(4))) float*)(recb + off + 32);
                 R.ex[u] = 0;
             }
+            R.op[u] = R.a[u][5];
+            if (FAST) R.op[u] = *(const __attribute__((address_space(4))) float*)(recb + off + 40);   // fast-blend record: slot 5 holds log2(opacity), slot 10 the opacity
             R.id[u] = P.p[u];   // the stream entry IS the splat index
         }
     };
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
                 power = -0.5f * (R.a[u][2] * dxs[u] * dxs[u] + R.a[u][4] * dys[u] * dys[u]) - R.a[u][3] * dxs[u] * dys[u];
                 G[u] = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
             }
-            alpha[u] = sel_min(0.99f, R.a[u][5] * G[u]);
+            alpha[u] = sel_min(0.99f, R.op[u] * G[u]);
             hit[u] = (jp + u) < last && power <= 0.0f && alpha[u] >= 1.0f / 255.0f;
             id[uo + u] = R.id[u];
             ex[uo + u] = R.ex[u];
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(Settings s, const uint32_t* 
             const float cg = R.a[u][6] * g0 + R.a[u][7] * g1 + R.cbl[u] * g2;
             Sb = last_alpha * last_cg + last_one_m * Sb;
             const float dL_dalpha = (cg - Sb) * Tn + neg_Tf_bg * rinv;
-            const float q = Gh * (R.a[u][5] * dL_dalpha);     // G * dL/dG
+            const float q = Gh * (R.op[u] * dL_dalpha);       // G * dL/dG
             const float ax = q * dxs[u], ay = q * dys[u];
             float* vv = v[uo + u];
             vv[0] = w * g0;
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_
         const float4 r0 = grec[3 * (size_t)idx + 0], r1 = grec[3 * (size_t)idx + 1], r2 = grec[3 * (size_t)idx + 2];
         const float xq = r0.x - fqx0, yq = r0.y - fqy0;          // relative to the quadrant's first pixel
         const float cA = r0.z, cB = r0.w, cC = r1.x;             // the conic, pre-scaled into the 2^x domain (k_preprocess)
-        const float op = valid ? r1.y : 0.f;
+        const float op = valid ? r2.z : 0.f;                      // (fast-blend record: slot 5 holds log2(opacity) for the forward, slot 10 the opacity)
         const float cr = r1.z, cgn = r1.w, cb = r2.x;
         const int jrec = valid ? j : 0x7fffffff;                 // "last > jrec" is the pixel's range test
         const unsigned long long act = __ballot(last_pix > lo);  // pixels with something in this chunk
@@ -738,7 +740,7 @@ __global__ __launch_bounds__(GSR_PREBWD_ROWS) void k_preprocess_bwd(Settings s, 
             const float kA = cc * det_inv, kB = -cb * det_inv, kC = ca * det_inv;
             g2x = -0.5f * (float)s.W * (kA * q0.w + kB * q1.x);
             g2y = -0.5f * (float)s.H * (kC * q1.x + kB * q0.w);
-            const float opac = a.grec[3 * (size_t)i + 1].y;   // the blend summed opacity * G * dL/dalpha
+            const float opac = a.grec[3 * (size_t)i + 2].z;   // the blend summed opacity * G * dL/dalpha (fast-blend record: the opacity sits in slot 10)
             gop = opac > 0.f ? q2.x / opac : 0.f;
         }
         const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);

@@ -263,8 +263,21 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
     {
         // fast blend (include/gsr.h: GsrSettings.fast_blend): the blend kernels evaluate opacity * 2^(A' dx^2 + B' dx dy + C' dy^2)
         const float k2 = s.fast_blend ? -0.72134752044448170368f : 1.0f;   // -log2(e) / 2
-        const float4 rec[3] = {make_float4(px, py, con0 * k2, s.fast_blend ? con1 * (2.0f * k2) : con1), make_float4(con2 * k2, opac, col[0], col[1]),
-                               make_float4(col[2], __int_as_float(sum_exp), 0.f, 0.f)};
+        float4 rec[3] = {make_float4(px, py, con0 * k2, s.fast_blend ? con1 * (2.0f * k2) : con1), make_float4(con2 * k2, opac, col[0], col[1]),
+                         make_float4(col[2], __int_as_float(sum_exp), 0.f, 0.f)};
+        if (s.fast_blend) {
+            // fast blend (round 4): the opacity enters the exponent -- alpha = 2^(A' dx^2 + B' dx dy + C' dy^2 + log2 opacity), one
+            // instruction less per record and pixel than opacity * 2^(...) -- so slot 5 holds L = log2(opacity) (hardware v_log_f32),
+            // slot 9 the upper bound of the blend's acceptance test 1/255 <= alpha <= 2^L (1 + 2^-18): that bound IS the reference's
+            // `power <= 0` (alpha <= opacity <=> exponent <= 0), with a margin far below the stated tolerance, so that a pixel on the
+            // splat's centre can never fall out by an ulp of the hardware exponential; slot 10 keeps the opacity itself for the backward.
+            // An opacity that cannot reach 1/255 (or is not a number) gets L = NaN: its alpha is NaN and fails every comparison.
+            const bool can = opac >= 1.0f / 255.0f;
+            const float L = can ? __builtin_amdgcn_logf(opac) : __int_as_float(0x7fc00000);
+            rec[1].y = L;
+            rec[2].y = can ? __builtin_amdgcn_exp2f(L) * 1.000003814697265625f : 0.0f;
+            rec[2].z = opac;
+        }
         put_rows(a.grec, rec, std::integral_constant<int, 3>{});
     }
     if (!s.forward_only) {
@@ -830,7 +843,10 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     // A wave on the critical path retires one instruction per ~6.6 cycles whatever its kind (measured: tools/pmc_kernel.sh,
     // tools/bwd_timeline.py), so the loop is written for INSTRUCTION COUNT, scalar ones included: no per-record bounds
     // tests (full batches take an unmasked body), 32-bit record offsets, no exec-mask branches around the exponential.
-    constexpr int RB = 3;
+#ifndef GSR_EXP_RB
+#define GSR_EXP_RB 3
+#endif
+    constexpr int RB = GSR_EXP_RB;
 #ifndef GSR_FAST_TAIL_LANES
 #define GSR_FAST_TAIL_LANES 12
 #endif
@@ -839,7 +855,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     // 60 records with one wave scan (no serial loop), ~75 instructions per (pixel, chunk) against 60 x 42 for the walk, so it takes over
     // much earlier (model on the cfg3 frame, tools/remap_model.py: 31.7 M -> 26.3 M instructions at 8..16 open pixels).
     constexpr int TAIL_LANES = FAST ? GSR_FAST_TAIL_LANES : 4;
-    struct Rec4 { f32x8 a[RB]; float cbl[RB]; };   // a = (x, y, conic a, conic b, conic c, opacity, red, green)
+    struct Rec4 { f32x8 a[RB]; float cbl[RB]; float hi[RB]; };   // a = (x, y, conic a, conic b, conic c, opacity | fast: log2 opacity, red, green); blue; fast: alpha's upper bound
     struct Pos4 { uint32_t p[RB]; };
     // Two-level scalar fetch: stream entries (4-byte splat indices) two batches ahead, the records they name one batch ahead,
     // every record address the base pointer plus a 32-bit byte offset (s_load with a register offset: no 64-bit address
@@ -849,11 +865,23 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     typedef const __attribute__((address_space(4))) char* cbytes;
     const cbytes recb = (cbytes)(uintptr_t)rec;
     const cbytes qpb = (cbytes)(uintptr_t)qp;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     auto loadp = [&](int jb, Pos4& P, auto whole) {
+#ifndef GSR_EXP_NO_X4
+        if constexpr (decltype(whole)::value && RB <= 4) {
+            // steady state (jb + RB <= n): the batch's positions are ONE s_load_dwordx4 behind one address computation (scalar loads need
+            // dword alignment only); its fourth word -- at most the entry one past the stream, still inside the binning buffer -- is not used
+            const u32x4 v = *(const __attribute__((address_space(4))) u32x4*)(qpb + (uint32_t)jb * 4u);
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {   // past the end: re-read the last one, masked out in blend4<true>
-            const uint32_t j = decltype(whole)::value ? (uint32_t)(jb + u) : (uint32_t)min(jb + u, n - 1);
-            P.p[u] = *(const __attribute__((address_space(4))) uint32_t*)(qpb + j * 4u);
+            for (int u = 0; u < RB; ++u) P.p[u] = v[u];
+        } else
+#endif
+        {
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {   // past the end: re-read the last one, masked out in blend4<true>
+                const uint32_t j = (uint32_t)min(jb + u, n - 1);
+                P.p[u] = *(const __attribute__((address_space(4))) uint32_t*)(qpb + j * 4u);
+            }
         }
     };
     auto load4 = [&](const Pos4& P, Rec4& R) {
@@ -861,14 +889,26 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         for (int u = 0; u < RB; ++u) {
             const uint32_t off = P.p[u] * 48u;   // byte offset of the splat's record: < 4 GiB (89 M splats)
             R.a[u] = *(const __attribute__((address_space(4))) f32x8*)(recb + off);
-            R.cbl[u] = *(const __attribute__((address_space(4))) float*)(recb + off + 32);
+            if constexpr (FAST) {   // blue and the acceptance bound in one 8-byte load
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 bh = *(const __attribute__((address_space(4))) f32x2*)(recb + off + 32);
+                R.cbl[u] = bh[0];
+                R.hi[u] = bh[1];
+            } else {
+                R.cbl[u] = *(const __attribute__((address_space(4))) float*)(recb + off + 32);
+                R.hi[u] = 0.f;
+            }
         }
     };
     // Scalar loads return out of order, so the only wait is lgkmcnt(0); the empty asm pins that wait (first use of the current
     // batch, whose loads were issued a whole batch ago) ahead of the next issue, instead of letting it land after it and
     // stall on the fresh loads.
     auto arrived = [&](Rec4& R, Pos4& P) { asm volatile("" ::"s"(R.a[0]), "s"(P.p[0]) : "memory"); };
-    auto blend4 = [&](int jb, const Rec4& R, auto masked) {
+    // last_q is carried RELATIVE to the walk position (lq = last_q - j0 at the top of an iteration): a hit then stores a small constant,
+    // which v_cndmask takes inline -- an absolute index costs a scalar add and a v_mov per record on top of the select
+    int lq = 0;
+    auto blend4 = [&](int jb, const Rec4& R, auto masked, auto off) {
+        constexpr int OFF = decltype(off)::value;   // jb - (the iteration's j0)
         float alpha[RB];
         bool ok[RB];
 #pragma unroll
@@ -876,15 +916,22 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
             const float dx = R.a[u][0] - pixx;
             const float dy = R.a[u][1] - pixy;
             float power, a;
-            if constexpr (FAST) {   // the record holds the conic scaled by -log2(e)/2: power = log2 of the Gaussian, five instructions
-                power = __builtin_fmaf(__builtin_fmaf(R.a[u][3], dy, R.a[u][2] * dx), dx, (R.a[u][4] * dy) * dy);
-                a = __builtin_fminf(0.99f, R.a[u][5] * __builtin_amdgcn_exp2f(power));   // (one v_min_f32; a NaN power fails the test below either way)
+            if constexpr (FAST) {
+                // the record holds the conic scaled by -log2(e)/2 and L = log2(opacity): power = log2(opacity * G), five instructions, and
+                // alpha's raw value is the exponential itself.  Accepted iff 1/255 <= raw <= its upper bound (= opacity: `power <= 0`), as
+                // ONE median + ONE comparison (a NaN -- an opacity below 1/255 has L = NaN -- fails it)
+                power = __builtin_fmaf(__builtin_fmaf(R.a[u][3], dy, R.a[u][2] * dx), dx, __builtin_fmaf(R.a[u][4] * dy, dy, R.a[u][5]));
+                const float raw = __builtin_amdgcn_exp2f(power);
+                ok[u] = __builtin_amdgcn_fmed3f(raw, 1.0f / 255.0f, R.hi[u]) == raw;
+                a = __builtin_amdgcn_fmed3f(raw, 0.0f, 0.99f);   // = min(0.99, raw) for raw >= 0.  (fminf would first canonicalise the exponential's result, one more
+                                                                 // instruction; an inline-asm v_min hides the operand from the compiler's hazard recogniser, which has to
+                                                                 // put a wait state between a transcendental and the VALU instruction that reads its result: measured, T > 1)
             } else {
                 power = -0.5f * (R.a[u][2] * dx * dx + R.a[u][4] * dy * dy) - R.a[u][3] * dx * dy;
                 a = sel_min(0.99f, R.a[u][5] * gsr_expf_blend(power));
+                asm volatile("" : "+v"(a));   // evaluated for every lane: power > 0 is too rare to pay an exec-mask branch per record
+                ok[u] = power <= 0.0f && a >= 1.0f / 255.0f;
             }
-            asm volatile("" : "+v"(a));   // evaluated for every lane: power > 0 is too rare to pay an exec-mask branch per record
-            ok[u] = power <= 0.0f && a >= 1.0f / 255.0f;
             if (decltype(masked)::value) ok[u] = ok[u] && (jb + u) < n;
             alpha[u] = ok[u] ? a : 0.0f;
         }
@@ -905,17 +952,21 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
             }
             T = keep ? test_T : T;
             Tw = keep ? test_T : 0.0f;
-            last_q = (keep && ok[u]) ? (uint32_t)(jb + u + 1) : last_q;
+            lq = (keep && ok[u]) ? OFF + u + 1 : lq;
         }
     };
-    auto blend = [&](int jb, const Rec4& R) {
-        if (jb + RB <= n) blend4(jb, R, std::false_type{});
-        else blend4(jb, R, std::true_type{});
+    auto blend = [&](int jb, const Rec4& R, auto off) {
+        if (jb + RB <= n) blend4(jb, R, std::false_type{}, off);
+        else blend4(jb, R, std::true_type{}, off);
     };
+    using Off0 = std::integral_constant<int, 0>;
+    using Off1 = std::integral_constant<int, RB>;
     auto keep_going = [&](int jb) {
         const unsigned long long open_mask = __ballot(Tw > 0.0f);
-        if (__builtin_popcountll(open_mask) > TAIL_LANES) return true;
-        return open_mask != 0ull && n - jb <= 2 * GSR_WAVE;   // nothing open: stop; few open pixels and a long way to go: tail mode
+        int open;    // (through asm: the compiler widens popcountll's comparison to 64 bits and then does it on the VECTOR unit)
+        asm("s_bcnt1_i32_b64 %0, %1" : "=s"(open) : "s"(open_mask) : "scc");
+        if (open > TAIL_LANES) return true;
+        return open != 0 && n - jb <= 2 * GSR_WAVE;   // nothing open: stop; few open pixels and a long way to go: tail mode
     };
     // Software-pipelined walk: the scalar loads of batch k+1 are issued BEFORE batch k is blended, right after the wait for
     // batch k's own loads (issued a whole batch ago) -- placed the other way round the wait would stall on the fresh loads.
@@ -948,22 +999,41 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         // invariant at the top of both loops: A holds batch j0 (issued a batch ago), PB the positions of batch j0+RB (issued two
         // batches ago).  Steady state: four whole batches ahead, so nothing in the body needs a bounds test; the open-pixel
         // test runs once per two batches (a closed pixel ignores the extra records by construction).
+        // (round 4) the steady state really is a loop of its own again: while four whole batches lie ahead no position is clamped (one
+        // dwordx4 load per batch), no batch is masked and nothing tests j0 against n between the two halves
+        while (j0 + 4 * RB <= n && keep_going(j0)) {
+            checkpoint(j0);
+            arrived(A, PB);
+            load4(PB, B);
+            loadp(j0 + 2 * RB, PA, std::true_type{});
+            blend4(j0, A, std::false_type{}, Off0{});
+            j0 += RB;
+            arrived(B, PA);
+            load4(PA, A);
+            loadp(j0 + 2 * RB, PB, std::true_type{});
+            blend4(j0, B, std::false_type{}, Off1{});
+            j0 += RB;
+            lq -= 2 * RB;
+        }
         // the last batches of the stream: the same walk with every fetch and the last batch bounds-tested
         while (j0 < n && keep_going(j0)) {
             checkpoint(j0);
             arrived(A, PB);
             load4(PB, B);   // clamped positions are always valid: past the end these re-fetch the last record
             loadp(j0 + 2 * RB, PA, std::false_type{});
-            blend(j0, A);
+            blend(j0, A, Off0{});
             j0 += RB;
+            lq -= RB;
             if (j0 >= n) break;   // the open-pixel test runs once per two batches: closed pixels ignore the extra records by construction
             arrived(B, PA);
             load4(PA, A);
             loadp(j0 + 2 * RB, PB, std::false_type{});
-            blend(j0, B);
+            blend(j0, B, Off0{});
             j0 += RB;
+            lq -= RB;
         }
     }
+    last_q = (uint32_t)(lq + j0);   // (lq + j0 >= 0: a pixel without a hit kept lq = -j0)
 
     if (j0 < n) checkpoint(j0);   // the walk stopped exactly on a checkpoint entry (tail mode takes over from here)
 #ifdef GSR_EXPERIMENT_TIMELINE
@@ -1008,9 +1078,10 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
                     const float ppy = (float)(tile_y * GSR_BLOCK_Y + (wave >> 1) * 8 + (pp[e] >> 3));
                     Tp[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tw), pp[e]));   // open: Tw == T
                     const float dx = r0.x - ppx, dy = r0.y - ppy;
-                    const float power = __builtin_fmaf(__builtin_fmaf(r0.w, dy, r0.z * dx), dx, (r1.x * dy) * dy);
-                    const float a = __builtin_fminf(0.99f, r1.y * __builtin_amdgcn_exp2f(power));
-                    ok[e] = valid && power <= 0.0f && a >= 1.0f / 255.0f;
+                    const float power = __builtin_fmaf(__builtin_fmaf(r0.w, dy, r0.z * dx), dx, __builtin_fmaf(r1.x * dy, dy, r1.y));   // (the walk's expressions)
+                    const float raw = __builtin_amdgcn_exp2f(power);
+                    ok[e] = valid && __builtin_amdgcn_fmed3f(raw, 1.0f / 255.0f, r2.y) == raw;
+                    const float a = __builtin_amdgcn_fmed3f(raw, 0.0f, 0.99f);
                     am[e] = ok[e] ? a : 0.0f;
                     prod[e] = 1.0f - am[e];
                     okf[e] = am[e] * __builtin_amdgcn_rcpf(prod[e]);   // alpha / (1 - alpha)

@@ -68,13 +68,16 @@ def _forward_state(rs, means3D, shs, colors_precomp, opacities, scales, rotation
     lib.gsr_image_layout(W, H, C.byref(il))
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     f32, u32, i16 = torch.float32, torch.int32, torch.int16
+    rec = _view(geom, gl.grec, 12 * P, f32).view(P, 12)
+    fast = bool(ctx.fast_blend) and not ctx.deterministic and bl.path != 2   # gsr_api.hip: fast_effective
     out = dict(
         color=color, radii=radii, num_rendered=I, capacity=cap,
         rect_instances=int(_view(binning, 8, 1, torch.int64).item()),
         depths=_view(geom, gl.depths, P, f32),
         xy=_view(geom, gl.grec, 12 * P, f32).view(P, 12)[:, 0:2],
-        conic_opacity=_view(geom, gl.grec, 12 * P, f32).view(P, 12)[:, 2:6],
+        conic_opacity=rec[:, 2:6] if not fast else torch.cat([rec[:, 2:5], rec[:, 10:11]], 1),   # fast-blend record: slot 5 is log2(opacity), the opacity sits in slot 10
         rgb=_view(geom, gl.grec, 12 * P, f32).view(P, 12)[:, 6:9],
+        grec=rec,   # the raw 12-float records
         cov3D=_view(geom, gl.cov3D, 6 * P, f32).view(P, 6),
         rect=_view(geom, gl.rect, 4 * P, i16).view(P, 4),
         tiles_touched=_view(geom, gl.tiles_touched, P, u32),

@@ -17,6 +17,9 @@ a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4)[:7140].astype(np.int64)
 t0, t1, jm, hw = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
 live = t1 > 0
 t0, t1, jm, hw = t0[live], t1[live], jm[live], hw[live]
+if not live.any():      # fast blend (the default): the backward is k_render_bwd_rp, which carries no stamps
+    print("no stamps from k_render_bwd (fast blend runs k_render_bwd_rp); GSR_FAST_BLEND=0 for the pixel-parallel walk")
+    t0 = t1 = jm = hw = np.zeros(1, np.int64)
 base = t0.min()
 dur = (t1 - t0) / 100.0            # wall_clock64 ticks at 100 MHz -> us
 print("waves", len(t0), "kernel span %.1f us" % ((t1.max() - base) / 100.0), "latest start %.1f us" % ((t0.max() - base) / 100.0))
@@ -47,3 +50,15 @@ print("wave duration us: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f;  sum wal
 print("last finishers: (end us, dur us, stream n, walked pixel-parallel, tail us, us per walked record)")
 for w in np.argsort(-(t1 - base))[:10]:
     print("   %.1f %.1f %d %d %.1f %.3f" % ((t1[w] - base) / 100.0, dur[w], n[w], jmain[w], tail[w], (dur[w] - tail[w]) / max(jmain[w], 1)))
+# distribution of the pixel-parallel walk lengths and what a cap on the serial walk would leave
+for cap in (600, 400, 300, 240, 180, 120):
+    print("   walks longer than %d records: %d waves, %d records beyond the cap" % (cap, int((jmain > cap).sum()), int(np.maximum(jmain - cap, 0).sum())))
+print("   walk length percentiles 50/90/99/99.9/max:", *np.percentile(jmain, [50, 90, 99, 99.9, 100]).astype(int))
+busy = dur.sum()
+span = (t1.max() - base) / 100.0
+print("   sum of wave durations %.0f us = %.1f waves in flight on average over the %.1f us span (1024 SIMDs)" % (busy, busy / span, span))
+# time per walked record by how many records the wave walks: lone deep waves vs crowded shallow ones
+for lo, hi in ((0, 60), (60, 120), (120, 240), (240, 400), (400, 10000)):
+    s = (jmain > lo) & (jmain <= hi)
+    if s.any():
+        print("   walks of %d..%d records: %d waves, median %.3f us per record, median end %.1f us" % (lo, hi, int(s.sum()), np.median((dur[s] - tail[s]) / jmain[s]), np.median((t1[s] - base) / 100.0)))

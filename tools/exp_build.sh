@@ -6,7 +6,7 @@ NAME=$1; DEFS=$2
 cd "$(dirname "$0")/../gaussianavatars_amd/csrc"
 OUT=../../build/exp; mkdir -p $OUT
 C="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable -munsafe-fp-atomics $DEFS"
-/opt/rocm/bin/hipcc $C -ffp-contract=off -c gsr_forward.hip -o $OUT/fwd_$NAME.o &
+/opt/rocm/bin/hipcc $C -ffp-contract=off ${FWD_FLAGS--fno-slp-vectorize} -c gsr_forward.hip -o $OUT/fwd_$NAME.o &
 /opt/rocm/bin/hipcc $C -ffp-contract=fast -c gsr_backward.hip -o $OUT/bwd_$NAME.o &
 /opt/rocm/bin/hipcc $C -ffp-contract=off -c gsr_api.hip -o $OUT/api_$NAME.o &
 /opt/rocm/bin/hipcc $C -ffp-contract=off -c gsr_binning.hip -o $OUT/bin_$NAME.o &
