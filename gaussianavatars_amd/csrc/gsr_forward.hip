@@ -855,7 +855,11 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     // 60 records with one wave scan (no serial loop), ~75 instructions per (pixel, chunk) against 60 x 42 for the walk, so it takes over
     // much earlier (model on the cfg3 frame, tools/remap_model.py: 31.7 M -> 26.3 M instructions at 8..16 open pixels).
     constexpr int TAIL_LANES = FAST ? GSR_FAST_TAIL_LANES : 4;
+#ifdef GSR_EXP_SMEM_WALK
     struct Rec4 { f32x8 a[RB]; float cbl[RB]; float hi[RB]; };   // a = (x, y, conic a, conic b, conic c, opacity | fast: log2 opacity, red, green); blue; fast: alpha's upper bound
+#else
+    struct Rec4 { float a[RB][8]; float cbl[RB]; float hi[RB]; };   // the same fields in vector registers (read from the wave's LDS stage)
+#endif
     struct Pos4 { uint32_t p[RB]; };
     // Two-level scalar fetch: stream entries (4-byte splat indices) two batches ahead, the records they name one batch ahead,
     // every record address the base pointer plus a 32-bit byte offset (s_load with a register offset: no 64-bit address
@@ -865,6 +869,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     typedef const __attribute__((address_space(4))) char* cbytes;
     const cbytes recb = (cbytes)(uintptr_t)rec;
     const cbytes qpb = (cbytes)(uintptr_t)qp;
+#ifdef GSR_EXP_SMEM_WALK
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     auto loadp = [&](int jb, Pos4& P, auto whole) {
 #ifndef GSR_EXP_NO_X4
@@ -904,6 +909,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     // batch, whose loads were issued a whole batch ago) ahead of the next issue, instead of letting it land after it and
     // stall on the fresh loads.
     auto arrived = [&](Rec4& R, Pos4& P) { asm volatile("" ::"s"(R.a[0]), "s"(P.p[0]) : "memory"); };
+#endif
     // last_q is carried RELATIVE to the walk position (lq = last_q - j0 at the top of an iteration): a hit then stores a small constant,
     // which v_cndmask takes inline -- an absolute index costs a scalar add and a v_mov per record on top of the select
     int lq = 0;
@@ -989,6 +995,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         }
     };
     int j0 = 0;
+#ifdef GSR_EXP_SMEM_WALK
     if (n > 0) {
         Rec4 A, B;
         Pos4 PA, PB;
@@ -1033,6 +1040,138 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
             lq -= RB;
         }
     }
+#else
+    // ---- the walk, records staged through LDS (round 4) ------------------------------------------------------------------------
+    // Through the scalar unit (above, kept for A/B builds) a batch's records can only be requested ONE batch ahead -- scalar loads
+    // return out of order, so the only wait is lgkmcnt(0), which also waits for whatever was issued last -- and a request takes ~300 ns
+    // (K-cache miss -> L2): the deepest quadrant's walk, which IS the kernel's duration, ran at 107 ns per record whether a record cost 40
+    // instructions or 32 (measured: RB = 2 -> 85 us, RB = 3 -> 72 us).  Here the wave gathers a whole CHUNK of 60 records with
+    // vector loads (lane l: entry 60 c + l, three 16-byte loads), one chunk ahead of the walk, parks them in its own 2 x 2880 bytes of
+    // LDS and walks them with broadcast ds_read_b128: LDS returns in order (the compiler counts lgkmcnt exactly, a batch ahead costs
+    // nothing), takes ~50 ns instead of ~300, and the record's fields arrive in VECTOR registers -- a VALU instruction with a scalar
+    // operand issues at half rate on gfx950 (tools/valu_peak.hip), so the per-record arithmetic gets cheaper for the crowded SIMDs too.
+    // Chunks are the backward's segments: the checkpoint test sits at the chunk boundary.
+    constexpr int CH = GSR_BWD_SEGMENT;
+    static_assert(CH <= GSR_WAVE && CH % (2 * RB) == 0, "a chunk is one gather of the wave and a whole number of double batches");
+    __shared__ float4 stage_all[4][2][CH * 3 + 3];   // (+3: the walk's read-ahead of a chunk's last double batch ends one batch past the chunk -- harmless, never used, but it has to be inside the allocation)
+    float4(*const stage)[CH * 3 + 3] = stage_all[wave];
+    if (n > 0) {
+        float4 g0, g1, g2;   // the chunk in flight: this lane's record
+        auto gather = [&](int c) {   // entries past the end re-read the last one (never walked); lanes CH.. load too (never parked)
+            const size_t idx = (size_t)qp[min(c * CH + lane, n - 1)];
+            g0 = rec[3 * idx + 0];
+            g1 = rec[3 * idx + 1];
+            g2 = rec[3 * idx + 2];
+        };
+        auto park = [&](int c) {
+            if (lane < CH) {
+                float4* d = &stage[c & 1][3 * lane];
+                d[0] = g0; d[1] = g1; d[2] = g2;
+            }
+        };
+        // A batch's records come out of LDS with ds_read_b128 / ds_read_b64 at a wave-uniform address (broadcast), issued from inline
+        // assembly: the reads have to be ISSUED a batch ahead of their use, behind the blend that frees their registers, and left to the
+        // compiler they all end up at the top of the loop body (the fetched batch copied aside, the LDS waited for with nothing to do;
+        // volatile loads turn into flat loads).  LDS returns in order, so `ready` waits with the exact count of reads issued since.
+        // Rules that keep this sound: every `issue` is followed by a `ready` on the same registers before they die (the compiler
+        // believes they were written at the issue), and nothing else of this wave is in flight on lgkmcnt inside the loop (no scalar
+        // loads, no compiler-made LDS access: the parks sit between chunks, behind a full wait).
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        struct RecV { v4f q0[RB], q1[RB]; v2f q2[RB]; };
+        static_assert(RB == 3, "the issue / ready assembly below is written for three records per batch");
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)&stage[0][0], lds1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)&stage[1][0];
+        // `addr`: the LDS byte address of the walk's current double batch (a vector register that only ever gets a constant added);
+        // `off`: 0, 144 or 288 bytes ahead of it as an immediate -- no address arithmetic per batch
+        // (a macro: captured variables inside the operand list of an asm in a GENERIC lambda do not compile with this clang)
+#define GSR_ISSUE(ADDR, O, V)                                                                                                                        \
+        asm volatile("ds_read_b128 %0, %15 offset:%16\n\tds_read_b128 %1, %15 offset:%16+16\n\tds_read_b64 %2, %15 offset:%16+32\n\t"                \
+                     "ds_read_b128 %3, %15 offset:%16+48\n\tds_read_b128 %4, %15 offset:%16+64\n\tds_read_b64 %5, %15 offset:%16+80\n\t"             \
+                     "ds_read_b128 %6, %15 offset:%16+96\n\tds_read_b128 %7, %15 offset:%16+112\n\tds_read_b64 %8, %15 offset:%16+128"                \
+                     : "=&v"(V.q0[0]), "=&v"(V.q1[0]), "=&v"(V.q2[0]), "=&v"(V.q0[1]), "=&v"(V.q1[1]), "=&v"(V.q2[1]), "=&v"(V.q0[2]),              \
+                       "=&v"(V.q1[2]), "=&v"(V.q2[2]), /* the blend state as pass-through operands: the reads are issued BEHIND everything the */    \
+                       /* previous blend computes (its instructions are free to move otherwise, and below this statement they need the old */       \
+                       /* batch copied aside) */                                                                                                    \
+                       "+v"(T), "+v"(Tw), "+v"(C0), "+v"(C1), "+v"(C2), "+v"(lq)                                                                    \
+                     : "v"(ADDR), "n"(O))
+        // the batch is in its registers once at most `behind` reads issued after it are still in flight (9 = one batch)
+        auto ready = [&](RecV& V, auto behind, Rec4& R) {
+            if constexpr (decltype(behind)::value == 9)
+                asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(V.q0[0]), "+v"(V.q1[0]), "+v"(V.q2[0]), "+v"(V.q0[1]), "+v"(V.q1[1]), "+v"(V.q2[1]),
+                             "+v"(V.q0[2]), "+v"(V.q1[2]), "+v"(V.q2[2]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V.q0[0]), "+v"(V.q1[0]), "+v"(V.q2[0]), "+v"(V.q0[1]), "+v"(V.q1[1]), "+v"(V.q2[1]),
+                             "+v"(V.q0[2]), "+v"(V.q1[2]), "+v"(V.q2[2]));
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                R.a[u][0] = V.q0[u].x; R.a[u][1] = V.q0[u].y; R.a[u][2] = V.q0[u].z; R.a[u][3] = V.q0[u].w;
+                R.a[u][4] = V.q1[u].x; R.a[u][5] = V.q1[u].y; R.a[u][6] = V.q1[u].z; R.a[u][7] = V.q1[u].w;
+                R.cbl[u] = V.q2[u].x; R.hi[u] = V.q2[u].y;
+            }
+        };
+        using Behind9 = std::integral_constant<int, 9>;
+        using Behind0 = std::integral_constant<int, 0>;
+        gather(0);
+        park(0);
+        if (n > CH) gather(1);
+        bool go = true;
+        for (int c = 0;; ++c) {
+            const int b = c & 1;
+            const int m = min(CH, n - c * CH);   // records of this chunk
+            checkpoint(j0);                      // j0 == c * CH: the state before the chunk's first entry
+            RecV VA, VB;
+            Rec4 A, B;
+            uint32_t addr = b ? lds1 : lds0;
+            GSR_ISSUE(addr, 0, VA);
+            int k = 0;
+            // whole double batches: nothing masked.  The test at the BOTTOM of the loop (one block, the state in place: with the test at the
+            // top the compiler copied the six state registers in and out of the body) is the cheap half of keep_going -- more than
+            // TAIL_LANES pixels open --; what to do when it fails (stop, tail mode, or walk on because the stream is nearly over) is
+            // decided outside, and the rare "walk on" continues in the second loop with the full test.
+            auto many_open = [&]() {
+                int open;
+                asm("s_bcnt1_i32_b64 %0, %1" : "=s"(open) : "s"(__ballot(Tw > 0.0f)) : "scc");
+                return open > TAIL_LANES;
+            };
+            auto double_batch = [&]() {
+                GSR_ISSUE(addr, 48 * RB, VB);
+                ready(VA, Behind9{}, A);
+                blend4(j0, A, std::false_type{}, Off0{});
+                GSR_ISSUE(addr, 96 * RB, VA);   // the next double batch's (or the remainder's) first batch; at a chunk's end: one batch past it, unused
+                ready(VB, Behind9{}, B);
+                blend4(j0 + RB, B, std::false_type{}, Off1{});
+                addr += 96 * RB;
+                j0 += 2 * RB;
+                lq -= 2 * RB;
+                k += 2 * RB;
+            };
+            if (2 * RB <= m && many_open()) {
+                do double_batch(); while (k + 2 * RB <= m && many_open());
+            }
+            while (k + 2 * RB <= m && (go = keep_going(j0))) double_batch();   // (few pixels open, the stream nearly over)
+            ready(VA, Behind0{}, A);   // (always: the reads issued last land in registers the compiler considers written)
+            if (go && k < m) {   // the stream ends inside this chunk: one or two bounds-tested batches (A holds the first)
+                if (keep_going(j0)) {
+                    blend4(j0, A, std::true_type{}, Off0{});
+                    j0 += RB;
+                    lq -= RB;
+                    if (j0 < n) {
+                        GSR_ISSUE(addr, 48 * RB, VB);
+                        ready(VB, Behind0{}, B);
+                        blend4(j0, B, std::true_type{}, Off0{});
+                        j0 += RB;
+                        lq -= RB;
+                    }
+                } else {
+                    go = false;
+                }
+            }
+            if (!go || j0 >= n) break;
+            park(c + 1);
+            if ((c + 2) * CH < n) gather(c + 2);
+        }
+    }
+#endif
     last_q = (uint32_t)(lq + j0);   // (lq + j0 >= 0: a pixel without a hit kept lq = -j0)
 
     if (j0 < n) checkpoint(j0);   // the walk stopped exactly on a checkpoint entry (tail mode takes over from here)
