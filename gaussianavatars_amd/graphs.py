@@ -192,7 +192,7 @@ class FlameRowFeeder:
         self.cursor.fill_(int(position))
 
     def feed_next(self) -> None:
-        """row <- packed[schedule[cursor]]; cursor += 1 -- one kernel on the current stream (include/gab.h: gab_feed_row), capturable."""
+        """row <- packed[schedule[cursor]]; cursor = (cursor + 1) mod len(schedule) -- one kernel on the current stream (include/gab.h: gab_feed_row), capturable."""
         import ctypes as C
 
         from . import _lib

@@ -168,8 +168,8 @@ int gab_zero_buffers(int32_t count, float* const* buffers_host, const int32_t* s
 /* The frame feed of a RECORDED step (one hipGraph per K frames; scene/flame_gaussian_model.py:117-135 addresses row `timestep` of the
  * flame_param tables with a host integer, which a recording would freeze): copies row schedule[*cursor % n_sched] (schedule NULL: row
  * *cursor) modulo T of `packed` (T x width floats: the per-timestep tables side by side) into `row` (width floats, the static one-row
- * tables the recorded kernels read) and advances the DEVICE cursor by one.  A kernel like any other: capturable, replays walk the
- * schedule on their own. */
+ * tables the recorded kernels read) and advances the DEVICE cursor by one, modulo the schedule's length (T without a schedule): the
+ * cursor stays in [0, length) however long the run.  A kernel like any other: capturable, replays walk the schedule on their own. */
 int gab_feed_row(const float* packed, int32_t T, int32_t width, const int32_t* schedule, int32_t n_sched, int32_t* cursor, float* row,
                  void* stream);
 
