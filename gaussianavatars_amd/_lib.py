@@ -52,7 +52,7 @@ _ONE_DEVICE = None   # a process that sees one GPU never switches devices
 GSR_LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr_hip.so")
 
 GSR_OK = 0
-GSR_ABI_VERSION = 9
+GSR_ABI_VERSION = 10
 GSR_E_CAPACITY = 1
 GSR_COUNT_SLOTS = 128   # include/gsr.h: persistent instance-count slots of the deferred forwards
 
@@ -100,7 +100,7 @@ class GsrBound(C.Structure):
 
 
 class GsrImageLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("final_T", "n_contrib", "n_contrib_q", "c_final", "ck", "gmax", "seg_need", "total")]
+    _fields_ = [(n, C.c_size_t) for n in ("final_T", "n_contrib", "n_contrib_q", "c_final", "ck", "gmax", "units", "total")]
 
 
 #: every symbol include/gsr.h declares -> (restype, argtypes)

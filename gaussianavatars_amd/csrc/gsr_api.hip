@@ -316,7 +316,8 @@ int gsr_image_layout(int32_t width, int32_t height, GsrImageLayout* o)
     o->ck = off;        off = align_up(off + hw * 16 * (GSR_BWD_SEGMENTS - 1), A);
     o->gmax = off;      off = align_up(off + 4, A);
     const size_t tiles = (size_t)((width + GSR_BLOCK_X - 1) / GSR_BLOCK_X) * (size_t)((height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y);
-    o->seg_need = off;  off = align_up(off + tiles * 4, A);
+    const size_t unit_cap = (4 * tiles + GSR_UNIT_LISTS - 1) / GSR_UNIT_LISTS * (size_t)GSR_BWD_SEGMENTS;
+    o->units = off;     off = align_up(off + ((size_t)32 * GSR_UNIT_LISTS + (size_t)GSR_UNIT_LISTS * unit_cap) * 4, A);
     o->total = off + A;
     return 0;
 }
@@ -398,7 +399,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     } else if (P == 0) {   // otherwise k_preprocess zeroes both
         HIP_TRY(hipMemsetAsync(tile_count, 0, (size_t)tiles * 4, stream));
         HIP_TRY(hipMemsetAsync(rect_total, 0, 8, stream));
-        HIP_TRY(hipMemsetAsync(im + il.seg_need, 0, (size_t)tiles * 4, stream));
+        HIP_TRY(hipMemsetAsync(im + il.units, 0, (size_t)32 * GSR_UNIT_LISTS * 4, stream));
     }
 
     gsr::PreprocessArgs pa;
@@ -416,7 +417,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     pa.acc = (float4*)(g + gl.acc);
     pa.acc64 = (float4*)(g + gl.acc64);
     pa.tile_count = tile_count;
-    pa.seg_need = (uint32_t*)(im + il.seg_need);
+    pa.units = (uint32_t*)(im + il.units);
     pa.rect_total = rect_total;
     pa.tiles = tiles;
     pa.brec = prod ? (float4*)(g + gl.brec) : nullptr;
@@ -655,7 +656,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         hipLaunchKernelGGL(ds.fast_blend ? gsr::k_render<true> : gsr::k_render<false>, dim3(tiles), dim3(256), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
                            (const uint32_t*)qcount, (const float4*)pa.grec, (const uint32_t*)qpos, write_lists ? (const uint32_t*)qlist : nullptr, (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib),
                            (uint32_t*)(im + il.n_contrib_q), (float*)(im + il.c_final), (float4*)(im + il.ck), out_color, cap,
-                           (const unsigned long long*)total_dev, (uint32_t*)(im + il.seg_need));
+                           (const unsigned long long*)total_dev, (uint32_t*)(im + il.units));
         KERNEL_CHECK("k_render", stream, dbg);
     }
 
@@ -769,14 +770,18 @@ static int backward_impl(const GsrSettings* settings, int32_t P, int32_t M, cons
     if (num_rendered > 0) {
         TIMED(GSR_K_RENDER_BWD, stream);
         if (ds.fast_blend && settings->fast_blend != 2) {   // fast blend: the record-parallel kernel (fast_blend == 2 keeps the pixel-parallel walk: A/B runs)
-#ifndef GSR_EXP_RP_SEGS
-#define GSR_EXP_RP_SEGS GSR_BWD_SEGMENTS
+            // a fixed grid: every wave takes the units of its list in turn (gsr.h: GsrImageLayout.units), so the size only sets how many
+            // share the work -- about one unit per wave at 100 k splats and 802 x 550, never more workgroups than the old one per (tile, segment)
+#ifndef GSR_EXP_RP_GRID
+#define GSR_EXP_RP_GRID 3072
 #endif
-            hipLaunchKernelGGL(gsr::k_render_bwd_rp, dim3(gx * gy * GSR_EXP_RP_SEGS), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order),
+            int rp_grid = gx * gy * GSR_BWD_SEGMENTS;
+            rp_grid = rp_grid < GSR_EXP_RP_GRID ? (rp_grid + 15) / 16 * 16 : GSR_EXP_RP_GRID;   // a multiple of GSR_UNIT_LISTS / 4 workgroups: every list sees the same stride
+            hipLaunchKernelGGL(gsr::k_render_bwd_rp, dim3(rp_grid), dim3(256), 0, stream, ds,
                                (const uint32_t*)(b + bl.qstart), (const uint32_t*)(b + bl.qcount), (const float4*)(g + gl.grec), (const uint32_t*)(b + bl.qpos),
                                (const float*)(im + il.final_T), (const uint32_t*)(im + il.n_contrib_q), dL_dpix, grad_scratch,
                                (const float*)(im + il.c_final), (const float4*)(im + il.ck), gx * gy,
-                               (unsigned long long)binning_capacity, (const unsigned long long*)b, (const uint32_t*)(im + il.seg_need));
+                               (unsigned long long)binning_capacity, (const unsigned long long*)b, (const uint32_t*)(im + il.units));
         } else {
         auto* const render_bwd = det ? &gsr::k_render_bwd<true, false> : (ds.fast_blend ? &gsr::k_render_bwd<false, true> : &gsr::k_render_bwd<false, false>);
         hipLaunchKernelGGL(render_bwd, dim3(gx * gy * GSR_BWD_SEGMENTS), dim3(256), 0, stream, ds, (const uint32_t*)(b + bl.tile_order),

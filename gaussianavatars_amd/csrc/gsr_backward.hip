@@ -381,33 +381,40 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifdef GSR_EXP_RP_WAVES
 __attribute__((amdgpu_waves_per_eu(GSR_EXP_RP_WAVES, GSR_EXP_RP_WAVES)))
 #endif
-__global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ qstart,
+__global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_t* __restrict__ qstart,
                                                         const uint32_t* __restrict__ qcount, const float4* __restrict__ grec,
                                                         const uint32_t* __restrict__ qpos, const float* __restrict__ final_T,
                                                         const uint32_t* __restrict__ n_contrib_q, const float* __restrict__ dL_dpix,
                                                         float* __restrict__ acc /* [P][GSR_ACC_STRIDE] */, const float* __restrict__ c_final,
                                                         const float4* __restrict__ ck, int tiles, unsigned long long capacity,
-                                                        const unsigned long long* __restrict__ total_dev, const uint32_t* __restrict__ seg_need)
+                                                        const unsigned long long* __restrict__ total_dev, const uint32_t* __restrict__ units)
 {
     if (*total_dev > capacity) return;
-    {   // four of five workgroups of the grid own a segment no quadrant of their tile reaches: the forward left the tile's need behind
-        const int seg_ = (int)blockIdx.x / tiles;
-        if ((uint32_t)seg_ >= min(seg_need[(int)blockIdx.x - seg_ * tiles], (uint32_t)GSR_BWD_SEGMENTS)) return;   // (unsigned, clamped: a stray word can only cost time)
-    }
     __shared__ __attribute__((aligned(16))) float tab_all[4][32 * 12];   // per wave: the pixel table (below)
     __shared__ float xpose_all[4][64 * 9];                                // per wave: the nine sums of every lane on their way out
     constexpr int CH = GSR_BWD_SEGMENT;          // records per chunk = lanes in use (60 of 64)
     static_assert(CH <= 64 && CH > 32, "a chunk of the stream has to fit the wave");
     const int W = s.W, H = s.H;
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X;
-    const int seg = (int)blockIdx.x / tiles;
-    const int tile = (int)tile_order[(int)blockIdx.x - seg * tiles];
-    const int tile_x = tile % gx, tile_y = tile / gx;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
+    // ---- the wave's UNITS (gsr.h: GsrImageLayout.units): entries p, p + stride, ... of list (wave id mod GSR_UNIT_LISTS); every unit is a
+    // (tile, quadrant, segment) the forward found a contributor in, so a wave that gets one has work (round 3 launched a workgroup per (tile,
+    // segment): four of five found nothing, and the waves of the others were tied to the four quadrants whether those reached the segment or not)
+    const uint32_t wid = (uint32_t)blockIdx.x * 4u + (uint32_t)wave_in_wg, list = wid % (uint32_t)GSR_UNIT_LISTS;
+    const uint32_t ustride = (uint32_t)gridDim.x * 4u / (uint32_t)GSR_UNIT_LISTS;
+    const uint32_t ucap = (4u * (uint32_t)tiles + GSR_UNIT_LISTS - 1u) / GSR_UNIT_LISTS * (uint32_t)GSR_BWD_SEGMENTS;
+    const uint32_t ucount = min(units[32u * list], ucap);
+    const uint32_t* __restrict__ ulist = units + 32u * GSR_UNIT_LISTS + list * ucap;
+    float* const tab = tab_all[wave_in_wg];
+    float* const xs = xpose_all[wave_in_wg];
+    for (uint32_t up = wid / (uint32_t)GSR_UNIT_LISTS; up < ucount; up += ustride) {
+    const uint32_t unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)ulist[up]);
+    const int seg = (int)(unit & 15u), wave = (int)((unit >> 4) & 3u), tile = (int)(unit >> 6);   // `wave`: the quadrant
+    const int tile_x = tile % gx, tile_y = tile / gx;
     const int nq = (int)qcount[4 * tile + wave];
     const int seg_lo = seg * CH;
-    if (nq <= seg_lo) return;
+    if (nq <= seg_lo) continue;
     const uint32_t* __restrict__ qp = qpos + qstart[4 * tile + wave];
 
     // ---- this lane's PIXEL (lane = 8 * row + column of the quadrant): what the pixel contributes to the table below
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_
     const size_t HW = (size_t)H * W;
     const int last_pix = inside ? (int)n_contrib_q[pix_id] : 0;        // one past the pixel's last contributing stream entry
     const int jtop = (int)wave_max_u32((uint32_t)last_pix);
-    if (jtop <= seg_lo) return;                                        // nothing of this segment in this quadrant
+    if (jtop <= seg_lo) continue;                                      // (cannot happen: the forward listed the unit because something reaches it)
     const bool open_ended = seg == GSR_BWD_SEGMENTS - 1;               // the last segment takes whatever is left, a chunk at a time
     int hi = open_ended ? seg_lo + ((jtop - seg_lo + CH - 1) / CH) * CH : seg_lo + CH;
     {
@@ -439,10 +446,9 @@ __global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_
         }
         // ---- the wave's pixel table (LDS, 12 floats per PAIR of horizontally adjacent pixels, three broadcast ds_read_b128 per pair):
         //      (T_end, T_end', S, S' | g0, g0', g1, g1' | g2, g2', last, last')
-        float* tw = tab_all[wave] + ((lane >> 3) * 4 + ((lane & 7) >> 1)) * 12 + (lane & 1);
+        float* tw = tab + ((lane >> 3) * 4 + ((lane & 7) >> 1)) * 12 + (lane & 1);
         tw[0] = Tend; tw[2] = Sx; tw[4] = g0; tw[6] = g1; tw[8] = g2; tw[10] = __int_as_float(last_pix);
     }
-    float* const tab = tab_all[wave];
     const float fqx0 = (float)qx0, fqy0 = (float)qy0;
 
     for (;;) {
@@ -545,7 +551,6 @@ __global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_
         // consecutive lanes of one instruction and reach its 48-byte accumulator as one burst.
 #ifndef GSR_EXP_RP_NOATOMIC
         {
-            float* xs = xpose_all[wave];
             const float v[9] = {a0.x + a0.y, a1.x + a1.y, a2.x + a2.y, a3.x + a3.y, a4.x + a4.y, a5.x + a5.y, a6.x + a6.y, a7.x + a7.y, a8.x + a8.y};
 #pragma unroll
             for (int c = 0; c < 9; ++c) xs[9 * lane + c] = v[c];
@@ -569,6 +574,7 @@ __global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_
         if (!more) break;
         hi = lo;
     }
+    }   // units
 }
 
 // ------------------------------------------------------------------------------------------

@@ -516,7 +516,7 @@ struct PreprocessArgs {
     float4* __restrict__ acc;             // [P][3] backward accumulators, zeroed here for visible splats
     float4* __restrict__ acc64;           // [P][5] the deterministic mode's (80 B per splat), zeroed instead when settings.deterministic
     uint32_t* __restrict__ tile_count;    // [tiles] zeroed here (the binning histogram of this frame)
-    uint32_t* __restrict__ seg_need;      // [tiles] zeroed here (GsrImageLayout.seg_need: k_render<true> raises it, k_render_bwd_rp reads it)
+    uint32_t* __restrict__ units;         // the GSR_UNIT_LISTS counters of GsrImageLayout.units are zeroed here (k_render<true> appends, k_render_bwd_rp consumes)
     unsigned long long* __restrict__ rect_total;   // zeroed here; k_count sums tiles_touched into it
     int tiles;
     // production binning (gsr_binning.hip); brec == nullptr on the per-tile sort path
@@ -579,17 +579,17 @@ template <bool FAST>
 __global__ void k_render(Settings s, const uint32_t* tile_order, const uint32_t* qstart, const uint32_t* qcount, const float4* grec,
                          const uint32_t* qpos, const uint32_t* qlist, float* final_T,
                          uint32_t* n_contrib, uint32_t* n_contrib_q, float* c_final, float4* ck, float* out_color, unsigned long long capacity,
-                         const unsigned long long* total_dev, uint32_t* seg_need);
+                         const unsigned long long* total_dev, uint32_t* units);
 __global__ void k_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present);
 template <bool DET, bool FAST>
 __global__ void k_render_bwd(Settings s, const uint32_t* tile_order, const uint32_t* qstart, const uint32_t* qcount, const float4* grec,
                              const uint32_t* qpos, const float* final_T,
                              const uint32_t* n_contrib_q, const float* dL_dpix, float* acc, const float* c_final, const float4* ck, int tiles,
                              long long* acc64, const uint32_t* gmax, unsigned long long capacity, const unsigned long long* total_dev);
-__global__ void k_render_bwd_rp(Settings s, const uint32_t* tile_order, const uint32_t* qstart, const uint32_t* qcount, const float4* grec,
+__global__ void k_render_bwd_rp(Settings s, const uint32_t* qstart, const uint32_t* qcount, const float4* grec,
                                 const uint32_t* qpos, const float* final_T, const uint32_t* n_contrib_q, const float* dL_dpix, float* acc,
                                 const float* c_final, const float4* ck, int tiles, unsigned long long capacity, const unsigned long long* total_dev,
-                                const uint32_t* seg_need);
+                                const uint32_t* units);
 __global__ void k_gmax(size_t n, const float* dL_dpix, uint32_t* gmax);
 // exponent e_g with 2^e_g > the float whose bits are given (0 for no gradient at all)
 __device__ __forceinline__ int gmax_exponent(uint32_t gmax_bits) { return gmax_bits ? (int)((gmax_bits >> 23) & 0xFFu) - 127 + 1 : 0; }

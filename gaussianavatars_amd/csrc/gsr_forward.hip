@@ -36,11 +36,12 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         // production binning: the depth-bucket histogram starts at zero (k_dbucket runs after this kernel); the header was
         // zeroed by the API before this launch and collects this kernel's statistics
         for (int t = i; t < a.nb; t += (int)(gridDim.x * blockDim.x)) a.bcount[t] = 0u;
-        // the per-tile backward depth (k_render<true> raises it with atomicMax): the image state is a fresh, uninitialised allocation per forward
-        for (int t = i; t < a.tiles; t += (int)(gridDim.x * blockDim.x)) a.seg_need[t] = 0u;
+        // the backward's work lists start empty (k_render<true> appends): the image state is a fresh, uninitialised allocation per forward
+        if (i < GSR_UNIT_LISTS) a.units[32 * i] = 0u;
     } else {
         // this frame's tile histogram starts at zero (k_count runs after this kernel)
-        for (int t = i; t < a.tiles; t += (int)(gridDim.x * blockDim.x)) { a.tile_count[t] = 0u; a.seg_need[t] = 0u; }
+        for (int t = i; t < a.tiles; t += (int)(gridDim.x * blockDim.x)) a.tile_count[t] = 0u;
+        if (i < GSR_UNIT_LISTS) a.units[32 * i] = 0u;   // the backward's work lists start empty (k_render<true> appends)
         if (i == 0) *a.rect_total = 0ull;
         if (a.pstat)   // rank path: the depth-bucket histogram and its fill cursors start at zero as well
             for (int t = i; t < a.nb; t += (int)(gridDim.x * blockDim.x)) { a.bcount[t] = 0u; a.bcursor[t] = 0u; }
@@ -802,7 +803,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
                                                  uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ n_contrib_q,
                                                  float* __restrict__ c_final, float4* __restrict__ ck,
                                                  float* __restrict__ out_color, unsigned long long capacity,
-                                                 const unsigned long long* __restrict__ total_dev, uint32_t* __restrict__ seg_need)
+                                                 const unsigned long long* __restrict__ total_dev, uint32_t* __restrict__ units)
 {
     if (*total_dev > capacity) return;
 #ifdef GSR_EXPERIMENT_TIMELINE
@@ -1351,9 +1352,20 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         d[3] = t_main;
     }
 #endif
-    if (FAST && !s.forward_only) {   // how many backward segments this tile needs (by launch position: what k_render_bwd_rp's workgroups index)
+    if (FAST && !s.forward_only) {
+        // the backward's work list (gsr.h: GsrImageLayout.units): one unit per 60-entry segment up to this quadrant's deepest last
+        // contributor, appended to the list of this wave's launch position (one returning atomic per wave, spread over 64 counters)
         const uint32_t qmax = wave_max_u32(inside ? last_q : 0u);
-        if (lane == 0 && qmax) atomicMax(seg_need + blockIdx.x, min((qmax + GSR_BWD_SEGMENT - 1u) / GSR_BWD_SEGMENT, (uint32_t)GSR_BWD_SEGMENTS));
+        const uint32_t nseg = min((qmax + GSR_BWD_SEGMENT - 1u) / GSR_BWD_SEGMENT, (uint32_t)GSR_BWD_SEGMENTS);
+        if (nseg) {
+            const uint32_t w = (uint32_t)blockIdx.x * 4u + (uint32_t)wave, list = w % (uint32_t)GSR_UNIT_LISTS;
+            const uint32_t cap = (4u * gridDim.x + GSR_UNIT_LISTS - 1u) / GSR_UNIT_LISTS * (uint32_t)GSR_BWD_SEGMENTS;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(units + 32u * list, nseg);   // (a 128-byte line per counter: returning atomics on one line queue up in L2)
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if ((uint32_t)lane < nseg)
+                units[32u * GSR_UNIT_LISTS + list * cap + base + (uint32_t)lane] = (uint32_t)tile << 6 | (uint32_t)wave << 4 | (uint32_t)lane;
+        }
     }
     if (inside) {
         const int pix_id = W * pyi + pxi;

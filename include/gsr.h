@@ -28,9 +28,10 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 9
+#define GSR_ABI_VERSION 10
 #define GSR_BWD_SEGMENT 60        /* stream entries per backward segment (a multiple of both blend kernels' batches)  */
 #define GSR_BWD_SEGMENTS 10       /* segments per quadrant stream; the last one takes whatever is left                */
+#define GSR_UNIT_LISTS 64         /* fast blend: the backward's work units (quadrant, segment) are appended to this many lists (GsrImageLayout.units) */
 #define GSR_BIN_BLOCKS 256        /* workgroups of the two binning passes (each owns a contiguous chunk of splats) */
 #define GSR_RANK_BLOCKS 256       /* the same for the rank path (csrc/gsr_rank.hip), 1024 threads each: one per CU (swept 64..512)  */
 #define GSR_BLOCK_X 16
@@ -206,9 +207,13 @@ typedef struct GsrImageLayout {
                           s*GSR_BWD_SEGMENT of its quadrant stream.  The backward walks each segment of a pixel's stream on
                           its own wave, starting from the checkpoint (the serial walk was the kernel's critical path). */
     size_t gmax;       /* uint32 [1]  deterministic backward: bits of max |dL/dpixel| of the current backward               */
-    size_t seg_need;   /* uint32 [tiles] fast blend: backward segments the tile needs (the deepest last contributor of its four quadrants
-                          / GSR_BWD_SEGMENT, rounded up), by the tile's position in the launch order: a backward workgroup beyond it exits
-                          on one load instead of finding out quadrant by quadrant                                                */
+    size_t units;      /* uint32 [32 GSR_UNIT_LISTS + GSR_UNIT_LISTS * cap], cap = ceil(4 tiles / GSR_UNIT_LISTS) * GSR_BWD_SEGMENTS.  Fast blend: the
+                          backward's WORK LIST.  A wave of the forward blend knows how deep its quadrant's last contributor sits and appends
+                          one unit tile << 6 | quadrant << 4 | segment per 60-entry segment the backward has to walk to list (launch position
+                          of the wave) mod GSR_UNIT_LISTS: the counters first (word 32 l = list l's, a 128-byte line each; zeroed by the frame's first kernel), then the lists, `cap` slots
+                          each (the mapping wave -> list is static, so `cap` cannot overflow).  The backward's waves take the units of list
+                          (wave id mod GSR_UNIT_LISTS) in turn: no workgroup is launched for a (tile, segment) pair nothing reaches -- four of
+                          five were, round 3 -- and a workgroup's four waves all carry work                                            */
     size_t total;
 } GsrImageLayout;
 
