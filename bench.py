@@ -44,7 +44,8 @@ class Pipe:
     convert_SHs_python = False
 
 
-SPATIAL_SORT = False   # --spatial-sort: the splats in Morton order of their positions (gaussianavatars_amd.io.spatial_sort), a loader-side layout choice
+SPATIAL_SORT = True   # the splats in Morton order of their positions (gaussianavatars_amd.io.spatial_sort): what the package's loaders and the densification
+                      # hook of patch.py produce by default since round 4 (GAA_SPATIAL_SORT=0 / --no-spatial-sort: the order the generator emits, random)
 
 
 def build_scene(device, n_splats, sh_degree, width, height, n_frames, binding_impl, requires_grad):
@@ -415,9 +416,10 @@ def main():
                          "binding, the rasterizer stubbed at its autograd Function; the line is marked as such and is not a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
-    ap.add_argument("--spatial-sort", action="store_true",
-                    help="load the synthetic splats in Morton order of their positions (io.spatial_sort): same image, gradients permuted with the splats; "
-                         "the layout a loader may choose freely, reported in config.splat_order")
+    ap.add_argument("--spatial-sort", action="store_true", help="(the default since round 4; kept so that older command lines still parse)")
+    ap.add_argument("--no-spatial-sort", action="store_true",
+                    help="keep the synthetic splats in the order the generator emits them (random) instead of the loaders' default, Morton order of "
+                         "their positions (io.spatial_sort: same image, gradients permuted with the splats); reported in config.splat_order")
     ap.add_argument("--graph-frames", type=int, default=4,
                     help="with --graph: frames per recording (the frame feed is a kernel inside it: gab_feed_row), so that the launch gap between two "
                          "graphs is paid once per K frames; steps that do not fill a recording use a one-frame recording")
@@ -430,9 +432,8 @@ def main():
                          "lanes (reported beside `value` as `frame_streams`); 0 skips the leg")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the process next to its GPU (host-sensitivity runs)")
     args = ap.parse_args()
-    if args.spatial_sort:
-        global SPATIAL_SORT
-        SPATIAL_SORT = True
+    global SPATIAL_SORT
+    SPATIAL_SORT = not args.no_spatial_sort and os.environ.get("GAA_SPATIAL_SORT", "1") != "0"
     if args.workload == "cfg3" and args.mode == "render":
         args.workload = "cfg2"
     if args.workload == "train":   # not a BASELINE config: cfg3 plus the fused L1+SSIM loss and the densification statistics (N3)
@@ -443,7 +444,7 @@ def main():
     elif args.workload == "cfg4":
         args.splats, args.frames = 200_000, 300
     elif args.workload == "cfg5":
-        args.mode, args.splats, args.width, args.height = "render", 2_000_000, 1600, 1100
+        args.mode, args.splats, args.width, args.height = "render", 2_000_000, 1100, 1600   # SURVEY.md 8(d) cfg 5: H = 1600, W = 1100 (6900 tiles)
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -617,7 +618,7 @@ def main():
             torch.cuda.synchronize(device)
 
     _lib.gsr_wait_stats()   # reset
-    rounds = timed_rounds(run, fence, args.steps, args.warmup, dist, device, min_rounds=args.rounds, min_seconds=args.min_seconds, max_rounds=256)
+    rounds = timed_rounds(run, fence, args.steps, args.warmup, dist, device, min_rounds=args.rounds, min_seconds=args.min_seconds, max_rounds=100_000)   # (--min-seconds is the stopping rule; round 3 capped it at 256 rounds)
     elapsed = float(np.median(rounds))   # the median round: exactly args.steps steps
     wait_ms, waits = _lib.gsr_wait_stats()
     info = {"binning_path": 0} if dry else R.last_forward_info()
@@ -652,7 +653,7 @@ def main():
                "--no-cpu-baseline", "--no-kernel-profile", "--workload", args.workload, "--steps", str(args.steps), "--warmup", str(args.warmup),
                "--rounds", str(args.rounds), "--min-seconds", str(min(args.min_seconds, 1.5)), "--splats", str(args.splats), "--width", str(args.width),
                "--height", str(args.height), "--frames", str(args.frames), "--binding", args.binding] + (["--no-pin"] if args.no_pin else []) + (
-                   ["--spatial-sort"] if args.spatial_sort else [])
+                   ([] if SPATIAL_SORT else ["--no-spatial-sort"]))
         try:
             out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
             sub = json.loads(out.stdout.strip().splitlines()[-1])
@@ -777,13 +778,13 @@ def main():
                                       "target, backward, densification statistics; no optimiser step"}[
                                  args.workload] % (N, args.height, args.width),
                 "splats": N, "width": args.width, "height": args.height, "sh_degree": 3,
-                "splat_order": "morton (io.spatial_sort)" if SPATIAL_SORT else "as generated (random)",
+                "splat_order": "morton (io.spatial_sort: the loaders' default)" if SPATIAL_SORT else "as generated (random; --no-spatial-sort)",
                 "num_rendered": I_rect, "num_binned": I_binned, "tile_culling": bool(info.get("tile_culling", False)),
                 "binning_path": {0: "rank", 1: "depth-ordered scatter", 2: "per-tile sort"}[path] + (f" ({bands} bands of tile rows)" if path == 0 and bands > 1 else ""),
                 "visible_fraction": round(vis, 4), "binding": args.binding,
-                "parallelism": (f"frame-parallel x{n_gpus}: {dist.get_world_size() if dist is not None else 1} "
-                                f"{('gloo (dry run)' if dry else 'RCCL (torch nccl)') if dist is not None else 'single-process'} rank(s), one process per GPU, frames per rank {counts}, "
-                                "one asynchronous scalar all-reduce (loss) per step"
+                "parallelism": (((f"frame-parallel x{n_gpus}: {dist.get_world_size()} {'gloo (dry run)' if dry else 'RCCL (torch nccl)'} rank(s), one process per GPU, "
+                                  f"frames per rank {counts}, one asynchronous scalar all-reduce (loss) per step") if dist is not None else
+                                 f"one process, one GPU, {counts[0]} frames in turn; no collective")
                                 + (f"; {len(lanes)} frame streams inside the GPU (independent frames overlap; ms_per_step is elapsed / steps, "
                                    f"not the latency of one frame)" if len(lanes) > 1 else "")),
             },

@@ -69,14 +69,17 @@ class GaussianModel:
         self.xyz_gradient_accum = torch.zeros((self._xyz.shape[0], 1), device=device)
         self.denom = torch.zeros((self._xyz.shape[0], 1), device=device)
 
-    def load_ply(self, path, device="cuda", spatial_sort: bool = False, face_centers=None, **kwargs):
-        """scene/gaussian_model.py:282-332: leaf tensors from the reference's PLY (binding -> int32).  `spatial_sort` (off by default: the
-        tensors then hold the file's rows in the file's order, as the reference's do): the splats in Morton order of their positions
-        (io.spatial_sort; a bound model passes the template's face centres) -- same images, per-splat tensors permuted, the binning pass of
-        large models ~1.6 x faster."""
+    def load_ply(self, path, device="cuda", spatial_sort: Optional[bool] = None, face_centers=None, **kwargs):
+        """scene/gaussian_model.py:282-332: leaf tensors from the reference's PLY (binding -> int32).  `spatial_sort` (round 4: ON by
+        default, `GAA_SPATIAL_SORT=0` or `spatial_sort=False` keep the file's order): the splats in Morton order of their positions
+        (io.spatial_sort; a bound model passes the template's face centres) -- same images, every per-splat tensor permuted the same way
+        (row i is then NOT the file's row i), the binning pass of large models ~1.6 x faster because a workgroup's consecutive splats share
+        tiles.  save_ply writes whatever order the model is in."""
         from . import io as gio
 
         arrs = gio.load_ply(str(path), self.max_sh_degree)
+        if spatial_sort is None:
+            spatial_sort = spatial_order_default()
         if spatial_sort:
             arrs = gio.spatial_sort(arrs, face_centers)
         self.load_arrays(arrs, device=device)
@@ -207,13 +210,15 @@ class FlameGaussianModel(GaussianModel):
         self.flame_param = fp
         self.num_timesteps = fp["expr"].shape[0]
 
-    def load_ply(self, path, device="cuda", spatial_sort: bool = False, **kwargs):
-        """scene/flame_gaussian_model.py:229-237: the PLY plus the flame_param.npz stored next to it.  `spatial_sort`: as GaussianModel.load_ply,
-        by the template centre of each splat's face."""
+    def load_ply(self, path, device="cuda", spatial_sort: Optional[bool] = None, **kwargs):
+        """scene/flame_gaussian_model.py:229-237: the PLY plus the flame_param.npz stored next to it.  `spatial_sort`: as GaussianModel.load_ply
+        (default on), by the template centre of each splat's face."""
         import os
 
         from . import io as gio
 
+        if spatial_sort is None:
+            spatial_sort = spatial_order_default()
         super().load_ply(path, device=device, spatial_sort=spatial_sort, face_centers=template_face_centers(self) if spatial_sort else None)
         if not kwargs.get("has_target", False):
             self.load_flame_param(gio.load_flame_param(os.path.join(os.path.dirname(str(path)), "flame_param.npz")), device=device)
@@ -261,6 +266,15 @@ class FlameGaussianModel(GaussianModel):
 from .patch import patch_classes as _patch_classes  # noqa: E402
 
 _patch_classes(GaussianModel, FlameGaussianModel, FlameHead)
+
+
+def spatial_order_default() -> bool:
+    """Whether loaders (and the densification hook of patch.py) keep the splats in Morton order of their positions: yes unless
+    GAA_SPATIAL_SORT=0.  A layout choice -- the rasterizer's outputs do not depend on the order of the splats -- that decides how far apart in
+    time the binning pass writes the entries of one tile (492 -> 141 MB written per frame at 2 M splats)."""
+    import os
+
+    return os.environ.get("GAA_SPATIAL_SORT", "1") != "0"
 
 
 def template_face_centers(model):

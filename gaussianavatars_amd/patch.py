@@ -182,6 +182,46 @@ def _make_flame_forward(cls):
 
 
 # ------------------------------------------------------------------------------------------------
+def _hook_spatial_order(G) -> None:
+    """Keeps the splats of a model of the REFERENCE's class in Morton order of their positions (gaussian_model.spatial_order_default:
+    GAA_SPATIAL_SORT=0 opts out): after `load_ply` (scene/gaussian_model.py:282-332; the reference's FlameGaussianModel.load_ply calls it
+    through super()) and after every `densify_and_prune` (:501-515, called from train.py:197-206), which appends its new splats at the end.
+    The order is a layout choice -- images and gradients do not depend on it -- that lets a workgroup of the binning pass meet a compact set
+    of tiles.  gaussian_model.spatial_resort moves the six leaves, their Adam moments (through the model's own
+    _prune_optimizer), the densification statistics and the binding together.  Classes whose load_ply takes `spatial_sort` itself (this
+    package's mirror) are left alone."""
+    import inspect
+
+    load = G.__dict__.get("load_ply")
+    if load is not None and "spatial_sort" not in inspect.signature(load).parameters:
+        _ORIG[(G, "load_ply")] = load
+
+        def load_ply(self, *a, **k):
+            out = load(self, *a, **k)
+            from .gaussian_model import spatial_order_default, spatial_resort
+
+            if spatial_order_default() and getattr(self, "_xyz", None) is not None and self._xyz.shape[0] > 1:
+                spatial_resort(self)
+            return out
+
+        load_ply.__doc__ = load.__doc__
+        G.load_ply = load_ply
+    dens = G.__dict__.get("densify_and_prune")
+    if dens is not None:
+        _ORIG[(G, "densify_and_prune")] = dens
+
+        def densify_and_prune(self, *a, **k):
+            out = dens(self, *a, **k)
+            from .gaussian_model import spatial_order_default, spatial_resort
+
+            if spatial_order_default() and self._xyz.shape[0] > 1:
+                spatial_resort(self)
+            return out
+
+        densify_and_prune.__doc__ = dens.__doc__
+        G.densify_and_prune = densify_and_prune
+
+
 def patch_classes(gaussian_model_cls, flame_gaussian_model_cls=None, flame_head_cls=None) -> None:
     """Rebinds the per-frame methods of classes shaped like the reference's (idempotent)."""
     G = gaussian_model_cls
@@ -194,6 +234,7 @@ def patch_classes(gaussian_model_cls, flame_gaussian_model_cls=None, flame_head_
         G.get_opacity = _make_opacity(G)
         if "get_features_split" not in G.__dict__:
             G.get_features_split = property(_get_features_split)
+        _hook_spatial_order(G)
         G._gaa_patched = True
     F = flame_gaussian_model_cls
     if F is not None and not F.__dict__.get("_gaa_patched_flame", False):

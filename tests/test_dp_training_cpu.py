@@ -81,6 +81,10 @@ def _train(rank, world, port, farm, ply, q):
     fp.init_process_group("gloo")
     torch.manual_seed(0)
     g = FlameGaussianModel(3)
+    # patch_reference keeps a model in Morton order by default (patch._hook_spatial_order: after load_ply and after every
+    # densify_and_prune); the loop below runs with the hook OFF so that the explicit re-sort at its end has something to move, the hook
+    # itself is exercised after that
+    os.environ["GAA_SPATIAL_SORT"] = "0"
     g.load_ply(Path(ply), has_target=False)
     g.spatial_lr_scale = 1.0
     g.max_radii2D = torch.zeros(g.get_xyz.shape[0])     # (create_from_pcd / restore set it in train.py's own start-up, load_ply does not)
@@ -147,6 +151,16 @@ def _train(rank, world, port, farm, ply, q):
         fp.allreduce_gradients([p for grp in g.optimizer.param_groups for p in grp["params"]], average=True, method="reduce_scatter")
         g.optimizer.step()
         g.optimizer.zero_grad(set_to_none=True)
+    # ---- the default: the reference's densify_and_prune followed by the re-sort hook -- nothing left for an explicit re-sort to move
+    os.environ["GAA_SPATIAL_SORT"] = "1"
+    with torch.no_grad():
+        fp.sync_densification_stats(g)
+        fp.sync_mesh_for_densification(g, 0)
+        fp.seed_all_ranks(99)
+        g.densify_and_prune(6e-3, 0.3, 1.0, 20)
+        again = spatial_resort(g)
+    assert torch.equal(again, torch.arange(again.shape[0])), "densify_and_prune did not leave the model in Morton order"
+    assert g._xyz is [gr["params"][0] for gr in g.optimizer.param_groups if gr["name"] == "xyz"][0]
     state = {k: _digest(getattr(g, k)) for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "binding",
                                                    "binding_counter", "max_radii2D", "xyz_gradient_accum", "denom")}
     state.update({"flame_" + k: _digest(v) for k, v in g.flame_param.items()})

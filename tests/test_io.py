@@ -1,5 +1,7 @@
 """CPU tests of the on-disk formats: round trips, and the byte layout the reference's
 plyfile-based writer produces (scene/gaussian_model.py:236-275)."""
+import os
+
 import numpy as np
 
 from gaussianavatars_amd import io as gio
@@ -72,8 +74,8 @@ def test_morton_order_keeps_every_splat_whole_and_neighbours_close():
 
 
 def test_load_ply_spatial_sort_on_both_model_classes(tmp_path):
-    """GaussianModel.load_ply(spatial_sort=True): the file's splats in Morton order of their positions, a bound model's by the template centre
-    of their faces; off by default (row i of the tensors = row i of the file)."""
+    """GaussianModel.load_ply: the file's splats in Morton order of their positions, a bound model's by the template centre of their faces --
+    the DEFAULT since round 4 (GAA_SPATIAL_SORT=0 or spatial_sort=False: row i of the tensors = row i of the file)."""
     import torch
 
     from gaussianavatars_amd.gaussian_model import FlameGaussianModel, GaussianModel, template_face_centers
@@ -86,10 +88,17 @@ def test_load_ply_spatial_sort_on_both_model_classes(tmp_path):
     gio.save_flame_param(str(d / "flame_param.npz"), seq)
     rig = S.flame_rig(seed=4)
     plain = FlameGaussianModel(1, rig, binding_impl="unfused", device="cpu")
-    plain.load_ply(p, device="cpu")
+    plain.load_ply(p, device="cpu", spatial_sort=False)
     np.testing.assert_array_equal(plain._xyz.detach().numpy(), sp["_xyz"])
     srt = FlameGaussianModel(1, rig, binding_impl="unfused", device="cpu")
-    srt.load_ply(p, device="cpu", spatial_sort=True)
+    srt.load_ply(p, device="cpu")                       # the default
+    env = FlameGaussianModel(1, rig, binding_impl="unfused", device="cpu")
+    os.environ["GAA_SPATIAL_SORT"] = "0"
+    try:
+        env.load_ply(p, device="cpu")                   # the opt-out
+    finally:
+        del os.environ["GAA_SPATIAL_SORT"]
+    np.testing.assert_array_equal(env._xyz.detach().numpy(), sp["_xyz"])
     centers = template_face_centers(srt)
     assert centers.shape == (S.FLAME_F, 3)
     b0, b1 = plain.binding.long().numpy(), srt.binding.long().numpy()
@@ -105,7 +114,7 @@ def test_load_ply_spatial_sort_on_both_model_classes(tmp_path):
     q = str(tmp_path / "u.ply")
     gio.save_ply(q, un)
     g = GaussianModel(1)
-    g.load_ply(q, device="cpu", spatial_sort=True)
+    g.load_ply(q, device="cpu")
     x = g._xyz.detach().numpy()
     assert np.linalg.norm(np.diff(x, axis=0), axis=1).mean() < 0.5 * np.linalg.norm(np.diff(sp["_xyz"], axis=0), axis=1).mean()
 

@@ -196,6 +196,39 @@ def test_reference_ply_writer_and_reader_interoperate_with_io():
     assert out.strip().endswith("OK")
 
 
+@needs_ref
+def test_patched_reference_model_keeps_its_splats_in_morton_order():
+    """patch._hook_spatial_order: the reference's own GaussianModel.load_ply (scene/gaussian_model.py:282-332), rebound by
+    patch_reference(), leaves the splats in Morton order of their positions (the default; every per-splat tensor permuted alike), and in the
+    file's order with GAA_SPATIAL_SORT=0."""
+    out = _run("""
+        import os, tempfile, numpy as np, torch
+        from unittest import mock
+        from gaussianavatars_amd import patch, io as gio, synthetic as S
+        patch.patch_reference(pin=False)
+        from scene.gaussian_model import GaussianModel
+        sp = S.bound_splats(400, 120, 3, 9)
+        sp.pop("binding")
+        d = tempfile.mkdtemp()
+        gio.save_ply(os.path.join(d, "u.ply"), sp)
+        orig = torch.tensor
+        def load():
+            with mock.patch("torch.tensor", lambda *a, **k: orig(*a, **{kk: v for kk, v in k.items() if kk != "device"})):
+                m = GaussianModel(3); m.load_ply(os.path.join(d, "u.ply"))
+            return m
+        m = load()
+        x = m._xyz.detach().numpy()
+        perm = gio.morton_order(sp["_xyz"])
+        assert not np.array_equal(x, sp["_xyz"]) and np.array_equal(x, sp["_xyz"][perm])
+        for k in ("_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+            assert np.array_equal(getattr(m, k).detach().numpy(), sp[k][perm]), k
+        os.environ["GAA_SPATIAL_SORT"] = "0"
+        assert np.array_equal(load()._xyz.detach().numpy(), sp["_xyz"])
+        print("OK")
+    """)
+    assert out.strip().endswith("OK")
+
+
 def test_shims_only_fill_gaps_and_uninstall_cleanly():
     from gaussianavatars_amd import shims
 
