@@ -638,6 +638,29 @@ def main():
         torch.cuda.synchronize(device)
         kern = _lib.gsr_profile_read()
         _lib.gsr_profile_enable(False)
+    # ---- `--workload train`: the fused L1+SSIM pair has no timing slot in the rasterizer's C ABI; its three launches (forward, reduce, backward)
+    # are timed here with events on the launch stream, on one image pair, for the roofline line of the loss
+    loss_line = None
+    if rank == 0 and SSIM_STEP and not args.no_kernel_profile:
+        from gaussianavatars_amd.loss import l1_ssim
+
+        img = torch.rand((3, args.height, args.width), device=device).requires_grad_(True)
+        reps, a, b = 50, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for k in range(reps + 10):
+            if k == 10:
+                a.record()
+            l1, ss = l1_ssim(img, target)
+            (0.8 * l1 + 0.2 * (1.0 - ss)).backward()
+            img.grad = None
+        b.record()
+        torch.cuda.synchronize(device)
+        us = 1e3 * a.elapsed_time(b) / reps
+        hw = args.width * args.height
+        # forward: two images in (24 HW), three derivative planes per channel out (36 HW); backward: the planes in (36 HW), the gradient out (12 HW)
+        algo_loss = 108 * hw
+        loss_line = dict(kernels="gls::k_l1_ssim_fwd + k_l1_ssim_reduce + k_l1_ssim_bwd (+ the torch scalar ops of 0.8 L1 + 0.2 (1 - SSIM))", avg_us=round(us, 2),
+                         algorithmic_bytes=int(algo_loss), algo_GBs=round(algo_loss / (us * 1e-6) / 1e9, 1), frac=round(algo_loss / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                         note="three launches + four elementwise torch kernels for 48 MB: launch-latency bound, HBM fraction reported as asked")
     if dist is not None:
         dist.barrier()
 
@@ -711,12 +734,26 @@ def main():
         if path == 0:
             stream.update({"k_count": 16 * N, "k_depth_sort": 20 * N, "k_scatter": 44 * N, "k_tile_sort": 8 * I_binned})
         pmc, pmc_raw = {}, {}
-        pmc_tag = {"cfg5": "cfg5", "cfg4": "cfg4", "cfg3": "cfg3", "cfg2": "cfg3"}.get(args.workload)
+        pmc_tag = {"cfg5": "cfg5", "cfg4": "cfg4", "cfg3": "cfg3", "cfg2": "cfg3", "train": "cfg3"}.get(args.workload)   # (train: cfg3's rasterizer kernels)
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{pmc_tag}_pmc_fetch_write_per_launch.json"))) if pmc_tag else []
         pmc_path = cands[-1] if cands else ""   # the newest committed PMC summary of this workload
+        pmc_stale = None
         if pmc_path:   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/README.md)
-            for k, v in json.load(open(pmc_path)).items():
+            pmc_json = json.load(open(pmc_path))
+            meta = pmc_json.pop("_meta", None)   # tools/pmc_per_launch.py: commit, library digests, box
+            if meta is None:
+                pmc_stale = "no provenance in the PMC file (collected before round 4)"
+            else:
+                import hashlib
+
+                from gaussianavatars_amd import _lib as _L
+                have = hashlib.sha256(open(_L.GSR_LIB_PATH, "rb").read()).hexdigest()[:16]
+                if meta.get("libraries", {}).get("libgsr_hip.so") != have:
+                    pmc_stale = f"libgsr_hip.so changed since the PMC passes (commit {meta.get('commit') or '?'}): re-run tools/collect_profiles.sh"
+            if pmc_stale and rank == 0:
+                print(f"bench.py: roofline.traffic comes from {os.path.basename(pmc_path)} -- {pmc_stale}", file=sys.stderr)
+            for k, v in pmc_json.items():
                 name = k.replace("void ", "").split("::")[-1].split("<")[0]   # the k_tile_sort classes add up
                 name = PMC_ALIAS.get(name, name)                              # kernels that share one timing slot add up as well
                 f, w = pmc_raw.get(name, (0.0, 0.0))
@@ -736,7 +773,7 @@ def main():
             roofline = dict(kernel=dom, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(ach / HBM_PEAK_GBS, 5), traffic=pmc.get(dom),
                             traffic_bounds=[int(sum(pmc_raw[dom])), int(2 * pmc_raw[dom][0] + pmc_raw[dom][1])] if dom in pmc_raw else None,
-                            traffic_source=os.path.basename(pmc_path) if pmc_path else None,
+                            traffic_source=os.path.basename(pmc_path) if pmc_path else None, traffic_stale=pmc_stale,
                             algorithmic_bytes_per_launch=int(algo[dom]), algorithmic_bytes_rect_based=int(algo_rect[dom]),
                             instances=dict(binned=int(I_binned), rect_based=int(I_rect)),
                             avg_launch_us=round(per_kernel[dom]["avg_us"], 2), note=notes.get(dom, "HBM-bound streaming kernel"),
@@ -792,7 +829,7 @@ def main():
             "rounds": {"n": len(rounds), "frames_per_s": [round(n_gpus * args.steps / r, 2) for r in rounds],
                        "min": round(n_gpus * args.steps / max(rounds), 2), "p10": round(n_gpus * args.steps / float(np.percentile(rounds, 90)), 2),
                        "max": round(n_gpus * args.steps / min(rounds), 2), "timed_seconds": round(float(sum(rounds)), 4)},
-            "roofline": roofline,
+            "roofline": dict(roofline, loss=loss_line) if roofline is not None and loss_line is not None else roofline,
             "cpu_baseline": cpu,
             "frame_streams": frame_streams,
             # the frame's single host wait (for the instance count): ~0 would mean the host paces the loop, not the GPU
