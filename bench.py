@@ -427,6 +427,10 @@ def main():
                     help="record the frame step once and replay it as one hipGraph launch per step (gaussianavatars_amd.graphs.GraphedStep)")
     ap.add_argument("--streams", type=int, default=1,
                     help="with --graph: this many recordings on this many streams, frames dealt to them in turn (frame parallelism inside one GPU)")
+    ap.add_argument("--lane-models", choices=["shared", "replica"], default="shared",
+                    help="with --streams > 1: `shared` (default) -- the lanes read ONE set of splat parameters (gaussianavatars_amd.graphs.shared_lane_model: "
+                         "leaves over the same storage, a .grad of its own per lane; accumulate_lane_grads adds them up); `replica` -- a full model per lane "
+                         "(round 3's arrangement)")
     ap.add_argument("--frame-streams", type=int, default=4,
                     help="N=1, eager default run only: after the timed rounds, the same workload again as this many recorded frame "
                          "lanes (reported beside `value` as `frame_streams`); 0 skips the leg")
@@ -462,7 +466,7 @@ def main():
         args.splats, args.width, args.height, args.frames = min(args.splats, 12_000), 64, 48, min(args.frames, 16)
         args.binding, args.no_cpu_baseline, args.no_kernel_profile, args.frame_streams, args.no_pin = "unfused", True, True, 0, True
         if args.graph or args.workload == "cfg5":
-            raise SystemExit("--backend gloo covers the eager frame loop of the bound workloads only")
+            raise SystemExit("--backend gloo covers the eager frame loop of the bound workloads only (--streams S without --graph: the lanes as plain step functions)")
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: there is no CPU path for the rasterizer (--backend gloo is the dry run of the multi-rank plumbing)")
@@ -508,10 +512,11 @@ def main():
 
     run = make_runner(step_fn, my_frames, dist, device, post_step=(lambda: zero_grads(g)) if train else None)
     run_eager, graphed, lanes = run, None, []
-    if args.streams > 1 and not args.graph:
+    if args.streams > 1 and not args.graph and not dry:
         raise SystemExit("--streams needs --graph (two eager frame loops in one process are host-bound)")
-    if args.streams > 1 and dist is not None:
-        raise SystemExit("--streams > 1 is a single-rank experiment")
+    # (round 4) lanes x ranks: every rank deals ITS frames to its --streams recorded lanes; the lanes add their losses up on the device and the
+    # rank contributes the sum to ONE scalar all-reduce per run of K steps (the path's only collective).  `--backend gloo
+    # --streams S` is the dry run of that plumbing: the lanes are plain step functions called in turn (no hipGraph, no streams on a CPU).
 
     def build_lanes(n_lanes):
         """The step recorded once per lane and replayed (gaussianavatars_amd.graphs): the frame's FLAME parameters are fed into
@@ -520,6 +525,26 @@ def main():
         gradients, as a second rank would have); consecutive frames go to the lanes in turn, so independent frames overlap
         on the GPU the way they do across GPUs."""
         from gaussianavatars_amd.graphs import FlameRowFeeder, GraphedStep, release_mesh
+
+        import copy
+
+        base_model = copy.copy(g)   # (lane 0 swaps g.flame_param for its static rows below: the other lanes clone the full tables from this handle)
+
+        class _EagerLane:   # --backend gloo: a "recording" that simply runs (the dry run of the lanes x ranks plumbing)
+            def __init__(self, fn, before):
+                self.fn, self.before = fn, before
+
+            def replay(self):
+                self.before()
+                return self.fn()
+
+            def check(self):
+                pass
+
+            def instances(self):
+                return [0]
+
+            capacity = 0
 
         def make_lane(gm, lane, n_lanes):
             feeder = None
@@ -546,7 +571,7 @@ def main():
                             zero_grads(gm)
                             release_mesh(gm)
                     l = ls[0] if k == 1 else torch.stack(ls).sum()
-                    if dist is None and train:
+                    if (dist is None or n_lanes > 1) and train:
                         loss_sum.add_(l)
                     return l
                 return fn
@@ -555,15 +580,20 @@ def main():
                 zero_grads(gm)
                 release_mesh(gm)
 
-            K = max(1, int(args.graph_frames)) if dist is None else 1   # (ranks all-reduce every step's scalar: one frame per recording)
-            ln = dict(g=gm, feeder=feeder, loss_sum=loss_sum, fixed_step=fixed_step, stream=torch.cuda.Stream(device), K=K,
-                      graphed=GraphedStep(frames_step(1), before_capture=fresh))
-            ln["graphed_k"] = GraphedStep(frames_step(K), before_capture=fresh) if K > 1 else ln["graphed"]
+            K = max(1, int(args.graph_frames)) if (dist is None or n_lanes > 1) else 1   # (one lane per rank: every step's scalar is all-reduced, one frame per recording)
+            Rec = (lambda fn: _EagerLane(fn, fresh)) if dry else (lambda fn: GraphedStep(fn, before_capture=fresh))
+            ln = dict(g=gm, feeder=feeder, loss_sum=loss_sum, fixed_step=fixed_step, stream=None if dry else torch.cuda.Stream(device), K=K,
+                      graphed=Rec(frames_step(1)))
+            ln["graphed_k"] = Rec(frames_step(K)) if K > 1 else ln["graphed"]
             return ln
 
         out = [make_lane(g, 0, n_lanes)]
         for lane in range(1, n_lanes):
-            if args.workload == "cfg5":
+            if args.lane_models == "shared":   # (round 4) one set of splats per GPU: the lane's leaves alias lane 0's storage, its gradients are its own
+                from gaussianavatars_amd.graphs import shared_lane_model
+
+                gk = shared_lane_model(base_model)
+            elif args.workload == "cfg5":
                 gk, _ = build_unbound_scene(device, args.splats, 3, args.width, args.height)
             else:
                 gk, _ = build_scene(device, args.splats, 3, args.width, args.height, args.frames, args.binding, train)
@@ -571,12 +601,17 @@ def main():
         return out
 
     def lane_runner(lanes):
-        def run(n, offset):   # one rank: the recordings add their losses to a static accumulator, nothing else runs per step
-            cur = torch.cuda.current_stream(device)
+        import contextlib
+
+        on = (lambda ln: contextlib.nullcontext()) if dry else (lambda ln: torch.cuda.stream(ln["stream"]))
+
+        def run(n, offset):   # the recordings add their losses to a static accumulator, nothing else runs per step
+            cur = None if dry else torch.cuda.current_stream(device)
             plan = lane_plan(n, offset, len(lanes), lanes[0]["K"])   # frame i of the run belongs to lane (offset + i) % L
             for ln, (start, _) in zip(lanes, plan):
-                ln["stream"].wait_stream(cur)
-                with torch.cuda.stream(ln["stream"]):
+                if cur is not None:
+                    ln["stream"].wait_stream(cur)
+                with on(ln):
                     ln["loss_sum"].zero_()
                     if ln["feeder"] is not None:
                         ln["feeder"].seek(start)
@@ -585,15 +620,21 @@ def main():
                 for ln, td in zip(lanes, todo):
                     if td:
                         k = td.pop(0)
-                        with torch.cuda.stream(ln["stream"]):
+                        with on(ln):
                             (ln["graphed_k"] if k > 1 else ln["graphed"]).replay()
-            for ln in lanes:
-                cur.wait_stream(ln["stream"])
-            return torch.stack([ln["loss_sum"] for ln in lanes]).sum()
+            if cur is not None:
+                for ln in lanes:
+                    cur.wait_stream(ln["stream"])
+            total = torch.stack([ln["loss_sum"] for ln in lanes]).sum()
+            if dist is not None:   # lanes x ranks: ONE scalar all-reduce per run, of what this rank's lanes added up
+                total = total.reshape(1)
+                dist.all_reduce(total, op=dist.ReduceOp.SUM)
+                total = total[0]
+            return total
 
         return run
 
-    if args.graph:
+    if args.graph or (dry and args.streams > 1):
         lanes = build_lanes(args.streams)
         graphed = lanes[0]["graphed"]
 
@@ -609,7 +650,8 @@ def main():
                 lanes[0]["feeder"].seek(my_frames.index(t) if t in my_frames else 0)
             return graphed.replay().clone()   # the recorded scalar is overwritten by the next replay
 
-        run = make_runner(graph_step, my_frames, dist, device) if dist is not None else lane_runner(lanes)   # (the per-step all-reduce takes its copy of the scalar anyway)
+        # one lane per rank: a replay per step and the per-step asynchronous all-reduce of its scalar; otherwise the lanes run on their own
+        run = make_runner(graph_step, my_frames, dist, device) if (dist is not None and len(lanes) == 1) else lane_runner(lanes)
 
     def fence():
         if dist is not None:

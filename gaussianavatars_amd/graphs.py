@@ -37,7 +37,7 @@ import torch
 
 from . import rasterizer as _R
 
-__all__ = ["GraphedStep", "CapacityOverflow", "FlameRowFeeder", "release_mesh"]
+__all__ = ["GraphedStep", "CapacityOverflow", "FlameRowFeeder", "release_mesh", "shared_lane_model", "accumulate_lane_grads", "LEAF_NAMES"]
 
 
 def release_mesh(model) -> None:
@@ -46,6 +46,57 @@ def release_mesh(model) -> None:
     for k in ("verts", "verts_cano", "face_center", "face_orien_mat", "face_scaling", "face_orien_quat"):
         if hasattr(model, k):
             setattr(model, k, None)
+
+
+LEAF_NAMES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+
+
+def shared_lane_model(model):
+    """A second handle on `model` for another frame lane (a recorded step on its own stream): the six leaf parameters are new leaf tensors
+    over the SAME storage (`detach()` shares memory: the lanes read one set of splats, 236 B per splat once per GPU, not once per lane), so
+    each lane's backward writes its OWN `.grad` tensors; the FLAME tables are the lane's own clones (a recorded lane feeds its frame into
+    static one-row tables, FlameRowFeeder) and the per-frame mesh tensors start empty.  Everything else (rig, binding, CSR, counters) is
+    shared by reference.  `accumulate_lane_grads` adds the lanes' gradients up: S lanes x K frames = gradient accumulation over S K frames,
+    after which ONE optimiser step on `model`'s leaves moves every lane (same storage)."""
+    import copy
+
+    lane = copy.copy(model)                      # shallow: attributes by reference
+    for name in LEAF_NAMES:
+        p = getattr(model, name)
+        setattr(lane, name, p.detach().requires_grad_(p.requires_grad))
+    fp = getattr(model, "flame_param", None)
+    if fp is not None:
+        lane.flame_param = {k: v.detach().clone().requires_grad_(v.requires_grad) for k, v in fp.items()}
+    release_mesh(lane)
+    return lane
+
+
+def accumulate_lane_grads(model, lanes, flame: bool = True) -> None:
+    """model.<leaf>.grad (+)= sum over `lanes` of their <leaf>.grad, on the device, in lane order (torch._foreach_add_: one fused launch per
+    lane); with `flame`, the same for the FLAME tables that require gradients.  Call it on a stream that has waited for the lanes' streams.
+    The sum order is fixed, so with the rasterizer's deterministic backward the result is the bits of the sequential accumulation
+    loss_0.backward(); loss_1.backward(); ... on one model."""
+    names = list(LEAF_NAMES)
+    targets = [getattr(model, n) for n in names]
+    if flame and getattr(model, "flame_param", None) is not None:
+        keys = [k for k, v in model.flame_param.items() if v.requires_grad]
+        targets += [model.flame_param[k] for k in keys]
+    else:
+        keys = []
+    with torch.no_grad():
+        for lane in lanes:
+            srcs = [getattr(lane, n).grad for n in names] + [lane.flame_param[k].grad for k in keys]
+            dst, add = [], []
+            for t, g in zip(targets, srcs):
+                if g is None:
+                    continue
+                if t.grad is None:
+                    t.grad = g.detach().clone()
+                else:
+                    dst.append(t.grad)
+                    add.append(g)
+            if dst:
+                torch._foreach_add_(dst, add)
 
 
 class CapacityOverflow(RuntimeError):
@@ -200,6 +251,12 @@ class FlameRowFeeder:
         if getattr(self, "schedule", None) is None:
             raise RuntimeError("FlameRowFeeder.feed_next(): call set_schedule(frames) first (the order of the frames lives on the device)")
         dev = self.packed.device
+        if dev.type != "cuda":   # host tensors (the gloo dry run of the frame-parallel plumbing): the same walk, in Python
+            n = int(self.schedule.numel())
+            c = int(self.cursor.item()) % n
+            self.feed(int(self.schedule[c].item()))
+            self.cursor.fill_((c + 1) % n)
+            return
         with _lib.on_device(dev):
             rc = _lib.gab().gab_feed_row(C.c_void_p(self.packed.data_ptr()), self.T, int(self.packed.shape[1]), C.c_void_p(self.schedule.data_ptr()),
                                          int(self.schedule.numel()), C.c_void_p(self.cursor.data_ptr()), C.c_void_p(self.row.data_ptr()),

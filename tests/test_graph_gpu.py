@@ -337,3 +337,82 @@ def test_recorded_step_in_a_training_loop_with_an_optimiser():
         step.close()
     finally:
         R.set_deterministic(prev)
+
+
+def test_lanes_on_shared_leaves_accumulate_like_sequential_backwards():
+    """graphs.shared_lane_model + accumulate_lane_grads (round 4): two recorded lanes on two streams read ONE set of splat parameters and
+    write their own gradients; added up in lane order they are, with the deterministic backward, the BITS of loss_a.backward();
+    loss_b.backward() on the one model (gradient accumulation over the lanes' frames), FLAME rows included; an optimiser step on the
+    shared storage is seen by every lane's next replay."""
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd.graphs import FlameRowFeeder, GraphedStep, accumulate_lane_grads, shared_lane_model
+
+    dev = _dev()
+    g, cam = _scene(dev)
+    bg = torch.ones(3, device=dev)
+    target = torch.full((3, 176, 208), 0.5, device=dev)
+    prev = R.set_deterministic(True)
+    try:
+        frames = (2, 9)
+        # ---- the reference result: two frames accumulated on ONE model, eagerly
+        _zero(g)
+        want_loss = []
+        for t in frames:
+            from gaussianavatars_amd.graphs import release_mesh
+
+            release_mesh(g)
+            want_loss.append(_step(g, cam, bg, target, t)[0].clone())
+        want = [getattr(g, n).grad.clone() for n in _LEAVES]
+        want_flame = {k: v.grad.clone() for k, v in g.flame_param.items() if v.requires_grad}
+        _zero(g)
+        # ---- two lanes over the same storage, each with its own recording, feeder and stream
+        lanes = []
+        for t in frames:
+            m = shared_lane_model(g)
+            feeder = FlameRowFeeder(m.flame_param, requires_grad=True)
+            full = m.flame_param
+            m.flame_param = feeder.static_param
+            step = GraphedStep(lambda m=m: _step(m, cam, bg, target, 0)[0], before_capture=lambda m=m: _zero(m))
+            lanes.append(dict(m=m, feeder=feeder, step=step, stream=torch.cuda.Stream(dev), t=t, full=full))
+        cur = torch.cuda.current_stream(dev)
+        outs = []
+        for ln in lanes:
+            ln["stream"].wait_stream(cur)
+            with torch.cuda.stream(ln["stream"]):
+                ln["feeder"].feed(ln["t"])
+                outs.append(ln["step"].replay())
+        for ln in lanes:
+            cur.wait_stream(ln["stream"])
+        # the lanes' FLAME gradients are one-row tables: scatter them to the rows of the frames they rendered before adding up
+        accumulate_lane_grads(g, [ln["m"] for ln in lanes], flame=False)
+        torch.cuda.synchronize()
+        for ln, wl, out in zip(lanes, want_loss, outs):
+            ln["step"].check()
+            assert torch.equal(out, wl)
+        for n, w in zip(_LEAVES, want):
+            assert torch.equal(getattr(g, n).grad, w), n
+        for k, w in want_flame.items():
+            if k not in FlameRowFeeder.ROWS:
+                continue
+            got = torch.zeros_like(w)
+            for ln in lanes:
+                got[ln["t"]] += ln["m"].flame_param[k].grad.reshape(-1)
+            assert torch.equal(got, w), k
+        # ---- one optimiser step on the shared storage: the lanes' next replays render the moved splats
+        with torch.no_grad():
+            g._xyz.add_(0.01 * torch.sign(g._xyz.grad))
+        _zero(g)
+        from gaussianavatars_amd.graphs import release_mesh
+
+        release_mesh(g)
+        ref_loss = _step(g, cam, bg, target, frames[0])[0].clone()
+        with torch.cuda.stream(lanes[0]["stream"]):
+            lanes[0]["stream"].wait_stream(cur)
+            lanes[0]["feeder"].feed(frames[0])
+            out = lanes[0]["step"].replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref_loss) and not torch.equal(out, want_loss[0])
+        for ln in lanes:
+            ln["step"].close()
+    finally:
+        R.set_deterministic(prev)
