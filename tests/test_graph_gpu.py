@@ -397,7 +397,8 @@ def test_lanes_on_shared_leaves_accumulate_like_sequential_backwards():
             got = torch.zeros_like(w)
             for ln in lanes:
                 got[ln["t"]] += ln["m"].flame_param[k].grad.reshape(-1)
-            assert torch.equal(got, w), k
+            # (the binding kernels' reductions run over a (T, k) table in the eager frames and over the lane's one-row table here: same sums, not the same order)
+            assert torch.allclose(got, w, rtol=1e-4, atol=1e-7 * float(w.abs().max())), k
         # ---- one optimiser step on the shared storage: the lanes' next replays render the moved splats
         with torch.no_grad():
             g._xyz.add_(0.01 * torch.sign(g._xyz.grad))
