@@ -2,7 +2,7 @@
 # Collects the rocprofv3 evidence for profiles/ on a GPU box:  bash tools/collect_profiles.sh <tag>   (e.g. r02_a)
 # kernel stats and the two PMC counters are separate runs (PMC is never combined with other trace domains).
 set -u
-TAG=${1:-r03_x}
+TAG=${1:-r04_x}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
@@ -23,9 +23,12 @@ timeout 200 python bench.py --steps 150 --warmup 30 --no-cpu-baseline --frame-st
 timeout 200 python bench.py --workload cfg2 --steps 300 --warmup 40 --no-cpu-baseline --frame-streams 0 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg2.json
 timeout 200 python bench.py --workload cfg4 --steps 100 --warmup 20 --no-cpu-baseline --frame-streams 0 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg4.json
 timeout 200 python bench.py --workload cfg5 --steps 40 --warmup 8 --no-cpu-baseline --frame-streams 0 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg5.json
-timeout 200 python bench.py --workload cfg5 --steps 40 --warmup 8 --no-cpu-baseline --frame-streams 0 --spatial-sort 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg5_morton.json
+timeout 200 python bench.py --workload cfg5 --steps 40 --warmup 8 --no-cpu-baseline --frame-streams 0 --no-spatial-sort 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg5_as_generated.json
 # the plain default line (cpu_baseline, frame_streams leg), the train workload, and the recorded step pinned / un-pinned beside the eager loop un-pinned
 timeout 400 python bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench_default.json
+timeout 400 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${TAG}_bench_driver_style.json
+timeout 200 python bench.py --steps 150 --warmup 30 --no-cpu-baseline --frame-streams 0 --no-spatial-sort 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3_as_generated.json
+timeout 300 python bench.py --graph --streams 4 --steps 100 --warmup 20 --no-cpu-baseline --no-kernel-profile 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3_4lanes_shared.json
 timeout 200 python bench.py --workload train --steps 100 --warmup 20 --no-cpu-baseline --frame-streams 0 2>/dev/null | tail -1 > $OUT/${TAG}_bench_train.json
 G="--steps 200 --warmup 30 --no-cpu-baseline --no-kernel-profile --frame-streams 0"
 timeout 200 python bench.py --graph $G 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3_graph.json
