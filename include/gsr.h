@@ -33,7 +33,9 @@ extern "C" {
 #define GSR_BWD_SEGMENTS 10       /* segments per quadrant stream; the last one takes whatever is left                */
 #define GSR_UNIT_LISTS 64         /* fast blend: the backward's work units (quadrant, segment) are appended to this many lists (GsrImageLayout.units) */
 #define GSR_BIN_BLOCKS 256        /* workgroups of the two binning passes (each owns a contiguous chunk of splats) */
+#ifndef GSR_RANK_BLOCKS
 #define GSR_RANK_BLOCKS 256       /* the same for the rank path (csrc/gsr_rank.hip), 1024 threads each: one per CU (swept 64..512)  */
+#endif
 #define GSR_BLOCK_X 16
 #define GSR_BLOCK_Y 16
 
