@@ -522,7 +522,10 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
             if (int rc = ensure_dynamic_lds((const void*)gsr::k_rcount, (size_t)count_lds)) return rc;
         }
         if (hist_bytes > 48 * 1024)
-            if (int rc = ensure_dynamic_lds((const void*)gsr::k_rscatter, (size_t)hist_bytes)) return rc;
+        {
+            if (int rc = ensure_dynamic_lds((const void*)gsr::k_rscatter<16>, (size_t)hist_bytes)) return rc;
+            if (int rc = ensure_dynamic_lds((const void*)gsr::k_rscatter<8>, (size_t)hist_bytes)) return rc;
+        }
         uint32_t* block_hist = (uint32_t*)(b + bl.block_hist);
         uint32_t* bcount = (uint32_t*)(b + bl.bcount);
         uint32_t* bstart = (uint32_t*)(b + bl.bstart);
@@ -576,7 +579,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         }
         if (pblocks > 0) {
             TIMED(GSR_K_SCATTER, stream);
-            hipLaunchKernelGGL(gsr::k_rscatter, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), hist_bytes, stream, P, gx, tiles, bt,
+            hipLaunchKernelGGL(nbands > 1 ? gsr::k_rscatter<8> : gsr::k_rscatter<16>, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), hist_bytes, stream, P, gx, tiles, bt,
                                (const ushort4*)srect, (const uint32_t*)rank, (const float4*)pa.sspan, (const uint32_t*)tile_start, tile_cursor, ranks, cap,
                                (const unsigned long long*)total_dev, (const uint32_t*)block_hist);
             KERNEL_CHECK("k_rscatter", stream, dbg);

@@ -34,7 +34,9 @@
 #define GSR_RANK_MAX_SPLATS 262144 // ranks one tile bitmap holds (8192 words of LDS: k_tile_rank); frames with more splats rank them per band of tile rows
 #define GSR_RANK_TILE_THREADS 512 // threads of a k_tile_rank workgroup (a tile); swept 256 / 512 / 1024: 29 / 21 / 31 us at cfg3
 #define GSR_RANK_WINDOW 4096     // k_tile_rank: entries of the sorted list per epilogue round (16 per thread)
+#ifndef GSR_RANK_GROUP
 #define GSR_RANK_GROUP 16         // lanes that expand one splat's tile rect together in k_rcount / k_rscatter (4 splats per wave at a time)
+#endif
 #define GSR_RANK_BIN_THREADS 1024 // threads per workgroup of k_rcount / k_rdscatter / k_rscatter (<= GSR_BIN_BLOCKS workgroups: 16 waves each keep the SIMDs busy)
 
 #include "bind_math.h"
@@ -634,6 +636,7 @@ __global__ void k_band_rank(const BinHeader* hdr, const uint2* obs, uint32_t nba
 __global__ void k_rdsort(const uint32_t* bcount, const uint32_t* bstart, unsigned long long* dkeys, unsigned long long* tmp,
                          uint32_t* rank, uint2* obs, const ushort4* srect, int band_rows, int tiles, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, uint2* ranges,
                          uint32_t* tile_order, uint4* tdesc, unsigned long long* total_dev, unsigned long long* mailbox, unsigned long long seq, unsigned long long post_capacity);
+template <int G>
 __global__ void k_rscatter(int P, int gx, int tiles, BandTables bt, const ushort4* srect, const uint32_t* rank, const float4* sspan, const uint32_t* tile_start,
                            uint32_t* tile_cursor, uint2* ranks, unsigned long long capacity, const unsigned long long* total_dev, const uint32_t* block_hist);
 __global__ void k_tile_rank(uint32_t words, int gx, int nbands, float inv_band_rows, const uint4* tdesc, const uint2* ranks,

@@ -40,15 +40,15 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return ~wave_max_
 // pass latency-bound.  Rects beyond BIG tiles are expanded by the whole wave, one splat at a time, so that a screen-filling splat
 // does not serialise one group for thousands of iterations.  Must be called by all 64 lanes; every lane of a group passes the same
 // rect (n == 0 for idle groups).  f(x, y, src_lane): src_lane = the lane whose splat this tile belongs to (lane of its group).
-template <typename F>
+template <int G = GSR_RANK_GROUP, typename F>
 __device__ __forceinline__ void for_each_tile_grouped(int minx, int miny, int maxx, int maxy, uint32_t n, F f)
 {
     constexpr uint32_t BIG = 256;
-    const int lane = lane_id(), sub = lane & (GSR_RANK_GROUP - 1);
+    const int lane = lane_id(), sub = lane & (G - 1);
     if (n > 0 && n <= BIG) {
         const uint32_t w = (uint32_t)(maxx - minx);
         const float rw = __builtin_amdgcn_rcpf((float)w);      // k / w = floor((k + 0.5) * (1 / w)): exact for k < 2^15
-        for (uint32_t k = (uint32_t)sub; k < n; k += GSR_RANK_GROUP) {
+        for (uint32_t k = (uint32_t)sub; k < n; k += G) {
             const uint32_t row = (uint32_t)(((float)k + 0.5f) * rw);
             f((uint32_t)minx + k - row * w, (uint32_t)miny + row, lane);
         }
@@ -476,6 +476,9 @@ __global__ __launch_bounds__(256) void k_band_rank(const BinHeader* __restrict__
 // copy) was SLOWER at those sizes (26 -> 34 us, 45 -> 58 us: the runs of one (workgroup, tile) pair are only ~4 entries long) and is not
 // kept; for the band mode of large frames the runs would have to come from splats grouped by band first.
 // ------------------------------------------------------------------------------------------
+// G lanes expand one splat's rect together: 16 where a rect holds ~18 tiles (100 k - 200 k splats at 802 x 550), 8 on the large frames of the
+// band mode, whose rects are smaller (2 M splats at 1600 x 1100: ~12 tiles; k_rscatter 303 -> 265 us; at 100 k splats 8 lanes cost 28.6 -> 31 us)
+template <int G>
 __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx, int tiles, BandTables bt, const ushort4* __restrict__ srect,
                                                                     const uint32_t* __restrict__ rank, const float4* __restrict__ sspan,
                                                                     const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
                                                                     const uint32_t* __restrict__ block_hist)
 {
     extern __shared__ uint32_t hist[];
-    constexpr int NT = GSR_RANK_BIN_THREADS, G = GSR_RANK_GROUP;
+    constexpr int NT = GSR_RANK_BIN_THREADS;
     if (*total_dev > capacity) return;  // the host will grow the buffer and replay the frame
     const int tid = threadIdx.x;
     const bool direct = rank_direct(gx, tiles);
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
         Span sp;
         sp.px = cur.s0.x; sp.py = cur.s0.y; sp.B = cur.s0.z; sp.det = cur.s0.w;
         sp.twoTA = cur.s1.x; sp.A = cur.s1.y; sp.dyr = cur.s1.z; sp.mode = __float_as_int(cur.s1.w);
-        for_each_tile_grouped(minx, miny, maxx, maxy, n, [&](uint32_t x, uint32_t y, int src) {
+        for_each_tile_grouped<G>(minx, miny, maxx, maxy, n, [&](uint32_t x, uint32_t y, int src) {
             const int me = lane_id();
             Span b = sp;
             uint4 brk4 = rk;
@@ -554,6 +557,11 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
         });
     }
 }
+
+template __global__ void k_rscatter<16>(int, int, int, BandTables, const ushort4*, const uint32_t*, const float4*, const uint32_t*, uint32_t*, uint2*, unsigned long long,
+                                        const unsigned long long*, const uint32_t*);
+template __global__ void k_rscatter<8>(int, int, int, BandTables, const ushort4*, const uint32_t*, const float4*, const uint32_t*, uint32_t*, uint2*, unsigned long long,
+                                       const unsigned long long*, const uint32_t*);
 
 // ------------------------------------------------------------------------------------------
 // The tile's sorted list -> its four quadrant streams, GSR_RANK_WINDOW entries at a time (striped like round 1's epilogue): every
