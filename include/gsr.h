@@ -104,9 +104,10 @@ typedef struct GsrSettings {
                                  polynomial, no contraction): image, final_T and n_contrib are bit-identical to oracle/gsr_oracle.c -- the mode
                                  every bit-exact parity test runs in.
                                  !=0 (what render() passes): the blend works in the 2^x domain -- k_preprocess stores the conic pre-multiplied by
-                                 -log2(e)/2 (the record's A, B, C slots then hold A' = -A log2(e)/2, B' = -B log2(e), C' = -C log2(e)/2), the
-                                 exponential is the hardware's v_exp_f32 (~1 ulp), products are fused -- about a third fewer instructions per
-                                 record in both kernels.  Everything integer (radii, rects, tiles_touched, keys, lists, ranges) is unchanged;
+                                 -log2(e)/2 (the record's A, B, C slots then hold A' = -A log2(e)/2, B' = -B log2(e), C' = -C log2(e)/2) and,
+                                 since ABI 10, log2(opacity) in the opacity's slot (alpha = 2^(quadratic + log2 opacity): see GsrGeomLayout.grec), the
+                                 exponential is the hardware's v_exp_f32 (~1 ulp), products are fused -- about half the instructions per
+                                 record of the exact forward kernel.  Everything integer (radii, rects, tiles_touched, keys, lists, ranges) is unchanged;
                                  the image agrees with the exact mode to ~1e-6 except where a record's alpha sits within an ulp of 1/255 or a
                                  pixel's transmittance within an ulp of 1e-4 (the record is then taken on one side and skipped on the other: a
                                  difference bounded by 1/255 resp. 1e-4 per such pixel; tests/test_fast_blend_gpu.py counts them).  Same value in
@@ -124,7 +125,11 @@ typedef struct GsrGeomLayout {
                               tile sort gathers per instance and what the two blend kernels fetch (scalar loads) per
                               stream entry:  (x, y, A, B | C, opacity, r, g | b, e, 0, 0)
                               x,y = pixel centre, A,B,C = conic, e = (int32 bits) the splat's fixed-point exponent of the
-                              deterministic backward                                                    */
+                              deterministic backward.  FAST BLEND (GsrSettings.fast_blend, effective): the record is
+                              (x, y, A', B' | C', L, r, g | b, hi, opacity, 0) -- the conic pre-scaled into the 2^x domain, L = log2(opacity)
+                              (NaN for an opacity below 1/255: such a splat fails every test), hi = 2^L (1 + 2^-18) the upper bound of the
+                              blend's acceptance test 1/255 <= 2^(A'dx^2 + B'dx dy + C'dy^2 + L) <= hi (= the reference's
+                              `power <= 0`), and the opacity itself in slot 10 for the backward                          */
     size_t cov3D;          /* float  [6P]  xx xy xz yy yz zz                */
     size_t rect;           /* uint16 [4P]  tile rect min.x min.y max.x max.y */
     size_t tiles_touched;  /* uint32 [P]                                   */
