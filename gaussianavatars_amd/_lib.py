@@ -214,6 +214,8 @@ GAB_SYMBOLS = {
     "gab_flame_prepared_floats": (C.c_int64, [C.POINTER(GabRig)]),
     "gab_flame_prepare": (C.c_int, [C.POINTER(GabRig), _P, _P, _P, _P]),
     "gab_flame_forward_prepared": (C.c_int, [C.POINTER(GabRig), _P] + [_P] * 6 + [_P, _P, _P, _P]),
+    "gab_blend_sequence": (C.c_int, [C.POINTER(GabRig), _P, _P, C.c_int32, _P, _P]),
+    "gab_flame_forward_sequence": (C.c_int, [C.POINTER(GabRig), _P, _P] + [_P] * 6 + [_P, _P, _P, _P]),
     "gab_flame_backward_prepared": (C.c_int, [C.POINTER(GabRig), _P] + [_P] * 4 + [_P, _P, _P] + [_P] * 6 + [_P] +
                                     [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _P]),
     "gab_mesh_backward_prepared": (C.c_int, [C.POINTER(GabRig), _P] + [_P] * 4 + [_P, _P, _P, _P, _P] + [_P] * 5 + [_P] * 6 + [_P] +
@@ -243,8 +245,8 @@ def gab():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.gab_abi_version() != 3:
-            raise RuntimeError(f"gab ABI version {lib.gab_abi_version()} != 3")
+        if lib.gab_abi_version() != 4:
+            raise RuntimeError(f"gab ABI version {lib.gab_abi_version()} != 4")
         _gab = lib
     return _gab
 

@@ -112,6 +112,44 @@ def _prepared_rig(head, rig, shape_flat, so_flat):
     return c[1]
 
 
+def _sequence_mode() -> str:
+    import os
+
+    return os.environ.get("GAA_MESH_SEQUENCE", "off")
+
+
+def _sequence_table(head, rig, prepared, expr_tab):
+    """Render mode over a timestep sequence (render.py:68-76, fps_benchmark_dataset.py:19-32: select_mesh_by_timestep under no_grad, frame
+    after frame of one avatar): `v_shaped` of ALL T frames as one fp32-MFMA product (include/gab.h: gab_blend_sequence, the one GEMM-shaped
+    product of the path), cached on the head and keyed on the prepared rig and on the expression table's identity and in-place version;
+    a frame then takes its row (gab_flame_forward_sequence) instead of re-reading the 6 MB expression block.  Built on the SECOND
+    gradient-free call that sees the same key (a training loop whose optimiser rewrites `expr` between two evaluation frames never pays
+    for a table it would use once); tables beyond 1 GiB are not built.  OFF by default -- measured, it does not pay: the per-frame kernel
+    already hides its GEMV behind the joint chain (cfg2: 6444 frames/s without the table, 6375 with it; DESIGN.md section 8) --;
+    GAA_MESH_SEQUENCE=auto enables the behaviour above, =eager builds on the first call.  Returns the (T, 3V) table or None."""
+    mode = _sequence_mode()
+    if mode == "off" or getattr(head, "flame_sequence", True) is False or rig.n_expr <= 0:
+        return None
+    T = int(expr_tab.shape[0])
+    if T < 2 or T * 3 * rig.V * 4 > (1 << 30):
+        return None
+    key = (prepared.data_ptr(), id(prepared), expr_tab.data_ptr(), expr_tab._version, T)
+    c = getattr(head, "_gab_sequence", None)
+    if c is not None and c[0] == key:
+        if c[1] is not None:
+            return c[1]
+    elif mode != "eager":
+        head._gab_sequence = (key, None, None, None)   # seen once: the next gradient-free frame of this table builds it
+        return None
+    lib = _lib.gab()
+    dev = expr_tab.device
+    seq = torch.empty((T, 3 * rig.V), dtype=torch.float32, device=dev)
+    with _lib.on_device(dev):
+        _chk(lib.gab_blend_sequence(C.byref(rig), _p(prepared), _p(expr_tab), T, _p(seq), _stream(dev)), "gab_blend_sequence")
+    head._gab_sequence = (key, seq, prepared, expr_tab)   # (the sources stay alive: their addresses are part of the key)
+    return seq
+
+
 def _use_prepared(head, shape_needs_grad, so_needs_grad) -> bool:
     """One launch forward / two backward (prepared rig) when neither shape nor static_offset is being optimised -- the
     reference's training setup (scene/flame_gaussian_model.py:155-178 puts only the per-timestep parameters in the optimiser).
@@ -221,8 +259,13 @@ class _FlameForwardTimestep(torch.autograd.Function):
         ws = torch.empty(_lib.GAB_FLAME_WS_FLOATS, dtype=torch.float32, device=dev)
         need = ctx.needs_input_grad  # (head, t, shape, expr, rotation, neck, jaw, eyes, translation, static_offset)
         ctx.prepared = _prepared_rig(head, rig, sh, so) if _use_prepared(head, need[2], so is not None and need[9]) else None
+        # gradient-free frames of a sequence (render mode) take their row of the MFMA-made v_shaped table
+        seq = _sequence_table(head, rig, ctx.prepared, tabs[0]) if (ctx.prepared is not None and not any(need[2:])) else None
         with _lib.on_device(dev):
-            if ctx.prepared is not None:
+            if seq is not None:
+                _chk(lib.gab_flame_forward_sequence(C.byref(rig), _p(ctx.prepared), seq.data_ptr() + 4 * t * 3 * V, *rows, _p(verts), _p(v_shaped),
+                                                    _p(ws), _stream(dev)), "gab_flame_forward_sequence")
+            elif ctx.prepared is not None:
                 _chk(lib.gab_flame_forward_prepared(C.byref(rig), _p(ctx.prepared), *rows, _p(verts), _p(v_shaped), _p(ws), _stream(dev)),
                      "gab_flame_forward_prepared")
             else:

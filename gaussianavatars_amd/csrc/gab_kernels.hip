@@ -364,8 +364,10 @@ __global__ __launch_bounds__(256) void k_flame_fused(Rig rig, const float* __res
                                                       const float* __restrict__ rotation, const float* __restrict__ neck,
                                                       const float* __restrict__ jaw, const float* __restrict__ eyes,
                                                       const float* __restrict__ translation, float* __restrict__ verts,
-                                                      float* __restrict__ v_shaped, float* __restrict__ ws)
+                                                      float* __restrict__ v_shaped, float* __restrict__ ws, const float* __restrict__ vs_pre)
 {
+    // vs_pre != NULL: this frame's row of the SEQUENCE table (k_blend_seq_mfma: v_shaped of every frame of an expression sequence as one
+    // fp32-MFMA product) -- the expression block of the blend shapes (6 MB per frame) is then neither read nor multiplied here
     constexpr int VW = GAB_FUSED_VERTS, ROWS = 3 * VW, PER = ROWS / 8;   // rows per half-wave (8 half-waves)
     __shared__ float out[WS_DA];        // the forward half of the workspace: J, R, pose features, A
     __shared__ float vs[ROWS];          // this workgroup's rows of v_shaped
@@ -381,7 +383,9 @@ __global__ __launch_bounds__(256) void k_flame_fused(Rig rig, const float* __res
     float acc[PER];
 #pragma unroll
     for (int r = 0; r < PER; ++r) acc[r] = 0.f;
-    if (vec) {
+    if (vs_pre) {
+        // nothing to multiply
+    } else if (vec) {
         float4 rw[PER];
         const float4 b = hl < nq ? reinterpret_cast<const float4*>(expr)[hl] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(256) void k_flame_fused(Rig rig, const float* __res
         a += dpp_f<0x142, 0xa>(a);   // lanes 16..31 / 48..63 now hold their half-wave's sum
         const int e = e0 + hw * PER + r;
         if (hl == 31 && e < E) {
-            const float x = prepared[e] + a;
+            const float x = vs_pre ? vs_pre[e] : prepared[e] + a;
             vs[hw * PER + r] = x;
             v_shaped[e] = x;
         }
@@ -1358,6 +1362,126 @@ __global__ __launch_bounds__(256) void k_bind_bwd_faces(int F, const int* __rest
 // one launch that zero-fills up to 8 small buffers (the full-table gradients of the per-timestep FLAME rows)
 // The frame feed of a recorded step (graphs.py): row schedule[cursor % n] of the packed per-timestep table -> the static one-row table the
 // recorded kernels read; then the cursor moves on.  One workgroup; every thread reads the cursor before thread 0 advances it.
+// ---------------------------------------------------------------------------------------------
+// k_blend_seq_mfma: v_shaped of EVERY frame of an expression sequence in one launch,
+//     out[t][e] = prepared[e] + sum_l shapedirs[e][n_shape + l] * expr[t][l]      (T x n_expr) . (n_expr x 3V), fp32,
+// on the matrix cores: v_mfma_f32_32x32x2_f32, one wave per 32 frames x 32 outputs.  This is the one GEMM-shaped product of the path
+// (SURVEY.md H9): per frame it is a GEMV that re-reads the 6 MB expression block, batched over the T frames of a sequence it is
+// 2 T n_expr 3V flops (0.93 GFLOP at T = 300) on 6 MB + the 4 T 3V bytes it writes.  Operand layout of the instruction (one float per lane):
+// A[m][k]: m = lane % 32, k = lane / 32;  B[k][n]: k = lane / 32, n = lane % 32;  D[i][j] in 16 registers: j = lane % 32,
+// i = 8 (v / 4) + 4 (lane / 32) + v % 4.  The two k-slots of a step are fed from the two HALVES of the k range (lane half h walks
+// k = h K/2 + s: any bijection of k onto (step, slot) gives the same sum), so that every lane streams through contiguous floats of its row.
+// fp32 in, fp32 accumulate: the instruction is an exact fma chain; against the per-frame kernel (float4 partial sums + DPP) the sums differ
+// in order only (tests: <= 1e-6 of the value range).
+// ---------------------------------------------------------------------------------------------
+typedef float gab_v16f __attribute__((ext_vector_type(16)));
+#define GAB_SEQ_KMAX 100          // expression coefficients the LDS-staged product holds per tile row (FLAME: 100)
+__global__ __launch_bounds__(256) void k_blend_seq_mfma(Rig rig, const float* __restrict__ prepared, const float* __restrict__ expr, int T, int MT,
+                                                         float* __restrict__ out)
+{
+    // One workgroup = 128 outputs (four waves, 32 each) x MT tiles of 32 frames.  The operand tiles go through LDS: a lane's operands walk
+    // along ITS row (32 rows per wave), which as global loads is 64 cache lines per instruction -- the texture path, not the matrix core,
+    // paced the first version (54 us at T = 300) --; staged, the rows arrive as coalesced float4 streams and are read back bank-conflict-free
+    // (row stride 101 floats).  The table tile (51 KB) is staged ONCE and kept for all MT frame tiles -- re-staging it per frame tile made
+    // the kernel L2-bandwidth-bound (64 KB in for 1.3 us of matrix work per workgroup: 38 us at T = 300) --; the coefficient tile of the
+    // next frame tile is in flight in registers while the matrix core works on the current one (two LDS buffers, one barrier per tile).
+    __shared__ float tiles[6][32][GAB_SEQ_KMAX + 1];   // [0], [1]: the two coefficient buffers; [2 + wave]: the table tile of each wave
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int E = 3 * rig.V, K = rig.n_expr, NB = rig.n_shape + rig.n_expr;
+    const int nb0 = (int)blockIdx.x * 128, n0 = nb0 + wid * 32;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int Kh = (K + 1) / 2, kbeg = half * Kh, kend = min(K, kbeg + Kh);
+    const bool staged = K <= GAB_SEQ_KMAX && (K & 3) == 0 && (rig.n_shape & 3) == 0 && (NB & 3) == 0;
+    const int e = n0 + l32;
+    const float base = e < E ? prepared[e] : 0.f;
+    const int mt0 = (int)blockIdx.y * MT, mt1 = min(mt0 + MT, (T + 31) / 32);
+    if (staged) {
+        const int q = K >> 2;   // float4 per row
+        constexpr int A_IT = (32 * GAB_SEQ_KMAX / 4 + 255) / 256, B_IT = (128 * GAB_SEQ_KMAX / 4 + 255) / 256, KH = GAB_SEQ_KMAX / 2;
+        // LDS column of coefficient k: the lane half that owns it (k / Kh) times KH, plus its step.  Columns no coefficient maps to stay
+        // zero, so the product loop below is KH unmasked steps whatever K is (K = 100: the identity).
+        auto col = [&](int k) { return k >= Kh ? KH + k - Kh : k; };
+        if (K < GAB_SEQ_KMAX) {
+            for (int i = tid; i < 6 * 32 * (GAB_SEQ_KMAX + 1); i += 256) (&tiles[0][0][0])[i] = 0.f;
+            __syncthreads();
+        }
+        float4 va[A_IT];
+        auto fetch_a = [&](int mt) {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const int i = tid + 256 * it, r = i / q, c = i - r * q;
+                if (i < 32 * q) va[it] = *reinterpret_cast<const float4*>(expr + (size_t)min(32 * mt + r, T - 1) * K + 4 * c);
+            }
+        };
+        auto park_a = [&](int buf) {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const int i = tid + 256 * it, r = i / q, c = i - r * q;
+                if (i < 32 * q) { float* d = tiles[buf][r]; d[col(4 * c)] = va[it].x; d[col(4 * c + 1)] = va[it].y; d[col(4 * c + 2)] = va[it].z; d[col(4 * c + 3)] = va[it].w; }
+            }
+        };
+        fetch_a(mt0);
+        {
+            float4 vb[B_IT];   // every load in flight before the first LDS store: one memory latency per tile, not one per row
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) {
+                const int i = tid + 256 * it, r = i / q, c = i - r * q;
+                if (i < 128 * q) vb[it] = *reinterpret_cast<const float4*>(rig.shapedirs + (size_t)min(nb0 + r, E - 1) * NB + rig.n_shape + 4 * c);
+            }
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) {
+                const int i = tid + 256 * it, r = i / q, c = i - r * q;
+                if (i < 128 * q) { float* d = tiles[2 + (r >> 5)][r & 31]; d[col(4 * c)] = vb[it].x; d[col(4 * c + 1)] = vb[it].y; d[col(4 * c + 2)] = vb[it].z; d[col(4 * c + 3)] = vb[it].w; }
+            }
+        }
+        int buf = 0;
+        for (int mt = mt0; mt < mt1; ++mt, buf ^= 1) {
+            park_a(buf);
+            __syncthreads();
+            if (mt + 1 < mt1) fetch_a(mt + 1);
+            gab_v16f acc;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+            const float* __restrict__ ap = &tiles[buf][l32][half * KH];
+            const float* __restrict__ bp = &tiles[2 + wid][l32][half * KH];
+#pragma unroll
+            for (int g = 0; g < KH; g += 10) {   // ten steps' operands in flight ahead of their matrix instructions
+                float a[10], b[10];
+#pragma unroll
+                for (int u = 0; u < 10; ++u) { a[u] = ap[g + u]; b[u] = bp[g + u]; }
+#pragma unroll
+                for (int u = 0; u < 10; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+            }
+            if (e < E) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int t = 32 * mt + 8 * (v >> 2) + 4 * half + (v & 3);
+                    if (t < T) out[(size_t)t * E + e] = base + acc[v];
+                }
+            }
+        }
+    } else {
+        if (n0 >= E) return;
+        const float* __restrict__ brow = rig.shapedirs + (size_t)min(n0 + l32, E - 1) * NB + rig.n_shape;   // B[k][n = l32]
+        for (int mt = mt0; mt < mt1; ++mt) {
+            const float* __restrict__ arow = expr + (size_t)min(32 * mt + l32, T - 1) * K;                      // A[m = l32][k]
+            gab_v16f acc;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+            for (int s = 0; s < Kh; ++s) {
+                const int k = kbeg + s;
+                const float a = k < kend ? arow[k] : 0.f, b = k < kend ? brow[k] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int t = 32 * mt + 8 * (v >> 2) + 4 * half + (v & 3);
+                if (t < T && e < E) out[(size_t)t * E + e] = base + acc[v];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_feed_row(const float* __restrict__ packed, int T, int width, const int* __restrict__ schedule, int n_sched,
                                                    int* __restrict__ cursor, float* __restrict__ row)
 {
@@ -1518,9 +1642,46 @@ int gab_flame_forward_prepared(const GabRig* rig_, const float* prepared, const 
     const int blocks = (rig.V + GAB_FUSED_VERTS - 1) / GAB_FUSED_VERTS;
     const bool flame_tree = rig.parents[1] == 0 && rig.parents[2] == 1 && rig.parents[3] == 1 && rig.parents[4] == 1;
     if (flame_tree)
-        hipLaunchKernelGGL(gab::k_flame_fused<true>, dim3(blocks), dim3(256), 0, st, rig, prepared, expr, rotation, neck, jaw, eyes, translation, verts, v_shaped, ws);
+        hipLaunchKernelGGL(gab::k_flame_fused<true>, dim3(blocks), dim3(256), 0, st, rig, prepared, expr, rotation, neck, jaw, eyes, translation, verts, v_shaped, ws, (const float*)nullptr);
     else
-        hipLaunchKernelGGL(gab::k_flame_fused<false>, dim3(blocks), dim3(256), 0, st, rig, prepared, expr, rotation, neck, jaw, eyes, translation, verts, v_shaped, ws);
+        hipLaunchKernelGGL(gab::k_flame_fused<false>, dim3(blocks), dim3(256), 0, st, rig, prepared, expr, rotation, neck, jaw, eyes, translation, verts, v_shaped, ws, (const float*)nullptr);
+    LAUNCH_CHECK("k_flame_fused");
+    return GAB_OK;
+}
+
+int gab_blend_sequence(const GabRig* rig_, const float* prepared, const float* expr_table, int32_t T, float* v_shaped_seq, void* stream_)
+{
+    gab::Rig rig;
+    if (int rc = to_rig(rig_, &rig)) return rc;
+    if (T < 0 || (T > 0 && (!prepared || !expr_table || !v_shaped_seq))) return fail(GAB_E_ARG, "gab_blend_sequence: bad arguments");
+    if (T == 0) return GAB_OK;
+    if (rig.n_expr <= 0) return fail(GAB_E_ARG, "gab_blend_sequence: the rig has no expression block");
+    const int E = 3 * rig.V;
+    // frame tiles per workgroup: as many as keep the launch at about two workgroups per CU (what the LDS tiles allow), so that the table
+    // tile each workgroup stages is re-used instead of re-read
+    const int gx = ((E + 31) / 32 + 3) / 4, mtiles = (T + 31) / 32;
+    const int MT = std::min(16, std::max(1, (mtiles * gx + 511) / 512));
+    dim3 grid((unsigned)gx, (unsigned)((mtiles + MT - 1) / MT));
+    hipLaunchKernelGGL(gab::k_blend_seq_mfma, grid, dim3(256), 0, (hipStream_t)stream_, rig, prepared, expr_table, (int)T, MT, v_shaped_seq);
+    LAUNCH_CHECK("k_blend_seq_mfma");
+    return GAB_OK;
+}
+
+int gab_flame_forward_sequence(const GabRig* rig_, const float* prepared, const float* v_shaped_row, const float* expr, const float* rotation,
+                               const float* neck, const float* jaw, const float* eyes, const float* translation, float* verts, float* v_shaped,
+                               float* ws, void* stream_)
+{
+    gab::Rig rig;
+    if (int rc = to_rig(rig_, &rig)) return rc;
+    if (!prepared || !v_shaped_row || (rig.n_expr && !expr) || !rotation || !neck || !jaw || !eyes || !translation || !verts || !v_shaped || !ws)
+        return fail(GAB_E_ARG, "gab_flame_forward_sequence: NULL buffer");
+    hipStream_t st = (hipStream_t)stream_;
+    const int blocks = (rig.V + GAB_FUSED_VERTS - 1) / GAB_FUSED_VERTS;
+    const bool flame_tree = rig.parents[1] == 0 && rig.parents[2] == 1 && rig.parents[3] == 1 && rig.parents[4] == 1;
+    if (flame_tree)
+        hipLaunchKernelGGL(gab::k_flame_fused<true>, dim3(blocks), dim3(256), 0, st, rig, prepared, expr, rotation, neck, jaw, eyes, translation, verts, v_shaped, ws, v_shaped_row);
+    else
+        hipLaunchKernelGGL(gab::k_flame_fused<false>, dim3(blocks), dim3(256), 0, st, rig, prepared, expr, rotation, neck, jaw, eyes, translation, verts, v_shaped, ws, v_shaped_row);
     LAUNCH_CHECK("k_flame_fused");
     return GAB_OK;
 }

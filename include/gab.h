@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GAB_ABI_VERSION 3
+#define GAB_ABI_VERSION 4
 #define GAB_OK 0
 #define GAB_E_ARG (-1)
 #define GAB_E_HIP (-2)
@@ -86,6 +86,19 @@ int64_t gab_flame_prepared_floats(const GabRig* rig);
 int gab_flame_prepare(const GabRig* rig, const float* shape, const float* static_offset /*(V,3) or NULL*/, float* prepared, void* stream);
 int gab_flame_forward_prepared(const GabRig* rig, const float* prepared, const float* expr, const float* rotation, const float* neck,
                                const float* jaw, const float* eyes /*6*/, const float* translation,
+                               float* verts /*(V,3)*/, float* v_shaped /*(V,3)*/, float* ws /*GAB_FLAME_WS_FLOATS*/, void* stream);
+/* ---- a SEQUENCE of frames (render mode: render.py:68-76, fps_benchmark_dataset.py:19-32 walk the timesteps of one avatar under no_grad) ----
+ * gab_blend_sequence evaluates the expression block of the blend shapes (flame_model/lbs.py:218-239) for ALL T frames at once,
+ *     v_shaped_seq[t][e] = prepared[e] + sum_l shapedirs[e][n_shape + l] * expr_table[t][l],
+ * as one (T x n_expr) . (n_expr x 3V) fp32 product on the matrix cores (v_mfma_f32_32x32x2_f32) -- the one GEMM-shaped product of the path
+ * (SURVEY.md H9): per frame it is a GEMV over the same 6 MB table.  gab_flame_forward_sequence is gab_flame_forward_prepared for a frame
+ * whose row of that table is at hand (v_shaped_row = v_shaped_seq + t * 3V): the expression block is neither read nor multiplied again.
+ * Forward only (a frame that needs gradients takes gab_flame_forward_prepared); same outputs as the per-frame entry up to the
+ * summation order of the product (<= 1e-6 of the vertices' range, tests/test_binding_gpu.py).                                        */
+int gab_blend_sequence(const GabRig* rig, const float* prepared, const float* expr_table /*(T, n_expr)*/, int32_t T,
+                       float* v_shaped_seq /*(T, 3V)*/, void* stream);
+int gab_flame_forward_sequence(const GabRig* rig, const float* prepared, const float* v_shaped_row /*(3V)*/, const float* expr,
+                               const float* rotation, const float* neck, const float* jaw, const float* eyes /*6*/, const float* translation,
                                float* verts /*(V,3)*/, float* v_shaped /*(V,3)*/, float* ws /*GAB_FLAME_WS_FLOATS*/, void* stream);
 /* zero_*: as gab_flame_backward, at most 7 buffers (d_expr is zero-filled by the first kernel as well unless one of them covers it) */
 int gab_flame_backward_prepared(const GabRig* rig, const float* prepared, const float* rotation, const float* neck, const float* jaw,

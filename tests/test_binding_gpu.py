@@ -133,6 +133,55 @@ def test_flame_prepared_rig_path_vs_torch_and_classic():
     _close(v1b, v2b, 2e-5, "verts after an in-place shape update")
 
 
+def test_sequence_table_on_the_matrix_cores_equals_the_per_frame_kernel(monkeypatch):
+    """include/gab.h: gab_blend_sequence -- v_shaped of every frame of an expression sequence as ONE (T x 100) . (100 x 3V) fp32 product on
+    the matrix cores (v_mfma_f32_32x32x2_f32) -- and gab_flame_forward_sequence, the per-frame forward that takes its row of that table.
+    Stated tolerance: the product's terms are the per-frame kernel's, summed in another order: |difference| <= 1e-6 of the vertices' range
+    (measured ~1e-7); posed vertices likewise.  The table is built on the SECOND gradient-free frame of a table (binding._sequence_table),
+    used from then on, bypassed by frames that need gradients, and re-made when `expr` changes in place."""
+    from gaussianavatars_amd import binding as B
+
+    dev = _dev()
+    rig = S.flame_rig(4)
+    T = 45                                  # not a multiple of the 32-frame tiles
+    seq = S.flame_sequence(T, 4)
+    head = _Head(rig, dev, 300)
+    fp = {k: torch.as_tensor(v, device=dev).clone() for k, v in seq.items()}
+    monkeypatch.setenv("GAA_MESH_SEQUENCE", "off")
+    with torch.no_grad():
+        want = [B.flame_forward_timestep(head, fp, t) for t in range(T)]
+    monkeypatch.setenv("GAA_MESH_SEQUENCE", "auto")
+    with torch.no_grad():
+        B.flame_forward_timestep(head, fp, 0)
+        assert head._gab_sequence[1] is None                      # seen once: nothing built yet
+        got1 = B.flame_forward_timestep(head, fp, 1)
+        table = head._gab_sequence[1]
+        assert table is not None and tuple(table.shape) == (T, 3 * 5143)
+        got = [B.flame_forward_timestep(head, fp, t) for t in range(T)]
+        assert head._gab_sequence[1] is table                     # one table for the whole sequence
+    rng = float(torch.stack([w[1] for w in want]).abs().max())
+    for t in range(T):
+        (v, vs), (wv, wvs) = got[t], want[t]
+        assert float((table[t].view(-1) - wvs.view(-1)).abs().max()) <= 1e-6 * rng, t
+        assert torch.equal(vs.view(-1), table[t].view(-1))       # the frame's v_shaped IS its row
+        assert float((v - wv).abs().max()) <= 2e-6 * rng, t
+    assert float((got1[0] - want[1][0]).abs().max()) <= 2e-6 * rng
+    # a frame that needs gradients does not touch the table; its values are the per-frame kernel's
+    fpg = dict(fp, expr=fp["expr"].clone().requires_grad_(True))
+    v, _ = B.flame_forward_timestep(head, fpg, 7)
+    v.sum().backward()
+    assert fpg["expr"].grad is not None and head._gab_sequence[1] is table
+    # an in-place change of the expression table: the old table is not used again
+    with torch.no_grad():
+        fp["expr"].mul_(0.5)
+        B.flame_forward_timestep(head, fp, 3)                     # new key, seen once
+        v2, vs2 = B.flame_forward_timestep(head, fp, 3)           # builds
+        assert head._gab_sequence[1] is not table
+        monkeypatch.setenv("GAA_MESH_SEQUENCE", "off")
+        w2, ws2 = B.flame_forward_timestep(head, fp, 3)
+    assert float((vs2 - ws2).abs().max()) <= 1e-6 * rng and float((v2 - w2).abs().max()) <= 2e-6 * rng
+
+
 @pytest.mark.parametrize("with_verts_grad", [False, True])
 def test_mesh_backward_gather_equals_the_scatter_form(monkeypatch, with_verts_grad):
     """select_mesh_by_timestep + update_mesh_properties as one autograd node (binding.mesh_frames_timestep): its backward with the face-frame
