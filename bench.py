@@ -492,6 +492,11 @@ def main():
 
     all_cpus = os.sched_getaffinity(0)
     pinned = None if args.no_pin else pin_to_gpu_numa_node(local_rank)   # host launch latency: stay on the GPU's socket
+    seeded = os.environ.get("GAA_LOSS_SEED", "1") != "0"
+    if seeded:   # as patch_reference() does for train.py: `loss.backward()` is seeded with a cached device 1 (no one-element fill launch)
+        from gaussianavatars_amd.loss import install_backward_seed
+
+        install_backward_seed()
     if args.workload == "cfg5":
         g, cam = build_unbound_scene(device, args.splats, 3, args.width, args.height)
     else:
@@ -858,6 +863,7 @@ def main():
                                  args.workload] % (N, args.height, args.width),
                 "splats": N, "width": args.width, "height": args.height, "sh_degree": 3,
                 "splat_order": "morton (io.spatial_sort: the loaders' default)" if SPATIAL_SORT else "as generated (random; --no-spatial-sort)",
+                "backward_seed": "cached device scalar (loss.install_backward_seed, what patch_reference() installs)" if seeded else "torch (ones_like fill; GAA_LOSS_SEED=0)",
                 "num_rendered": I_rect, "num_binned": I_binned, "tile_culling": bool(info.get("tile_culling", False)),
                 "binning_path": {0: "rank", 1: "depth-ordered scatter", 2: "per-tile sort"}[path] + (f" ({bands} bands of tile rows)" if path == 0 and bands > 1 else ""),
                 "visible_fraction": round(vis, 4), "binding": args.binding,

@@ -275,8 +275,10 @@ def patch_reference(reference_root: str | None = None, fast_render: bool = True,
        (split-SH read in place, screen-space leaf without the zeros_like + 0 + retain_grad round trip).
     4. with pin (default; GAA_PIN=0 opts out), moves the process next to its GPU (frame_parallel.pin_host_process: the host conditions
        bench.py measures under -- the frame loop is host-paced; forked DataLoader workers keep the original CPU mask).
-    Returns {'shims': [...], 'classes': [...], 'render': bool, 'pinned_cpus': [...] | None}.  Call it before the entry script imports
-    `render`."""
+    5. (GAA_LOSS_SEED=0 opts out) installs loss.install_backward_seed: train.py's `loss.backward()` seeds the backward pass with a cached
+       device 1 instead of a one-element fill launch.
+    Returns {'shims': [...], 'classes': [...], 'render': bool, 'pinned_cpus': [...] | None, 'backward_seed': bool}.  Call it before the entry
+    script imports `render`."""
     from . import shims
 
     repo_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -305,4 +307,11 @@ def patch_reference(reference_root: str | None = None, fast_render: bool = True,
         from .frame_parallel import pin_host_process
 
         pinned = pin_host_process()
-    return dict(shims=served, classes=[gm.GaussianModel, fgm.FlameGaussianModel, flame.FlameHead], render=did_render, pinned_cpus=pinned)
+    seeded = False
+    if os.environ.get("GAA_LOSS_SEED", "1") != "0":
+        from .loss import install_backward_seed
+
+        install_backward_seed()
+        seeded = True
+    return dict(shims=served, classes=[gm.GaussianModel, fgm.FlameGaussianModel, flame.FlameHead], render=did_render, pinned_cpus=pinned,
+                backward_seed=seeded)

@@ -166,3 +166,44 @@ def test_training_iteration_statistics_and_loss():
     assert int(vis.sum()) > 1000
     assert torch.equal(g.max_radii2D, ref_max) and torch.equal(g.denom, ref_den)
     assert float((g.xyz_gradient_accum - ref_acc).abs().max()) <= 4e-7 * float(ref_acc.abs().max())
+
+
+def test_seeded_backward_gives_the_gradients_of_the_engines_own_seed():
+    """loss.install_backward_seed: `loss.backward()` as train.py:133 writes it, through the arithmetic of train.py:132, gives the gradients of
+    torch's own method bit for bit; explicit seeds and retain_graph pass through; uninstalling restores torch's method."""
+    from gaussianavatars_amd import loss as L
+
+    DEV = _dev()
+    a0 = torch.rand(3, 40, 52, device=DEV)
+    b = torch.rand(3, 40, 52, device=DEV)
+    L.install_backward_seed(False)
+    torch_backward = torch.Tensor.backward
+
+    def run():
+        a = a0.clone().requires_grad_(True)
+        l1, ss = L.l1_ssim(a, b)
+        loss = (1.0 - 0.2) * l1 + 0.2 * (1.0 - ss)
+        loss.backward(retain_graph=True)
+        g1 = a.grad.clone()
+        a.grad = None
+        loss.backward(torch.full((), 2.0, device=DEV))
+        return loss.detach().clone(), g1, a.grad.clone()
+
+    try:
+        v0, g0, h0 = run()
+        assert L.install_backward_seed() is True and L.install_backward_seed() is False
+        assert torch.Tensor.backward is not torch_backward
+        v1, g1, h1 = run()
+        assert torch.equal(v0, v1) and torch.equal(g0, g1) and torch.equal(h0, h1) and torch.equal(h1, 2.0 * g1)
+        assert (DEV, torch.float32) in L._UNIT_SEEDS
+        a = a0.clone().requires_grad_(True)
+        L.l1_loss(a, b).backward()
+        assert torch.equal(a.grad, torch.sign(a0 - b) / a0.numel())
+        c = torch.ones(3, requires_grad=True)                      # CPU tensors and non-scalars are torch's business
+        (c * 2).sum().backward()
+        assert torch.equal(c.grad, torch.full((3,), 2.0))
+        with pytest.raises(RuntimeError):
+            (a * 2).backward()
+    finally:
+        assert L.install_backward_seed(False) is True
+    assert torch.Tensor.backward is torch_backward
