@@ -94,7 +94,7 @@ SSIM_STEP = False   # --workload train: the loss and statistics lines of train.p
 
 _ZERO = {}
 # rocprofv3 kernel name -> the timing slot (include/gsr.h GSR_K_*) its launches are accounted under
-PMC_ALIAS = {"k_render_bwd_rp": "k_render_bwd", "k_rcount": "k_count", "k_rscatter": "k_scatter", "k_tile_rank": "k_tile_sort", "k_rdscatter": "k_depth_sort", "k_rdsort": "k_depth_sort",
+PMC_ALIAS = {"k_render_bwd_rp": "k_render_bwd", "k_rcount": "k_count", "k_rscatter": "k_scatter", "k_rsort_rscatter": "k_scatter", "k_tile_rank": "k_tile_sort", "k_rdscatter": "k_depth_sort", "k_rdsort": "k_depth_sort",
              "k_band_count": "k_depth_sort", "k_band_scan": "k_depth_sort", "k_band_rank": "k_depth_sort",
              "k_dbucket": "k_depth_sort", "k_dscan": "k_depth_sort", "k_dscatter": "k_depth_sort", "k_dsort": "k_depth_sort", "k_qscan_glob": "k_qscan"}
 

@@ -523,7 +523,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         }
         if (hist_bytes > 48 * 1024)
         {
-            if (int rc = ensure_dynamic_lds((const void*)gsr::k_rscatter<16>, (size_t)hist_bytes)) return rc;
+            if (int rc = ensure_dynamic_lds((const void*)gsr::k_rsort_rscatter, (size_t)hist_bytes)) return rc;
             if (int rc = ensure_dynamic_lds((const void*)gsr::k_rscatter<8>, (size_t)hist_bytes)) return rc;
         }
         uint32_t* block_hist = (uint32_t*)(b + bl.block_hist);
@@ -555,19 +555,22 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
                                (const float*)pa.depths, (const uint2*)pa.pstat, tile_count, rect_total, block_hist, bcount, bhist, hdr);
             KERNEL_CHECK("k_rcount", stream, dbg);
         }
+        const bool one_band = nbands <= 1;
         {
             TIMED(GSR_K_DEPTH_SORT, stream);
-            if (pblocks > 0)
-                hipLaunchKernelGGL(gsr::k_rdscatter, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), (size_t)nb * 4, stream, P, nb, (const ushort4*)srect,
-                                   (const float*)pa.depths, hdr, (const uint32_t*)bcount, bstart, bcursor, dkeys, (const uint32_t*)bhist);
-            // workgroup 0 scans the tile counters and posts the instance count; launched even when P == 0
-            hipLaunchKernelGGL(gsr::k_rdsort, dim3(1 + (pblocks > 0 ? nb : 0u)), dim3(256), 0, stream, (const uint32_t*)bcount,
-                               (const uint32_t*)bstart, dkeys, dtmp, rank, obs, (const ushort4*)srect, (int)bl.band_rows, tiles,
-                               (const uint32_t*)tile_count, tile_start, tile_cursor,
-                               ranges, tile_order, (uint4*)(b + bl.tdesc), total_dev, slot_dev, seq, post_cap);
-            KERNEL_CHECK("k_rdsort", stream, dbg);
-            if (nbands > 1 && pblocks > 0) {
+            // the depth keys into their buckets; the last workgroup scans the tile counters and posts the instance count (launched even when P == 0)
+            gsr::TileScanArgs ts;
+            ts.tiles = tiles; ts.tile_count = tile_count; ts.tile_start = tile_start; ts.tile_cursor = tile_cursor; ts.ranges = ranges;
+            ts.tile_order = tile_order; ts.tdesc = (uint4*)(b + bl.tdesc); ts.total_dev = total_dev; ts.mailbox = slot_dev; ts.seq = seq;
+            ts.post_capacity = post_cap;
+            hipLaunchKernelGGL(gsr::k_rdscatter, dim3((pblocks > 0 ? bin_blocks : 0) + 1), dim3(GSR_RANK_BIN_THREADS), (size_t)nb * 4, stream, P, nb,
+                               (const ushort4*)srect, (const float*)pa.depths, hdr, (const uint32_t*)bcount, bstart, bcursor, dkeys, (const uint32_t*)bhist, ts);
+            KERNEL_CHECK("k_rdscatter", stream, dbg);
+            if (!one_band && pblocks > 0) {
                 // large frames: a rank per (splat, band of tile rows) -- see gsr_rank.hip
+                hipLaunchKernelGGL(gsr::k_rdsort, dim3(nb), dim3(256), 0, stream, (const uint32_t*)bcount, (const uint32_t*)bstart, dkeys, dtmp, rank, obs,
+                                   (const ushort4*)srect, (int)bl.band_rows);
+                KERNEL_CHECK("k_rdsort", stream, dbg);
                 const uint32_t wgs = (nwc + 3u) / 4u;
                 hipLaunchKernelGGL(gsr::k_band_count, dim3(wgs), dim3(256), 0, stream, (const gsr::BinHeader*)hdr, (const uint2*)obs,
                                    (uint32_t)nbands, nwc, bandcnt);
@@ -579,10 +582,18 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         }
         if (pblocks > 0) {
             TIMED(GSR_K_SCATTER, stream);
-            hipLaunchKernelGGL(nbands > 1 ? gsr::k_rscatter<8> : gsr::k_rscatter<16>, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), hist_bytes, stream, P, gx, tiles, bt,
-                               (const ushort4*)srect, (const uint32_t*)rank, (const float4*)pa.sspan, (const uint32_t*)tile_start, tile_cursor, ranks, cap,
-                               (const unsigned long long*)total_dev, (const uint32_t*)block_hist);
-            KERNEL_CHECK("k_rscatter", stream, dbg);
+            if (one_band) {   // the depth sort beside the scatter, one launch (k_rsort_rscatter): 4-byte entries, k_tile_rank gathers the ranks
+                hipLaunchKernelGGL(gsr::k_rsort_rscatter, dim3(bin_blocks + nb), dim3(GSR_RANK_BIN_THREADS), hist_bytes, stream, bin_blocks, P, gx, tiles,
+                                   (const ushort4*)srect, (const float4*)pa.sspan, (const uint32_t*)tile_start, tile_cursor, (uint32_t*)ranks, cap,
+                                   (const unsigned long long*)total_dev, (const uint32_t*)block_hist, (const uint32_t*)bcount, (const uint32_t*)bstart,
+                                   dkeys, dtmp, rank);
+                KERNEL_CHECK("k_rsort_rscatter", stream, dbg);
+            } else {
+                hipLaunchKernelGGL(gsr::k_rscatter<8>, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), hist_bytes, stream, P, gx, tiles, bt,
+                                   (const ushort4*)srect, (const uint32_t*)rank, (const float4*)pa.sspan, (const uint32_t*)tile_start, tile_cursor, ranks, cap,
+                                   (const unsigned long long*)total_dev, (const uint32_t*)block_hist);
+                KERNEL_CHECK("k_rscatter", stream, dbg);
+            }
         }
         {
             TIMED(GSR_K_TILE_SORT, stream);
@@ -590,7 +601,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
             const size_t space = (size_t)P < (size_t)GSR_RANK_MAX_SPLATS ? (size_t)P : (size_t)GSR_RANK_MAX_SPLATS;
             const uint32_t words = (uint32_t)((space + 2047) / 2048) * 64u;
             hipLaunchKernelGGL(gsr::k_tile_rank, dim3(tiles), dim3(GSR_RANK_TILE_THREADS), (size_t)words * 6, stream, words, gx, nbands,
-                               inv_band_rows, (const uint4*)(b + bl.tdesc), (const uint2*)ranks, (const float*)pa.depths,
+                               inv_band_rows, (const uint4*)(b + bl.tdesc), (const uint2*)ranks, one_band ? (const uint32_t*)rank : nullptr, (const float*)pa.depths,
                                (const gsr::BinHeader*)hdr, write_lists ? (unsigned long long*)(b + bl.keys) : nullptr,
                                (uint32_t*)(b + bl.point_list), write_lists ? qlist : nullptr, qpos, qcount, qstart,
                                cap, (const unsigned long long*)total_dev);

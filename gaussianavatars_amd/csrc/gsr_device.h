@@ -615,8 +615,16 @@ __host__ __device__ inline bool rank_direct(int gx, int tiles) { return (long lo
 __global__ void k_rcount(int P, int gx, int tiles, int pblocks, uint32_t nb, const ushort4* srect, const uint32_t* tiles_touched,
                          const float* depths, const uint2* pstat, uint32_t* tile_count, unsigned long long* rect_total, uint32_t* block_hist,
                          uint32_t* bcount, uint32_t* bhist, BinHeader* hdr);
+struct TileScanArgs {            // the tile-counter scan that rides in k_rdscatter's last workgroup (gsr_rank.hip: tile_scan_256)
+    int tiles;
+    const uint32_t* __restrict__ tile_count;
+    uint32_t* __restrict__ tile_start; uint32_t* __restrict__ tile_cursor;
+    uint2* __restrict__ ranges; uint32_t* __restrict__ tile_order; uint4* __restrict__ tdesc;
+    unsigned long long* __restrict__ total_dev; unsigned long long* mailbox;
+    unsigned long long seq, post_capacity;
+};
 __global__ void k_rdscatter(int P, uint32_t nb, const ushort4* srect, const float* depths, BinHeader* hdr, const uint32_t* bcount, uint32_t* bstart,
-                            uint32_t* bcursor, unsigned long long* dkeys, const uint32_t* bhist);
+                            uint32_t* bcursor, unsigned long long* dkeys, const uint32_t* bhist, TileScanArgs ts);
 // bands of the rank path: 1 (the whole frame) up to GSR_RANK_MAX_SPLATS splats, else bands of *band_rows tile rows
 __host__ __device__ inline int rank_bands(long long P, int gy, bool force, int* band_rows)
 {
@@ -634,12 +642,15 @@ __global__ void k_band_count(const BinHeader* hdr, const uint2* obs, uint32_t nb
 __global__ void k_band_scan(BinHeader* hdr, uint32_t nwc, uint32_t* bandcnt);
 __global__ void k_band_rank(const BinHeader* hdr, const uint2* obs, uint32_t nbands, uint32_t nwc, const uint32_t* bandcnt, uint4* rank4, uint32_t* over);
 __global__ void k_rdsort(const uint32_t* bcount, const uint32_t* bstart, unsigned long long* dkeys, unsigned long long* tmp,
-                         uint32_t* rank, uint2* obs, const ushort4* srect, int band_rows, int tiles, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, uint2* ranges,
-                         uint32_t* tile_order, uint4* tdesc, unsigned long long* total_dev, unsigned long long* mailbox, unsigned long long seq, unsigned long long post_capacity);
+                         uint32_t* rank, uint2* obs, const ushort4* srect, int band_rows);
+__global__ void k_rsort_rscatter(int scatter_blocks, int P, int gx, int tiles, const ushort4* srect, const float4* sspan, const uint32_t* tile_start,
+                                 uint32_t* tile_cursor, uint32_t* entries, unsigned long long capacity, const unsigned long long* total_dev,
+                                 const uint32_t* block_hist, const uint32_t* bcount, const uint32_t* bstart, unsigned long long* dkeys,
+                                 unsigned long long* dtmp, uint32_t* rank);
 template <int G>
 __global__ void k_rscatter(int P, int gx, int tiles, BandTables bt, const ushort4* srect, const uint32_t* rank, const float4* sspan, const uint32_t* tile_start,
                            uint32_t* tile_cursor, uint2* ranks, unsigned long long capacity, const unsigned long long* total_dev, const uint32_t* block_hist);
-__global__ void k_tile_rank(uint32_t words, int gx, int nbands, float inv_band_rows, const uint4* tdesc, const uint2* ranks,
+__global__ void k_tile_rank(uint32_t words, int gx, int nbands, float inv_band_rows, const uint4* tdesc, const uint2* ranks, const uint32_t* rank_of,
                             const float* depths, const BinHeader* hdr, unsigned long long* keys, uint32_t* point_list,
                             uint32_t* qlist, uint32_t* qpos, uint32_t* qcount, uint32_t* qstart, unsigned long long capacity,
                             const unsigned long long* total_dev);

@@ -8,13 +8,16 @@
 //   k_rcount    per chunk  : tile-instance histogram (as round 1's k_count) + depth-bucket histogram of the binned splats,
 //                            snug tile rect of every splat kept for the two scatters
 //   k_rdscatter per chunk  : bucket offsets (every workgroup scans the nb counters itself), (depth bits << 32 | splat) into buckets
-//   k_rdsort    per bucket : register bitonic sort (gsr_sort.h) -> rank[splat];
 //               + 1 WG     : exclusive scan of the tile counters, heavy-first tile order, instance count posted to the host
-//   (k_band_*   frames beyond GSR_RANK_MAX_SPLATS splats only: the rank of a splat inside every band of tile rows it touches)
-//   k_rscatter  per chunk  : (rank[splat], splat) into every tile segment the splat's snug rect covers (8 bytes per instance)
-//   k_tile_rank per tile   : bitmap of the tile's ranks in LDS (ds_or), word popcounts scanned; an entry's position in the sorted
-//                            list is the number of set bits below its own; then the four 8x8-quadrant streams exactly as round
-//                            1's sort epilogue wrote them (stable compaction of the entries whose ellipse reaches the quadrant)
+//   k_rsort_rscatter (one band; round 4), ONE launch with two kinds of workgroup that do not depend on each other:
+//               per chunk  : (splat | quadrant mask << 28) into every tile segment the splat's snug rect covers (4 bytes per instance)
+//               per bucket : register bitonic sort (gsr_sort.h) -> rank[splat]
+//   (frames beyond GSR_RANK_MAX_SPLATS splats: k_rdsort per bucket, k_band_* = the rank of a splat inside every band of tile rows it
+//    touches, then k_rscatter with (rank in the tile's band, splat | mask) entries of 8 bytes)
+//   k_tile_rank per tile   : bitmap of the tile's ranks in LDS (ds_or; one band: rank[splat] gathered per entry), word popcounts scanned; an
+//                            entry's position in the sorted list is the number of set bits below its own; then the four 8x8-quadrant
+//                            streams exactly as round 1's sort epilogue wrote them (stable compaction of the entries whose ellipse reaches
+//                            the quadrant)
 //
 // Lists come out identical to a (depth, index) sort per tile: ranks are unique, and rank order IS (depth, index) order.
 #include "gsr_device.h"
@@ -192,66 +195,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int P, int gx, 
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// k_rdscatter: same chunking.  Every workgroup scans the nb bucket counters itself (nb <= GSR_RANK_MAX_BUCKETS: a few
-// microseconds, no separate one-workgroup launch) and hands out slots from LDS cursors that start at the sub-range k_rcount
-// reserved for it in every bucket.  Workgroup 0 publishes the bucket offsets and the number
-// of ranked splats.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rdscatter(int P, uint32_t nb, const ushort4* __restrict__ srect, const float* __restrict__ depths,
-                                                    BinHeader* __restrict__ hdr, const uint32_t* __restrict__ bcount,
-                                                    uint32_t* __restrict__ bstart, uint32_t* __restrict__ bcursor,
-                                                    unsigned long long* __restrict__ dkeys, const uint32_t* __restrict__ bhist)
-{
-    extern __shared__ uint32_t base[];   // [nb]
-    constexpr int NT = GSR_RANK_BIN_THREADS, NWV = NT / 64;
-    __shared__ uint32_t wave_tot[NWV];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint32_t per = (nb + (uint32_t)NT - 1u) / (uint32_t)NT;   // consecutive counters per thread
-    uint32_t sum = 0;
-    for (uint32_t k = 0; k < per; ++k) {
-        const uint32_t t = (uint32_t)tid * per + k;
-        sum += t < nb ? bcount[t] : 0u;
-    }
-    const uint32_t incl = wave_scan_incl_u32(sum);
-    if (lane == 63) wave_tot[wid] = incl;
-    __syncthreads();
-    uint32_t run = incl - sum;
-    for (int w = 0; w < wid; ++w) run += wave_tot[w];
-    const uint32_t* __restrict__ mine = bhist + (size_t)blockIdx.x * nb;
-    for (uint32_t k = 0; k < per; ++k) {
-        const uint32_t t = (uint32_t)tid * per + k;
-        if (t < nb) {
-            const uint32_t c = bcount[t];
-            if (blockIdx.x == 0) bstart[t] = run;
-            base[t] = run + mine[t];   // this workgroup's first slot in bucket t (k_rcount reserved it)
-            run += c;
-        }
-    }
-    if (blockIdx.x == 0 && tid == 0) {
-        uint32_t tot = 0;
-#pragma unroll
-        for (int w = 0; w < NWV; ++w) tot += wave_tot[w];
-        hdr->nvis = tot;
-    }
-    __syncthreads();
-    float lo, scale;
-    rank_bucket_map(hdr->dmin_bits, hdr->dmax_bits, nb, lo, scale);
-    const int chunk = ((P + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
-    const int begin = blockIdx.x * chunk, end = min(P, begin + chunk);
-    for (int i = begin + tid; i < end; i += NT) {
-        const ushort4 r = srect[i];
-        if (r.z == r.x) continue;   // not binned
-        const float d = depths[i];
-        const uint32_t slot = atomicAdd(&base[rank_bucket(d, lo, scale, nb)], 1u);
-        dkeys[slot] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(uint32_t)i;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_rdsort: workgroup 0 scans the tile counters (independent of the depth sort: it rides along instead of taking a launch of
-// its own); workgroup 1 + b sorts bucket b by (depth, splat) and writes order[] / rank[].
-// ------------------------------------------------------------------------------------------
+// the tile counters -> tile offsets, heavy-first tile order, the instance count posted to the host: 256 threads of ONE workgroup
 __device__ __forceinline__ void tile_scan_256(int tiles, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
                                               uint32_t* __restrict__ tile_cursor, uint2* __restrict__ ranges,
                                               uint32_t* __restrict__ tile_order, uint4* __restrict__ tdesc,
@@ -325,28 +269,185 @@ __device__ __forceinline__ void tile_scan_256(int tiles, const uint32_t* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void k_rdsort(const uint32_t* __restrict__ bcount, const uint32_t* __restrict__ bstart,
-                                                 unsigned long long* __restrict__ dkeys, unsigned long long* __restrict__ tmp,
-                                                 uint32_t* __restrict__ rank, uint2* __restrict__ obs,
-                                                 const ushort4* __restrict__ srect, int band_rows, int tiles,
-                                                 const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
-                                                 uint32_t* __restrict__ tile_cursor, uint2* __restrict__ ranges,
-                                                 uint32_t* __restrict__ tile_order, uint4* __restrict__ tdesc,
-                                                 unsigned long long* __restrict__ total_dev, unsigned long long* mailbox, unsigned long long seq, unsigned long long post_capacity)
+// The same by all GSR_RANK_BIN_THREADS threads of a workgroup, for grids of up to TS_PER tiles per thread: every counter is loaded ONCE and stays in
+// registers through the scan, the heavy-first bucket count and the placement -- one level of global loads instead of four dependent ones (the
+// 256-thread version above runs 8 - 13 us on its own; beside the depth sort that was hidden, in front of k_rsort_rscatter it would not be).
+constexpr int TS_PER = 8;
+#ifndef GSR_TS_SUB
+#define GSR_TS_SUB 0   // heavy-first order: 2^GSR_TS_SUB classes per octave of the tile's entry count
+#endif
+constexpr int TS_BUCKETS = 32 * (1 << GSR_TS_SUB) + 1;
+__device__ __forceinline__ void tile_scan_wide(const TileScanArgs& ts)
 {
-    if (blockIdx.x == 0) {
-        tile_scan_256(tiles, tile_count, tile_start, tile_cursor, ranges, tile_order, tdesc, total_dev, mailbox, seq, post_capacity);
+    constexpr int NT = GSR_RANK_BIN_THREADS, NWV = NT / 64;
+    __shared__ uint32_t wave_tot[NWV];
+    __shared__ uint32_t bucket[TS_BUCKETS + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // wave w owns the tiles [64 per w, 64 per (w + 1)), lane l the tiles 64 per w + 64 k + l: coalesced loads, and the placement below hands out
+    // positions in tile order inside a wave -- neighbouring tiles stay neighbours in the launch order of the per-tile kernels, which is worth
+    // 2 us of k_render (their records are shared in L2); `per` <= TS_PER
+    const int tiles = ts.tiles, per = (tiles + NT - 1) / NT;
+    const int w0 = wid * 64 * per;
+    uint32_t v[TS_PER], excl[TS_PER], carry = 0;
+#pragma unroll
+    for (int k = 0; k < TS_PER; ++k) {
+        const int t = w0 + 64 * k + lane;
+        v[k] = (k < per && t < tiles) ? ts.tile_count[t] : 0u;
+    }
+    for (int k = tid; k <= TS_BUCKETS; k += NT) bucket[k] = 0u;
+#pragma unroll
+    for (int k = 0; k < TS_PER; ++k) {
+        const uint32_t incl = wave_scan_incl_u32(v[k]);
+        excl[k] = carry + incl - v[k];
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (lane == 63) wave_tot[wid] = carry;
+    __syncthreads();
+    // big counts first, empty last: the octave of the count and its next GSR_TS_SUB bits (0: whole octaves; finer classes were measured and are
+    // not better: 2 us of k_render lost at 8 / 32 classes per octave)
+    auto bucket_of = [](uint32_t c) {
+        if (!c) return (uint32_t)TS_BUCKETS - 1u;
+        const uint32_t o = 31u - (uint32_t)__builtin_clz(c);
+        const uint32_t sub = (o >= GSR_TS_SUB ? c >> (o - GSR_TS_SUB) : c << (GSR_TS_SUB - o)) & ((1u << GSR_TS_SUB) - 1u);
+        return (uint32_t)TS_BUCKETS - 2u - (o << GSR_TS_SUB | sub);
+    };
+    unsigned long long wave_off = 0, grand = 0;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) {
+        const uint32_t t = wave_tot[w];
+        if (w < wid) wave_off += t;
+        grand += t;   // 64-bit total: a frame past 2^32 instances is reported, not wrapped
+    }
+#pragma unroll
+    for (int k = 0; k < TS_PER; ++k) {
+        const int t = w0 + 64 * k + lane;
+        excl[k] += (uint32_t)wave_off;   // offsets are 32-bit like upstream's
+        if (k < per && t < tiles) {
+            ts.tile_start[t] = excl[k];
+            ts.tile_cursor[t] = 0u;
+            if (ts.ranges) ts.ranges[t] = v[k] ? make_uint2(excl[k], excl[k] + v[k]) : make_uint2(0u, 0u);
+            atomicAdd(&bucket[bucket_of(v[k])], 1u);
+        }
+    }
+    if (tid == 0) {
+        *ts.total_dev = grand;
+        // post (seq, I) to the host: one 8-byte system-scope store into mapped pinned memory
+        __hip_atomic_store(ts.mailbox, (ts.seq << 40) | (grand & 0xFFFFFFFFFFull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // deferred count (post_capacity = the binning capacity, else ~0): a frame that does not fit leaves a STICKY mark in the slot's second
+        // word -- later frames overwrite the count above, nothing but the host clears this one (gsr_count_slot_overflow)
+        if (grand > ts.post_capacity) __hip_atomic_store(ts.mailbox + GSR_COUNT_SLOTS, grand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    if (wid == 0) {   // exclusive scan of the bucket counts (consecutive buckets per lane)
+        constexpr int BPL = (TS_BUCKETS + 63) / 64;
+        uint32_t c[BPL], tot = 0;
+#pragma unroll
+        for (int j = 0; j < BPL; ++j) {
+            const int bi = lane * BPL + j;
+            c[j] = bi < TS_BUCKETS ? bucket[bi] : 0u;
+            tot += c[j];
+        }
+        uint32_t acc = wave_scan_incl_u32(tot) - tot;
+#pragma unroll
+        for (int j = 0; j < BPL; ++j) {
+            const int bi = lane * BPL + j;
+            if (bi < TS_BUCKETS) bucket[bi] = acc;
+            acc += c[j];
+        }
+    }
+    __syncthreads();
+    // heavy-first launch order for the per-tile kernels (pure scheduling, see round 1's k_tile_scan)
+#pragma unroll
+    for (int k = 0; k < TS_PER; ++k) {
+        const int t = w0 + 64 * k + lane;
+        if (k < per && t < tiles) {
+            const uint32_t pos = atomicAdd(&bucket[bucket_of(v[k])], 1u);
+            ts.tile_order[pos] = (uint32_t)t;
+            ts.tdesc[pos] = make_uint4((uint32_t)t, v[k], excl[k], 0u);   // what the per-tile kernel needs, in one load
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rdscatter: same chunking.  Every workgroup scans the nb bucket counters itself (nb <= GSR_RANK_MAX_BUCKETS: a few
+// microseconds, no separate one-workgroup launch) and hands out slots from LDS cursors that start at the sub-range k_rcount
+// reserved for it in every bucket.  Workgroup 0 publishes the bucket offsets and the number
+// of ranked splats.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rdscatter(int P, uint32_t nb, const ushort4* __restrict__ srect, const float* __restrict__ depths,
+                                                    BinHeader* __restrict__ hdr, const uint32_t* __restrict__ bcount,
+                                                    uint32_t* __restrict__ bstart, uint32_t* __restrict__ bcursor,
+                                                    unsigned long long* __restrict__ dkeys, const uint32_t* __restrict__ bhist, TileScanArgs ts)
+{
+    extern __shared__ uint32_t base[];   // [nb]
+    constexpr int NT = GSR_RANK_BIN_THREADS, NWV = NT / 64;
+    const uint32_t nblk = gridDim.x - 1u;   // the chunk workgroups (k_rcount's chunking); the LAST workgroup scans the tile counters instead:
+    if (blockIdx.x == nblk) {               // independent of the depth keys, it rides along here so that k_rscatter can start beside the depth sort
+        if (ts.tiles <= TS_PER * NT) { tile_scan_wide(ts); return; }
+        if (threadIdx.x >= 256) return;
+        tile_scan_256(ts.tiles, ts.tile_count, ts.tile_start, ts.tile_cursor, ts.ranges, ts.tile_order, ts.tdesc, ts.total_dev, ts.mailbox, ts.seq,
+                      ts.post_capacity);
         return;
     }
+    __shared__ uint32_t wave_tot[NWV];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t per = (nb + (uint32_t)NT - 1u) / (uint32_t)NT;   // consecutive counters per thread
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < per; ++k) {
+        const uint32_t t = (uint32_t)tid * per + k;
+        sum += t < nb ? bcount[t] : 0u;
+    }
+    const uint32_t incl = wave_scan_incl_u32(sum);
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wid; ++w) run += wave_tot[w];
+    const uint32_t* __restrict__ mine = bhist + (size_t)blockIdx.x * nb;
+    for (uint32_t k = 0; k < per; ++k) {
+        const uint32_t t = (uint32_t)tid * per + k;
+        if (t < nb) {
+            const uint32_t c = bcount[t];
+            if (blockIdx.x == 0) bstart[t] = run;
+            base[t] = run + mine[t];   // this workgroup's first slot in bucket t (k_rcount reserved it)
+            run += c;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) tot += wave_tot[w];
+        hdr->nvis = tot;
+    }
+    __syncthreads();
+    float lo, scale;
+    rank_bucket_map(hdr->dmin_bits, hdr->dmax_bits, nb, lo, scale);
+    const int chunk = ((P + (int)nblk - 1) / (int)nblk + 255) / 256 * 256;
+    const int begin = blockIdx.x * chunk, end = min(P, begin + chunk);
+    for (int i = begin + tid; i < end; i += NT) {
+        const ushort4 r = srect[i];
+        if (r.z == r.x) continue;   // not binned
+        const float d = depths[i];
+        const uint32_t slot = atomicAdd(&base[rank_bucket(d, lo, scale, nb)], 1u);
+        dkeys[slot] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(uint32_t)i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The depth sort: a workgroup per bucket, by (depth, splat) -> order[] / rank[].
+// ------------------------------------------------------------------------------------------
+// one depth bucket, by 256 threads: sorted by (depth, splat); one band: rank[splat] (obs == nullptr); bands: (splat, first band | last band << 8)
+// by rank, for k_band_count / k_band_rank
+__device__ __forceinline__ void depth_sort_bucket(uint32_t b, const uint32_t* __restrict__ bcount, const uint32_t* __restrict__ bstart,
+                                                  unsigned long long* __restrict__ dkeys, unsigned long long* __restrict__ tmp,
+                                                  uint32_t* __restrict__ rank, uint2* __restrict__ obs, const ushort4* __restrict__ srect, int band_rows)
+{
     constexpr int KEYS = GSR_SORT_SMALL_KEYS, THREADS = 256, EPT = KEYS / THREADS;
     __shared__ unsigned long long skeys[KEYS];
-    const uint32_t b = blockIdx.x - 1u;
     const uint32_t n = bcount[b];
     if (n == 0) return;
     const uint32_t start = bstart[b];
     const int tid = threadIdx.x;
     unsigned long long* seg = dkeys + start;
-    // one band: rank[splat]; bands: (splat, first band | last band << 8) by rank, for k_band_count / k_band_rank
     auto put = [&](uint32_t splat, uint32_t r) {
         if (obs) {
             const ushort4 q = srect[splat];
@@ -368,6 +469,15 @@ __global__ __launch_bounds__(256) void k_rdsort(const uint32_t* __restrict__ bco
         __syncthreads();
         for (uint32_t i = tid; i < n; i += THREADS) put((uint32_t)seg[i], start + i);
     }
+}
+
+// k_rdsort (band mode only: one band sorts beside k_rscatter, see k_rsort_rscatter): workgroup b sorts bucket b
+__global__ __launch_bounds__(256) void k_rdsort(const uint32_t* __restrict__ bcount, const uint32_t* __restrict__ bstart,
+                                                 unsigned long long* __restrict__ dkeys, unsigned long long* __restrict__ tmp,
+                                                 uint32_t* __restrict__ rank, uint2* __restrict__ obs,
+                                                 const ushort4* __restrict__ srect, int band_rows)
+{
+    depth_sort_bucket(blockIdx.x, bcount, bstart, dkeys, tmp, rank, obs, srect, band_rows);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -478,22 +588,25 @@ __global__ __launch_bounds__(256) void k_band_rank(const BinHeader* __restrict__
 // ------------------------------------------------------------------------------------------
 // G lanes expand one splat's rect together: 16 where a rect holds ~18 tiles (100 k - 200 k splats at 802 x 550), 8 on the large frames of the
 // band mode, whose rects are smaller (2 M splats at 1600 x 1100: ~12 tiles; k_rscatter 303 -> 265 us; at 100 k splats 8 lanes cost 28.6 -> 31 us)
-template <int G>
-__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx, int tiles, BandTables bt, const ushort4* __restrict__ srect,
-                                                                    const uint32_t* __restrict__ rank, const float4* __restrict__ sspan,
-                                                                    const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
-                                                                    uint2* __restrict__ ranks, unsigned long long capacity,
-                                                                    const unsigned long long* __restrict__ total_dev,
-                                                                    const uint32_t* __restrict__ block_hist)
+// LEAN (one band): the entry is the 4-byte (splat | quadrant mask << 28) alone -- nothing here depends on the depth sort, so the workgroups run
+// BESIDE it in one launch (k_rsort_rscatter) and k_tile_rank gathers rank[splat] itself.
+template <int G, bool LEAN>
+__device__ __forceinline__ void rscatter_body(int P, int gx, int tiles, BandTables bt, const ushort4* __restrict__ srect,
+                                              const uint32_t* __restrict__ rank, const float4* __restrict__ sspan,
+                                              const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
+                                              uint2* __restrict__ ranks, unsigned long long capacity,
+                                              const unsigned long long* __restrict__ total_dev,
+                                              const uint32_t* __restrict__ block_hist, int nblk)
 {
     extern __shared__ uint32_t hist[];
+    uint32_t* __restrict__ const lean = reinterpret_cast<uint32_t*>(ranks);
     constexpr int NT = GSR_RANK_BIN_THREADS;
     if (*total_dev > capacity) return;  // the host will grow the buffer and replay the frame
     const int tid = threadIdx.x;
     const bool direct = rank_direct(gx, tiles);
-    const bool bands = bt.nbands > 1;
+    const bool bands = !LEAN && bt.nbands > 1;
     const uint4* __restrict__ rank4 = reinterpret_cast<const uint4*>(rank);   // bands: the ranks inside the first four bands of the rect
-    const int chunk = ((P + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
+    const int chunk = ((P + nblk - 1) / nblk + 255) / 256 * 256;
     const int begin = blockIdx.x * chunk;
     const int end = min(P, begin + chunk);
     // a splat's inputs, fetched one round ahead of their use (all four loads are independent: rank / operands of a splat that is
@@ -504,7 +617,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
         v.q = make_ushort4(0, 0, 0, 0); v.rk = make_uint4(0u, 0u, 0u, 0u); v.s0 = v.s1 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < end) {
             v.q = srect[i]; v.s0 = sspan[2 * (size_t)i]; v.s1 = sspan[2 * (size_t)i + 1];
-            if (bands) v.rk = rank4[i]; else v.rk.x = rank[i];
+            if (bands) v.rk = rank4[i]; else if (!LEAN) v.rk.x = rank[i];
         }
         return v;
     };
@@ -552,14 +665,49 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
 #ifdef GSR_EXP_RSCATTER_NOSTORE   // timing experiment: everything but the store (the condition keeps the rank, the mask and the slot live; no frame meets it)
             if (brk == 0xFFFFFFF0u && m == 15u && bidx == 0x0FFFFFFFu) ranks[slot] = make_uint2(brk, bidx);
 #else
-            ranks[slot] = make_uint2(brk, bidx | (m << GSR_RANK_IDX_BITS));
+            if (LEAN) lean[slot] = bidx | (m << GSR_RANK_IDX_BITS);
+            else ranks[slot] = make_uint2(brk, bidx | (m << GSR_RANK_IDX_BITS));
 #endif
         });
     }
 }
 
-template __global__ void k_rscatter<16>(int, int, int, BandTables, const ushort4*, const uint32_t*, const float4*, const uint32_t*, uint32_t*, uint2*, unsigned long long,
-                                        const unsigned long long*, const uint32_t*);
+template <int G>
+__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx, int tiles, BandTables bt, const ushort4* __restrict__ srect,
+                                                                    const uint32_t* __restrict__ rank, const float4* __restrict__ sspan,
+                                                                    const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
+                                                                    uint2* __restrict__ ranks, unsigned long long capacity,
+                                                                    const unsigned long long* __restrict__ total_dev,
+                                                                    const uint32_t* __restrict__ block_hist)
+{
+    rscatter_body<G, false>(P, gx, tiles, bt, srect, rank, sspan, tile_start, tile_cursor, ranks, capacity, total_dev, block_hist, (int)gridDim.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rsort_rscatter (one band): the first `scatter_blocks` workgroups are k_rscatter's (LEAN entries), workgroup scatter_blocks + b sorts
+// depth bucket b with its first four waves.  The two halves have no dependence on each other -- both only need the launch before
+// (k_rdscatter: bucket contents, tile offsets) -- and the scatter, one 16-wave workgroup per CU at 67 VGPRs, leaves three wave slots per SIMD
+// and 130 KB of LDS per CU for the sorting workgroups: the depth sort (10.6 - 15 us as a launch of its own) disappears behind the scatter.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rsort_rscatter(int scatter_blocks, int P, int gx, int tiles, const ushort4* __restrict__ srect,
+                                                                          const float4* __restrict__ sspan, const uint32_t* __restrict__ tile_start,
+                                                                          uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ entries,
+                                                                          unsigned long long capacity, const unsigned long long* __restrict__ total_dev,
+                                                                          const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ bcount,
+                                                                          const uint32_t* __restrict__ bstart, unsigned long long* __restrict__ dkeys,
+                                                                          unsigned long long* __restrict__ dtmp, uint32_t* __restrict__ rank)
+{
+    if ((int)blockIdx.x < scatter_blocks) {
+        BandTables bt;
+        bt.nbands = 1u; bt.inv_band_rows = 1.f; bt.over = nullptr;
+        rscatter_body<GSR_RANK_GROUP, true>(P, gx, tiles, bt, srect, nullptr, sspan, tile_start, tile_cursor, reinterpret_cast<uint2*>(entries), capacity,
+                                            total_dev, block_hist, scatter_blocks);
+        return;
+    }
+    if (threadIdx.x >= 256) return;   // (ended waves do not take part in the barriers of the sort)
+    depth_sort_bucket(blockIdx.x - (uint32_t)scatter_blocks, bcount, bstart, dkeys, dtmp, rank, nullptr, nullptr, 1);
+}
+
 template __global__ void k_rscatter<8>(int, int, int, BandTables, const ushort4*, const uint32_t*, const float4*, const uint32_t*, uint32_t*, uint2*, unsigned long long,
                                        const unsigned long long*, const uint32_t*);
 
@@ -670,7 +818,7 @@ __device__ __forceinline__ void tile_streams(uint32_t total, uint32_t n, uint32_
 // No comparison, no data-dependent loop, every step entry-parallel.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GSR_RANK_TILE_THREADS) void k_tile_rank(uint32_t words, int gx, int nbands, float inv_band_rows,
-                                                    const uint4* __restrict__ tdesc, const uint2* __restrict__ ranks,
+                                                    const uint4* __restrict__ tdesc, const uint2* __restrict__ ranks, const uint32_t* __restrict__ rank_of,
                                                     const float* __restrict__ depths, const BinHeader* __restrict__ hdr,
                                                     unsigned long long* __restrict__ keys, uint32_t* __restrict__ point_list,
                                                     uint32_t* __restrict__ qlist, uint32_t* __restrict__ qpos, uint32_t* __restrict__ qcount,
@@ -697,7 +845,14 @@ __global__ __launch_bounds__(GSR_RANK_TILE_THREADS) void k_tile_rank(uint32_t wo
     }
     const uint32_t start = td.z;
     if (tid < 4) qstart[4 * tile + tid] = 4u * start + (uint32_t)tid * n;   // the tile's four n-slot streams
-    const uint2* __restrict__ rk = ranks + start;
+    // the tile's entries: (rank, splat | mask) pairs, or -- one band (rank_of) -- the 4-byte (splat | mask) with the rank gathered here
+    const uint2* __restrict__ rk2 = ranks + start;
+    const uint32_t* __restrict__ rk1 = reinterpret_cast<const uint32_t*>(ranks) + start;
+    auto entry = [&](uint32_t i) {
+        if (!rank_of) return rk2[i];
+        const uint32_t e = rk1[i];
+        return make_uint2(rank_of[e & ((1u << GSR_RANK_IDX_BITS) - 1u)], e);
+    };
     uint32_t* const qpbase = qpos + (size_t)4 * start;
     uint32_t* const qlbase = qlist ? qlist + (size_t)4 * start : nullptr;
     // the rank space of this tile's entries: the frame's binned splats, or those of the tile's band
@@ -711,7 +866,7 @@ __global__ __launch_bounds__(GSR_RANK_TILE_THREADS) void k_tile_rank(uint32_t wo
 #pragma unroll
     for (int k = 0; k < UB; ++k) {   // the first UB * THREADS entries: issued before the bitmap is cleared
         const uint32_t i = (uint32_t)(k * THREADS + tid);
-        e0[k] = i < n ? rk[i] : make_uint2(0xFFFFFFFFu, 0u);
+        e0[k] = i < n ? entry(i) : make_uint2(0xFFFFFFFFu, 0u);
     }
     // one pass over the ranks [lo, lo + span): the tile's entries in there go to the list from position `placed`; returns their number
     auto pass = [&](const uint32_t lo, const uint32_t span, const bool in_lds, const uint32_t placed) {
@@ -728,7 +883,7 @@ __global__ __launch_bounds__(GSR_RANK_TILE_THREADS) void k_tile_rank(uint32_t wo
 #pragma unroll
             for (int k = 0; k < UB; ++k) {
                 const uint32_t i = base + (uint32_t)(k * THREADS + tid);
-                r[k] = i < n ? rk[i].x - lo : 0xFFFFFFFFu;
+                r[k] = i < n ? entry(i).x - lo : 0xFFFFFFFFu;
             }
 #pragma unroll
             for (int k = 0; k < UB; ++k)
@@ -779,7 +934,7 @@ __global__ __launch_bounds__(GSR_RANK_TILE_THREADS) void k_tile_rank(uint32_t wo
 #pragma unroll
                 for (int k = 0; k < UB; ++k) {
                     const uint32_t i = base + (uint32_t)(k * THREADS + tid);
-                    e[k] = i < n ? rk[i] : make_uint2(0xFFFFFFFFu, 0u);
+                    e[k] = i < n ? entry(i) : make_uint2(0xFFFFFFFFu, 0u);
                 }
 #pragma unroll
                 for (int k = 0; k < UB; ++k) {

@@ -324,13 +324,13 @@ int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, c
  */
 #define GSR_K_PREPROCESS 0
 #define GSR_K_TILE_SCAN 1
-#define GSR_K_SCATTER 2
+#define GSR_K_SCATTER 2       /* rank path, one band: k_rsort_rscatter (the depth sort rides beside the scatter)       */
 #define GSR_K_TILE_SORT 3
 #define GSR_K_RENDER 4
 #define GSR_K_RENDER_BWD 5
 #define GSR_K_PREPROCESS_BWD 6
 #define GSR_K_COUNT 7
-#define GSR_K_DEPTH_SORT 8    /* production binning: k_dbucket + k_dscan + k_dscatter + k_dsort, timed as one      */
+#define GSR_K_DEPTH_SORT 8    /* k_dbucket + k_dscan + k_dscatter + k_dsort / rank path: k_rdscatter (+ tile scan), bands: + k_rdsort, k_band_* */
 #define GSR_K_QCOUNT 9
 #define GSR_K_QSCAN 10        /* k_qscan + k_qscan_glob                                                            */
 #define GSR_K_QSCATTER 11
