@@ -262,6 +262,7 @@ GLS_SYMBOLS = {
     "gls_l1_ssim_forward": (C.c_int, [C.c_int32] * 4 + [_P, _P, C.c_float] + [_P] * 4),
     "gls_l1_ssim_backward": (C.c_int, [C.c_int32] * 4 + [_P] * 4 + [C.c_float, _P, _P]),
     "gls_l1_forward": (C.c_int, [C.c_int64, _P, _P, C.c_float, _P, _P, _P]),
+    "gls_l1_forward_grad": (C.c_int, [C.c_int64, _P, _P, C.c_float, _P, _P, _P, _P]),
     "gls_l1_backward": (C.c_int, [C.c_int64, _P, _P, _P, C.c_float, _P, _P]),
     "gls_densification_stats": (C.c_int, [C.c_int32] + [_P] * 6),
 }
@@ -281,8 +282,8 @@ def gls():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.gls_abi_version() != 1:
-            raise RuntimeError(f"gls ABI version {lib.gls_abi_version()} != 1")
+        if lib.gls_abi_version() != 2:
+            raise RuntimeError(f"gls ABI version {lib.gls_abi_version()} != 2")
         _gls = lib
     return _gls
 

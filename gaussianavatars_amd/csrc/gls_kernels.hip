@@ -190,7 +190,12 @@ __global__ __launch_bounds__(256) void k_l1_ssim_bwd(int C, int H, int W, const 
 }
 
 // ---- plain L1 -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_l1_fwd(long long n, const float* __restrict__ a, const float* __restrict__ b, float2* __restrict__ partial)
+__device__ __forceinline__ float sgn_scaled(float d, float g) { return d > 0.f ? g : (d < 0.f ? -g : 0.f); }
+// GRAD: also d_a <- gs * sign(a - b), the gradient for an upstream gradient of exactly 1 (gs = the forward's mean scale): a backward seeded
+// with the constant 1 (loss.backward() on the loss itself) then has nothing left to launch
+template <bool GRAD>
+__global__ __launch_bounds__(256) void k_l1_fwd(long long n, const float* __restrict__ a, const float* __restrict__ b, float2* __restrict__ partial,
+                                                 float gs, float* __restrict__ d_a)
 {
     __shared__ float red[4];
     const int tid = threadIdx.x;
@@ -198,9 +203,15 @@ __global__ __launch_bounds__(256) void k_l1_fwd(long long n, const float* __rest
     float s = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + tid; i < n4; i += (long long)gridDim.x * 256) {
         const float4 u = ((const float4*)a)[i], v = ((const float4*)b)[i];
-        s += (fabsf(u.x - v.x) + fabsf(u.y - v.y)) + (fabsf(u.z - v.z) + fabsf(u.w - v.w));
+        const float dx = u.x - v.x, dy = u.y - v.y, dz = u.z - v.z, dw = u.w - v.w;
+        s += (fabsf(dx) + fabsf(dy)) + (fabsf(dz) + fabsf(dw));
+        if (GRAD) ((float4*)d_a)[i] = make_float4(sgn_scaled(dx, gs), sgn_scaled(dy, gs), sgn_scaled(dz, gs), sgn_scaled(dw, gs));
     }
-    if (blockIdx.x == 0 && tid < (int)(n & 3)) s += fabsf(a[(n4 << 2) + tid] - b[(n4 << 2) + tid]);
+    if (blockIdx.x == 0 && tid < (int)(n & 3)) {
+        const float d = a[(n4 << 2) + tid] - b[(n4 << 2) + tid];
+        s += fabsf(d);
+        if (GRAD) d_a[(n4 << 2) + tid] = sgn_scaled(d, gs);
+    }
     s = wave_sum_hi(s);
     if ((tid & 63) == 63) red[tid >> 6] = s;
     __syncthreads();
@@ -217,7 +228,6 @@ __global__ __launch_bounds__(256) void k_l1_reduce(const float2* __restrict__ pa
     __syncthreads();
     if (tid == 0) *sum = scale * ((red[0] + red[1]) + (red[2] + red[3]));
 }
-__device__ __forceinline__ float sgn_scaled(float d, float g) { return d > 0.f ? g : (d < 0.f ? -g : 0.f); }
 __global__ __launch_bounds__(256) void k_l1_bwd(long long n, const float* __restrict__ a, const float* __restrict__ b,
                                                  const float* __restrict__ g, float scale, float* __restrict__ d_a)
 {
@@ -325,18 +335,29 @@ int gls_l1_ssim_backward(int32_t B, int32_t C, int32_t H, int32_t W, const float
     return GLS_OK;
 }
 
-int gls_l1_forward(int64_t n, const float* a, const float* b, float scale, float* sum, float* partial, void* stream_)
+static int l1_forward_impl(int64_t n, const float* a, const float* b, float scale, float* sum, float* partial, float* d_a, bool grad, void* stream_)
 {
-    if (n < 0 || !sum || !partial || (n > 0 && (!a || !b))) return fail(GLS_E_ARG, "bad arguments");
-    if ((((uintptr_t)a) | ((uintptr_t)b)) & 15) return fail(GLS_E_ARG, "inputs must be 16-byte aligned");
+    if (n < 0 || !sum || !partial || (n > 0 && (!a || !b || (grad && !d_a)))) return fail(GLS_E_ARG, "bad arguments");
+    if ((((uintptr_t)a) | ((uintptr_t)b) | (grad ? (uintptr_t)d_a : 0)) & 15) return fail(GLS_E_ARG, "buffers must be 16-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
     int blocks = (int)(((n >> 2) + 255) / 256);
     blocks = blocks < 1 ? 1 : (blocks > kL1Blocks ? kL1Blocks : blocks);
-    hipLaunchKernelGGL(gls::k_l1_fwd, dim3(blocks), dim3(256), 0, stream, (long long)n, a, b, (float2*)partial);
+    if (grad) hipLaunchKernelGGL(gls::k_l1_fwd<true>, dim3(blocks), dim3(256), 0, stream, (long long)n, a, b, (float2*)partial, scale, d_a);
+    else hipLaunchKernelGGL(gls::k_l1_fwd<false>, dim3(blocks), dim3(256), 0, stream, (long long)n, a, b, (float2*)partial, scale, (float*)nullptr);
     LAUNCH_CHECK("k_l1_fwd");
     hipLaunchKernelGGL(gls::k_l1_reduce, dim3(1), dim3(256), 0, stream, (const float2*)partial, blocks, scale, sum);
     LAUNCH_CHECK("k_l1_reduce");
     return GLS_OK;
+}
+
+int gls_l1_forward(int64_t n, const float* a, const float* b, float scale, float* sum, float* partial, void* stream_)
+{
+    return l1_forward_impl(n, a, b, scale, sum, partial, nullptr, false, stream_);
+}
+
+int gls_l1_forward_grad(int64_t n, const float* a, const float* b, float scale, float* sum, float* partial, float* d_a, void* stream_)
+{
+    return l1_forward_impl(n, a, b, scale, sum, partial, d_a, true, stream_);
 }
 
 int gls_l1_backward(int64_t n, const float* a, const float* b, const float* g, float scale, float* d_a, void* stream_)

@@ -819,9 +819,10 @@ static int backward_impl(const GsrSettings* settings, int32_t P, int32_t M, cons
     pa.use_precomp_cov = pre_cov ? 1 : 0;
     pa.use_precomp_color = pre_col ? 1 : 0;
     pa.dL_dmeans3D = dL_dmeans3D; pa.dL_dmeans2D = dL_dmeans2D; pa.dL_dsh = pre_col ? nullptr : dL_dsh; pa.dL_dsh_rest = shs_rest ? dL_dsh_rest : nullptr;
-    pa.dL_dcolors = dL_dcolors; pa.dL_dopacity = dL_dopacity;
+    // leaves entries (bound != nullptr): colours come from SH and the covariance from scale / rotation there, nobody reads these two
+    pa.dL_dcolors = bound ? nullptr : dL_dcolors; pa.dL_dopacity = dL_dopacity;
     pa.dL_dscales = pre_cov ? nullptr : dL_dscales; pa.dL_drotations = pre_cov ? nullptr : dL_drotations;
-    pa.dL_dcov3D = dL_dcov3D;
+    pa.dL_dcov3D = bound ? nullptr : dL_dcov3D;
     if (int rc = to_bound(bound, P, true, &pa.bound)) return rc;
     pa.opacities = opacity_logit;
     if (bound && !opacity_logit) return fail(GSR_E_ARG, "gsr_backward_bound: opacity_logit is NULL");

@@ -884,11 +884,15 @@ __global__ __launch_bounds__(GSR_PREBWD_ROWS) void k_preprocess_bwd(Settings s, 
     a.dL_dmeans2D[3 * i + 0] = g2x;
     a.dL_dmeans2D[3 * i + 1] = g2y;
     a.dL_dmeans2D[3 * i + 2] = 0.f;
+    if (a.dL_dcolors) {   // (the leaves entries have no consumer for the colour / covariance gradients: 36 bytes per splat not written)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) a.dL_dcolors[3 * i + k] = gcol[k];
+        for (int k = 0; k < 3; ++k) a.dL_dcolors[3 * i + k] = gcol[k];
+    }
     a.dL_dopacity[i] = gop;
+    if (a.dL_dcov3D) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) a.dL_dcov3D[6 * i + k] = gcov[k];
+        for (int k = 0; k < 6; ++k) a.dL_dcov3D[6 * i + k] = gcov[k];
+    }
     if (a.dL_dscales) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) a.dL_dscales[3 * i + k] = dscale[k];

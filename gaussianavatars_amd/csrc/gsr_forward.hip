@@ -985,7 +985,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     const size_t HWs = (size_t)H * W;
     float4* ck_ptr = ck + (inside ? (size_t)(W * pyi + pxi) : (size_t)(GSR_BWD_SEGMENTS - 1) * HWs);
     const size_t ck_step = inside ? HWs : 0;
-    int next_ck = GSR_BWD_SEGMENT;
+    int next_ck = s.forward_only ? 0x7fffffff : GSR_BWD_SEGMENT;   // (forward_only: no backward will read a checkpoint -- the test below never fires)
     auto checkpoint = [&](int jtop) {
         if (jtop == next_ck) {
             if (next_ck <= (GSR_BWD_SEGMENTS - 1) * GSR_BWD_SEGMENT) {
@@ -1295,7 +1295,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
             uint32_t lastqp = (uint32_t)__builtin_amdgcn_readlane((int)last_q, p);
             bool donep = false;
             int e_ck = next_ck;                               // this pixel's next checkpoint (the main loop stored the earlier ones)
-            float4* at_ck = ck + (size_t)(e_ck / GSR_BWD_SEGMENT - 1) * HWs + (size_t)(W * (int)ppy + (int)ppx);
+            float4* at_ck = ck + (size_t)((s.forward_only ? GSR_BWD_SEGMENT : e_ck) / GSR_BWD_SEGMENT - 1) * HWs + (size_t)(W * (int)ppy + (int)ppx);
             for (int c0 = j0; c0 < n && !donep; c0 += GSR_WAVE) {
                 const int j = c0 + lane;
                 const bool valid = j < n;
@@ -1371,14 +1371,16 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         const int pix_id = W * pyi + pxi;
         // the reference's n_contrib counts positions in the TILE list: the parity modes keep those in a twin stream; in
         // production it is the position in the quadrant stream (nothing reads it: the backward walks n_contrib_q)
-        const uint32_t last_contributor = !qlist ? last_q : (last_q ? (qlist + qs)[last_q - 1] + 1u : 0u);
-        final_T[pix_id] = T;
-        n_contrib[pix_id] = last_contributor;
-        n_contrib_q[pix_id] = last_q;
         const size_t HW = (size_t)H * W;
-        c_final[0 * HW + pix_id] = C0;
-        c_final[1 * HW + pix_id] = C1;
-        c_final[2 * HW + pix_id] = C2;
+        if (!s.forward_only) {   // what only the backward reads: 24 bytes per pixel (and the checkpoints above) less to store under torch.no_grad()
+            const uint32_t last_contributor = !qlist ? last_q : (last_q ? (qlist + qs)[last_q - 1] + 1u : 0u);
+            final_T[pix_id] = T;
+            n_contrib[pix_id] = last_contributor;
+            n_contrib_q[pix_id] = last_q;
+            c_final[0 * HW + pix_id] = C0;
+            c_final[1 * HW + pix_id] = C1;
+            c_final[2 * HW + pix_id] = C2;
+        }
         out_color[0 * HW + pix_id] = C0 + T * s.bg[0];
         out_color[1 * HW + pix_id] = C1 + T * s.bg[1];
         out_color[2 * HW + pix_id] = C2 + T * s.bg[2];

@@ -151,7 +151,18 @@ def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_ave
     return per_image[0] if per_image.shape[0] == 1 else per_image.mean()
 
 
+def _is_unit_seed(g: torch.Tensor) -> bool:
+    """True iff `g` IS the cached constant 1 `install_backward_seed` hands to `loss.backward()` (same storage: a host-side test, no read of
+    the device value; nothing else writes that tensor)."""
+    seed = _UNIT_SEEDS.get((g.device, g.dtype))
+    return seed is not None and g.dim() == 0 and g.data_ptr() == seed.data_ptr()
+
+
 class _L1(torch.autograd.Function):
+    """mean |a - b|.  When only `a` needs a gradient the forward also leaves sign(a - b) / n behind (gls_l1_forward_grad: one more coalesced store
+    in the pass that reads the pair anyway); a backward whose upstream gradient is the unit seed of `install_backward_seed` returns that image
+    and launches nothing (5 us of launch floor on BASELINE config 3's step), any other upstream gradient takes the scaling kernel."""
+
     @staticmethod
     def forward(ctx, a, b):
         lib = _lib.gls()
@@ -159,12 +170,21 @@ class _L1(torch.autograd.Function):
         n = a.numel()
         out = torch.empty((), dtype=torch.float32, device=dev)
         partial = torch.empty(int(lib.gls_partial_floats(1, 1, 1, 1)), dtype=torch.float32, device=dev)
-        _launch(dev, "gls_l1_forward", lib.gls_l1_forward, n, _p(a), _p(b), 1.0 / float(max(n, 1)), _p(out), _p(partial), _stream(dev))
+        scale = 1.0 / float(max(n, 1))
+        ctx.da = None
+        if ctx.needs_input_grad[0] and not ctx.needs_input_grad[1] and getattr(torch.Tensor.backward, "__gaussianavatars_amd_seed__", False):
+            ctx.da = torch.empty_like(a)
+            _launch(dev, "gls_l1_forward_grad", lib.gls_l1_forward_grad, n, _p(a), _p(b), scale, _p(out), _p(partial), _p(ctx.da), _stream(dev))
+        else:
+            _launch(dev, "gls_l1_forward", lib.gls_l1_forward, n, _p(a), _p(b), scale, _p(out), _p(partial), _stream(dev))
         ctx.save_for_backward(a, b)
         return out
 
     @staticmethod
     def backward(ctx, g):
+        da, ctx.da = ctx.da, None   # (handed out at most once: a second backward over a retained graph takes the kernel below)
+        if da is not None and _is_unit_seed(g):
+            return da, None
         a, b = ctx.saved_tensors
         lib = _lib.gls()
         dev = a.device
@@ -182,7 +202,7 @@ class _L1(torch.autograd.Function):
 
 
 def l1_loss(network_output: torch.Tensor, gt: torch.Tensor):
-    """utils/loss_utils.py:17-18: mean |network_output - gt| (2 launches forward, 1 backward)."""
+    """utils/loss_utils.py:17-18: mean |network_output - gt| (2 launches forward; backward 1, or none when seeded with the unit seed)."""
     if network_output.shape != gt.shape:
         gt = gt.expand_as(network_output)
     return _L1.apply(_as_input(network_output, "network_output"), _as_input(gt, "gt"))

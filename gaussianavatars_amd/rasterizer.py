@@ -98,6 +98,29 @@ def set_fast_blend(enabled) -> int:
 # a word that is read before it is written shows up in the tests instead of depending on what the caching allocator recycled.
 _poison_state = int(os.environ.get("GSR_POISON_STATE", "0"))
 
+# Whether a backward can follow a forward is decided by the caller's GRAD MODE as well as by its inputs: inside Function.forward autograd is
+# always off and ctx.needs_input_grad only repeats the inputs' requires_grad flags -- render.py / fps_benchmark_*.py render nn.Parameters under
+# torch.no_grad(), and render() hands every call a screen-space leaf that requires a gradient.  The entry points below note the mode around
+# .apply (thread-local); a direct .apply from elsewhere finds None and is treated as "a backward may follow".
+import threading as _threading
+
+_call_state = _threading.local()
+
+
+def _apply_noting_grad_mode(fn, *args):
+    prev = getattr(_call_state, "grad", None)
+    _call_state.grad = torch.is_grad_enabled()
+    try:
+        return fn.apply(*args)
+    finally:
+        _call_state.grad = prev
+
+
+def _backward_may_follow(needs) -> bool:
+    grad = getattr(_call_state, "grad", None)
+    return bool(needs) and (grad is None or grad)
+
+
 
 def set_poison_state(enabled: bool) -> bool:
     """Process-wide debugging switch; returns the previous value."""
@@ -294,7 +317,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         keep: list = []
         s = _make_settings(raster_settings, keep)
         # no differentiable input (torch.no_grad, inference): no backward can follow, the forward skips preparing for one
-        s.forward_only = int(not any(ctx.needs_input_grad[:8]) and not (len(ctx.needs_input_grad) > 9 and ctx.needs_input_grad[9]))
+        s.forward_only = int(not _backward_may_follow(any(ctx.needs_input_grad[:8]) or (len(ctx.needs_input_grad) > 9 and ctx.needs_input_grad[9])))
         means3D = _f32c(means3D, "means3D")
         if means3D.dim() != 2 or means3D.shape[1] != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -366,7 +389,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
         if defer is None:
             _forward_peak[0] = max(_forward_peak[0], I)
-        _last_info.update(num_rendered=I if defer is None else -1, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod,
+        _last_info.update(num_rendered=I if defer is None else -1, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod, forward_only=bool(s.forward_only),
                           binning_path=int(bl.path), rank_bands=int(bl.nbands), bound=False)   # 0 rank path, 1 depth-ordered scatter, 2 per-tile sort (include/gsr.h)
         _last_binning[0] = binning
 
@@ -443,7 +466,7 @@ class _RasterizeBound(torch.autograd.Function):
         keep: list = []
         s = _make_settings(raster_settings, keep)
         need = ctx.needs_input_grad
-        s.forward_only = int(not any(need[:11]))
+        s.forward_only = int(not _backward_may_follow(any(need[:11])))
         xyz, sh_dc, sh_rest = _f32c(xyz, "_xyz"), _f32c(sh_dc, "_features_dc"), _f32c(sh_rest, "_features_rest")
         opacity_logit, log_scaling, rotation = _f32c(opacity_logit, "_opacity"), _f32c(log_scaling, "_scaling"), _f32c(rotation, "_rotation")
         P = xyz.shape[0]
@@ -503,7 +526,7 @@ class _RasterizeBound(torch.autograd.Function):
             _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
         if defer is None:
             _forward_peak[0] = max(_forward_peak[0], I)
-        _last_info.update(num_rendered=I if defer is None else -1, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod,
+        _last_info.update(num_rendered=I if defer is None else -1, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod, forward_only=bool(s.forward_only),
                           binning_path=int(bl.path), rank_bands=int(bl.nbands), bound=True)
         _last_binning[0] = binning
         ctx.raster_settings = raster_settings
@@ -574,21 +597,21 @@ def rasterize_leaves(xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, r
     """-> (color, radii, visibility_filter) of an UNBOUND model straight from its leaves: get_scaling = exp, get_rotation = normalize,
     get_opacity = sigmoid (scene/gaussian_model.py:113-160) are evaluated inside the rasterizer's first kernel and their chain rule in
     its last one -- no activation launches, no activated tensors."""
-    return _RasterizeBound.apply(xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, None, None, None, None, None, None,
+    return _apply_noting_grad_mode(_RasterizeBound, xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, None, None, None, None, None, None,
                                  raster_settings)
 
 
 def rasterize_bound(xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, face_R, face_scale, face_center, face_quat, binding, csr,
                     raster_settings):
     """-> (color, radii, visibility_filter) of a mesh-bound model straight from its leaves and face frames (see _RasterizeBound)."""
-    return _RasterizeBound.apply(xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, face_R, face_scale, face_center, face_quat,
+    return _apply_noting_grad_mode(_RasterizeBound, xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, face_R, face_scale, face_center, face_quat,
                                  binding, csr, raster_settings)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
                         sh_rest=None):
     """-> (color, radii), the reference's pair."""
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+    return _apply_noting_grad_mode(_RasterizeGaussians, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings, sh_rest)[:2]
 
 
@@ -628,7 +651,7 @@ class GaussianRasterizer(nn.Module):
         scales = empty if scales is None else scales
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
-        color, radii, visible = _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+        color, radii, visible = _apply_noting_grad_mode(_RasterizeGaussians, means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                                           cov3D_precomp, rs, shs_rest)
         # extension: `radii > 0` of THIS call as the forward kernel wrote it (what render() returns as visibility_filter)
         self.visibility_filter = visible

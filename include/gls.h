@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GLS_ABI_VERSION 1
+#define GLS_ABI_VERSION 2
 #define GLS_OK 0
 #define GLS_E_ARG (-1)
 #define GLS_E_HIP (-2)
@@ -50,6 +50,9 @@ int gls_l1_ssim_backward(int32_t B, int32_t C, int32_t H, int32_t W, const float
 
 /* n elements.  sum: 1 float <- scale * sum |a-b|.  partial: gls_partial_floats(1,1,1,1) floats. */
 int gls_l1_forward(int64_t n, const float* a, const float* b, float scale, float* sum, float* partial, void* stream);
+/* The same, and d_a: n floats <- scale * sign(a-b) = d(sum)/d(a), written by the pass that reads the pair anyway: a backward whose
+ * upstream gradient is the constant 1 (utils/loss_utils.py:17-18 followed by loss.backward(), BASELINE config 3) launches nothing. (ABI 2) */
+int gls_l1_forward_grad(int64_t n, const float* a, const float* b, float scale, float* sum, float* partial, float* d_a, void* stream);
 /* g: 1 DEVICE float dL/d(sum).  d_a: n floats <- g * scale * sign(a-b). */
 int gls_l1_backward(int64_t n, const float* a, const float* b, const float* g, float scale, float* d_a, void* stream);
 

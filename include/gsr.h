@@ -79,8 +79,9 @@ typedef struct GsrSettings {
                                     The binning path of a call is GsrBinningLayout.path.                                       */
     int32_t forward_only;     /* !=0: no backward will follow this forward (inference, torch.no_grad): the forward skips zero-filling
                                  the backward's per-splat accumulators (48 B per visible splat) and writing what only the backward reads
-                                 (GsrGeomLayout.cov3D, clamped; rect on the rank path); gsr_backward on such a state is an
-                                 error                                                                                   */
+                                 (GsrGeomLayout.cov3D, clamped; rect on the rank path; round 4: the image state as well -- final_T,
+                                 n_contrib, n_contrib_q, c_final and the blend checkpoints stay unwritten, only out_color leaves the
+                                 blend); gsr_backward on such a state is an error                                          */
     int32_t deterministic;    /* !=0: bit-reproducible backward.  The blend backward then adds its per-(wave, splat) partial sums as 64-bit
                                  FIXED-POINT integers (integer addition is associative: the result does not depend on the order the
                                  atomics land in), scaled by a power of two derived from max |dL/dpixel| (one extra reduction kernel);
@@ -361,7 +362,8 @@ int gsr_forward_bound(const GsrSettings* settings, int32_t P, int32_t M, const G
                       const float* shs_rest, const float* opacity_logit, const float* log_scales, const float* rot_local,
                       float* out_color, int32_t* radii, void* geom, void* binning, int64_t binning_capacity, void* img,
                       int64_t* num_rendered_host, void* stream);
-/* scratch9: 9 P floats (the colour / covariance gradients the world-space entry hands out, internal here) */
+/* scratch9: 9 P floats, kept in the signature (rounds 2-3 parked the colour / covariance gradients of the world-space entry there; since round 4
+ * nothing is written to it: a leaves entry has no consumer for those two, 36 bytes per splat less to store) */
 int gsr_backward_bound(const GsrSettings* settings, int32_t P, int32_t M, const GsrBound* bound, const float* xyz_local, const float* shs,
                        const float* shs_rest, const float* opacity_logit, const float* log_scales, const float* rot_local,
                        const int32_t* radii, void* geom, const void* binning, int64_t binning_capacity, const void* img,

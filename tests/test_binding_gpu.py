@@ -187,7 +187,12 @@ def test_mesh_backward_gather_equals_the_scatter_form(monkeypatch, with_verts_gr
     """select_mesh_by_timestep + update_mesh_properties as one autograd node (binding.mesh_frames_timestep): its backward with the face-frame
     and skinning backward as ONE gathering launch (gab_mesh_backward_prepared: no d_verts buffer, no global atomics into the vertices)
     against the scatter + skinning launches it replaces, full-size rig, every per-face output weighted, with and without a gradient
-    arriving at the posed vertices themselves; twice over the same forward.  Both are fp32 sums in different orders: 1e-4 of each row's max."""
+    arriving at the posed vertices themselves; twice over the same forward.  Both are fp32 sums in different orders (float atomics land in arrival
+    order, so even the same kernel differs run to run): 1e-4 of each row's max -- except d_translation, 1e-3: it is the plain sum of the 5143
+    per-vertex gradients, whose face-frame parts (orientation, scale: translation invariant) cancel exactly in mathematics and are hundreds of
+    times larger than what is left, so the sum of 161 workgroup partials carries their rounding (tools/mesh_bwd_repeat.py, 40 repetitions of this
+    test's body on an MI355X: worst run-to-run difference 1.6e-4 of the row's max for translation, 2.6e-5 for the rotation, <= 1.2e-5 elsewhere;
+    the composed-torch formulation sums the same terms in fp32 and is no better conditioned)."""
     from gaussianavatars_amd import binding as B
 
     dev = _dev()
@@ -199,6 +204,7 @@ def test_mesh_backward_gather_equals_the_scatter_form(monkeypatch, with_verts_gr
     gen = torch.Generator(device="cpu").manual_seed(7)
     wts = [torch.randn(s, generator=gen).to(dev) for s in ((F, 3), (F, 3, 3), (F, 1), (F, 4), (1, rig["v_template"].shape[0], 3))]
     keys = ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation")
+    tol = {k: (1e-3 if k == "translation" else 1e-4) for k in keys}
     res = {}
     for mode in ("merged", "split"):
         monkeypatch.setenv("GAA_MESH_BWD", mode)
@@ -213,11 +219,11 @@ def test_mesh_backward_gather_equals_the_scatter_form(monkeypatch, with_verts_gr
             fp[k].grad = None
         loss.backward()
         for k in keys:
-            assert float((fp[k].grad - first[k]).abs().max()) <= 1e-4 * float(first[k].abs().max()), f"{k}: a second backward over the same forward differs"
+            assert float((fp[k].grad - first[k]).abs().max()) <= tol[k] * float(first[k].abs().max()), f"{k}: a second backward over the same forward differs"
             assert float(fp[k].grad[:5].abs().max()) == 0.0 and float(fp[k].grad[6:].abs().max()) == 0.0, f"{k}: gradient outside row 5"
         res[mode] = first
     for k in keys:
-        _close(res["merged"][k][5], res["split"][k][5], 1e-4, f"d_{k}: gather vs scatter")
+        _close(res["merged"][k][5], res["split"][k][5], tol[k], f"d_{k}: gather vs scatter")
 
 
 def test_face_frames_and_bind_forward_backward_vs_torch():

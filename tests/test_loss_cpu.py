@@ -59,15 +59,16 @@ def test_gls_library_exports_every_declared_symbol():
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "gls.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(gls_[a-z0-9_]+)\s*\(", txt)))
     lib = _lib.gls()
-    assert len(names) == 8
+    assert len(names) == 9
     for n in names:
         assert hasattr(lib, n), f"include/gls.h declares {n} but libgls_hip.so does not export it"
         assert n in _lib.GLS_SYMBOLS
-    assert lib.gls_abi_version() == 1
+    assert lib.gls_abi_version() == 2
     assert lib.gls_partial_floats(1, 3, 802, 550) == 2 * 51 * 35 * 3
     # argument errors are reported before any device work
     assert lib.gls_l1_ssim_forward(1, 3, 0, 5, None, None, 1.0, None, None, None, None) < 0
     assert b"bad image shape" in lib.gls_last_error()
+    assert lib.gls_l1_forward_grad(16, None, None, 1.0, None, None, None, None) < 0   # (ABI 2: the forward that also leaves the gradient image)
     assert lib.gls_l1_ssim_forward(1, 3, 8, 8, None, None, 1.0, None, None, None, None) < 0 and b"null" in lib.gls_last_error()
 
 

@@ -207,3 +207,61 @@ def test_seeded_backward_gives_the_gradients_of_the_engines_own_seed():
     finally:
         assert L.install_backward_seed(False) is True
     assert torch.Tensor.backward is torch_backward
+
+
+def test_l1_backward_on_the_unit_seed_launches_nothing_and_equals_the_kernel():
+    """`l1_loss(image, gt).backward()` under install_backward_seed: the forward (gls_l1_forward_grad) leaves sign(a - b) / n behind and the backward
+    returns it without a launch; the same bits as gls_l1_backward gives.  Any other upstream gradient (a scaled loss, an explicit seed, a second
+    backward over a retained graph, no seed installed) takes the kernel."""
+    from gaussianavatars_amd import _lib
+    from gaussianavatars_amd import loss as L
+
+    DEV = _dev()
+    lib = _lib.gls()
+    calls = []
+    real_bwd, real_fwd_grad = lib.gls_l1_backward, lib.gls_l1_forward_grad
+
+    class Spy:
+        def __init__(self, fn, name):
+            self.fn, self.name = fn, name
+
+        def __call__(self, *a):
+            calls.append(self.name)
+            return self.fn(*a)
+
+    for n in ((3, 802, 550), (3, 37, 41), (5,)):   # BASELINE image; n % 4 != 0 tails
+        a0, b = torch.rand(*n, device=DEV), torch.rand(*n, device=DEV)
+        a0.view(-1)[:2] = b.view(-1)[:2]            # exact ties: gradient 0
+        ref = torch.sign(a0 - b) / a0.numel()
+        L.install_backward_seed(False)
+        a = a0.clone().requires_grad_(True)
+        L.l1_loss(a, b).backward()
+        g_kernel = a.grad.clone()
+        assert torch.equal(g_kernel, ref)
+        assert L.install_backward_seed() is True
+        lib.gls_l1_backward, lib.gls_l1_forward_grad = Spy(real_bwd, "bwd"), Spy(real_fwd_grad, "fwd_grad")
+        try:
+            calls.clear()
+            a = a0.clone().requires_grad_(True)
+            loss = L.l1_loss(a, b)
+            loss.backward(retain_graph=True)
+            assert calls == ["fwd_grad"] and torch.equal(a.grad, g_kernel)
+            assert abs(float(loss) - float((a0 - b).abs().mean())) < 2e-6
+            a.grad = None
+            loss.backward()                                        # the image was handed out once: the kernel this time
+            assert calls == ["fwd_grad", "bwd"] and torch.equal(a.grad, g_kernel)
+            calls.clear()
+            a = a0.clone().requires_grad_(True)
+            (0.8 * L.l1_loss(a, b)).backward()                     # train.py:132's weighting: not the unit seed
+            assert calls == ["fwd_grad", "bwd"] and torch.equal(a.grad, 0.8 * g_kernel)
+            calls.clear()
+            a = a0.clone().requires_grad_(True)
+            L.l1_loss(a, b).backward(torch.full((), 3.0, device=DEV))
+            assert calls == ["fwd_grad", "bwd"] and torch.equal(a.grad, 3.0 * g_kernel)
+            calls.clear()
+            a, b2 = a0.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            L.l1_loss(a, b2).backward()                            # both images differentiable: the plain forward
+            assert calls == ["bwd", "bwd"] and torch.equal(a.grad, g_kernel) and torch.equal(b2.grad, -g_kernel)
+        finally:
+            lib.gls_l1_backward, lib.gls_l1_forward_grad = real_bwd, real_fwd_grad
+            L.install_backward_seed(False)

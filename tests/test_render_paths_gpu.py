@@ -258,3 +258,59 @@ def test_morton_ordered_model_renders_the_same_frame():
     for a, b in zip(gr0 + [vs0], gr1 + [vs1]):
         err = float((a[perm] - b).abs().max()) / (float(a.abs().max()) + 1e-30)
         assert err <= 5e-3, err
+
+
+@pytest.mark.fast_blend
+@pytest.mark.parametrize("fast", [True, False])
+def test_no_grad_render_of_trainable_parameters_takes_the_forward_only_path(fast):
+    """render.py:68-76 / fps_benchmark_*.py render a model whose leaves are nn.Parameters under torch.no_grad(), and render() hands the rasterizer a
+    screen-space leaf that requires a gradient: whether a backward can follow is the caller's grad mode, not ctx.needs_input_grad (which only
+    repeats requires_grad).  Under no_grad every entry (bound, leaves, world-space module) must take GsrSettings.forward_only -- no accumulator
+    zero-fill, no covariance / checkpoint / final-state stores -- and give the SAME BITS as the frame rendered with autograd on, whose backward
+    still works afterwards; poisoned state buffers show that nothing the image depends on was skipped."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import bench
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd.gaussian_renderer import render
+
+    dev = torch.device("cuda:0")
+    prev_fast, prev_poison = R.set_fast_blend(fast), R._poison_state
+    R._poison_state = 1
+    try:
+        H, W = 208, 176
+        gb, cam = bench.build_scene(dev, 20000, 3, W, H, 4, "fused", True)
+        gb.select_mesh_by_timestep(2)
+        gu, cam_u = _scene(dev)
+        bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+        for g, c, what in ((gb, cam, "bound"), (gu, cam_u, "leaves")):
+            pkg = render(c, g, bench.Pipe, bg)
+            info = R.last_forward_info()
+            assert info["forward_only"] is False, what
+            with torch.no_grad():
+                ng = render(c, g, bench.Pipe, bg)
+            info = R.last_forward_info()
+            assert info["forward_only"] is True, what
+            assert torch.equal(ng["render"].view(torch.int32), pkg["render"].detach().view(torch.int32)), what
+            assert torch.equal(ng["radii"], pkg["radii"]) and torch.equal(ng["visibility_filter"], pkg["visibility_filter"]), what
+            assert ng["render"].grad_fn is None
+            pkg["render"].sum().backward()      # the grad-mode frame's state is its own: its backward is untouched by the frame in between
+            assert float(g._xyz.grad.abs().max()) > 0 and bool(torch.isfinite(g._xyz.grad).all())
+        # the reference-shaped module (world-space tensors, what an unpatched gaussian_renderer.render() calls)
+        rs = R.GaussianRasterizationSettings(H, W, math.tan(cam_u.FoVx * 0.5), math.tan(cam_u.FoVy * 0.5), bg, 1.0, cam_u.world_view_transform,
+                                             cam_u.full_proj_transform, 3, cam_u.camera_center, False, False)
+        rast = R.GaussianRasterizer(rs)
+        args = dict(means3D=gu.get_xyz, means2D=torch.zeros_like(gu.get_xyz, requires_grad=True), opacities=gu.get_opacity, shs=gu.get_features,
+                    scales=gu.get_scaling, rotations=gu.get_rotation)
+        img, radii = rast(**args)
+        assert R.last_forward_info()["forward_only"] is False
+        with torch.no_grad():
+            img2, radii2 = rast(**args)
+        assert R.last_forward_info()["forward_only"] is True
+        assert torch.equal(img2.view(torch.int32), img.detach().view(torch.int32)) and torch.equal(radii, radii2)
+        with torch.inference_mode():
+            img3, _ = rast(**{k: v.detach() for k, v in args.items()})
+        assert R.last_forward_info()["forward_only"] is True and torch.equal(img3.view(torch.int32), img.detach().view(torch.int32))
+    finally:
+        R.set_fast_blend(prev_fast)
+        R._poison_state = prev_poison
