@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -521,10 +522,18 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         if (count_lds > 48 * 1024) {
             if (int rc = ensure_dynamic_lds((const void*)gsr::k_rcount, (size_t)count_lds)) return rc;
         }
-        if (hist_bytes > 48 * 1024)
+        // the scatter's dynamic LDS: the tile histogram, then (when they fit the 160 KB beside it and the sort's 16 KB of keys) the staging
+        // rows of the balanced expansion -- GSR_RSCATTER_BALANCED=0 keeps the lockstep form (A/B runs)
+        const bool one_band_lds = (int)bl.nbands <= 1;
+        const size_t stage_bytes = GSR_RSCATTER_STAGE_BYTES(one_band_lds), hist_al = (hist_bytes + 15) & ~(size_t)15;
+        static const bool balanced_on = [] { const char* e = getenv("GSR_RSCATTER_BALANCED"); return !(e && e[0] == '0'); }();
+        const bool balanced = balanced_on && hist_al + stage_bytes + 20 * 1024 <= 160 * 1024;
+        const int stage_off = balanced ? (int)hist_al : -1;
+        const size_t scatter_lds = balanced ? hist_al + stage_bytes : hist_bytes;
+        if (scatter_lds > 48 * 1024)
         {
-            if (int rc = ensure_dynamic_lds((const void*)gsr::k_rsort_rscatter, (size_t)hist_bytes)) return rc;
-            if (int rc = ensure_dynamic_lds((const void*)gsr::k_rscatter<8>, (size_t)hist_bytes)) return rc;
+            if (int rc = ensure_dynamic_lds((const void*)gsr::k_rsort_rscatter, scatter_lds)) return rc;
+            if (int rc = ensure_dynamic_lds((const void*)gsr::k_rscatter<8>, scatter_lds)) return rc;
         }
         uint32_t* block_hist = (uint32_t*)(b + bl.block_hist);
         uint32_t* bcount = (uint32_t*)(b + bl.bcount);
@@ -583,15 +592,15 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         if (pblocks > 0) {
             TIMED(GSR_K_SCATTER, stream);
             if (one_band) {   // the depth sort beside the scatter, one launch (k_rsort_rscatter): 4-byte entries, k_tile_rank gathers the ranks
-                hipLaunchKernelGGL(gsr::k_rsort_rscatter, dim3(bin_blocks + nb), dim3(GSR_RANK_BIN_THREADS), hist_bytes, stream, bin_blocks, P, gx, tiles,
+                hipLaunchKernelGGL(gsr::k_rsort_rscatter, dim3(bin_blocks + nb), dim3(GSR_RANK_BIN_THREADS), scatter_lds, stream, bin_blocks, P, gx, tiles,
                                    (const ushort4*)srect, (const float4*)pa.sspan, (const uint32_t*)tile_start, tile_cursor, (uint32_t*)ranks, cap,
                                    (const unsigned long long*)total_dev, (const uint32_t*)block_hist, (const uint32_t*)bcount, (const uint32_t*)bstart,
-                                   dkeys, dtmp, rank);
+                                   dkeys, dtmp, rank, stage_off);
                 KERNEL_CHECK("k_rsort_rscatter", stream, dbg);
             } else {
-                hipLaunchKernelGGL(gsr::k_rscatter<8>, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), hist_bytes, stream, P, gx, tiles, bt,
+                hipLaunchKernelGGL(gsr::k_rscatter<8>, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), scatter_lds, stream, P, gx, tiles, bt,
                                    (const ushort4*)srect, (const uint32_t*)rank, (const float4*)pa.sspan, (const uint32_t*)tile_start, tile_cursor, ranks, cap,
-                                   (const unsigned long long*)total_dev, (const uint32_t*)block_hist);
+                                   (const unsigned long long*)total_dev, (const uint32_t*)block_hist, stage_off);
                 KERNEL_CHECK("k_rscatter", stream, dbg);
             }
         }

@@ -611,6 +611,9 @@ __device__ __forceinline__ int splat_sum_exponents(uint32_t tiles, float conA, f
 __global__ void k_preprocess_bwd(Settings s, PreBwdArgs a);
 // rank path (gsr_rank.hip)
 // true: the grid of tile corners does not fit the LDS histogram; instances are counted / placed with L2 atomics
+// the splats of one workgroup of the rank path's three chunked passes (k_rcount reserves what k_rdscatter / k_rscatter fill: the same chunks in
+// all three): an even share rounded up to 32 -- round 3 rounded to 256, which at 100 k splats left 60 of the 256 workgroups without a chunk
+__host__ __device__ inline int rank_chunk(int P, int nblk) { return ((P + nblk - 1) / nblk + 31) / 32 * 32; }
 __host__ __device__ inline bool rank_direct(int gx, int tiles) { return (long long)(gx + 1) * (long long)(tiles / gx + 1) > (long long)GSR_RANK_HIST_TILES; }
 __global__ void k_rcount(int P, int gx, int tiles, int pblocks, uint32_t nb, const ushort4* srect, const uint32_t* tiles_touched,
                          const float* depths, const uint2* pstat, uint32_t* tile_count, unsigned long long* rect_total, uint32_t* block_hist,
@@ -633,6 +636,8 @@ __host__ __device__ inline int rank_bands(long long P, int gy, bool force, int* 
     *band_rows = bt;
     return (gy + bt - 1) / bt;
 }
+// bytes of LDS the balanced expansion of k_rscatter / k_rsort_rscatter stages its 64 splats per wave in (gsr_rank.hip: RscatterStage)
+#define GSR_RSCATTER_STAGE_BYTES(LEAN) ((size_t)(GSR_RANK_BIN_THREADS / 64) * 64 * (((LEAN) ? 3 : 4) * 16 + 4))
 struct BandTables {              // rank path with bands (gsr_rank.hip)
     uint32_t nbands;
     float inv_band_rows;
@@ -646,10 +651,11 @@ __global__ void k_rdsort(const uint32_t* bcount, const uint32_t* bstart, unsigne
 __global__ void k_rsort_rscatter(int scatter_blocks, int P, int gx, int tiles, const ushort4* srect, const float4* sspan, const uint32_t* tile_start,
                                  uint32_t* tile_cursor, uint32_t* entries, unsigned long long capacity, const unsigned long long* total_dev,
                                  const uint32_t* block_hist, const uint32_t* bcount, const uint32_t* bstart, unsigned long long* dkeys,
-                                 unsigned long long* dtmp, uint32_t* rank);
+                                 unsigned long long* dtmp, uint32_t* rank, int stage_off);
 template <int G>
 __global__ void k_rscatter(int P, int gx, int tiles, BandTables bt, const ushort4* srect, const uint32_t* rank, const float4* sspan, const uint32_t* tile_start,
-                           uint32_t* tile_cursor, uint2* ranks, unsigned long long capacity, const unsigned long long* total_dev, const uint32_t* block_hist);
+                           uint32_t* tile_cursor, uint2* ranks, unsigned long long capacity, const unsigned long long* total_dev, const uint32_t* block_hist,
+                           int stage_off);
 __global__ void k_tile_rank(uint32_t words, int gx, int nbands, float inv_band_rows, const uint4* tdesc, const uint2* ranks, const uint32_t* rank_of,
                             const float* depths, const BinHeader* hdr, unsigned long long* keys, uint32_t* point_list,
                             uint32_t* qlist, uint32_t* qpos, uint32_t* qcount, uint32_t* qstart, unsigned long long capacity,

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int P, int gx, 
     float lo, scale;
     rank_bucket_map(mn, mx, nb, lo, scale);
 
-    const int chunk = ((P + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256 * 256;
+    const int chunk = rank_chunk(P, (int)gridDim.x);
     const int begin = blockIdx.x * chunk;
     const int end = min(P, begin + chunk);
     unsigned long long touched = 0;
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rdscatter(int P, uint3
     __syncthreads();
     float lo, scale;
     rank_bucket_map(hdr->dmin_bits, hdr->dmax_bits, nb, lo, scale);
-    const int chunk = ((P + (int)nblk - 1) / (int)nblk + 255) / 256 * 256;
+    const int chunk = rank_chunk(P, (int)nblk);
     const int begin = blockIdx.x * chunk, end = min(P, begin + chunk);
     for (int i = begin + tid; i < end; i += NT) {
         const ushort4 r = srect[i];
@@ -439,10 +439,10 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rdscatter(int P, uint3
 // by rank, for k_band_count / k_band_rank
 __device__ __forceinline__ void depth_sort_bucket(uint32_t b, const uint32_t* __restrict__ bcount, const uint32_t* __restrict__ bstart,
                                                   unsigned long long* __restrict__ dkeys, unsigned long long* __restrict__ tmp,
-                                                  uint32_t* __restrict__ rank, uint2* __restrict__ obs, const ushort4* __restrict__ srect, int band_rows)
+                                                  uint32_t* __restrict__ rank, uint2* __restrict__ obs, const ushort4* __restrict__ srect, int band_rows,
+                                                  unsigned long long* __restrict__ skeys /* GSR_SORT_SMALL_KEYS keys of LDS */)
 {
     constexpr int KEYS = GSR_SORT_SMALL_KEYS, THREADS = 256, EPT = KEYS / THREADS;
-    __shared__ unsigned long long skeys[KEYS];
     const uint32_t n = bcount[b];
     if (n == 0) return;
     const uint32_t start = bstart[b];
@@ -477,7 +477,8 @@ __global__ __launch_bounds__(256) void k_rdsort(const uint32_t* __restrict__ bco
                                                  uint32_t* __restrict__ rank, uint2* __restrict__ obs,
                                                  const ushort4* __restrict__ srect, int band_rows)
 {
-    depth_sort_bucket(blockIdx.x, bcount, bstart, dkeys, tmp, rank, obs, srect, band_rows);
+    __shared__ unsigned long long skeys[GSR_SORT_SMALL_KEYS];
+    depth_sort_bucket(blockIdx.x, bcount, bstart, dkeys, tmp, rank, obs, srect, band_rows, skeys);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -606,7 +607,7 @@ __device__ __forceinline__ void rscatter_body(int P, int gx, int tiles, BandTabl
     const bool direct = rank_direct(gx, tiles);
     const bool bands = !LEAN && bt.nbands > 1;
     const uint4* __restrict__ rank4 = reinterpret_cast<const uint4*>(rank);   // bands: the ranks inside the first four bands of the rect
-    const int chunk = ((P + nblk - 1) / nblk + 255) / 256 * 256;
+    const int chunk = rank_chunk(P, nblk);
     const int begin = blockIdx.x * chunk;
     const int end = min(P, begin + chunk);
     // a splat's inputs, fetched one round ahead of their use (all four loads are independent: rank / operands of a splat that is
@@ -672,15 +673,183 @@ __device__ __forceinline__ void rscatter_body(int P, int gx, int tiles, BandTabl
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same pass with the tile instances dealt EVENLY to the lanes (round 4).  Above, G lanes expand one splat's rect in lockstep with the
+// wave's other groups: a rect of n tiles costs ceil(n / G) trips whether its last trip fills the group or not, and the wave makes as many
+// trips as its LARGEST rect needs -- about half of the lane-trips carry an instance (rects of 12 - 23 tiles, G = 8 / 16), and every trip is
+// the ~150 instructions of the quadrant mask, the slot and the store.  Here a wave takes 64 splats (a splat per lane: coalesced loads),
+// scans their tile counts, parks the operands of the 64 in its own corner of LDS, and walks the instances 64 at a time: instance k belongs
+// to the splat whose range [excl, excl + n) holds it -- found without a search: every splat drops its lane number at the window position
+// its range starts at, an inclusive max-scan (DPP) spreads it over the positions behind, the previous window's last owner carries over --
+// and its operands come back as four ds_read_b128 at the owner's row.  Every lane of every trip but the round's last carries an instance.
+// Rects beyond 256 tiles go through the whole-wave expansion as before.  No barriers: the staging rows are the wave's own, and LDS
+// instructions of one wave execute in order.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_scan_incl_max_u32(uint32_t v)
+{
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1 (lanes without a source see 0)
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// What one lane wrote to the wave's LDS rows, another lane reads: to the compiler that is a data race between threads (it forwarded a lane's
+// own store of 0 to its later load of the same word and dropped the load: the owners the other lanes had written never arrived).  A
+// wavefront-scope release / acquire pair around a wave barrier makes the hand-over visible to it; the hardware needs nothing (the LDS
+// instructions of one wave execute in order), so no instruction is emitted.
+__device__ __forceinline__ void wave_lds_handover()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <bool LEAN>
+struct RscatterStage {
+    static constexpr int ROW = LEAN ? 3 : 4;                       // uint4 per splat: span (2), [band ranks], (rect, width, excl, splat)
+    uint4 row[GSR_RANK_BIN_THREADS / 64][64][ROW];
+    uint32_t own[GSR_RANK_BIN_THREADS / 64][64];
+};
+template <bool LEAN>
+__device__ __forceinline__ void rscatter_balanced(RscatterStage<LEAN>& stage, int P, int gx, int tiles, BandTables bt, const ushort4* __restrict__ srect,
+                                                  const uint32_t* __restrict__ rank, const float4* __restrict__ sspan,
+                                                  const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
+                                                  uint2* __restrict__ ranks, unsigned long long capacity,
+                                                  const unsigned long long* __restrict__ total_dev,
+                                                  const uint32_t* __restrict__ block_hist, int nblk)
+{
+    extern __shared__ uint32_t hist[];
+    uint32_t* __restrict__ const lean = reinterpret_cast<uint32_t*>(ranks);
+    constexpr int NT = GSR_RANK_BIN_THREADS, ROW = RscatterStage<LEAN>::ROW;
+    constexpr uint32_t BIG = 256;
+    if (*total_dev > capacity) return;  // the host will grow the buffer and replay the frame
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool direct = rank_direct(gx, tiles);
+    const bool bands = !LEAN && bt.nbands > 1;
+    const uint4* __restrict__ rank4 = reinterpret_cast<const uint4*>(rank);
+    const int chunk = rank_chunk(P, nblk);
+    const int begin = blockIdx.x * chunk;
+    const int end = min(P, begin + chunk);
+    uint4(*const rows)[ROW] = stage.row[wv];
+    uint32_t* const own = stage.own[wv];
+    struct In { ushort4 q; uint4 rk; float4 s0, s1; };
+    auto fetch = [&](int i) {
+        In v;
+        v.q = make_ushort4(0, 0, 0, 0); v.rk = make_uint4(0u, 0u, 0u, 0u); v.s0 = v.s1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < end) {
+            v.q = srect[i]; v.s0 = sspan[2 * (size_t)i]; v.s1 = sspan[2 * (size_t)i + 1];
+            if (bands) v.rk = rank4[i]; else if (!LEAN) v.rk.x = rank[i];
+        }
+        return v;
+    };
+    // a wave takes SB splats per round (lanes SB.. carry none into the scan, but every lane takes instances): 64 on large frames; on small
+    // ones the chunk is dealt over all sixteen waves -- at 100 k splats a workgroup's ~400 would otherwise keep seven waves busy and nine idle
+    const int SB = min(64, max(8, (chunk + NT / 64 - 1) / (NT / 64)));
+    const int stride = SB * (NT / 64);
+    auto mine_of = [&](int base) { return lane < SB ? base + wv * SB + lane : end; };
+    In nxt = fetch(mine_of(begin));
+    if (!direct) {
+        const uint32_t* __restrict__ mine = block_hist + (size_t)blockIdx.x * tiles;
+        for (int t = tid; t < tiles; t += NT) hist[t] = tile_start[t] + mine[t];   // first slot of this workgroup in tile t (k_rcount reserved it)
+        __syncthreads();
+    }
+    auto f4u = [](float4 v) { return make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)); };
+    // one instance: tile (x, y) of the splat whose operands are (sp, rk4, first band fb, index idx)
+    auto emit = [&](uint32_t x, uint32_t y, const Span& b, const uint4& brk4, uint32_t bfb, uint32_t bidx) {
+        const uint32_t tile = y * (uint32_t)gx + x;
+        uint32_t brk = brk4.x;
+        if (bands) {   // the splat's rank inside the tile's band
+            const uint32_t band = (uint32_t)(((float)y + 0.5f) * bt.inv_band_rows), k = band - bfb;
+            brk = k == 0u ? brk4.x : k == 1u ? brk4.y : k == 2u ? brk4.z : brk4.w;
+            if (k > 3u) brk = bt.over[(size_t)bidx * bt.nbands + band];   // fifth band onwards of a very tall rect
+        }
+        const uint32_t m = quadrant_mask_of(b, (float)(x * GSR_BLOCK_X), (float)(y * GSR_BLOCK_Y));
+        // tile grids beyond the LDS histogram: one returning L2 atomic per instance
+        const uint32_t slot = direct ? tile_start[tile] + atomicAdd(&tile_cursor[tile], 1u) : atomicAdd(&hist[tile], 1u);
+        if (LEAN) lean[slot] = bidx | (m << GSR_RANK_IDX_BITS);
+        else ranks[slot] = make_uint2(brk, bidx | (m << GSR_RANK_IDX_BITS));
+    };
+    for (int base = begin; base < end; base += stride) {
+        const int i = mine_of(base);
+        const In cur = nxt;
+        nxt = fetch(mine_of(base + stride));
+        const int minx = cur.q.x, miny = cur.q.y, maxx = cur.q.z, maxy = cur.q.w;
+        const uint32_t n = (uint32_t)((maxx - minx) * (maxy - miny)), w = (uint32_t)(maxx - minx);
+        const bool big = n > BIG;
+        const uint32_t nbal = big ? 0u : n;
+        const uint32_t incl = wave_scan_incl_u32(nbal), excl = incl - nbal;
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        wave_lds_handover();   // (the previous round's reads of these rows are behind us)
+        rows[lane][0] = f4u(cur.s0);
+        rows[lane][1] = f4u(cur.s1);
+        if (!LEAN) rows[lane][2] = cur.rk;
+        rows[lane][ROW - 1] = make_uint4((uint32_t)minx | (uint32_t)miny << 16, w, excl, (uint32_t)i);
+        wave_lds_handover();
+        uint32_t carry = 0u;   // (owner lane + 1) of the position in front of the window
+        for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
+            own[lane] = 0u;
+            const uint32_t rel = excl - k0;                     // (unsigned: ranges that began in an earlier window wrap far above 64)
+            if (nbal != 0u && rel < 64u) own[rel] = (uint32_t)lane + 1u;
+            wave_lds_handover();
+            uint32_t o = wave_scan_incl_max_u32(own[lane]);
+            o = o > carry ? o : carry;
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)o, 63);
+            const uint32_t k = k0 + (uint32_t)lane;
+            if (k < total) {
+                const uint4(&r)[ROW] = rows[o - 1u];
+                const uint4 a0 = r[0], a1 = r[1], a3 = r[ROW - 1];
+                uint4 brk4 = make_uint4(0u, 0u, 0u, 0u);
+                if (!LEAN) brk4 = r[2];
+                Span sp;
+                sp.px = __uint_as_float(a0.x); sp.py = __uint_as_float(a0.y); sp.B = __uint_as_float(a0.z); sp.det = __uint_as_float(a0.w);
+                sp.twoTA = __uint_as_float(a1.x); sp.A = __uint_as_float(a1.y); sp.dyr = __uint_as_float(a1.z); sp.mode = (int)a1.w;
+                const uint32_t ominx = a3.x & 0xFFFFu, ominy = a3.x >> 16, ow = a3.y, t = k - a3.z;
+                const uint32_t row = (uint32_t)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)ow));   // t / ow: exact for t < 2^15
+                const uint32_t fb = bands ? (uint32_t)(((float)ominy + 0.5f) * bt.inv_band_rows) : 0u;
+                emit(ominx + t - row * ow, ominy + row, sp, brk4, fb, a3.w);
+            }
+        }
+        // rects beyond BIG tiles: the whole wave expands one splat at a time (a screen-filling splat must not serialise one lane)
+        uint64_t bigm = __ballot(big);
+        if (bigm) {
+            Span sp;
+            sp.px = cur.s0.x; sp.py = cur.s0.y; sp.B = cur.s0.z; sp.det = cur.s0.w;
+            sp.twoTA = cur.s1.x; sp.A = cur.s1.y; sp.dyr = cur.s1.z; sp.mode = __float_as_int(cur.s1.w);
+            const uint32_t fb = bands ? (uint32_t)(((float)miny + 0.5f) * bt.inv_band_rows) : 0u;
+            while (bigm) {
+                const int src = __builtin_ctzll(bigm);
+                bigm &= bigm - 1;
+                auto bf = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+                auto bu = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
+                Span b;
+                b.px = bf(sp.px); b.py = bf(sp.py); b.B = bf(sp.B); b.det = bf(sp.det); b.twoTA = bf(sp.twoTA); b.A = bf(sp.A); b.dyr = bf(sp.dyr);
+                b.mode = __builtin_amdgcn_readlane(sp.mode, src);
+                const uint4 brk4 = make_uint4(bu(cur.rk.x), bu(cur.rk.y), bu(cur.rk.z), bu(cur.rk.w));
+                const uint32_t bfb = bu(fb), bidx = bu((uint32_t)i), bminx = bu((uint32_t)minx), bminy = bu((uint32_t)miny), bw = bu(w), bn = bu(n);
+                for (uint32_t k = (uint32_t)lane; k < bn; k += GSR_WAVE) emit(bminx + k % bw, bminy + k / bw, b, brk4, bfb, bidx);
+            }
+        }
+    }
+}
+
+// stage_off >= 0: the balanced expansion, its staging rows at that byte offset of the dynamic LDS (behind the tile histogram); < 0: the
+// lockstep form (the API takes it when the rows do not fit beside the histogram: tile grids of ~23 k tiles and more)
 template <int G>
 __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx, int tiles, BandTables bt, const ushort4* __restrict__ srect,
                                                                     const uint32_t* __restrict__ rank, const float4* __restrict__ sspan,
                                                                     const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
                                                                     uint2* __restrict__ ranks, unsigned long long capacity,
                                                                     const unsigned long long* __restrict__ total_dev,
-                                                                    const uint32_t* __restrict__ block_hist)
+                                                                    const uint32_t* __restrict__ block_hist, int stage_off)
 {
-    rscatter_body<G, false>(P, gx, tiles, bt, srect, rank, sspan, tile_start, tile_cursor, ranks, capacity, total_dev, block_hist, (int)gridDim.x);
+    extern __shared__ uint32_t dyn_lds[];
+    if (stage_off >= 0)
+        rscatter_balanced<false>(*reinterpret_cast<RscatterStage<false>*>(reinterpret_cast<unsigned char*>(dyn_lds) + stage_off), P, gx, tiles, bt, srect, rank, sspan,
+                                 tile_start, tile_cursor, ranks, capacity, total_dev, block_hist, (int)gridDim.x);
+    else
+        rscatter_body<G, false>(P, gx, tiles, bt, srect, rank, sspan, tile_start, tile_cursor, ranks, capacity, total_dev, block_hist, (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -695,21 +864,27 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rsort_rscatter(int sca
                                                                           unsigned long long capacity, const unsigned long long* __restrict__ total_dev,
                                                                           const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ bcount,
                                                                           const uint32_t* __restrict__ bstart, unsigned long long* __restrict__ dkeys,
-                                                                          unsigned long long* __restrict__ dtmp, uint32_t* __restrict__ rank)
+                                                                          unsigned long long* __restrict__ dtmp, uint32_t* __restrict__ rank, int stage_off)
 {
+    extern __shared__ uint32_t dyn_lds[];
     if ((int)blockIdx.x < scatter_blocks) {
         BandTables bt;
         bt.nbands = 1u; bt.inv_band_rows = 1.f; bt.over = nullptr;
-        rscatter_body<GSR_RANK_GROUP, true>(P, gx, tiles, bt, srect, nullptr, sspan, tile_start, tile_cursor, reinterpret_cast<uint2*>(entries), capacity,
-                                            total_dev, block_hist, scatter_blocks);
+        if (stage_off >= 0)   // (52 KB of rows + the histogram: two workgroups per CU at 802 x 550 -- a scatter workgroup and a sorting one beside it)
+            rscatter_balanced<true>(*reinterpret_cast<RscatterStage<true>*>(reinterpret_cast<unsigned char*>(dyn_lds) + stage_off), P, gx, tiles, bt, srect, nullptr,
+                                    sspan, tile_start, tile_cursor, reinterpret_cast<uint2*>(entries), capacity, total_dev, block_hist, scatter_blocks);
+        else
+            rscatter_body<GSR_RANK_GROUP, true>(P, gx, tiles, bt, srect, nullptr, sspan, tile_start, tile_cursor, reinterpret_cast<uint2*>(entries), capacity,
+                                                total_dev, block_hist, scatter_blocks);
         return;
     }
     if (threadIdx.x >= 256) return;   // (ended waves do not take part in the barriers of the sort)
-    depth_sort_bucket(blockIdx.x - (uint32_t)scatter_blocks, bcount, bstart, dkeys, dtmp, rank, nullptr, nullptr, 1);
+    __shared__ unsigned long long skeys[GSR_SORT_SMALL_KEYS];
+    depth_sort_bucket(blockIdx.x - (uint32_t)scatter_blocks, bcount, bstart, dkeys, dtmp, rank, nullptr, nullptr, 1, skeys);
 }
 
 template __global__ void k_rscatter<8>(int, int, int, BandTables, const ushort4*, const uint32_t*, const float4*, const uint32_t*, uint32_t*, uint2*, unsigned long long,
-                                       const unsigned long long*, const uint32_t*);
+                                       const unsigned long long*, const uint32_t*, int);
 
 // ------------------------------------------------------------------------------------------
 // The tile's sorted list -> its four quadrant streams, GSR_RANK_WINDOW entries at a time (striped like round 1's epilogue): every
