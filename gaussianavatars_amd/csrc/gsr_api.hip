@@ -239,8 +239,11 @@ static int binning_path(int32_t P, size_t tiles, int32_t tile_culling, size_t* c
 {
     if (production_params(P, tiles, tile_culling, chunks, nb)) return 1;
     if (tile_culling == 5) return 2;
+    // about 256 splats per depth bucket (GSR_RANK_BUCKET_SPLATS: experiment knob, a power of two up to 1024 -- a bucket is sorted in the registers
+    // of 256 threads up to 2048 keys)
+    static const size_t per = [] { const char* e = getenv("GSR_RANK_BUCKET_SPLATS"); const long v = e ? atol(e) : 0; return (size_t)(v >= 64 && v <= 1024 ? v : 256); }();
     size_t b = 16;
-    while (b < (size_t)GSR_RANK_MAX_BUCKETS && b * 256 < (size_t)P) b <<= 1;   // about 256 splats per depth bucket
+    while (b < (size_t)GSR_RANK_MAX_BUCKETS && b * per < (size_t)P) b <<= 1;
     *nb = b;
     return 0;
 }

@@ -1002,7 +1002,10 @@ __global__ __launch_bounds__(GSR_RANK_TILE_THREADS) void k_tile_rank(uint32_t wo
 {
     constexpr int THREADS = GSR_RANK_TILE_THREADS, NW = THREADS / 64, EPT = GSR_RANK_WINDOW / THREADS, NE = EPT * NW;
     constexpr int ROWS = GSR_RANK_MAX_SPLATS / 2048, RPL = (ROWS + 63) / 64;   // rows of 64 words = 2048 ranks
-    constexpr int UB = 8;   // entries per thread whose loads are in flight together
+#ifndef GSR_RANK_UB
+#define GSR_RANK_UB 8
+#endif
+    constexpr int UB = GSR_RANK_UB;   // entries per thread whose loads are in flight together (and that stay in registers between the two passes)
     static_assert(NE <= 64, "one (chunk, wave) counter per lane in the epilogue's scan");
     static_assert(EPT % 4 == 0, "the epilogue gathers four chunks at a time");
     extern __shared__ uint32_t bitmap[];                                   // [words] (a multiple of 64, at most 64 * ROWS), then

@@ -482,6 +482,45 @@ def test_rank_path_equals_the_per_tile_sort_on_random_scenes(seed):
         _same_streams(new, old, packed=False)
 
 
+@pytest.mark.parametrize("W,H", [(2560, 2400), (1100, 1600)])
+def test_rank_scatter_forms_on_tile_grids_around_the_staging_limit(W, H):
+    """k_rscatter / k_rsort_rscatter deal the tile instances evenly to the lanes from staging rows in LDS when those fit beside the tile
+    histogram (1100 x 1600: 6900 tiles) and fall back to the lockstep expansion when they do not (2560 x 2400: 24000 tiles = 96 KB of
+    histogram), one band and forced bands: same streams, image bits and counters as round 1's per-tile sort either way.  (Grids beyond the LDS
+    histogram altogether -- per-instance L2 atomics -- are the 3300 x 3300 scene of the oracle tests.)"""
+    from gaussianavatars_amd import debug as D
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd import synthetic as S
+    from gaussianavatars_amd.rasterizer import GaussianRasterizationSettings
+
+    dev = _dev()
+    P, deg = 6000, 1
+    sp = S.random_splats(P, deg, 91, xyz_sigma=0.12, log_scale_mean=math.log(0.006), log_scale_sigma=1.0)   # a few tiles to hundreds of tiles per splat
+    cam = S.orbit_camera(W, H, yaw_deg=12.0, pitch_deg=-5.0)
+    a = settings_args(cam, [0.1, 0.2, 0.3], deg, 1.0)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    rs = GaussianRasterizationSettings(a["H"], a["W"], a["tanfovx"], a["tanfovy"], t(a["bg"]), 1.0, t(a["viewmatrix"]), t(a["projmatrix"]), deg,
+                                       t(a["campos"]), False, False)
+    args = (t(sp["means3D"]), t(sp["shs"]), None, t(sp["opacities"]), t(sp["scales"]), t(sp["rotations"]), None)
+    out = {}
+    for mode in (3, 6, 5):
+        prev = R.set_tile_culling(mode)
+        try:
+            out[mode] = D._forward_state(rs, *args)
+        finally:
+            R.set_tile_culling(prev)
+    old = out[5]
+    assert old["binning_path"] == 2 and old["num_rendered"] > 20 * P
+    for mode in (3, 6):
+        new = out[mode]
+        assert new["binning_path"] == 0 and new["num_rendered"] == old["num_rendered"]
+        for k in ("color", "final_T"):
+            assert np.array_equal(_np(new[k]).view(np.uint32), _np(old[k]).view(np.uint32)), (mode, k)
+        for k in ("radii", "n_contrib", "n_contrib_q", "tiles_touched"):
+            np.testing.assert_array_equal(_np(new[k]), _np(old[k]), err_msg=f"{mode}/{k}")
+        _same_streams(new, old, packed=False)
+
+
 @pytest.mark.parametrize("W,H,nbands", [(96, 80, 5), (96, 16, 1)])
 def test_rank_bands_with_more_splats_than_one_bitmap_holds(W, H, nbands):
     """300 000 splats crowded into the middle of a small image: past 262144 splats the rank path ranks per band of tile rows, and here
