@@ -261,6 +261,7 @@ GLS_SYMBOLS = {
     "gls_partial_floats": (C.c_int64, [C.c_int32] * 4),
     "gls_l1_ssim_forward": (C.c_int, [C.c_int32] * 4 + [_P, _P, C.c_float] + [_P] * 4),
     "gls_l1_ssim_backward": (C.c_int, [C.c_int32] * 4 + [_P] * 4 + [C.c_float, _P, _P]),
+    "gls_l1_ssim_backward_split": (C.c_int, [C.c_int32] * 4 + [_P] * 5 + [C.c_int32, C.c_float, _P, _P]),
     "gls_l1_forward": (C.c_int, [C.c_int64, _P, _P, C.c_float, _P, _P, _P]),
     "gls_l1_forward_grad": (C.c_int, [C.c_int64, _P, _P, C.c_float, _P, _P, _P, _P]),
     "gls_l1_backward": (C.c_int, [C.c_int64, _P, _P, _P, C.c_float, _P, _P]),

@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float2* __restric
 
 __global__ __launch_bounds__(256) void k_l1_ssim_bwd(int C, int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                                                       const float* __restrict__ maps, size_t map_stride, Window win,
-                                                      const float2* __restrict__ g, float scale, float* __restrict__ d_img1)
+                                                      const float* __restrict__ g_l1, const float* __restrict__ g_ssim, int g_stride, float scale,
+                                                      float* __restrict__ d_img1)
 {
     __shared__ float sm[3][HY][HX + 1];
     __shared__ float hq[3][HY][TX];
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(256) void k_l1_ssim_bwd(int C, int H, int W, const 
     if (px < W && py < H) {
         const size_t o = poff + (size_t)py * W + px;
         const float x = img1[o], y = img2[o];
-        float2 gi = g[plane / C];
+        const int img = plane / C;   // dL/d(mean |x - y|) and dL/d(mean ssim) of this image; a missing one is zero
+        float2 gi = make_float2(g_l1 ? g_l1[(size_t)img * g_stride] : 0.f, g_ssim ? g_ssim[(size_t)img * g_stride] : 0.f);
         gi.x *= scale;
         gi.y *= scale;
         const float df = x - y;
@@ -322,17 +324,30 @@ int gls_l1_ssim_forward(int32_t B, int32_t C, int32_t H, int32_t W, const float*
     return GLS_OK;
 }
 
-int gls_l1_ssim_backward(int32_t B, int32_t C, int32_t H, int32_t W, const float* img1, const float* img2, const float* maps,
-                         const float* g, float scale, float* d_img1, void* stream_)
+static int l1_ssim_backward_impl(int32_t B, int32_t C, int32_t H, int32_t W, const float* img1, const float* img2, const float* maps,
+                                 const float* g_l1, const float* g_ssim, int g_stride, float scale, float* d_img1, void* stream_)
 {
     if (!image_args_ok(B, C, H, W)) return fail(GLS_E_ARG, "bad image shape (%d,%d,%d,%d)", B, C, H, W);
-    if (!img1 || !img2 || !maps || !g || !d_img1) return fail(GLS_E_ARG, "null pointer");
+    if (!img1 || !img2 || !maps || !d_img1 || g_stride < 0) return fail(GLS_E_ARG, "null pointer");
     hipStream_t stream = (hipStream_t)stream_;
     const dim3 grid((W + gls::TX - 1) / gls::TX, (H + gls::TY - 1) / gls::TY, B * C);
     const size_t stride = (size_t)B * C * H * W;
-    hipLaunchKernelGGL(gls::k_l1_ssim_bwd, grid, dim3(256), 0, stream, C, H, W, img1, img2, maps, stride, make_window(), (const float2*)g, scale, d_img1);
+    hipLaunchKernelGGL(gls::k_l1_ssim_bwd, grid, dim3(256), 0, stream, C, H, W, img1, img2, maps, stride, make_window(), g_l1, g_ssim, g_stride, scale, d_img1);
     LAUNCH_CHECK("k_l1_ssim_bwd");
     return GLS_OK;
+}
+
+int gls_l1_ssim_backward(int32_t B, int32_t C, int32_t H, int32_t W, const float* img1, const float* img2, const float* maps,
+                         const float* g, float scale, float* d_img1, void* stream_)
+{
+    if (!g) return fail(GLS_E_ARG, "null pointer");
+    return l1_ssim_backward_impl(B, C, H, W, img1, img2, maps, g, g + 1, 2, scale, d_img1, stream_);
+}
+
+int gls_l1_ssim_backward_split(int32_t B, int32_t C, int32_t H, int32_t W, const float* img1, const float* img2, const float* maps,
+                               const float* g_l1, const float* g_ssim, int32_t g_stride, float scale, float* d_img1, void* stream_)
+{
+    return l1_ssim_backward_impl(B, C, H, W, img1, img2, maps, g_l1, g_ssim, g_stride, scale, d_img1, stream_);
 }
 
 static int l1_forward_impl(int64_t n, const float* a, const float* b, float scale, float* sum, float* partial, float* d_a, bool grad, void* stream_)

@@ -80,10 +80,15 @@ def _as_input(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 class _L1Ssim(torch.autograd.Function):
-    """(B,C,H,W) x (B,C,H,W) -> (B,2) = [mean |a-b|, mean ssim_map] per image."""
+    """(B,C,H,W) x (B,C,H,W) -> (l1, ssim) = (mean |a-b|, mean ssim_map) per image: two outputs, 0-dim for one image (what train.py:131-132
+    combines), (B,) otherwise.  The node hands out the scalars themselves -- views of its (B,2) result made inside forward, where autograd is
+    off -- so nothing sits between the caller's loss arithmetic and the backward kernel: indexing a (B,2) output from outside cost three select
+    nodes per step, each a zero-fill and a copy in the backward plus an accumulation (eight launch-floor kernels and their Python dispatch on a
+    step that is host-bound to begin with)."""
 
     @staticmethod
     def forward(ctx, img1, img2):
+        ctx.set_materialize_grads(False)
         lib = _lib.gls()
         B, Cc, H, W = img1.shape
         dev = img1.device
@@ -95,20 +100,38 @@ class _L1Ssim(torch.autograd.Function):
                                        _stream(dev))
         if need:
             ctx.save_for_backward(img1, img2, maps)
-        return sums
+        if B == 1:
+            return sums[0, 0], sums[0, 1]
+        return sums[:, 0], sums[:, 1]
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g_l1, g_ss):
+        if g_l1 is None and g_ss is None:
+            return None, None
         img1, img2, maps = ctx.saved_tensors
         lib = _lib.gls()
         B, Cc, H, W = img1.shape
         dev = img1.device
-        gs = g.to(torch.float32).contiguous()
+
+        def arg(g):   # -> (tensor kept alive, elements between two images)
+            if g is None:
+                return None, 0
+            g = g.to(torch.float32)
+            if g.numel() == 1:
+                return g, 0
+            g = g.reshape(B)
+            return g, int(g.stride(0))
+
+        (a1, s1), (a2, s2) = arg(g_l1), arg(g_ss)
+        if a1 is not None and a2 is not None and s1 != s2:
+            a1, a2, s1 = a1.expand(B).contiguous(), a2.expand(B).contiguous(), 1
+        stride = s1 if a1 is not None else s2
         scale = 1.0 / float(Cc * H * W)
         d1 = d2 = None
         if ctx.needs_input_grad[0]:
             d1 = torch.empty_like(img1)
-            _launch(dev, "gls_l1_ssim_backward", lib.gls_l1_ssim_backward, B, Cc, H, W, _p(img1), _p(img2), _p(maps), _p(gs), scale, _p(d1), _stream(dev))
+            _launch(dev, "gls_l1_ssim_backward_split", lib.gls_l1_ssim_backward_split, B, Cc, H, W, _p(img1), _p(img2), _p(maps), _p(a1), _p(a2), stride, scale,
+                    _p(d1), _stream(dev))
         if ctx.needs_input_grad[1]:
             # both statistics are symmetric in their arguments: the gradient w.r.t. the second image is the gradient
             # w.r.t. the first of the swapped pair (rare: the ground truth is data)
@@ -117,7 +140,8 @@ class _L1Ssim(torch.autograd.Function):
             maps2 = torch.empty((3, B, Cc, H, W), dtype=torch.float32, device=dev)
             _launch(dev, "gls_l1_ssim_forward", lib.gls_l1_ssim_forward, B, Cc, H, W, _p(img2), _p(img1), scale, _p(sums), _p(maps2), _p(partial), _stream(dev))
             d2 = torch.empty_like(img2)
-            _launch(dev, "gls_l1_ssim_backward", lib.gls_l1_ssim_backward, B, Cc, H, W, _p(img2), _p(img1), _p(maps2), _p(gs), scale, _p(d2), _stream(dev))
+            _launch(dev, "gls_l1_ssim_backward_split", lib.gls_l1_ssim_backward_split, B, Cc, H, W, _p(img2), _p(img1), _p(maps2), _p(a1), _p(a2), stride, scale,
+                    _p(d2), _stream(dev))
         return d1, d2
 
 
@@ -135,9 +159,10 @@ def l1_ssim(image: torch.Tensor, gt: torch.Tensor):
     """-> (l1, ssim): the two scalars train.py:131-132 combines, from ONE pass over (image, gt).
     l1 == l1_loss(image, gt), ssim == ssim(image, gt) (size_average=True)."""
     a, b = _batched(_as_input(image, "image"), _as_input(gt, "gt"))
-    m = _L1Ssim.apply(a, b)
-    m = m[0] if m.shape[0] == 1 else m.mean(dim=0)
-    return m[0], m[1]
+    l1, ss = _L1Ssim.apply(a, b)
+    if l1.dim() == 0:
+        return l1, ss
+    return l1.mean(), ss.mean()
 
 
 def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_average: bool = True):
@@ -145,10 +170,10 @@ def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_ave
     if window_size != 11:
         raise NotImplementedError("the fused SSIM kernel implements the reference's 11x11 window only")
     a, b = _batched(_as_input(img1, "img1"), _as_input(img2, "img2"))
-    per_image = _L1Ssim.apply(a, b)[:, 1]
+    _, per_image = _L1Ssim.apply(a, b)
     if not size_average:
-        return per_image
-    return per_image[0] if per_image.shape[0] == 1 else per_image.mean()
+        return per_image.reshape(-1)
+    return per_image if per_image.dim() == 0 else per_image.mean()
 
 
 def _is_unit_seed(g: torch.Tensor) -> bool:

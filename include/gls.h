@@ -48,6 +48,13 @@ int gls_l1_ssim_forward(int32_t B, int32_t C, int32_t H, int32_t W, const float*
 int gls_l1_ssim_backward(int32_t B, int32_t C, int32_t H, int32_t W, const float* img1, const float* img2,
                          const float* maps, const float* g, float scale, float* d_img1, void* stream);
 
+/* The same with the two upstream gradients as separate DEVICE arrays of B floats each, element i at [i * g_stride] (g_stride 0: one value for
+ * every image); either may be NULL (= zero): what autograd hands a node whose two outputs are the scalars themselves -- no (B,2) gradient to
+ * assemble, no select / index nodes between the loss arithmetic of train.py:132 and this kernel.  (ABI 2) */
+int gls_l1_ssim_backward_split(int32_t B, int32_t C, int32_t H, int32_t W, const float* img1, const float* img2,
+                               const float* maps, const float* g_l1, const float* g_ssim, int32_t g_stride, float scale,
+                               float* d_img1, void* stream);
+
 /* n elements.  sum: 1 float <- scale * sum |a-b|.  partial: gls_partial_floats(1,1,1,1) floats. */
 int gls_l1_forward(int64_t n, const float* a, const float* b, float scale, float* sum, float* partial, void* stream);
 /* The same, and d_a: n floats <- scale * sign(a-b) = d(sum)/d(a), written by the pass that reads the pair anyway: a backward whose
