@@ -729,11 +729,25 @@ def main():
             sub = json.loads(out.stdout.strip().splitlines()[-1])
             frame_streams = {"streams": args.frame_streams, "value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"],
                              "rounds": sub["rounds"]["n"],
-                             "what": "the same steps dealt in turn to recorded (hipGraph) lanes on separate streams, one model replica per lane "
+                             "what": "the same steps dealt in turn to recorded (hipGraph) lanes on separate streams, the lanes sharing one set of splats "
                                      "(`bench.py --graph --streams %d`, run as a child process after the timed rounds above); "
                                      "ms_per_step = elapsed / steps, not the latency of one frame" % args.frame_streams}
         except Exception as e:   # noqa: BLE001 -- the leg is extra evidence, never a reason to lose the line
             frame_streams = {"streams": args.frame_streams, "error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        # the same step recorded once and replayed as ONE hipGraph launch per four frames on ONE stream (`bench.py --graph`): what the GPU side of
+        # the step costs when the host is out of the way -- the eager loop above (`value`: one Python-driven launch per kernel, what an unchanged
+        # train.py does) is bound by its ~300 us of host work per step since round 4, not by the 283 us of kernels
+        if train:
+            cmd1 = [c for c in cmd]
+            i_s = cmd1.index("--streams")
+            del cmd1[i_s:i_s + 2]
+            try:
+                out = subprocess.run(cmd1, capture_output=True, text=True, timeout=240)
+                sub = json.loads(out.stdout.strip().splitlines()[-1])
+                frame_streams["recorded_step"] = {"value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"], "min": sub["rounds"]["min"],
+                                                  "what": "one recorded lane (`bench.py --graph`): the same frames, one hipGraph launch per four frames"}
+            except Exception as e:   # noqa: BLE001
+                frame_streams["recorded_step"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
     if rank == 0:
         N, HW = args.splats, args.width * args.height
