@@ -52,7 +52,7 @@ _ONE_DEVICE = None   # a process that sees one GPU never switches devices
 GSR_LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsr_hip.so")
 
 GSR_OK = 0
-GSR_ABI_VERSION = 10
+GSR_ABI_VERSION = 11
 GSR_E_CAPACITY = 1
 GSR_COUNT_SLOTS = 128   # include/gsr.h: persistent instance-count slots of the deferred forwards
 
@@ -109,6 +109,8 @@ GSR_SYMBOLS = {
     "gsr_last_error": (C.c_char_p, []),
     "gsr_count_slot_read": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gsr_count_slot_overflow": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.c_int32]),
+    "gsr_last_forward_seq": (C.c_int64, []),
+    "gsr_count_slot_wait": (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]),
     "gsr_geom_layout": (C.c_int, [C.c_int32, C.POINTER(GsrGeomLayout)]),
     "gsr_binning_layout": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GsrBinningLayout)]),
     "gsr_image_layout": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(GsrImageLayout)]),

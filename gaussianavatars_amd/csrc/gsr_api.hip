@@ -71,6 +71,7 @@ struct Mailbox {
 };
 Mailbox g_mail;
 std::atomic<long long> g_wait_ns{0}, g_waits{0};
+thread_local long long g_last_seq = 0;   // the sequence number of this thread's newest forward (gsr_last_forward_seq)
 
 // ---- optional per-kernel event timing -------------------------------------------------------
 struct Profiler {
@@ -180,6 +181,40 @@ int gsr_count_slot_read(int32_t slot, int64_t* count, int64_t* seq)
     const unsigned long long v = __atomic_load_n(g_mail.host + Mailbox::kSlots + slot, __ATOMIC_ACQUIRE);
     *count = v ? (int64_t)(v & 0xFFFFFFFFFFull) : -1;
     if (seq) *seq = (int64_t)(v >> 40);
+    return GSR_OK;
+}
+
+int64_t gsr_last_forward_seq(void) { return g_last_seq; }
+
+int gsr_count_slot_wait(int32_t slot, int64_t want_seq, void* stream_, int64_t* count)
+{
+    if (slot < 0 || slot >= GSR_COUNT_SLOTS || !count || want_seq <= 0) return fail(GSR_E_ARG, "gsr_count_slot_wait: bad arguments");
+    if (int rc = g_mail.init()) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    const unsigned long long* w = g_mail.host + Mailbox::kSlots + slot;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long long v;
+    unsigned spins = 0;
+    for (;;) {
+        v = __atomic_load_n(w, __ATOMIC_ACQUIRE);
+        if (v != 0 && (long long)(v >> 40) == want_seq) break;
+        if (++spins > 2000) {
+            std::this_thread::yield();
+            if ((spins & 0xFFF) == 0) {
+                if (hipStreamQuery(stream) != hipErrorNotReady) {   // stream drained (or faulted) without the post
+                    v = __atomic_load_n(w, __ATOMIC_ACQUIRE);
+                    if (v != 0 && (long long)(v >> 40) == want_seq) break;
+                    hipError_t e = hipStreamSynchronize(stream);
+                    return fail(GSR_E_HIP, "stream finished without posting the instance count: %s", hipGetErrorString(e));
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+                    return fail(GSR_E_TIMEOUT, "timed out waiting for the instance count");
+            }
+        }
+    }
+    g_wait_ns.fetch_add((long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+    g_waits.fetch_add(1);
+    *count = (int64_t)(v & 0xFFFFFFFFFFull);
     return GSR_OK;
 }
 
@@ -443,6 +478,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     }
 
     const unsigned long long seq = (g_mail.seq.fetch_add(1) % 0xFFFFFEull) + 1;  // 1 .. 2^24-2, never 0
+    g_last_seq = (long long)seq;
     // where the scan posts (seq, I): a ring slot this call spins on, or -- deferred count -- the caller's persistent slot, read
     // later through gsr_count_slot_read (nothing waits, so the call can sit inside a stream capture and be replayed as a hipGraph)
     const bool deferred = settings->deferred_count != 0;

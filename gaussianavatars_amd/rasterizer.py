@@ -214,6 +214,70 @@ class _Deferred:
 
 
 _free_slots = list(range(_lib.GSR_COUNT_SLOTS - 1, -1, -1))
+
+# ---- the count wait of an eager frame, moved behind the rest of the call's host work (round 4) ---------------------------------------------
+# gsr_forward launches the frame's eight kernels and then spins until the fifth has posted the instance count -- ~18 us per step during which
+# the Python side of a step that is bound by its host work does nothing.  The entry points of the leaves entries
+# (rasterize_bound / rasterize_leaves) take the deferred form of the call instead -- the count goes to a persistent slot of this (device,
+# stream) -- let Function.forward and autograd's wrapping of its outputs finish, and wait THEN (gsr_count_slot_wait), still before the image
+# is handed to code that cannot be replayed.  A frame that did not fit its buffer rendered nothing: the call is made again with a larger one,
+# exactly as the loop inside forward() does for the blocking form.  GSR_LATE_COUNT=0 keeps the blocking form.
+_late_count = os.environ.get("GSR_LATE_COUNT", "1") != "0"
+_late_slots: dict = {}   # (device index, raw stream) -> persistent slot
+
+
+def _late_slot(dev, stream) -> int:
+    k = (dev.index, stream)
+    slot = _late_slots.get(k)
+    if slot is None:
+        if not _free_slots:
+            return -1   # (every slot handed to recordings: this call takes the blocking form)
+        slot = _late_slots[k] = _free_slots.pop()
+        _lib.gsr().gsr_count_slot_overflow(slot, None, 1)
+    return slot
+
+
+def _finish_late(pend) -> bool:
+    """Waits for the count of the frame `pend` describes; True when the frame fitted its binning buffer (then the bookkeeping the blocking form
+    does inside forward() happens here), False when it has to be rendered again (the capacity hint is raised first)."""
+    slot, seq, cap, key, stream, dev = pend
+    lib = _lib.gsr()
+    n = C.c_int64(0)
+    with _lib.on_device(dev):
+        rc = lib.gsr_count_slot_wait(slot, seq, stream, C.byref(n))
+    if rc != _lib.GSR_OK:
+        raise RuntimeError(f"gsr_count_slot_wait failed ({rc}): {_lib.gsr_error()}")
+    I = int(n.value)
+    if I > cap:
+        lib.gsr_count_slot_overflow(slot, None, 1)   # (the device left its sticky mark: this slot's only reader is this function)
+        _capacity_hint[key] = _round_cap(int(I * 1.25) + 1)
+        return False
+    _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
+    _forward_peak[0] = max(_forward_peak[0], I)
+    _last_info["num_rendered"] = I
+    return True
+
+
+def _apply_leaves_entry(*args):
+    """_RasterizeBound.apply with the caller's grad mode noted and, unless a recording or GSR_LATE_COUNT=0 says otherwise, the count awaited
+    after the call's own host work instead of inside it."""
+    if not _late_count or _deferred is not None:
+        return _apply_noting_grad_mode(_RasterizeBound, *args)
+    replays = 0
+    while True:
+        _call_state.late, _call_state.pending = True, None
+        try:
+            out = _apply_noting_grad_mode(_RasterizeBound, *args)
+        finally:
+            _call_state.late = False
+        pend, _call_state.pending = _call_state.pending, None
+        if pend is None:
+            return out
+        if _finish_late(pend):
+            if replays:
+                _last_info["replays"] = replays
+            return out
+        replays += 1   # the frame did not fit: its kernels did nothing, the node just made is dropped un-walked
 _deferred: Optional[_Deferred] = None
 
 
@@ -498,9 +562,14 @@ class _RasterizeBound(torch.autograd.Function):
         key = (dev.index, H, W, prod)
         cap = _capacity_hint.get(key) or _round_cap((24 if prod else 8) * P)
         defer = _deferred
+        stream = _lib.raw_stream(dev)
+        late_slot = -1
         if defer is not None:   # fixed capacity, count posted to a persistent slot, nothing waits (see deferred_count)
             cap, s.deferred_count = defer.capacity, defer.take() + 1
-        stream = _lib.raw_stream(dev)
+        elif getattr(_call_state, "late", False):   # (_apply_leaves_entry) the count is awaited after this call's host work, not inside it
+            late_slot = _late_slot(dev, stream)
+            if late_slot >= 0:
+                s.deferred_count = late_slot + 1
         n_host = C.c_int64(0)
         replays = 0
         with _lib.on_device(dev):
@@ -520,13 +589,15 @@ class _RasterizeBound(torch.autograd.Function):
                     raise RuntimeError(f"gsr_forward_bound failed ({rc}): {_lib.gsr_error()}")
                 break
         I = int(n_host.value)
-        if defer is not None:
+        if late_slot >= 0:
+            _call_state.pending = (late_slot, int(lib.gsr_last_forward_seq()), cap, key, stream, dev)
+            I = cap      # as a recording's frame: the backward takes the capacity as the bound; _finish_late does the bookkeeping
+        elif defer is not None:
             I = cap      # unknown until the kernels have run: the backward takes the capacity as the bound
         else:
             _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
-        if defer is None:
             _forward_peak[0] = max(_forward_peak[0], I)
-        _last_info.update(num_rendered=I if defer is None else -1, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod, forward_only=bool(s.forward_only),
+        _last_info.update(num_rendered=I if (defer is None and late_slot < 0) else -1, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod, forward_only=bool(s.forward_only),
                           binning_path=int(bl.path), rank_bands=int(bl.nbands), bound=True)
         _last_binning[0] = binning
         ctx.raster_settings = raster_settings
@@ -598,14 +669,14 @@ def rasterize_leaves(xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, r
     """-> (color, radii, visibility_filter) of an UNBOUND model straight from its leaves: get_scaling = exp, get_rotation = normalize,
     get_opacity = sigmoid (scene/gaussian_model.py:113-160) are evaluated inside the rasterizer's first kernel and their chain rule in
     its last one -- no activation launches, no activated tensors."""
-    return _apply_noting_grad_mode(_RasterizeBound, xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, None, None, None, None, None, None,
+    return _apply_leaves_entry(xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, None, None, None, None, None, None,
                                  raster_settings)
 
 
 def rasterize_bound(xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, face_R, face_scale, face_center, face_quat, binding, csr,
                     raster_settings):
     """-> (color, radii, visibility_filter) of a mesh-bound model straight from its leaves and face frames (see _RasterizeBound)."""
-    return _apply_noting_grad_mode(_RasterizeBound, xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, face_R, face_scale, face_center, face_quat,
+    return _apply_leaves_entry(xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, face_R, face_scale, face_center, face_quat,
                                  binding, csr, raster_settings)
 
 

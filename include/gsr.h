@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 10
+#define GSR_ABI_VERSION 11
 #define GSR_BWD_SEGMENT 60        /* stream entries per backward segment (a multiple of both blend kernels' batches)  */
 #define GSR_BWD_SEGMENTS 10       /* segments per quadrant stream; the last one takes whatever is left                */
 #define GSR_UNIT_LISTS 64         /* fast blend: the backward's work units (quadrant, segment) are appended to this many lists (GsrImageLayout.units) */
@@ -235,6 +235,12 @@ int gsr_count_slot_read(int32_t slot, int64_t* count, int64_t* seq);
  * recording overwrites it every launch -- so "did every replay fit" is asked here.  reset != 0 clears the mark (call it with no
  * frame of the slot in flight: before handing the slot to a new recording).  Plain accesses of mapped host memory.             */
 int gsr_count_slot_overflow(int32_t slot, int64_t* worst, int32_t reset);
+/* (ABI 11) A deferred forward whose caller does want the count before it hands the image on -- but not before it has done the rest of its own
+ * host work: gsr_last_forward_seq() = the sequence number of the calling thread's newest gsr_forward* call; gsr_count_slot_wait spins (as
+ * gsr_forward does) until persistent slot `slot` holds the post of that frame and returns its instance count.  The caller compares it with
+ * the capacity it passed: a frame that did not fit rendered nothing and has to be replayed with a larger buffer, exactly as after GSR_E_CAPACITY. */
+int64_t gsr_last_forward_seq(void);
+int gsr_count_slot_wait(int32_t slot, int64_t want_seq, void* stream, int64_t* count);
 
 /* sizes/layouts of the state buffers (pure host arithmetic, no device access) */
 int gsr_geom_layout(int32_t P, GsrGeomLayout* out);

@@ -314,3 +314,60 @@ def test_no_grad_render_of_trainable_parameters_takes_the_forward_only_path(fast
     finally:
         R.set_fast_blend(prev_fast)
         R._poison_state = prev_poison
+
+
+@pytest.mark.fast_blend
+def test_late_count_wait_equals_the_blocking_form_and_replays_a_frame_that_did_not_fit():
+    """The leaves entries (render() of a bound or un-bound model) take the deferred form of gsr_forward and wait for the instance count behind
+    the call's own host work (rasterizer._apply_leaves_entry); GSR_LATE_COUNT=0 / rasterizer._late_count = False is the blocking form.  Same image
+    bits, radii, instance count and gradients either way; a frame that does not fit its binning buffer (capacity hint forced down to a
+    fraction of the frame) is rendered again with a larger one -- the image the caller gets is the full frame, `replays` says so, and the
+    backward of the returned node works."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import bench
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd.gaussian_renderer import render
+
+    dev = torch.device("cuda:0")
+    H, W = 208, 176
+    g, cam = bench.build_scene(dev, 20000, 3, W, H, 4, "fused", True)
+    gu, cam_u = _scene(dev)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    prev = R._late_count
+    try:
+        for model, c, what in ((g, cam, "bound"), (gu, cam_u, "leaves")):
+            out = {}
+            for late in (False, True):
+                R._late_count = late
+                if what == "bound":
+                    bench.zero_grads(model)
+                    model.select_mesh_by_timestep(1)
+                else:
+                    for p_ in (model._xyz, model._features_dc, model._features_rest, model._scaling, model._rotation, model._opacity):
+                        p_.grad = None
+                pkg = render(c, model, bench.Pipe, bg)
+                info = R.last_forward_info()
+                pkg["render"].sum().backward()
+                out[late] = (pkg["render"].detach().clone(), pkg["radii"].clone(), int(info["num_rendered"]), model._xyz.grad.clone())
+            assert out[True][2] == out[False][2] > 0, what
+            assert torch.equal(out[True][0].view(torch.int32), out[False][0].view(torch.int32)) and torch.equal(out[True][1], out[False][1]), what
+            err = float((out[True][3] - out[False][3]).abs().max()) / float(out[False][3].abs().max())
+            assert err < 1e-5, (what, err)      # float atomics: two backwards of the same frame differ by rounding
+            # a buffer far too small for the frame: rendered again, transparently
+            R._late_count = True
+            I = out[True][2]
+            for key in list(R._capacity_hint):
+                R._capacity_hint[key] = max(1024, I // 7)
+            if what == "bound":
+                model.select_mesh_by_timestep(1)
+            pkg = render(c, model, bench.Pipe, bg)
+            info = R.last_forward_info()
+            assert info["replays"] >= 1 and int(info["num_rendered"]) == I and info["capacity"] >= I, (what, info)
+            assert torch.equal(pkg["render"].detach().view(torch.int32), out[True][0].view(torch.int32)), what
+            pkg["render"].sum().backward()
+            assert bool(torch.isfinite(model._xyz.grad).all())
+            pkg2 = render(c, model, bench.Pipe, bg)                      # the next frame fits at once
+            assert R.last_forward_info()["replays"] == 0 and torch.equal(pkg2["render"].detach().view(torch.int32), out[True][0].view(torch.int32))
+    finally:
+        R._late_count = prev
