@@ -259,15 +259,19 @@ def _finish_late(pend) -> bool:
 
 
 def _apply_leaves_entry(*args):
-    """_RasterizeBound.apply with the caller's grad mode noted and, unless a recording or GSR_LATE_COUNT=0 says otherwise, the count awaited
-    after the call's own host work instead of inside it."""
+    return _apply_late(_RasterizeBound, *args)
+
+
+def _apply_late(fn, *args):
+    """fn.apply with the caller's grad mode noted and, unless a recording or GSR_LATE_COUNT=0 says otherwise, the count awaited after the
+    call's own host work instead of inside it."""
     if not _late_count or _deferred is not None:
-        return _apply_noting_grad_mode(_RasterizeBound, *args)
+        return _apply_noting_grad_mode(fn, *args)
     replays = 0
     while True:
         _call_state.late, _call_state.pending = True, None
         try:
-            out = _apply_noting_grad_mode(_RasterizeBound, *args)
+            out = _apply_noting_grad_mode(fn, *args)
         finally:
             _call_state.late = False
         pend, _call_state.pending = _call_state.pending, None
@@ -417,9 +421,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         key = (dev.index, H, W, prod)
         cap = _capacity_hint.get(key) or _round_cap((24 if prod else 8) * P)
         defer = _deferred
+        stream = _lib.raw_stream(dev)
+        late_slot = -1
         if defer is not None:   # fixed capacity, count posted to a persistent slot, nothing waits (see deferred_count)
             cap, s.deferred_count = defer.capacity, defer.take() + 1
-        stream = _lib.raw_stream(dev)
+        elif getattr(_call_state, "late", False):   # (_apply_late) the count is awaited after this call's host work, not inside it
+            late_slot = _late_slot(dev, stream)
+            if late_slot >= 0:
+                s.deferred_count = late_slot + 1
         n_host = C.c_int64(0)
         replays = 0
         with _lib.on_device(dev):
@@ -447,13 +456,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                     raise RuntimeError(f"gsr_forward failed ({rc}): {msg}")
                 break
         I = int(n_host.value)
-        if defer is not None:
+        if late_slot >= 0:
+            _call_state.pending = (late_slot, int(lib.gsr_last_forward_seq()), cap, key, stream, dev)
+            I = cap      # as a recording's frame: the backward takes the capacity as the bound; _finish_late does the bookkeeping
+        elif defer is not None:
             I = cap      # unknown until the kernels have run: the backward takes the capacity as the bound
         else:   # next frame: 25 % headroom over what this one needed, never shrinking below it
             _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
-        if defer is None:
             _forward_peak[0] = max(_forward_peak[0], I)
-        _last_info.update(num_rendered=I if defer is None else -1, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod, forward_only=bool(s.forward_only),
+        _last_info.update(num_rendered=I if (defer is None and late_slot < 0) else -1, capacity=cap, replays=replays, tile_culling=bool(s.tile_culling), production_binning=prod, forward_only=bool(s.forward_only),
                           binning_path=int(bl.path), rank_bands=int(bl.nbands), bound=False)   # 0 rank path, 1 depth-ordered scatter, 2 per-tile sort (include/gsr.h)
         _last_binning[0] = binning
 
@@ -683,7 +694,7 @@ def rasterize_bound(xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, ro
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
                         sh_rest=None):
     """-> (color, radii), the reference's pair."""
-    return _apply_noting_grad_mode(_RasterizeGaussians, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+    return _apply_late(_RasterizeGaussians, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings, sh_rest)[:2]
 
 
@@ -723,7 +734,7 @@ class GaussianRasterizer(nn.Module):
         scales = empty if scales is None else scales
         rotations = empty if rotations is None else rotations
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
-        color, radii, visible = _apply_noting_grad_mode(_RasterizeGaussians, means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+        color, radii, visible = _apply_late(_RasterizeGaussians, means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                                           cov3D_precomp, rs, shs_rest)
         # extension: `radii > 0` of THIS call as the forward kernel wrote it (what render() returns as visibility_filter)
         self.visibility_filter = visible

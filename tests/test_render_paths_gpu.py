@@ -369,5 +369,24 @@ def test_late_count_wait_equals_the_blocking_form_and_replays_a_frame_that_did_n
             assert bool(torch.isfinite(model._xyz.grad).all())
             pkg2 = render(c, model, bench.Pipe, bg)                      # the next frame fits at once
             assert R.last_forward_info()["replays"] == 0 and torch.equal(pkg2["render"].detach().view(torch.int32), out[True][0].view(torch.int32))
+        # the reference-shaped module (what an unpatched gaussian_renderer.render() calls) takes the same route
+        rs = R.GaussianRasterizationSettings(H, W, math.tan(cam_u.FoVx * 0.5), math.tan(cam_u.FoVy * 0.5), bg, 1.0, cam_u.world_view_transform,
+                                             cam_u.full_proj_transform, 3, cam_u.camera_center, False, False)
+        rast = R.GaussianRasterizer(rs)
+        args = dict(means3D=gu.get_xyz, means2D=torch.zeros_like(gu.get_xyz, requires_grad=True), opacities=gu.get_opacity, shs=gu.get_features,
+                    scales=gu.get_scaling, rotations=gu.get_rotation)
+        R._late_count = False
+        img0, radii0 = rast(**args)
+        I = int(R.last_forward_info()["num_rendered"])
+        R._late_count = True
+        img1, radii1 = rast(**args)
+        assert int(R.last_forward_info()["num_rendered"]) == I and torch.equal(img1.view(torch.int32), img0.view(torch.int32)) and torch.equal(radii0, radii1)
+        for key in list(R._capacity_hint):
+            R._capacity_hint[key] = max(1024, I // 5)
+        img2, _ = rast(**args)
+        info = R.last_forward_info()
+        assert info["replays"] >= 1 and int(info["num_rendered"]) == I and torch.equal(img2.view(torch.int32), img0.view(torch.int32))
+        img2.sum().backward()
+        assert bool(torch.isfinite(gu._xyz.grad).all()) and float(gu._xyz.grad.abs().max()) > 0
     finally:
         R._late_count = prev
