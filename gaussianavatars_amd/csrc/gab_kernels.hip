@@ -358,7 +358,9 @@ __global__ __launch_bounds__(256) void k_prep_joints(Rig rig, float* __restrict_
 // in flight: a half-wave per row of the expression block (25 float4 of the 400-byte run that starts at column n_shape), all
 // rows of a half-wave issued before the first is consumed.  Then 16 lanes per vertex gather the 36 pose-corrective rows and one
 // lane per vertex applies the blended rigid transform.  Workgroup 0 also leaves the workspace the backward reads.
-#define GAB_FUSED_VERTS 16
+#ifndef GAB_FUSED_VERTS
+#define GAB_FUSED_VERTS 8   // swept 8 / 16 / 32 (round 4, rocprofv3): 8.8 / 10.5 / 13.7 us -- 643 workgroups of 24 blend-shape rows each
+#endif
 template <bool FLAME_TREE>
 __global__ __launch_bounds__(256) void k_flame_fused(Rig rig, const float* __restrict__ prepared, const float* __restrict__ expr,
                                                       const float* __restrict__ rotation, const float* __restrict__ neck,
@@ -985,7 +987,7 @@ struct GatherSkinArgs {
 __global__ __launch_bounds__(256) void k_gather_skin_bwd(Rig rig, GatherSkinArgs a, ZeroSpec zero)
 {
     constexpr int VPB = GAB_MESH_VPB, ROWS = 3 * VPB;
-    static_assert(VPB == 32 || VPB == 64, "a wave holds the workgroup's vertices");
+    static_assert(VPB == 16 || VPB == 32 || VPB == 64, "a wave holds the workgroup's vertices");
     __shared__ float gv[ROWS];          // dL/d(posed vertex) of this workgroup's vertices
     __shared__ float red[100];          // the 99 block sums
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
