@@ -825,10 +825,10 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     const float4* __restrict__ rec = grec;                      // the per-splat records (48 bytes each)
     const uint32_t* __restrict__ qp = qpos + qs;                // this quadrant's stream of splat indices
 
-    // Two transmittances per pixel: T is the one the pixel ends with (the last accepted product), Tw the WORKING one, equal to
-    // T while the pixel is open and 0 once it is closed (saturated, or outside the image).  A closed pixel then needs no
-    // flag: Tw * (1 - alpha) == 0 fails the ">= 0.0001" acceptance test by itself, and c * alpha * Tw adds +0.
-    float T = 1.0f;
+    // ONE transmittance register per pixel (round 4; rounds 1 - 3 carried the final T beside a working copy): Tw is the transmittance while
+    // the pixel is open and MINUS the transmittance it ended with once it is closed (saturated; outside the image: 0).  A closed pixel needs no
+    // flag: Tw * (1 - alpha) <= 0 fails the ">= 0.0001" acceptance test by itself, c * 0 * Tw adds a zero, and the closing select writes -|Tw|
+    // (source modifiers of v_cndmask: no instruction) -- one select per record less than updating T and Tw.  |Tw| is the pixel's T throughout.
     float Tw = inside ? 1.0f : 0.0f;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last_q = 0;
@@ -957,9 +957,8 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
                 C1 = C1 + R.a[u][7] * ae * Tw;
                 C2 = C2 + R.cbl[u] * ae * Tw;
             }
-            T = keep ? test_T : T;
-            Tw = keep ? test_T : 0.0f;
-            lq = (keep && ok[u]) ? OFF + u + 1 : lq;
+            Tw = keep ? test_T : -__builtin_fabsf(Tw);
+            lq = ((int)keep & (int)ok[u]) ? OFF + u + 1 : lq;   // (&, not &&: with the short-circuit form the compiler kept a branch per record once the closing select carried source modifiers)
         }
     };
     auto blend = [&](int jb, const Rec4& R, auto off) {
@@ -989,7 +988,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     auto checkpoint = [&](int jtop) {
         if (jtop == next_ck) {
             if (next_ck <= (GSR_BWD_SEGMENTS - 1) * GSR_BWD_SEGMENT) {
-                *ck_ptr = make_float4(T, C0, C1, C2);
+                *ck_ptr = make_float4(__builtin_fabsf(Tw), C0, C1, C2);
                 ck_ptr += ck_step;
             }
             next_ck += GSR_BWD_SEGMENT;
@@ -1086,14 +1085,14 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         // `off`: 0, 144 or 288 bytes ahead of it as an immediate -- no address arithmetic per batch
         // (a macro: captured variables inside the operand list of an asm in a GENERIC lambda do not compile with this clang)
 #define GSR_ISSUE(ADDR, O, V)                                                                                                                        \
-        asm volatile("ds_read_b128 %0, %15 offset:%16\n\tds_read_b128 %1, %15 offset:%16+16\n\tds_read_b64 %2, %15 offset:%16+32\n\t"                \
-                     "ds_read_b128 %3, %15 offset:%16+48\n\tds_read_b128 %4, %15 offset:%16+64\n\tds_read_b64 %5, %15 offset:%16+80\n\t"             \
-                     "ds_read_b128 %6, %15 offset:%16+96\n\tds_read_b128 %7, %15 offset:%16+112\n\tds_read_b64 %8, %15 offset:%16+128"                \
+        asm volatile("ds_read_b128 %0, %14 offset:%15\n\tds_read_b128 %1, %14 offset:%15+16\n\tds_read_b64 %2, %14 offset:%15+32\n\t"                \
+                     "ds_read_b128 %3, %14 offset:%15+48\n\tds_read_b128 %4, %14 offset:%15+64\n\tds_read_b64 %5, %14 offset:%15+80\n\t"             \
+                     "ds_read_b128 %6, %14 offset:%15+96\n\tds_read_b128 %7, %14 offset:%15+112\n\tds_read_b64 %8, %14 offset:%15+128"                \
                      : "=&v"(V.q0[0]), "=&v"(V.q1[0]), "=&v"(V.q2[0]), "=&v"(V.q0[1]), "=&v"(V.q1[1]), "=&v"(V.q2[1]), "=&v"(V.q0[2]),              \
                        "=&v"(V.q1[2]), "=&v"(V.q2[2]), /* the blend state as pass-through operands: the reads are issued BEHIND everything the */    \
                        /* previous blend computes (its instructions are free to move otherwise, and below this statement they need the old */       \
                        /* batch copied aside) */                                                                                                    \
-                       "+v"(T), "+v"(Tw), "+v"(C0), "+v"(C1), "+v"(C2), "+v"(lq)                                                                    \
+                       "+v"(Tw), "+v"(C0), "+v"(C1), "+v"(C2), "+v"(lq)                                                                             \
                      : "v"(ADDR), "n"(O))
         // the batch is in its registers once at most `behind` reads issued after it are still in flight (9 = one batch)
         auto ready = [&](RecV& V, auto behind, Rec4& R) {
@@ -1269,8 +1268,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
                     const int f = closed ? __builtin_ctzll(~K[e]) : 64;   // first lane whose record does not fit any more
                     const float Tlast = f == 0 ? Tp[e] : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tfull[e]), f - 1));
                     if (lane == pp[e]) {
-                        T = Tlast;
-                        Tw = closed ? 0.0f : Tlast;
+                        Tw = closed ? -Tlast : Tlast;
                         C0 += A0; C1 += A1; C2 += A2;
                         if (hits[e]) last_q = (uint32_t)(c0 + 64 - __builtin_clzll(hits[e]));
                     }
@@ -1340,7 +1338,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
                     lastqp = (uint32_t)(c0 + k + 1);
                 }
             }
-            if (lane == p) { T = Tp; C0 = A0; C1 = A1; C2 = A2; last_q = lastqp; }
+            if (lane == p) { Tw = Tp; C0 = A0; C1 = A1; C2 = A2; last_q = lastqp; }   // (|Tw| is the pixel's T; nothing reads the sign from here on)
         }
     }
 #ifdef GSR_EXPERIMENT_TIMELINE
@@ -1374,13 +1372,14 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         const size_t HW = (size_t)H * W;
         if (!s.forward_only) {   // what only the backward reads: 24 bytes per pixel (and the checkpoints above) less to store under torch.no_grad()
             const uint32_t last_contributor = !qlist ? last_q : (last_q ? (qlist + qs)[last_q - 1] + 1u : 0u);
-            final_T[pix_id] = T;
+            final_T[pix_id] = __builtin_fabsf(Tw);
             n_contrib[pix_id] = last_contributor;
             n_contrib_q[pix_id] = last_q;
             c_final[0 * HW + pix_id] = C0;
             c_final[1 * HW + pix_id] = C1;
             c_final[2 * HW + pix_id] = C2;
         }
+        const float T = __builtin_fabsf(Tw);
         out_color[0 * HW + pix_id] = C0 + T * s.bg[0];
         out_color[1 * HW + pix_id] = C1 + T * s.bg[1];
         out_color[2 * HW + pix_id] = C2 + T * s.bg[2];
