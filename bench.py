@@ -888,7 +888,9 @@ def main():
                                    f"not the latency of one frame)" if len(lanes) > 1 else "")),
             },
             # every timed round is exactly `steps` steps (barrier + device sync on both sides, MAX over ranks); value = median round
-            "rounds": {"n": len(rounds), "frames_per_s": [round(n_gpus * args.steps / r, 2) for r in rounds],
+            # (the per-round list is thinned to at most 64 evenly spaced rounds: with --min-seconds uncapped a default run has ~500 rounds, and the
+            #  line is read by tools that keep a bounded tail of stdout; n / min / p10 / max are over ALL rounds)
+            "rounds": {"n": len(rounds), "frames_per_s": [round(n_gpus * args.steps / rounds[int(i)], 2) for i in np.linspace(0, len(rounds) - 1, min(len(rounds), 64))],
                        "min": round(n_gpus * args.steps / max(rounds), 2), "p10": round(n_gpus * args.steps / float(np.percentile(rounds, 90)), 2),
                        "max": round(n_gpus * args.steps / min(rounds), 2), "timed_seconds": round(float(sum(rounds)), 4)},
             "roofline": dict(roofline, loss=loss_line) if roofline is not None and loss_line is not None else roofline,
