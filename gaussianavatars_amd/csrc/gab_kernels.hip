@@ -998,6 +998,11 @@ __global__ __launch_bounds__(256) void k_gather_skin_bwd(Rig rig, GatherSkinArgs
     for (int k = tid; k < ROWS; k += 256) gv[k] = 0.f;
     __syncthreads();
     // ---- gather the corners
+    // d(translation) is the plain sum of the vertex gradients, and of those the frames' orientation / scale parts -- translation invariant,
+    // hundreds of times larger than the rest -- cancel exactly in mathematics but not in fp32 (a run-to-run spread of 1.6e-4 of the row's
+    // max in arrival-order atomics, tools/mesh_bwd_repeat.py).  What survives the sum is each face centre's gradient, a third per corner:
+    // that is summed here directly (tc), and the vertex sums below only add the external vertex gradient to it.
+    float tc[3] = {0.f, 0.f, 0.f};
     const int p0 = a.vf_begin[vbase], p1 = a.vf_begin[vend];
     for (int p = p0 + tid; p < p1; p += 256) {
         const int4 e = a.vf_list[p];
@@ -1007,13 +1012,23 @@ __global__ __launch_bounds__(256) void k_gather_skin_bwd(Rig rig, GatherSkinArgs
         const Vec3 g = c == 0 ? g0 : (c == 1 ? g1 : g2);
         const int vl = (c == 0 ? e.y : (c == 1 ? e.z : e.w)) - vbase;
         atomicAdd(&gv[3 * vl], g.x); atomicAdd(&gv[3 * vl + 1], g.y); atomicAdd(&gv[3 * vl + 2], g.z);
+        if (a.d_center) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) tc[r] += a.d_center[3 * f + r] * (1.0f / 3.0f);
+        }
+    }
+    __shared__ float tcs[4][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float s = wave_sum_hi(tc[r]);
+        if (lane == 63) tcs[wid][r] = s;
     }
     __syncthreads();
     // ---- skinning backward: every wave evaluates the workgroup's vertices (lane = vertex), each reduces a quarter of the sums
     const int v = vbase + lane;
     const bool ok = lane < VPB && v < rig.V;
     const int E = 3 * rig.V;
-    float g[3] = {0.f, 0.f, 0.f}, vp[3] = {0.f, 0.f, 0.f}, T[12], gvp[3] = {0.f, 0.f, 0.f};
+    float g[3] = {0.f, 0.f, 0.f}, gx[3] = {0.f, 0.f, 0.f}, vp[3] = {0.f, 0.f, 0.f}, T[12], gvp[3] = {0.f, 0.f, 0.f};
     float w[GAB_NUM_JOINTS] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float pf[GAB_POSE_FEATURES];
 #pragma unroll
@@ -1021,7 +1036,7 @@ __global__ __launch_bounds__(256) void k_gather_skin_bwd(Rig rig, GatherSkinArgs
     if (ok) {
         vertex_posed_and_T<true>(rig, a.ws, a.v_shaped, v, vp, T);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) g[k] = gv[3 * lane + k] + (a.g_verts ? a.g_verts[3 * v + k] : 0.f);
+        for (int k = 0; k < 3; ++k) { gx[k] = a.g_verts ? a.g_verts[3 * v + k] : 0.f; g[k] = gv[3 * lane + k] + gx[k]; }
 #pragma unroll
         for (int c = 0; c < 3; ++c) gvp[c] = T[c] * g[0] + T[4 + c] * g[1] + T[8 + c] * g[2];
 #pragma unroll
@@ -1049,8 +1064,8 @@ __global__ __launch_bounds__(256) void k_gather_skin_bwd(Rig rig, GatherSkinArgs
     if (wid == 2) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const float s = wave_sum_hi(g[r]);
-            if (lane == 63) red[60 + r] = s;
+            const float s = wave_sum_hi(gx[r]);   // the external vertex gradient; the frames' share is the face centres' (tcs)
+            if (lane == 63) red[60 + r] = s + ((tcs[0][r] + tcs[1][r]) + (tcs[2][r] + tcs[3][r]));
         }
     }
 #pragma unroll

@@ -192,7 +192,8 @@ def test_mesh_backward_gather_equals_the_scatter_form(monkeypatch, with_verts_gr
     per-vertex gradients, whose face-frame parts (orientation, scale: translation invariant) cancel exactly in mathematics and are hundreds of
     times larger than what is left, so the sum of 161 workgroup partials carries their rounding (tools/mesh_bwd_repeat.py, 40 repetitions of this
     test's body on an MI355X: worst run-to-run difference 1.6e-4 of the row's max for translation, 2.6e-5 for the rotation, <= 1.2e-5 elsewhere;
-    the composed-torch formulation sums the same terms in fp32 and is no better conditioned)."""
+    the composed-torch formulation sums the same terms in fp32 and is no better conditioned).  The gathering form sums d_translation from the face
+    centres' gradients since (5e-7): it is held to 1e-4 on every row, the 1e-3 is the scatter form's and the comparison's."""
     from gaussianavatars_amd import binding as B
 
     dev = _dev()
@@ -218,8 +219,9 @@ def test_mesh_backward_gather_equals_the_scatter_form(monkeypatch, with_verts_gr
         for k in keys:
             fp[k].grad = None
         loss.backward()
-        for k in keys:
-            assert float((fp[k].grad - first[k]).abs().max()) <= tol[k] * float(first[k].abs().max()), f"{k}: a second backward over the same forward differs"
+        for k in keys:   # (the gathering form sums d_translation from the face centres' gradients: no cancelling sum, 1e-4 like the rest)
+            bar = 1e-4 if mode == "merged" else tol[k]
+            assert float((fp[k].grad - first[k]).abs().max()) <= bar * float(first[k].abs().max()), f"{mode} {k}: a second backward over the same forward differs"
             assert float(fp[k].grad[:5].abs().max()) == 0.0 and float(fp[k].grad[6:].abs().max()) == 0.0, f"{k}: gradient outside row 5"
         res[mode] = first
     for k in keys:
