@@ -435,6 +435,10 @@ def main():
                     help="N=1, eager default run only: after the timed rounds, the same workload again as this many recorded frame "
                          "lanes (reported beside `value` as `frame_streams`); 0 skips the leg")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the process next to its GPU (host-sensitivity runs)")
+    ap.add_argument("--dist-at-1", action="store_true",
+                    help="with --gpus 1 under a launcher (WORLD_SIZE=1): initialise the process group anyway and send the per-step scalar through the "
+                         "backend's all-reduce, so that a one-GPU box EXECUTES the RCCL path the N-GPU run takes (tests/test_rccl_gpu.py); the line "
+                         "says so in config.parallelism.  Not the default: at N = 1 the reference-shaped run has no collective")
     args = ap.parse_args()
     global SPATIAL_SORT
     SPATIAL_SORT = not args.no_spatial_sort and os.environ.get("GAA_SPATIAL_SORT", "1") != "0"
@@ -475,7 +479,7 @@ def main():
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or (args.dist_at_1 and "RANK" in os.environ):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -268,6 +268,7 @@ GLS_SYMBOLS = {
     "gls_l1_forward_grad": (C.c_int, [C.c_int64, _P, _P, C.c_float, _P, _P, _P, _P]),
     "gls_l1_backward": (C.c_int, [C.c_int64, _P, _P, _P, C.c_float, _P, _P]),
     "gls_densification_stats": (C.c_int, [C.c_int32] + [_P] * 6),
+    "gls_add_densification_stats": (C.c_int, [C.c_int32, _P, _P, C.c_int32, _P, _P, _P]),
 }
 
 _gls = None
@@ -285,8 +286,8 @@ def gls():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.gls_abi_version() != 2:
-            raise RuntimeError(f"gls ABI version {lib.gls_abi_version()} != 2")
+        if lib.gls_abi_version() != 3:
+            raise RuntimeError(f"gls ABI version {lib.gls_abi_version()} != 3")
         _gls = lib
     return _gls
 

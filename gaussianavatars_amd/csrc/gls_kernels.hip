@@ -296,6 +296,18 @@ __global__ __launch_bounds__(256) void k_densify_stats(int P, const int* __restr
     denom[i] += 1.f;
 }
 
+// GaussianModel.add_densification_stats alone (scene/gaussian_model.py:517-519) with the caller's own bool filter: the form the reference's
+// train.py:198 calls, rebound by patch_reference() (train.py:197's max_radii2D line is train.py's own torch code and stays there)
+__global__ __launch_bounds__(256) void k_add_densify_stats(int P, const unsigned char* __restrict__ filter, const float* __restrict__ vgrad, int vstride,
+                                                            float* __restrict__ accum, float* __restrict__ denom)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P || !filter[i]) return;
+    const float gx = vgrad[(size_t)vstride * i], gy = vgrad[(size_t)vstride * i + 1];
+    accum[i] += sqrtf(gx * gx + gy * gy);
+    denom[i] += 1.f;
+}
+
 }  // namespace gls
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -433,6 +445,18 @@ int gls_densification_stats(int32_t P, const int32_t* radii, const float* viewsp
     hipLaunchKernelGGL(gls::k_densify_stats, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, P, radii, viewspace_grad,
                        max_radii2D, xyz_gradient_accum, denom);
     LAUNCH_CHECK("k_densify_stats");
+    return GLS_OK;
+}
+
+int gls_add_densification_stats(int32_t P, const uint8_t* update_filter, const float* viewspace_grad, int32_t grad_stride, float* xyz_gradient_accum,
+                                float* denom, void* stream_)
+{
+    if (P < 0 || grad_stride < 2) return fail(GLS_E_ARG, "P < 0 or grad_stride < 2");
+    if (P == 0) return GLS_OK;
+    if (!update_filter || !viewspace_grad || !xyz_gradient_accum || !denom) return fail(GLS_E_ARG, "null pointer");
+    hipLaunchKernelGGL(gls::k_add_densify_stats, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, P, update_filter, viewspace_grad, grad_stride,
+                       xyz_gradient_accum, denom);
+    LAUNCH_CHECK("k_add_densify_stats");
     return GLS_OK;
 }
 

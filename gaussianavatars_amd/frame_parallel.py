@@ -31,11 +31,58 @@ def _cpulist(spec: str) -> List[int]:
     return cpus
 
 
-def _gpu_numa_node(device_index: int) -> int:
+def _gpu_bdf(device_index: int) -> str:
     props = torch.cuda.get_device_properties(device_index)
-    bdf = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
-    with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+    return "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+
+
+def _gpu_numa_node(device_index: int) -> int:
+    with open("/sys/bus/pci/devices/%s/numa_node" % _gpu_bdf(device_index)) as f:
         return int(f.read().strip())
+
+
+def _node_gpu_bdfs(node: int, root: str = "/sys/bus/pci/devices") -> List[str]:
+    """Every AMD GPU function 0 of NUMA node `node`, in PCI order, read from sysfs -- whatever this process is allowed to SEE.  In the
+    documented one-process-per-GPU mode (HIP_VISIBLE_DEVICES=k, utils/general_utils.py:133 pins cuda:0) torch reports one device to every
+    process, so the slot among the node's GPUs has to come from the physical topology: vendor 0x1002, class display (0x03xx) or processing
+    accelerator (0x12xx)."""
+    out = []
+    for bdf in sorted(os.listdir(root)):
+        if not bdf.endswith(".0"):
+            continue
+        try:
+            with open(os.path.join(root, bdf, "vendor")) as f:
+                if f.read().strip().lower() != "0x1002":
+                    continue
+            with open(os.path.join(root, bdf, "class")) as f:
+                cls = f.read().strip().lower()
+            if not (cls.startswith("0x03") or cls.startswith("0x12")):
+                continue
+            with open(os.path.join(root, bdf, "numa_node")) as f:
+                if int(f.read().strip()) != node:
+                    continue
+        except (OSError, ValueError):
+            continue
+        out.append(bdf)
+    return out
+
+
+def _slot_among_node_gpus(device_index: int, node: int) -> tuple:
+    """-> (slot, number of GPUs sharing the node).  Physical topology first (see _node_gpu_bdfs); when sysfs does not list this GPU (a
+    container without the PCI tree) the devices torch can see, and LOCAL_RANK when it sees only one of several ranks' GPUs."""
+    mine = _gpu_bdf(device_index)
+    try:
+        bdfs = _node_gpu_bdfs(node)
+    except OSError:
+        bdfs = []
+    if mine in bdfs:
+        return bdfs.index(mine), len(bdfs)
+    peers = [d for d in range(torch.cuda.device_count()) if _gpu_numa_node(d) == node]
+    if len(peers) > 1 or torch.cuda.device_count() > 1:
+        return (peers.index(device_index) if device_index in peers else 0), max(len(peers), 1)
+    world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+    rank = int(os.environ.get("LOCAL_RANK", "0") or 0)
+    return (rank % max(world, 1)), max(world, 1)
 
 
 def pin_to_gpu_numa_node(device_index: int = 0, cores: int = 8) -> Optional[List[int]]:
@@ -64,10 +111,11 @@ def pin_to_gpu_numa_node(device_index: int = 0, cores: int = 8) -> Optional[List
         firsts = [c for c in sorted(firsts) if c in allowed_now]
         if not firsts:
             return None
-        # my slot among the GPUs of this node
-        peers = [d for d in range(torch.cuda.device_count()) if _gpu_numa_node(d) == node]
-        slot = peers.index(device_index) if device_index in peers else 0
-        cores = max(1, min(cores, len(firsts) // max(len(peers), 1)))
+        # my slot among the GPUs of this node: from the PHYSICAL topology, so that N one-GPU processes (HIP_VISIBLE_DEVICES=k each, every
+        # one of them seeing "device 0") take N disjoint core groups instead of all landing on the node's first eight cores
+        slot, n_peers = _slot_among_node_gpus(device_index, node)
+        cores = max(1, min(cores, len(firsts) // max(n_peers, 1)))
+        slot %= max(1, len(firsts) // cores)
         mine = firsts[slot * cores: slot * cores + cores] or firsts[:cores]
         os.sched_setaffinity(0, mine)
         return mine
@@ -134,16 +182,27 @@ def init_process_group(backend: Optional[str] = None):
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("GAA_COLLECTIVES_AT_WORLD_1", "0") == "1") and not dist.is_initialized():
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+def _collectives_active() -> bool:
+    """True when the collectives below have to run: a process group of more than one rank -- or of ONE rank with GAA_COLLECTIVES_AT_WORLD_1=1,
+    which sends every call through the backend anyway (the single MI355X of a test box then executes the RCCL kernels the 8-GPU run
+    launches: tests/test_rccl_gpu.py)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("GAA_COLLECTIVES_AT_WORLD_1", "0") == "1"
 
 
 def allreduce_scalar(value: torch.Tensor, op: str = "sum") -> torch.Tensor:
     """In-place all-reduce of a 0-d / 1-element tensor; identity when not distributed."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_active():
         dist.all_reduce(value, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX)
     return value
 
@@ -197,7 +256,7 @@ def check_replica_consistency(tensors, device=None) -> None:
     mismatched buffers corrupts gradients or hangs."""
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_active():
         return
     fp = replica_fingerprint(tensors).to(_collective_device(device))
     lo, hi = fp.clone(), fp.clone()
@@ -217,7 +276,7 @@ def sync_densification_stats(model) -> None:
     sync_mesh_for_densification: the decisions also read the current mesh)."""
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_active():
         return
     dist.all_reduce(model.xyz_gradient_accum, op=dist.ReduceOp.SUM)
     dist.all_reduce(model.denom, op=dist.ReduceOp.SUM)
@@ -233,7 +292,7 @@ def sync_mesh_for_densification(model, timestep: int, src: int = 0) -> int:
     import torch.distributed as dist
 
     t = int(timestep)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_active():
         buf = torch.tensor([t], dtype=torch.int64, device=_collective_device())
         dist.broadcast(buf, src=src)
         t = int(buf.item())
@@ -265,7 +324,7 @@ def allreduce_gradients(params, average: bool = True, bucket_bytes: int = 64 << 
     the same bucket layout; with `check`, the replicas' shapes are compared first (check_replica_consistency)."""
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_active():
         return
     world = dist.get_world_size()
     params = [p for p in params if p is not None]

@@ -34,7 +34,9 @@ def _launch(dev, what, fn, *args):
         _check(fn(*args), what)
 
 
-_UNIT_SEEDS = {}
+_UNIT_SEEDS = {}        # (device, dtype) -> the cached constant 1
+_SEED_VERSIONS = {}     # (device, dtype) -> its ._version when it was made: an in-place op on it (a hook doing g.mul_(s)) would poison every later
+                        # backward, so a seed whose version moved is dropped and a fresh one made (stock torch hands out a fresh ones_like each time)
 
 
 def install_backward_seed(enable: bool = True) -> bool:
@@ -44,7 +46,9 @@ def install_backward_seed(enable: bool = True) -> bool:
     gradient is seeded with a cached device 1 instead -- the same gradients, one launch fewer, and train.py:133 keeps reading `loss.backward()`.
     Every other call (explicit gradient, non-scalar, CPU tensor, Tensor subclass) goes through untouched.  `patch_reference()` and `bench.py`
     install it (GAA_LOSS_SEED=0 opts out); `install_backward_seed(False)` restores torch's method.  Returns True when this call changed the state.
-    (A Tensor subclass carrying the seed through the loss arithmetic was measured first: +18 us of Python dispatch per step.)"""
+    (A Tensor subclass carrying the seed through the loss arithmetic was measured first: +18 us of Python dispatch per step.)
+    The seed is READ-ONLY by contract: a gradient hook that modifies its argument in place (`g.mul_(s)`) would change it for every later
+    backward, so its `_version` is checked on every use and a modified seed is discarded (and never taken for the unit seed by `_L1`)."""
     cur = torch.Tensor.backward
     wrapped = getattr(cur, "__gaussianavatars_amd_seed__", False)
     if not enable:
@@ -54,14 +58,19 @@ def install_backward_seed(enable: bool = True) -> bool:
     if wrapped:
         return False
     orig = cur
+    _L1_EMIT["on"], _L1_EMIT["misses"] = True, 0   # (a fresh installation starts with the grad-emitting L1 forward again: see _L1_EMIT)
 
     def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
         if gradient is None and type(self) is torch.Tensor and self.is_cuda and self.dim() == 0 and self.is_floating_point() and self.requires_grad:
             key = (self.device, self.dtype)
             gradient = _UNIT_SEEDS.get(key)
+            if gradient is not None and gradient._version != _SEED_VERSIONS[key]:   # somebody wrote into it (see _SEED_VERSIONS): never reuse it
+                gradient = None
+                del _UNIT_SEEDS[key]
             if gradient is None and not torch.cuda.is_current_stream_capturing():
                 # (never created under stream capture: the tensor would live in that graph's private pool)
                 gradient = _UNIT_SEEDS[key] = torch.ones((), dtype=self.dtype, device=self.device)
+                _SEED_VERSIONS[key] = gradient._version
         return orig(self, gradient, retain_graph, create_graph, inputs=inputs)
 
     backward.__gaussianavatars_amd_seed__ = True
@@ -179,8 +188,24 @@ def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_ave
 def _is_unit_seed(g: torch.Tensor) -> bool:
     """True iff `g` IS the cached constant 1 `install_backward_seed` hands to `loss.backward()` (same storage: a host-side test, no read of
     the device value; nothing else writes that tensor)."""
-    seed = _UNIT_SEEDS.get((g.device, g.dtype))
-    return seed is not None and g.dim() == 0 and g.data_ptr() == seed.data_ptr()
+    key = (g.device, g.dtype)
+    seed = _UNIT_SEEDS.get(key)
+    return seed is not None and g.dim() == 0 and g.data_ptr() == seed.data_ptr() and seed._version == _SEED_VERSIONS[key]
+
+
+_L1_EMIT = {"on": True, "misses": 0}   # the grad-emitting forward is kept while backward passes arrive seeded with the unit seed (BASELINE config 3's
+                                       # `l1_loss(...).backward()`); train.py combines L1 with other terms (:131-147), the upstream gradient is then never the
+                                       # seed and the extra image-sized store + retained buffer would be dead weight: two such backwards switch it off
+                                       # (GAA_L1_EMIT_GRAD=0 / 1 force it)
+
+
+def _l1_emit() -> bool:
+    import os
+
+    forced = os.environ.get("GAA_L1_EMIT_GRAD")
+    if forced is not None:
+        return forced != "0"
+    return _L1_EMIT["on"]
 
 
 class _L1(torch.autograd.Function):
@@ -197,7 +222,7 @@ class _L1(torch.autograd.Function):
         partial = torch.empty(int(lib.gls_partial_floats(1, 1, 1, 1)), dtype=torch.float32, device=dev)
         scale = 1.0 / float(max(n, 1))
         ctx.da = None
-        if ctx.needs_input_grad[0] and not ctx.needs_input_grad[1] and getattr(torch.Tensor.backward, "__gaussianavatars_amd_seed__", False):
+        if ctx.needs_input_grad[0] and not ctx.needs_input_grad[1] and getattr(torch.Tensor.backward, "__gaussianavatars_amd_seed__", False) and _l1_emit():
             ctx.da = torch.empty_like(a)
             _launch(dev, "gls_l1_forward_grad", lib.gls_l1_forward_grad, n, _p(a), _p(b), scale, _p(out), _p(partial), _p(ctx.da), _stream(dev))
         else:
@@ -208,8 +233,14 @@ class _L1(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         da, ctx.da = ctx.da, None   # (handed out at most once: a second backward over a retained graph takes the kernel below)
-        if da is not None and _is_unit_seed(g):
-            return da, None
+        if da is not None:
+            if _is_unit_seed(g):
+                _L1_EMIT["misses"] = 0
+                return da, None
+            _L1_EMIT["misses"] += 1            # the precomputed image was not usable (and is freed here): see _L1_EMIT
+            if _L1_EMIT["misses"] >= 2:
+                _L1_EMIT["on"] = False
+            da = None
         a, b = ctx.saved_tensors
         lib = _lib.gls()
         dev = a.device
@@ -231,6 +262,80 @@ def l1_loss(network_output: torch.Tensor, gt: torch.Tensor):
     if network_output.shape != gt.shape:
         gt = gt.expand_as(network_output)
     return _L1.apply(_as_input(network_output, "network_output"), _as_input(gt, "gt"))
+
+
+# ---- the reference's two calls, zero-edit (train.py:131-132) ---------------------------------------------------------------------------------
+# train.py calls `l1_loss(image, gt_image)` and then `ssim(image, gt_image)` on the SAME pair.  patch_reference() rebinds
+# utils.loss_utils.l1_loss / ssim to the two functions below: once a process has shown that pattern (an ssim() call on the pair the preceding
+# l1_loss() saw), l1_loss() runs the FUSED pass (_L1Ssim: both statistics from one read of the pair, one backward kernel) and parks the SSIM scalar
+# for the ssim() call that follows; until then -- and again after three fused results nobody collected -- it is the plain L1 kernel.  The parked
+# scalar is only handed out for the very same tensor objects at the same versions; any other call takes the stand-alone kernels.
+_PAIR = {"fused": False, "last": None, "parked": None, "unclaimed": 0}
+
+
+def _pair_key(a: torch.Tensor, b: torch.Tensor):
+    return (a, a._version, b, b._version, torch.is_grad_enabled())
+
+
+def _same_pair(k, a, b) -> bool:
+    return k is not None and k[0] is a and k[2] is b and k[1] == a._version and k[3] == b._version and k[4] == torch.is_grad_enabled()
+
+
+def _pairable(a, b) -> bool:
+    return (isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.is_cuda and b.is_cuda and a.dtype is torch.float32 and b.dtype is torch.float32
+            and a.shape == b.shape and a.dim() in (3, 4) and a.is_contiguous() and b.is_contiguous())
+
+
+def l1_loss_paired(network_output: torch.Tensor, gt: torch.Tensor):
+    """utils/loss_utils.py:17-18 as patch_reference() installs it (see _PAIR above)."""
+    if not _pairable(network_output, gt):
+        _PAIR["last"] = _PAIR["parked"] = None
+        return l1_loss(network_output, gt)
+    if _PAIR["parked"] is not None:            # the previous fused result was never collected by an ssim() call
+        _PAIR["unclaimed"] += 1
+        _PAIR["parked"] = None
+        if _PAIR["unclaimed"] >= 3:
+            _PAIR["fused"], _PAIR["unclaimed"] = False, 0
+    if _PAIR["fused"]:
+        l1, ss = l1_ssim(network_output, gt)
+        _PAIR["parked"] = (_pair_key(network_output, gt), ss)
+        _PAIR["last"] = None
+        return l1
+    _PAIR["last"] = _pair_key(network_output, gt)
+    return l1_loss(network_output, gt)
+
+
+def ssim_paired(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_average: bool = True):
+    """utils/loss_utils.py:36-63 as patch_reference() installs it: the scalar the preceding l1_loss() parked for this very pair, else the
+    stand-alone kernel (and the note that lets the NEXT l1_loss() of the process run the fused pass)."""
+    parked, _PAIR["parked"] = _PAIR["parked"], None
+    if window_size == 11 and size_average and parked is not None and _same_pair(parked[0], img1, img2):
+        _PAIR["unclaimed"] = 0
+        return parked[1]
+    if window_size == 11 and _same_pair(_PAIR["last"], img1, img2):
+        _PAIR["fused"] = True                  # the reference's pattern: from the next iteration on, one pass for both
+    _PAIR["last"] = None
+    return ssim(img1, img2, window_size, size_average)
+
+
+@torch.no_grad()
+def add_densification_stats(self, viewspace_point_tensor, update_filter) -> None:
+    """GaussianModel.add_densification_stats (scene/gaussian_model.py:517-519), as patch_reference() rebinds it on the reference's class:
+        xyz_gradient_accum[update_filter] += norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True);  denom[update_filter] += 1
+    in ONE launch (gls_add_densification_stats) instead of two masked read-modify-write chains (each a nonzero with a host sync).  Anything the
+    kernel does not take (an index list as the filter, other dtypes, host tensors) goes to the reference's own lines."""
+    g = viewspace_point_tensor.grad
+    acc, den = self.xyz_gradient_accum, self.denom
+    P = acc.shape[0]
+    ok = (g is not None and g.is_cuda and g.dtype is torch.float32 and g.dim() == 2 and g.shape[0] == P and g.shape[1] >= 2 and g.stride(1) == 1
+          and update_filter.dtype is torch.bool and update_filter.is_cuda and update_filter.shape == (P,) and update_filter.is_contiguous()
+          and acc.dtype is torch.float32 and den.dtype is torch.float32 and acc.is_contiguous() and den.is_contiguous() and acc.numel() == P and den.numel() == P)
+    if not ok:
+        acc[update_filter] += torch.norm(g[update_filter, :2], dim=-1, keepdim=True)
+        den[update_filter] += 1
+        return
+    dev = acc.device
+    _launch(dev, "gls_add_densification_stats", _lib.gls().gls_add_densification_stats, P, _p(update_filter), _p(g), int(g.stride(0)), _p(acc), _p(den), _stream(dev))
 
 
 @torch.no_grad()

@@ -257,7 +257,7 @@ def unpatch_classes(*classes) -> None:
             setattr(cls, name, orig)
             del _ORIG[(cls, name)]
     for cls in classes:
-        for flag in ("_gaa_patched", "_gaa_patched_flame", "_gaa_patched_head", "_gaa_patched_base"):
+        for flag in ("_gaa_patched", "_gaa_patched_flame", "_gaa_patched_head", "_gaa_patched_base", "_gaa_patched_stats"):
             if flag in cls.__dict__:
                 delattr(cls, flag)
         if isinstance(cls.__dict__.get("get_features_split"), property) and cls.__dict__["get_features_split"].fget is _get_features_split:
@@ -277,8 +277,10 @@ def patch_reference(reference_root: str | None = None, fast_render: bool = True,
        bench.py measures under -- the frame loop is host-paced; forked DataLoader workers keep the original CPU mask).
     5. (GAA_LOSS_SEED=0 opts out) installs loss.install_backward_seed: train.py's `loss.backward()` seeds the backward pass with a cached
        device 1 instead of a one-element fill launch.
-    Returns {'shims': [...], 'classes': [...], 'render': bool, 'pinned_cpus': [...] | None, 'backward_seed': bool}.  Call it before the entry
-    script imports `render`."""
+    6. (GAA_FUSED_LOSS=0 opts out) patch_loss_and_stats: `utils.loss_utils.l1_loss` / `ssim` and `GaussianModel.add_densification_stats`
+       -> the fused kernels of include/gls.h (train.py:131-132,198 unchanged).
+    Returns {'shims': [...], 'classes': [...], 'render': bool, 'pinned_cpus': [...] | None, 'backward_seed': bool, 'loss': [...]}.  Call it
+    before the entry script imports `render`."""
     from . import shims
 
     repo_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -313,5 +315,52 @@ def patch_reference(reference_root: str | None = None, fast_render: bool = True,
 
         install_backward_seed()
         seeded = True
+    fused_loss = patch_loss_and_stats(gm.GaussianModel) if os.environ.get("GAA_FUSED_LOSS", "1") != "0" else []
     return dict(shims=served, classes=[gm.GaussianModel, fgm.FlameGaussianModel, flame.FlameHead], render=did_render, pinned_cpus=pinned,
-                backward_seed=seeded)
+                backward_seed=seeded, loss=fused_loss)
+
+
+def patch_loss_and_stats(gaussian_model_cls=None, loss_utils=None) -> list:
+    """SURVEY.md 8(f) N3 behind the zero-edit boundary: the training-step neighbours of the render path, rebound BEFORE the entry script
+    imports them (train.py:22 `from utils.loss_utils import l1_loss, ssim`):
+
+        utils.loss_utils.l1_loss / ssim              utils/loss_utils.py:17-18,36-63 -> loss.l1_loss_paired / loss.ssim_paired: train.py:131-132's two
+                                                     calls on the same (image, gt) become ONE fused pass (gls_l1_ssim_*) from the second iteration on
+        GaussianModel.add_densification_stats        scene/gaussian_model.py:517-519 (train.py:198) -> gls_add_densification_stats, one launch
+
+    Host tensors / other dtypes / other window sizes keep the reference's own functions (kept on the module as `_gaa_orig_*`).  GAA_FUSED_LOSS=0
+    opts out.  Returns the names rebound (idempotent)."""
+    import importlib
+
+    from . import loss as L
+
+    done = []
+    lu = loss_utils if loss_utils is not None else importlib.import_module("utils.loss_utils")
+    if not getattr(lu, "_gaa_patched", False):
+        orig_l1, orig_ssim = lu.l1_loss, lu.ssim
+        _ORIG[(lu, "l1_loss")], _ORIG[(lu, "ssim")] = orig_l1, orig_ssim
+
+        def l1_loss(network_output, gt):
+            if not (isinstance(network_output, torch.Tensor) and network_output.is_cuda and network_output.dtype is torch.float32
+                    and isinstance(gt, torch.Tensor) and gt.is_cuda and gt.dtype is torch.float32):
+                return orig_l1(network_output, gt)
+            return L.l1_loss_paired(network_output, gt)
+
+        def ssim(img1, img2, window_size=11, size_average=True):
+            if not (window_size == 11 and isinstance(img1, torch.Tensor) and img1.is_cuda and img1.dtype is torch.float32 and img1.dim() in (3, 4)
+                    and isinstance(img2, torch.Tensor) and img2.is_cuda and img2.dtype is torch.float32 and img1.shape == img2.shape):
+                return orig_ssim(img1, img2, window_size, size_average)
+            return L.ssim_paired(img1, img2, window_size, size_average)
+
+        l1_loss.__doc__, ssim.__doc__ = L.l1_loss_paired.__doc__, L.ssim_paired.__doc__
+        lu._gaa_orig_l1_loss, lu._gaa_orig_ssim = orig_l1, orig_ssim
+        lu.l1_loss, lu.ssim = l1_loss, ssim
+        lu._gaa_patched = True
+        done += ["utils.loss_utils.l1_loss", "utils.loss_utils.ssim"]
+    G = gaussian_model_cls
+    if G is not None and "add_densification_stats" in G.__dict__ and not G.__dict__.get("_gaa_patched_stats", False):
+        _ORIG[(G, "add_densification_stats")] = G.__dict__["add_densification_stats"]
+        G.add_densification_stats = L.add_densification_stats
+        G._gaa_patched_stats = True
+        done.append(f"{G.__name__}.add_densification_stats")
+    return done

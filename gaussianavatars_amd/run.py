@@ -32,7 +32,7 @@ def main(argv=None) -> None:
     info = patch.patch_reference(reference_root=root, fast_render=os.environ.get("GSR_FAST_RENDER", "1") != "0")
     print(f"[gaussianavatars_amd] shims: {', '.join(info['shims']) or 'none'}; fused model methods on "
           f"{', '.join(c.__name__ for c in info['classes'])}; render fast path: {info['render']}; "
-          f"host CPUs: {info['pinned_cpus'] if info['pinned_cpus'] else 'unchanged'}", file=sys.stderr)
+          f"host CPUs: {info['pinned_cpus'] if info['pinned_cpus'] else 'unchanged'}; fused loss / statistics: {', '.join(info['loss']) or 'none'}", file=sys.stderr)
     sys.argv = [script] + argv[1:]
     runpy.run_path(script, run_name="__main__")
 

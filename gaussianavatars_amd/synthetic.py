@@ -276,8 +276,11 @@ def flame_masks_dict(v_template: np.ndarray) -> Dict[str, np.ndarray]:
         right_eye_region=sel(eye_r), left_eye_region=sel(eye_l))
 
 
+BENCHMARK_LOG_SCALE_OFFSET = 0.55   # measured with the CPU oracle at 100 000 splats, 802x550: 2.2 M rect instances (bench.py cfg2: 2.23 M); -0.5 gives 0.49 M, 0.8 gives 3.3 M
+
+
 def write_reference_assets(asset_dir: str, avatar_dir: str, template_obj: str, n_splats: int = FLAME_F, n_frames: int = 4, sh_degree: int = 3,
-                           seed: int = 4) -> Dict[str, str]:
+                           seed: int = 4, benchmark_scale: bool = False, log_scale_offset=None) -> Dict[str, str]:
     """Everything an unchanged `fps_benchmark_demo.py` / `render.py` of the reference opens, in the reference's own formats:
       asset_dir/flame2023.pkl, asset_dir/FLAME_masks.pkl   what FlameHead() unpickles (flame_model/flame.py:37-38,98-129,625-637);
       avatar_dir/point_cloud.ply + avatar_dir/flame_param.npz   a mesh-bound avatar as GaussianModel.save_ply / FlameGaussianModel.save_ply
@@ -300,7 +303,11 @@ def write_reference_assets(asset_dir: str, avatar_dir: str, template_obj: str, n
         pickle.dump(flame_masks_dict(v), fh, protocol=2)
     arrs = bound_splats(max(n_splats, FLAME_F), FLAME_F, sh_degree, seed=2)
     ext = float((v.max(0) - v.min(0)).max())
-    arrs["_scaling"] = arrs["_scaling"] - 0.5      # (smaller splats than the benchmark scene: this avatar is for starting scripts, not for timing)
+    if log_scale_offset is None:
+        # default: smaller splats than the benchmark scene (an avatar for STARTING scripts); benchmark_scale: the offset at which this avatar, on the
+        # real template's triangles, bins about as many tile instances per frame as bench.py's stand-in on its ellipsoid (tools/ref_on_gpu.py times it)
+        log_scale_offset = BENCHMARK_LOG_SCALE_OFFSET if benchmark_scale else -0.5
+    arrs["_scaling"] = arrs["_scaling"] + np.float32(log_scale_offset)
     gio.save_ply(out["point_cloud"], arrs)
     seq = flame_sequence(n_frames, seed)
     # the template sits where the FLAME fitting left it (its head around y = 1.5 m): the per-frame translation brings it in front of the

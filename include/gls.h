@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GLS_ABI_VERSION 2
+#define GLS_ABI_VERSION 3
 #define GLS_OK 0
 #define GLS_E_ARG (-1)
 #define GLS_E_HIP (-2)
@@ -67,6 +67,13 @@ int gls_l1_backward(int64_t n, const float* a, const float* b, const float* g, f
  * denom += 1.   viewspace_grad: (P,3) (the .grad of render()'s viewspace_points); the three state vectors: (P,) / (P,1). */
 int gls_densification_stats(int32_t P, const int32_t* radii, const float* viewspace_grad, float* max_radii2D,
                             float* xyz_gradient_accum, float* denom, void* stream);
+
+/* GaussianModel.add_densification_stats(viewspace_point_tensor, update_filter) alone (scene/gaussian_model.py:517-519, called at train.py:198):
+ * for every splat with update_filter[i] != 0 (P bytes, a torch.bool tensor):  xyz_gradient_accum += |viewspace_grad[i, :2]|;  denom += 1.
+ * viewspace_grad: rows of grad_stride floats (3 for render()'s viewspace_points.grad).  One launch instead of the reference's two masked
+ * read-modify-write chains (each a nonzero + gather + scatter with a host sync for the index count).  (ABI 3) */
+int gls_add_densification_stats(int32_t P, const uint8_t* update_filter, const float* viewspace_grad, int32_t grad_stride,
+                                float* xyz_gradient_accum, float* denom, void* stream);
 
 #ifdef __cplusplus
 }

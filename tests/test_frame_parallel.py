@@ -296,3 +296,26 @@ def test_recorded_lanes_walk_the_eager_loops_frames():
                     want = {offset + i: frames[(offset + i) % len(frames)] for i in range(n)}
                     assert got == want, (frames[:4], L, K, n, offset)
                     offset += n
+
+
+def test_pinning_slot_comes_from_the_physical_topology(tmp_path, monkeypatch):
+    """N one-GPU processes (HIP_VISIBLE_DEVICES=k each) all see "device 0"; their core groups must still be disjoint.
+    _node_gpu_bdfs reads the node's GPUs from sysfs whatever the process may see; _slot_among_node_gpus ranks this GPU among them."""
+    from gaussianavatars_amd import frame_parallel as FP
+
+    root = tmp_path / "pci"
+    devs = {"0000:05:00.0": ("0x1002", "0x120000", 0), "0000:15:00.0": ("0x1002", "0x120000", 0), "0000:15:00.1": ("0x1002", "0x040300", 0),
+            "0000:25:00.0": ("0x1002", "0x030000", 0), "0000:65:00.0": ("0x1002", "0x120000", 1), "0000:03:00.0": ("0x8086", "0x020000", 0)}
+    for bdf, (vendor, cls, node) in devs.items():
+        d = root / bdf
+        d.mkdir(parents=True)
+        (d / "vendor").write_text(vendor + "\n")
+        (d / "class").write_text(cls + "\n")
+        (d / "numa_node").write_text(f"{node}\n")
+    assert FP._node_gpu_bdfs(0, str(root)) == ["0000:05:00.0", "0000:15:00.0", "0000:25:00.0"]       # function 0 of AMD display / accelerator devices of node 0
+    assert FP._node_gpu_bdfs(1, str(root)) == ["0000:65:00.0"]
+    real = FP._node_gpu_bdfs
+    monkeypatch.setattr(FP, "_node_gpu_bdfs", lambda node: real(node, str(root)))
+    for k, bdf in enumerate(["0000:05:00.0", "0000:15:00.0", "0000:25:00.0"]):
+        monkeypatch.setattr(FP, "_gpu_bdf", lambda i, bdf=bdf: bdf)
+        assert FP._slot_among_node_gpus(0, 0) == (k, 3)        # every process asks about ITS "device 0": three different slots

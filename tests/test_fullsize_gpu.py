@@ -298,3 +298,110 @@ def test_non_default_stream_and_interleaved_forwards():
         for a, b in zip(grads_ref, grads):
             scale = float(a.abs().max()) + 1e-30
             assert float((a - b).abs().max()) / scale < 2e-4
+
+
+# ---- the frames bench.py times, in the mode it times them (round 5) ---------------------------------------------------------------------
+# Everything above runs the EXACT blend (tests/conftest.py) and, for the 2 M-splat frame, the parity binning of debug.forward_state on a
+# landscape image.  bench.py --workload cfg5 / cfg2 run render() under torch.no_grad(): fast blend, forward_only, default tile culling (the
+# 20-band rank path at 2 M splats), Morton-ordered leaves through the leaves / bound entry.  The two tests below compare exactly those frames
+# with the oracle fed the SAME world-space splats, under the tolerance tests/test_fast_blend_gpu.py states (shared constants), and then the
+# exact blend on the same frame bit for bit.
+def _kernel_activations(g):
+    """World-space (means3D, scales, rotations, opacities) of an UNBOUND model with the bits the rasterizer's first kernel computes in place:
+    csrc/bind_math.h is shared by gab::k_bind and gsr::k_preprocess, and binding every splat to ONE identity face frame (R = I, s = 1, c = 0,
+    q = (1,0,0,0)) makes k_bind's bound transform the unbound activations exactly (x*1+0, exp(ls)*1, 1 (x) normalize(q), sigmoid)."""
+    from gaussianavatars_amd import binding as fused
+
+    dev = g._xyz.device
+    P = g._xyz.shape[0]
+    eye = torch.eye(3, device=dev)[None].contiguous()
+    one, zero3 = torch.ones((1, 1), device=dev), torch.zeros((1, 3), device=dev)
+    quat = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=dev)
+    with torch.no_grad():
+        xyz, sc, rot, op = fused.bind_splats(g._xyz.detach(), g._scaling.detach(), g._rotation.detach(), torch.zeros(P, dtype=torch.int32, device=dev),
+                                             eye, one, zero3, quat, opacity_logit=g._opacity.detach())
+    assert torch.equal(xyz, g._xyz.detach())
+    return xyz, sc, rot, op
+
+
+@pytest.mark.fast_blend
+def test_config5_benchmarked_frame_in_the_benchmarked_mode(oracle):
+    """BASELINE configs[4] exactly as bench.py --workload cfg5 runs it: H = 1600, W = 1100 (portrait, 6900 tiles), 2 000 000 Morton-ordered
+    SH-3 splats of an unbound GaussianModel, render() under torch.no_grad()."""
+    import bench
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd.gaussian_renderer import render
+    from tests.test_fast_blend_gpu import check_image
+
+    dev = _dev()
+    H, W, N = 1600, 1100, 2_000_000
+    assert bench.SPATIAL_SORT
+    g, cam = bench.build_unbound_scene(dev, N, 3, W, H)
+    bg = torch.ones(3, device=dev)
+    assert R.get_tile_culling() == 1 and R._fast_blend == 1          # the product defaults, nothing selected by the test
+    with torch.no_grad():
+        pkg = render(cam, g, bench.Pipe, bg)
+    info = R.last_forward_info()
+    assert info["forward_only"] is True and info["bound"] is True and info["tile_culling"] is True
+    assert info["binning_path"] == 0 and info["rank_bands"] == 20, info     # the rank path over 20 bands of tile rows: what the 2 M-splat line times
+    xyz, sc, rot, op = _kernel_activations(g)
+    tfx, tfy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    s = oracle.make_settings(H, W, tfx, tfy, [1, 1, 1], 1.0, _np(cam.world_view_transform), _np(cam.full_proj_transform), 3, _np(cam.camera_center))
+    shs = _np(g.get_features)
+    st = oracle.forward(s, _np(xyz), shs, None, _np(op), _np(sc), _np(rot), None)
+    assert info["rect_instances"] == st.num_rendered                  # the reference's instance count; the culled lists hold fewer
+    assert 0 < info["num_rendered"] <= st.num_rendered
+    np.testing.assert_array_equal(_np(pkg["radii"]), st.radii)
+    np.testing.assert_array_equal(_np(pkg["visibility_filter"]), st.radii > 0)
+    n = check_image(_np(pkg["render"]), st.color, float(shs.max()) + 0.5, "cfg5 portrait, fast blend")
+    # the same frame, exact blend: the oracle's bits
+    prev = R.set_fast_blend(False)
+    try:
+        with torch.no_grad():
+            exact = render(cam, g, bench.Pipe, bg)
+    finally:
+        R.set_fast_blend(prev)
+    assert R.last_forward_info()["rank_bands"] == 20
+    assert np.array_equal(_np(exact["render"]).view(np.uint32), st.color.view(np.uint32)), f"exact blend: max |diff| {np.abs(_np(exact['render']) - st.color).max()}"
+    assert torch.equal(exact["radii"], pkg["radii"])
+    print(f"cfg5 product mode: {n} threshold pixel(s) of {H * W}; rect instances {st.num_rendered}, binned {info['num_rendered']}")
+
+
+@pytest.mark.fast_blend
+def test_config2_benchmarked_frame_in_the_benchmarked_mode(oracle):
+    """BASELINE configs[1] as bench.py --workload cfg2 / fps_benchmark_demo.py:59-61 run it: 100 000 Morton-ordered mesh-bound SH-3 splats,
+    802x550, select_mesh_by_timestep + render() under torch.no_grad() through the BOUND entry (fast blend, forward_only)."""
+    import bench
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd.gaussian_renderer import render
+    from tests.test_fast_blend_gpu import check_image
+
+    dev = _dev()
+    H, W, N = 802, 550, 100_000
+    g, cam = bench.build_scene(dev, N, 3, W, H, 300, "fused", False)
+    bg = torch.ones(3, device=dev)
+    tfx, tfy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    s = oracle.make_settings(H, W, tfx, tfy, [1, 1, 1], 1.0, _np(cam.world_view_transform), _np(cam.full_proj_transform), 3, _np(cam.camera_center))
+    shs = _np(g.get_features)
+    assert R.get_tile_culling() == 1 and R._fast_blend == 1
+    for ts in (0, 151):
+        with torch.no_grad():
+            g.bound_render = True
+            g.select_mesh_by_timestep(ts)
+            pkg = render(cam, g, bench.Pipe, bg)
+            info = R.last_forward_info()
+            assert info["forward_only"] is True and info["bound"] is True and info["tile_culling"] is True
+            g.bound_render = False          # the accessor path: the world-space tensors the oracle is fed (k_bind: the bound entry's bits)
+            world = dict(means3D=_np(g.get_xyz), opacities=_np(g.get_opacity), scales=_np(g.get_scaling), rotations=_np(g.get_rotation))
+        st = oracle.forward(s, world["means3D"], shs, None, world["opacities"], world["scales"], world["rotations"], None)
+        assert info["rect_instances"] == st.num_rendered
+        np.testing.assert_array_equal(_np(pkg["radii"]), st.radii)
+        check_image(_np(pkg["render"]), st.color, float(shs.max()) + 0.5, f"cfg2 t={ts}, fast blend")
+        prev = R.set_fast_blend(False)
+        try:
+            with torch.no_grad():
+                g.bound_render = True
+                exact = render(cam, g, bench.Pipe, bg)
+        finally:
+            R.set_fast_blend(prev)
+        assert np.array_equal(_np(exact["render"]).view(np.uint32), st.color.view(np.uint32)), f"t={ts} exact blend: max |diff| {np.abs(_np(exact['render']) - st.color).max()}"

@@ -304,3 +304,43 @@ def test_patched_mirror_classes_keep_the_reference_surface():
     g.flame_model.impl = "unfused"
     assert g.get_xyz.shape == (S.FLAME_F, 3) and g.timestep == 0
     assert type(g).select_mesh_by_timestep is patch._select_mesh_by_timestep
+
+
+def test_loss_and_statistics_rebinding_keeps_host_tensors_on_the_reference_functions():
+    """patch_loss_and_stats (SURVEY.md 8(f) N3 behind the zero-edit boundary): utils.loss_utils.l1_loss / ssim and
+    GaussianModel.add_densification_stats are rebound; whatever the kernels do not take -- here: host tensors -- reaches the reference's own
+    functions, with the reference's results (the GPU side: tests/test_reference_classes_gpu.py, tests/test_loss_gpu.py)."""
+    import types
+
+    import torch
+
+    from gaussianavatars_amd import patch as P
+
+    calls = []
+    lu = types.ModuleType("fake_loss_utils")
+    lu.l1_loss = lambda a, b: (calls.append("l1"), torch.abs(a - b).mean())[1]
+    lu.ssim = lambda a, b, window_size=11, size_average=True: (calls.append("ssim"), torch.tensor(0.5))[1]
+
+    class G:
+        def add_densification_stats(self, vsp, f):
+            raise AssertionError("the original method must have been replaced")
+
+    done = P.patch_loss_and_stats(G, loss_utils=lu)
+    assert done == ["utils.loss_utils.l1_loss", "utils.loss_utils.ssim", "G.add_densification_stats"]
+    assert P.patch_loss_and_stats(G, loss_utils=lu) == []          # idempotent
+    a, b = torch.rand(3, 8, 8), torch.rand(3, 8, 8)
+    assert float(lu.l1_loss(a, b)) == float(torch.abs(a - b).mean()) and float(lu.ssim(a, b)) == 0.5
+    assert calls == ["l1", "ssim"]
+    g = G()
+    n = 50
+    g.xyz_gradient_accum, g.denom = torch.rand(n, 1), torch.rand(n, 1)
+    vsp = torch.zeros(n, 3, requires_grad=True)
+    vsp.grad = torch.randn(n, 3)
+    f = torch.rand(n) > 0.5
+    want_acc, want_den = g.xyz_gradient_accum.clone(), g.denom.clone()
+    want_acc[f] += torch.norm(vsp.grad[f, :2], dim=-1, keepdim=True)
+    want_den[f] += 1
+    g.add_densification_stats(vsp, f)
+    assert torch.equal(g.xyz_gradient_accum, want_acc) and torch.equal(g.denom, want_den)
+    P.unpatch_classes(G)
+    assert "_gaa_patched_stats" not in G.__dict__
