@@ -472,10 +472,62 @@ class _MeshFramesTimestep(torch.autograd.Function):
         return (None, None, None) + tuple(grads[2:])
 
 
+_RIG_BUFFERS = ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights")
+
+
+def _plain(t) -> bool:
+    return t.is_cuda and t.dtype is torch.float32 and t.is_contiguous()
+
+
+def _mesh_plan(H, head, fp: dict, faces):
+    """The frame-independent half of select_mesh_by_timestep for the compiled host (csrc/gaa_host.cpp: MeshPlan): rig struct, prepared rig, topology
+    tables -- made once, kept on the head, and re-made when anything it was made from is replaced or modified in place (object identity + version
+    counters of shape / static_offset / faces, identity of the five rig buffers, the two mode switches).  None: this call is outside what the native
+    node takes (a gradient for shape or static_offset, the classic three-kernel FLAME, the split backward, the sequence table, other dtypes)."""
+    import os
+
+    shape, so = fp["shape"], fp.get("static_offset")
+    bufs = head.__dict__.get("_buffers")                      # an nn.Module's registered buffers (no __getattr__ walk), else plain attributes
+    if bufs is None or any(n not in bufs for n in _RIG_BUFFERS):
+        bufs = {n: getattr(head, n) for n in _RIG_BUFFERS}
+    env = (os.environ.get("GAA_MESH_BWD"), os.environ.get("GAA_MESH_SEQUENCE"))
+    st = head.__dict__.get("_gaa_mesh_plan")
+    if st is not None:
+        (plan, k_shape, v_shape, k_so, v_so, k_faces, v_faces, k_bufs, k_env, k_flags) = st
+        if (k_shape is shape and v_shape == shape._version and k_so is so and (so is None or v_so == so._version) and k_faces is faces and v_faces == faces._version
+                and k_env == env and k_flags == (shape.requires_grad, so is not None and so.requires_grad, getattr(head, "flame_impl", "prepared"))
+                and all(bufs[n] is b for n, b in zip(_RIG_BUFFERS, k_bufs))):
+            return plan
+    plan = None
+    flags = (shape.requires_grad, so is not None and so.requires_grad, getattr(head, "flame_impl", "prepared"))
+    ok = (not flags[0] and not flags[1] and flags[2] != "classic" and _mesh_backward_mode() == "merged" and _sequence_mode() == "off"
+          and all(_plain(bufs[n]) for n in _RIG_BUFFERS) and faces.is_cuda and faces.is_contiguous() and faces.dtype in (torch.int32, torch.int64)
+          and faces.device == bufs["v_template"].device)
+    if ok:
+        rig = _rig_struct(head)
+        sh = _f32(shape).reshape(-1)
+        sof = None if so is None else _f32(so).reshape(-1)
+        if sh.numel() == rig.n_shape and (sof is None or sof.numel() == 3 * rig.V):
+            prepared = _prepared_rig(head, rig, sh, sof)
+            vf_begin, vf_list = vertex_corner_csr(faces, int(rig.V))
+            plan = H.make_mesh_plan(*[bufs[n] for n in _RIG_BUFFERS], [int(x) for x in head.parents.tolist()], int(head.n_shape_params), prepared, faces, vf_begin, vf_list)
+    head.__dict__["_gaa_mesh_plan"] = (plan, shape, shape._version, so, None if so is None else so._version, faces, faces._version, tuple(bufs[n] for n in _RIG_BUFFERS), env, flags)
+    return plan
+
+
 def mesh_frames_timestep(head, flame_param: dict, t: int, faces):
     """select_mesh_by_timestep + update_mesh_properties in one autograd node:
     -> (verts (1,V,3), verts_cano (1,V,3), face_center, face_orien_mat, face_scaling, face_orien_quat)."""
     fp = flame_param
+    from . import _host
+
+    H = _host.get()
+    if H is not None:
+        expr, rot, neck, jaw, eyes, trans = fp["expr"], fp["rotation"], fp["neck_pose"], fp["jaw_pose"], fp["eyes_pose"], fp["translation"]
+        if _plain(expr) and _plain(rot) and _plain(neck) and _plain(jaw) and _plain(eyes) and _plain(trans):
+            plan = _mesh_plan(H, head, fp, faces)
+            if plan is not None:
+                return H.mesh_frames(plan, expr, rot, neck, jaw, eyes, trans, int(t))
     return _MeshFramesTimestep.apply(head, int(t), faces, fp["shape"], fp["expr"], fp["rotation"], fp["neck_pose"], fp["jaw_pose"],
                                      fp["eyes_pose"], fp["translation"], fp.get("static_offset"))
 

@@ -1,0 +1,690 @@
+// gaa_host.cpp -- the COMPILED host side of a frame step: one native call per autograd node.
+//
+// BASELINE.json's north_star asks for the kernels to be "surfaced to PyTorch-ROCm via a torch.autograd.Function C-ABI extension".  Rounds
+// 1-4 did that with Python autograd Functions over ctypes (rasterizer.py, binding.py, loss.py): ~314 us of interpreter work per step against
+// 281 us of kernels -- the eager step an unchanged train.py runs was paced by Python.  This translation unit is the same
+// host logic compiled: three torch::autograd::Node subclasses (mesh update, bound rasterizer, L1 / L1+SSIM loss) whose forward is ONE
+// pybind call and whose backward runs on autograd's device thread without the interpreter.  The numeric work is unchanged: every launch
+// still goes through the C ABI of include/gsr.h, gab.h, gls.h (resolved from the already loaded libraries with dlsym, so GSR_LIB /
+// GAB_LIB overrides and the ABI version checks of gaussianavatars_amd/_lib.py keep working).  torch supplies device memory, the current
+// stream and the autograd graph, nothing else.
+//
+// What each node mirrors in the reference (file:line relative to /root/reference):
+//   MeshNode    FlameGaussianModel.select_mesh_by_timestep + update_mesh_properties   scene/flame_gaussian_model.py:117-154
+//               (FlameHead.forward flame_model/flame.py:485-558, lbs flame_model/lbs.py:101-195, compute_face_orientation
+//               utils/graphics_utils.py:116-135)  -- the Python twin is binding._MeshFramesTimestep (prepared rig, merged backward)
+//   RasterNode  get_xyz/get_scaling/get_rotation/get_opacity + GaussianRasterizer.forward/backward
+//               scene/gaussian_model.py:113-160, gaussian_renderer/__init__.py:37-52,86-94 -- twin: rasterizer._RasterizeBound
+//   L1Node / L1SsimNode   utils/loss_utils.py:17-18,36-63 (train.py:131-132) -- twins: loss._L1, loss._L1Ssim
+// Anything outside the product default (recordings / deferred counts, poisoned state, debug dumps, P == 0, classic FLAME, batches) stays
+// with the Python twins, which remain the reference implementation of the host logic (tests/test_native_host_gpu.py compares the two).
+#include <torch/extension.h>
+
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <c10/hip/HIPStream.h>
+#include <dlfcn.h>
+#include <torch/csrc/autograd/function.h>
+#include <torch/csrc/autograd/functions/utils.h>
+
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#include "../../include/gab.h"
+#include "../../include/gls.h"
+#include "../../include/gsr.h"
+
+namespace {
+
+using at::Tensor;
+using torch::autograd::Node;
+using torch::autograd::variable_list;
+
+// ---- the C ABI, resolved at init() ---------------------------------------------------------------------------------------------------
+#define GAA_API(X)                                                                                                                      \
+    X(gsr_abi_version) X(gsr_last_error) X(gsr_geom_layout) X(gsr_binning_layout) X(gsr_image_layout) X(gsr_forward_bound)             \
+    X(gsr_backward_bound) X(gsr_last_forward_seq) X(gsr_count_slot_wait) X(gsr_count_slot_overflow)                                     \
+    X(gab_abi_version) X(gab_last_error) X(gab_flame_forward_prepared) X(gab_face_frames_forward) X(gab_mesh_backward_prepared)         \
+    X(gab_bind_backward_faces)                                                                                                           \
+    X(gls_abi_version) X(gls_last_error) X(gls_partial_floats) X(gls_l1_forward) X(gls_l1_forward_grad) X(gls_l1_backward)               \
+    X(gls_l1_ssim_forward) X(gls_l1_ssim_backward_split)
+
+struct Api {
+#define GAA_DECL(name) decltype(&::name) name = nullptr;
+    GAA_API(GAA_DECL)
+#undef GAA_DECL
+    bool ready = false;
+} api;
+
+void* open_loaded(const std::string& path)
+{
+    void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_NOLOAD);   // gaussianavatars_amd/_lib.py mapped it (after torch, so that torch's HIP runtime is the one in use)
+    if (!h) h = dlopen(path.c_str(), RTLD_NOW);
+    TORCH_CHECK(h, "gaa_host: cannot open ", path, ": ", dlerror());
+    return h;
+}
+
+void init(const std::string& gsr_path, const std::string& gab_path, const std::string& gls_path)
+{
+    void* hs[3] = {open_loaded(gsr_path), open_loaded(gab_path), open_loaded(gls_path)};
+#define GAA_LOAD(name)                                                                                       \
+    {                                                                                                        \
+        void* s = nullptr;                                                                                   \
+        for (void* h : hs)                                                                                   \
+            if (!s) s = dlsym(h, #name);                                                                     \
+        TORCH_CHECK(s, "gaa_host: the libraries do not export ", #name);                                     \
+        api.name = reinterpret_cast<decltype(api.name)>(s);                                                  \
+    }
+    GAA_API(GAA_LOAD)
+#undef GAA_LOAD
+    TORCH_CHECK(api.gsr_abi_version() == GSR_ABI_VERSION, "gaa_host was built for gsr ABI ", GSR_ABI_VERSION, ", the library is ", api.gsr_abi_version());
+    TORCH_CHECK(api.gab_abi_version() == GAB_ABI_VERSION, "gaa_host was built for gab ABI ", GAB_ABI_VERSION, ", the library is ", api.gab_abi_version());
+    TORCH_CHECK(api.gls_abi_version() == GLS_ABI_VERSION, "gaa_host was built for gls ABI ", GLS_ABI_VERSION, ", the library is ", api.gls_abi_version());
+    api.ready = true;
+}
+
+inline void need_api() { TORCH_CHECK(api.ready, "gaa_host.init() has not been called"); }
+
+// ---- small helpers -----------------------------------------------------------------------------------------------------------------------
+inline void* cur_stream(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+using DeviceGuard = c10::hip::HIPGuardMasqueradingAsCUDA;
+
+inline const float* fptr(const Tensor& t) { return t.defined() && t.numel() ? t.data_ptr<float>() : nullptr; }
+inline float* fptr_mut(Tensor& t) { return t.defined() && t.numel() ? t.data_ptr<float>() : nullptr; }
+
+inline void check_f32(const Tensor& t, const char* name)
+{
+    TORCH_CHECK(t.defined() && t.is_cuda(), name, " must be a device tensor; the MI355X path has no CPU implementation");
+    TORCH_CHECK(t.scalar_type() == at::kFloat && t.is_contiguous(), name, " must be contiguous float32 (the native host does not copy: take the Python entry)");
+}
+
+inline Tensor empty_f32(at::IntArrayRef sizes, const Tensor& like) { return at::empty(sizes, like.options().dtype(at::kFloat)); }
+
+// a contiguous fp32 gradient as the kernels read it (autograd may hand over an expanded / strided tensor)
+inline Tensor grad_f32(const Tensor& g)
+{
+    if (!g.defined()) return g;
+    if (g.scalar_type() == at::kFloat && g.is_contiguous()) return g;
+    return g.to(at::kFloat).contiguous();
+}
+
+// A tensor a node needs in its backward, kept for the node's whole life (the Python twins' binding._Keep): inputs as they are, tensors the
+// forward created as detached aliases (never the output object itself: no node -> output -> grad_fn -> node cycle), and the version
+// counter re-checked so that an in-place update between forward and backward raises as it does in stock autograd.
+struct Kept {
+    Tensor t;
+    uint32_t version = 0;
+    Kept() = default;
+    explicit Kept(const Tensor& x, bool alias = false) : t(x.defined() ? (alias ? x.detach() : x) : x), version(x.defined() ? x._version() : 0) {}
+    const Tensor& get(const char* what) const
+    {
+        TORCH_CHECK(!t.defined() || t._version() == version, "one of the variables needed for gradient computation has been modified by an inplace operation (",
+                    what, " saved by the native host is at version ", t.defined() ? t._version() : 0, ", expected ", version, ")");
+        return t;
+    }
+};
+
+inline bool any_requires_grad(std::initializer_list<std::reference_wrapper<const Tensor>> ts)
+{
+    if (!at::GradMode::is_enabled()) return false;
+    for (const Tensor& t : ts)
+        if (t.defined() && t.requires_grad()) return true;
+    return false;
+}
+
+// ======================================================================================================================================
+// 1. select_mesh_by_timestep + update_mesh_properties (prepared rig, merged backward)
+// ======================================================================================================================================
+struct MeshPlan {   // what does not change from frame to frame: built by binding._mesh_plan, revalidated there (identity + versions)
+    GabRig rig{};
+    Tensor keep[5];          // v_template, shapedirs, posedirs, J_regressor, lbs_weights (the rig struct points into them)
+    Tensor prepared;         // gab_flame_prepare's output for (rig, shape, static_offset)
+    Tensor faces;            // (F,3) int32 / int64
+    int faces_i64 = 0;
+    Tensor vf_begin, vf_list;   // vertex -> corner table of the merged backward (binding.vertex_corner_csr)
+    int64_t F = 0;
+};
+
+struct MeshNode : public Node {
+    std::shared_ptr<MeshPlan> plan;
+    Kept tabs[6];                  // expr, rotation, neck, jaw, eyes, translation: the (T,k) tables
+    Kept verts, v_shaped;          // aliases of two outputs
+    Tensor ws;                     // GAB_FLAME_WS_FLOATS of per-frame workspace (internal)
+    int64_t t = 0, T = 0;
+    int64_t widths[6] = {0, 3, 3, 3, 6, 3};
+
+    variable_list apply(variable_list&& grads) override
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        need_api();
+        // grads: verts, v_shaped, center, R, scale, quat
+        TORCH_CHECK(grads.size() == 6, "MeshNode: expected 6 gradients");
+        TORCH_CHECK(!grads[1].defined(), "the native mesh node has no path for a gradient w.r.t. verts_cano (v_shaped): take GAA_NATIVE_HOST=0");
+        const MeshPlan& p = *plan;
+        static const char* names[6] = {"expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation"};
+        const Tensor& v = verts.get("verts");
+        const Tensor& vs = v_shaped.get("verts_cano");
+        DeviceGuard guard(v.device().index());
+        void* stream = cur_stream(v);
+        const int V = p.rig.V;
+        Tensor tables[6];
+        float* zero_ptrs[6];
+        int32_t zero_sizes[6];
+        float* outp[6];
+        const float* rows[6];
+        for (int i = 0; i < 6; ++i) {
+            const Tensor& tab = tabs[i].get(names[i]);
+            tables[i] = empty_f32({T, widths[i]}, v);             // full (T,k) gradient tables: zero-filled by the backward's first kernel, row t written
+            zero_ptrs[i] = tables[i].data_ptr<float>();
+            zero_sizes[i] = (int32_t)(T * widths[i]);
+            outp[i] = zero_ptrs[i] + t * widths[i];
+            rows[i] = tab.data_ptr<float>() + t * widths[i];
+        }
+        Tensor scratch = empty_f32({3 * (int64_t)V}, v);
+        Tensor gc = grad_f32(grads[2]), gR = grad_f32(grads[3]), gs = grad_f32(grads[4]), gq = grad_f32(grads[5]), gv = grad_f32(grads[0]);
+        int rc = api.gab_mesh_backward_prepared(&p.rig, p.prepared.data_ptr<float>(), rows[1], rows[2], rows[3], rows[4], vs.data_ptr<float>(), ws.data_ptr<float>(),
+                                                v.data_ptr<float>(), p.vf_begin.data_ptr<int32_t>(), p.vf_list.data_ptr<int32_t>(), fptr(gc), fptr(gR), fptr(gs), fptr(gq),
+                                                fptr(gv), outp[0], outp[1], outp[2], outp[3], outp[4], outp[5], scratch.data_ptr<float>(), 6, zero_ptrs, zero_sizes, stream);
+        TORCH_CHECK(rc == 0, "gab_mesh_backward_prepared failed (", rc, "): ", api.gab_last_error());
+        variable_list out(6);
+        for (int i = 0; i < 6; ++i)
+            if (task_should_compute_output(i)) out[i] = tables[i];
+        return out;
+    }
+    void release_variables() override {}   // kept for the node's life: one mesh update may serve several render + backward passes (binding._Keep)
+};
+
+// -> (verts (1,V,3), verts_cano (1,V,3), face_center (F,3), face_orien_mat (F,3,3), face_scaling (F,1), face_orien_quat (F,4))
+std::vector<Tensor> mesh_frames(const std::shared_ptr<MeshPlan>& plan, const Tensor& expr, const Tensor& rotation, const Tensor& neck, const Tensor& jaw,
+                                const Tensor& eyes, const Tensor& translation, int64_t t)
+{
+    need_api();
+    const MeshPlan& p = *plan;
+    const Tensor* tabs[6] = {&expr, &rotation, &neck, &jaw, &eyes, &translation};
+    const int64_t widths[6] = {p.rig.n_expr, 3, 3, 3, 6, 3};
+    static const char* names[6] = {"expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation"};
+    const int64_t T = expr.dim() == 2 ? expr.size(0) : -1;
+    TORCH_CHECK(T > 0 && t >= 0 && t < T, "flame_forward_timestep: expected (T,n_expr),(T,3),(T,3),(T,3),(T,6),(T,3) tables and 0 <= t < T");
+    for (int i = 0; i < 6; ++i) {
+        check_f32(*tabs[i], names[i]);
+        TORCH_CHECK(tabs[i]->dim() == 2 && tabs[i]->size(0) == T && tabs[i]->size(1) == widths[i],
+                    "flame_forward_timestep: expected (T,n_expr),(T,3),(T,3),(T,3),(T,6),(T,3) tables and 0 <= t < T");
+    }
+    const Tensor& like = p.prepared;
+    DeviceGuard guard(like.device().index());
+    void* stream = cur_stream(like);
+    const int64_t V = p.rig.V, F = p.F;
+    Tensor verts = empty_f32({1, V, 3}, like), v_shaped = empty_f32({1, V, 3}, like), ws = empty_f32({GAB_FLAME_WS_FLOATS}, like);
+    Tensor center = empty_f32({F, 3}, like), R = empty_f32({F, 3, 3}, like), scale = empty_f32({F, 1}, like), quat = empty_f32({F, 4}, like);
+    const float* rows[6];
+    for (int i = 0; i < 6; ++i) rows[i] = tabs[i]->data_ptr<float>() + t * widths[i];
+    int rc = api.gab_flame_forward_prepared(&p.rig, p.prepared.data_ptr<float>(), rows[0], rows[1], rows[2], rows[3], rows[4], rows[5], verts.data_ptr<float>(),
+                                            v_shaped.data_ptr<float>(), ws.data_ptr<float>(), stream);
+    TORCH_CHECK(rc == 0, "gab_flame_forward_prepared failed (", rc, "): ", api.gab_last_error());
+    rc = api.gab_face_frames_forward((int32_t)V, (int32_t)F, verts.data_ptr<float>(), p.faces.data_ptr(), p.faces_i64, center.data_ptr<float>(), R.data_ptr<float>(),
+                                     scale.data_ptr<float>(), quat.data_ptr<float>(), nullptr /* merged backward: no scatter target to pre-zero */, stream);
+    TORCH_CHECK(rc == 0, "gab_face_frames_forward failed (", rc, "): ", api.gab_last_error());
+    if (any_requires_grad({expr, rotation, neck, jaw, eyes, translation})) {
+        auto node = std::shared_ptr<MeshNode>(new MeshNode(), torch::autograd::deleteNode);
+        node->set_next_edges(torch::autograd::collect_next_edges(expr, rotation, neck, jaw, eyes, translation));
+        node->plan = plan;
+        for (int i = 0; i < 6; ++i) {
+            node->tabs[i] = Kept(*tabs[i]);
+            node->widths[i] = widths[i];
+        }
+        node->verts = Kept(verts, true);
+        node->v_shaped = Kept(v_shaped, true);
+        node->ws = ws;
+        node->t = t;
+        node->T = T;
+        torch::autograd::set_history({verts, v_shaped, center, R, scale, quat}, node);
+    }
+    return {verts, v_shaped, center, R, scale, quat};
+}
+
+// ======================================================================================================================================
+// 2. the rasterizer's bound / leaves entry
+// ======================================================================================================================================
+struct Layouts {
+    GsrGeomLayout geom;
+    GsrImageLayout img;
+};
+std::mutex layout_mutex;
+std::map<std::tuple<int64_t, int, int>, Layouts> layout_cache;
+std::map<std::tuple<int64_t, int, int, int64_t, int>, GsrBinningLayout> binning_cache;
+
+const Layouts& layouts(int64_t P, int W, int H)
+{
+    std::lock_guard<std::mutex> lock(layout_mutex);
+    auto key = std::make_tuple(P, W, H);
+    auto it = layout_cache.find(key);
+    if (it == layout_cache.end()) {
+        if (layout_cache.size() > 64) layout_cache.clear();
+        Layouts l{};
+        TORCH_CHECK(api.gsr_geom_layout((int32_t)P, &l.geom) == 0 && api.gsr_image_layout(W, H, &l.img) == 0, "gsr layout: ", api.gsr_last_error());
+        it = layout_cache.emplace(key, l).first;
+    }
+    return it->second;
+}
+const GsrBinningLayout& binning_layout(int64_t cap, int W, int H, int64_t P, int mode)
+{
+    std::lock_guard<std::mutex> lock(layout_mutex);
+    auto key = std::make_tuple(cap, W, H, P, mode);
+    auto it = binning_cache.find(key);
+    if (it == binning_cache.end()) {
+        if (binning_cache.size() > 64) binning_cache.clear();
+        GsrBinningLayout b{};
+        TORCH_CHECK(api.gsr_binning_layout(cap, W, H, (int32_t)P, mode, &b) == 0, "gsr_binning_layout: ", api.gsr_last_error());
+        it = binning_cache.emplace(key, b).first;
+    }
+    return it->second;
+}
+
+struct RasterNode : public Node {
+    GsrSettings s{};
+    Tensor bg, viewmatrix, projmatrix, campos;          // what the settings point at
+    Kept xyz, dc, rest, opacity, scaling, rotation;     // the model's leaves
+    Kept fR, fs, fc, fq;                                // the per-face frames (undefined for an unbound model)
+    Tensor binding, csr_slot, face_begin;               // static per densification step
+    int binding_i64 = 0;
+    Tensor radii, state;                                // state: geom | img | binning in ONE allocation
+    size_t off_img = 0, off_binning = 0;
+    int64_t P = 0, M = 0, F = 0, capacity = 0, num_rendered = 0;
+    bool bound = false;
+
+    variable_list apply(variable_list&& grads) override
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        need_api();
+        variable_list out(11);
+        if (grads.empty() || !grads[0].defined()) return out;
+        TORCH_CHECK(state.defined(), "the rasterizer state of this frame has been released (backward through the graph a second time without retain_graph)");
+        const Tensor& x = xyz.get("_xyz");
+        DeviceGuard guard(x.device().index());
+        void* stream = cur_stream(x);
+        Tensor g = grad_f32(grads[0]);
+        TORCH_CHECK(g.is_cuda() && g.numel() == 3 * (int64_t)s.image_height * s.image_width, "grad_out_color must be a (3,H,W) device tensor");
+        Tensor g_xyz = empty_f32({P, 3}, x), g_m2 = empty_f32({P, 3}, x), g_dc = empty_f32({P, 1, 3}, x), g_rest = empty_f32({P, M - 1, 3}, x);
+        Tensor g_op = empty_f32({P, 1}, x), g_ls = empty_f32({P, 3}, x), g_rot = empty_f32({P, 4}, x);
+        GsrBound b{};
+        Tensor scratch, d_face;
+        if (!bound) {
+            scratch = empty_f32({9 * P}, x);
+        } else {
+            const int64_t rows_at = (9 * P + 3) / 4 * 4;   // the CSR rows are read and written as float4: 16-byte aligned whatever P is
+            scratch = empty_f32({rows_at + (int64_t)GAB_BIND_ROW_FLOATS * P}, x);
+            d_face = empty_f32({17 * F}, x);                // four contiguous blocks: center | orien_mat | scaling | orien_quat
+            b.binding = binding.data_ptr();
+            b.binding_is_i64 = binding_i64;
+            b.F = (int32_t)F;
+            b.face_R = fR.get("face_orien_mat").data_ptr<float>();
+            b.face_scale = fs.get("face_scaling").data_ptr<float>();
+            b.face_center = fc.get("face_center").data_ptr<float>();
+            b.face_quat = fq.get("face_orien_quat").data_ptr<float>();
+            b.slot = csr_slot.data_ptr<int32_t>();
+            b.rows = scratch.data_ptr<float>() + rows_at;
+        }
+        GsrSettings sb = s;
+        sb.forward_only = 0;
+        sb.deferred_count = 0;
+        uint8_t* st = state.data_ptr<uint8_t>();
+        int rc = api.gsr_backward_bound(&sb, (int32_t)P, (int32_t)M, &b, x.data_ptr<float>(), dc.get("_features_dc").data_ptr<float>(), rest.get("_features_rest").data_ptr<float>(),
+                                        opacity.get("_opacity").data_ptr<float>(), scaling.get("_scaling").data_ptr<float>(), rotation.get("_rotation").data_ptr<float>(),
+                                        radii.data_ptr<int32_t>(), st, st + off_binning, capacity, st + off_img, num_rendered, g.data_ptr<float>(), g_xyz.data_ptr<float>(),
+                                        g_m2.data_ptr<float>(), g_dc.data_ptr<float>(), g_rest.data_ptr<float>(), g_op.data_ptr<float>(), g_ls.data_ptr<float>(),
+                                        g_rot.data_ptr<float>(), scratch.data_ptr<float>(), stream);
+        TORCH_CHECK(rc == 0, "gsr_backward_bound failed (", rc, "): ", api.gsr_last_error());
+        if (bound) {
+            rc = api.gab_bind_backward_faces((int32_t)F, face_begin.data_ptr<int32_t>(), b.rows, d_face.data_ptr<float>(), stream);
+            TORCH_CHECK(rc == 0, "gab_bind_backward_faces failed (", rc, "): ", api.gab_last_error());
+        }
+        // inputs: xyz, means2D, dc, rest, opacity, scaling, rotation, face_R, face_scale, face_center, face_quat
+        out[0] = g_xyz, out[1] = g_m2, out[2] = g_dc, out[3] = g_rest, out[4] = g_op, out[5] = g_ls, out[6] = g_rot;
+        if (bound) {
+            if (task_should_compute_output(7)) out[7] = d_face.as_strided({F, 3, 3}, {9, 3, 1}, 3 * F);
+            if (task_should_compute_output(8)) out[8] = d_face.as_strided({F, 1}, {1, 1}, 12 * F);
+            if (task_should_compute_output(9)) out[9] = d_face.as_strided({F, 3}, {3, 1}, 0);
+            if (task_should_compute_output(10)) out[10] = d_face.as_strided({F, 4}, {4, 1}, 13 * F);
+        }
+        for (int i = 0; i < 7; ++i)
+            if (!task_should_compute_output(i)) out[i] = Tensor();
+        return out;
+    }
+    void release_variables() override
+    {   // as torch's saved tensors: the (large) per-frame state goes with the first backward unless the graph is retained
+        std::lock_guard<std::mutex> lock(mutex_);
+        state = Tensor();
+    }
+};
+
+struct RasterResult {
+    Tensor color, radii, visible, state;
+    int64_t num_rendered = 0, capacity = 0, off_binning = 0;
+    int forward_only = 0, path = 0, nbands = 0, fitted = 1;
+};
+
+// One frame through gsr_forward_bound.  late_slot >= 0: the deferred form of the call (the count goes to that persistent slot) and the wait
+// for it AFTER the node has been built (rasterizer._apply_late's order); late_slot < 0: the blocking form.  result.fitted == 0: the frame
+// needs `num_rendered` instances but the binning buffer held `capacity` -- nothing was rendered, the caller raises its hint and calls again.
+RasterResult rasterize_bound(const Tensor& xyz, const Tensor& means2D, const Tensor& dc, const Tensor& rest, const Tensor& opacity, const Tensor& scaling,
+                             const Tensor& rotation, const c10::optional<Tensor>& face_R, const c10::optional<Tensor>& face_scale,
+                             const c10::optional<Tensor>& face_center, const c10::optional<Tensor>& face_quat, const c10::optional<Tensor>& binding,
+                             const c10::optional<Tensor>& csr_slot, const c10::optional<Tensor>& face_begin, const Tensor& bg, const Tensor& viewmatrix,
+                             const Tensor& projmatrix, const Tensor& campos, int64_t H, int64_t W, double tanfovx, double tanfovy, double scale_modifier,
+                             int64_t sh_degree, int64_t debug, int64_t tile_culling, int64_t exact_scale_grad, int64_t deterministic, int64_t fast_blend,
+                             int64_t capacity, int64_t late_slot)
+{
+    need_api();
+    check_f32(xyz, "_xyz"), check_f32(dc, "_features_dc"), check_f32(rest, "_features_rest"), check_f32(opacity, "_opacity");
+    check_f32(scaling, "_scaling"), check_f32(rotation, "_rotation");
+    check_f32(bg, "bg"), check_f32(viewmatrix, "viewmatrix"), check_f32(projmatrix, "projmatrix"), check_f32(campos, "campos");
+    const int64_t P = xyz.size(0);
+    TORCH_CHECK(P > 0 && xyz.dim() == 2 && xyz.size(1) == 3, "_xyz must be (P,3) with P > 0");
+    TORCH_CHECK(rest.dim() == 3 && rest.size(0) == P && rest.size(1) >= 1 && dc.numel() == 3 * P, "split SH: _features_dc must be (P,1,3) and _features_rest (P,M-1,3)");
+    const int64_t M = 1 + rest.size(1);
+    const bool bound = binding.has_value() && binding->defined();
+    GsrBound b{};
+    int64_t F = 0;
+    if (bound) {
+        TORCH_CHECK(face_R && face_scale && face_center && face_quat && csr_slot && face_begin, "the bound rasterizer needs the four face-frame tensors and the binding's CSR");
+        check_f32(*face_R, "face_orien_mat"), check_f32(*face_scale, "face_scaling"), check_f32(*face_center, "face_center"), check_f32(*face_quat, "face_orien_quat");
+        F = face_center->size(0);
+        TORCH_CHECK((binding->scalar_type() == at::kInt || binding->scalar_type() == at::kLong) && binding->is_contiguous() && binding->numel() == P,
+                    "binding must be a contiguous int32 / int64 tensor with one face per splat");
+        TORCH_CHECK(face_begin->numel() == F + 1 && csr_slot->numel() == P && face_begin->scalar_type() == at::kInt && csr_slot->scalar_type() == at::kInt,
+                    "the bound rasterizer needs the binding's per-face CSR (binding.binding_csr) for this binding and mesh");
+        b.binding = binding->data_ptr();
+        b.binding_is_i64 = binding->scalar_type() == at::kLong;
+        b.F = (int32_t)F;
+        b.face_R = face_R->data_ptr<float>(), b.face_scale = face_scale->data_ptr<float>();
+        b.face_center = face_center->data_ptr<float>(), b.face_quat = face_quat->data_ptr<float>();
+    }
+    const Tensor undefined;
+    const Tensor& tR = bound ? *face_R : undefined;
+    const Tensor& ts = bound ? *face_scale : undefined;
+    const Tensor& tc = bound ? *face_center : undefined;
+    const Tensor& tq = bound ? *face_quat : undefined;
+    // whether a backward can follow is the caller's grad mode and its inputs (render.py / fps_benchmark_*.py render nn.Parameters under no_grad)
+    const bool needs = any_requires_grad({xyz, means2D, dc, rest, opacity, scaling, rotation, tR, ts, tc, tq});
+
+    GsrSettings s{};
+    s.image_height = (int32_t)H, s.image_width = (int32_t)W;
+    s.tanfovx = (float)tanfovx, s.tanfovy = (float)tanfovy, s.scale_modifier = (float)scale_modifier;
+    s.bg = bg.data_ptr<float>(), s.viewmatrix = viewmatrix.data_ptr<float>(), s.projmatrix = projmatrix.data_ptr<float>(), s.campos = campos.data_ptr<float>();
+    s.sh_degree = (int32_t)sh_degree, s.prefiltered = 0, s.debug = (int32_t)debug;
+    s.tile_culling = (int32_t)tile_culling, s.exact_scale_grad = (int32_t)exact_scale_grad, s.deterministic = (int32_t)deterministic, s.fast_blend = (int32_t)fast_blend;
+    s.forward_only = needs ? 0 : 1;
+    s.deferred_count = late_slot >= 0 ? (int32_t)late_slot + 1 : 0;
+
+    DeviceGuard guard(xyz.device().index());
+    void* stream = cur_stream(xyz);
+    const Layouts& L = layouts(P, (int)W, (int)H);
+    const GsrBinningLayout& bl = binning_layout(capacity, (int)W, (int)H, P, (int)tile_culling);
+    auto up = [](size_t n) { return (n + 255) / 256 * 256; };
+    const size_t off_img = up(L.geom.total), off_binning = off_img + up(L.img.total), total = off_binning + up(bl.total);
+    RasterResult r;
+    r.state = at::empty({(int64_t)total}, xyz.options().dtype(at::kByte));
+    r.color = empty_f32({3, H, W}, xyz);
+    r.radii = at::empty({P}, xyz.options().dtype(at::kInt));
+    uint8_t* st = r.state.data_ptr<uint8_t>();
+    int64_t n_host = 0;
+    int rc = api.gsr_forward_bound(&s, (int32_t)P, (int32_t)M, &b, xyz.data_ptr<float>(), dc.data_ptr<float>(), rest.data_ptr<float>(), opacity.data_ptr<float>(),
+                                   scaling.data_ptr<float>(), rotation.data_ptr<float>(), r.color.data_ptr<float>(), r.radii.data_ptr<int32_t>(), st, st + off_binning,
+                                   capacity, st + off_img, &n_host, stream);
+    r.capacity = capacity, r.off_binning = (int64_t)off_binning, r.forward_only = s.forward_only, r.path = (int)bl.path, r.nbands = (int)bl.nbands;
+    if (rc == GSR_E_CAPACITY) {
+        r.fitted = 0, r.num_rendered = n_host;
+        return r;
+    }
+    TORCH_CHECK(rc == GSR_OK, "gsr_forward_bound failed (", rc, "): ", api.gsr_last_error());
+    const int64_t seq = late_slot >= 0 ? api.gsr_last_forward_seq() : 0;
+    // render()'s visibility_filter (radii > 0) as the forward wrote it: a bool tensor over the state's `visible` bytes, no comparison launch
+    r.visible = at::empty({0}, xyz.options().dtype(at::kBool)).set_(r.state.storage(), (int64_t)L.geom.visible, {P}, {1});
+    if (needs) {
+        auto node = std::shared_ptr<RasterNode>(new RasterNode(), torch::autograd::deleteNode);
+        node->set_next_edges(torch::autograd::collect_next_edges(xyz, means2D, dc, rest, opacity, scaling, rotation, tR, ts, tc, tq));
+        node->s = s;
+        node->bg = bg, node->viewmatrix = viewmatrix, node->projmatrix = projmatrix, node->campos = campos;
+        node->xyz = Kept(xyz), node->dc = Kept(dc), node->rest = Kept(rest), node->opacity = Kept(opacity), node->scaling = Kept(scaling), node->rotation = Kept(rotation);
+        if (bound) {
+            node->fR = Kept(tR), node->fs = Kept(ts), node->fc = Kept(tc), node->fq = Kept(tq);
+            node->binding = *binding, node->csr_slot = *csr_slot, node->face_begin = *face_begin;
+            node->binding_i64 = b.binding_is_i64;
+        }
+        node->radii = r.radii, node->state = r.state;
+        node->off_img = off_img, node->off_binning = off_binning;
+        node->P = P, node->M = M, node->F = F, node->capacity = capacity, node->bound = bound;
+        node->num_rendered = late_slot >= 0 ? capacity : n_host;   // deferred form: the backward takes the capacity as the bound (include/gsr.h)
+        torch::autograd::set_history(r.color, node);
+    }
+    if (late_slot >= 0) {   // the count, awaited behind the call's own host work
+        int64_t n = 0;
+        rc = api.gsr_count_slot_wait((int32_t)late_slot, seq, stream, &n);
+        TORCH_CHECK(rc == GSR_OK, "gsr_count_slot_wait failed (", rc, "): ", api.gsr_last_error());
+        r.num_rendered = n;
+        if (n > capacity) {
+            api.gsr_count_slot_overflow((int32_t)late_slot, nullptr, 1);   // (the device left its sticky mark: this slot's only reader is this function)
+            r.fitted = 0;
+        }
+    } else {
+        r.num_rendered = n_host;
+    }
+    return r;
+}
+
+// ======================================================================================================================================
+// 3. losses
+// ======================================================================================================================================
+Tensor g_unit_seed;            // loss.install_backward_seed's cached constant 1 (set_unit_seed)
+uint32_t g_unit_seed_version = 0;
+std::atomic<int> g_l1_emit{1}, g_l1_misses{0};
+
+void set_unit_seed(const c10::optional<Tensor>& seed)
+{
+    g_unit_seed = seed.has_value() ? *seed : Tensor();
+    g_unit_seed_version = g_unit_seed.defined() ? g_unit_seed._version() : 0;
+    g_l1_emit = 1, g_l1_misses = 0;
+}
+inline bool is_unit_seed(const Tensor& g)
+{
+    return g_unit_seed.defined() && g.defined() && g.dim() == 0 && g.data_ptr() == g_unit_seed.data_ptr() && g_unit_seed._version() == g_unit_seed_version;
+}
+int64_t l1_emit_state() { return g_l1_emit.load(); }
+
+struct L1Node : public Node {
+    Kept a, b;
+    Tensor da;       // sign(a - b) / n written by the forward (gls_l1_forward_grad), handed out at most once
+    double scale = 0;
+    variable_list apply(variable_list&& grads) override
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        need_api();
+        variable_list out(2);
+        if (grads.empty() || !grads[0].defined()) return out;
+        Tensor pre = da;
+        da = Tensor();
+        if (pre.defined()) {
+            if (is_unit_seed(grads[0])) {
+                g_l1_misses = 0;
+                out[0] = pre;      // upstream gradient is the constant 1: the image the forward left behind, no launch
+                return out;
+            }
+            if (++g_l1_misses >= 2) g_l1_emit = 0;   // train.py combines L1 with other terms: the precomputed image is dead weight (loss._L1_EMIT)
+        }
+        const Tensor& x = a.get("network_output");
+        const Tensor& y = b.get("gt");
+        DeviceGuard guard(x.device().index());
+        void* stream = cur_stream(x);
+        Tensor g = grad_f32(grads[0]);
+        const int64_t n = x.numel();
+        if (task_should_compute_output(0)) {
+            out[0] = at::empty_like(x);
+            int rc = api.gls_l1_backward(n, x.data_ptr<float>(), y.data_ptr<float>(), g.data_ptr<float>(), (float)scale, out[0].data_ptr<float>(), stream);
+            TORCH_CHECK(rc == 0, "gls_l1_backward failed (", rc, "): ", api.gls_last_error());
+        }
+        if (task_should_compute_output(1)) {
+            out[1] = at::empty_like(y);
+            int rc = api.gls_l1_backward(n, y.data_ptr<float>(), x.data_ptr<float>(), g.data_ptr<float>(), (float)scale, out[1].data_ptr<float>(), stream);
+            TORCH_CHECK(rc == 0, "gls_l1_backward failed (", rc, "): ", api.gls_last_error());
+        }
+        return out;
+    }
+    void release_variables() override
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        da = Tensor();
+    }
+};
+
+// utils/loss_utils.py:17-18.  emit: -1 the sticky heuristic (loss._L1_EMIT), 0 / 1 forced; seeded: install_backward_seed is active
+Tensor l1_loss(const Tensor& a, const Tensor& b, int64_t emit, bool seeded)
+{
+    need_api();
+    check_f32(a, "network_output"), check_f32(b, "gt");
+    TORCH_CHECK(a.numel() == b.numel(), "l1_loss: the two images differ in size");
+    DeviceGuard guard(a.device().index());
+    void* stream = cur_stream(a);
+    const int64_t n = a.numel();
+    const double scale = 1.0 / (double)std::max<int64_t>(n, 1);
+    Tensor out = empty_f32({}, a), partial = empty_f32({api.gls_partial_floats(1, 1, 1, 1)}, a);
+    const bool ga = at::GradMode::is_enabled() && a.requires_grad(), gb = at::GradMode::is_enabled() && b.requires_grad();
+    Tensor da;
+    const bool want = emit < 0 ? g_l1_emit.load() != 0 : emit != 0;
+    if (ga && !gb && seeded && want) {
+        da = at::empty_like(a);
+        int rc = api.gls_l1_forward_grad(n, a.data_ptr<float>(), b.data_ptr<float>(), (float)scale, out.data_ptr<float>(), partial.data_ptr<float>(), da.data_ptr<float>(), stream);
+        TORCH_CHECK(rc == 0, "gls_l1_forward_grad failed (", rc, "): ", api.gls_last_error());
+    } else {
+        int rc = api.gls_l1_forward(n, a.data_ptr<float>(), b.data_ptr<float>(), (float)scale, out.data_ptr<float>(), partial.data_ptr<float>(), stream);
+        TORCH_CHECK(rc == 0, "gls_l1_forward failed (", rc, "): ", api.gls_last_error());
+    }
+    if (ga || gb) {
+        auto node = std::shared_ptr<L1Node>(new L1Node(), torch::autograd::deleteNode);
+        node->set_next_edges(torch::autograd::collect_next_edges(a, b));
+        node->a = Kept(a), node->b = Kept(b), node->da = da, node->scale = scale;
+        torch::autograd::set_history(out, node);
+    }
+    return out;
+}
+
+struct L1SsimNode : public Node {
+    Kept img1, img2;
+    Tensor maps;
+    int C = 0, H = 0, W = 0;
+    double scale = 0;
+    variable_list apply(variable_list&& grads) override
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        need_api();
+        variable_list out(2);
+        if (grads.size() != 2 || (!grads[0].defined() && !grads[1].defined())) return out;
+        TORCH_CHECK(maps.defined(), "the SSIM derivative planes of this frame have been released (backward through the graph a second time without retain_graph)");
+        const Tensor& x = img1.get("img1");
+        const Tensor& y = img2.get("img2");
+        DeviceGuard guard(x.device().index());
+        void* stream = cur_stream(x);
+        Tensor g1 = grad_f32(grads[0]), g2 = grad_f32(grads[1]);
+        out[0] = at::empty_like(x);
+        int rc = api.gls_l1_ssim_backward_split(1, C, H, W, x.data_ptr<float>(), y.data_ptr<float>(), maps.data_ptr<float>(), fptr(g1), fptr(g2), 0, (float)scale,
+                                                out[0].data_ptr<float>(), stream);
+        TORCH_CHECK(rc == 0, "gls_l1_ssim_backward_split failed (", rc, "): ", api.gls_last_error());
+        return out;
+    }
+    void release_variables() override
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        maps = Tensor();
+    }
+};
+
+// -> (l1, ssim) of ONE image pair (C,H,W) from one pass (train.py:131-132); the second image is data (no gradient): anything else takes loss._L1Ssim
+std::vector<Tensor> l1_ssim(const Tensor& img1, const Tensor& img2)
+{
+    need_api();
+    check_f32(img1, "image"), check_f32(img2, "gt");
+    TORCH_CHECK(img1.dim() == 3 && img1.sizes() == img2.sizes(), "the native l1_ssim takes one (C,H,W) pair");
+    TORCH_CHECK(!(at::GradMode::is_enabled() && img2.requires_grad()), "the native l1_ssim has no gradient for the second image");
+    const int C = (int)img1.size(0), H = (int)img1.size(1), W = (int)img1.size(2);
+    DeviceGuard guard(img1.device().index());
+    void* stream = cur_stream(img1);
+    const bool need = at::GradMode::is_enabled() && img1.requires_grad();
+    const double scale = 1.0 / ((double)C * H * W);
+    Tensor sums = empty_f32({2}, img1), partial = empty_f32({api.gls_partial_floats(1, C, H, W)}, img1);
+    Tensor maps = need ? empty_f32({3, 1, C, H, W}, img1) : Tensor();
+    int rc = api.gls_l1_ssim_forward(1, C, H, W, img1.data_ptr<float>(), img2.data_ptr<float>(), (float)scale, sums.data_ptr<float>(), fptr_mut(maps), partial.data_ptr<float>(), stream);
+    TORCH_CHECK(rc == 0, "gls_l1_ssim_forward failed (", rc, "): ", api.gls_last_error());
+    // the two scalars themselves, as fresh 0-dim tensors over the (2,) result: nothing between the caller's loss arithmetic and the backward kernel
+    Tensor l1 = at::empty({0}, sums.options()).set_(sums.storage(), 0, {}, {});
+    Tensor ss = at::empty({0}, sums.options()).set_(sums.storage(), 1, {}, {});
+    if (need) {
+        auto node = std::shared_ptr<L1SsimNode>(new L1SsimNode(), torch::autograd::deleteNode);
+        node->set_next_edges(torch::autograd::collect_next_edges(img1, img2));
+        node->img1 = Kept(img1), node->img2 = Kept(img2), node->maps = maps;
+        node->C = C, node->H = H, node->W = W, node->scale = scale;
+        torch::autograd::set_history({l1, ss}, node);
+    }
+    return {l1, ss};
+}
+
+std::shared_ptr<MeshPlan> make_mesh_plan(const Tensor& v_template, const Tensor& shapedirs, const Tensor& posedirs, const Tensor& J_regressor, const Tensor& lbs_weights,
+                                         std::vector<int64_t> parents, int64_t n_shape, const Tensor& prepared, const Tensor& faces, const Tensor& vf_begin,
+                                         const Tensor& vf_list)
+{
+    auto p = std::make_shared<MeshPlan>();
+    const Tensor* rig[5] = {&v_template, &shapedirs, &posedirs, &J_regressor, &lbs_weights};
+    static const char* names[5] = {"v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights"};
+    for (int i = 0; i < 5; ++i) {
+        check_f32(*rig[i], names[i]);
+        p->keep[i] = *rig[i];
+    }
+    check_f32(prepared, "prepared rig");
+    TORCH_CHECK(parents.size() == GAB_NUM_JOINTS, "the fused FLAME kernels are built for the 5-joint FLAME skeleton");
+    p->rig.V = (int32_t)v_template.size(0);
+    p->rig.n_shape = (int32_t)n_shape;
+    p->rig.n_expr = (int32_t)(shapedirs.size(2) - n_shape);
+    p->rig.v_template = v_template.data_ptr<float>(), p->rig.shapedirs = shapedirs.data_ptr<float>(), p->rig.posedirs = posedirs.data_ptr<float>();
+    p->rig.J_regressor = J_regressor.data_ptr<float>(), p->rig.lbs_weights = lbs_weights.data_ptr<float>();
+    for (int j = 0; j < GAB_NUM_JOINTS; ++j) p->rig.parents[j] = (int32_t)parents[j];
+    p->prepared = prepared;
+    TORCH_CHECK(faces.is_cuda() && faces.is_contiguous() && faces.dim() == 2 && faces.size(1) == 3 && (faces.scalar_type() == at::kInt || faces.scalar_type() == at::kLong),
+                "faces must be a contiguous (F,3) int32 / int64 device tensor");
+    TORCH_CHECK(faces.device() == prepared.device(), "select_mesh_by_timestep: faces live on ", faces.device(), ", the vertices on ", prepared.device());
+    p->faces = faces, p->faces_i64 = faces.scalar_type() == at::kLong, p->F = faces.size(0);
+    TORCH_CHECK(vf_begin.scalar_type() == at::kInt && vf_list.scalar_type() == at::kInt && vf_begin.is_contiguous() && vf_list.is_contiguous() && vf_begin.numel() == p->rig.V + 1 &&
+                    vf_list.numel() == 12 * p->F,
+                "vertex -> corner table does not match this topology");
+    p->vf_begin = vf_begin, p->vf_list = vf_list;
+    return p;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    m.doc() = "compiled host side of gaussianavatars_amd's autograd nodes (include/gsr.h, gab.h, gls.h underneath)";
+    m.def("init", &init, "resolve the C ABI from the three loaded libraries");
+    py::class_<MeshPlan, std::shared_ptr<MeshPlan>>(m, "MeshPlan");
+    m.def("make_mesh_plan", &make_mesh_plan);
+    m.def("mesh_frames", &mesh_frames);
+    py::class_<RasterResult>(m, "RasterResult")
+        .def_readonly("color", &RasterResult::color)
+        .def_readonly("radii", &RasterResult::radii)
+        .def_readonly("visible", &RasterResult::visible)
+        .def_readonly("state", &RasterResult::state)
+        .def_readonly("num_rendered", &RasterResult::num_rendered)
+        .def_readonly("capacity", &RasterResult::capacity)
+        .def_readonly("off_binning", &RasterResult::off_binning)
+        .def_readonly("forward_only", &RasterResult::forward_only)
+        .def_readonly("path", &RasterResult::path)
+        .def_readonly("nbands", &RasterResult::nbands)
+        .def_readonly("fitted", &RasterResult::fitted);
+    m.def("rasterize_bound", &rasterize_bound);
+    m.def("set_unit_seed", &set_unit_seed);
+    m.def("l1_emit_state", &l1_emit_state);
+    m.def("l1_loss", &l1_loss);
+    m.def("l1_ssim", &l1_ssim);
+    m.attr("GSR_ABI") = GSR_ABI_VERSION;
+    m.attr("GAB_ABI") = GAB_ABI_VERSION;
+    m.attr("GLS_ABI") = GLS_ABI_VERSION;
+}

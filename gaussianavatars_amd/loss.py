@@ -54,6 +54,8 @@ def install_backward_seed(enable: bool = True) -> bool:
     if not enable:
         if wrapped:
             torch.Tensor.backward = cur.__wrapped__
+            _UNIT_SEEDS.clear()
+            _tell_host_seed(None)
         return bool(wrapped)
     if wrapped:
         return False
@@ -71,6 +73,8 @@ def install_backward_seed(enable: bool = True) -> bool:
                 # (never created under stream capture: the tensor would live in that graph's private pool)
                 gradient = _UNIT_SEEDS[key] = torch.ones((), dtype=self.dtype, device=self.device)
                 _SEED_VERSIONS[key] = gradient._version
+                if self.dtype is torch.float32:
+                    _tell_host_seed(gradient)
         return orig(self, gradient, retain_graph, create_graph, inputs=inputs)
 
     backward.__gaussianavatars_amd_seed__ = True
@@ -78,6 +82,14 @@ def install_backward_seed(enable: bool = True) -> bool:
     backward.__doc__ = orig.__doc__
     torch.Tensor.backward = backward
     return True
+
+
+def _tell_host_seed(seed) -> None:
+    """The compiled host's L1 node recognises the unit seed by its storage, like _is_unit_seed below (csrc/gaa_host.cpp: set_unit_seed)."""
+    from . import _host
+
+    if _host.enabled() and (seed is not None or _host._mod is not None):
+        _host.get().set_unit_seed(seed)
 
 
 def _as_input(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -167,7 +179,15 @@ def _batched(img1, img2):
 def l1_ssim(image: torch.Tensor, gt: torch.Tensor):
     """-> (l1, ssim): the two scalars train.py:131-132 combines, from ONE pass over (image, gt).
     l1 == l1_loss(image, gt), ssim == ssim(image, gt) (size_average=True)."""
-    a, b = _batched(_as_input(image, "image"), _as_input(gt, "gt"))
+    image, gt = _as_input(image, "image"), _as_input(gt, "gt")
+    if image.dim() == 3 and image.shape == gt.shape and not (gt.requires_grad and torch.is_grad_enabled()):
+        from . import _host
+
+        H = _host.get()
+        if H is not None:   # the compiled host's node (csrc/gaa_host.cpp: l1_ssim): same two launches, no interpreter in the backward
+            l1, ss = H.l1_ssim(image, gt)
+            return l1, ss
+    a, b = _batched(image, gt)
     l1, ss = _L1Ssim.apply(a, b)
     if l1.dim() == 0:
         return l1, ss
@@ -261,7 +281,16 @@ def l1_loss(network_output: torch.Tensor, gt: torch.Tensor):
     """utils/loss_utils.py:17-18: mean |network_output - gt| (2 launches forward; backward 1, or none when seeded with the unit seed)."""
     if network_output.shape != gt.shape:
         gt = gt.expand_as(network_output)
-    return _L1.apply(_as_input(network_output, "network_output"), _as_input(gt, "gt"))
+    a, b = _as_input(network_output, "network_output"), _as_input(gt, "gt")
+    from . import _host
+
+    H = _host.get()
+    if H is not None:   # the compiled host's node (csrc/gaa_host.cpp: l1_loss)
+        import os
+
+        forced = os.environ.get("GAA_L1_EMIT_GRAD")
+        return H.l1_loss(a, b, -1 if forced is None else int(forced != "0"), bool(getattr(torch.Tensor.backward, "__gaussianavatars_amd_seed__", False)))
+    return _L1.apply(a, b)
 
 
 # ---- the reference's two calls, zero-edit (train.py:131-132) ---------------------------------------------------------------------------------

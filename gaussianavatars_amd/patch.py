@@ -91,11 +91,19 @@ def bound(self):
     return cache.out
 
 
+def _leaves_complete(self) -> bool:
+    """The four leaves the one-launch bind reads all hold N rows.  Not so in the middle of GaussianModel.create_from_pcd
+    (scene/gaussian_model.py:185-206 reads `self.get_xyz.shape[0]` after setting `_xyz` and before `_scaling` / `_rotation` / `_opacity` exist):
+    such a call takes the reference's own per-accessor code, once, at initialisation."""
+    n = self._xyz.shape[0]
+    return n > 0 and self._scaling.shape[0] == n and self._rotation.shape[0] == n and self._opacity.shape[0] == n
+
+
 def _make_accessor(cls, name: str, index: int, mesh_attr: str):
     orig = _ORIG[(cls, name)]
 
     def getter(self):
-        if self.binding is None or not _fused(self):
+        if self.binding is None or not _fused(self) or not _leaves_complete(self):
             return orig.fget(self)
         if getattr(self, mesh_attr) is None:          # same lazy initialisation as the reference (:119-120,131-132,146-147)
             self.select_mesh_by_timestep(0)
@@ -110,7 +118,7 @@ def _make_opacity(cls):
     orig = _ORIG[(cls, "get_opacity")]
 
     def get_opacity(self):
-        if self.binding is None or not _fused(self) or self.face_center is None:
+        if self.binding is None or not _fused(self) or self.face_center is None or not _leaves_complete(self):
             return orig.fget(self)
         return bound(self)[3]   # sigmoid(_opacity) rides in the bind kernel (same values, one launch fewer)
 

@@ -152,6 +152,8 @@ def last_forward_info() -> dict:
     (sum of tiles_touched; equal to num_rendered without tile culling) -- read back from the device on request."""
     info = dict(_last_info)
     b = _last_binning[0]
+    if isinstance(b, tuple):   # (state allocation, byte offset of the binning buffer inside it): the compiled host's frame, sliced on request
+        b = b[0][b[1]:]
     if b is not None:
         info["rect_instances"] = int(b[8:16].view(torch.int64).item())
         if info.get("production_binning"):   # header of the production path (csrc/gsr_device.h: BinHeader)
@@ -258,7 +260,87 @@ def _finish_late(pend) -> bool:
     return True
 
 
+def _is_plain(t) -> bool:
+    return t.is_cuda and t.dtype is torch.float32 and t.is_contiguous()
+
+
+_camera_copies: dict = {}   # id(tensor) -> (the tensor, its version, a contiguous fp32 copy)
+
+
+def _camera_tensor(t):
+    """A contiguous fp32 device tensor with `t`'s values, or None (a host tensor: not this entry's case).  fps_benchmark_demo.py:30-31 and scene/cameras.py:44-46
+    hand the rasterizer TRANSPOSED VIEWS (`.T`, `.transpose(0, 1)`) that live as long as the camera: copying them in every frame is a launch per matrix, so the copy
+    is made once per (object, version) and kept beside the camera's tensor."""
+    if t.is_cuda and t.dtype is torch.float32 and t.is_contiguous():
+        return t
+    if not t.is_cuda:
+        return None
+    hit = _camera_copies.get(id(t))
+    if hit is not None and hit[0] is t and hit[1] == t._version:
+        return hit[2]
+    if len(_camera_copies) > 256:
+        _camera_copies.clear()
+    c = t.detach().to(torch.float32).contiguous()
+    _camera_copies[id(t)] = (t, t._version, c)
+    return c
+
+
+def _native_leaves_entry(H, xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, face_R, face_scale, face_center, face_quat, binding, csr, rs):
+    """The same frame through the COMPILED host (csrc/gaa_host.cpp: rasterize_bound): layouts, ONE state allocation (geom | img | binning),
+    gsr_forward_bound in its deferred form, the autograd node, and the late count wait, in one native call; the backward runs on autograd's
+    device thread without the interpreter.  The capacity bookkeeping stays here (shared with the Python twin: one running estimate per path).
+    Returns None when the call is outside what the native entry takes (the caller then uses _RasterizeBound)."""
+    if not (_is_plain(xyz) and _is_plain(sh_dc) and _is_plain(sh_rest) and _is_plain(opacity_logit) and _is_plain(log_scaling) and _is_plain(rotation)):
+        return None
+    P = xyz.shape[0]
+    if P == 0 or sh_rest.dim() != 3 or sh_rest.shape[1] < 1 or rs.debug:
+        return None
+    bg, vm, pm, cp = _camera_tensor(rs.bg), _camera_tensor(rs.viewmatrix), _camera_tensor(rs.projmatrix), _camera_tensor(rs.campos)
+    if bg is None or vm is None or pm is None or cp is None:
+        return None
+    if binding is not None:
+        if not (_is_plain(face_R) and _is_plain(face_scale) and _is_plain(face_center) and _is_plain(face_quat)) or csr is None:
+            return None
+        face_begin, slot = csr[1], csr[3]
+    else:
+        face_begin = slot = None
+    dev = xyz.device
+    Hh, Ww = int(rs.image_height), int(rs.image_width)
+    lib = _lib.gsr()
+    tc = int(_tile_culling)
+    prod = _binning_layout(lib, 0, Ww, Hh, P, tc).path == 1
+    key = (dev.index, Hh, Ww, prod)
+    late = _late_slot(dev, _lib.raw_stream(dev))
+    replays = 0
+    while True:
+        cap = _capacity_hint.get(key) or _round_cap((24 if prod else 8) * P)
+        r = H.rasterize_bound(xyz, means2D, sh_dc, sh_rest, opacity_logit, log_scaling, rotation, face_R, face_scale, face_center, face_quat, binding, slot, face_begin,
+                              bg, vm, pm, cp, Hh, Ww, float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree), 0, tc,
+                              int(_exact_scale_grad), int(_deterministic), int(_fast_blend), cap, late)
+        I = r.num_rendered
+        if r.fitted:
+            break
+        _capacity_hint[key] = _round_cap(int(I * 1.25) + 1)   # the frame did not fit: its kernels did nothing, the node just made is dropped un-walked
+        replays += 1
+    _capacity_hint[key] = max(_round_cap(int(I * 1.25) + 1), min(cap, _round_cap(2 * I + 1)))
+    if I > _forward_peak[0]:
+        _forward_peak[0] = I
+    _last_info.update(num_rendered=I, capacity=cap, replays=replays, tile_culling=bool(tc), production_binning=prod, forward_only=bool(r.forward_only),
+                      binning_path=r.path, rank_bands=r.nbands, bound=True, native_host=True)
+    _last_binning[0] = (r.state, r.off_binning)
+    return r.color, r.radii, r.visible
+
+
 def _apply_leaves_entry(*args):
+    if _late_count and _deferred is None and not _poison_state:
+        from . import _host
+
+        H = _host.get()
+        if H is not None:
+            out = _native_leaves_entry(H, *args)
+            if out is not None:
+                return out
+    _last_info["native_host"] = False
     return _apply_late(_RasterizeBound, *args)
 
 

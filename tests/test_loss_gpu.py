@@ -212,11 +212,21 @@ def test_seeded_backward_gives_the_gradients_of_the_engines_own_seed():
 def test_l1_backward_on_the_unit_seed_launches_nothing_and_equals_the_kernel():
     """`l1_loss(image, gt).backward()` under install_backward_seed: the forward (gls_l1_forward_grad) leaves sign(a - b) / n behind and the backward
     returns it without a launch; the same bits as gls_l1_backward gives.  Any other upstream gradient (a scaled loss, an explicit seed, a second
-    backward over a retained graph, no seed installed) takes the kernel."""
+    backward over a retained graph, no seed installed) takes the kernel.  (The Python host side: the test watches its ctypes calls; the compiled
+    host's L1 node is held to the same behaviour by tests/test_native_host_gpu.py.)"""
+    from gaussianavatars_amd import _host
     from gaussianavatars_amd import _lib
     from gaussianavatars_amd import loss as L
 
     DEV = _dev()
+    prev_host = _host.set_enabled(False)
+    try:
+        _l1_unit_seed_body(DEV, _lib, L)
+    finally:
+        _host.set_enabled(prev_host)
+
+
+def _l1_unit_seed_body(DEV, _lib, L):
     lib = _lib.gls()
     calls = []
     real_bwd, real_fwd_grad = lib.gls_l1_backward, lib.gls_l1_forward_grad

@@ -103,6 +103,57 @@ def run(train_iterations=200, n_iter=500):
     """, 600)
     summary["scripts"]["fps_benchmark_demo.py"] = dict(rc=rc, seconds=round(el, 1), fps_rounds=_fps(txt), last_forward=_json_after(txt, "LAST_FORWARD"))
 
+    # 1b) the SAME avatar through this package's mirror classes (what bench.py and the GPU tests drive), timed with the harness's own protocol in one process
+    #     beside the reference's patched classes: the zero-edit boundary must cost nothing against the mirror on identical inputs.  bench.py's cfg2 line
+    #     (further down) is the synthetic stand-in of the same size on its ellipsoid mesh: another scene, quoted with its instance counts.
+    rc, el, txt = _launch("same_asset", f"""
+        import importlib, numpy as np
+        from pathlib import Path
+        from gaussianavatars_amd import patch, _lib
+        patch.patch_reference(reference_root={REF!r})
+        from scene.flame_gaussian_model import FlameGaussianModel as RefFGM
+        from gaussianavatars_amd import gaussian_model as M, rasterizer as R
+        from gaussianavatars_amd.gaussian_renderer import render
+        demo = importlib.import_module("fps_benchmark_demo")
+        dev = torch.device("cuda")
+        with torch.no_grad():
+            ref = RefFGM(3)
+            ref.load_ply(Path({avatar!r}), has_target=False)
+            fm = ref.flame_model
+            rig = {{k: getattr(fm, k).detach().cpu().numpy() for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights")}}
+            rig["parents"], rig["faces"] = fm.parents.cpu().numpy(), fm.faces.cpu().numpy()
+            mir = M.FlameGaussianModel(3, rig, device=dev)
+            mir.load_arrays({{k: getattr(ref, k).detach().cpu().numpy() for k in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")}}
+                            | {{"binding": ref.binding.cpu().numpy()}}, device=dev, requires_grad=False)
+            mir.load_flame_param({{k: v.detach().cpu().numpy() for k, v in ref.flame_param.items()}}, device=dev)
+            cam = demo.prepare_camera(550, 802)
+            pipe = demo.PipelineConfig()
+            bg = torch.tensor([1, 1, 1], dtype=torch.float32, device="cuda")
+            out = {{}}
+            for name, g in (("reference_classes", ref), ("mirror_classes", mir), ("reference_classes_again", ref)):
+                fps = []
+                for rnd in range(4):
+                    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    start.record()
+                    for _ in range({n_iter}):
+                        if g.binding != None:
+                            g.select_mesh_by_timestep(0)
+                        rendering = render(cam, g, pipe, bg)["render"]
+                    end.record()
+                    torch.cuda.synchronize()
+                    fps.append({n_iter} / (start.elapsed_time(end) / 1000))
+                out[name] = [round(f, 1) for f in fps[1:]]
+            _lib.gsr_profile_enable(True)
+            for _ in range(50):
+                ref.select_mesh_by_timestep(0)
+                render(cam, ref, pipe, bg)
+            torch.cuda.synchronize()
+            prof = {{k: round(1e3 * ms / max(n, 1), 2) for k, (ms, n) in _lib.gsr_profile_read().items() if n}}
+            _lib.gsr_profile_enable(False)
+        print("SAME_ASSET", json.dumps(dict(fps=out, rasterizer_kernels_us=prof, last_forward=R.last_forward_info())))
+    """, 600)
+    summary["same_asset"] = dict(rc=rc, **(_json_after(txt, "SAME_ASSET") or {{}}))
+
     # 2) train.py: densify_and_prune at iterations 100 and 150; no evaluation pass (LPIPS wants downloaded weights)
     rc, el, txt = _launch("train", f"""
         times = []
