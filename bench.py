@@ -682,13 +682,16 @@ def main():
     # ---- per-kernel durations: HIP events on the launch stream (recorded by the C ABI around every kernel).
     # Bracketing each launch with an event pair costs ~5 % of the frame rate (983 -> 933 frames/s measured),
     # so `value` above comes from the un-instrumented pass and the SAME K steps are repeated here with events on.
-    kern = {}
+    kern, kern_other = {}, {}
     if rank == 0 and not args.no_kernel_profile:
         _lib.gsr_profile_enable(True)
+        _lib.launch_profile_enable(True)     # libgab / libgls: the binding and loss kernels of the step (round 5: the whole step in the roofline record)
         run_eager(args.steps, args.warmup)
         torch.cuda.synchronize(device)
         kern = _lib.gsr_profile_read()
+        kern_other = _lib.launch_profile_read()
         _lib.gsr_profile_enable(False)
+        _lib.launch_profile_enable(False)
     # ---- `--workload train`: the fused L1+SSIM pair has no timing slot in the rasterizer's C ABI; its three launches (forward, reduce, backward)
     # are timed here with events on the launch stream, on one image pair, for the roofline line of the loss
     loss_line = None
@@ -790,6 +793,32 @@ def main():
                     })
             return a
         algo, algo_rect = algo_for(I_binned), algo_for(I_rect)
+        # ---- the binding (libgab) and loss (libgls) kernels of the step: SURVEY.md 8(d)'s "Binding (per frame)" row split by kernel -- the FLAME tables
+        # a kernel has to read once (expression block of the blend shapes 3V x n_expr, pose-corrective block 36 x 3V, skinning weights), the per-face
+        # table (17 floats per face) and, for the bound rasterizer entry's face reduction, the 20-float row per splat; the per-splat 44 B in / 40 B out of
+        # the bind itself are inside k_preprocess / k_preprocess_bwd on this path (N1).  Names as the launch sites spell them.
+        fm = getattr(g, "flame_model", None)
+        if fm is not None:
+            V_, F_, NE_ = int(fm.v_template.shape[0]), int(fm.faces.shape[0]), int(fm.shapedirs.shape[2]) - 300
+            T_ = int(g.flame_param["expr"].shape[0])
+            fbytes = 3 * F_ * fm.faces.element_size()
+            algo.update({
+                "gab::k_flame_fused": 4 * (3 * V_ * NE_ + 36 * 3 * V_ + 3 * V_ + 5 * V_ + 6 * V_),
+                "gab::k_face_frames": 4 * 3 * V_ + fbytes + 4 * 17 * F_,
+                "gab::k_bind_bwd_faces": 4 * 20 * N + 4 * (F_ + 1) + 4 * 17 * F_,
+                "gab::k_gather_skin_bwd": 16 * 3 * F_ + 4 * (V_ + 1) + 4 * 3 * V_ + 4 * 17 * F_ + 4 * 36 * 3 * V_ + 4 * 5 * V_ + 4 * 6 * V_ + 4 * T_ * (NE_ + 18),
+                "gab::k_chain_blend_bwd": 4 * (3 * V_ * NE_ + 3 * V_),
+                "gab::k_bind": 84 * N, "gab::k_bind_bwd_rows": (84 + 40 + 80) * N,
+            })
+        algo.update({"gls::k_l1_fwd": 4 * 3 * HW * 3, "gls::k_l1_reduce": 8 * ((3 * HW + 1023) // 1024), "gls::k_l1_bwd": 4 * 3 * HW * 3,
+                     "gls::k_l1_ssim_fwd": 60 * HW, "gls::k_l1_ssim_bwd": 48 * HW, "gls::k_reduce_partials": 8 * 51 * 18 * 3,
+                     "gls::k_densify_stats": 28 * N})
+        for name, (ms, n) in kern_other.items():
+            if n:
+                short = name.replace("void ", "").split("<")[0]
+                prev = per_kernel.get(short)
+                tot_ms, tot_n = ms + (prev["avg_us"] * prev["launches"] / 1e3 if prev else 0.0), n + (prev["launches"] if prev else 0)
+                per_kernel[short] = dict(avg_us=1e3 * tot_ms / tot_n, launches=tot_n)
         # Coalesced-read component of each kernel (bytes per launch), for the PMC calibration rule of profiles/r02_pmc_calibration.json:
         # FETCH_SIZE tallies 64 B per request; coalesced streams issue 128-byte requests (reported at half), per-lane gathers and
         # scalar loads issue 64-byte ones (face value).  The blend kernels' 2-D tile accesses (32-128 B runs) lie between the
@@ -835,14 +864,26 @@ def main():
                                      "streaming bandwidth; HBM fraction reported as asked"),
                      "k_render": "alpha-blend kernels are issue-bound (exp + per-wave instruction stream), HBM fraction reported as asked",
                      "k_render_bwd": "alpha-blend kernels are issue-bound (exp + per-wave instruction stream), HBM fraction reported as asked"}
-            roofline = dict(kernel=dom, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+            # the whole step (round 5): algorithmic bytes of every kernel of one step / the step's wall time, and the sum of the kernels' own durations
+            per_step = lambda v: v["launches"] / float(args.steps)
+            # (a libgsr timing slot may cover several launches of one frame -- k_depth_sort: the bucket scatter and the sorts -- its bytes are per FRAME)
+            step_bytes = sum(algo[k] * (per_step(v) if "::" in k else 1.0) for k, v in per_kernel.items() if k in algo)
+            kernel_sum_us = sum(v["avg_us"] * per_step(v) for v in per_kernel.values())
+            ms_step = 1e3 * elapsed / args.steps
+            step_line = dict(algorithmic_bytes=int(step_bytes), ms_per_step=round(ms_step, 4), achieved=round(step_bytes / (ms_step * 1e-3) / 1e9, 1), unit="GB/s",
+                             frac=round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), kernel_sum_us=round(kernel_sum_us, 1),
+                             launches_per_step=round(sum(per_step(v) for v in per_kernel.values()), 2),
+                             unaccounted_kernels=sorted(k for k in per_kernel if k not in algo),
+                             what="sum over every kernel of one step (libgsr + libgab + libgls) of its SURVEY.md 8(d) bytes, divided by ms_per_step of the timed "
+                                  "(un-instrumented) rounds; kernel_sum_us = the kernels' own event-timed durations added up (instrumented pass)")
+            roofline = dict(kernel=dom, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", step=step_line,
                             frac=round(ach / HBM_PEAK_GBS, 5), traffic=pmc.get(dom),
                             traffic_bounds=[int(sum(pmc_raw[dom])), int(2 * pmc_raw[dom][0] + pmc_raw[dom][1])] if dom in pmc_raw else None,
                             traffic_source=os.path.basename(pmc_path) if pmc_path else None, traffic_stale=pmc_stale,
                             algorithmic_bytes_per_launch=int(algo[dom]), algorithmic_bytes_rect_based=int(algo_rect[dom]),
                             instances=dict(binned=int(I_binned), rect_based=int(I_rect)),
                             avg_launch_us=round(per_kernel[dom]["avg_us"], 2), note=notes.get(dom, "HBM-bound streaming kernel"),
-                            all_kernels={k: dict(avg_us=round(v["avg_us"], 2),
+                            all_kernels={k: dict(avg_us=round(v["avg_us"], 2), launches_per_step=round(v["launches"] / float(args.steps), 2),
                                                  algo_GBs=round(algo[k] / (v["avg_us"] * 1e-6) / 1e9, 1) if k in algo else None,
                                                  frac=round(algo[k] / (v["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if k in algo else None,
                                                  traffic=pmc.get(k))

@@ -41,7 +41,7 @@ def load():
         spec = importlib.util.spec_from_file_location("gaussianavatars_amd.gaa_host", HOST_LIB_PATH)
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
-        if (mod.GSR_ABI, mod.GAB_ABI, mod.GLS_ABI) != (_lib.GSR_ABI_VERSION, 4, 3):
+        if (mod.GSR_ABI, mod.GAB_ABI, mod.GLS_ABI) != (_lib.GSR_ABI_VERSION, _lib.GAB_ABI_VERSION, _lib.GLS_ABI_VERSION):
             raise RuntimeError(f"gaa_host.so was built for ABI {(mod.GSR_ABI, mod.GAB_ABI, mod.GLS_ABI)}: rebuild it (csrc/build_host.py --force)")
         mod.init(_lib.GSR_LIB_PATH, _lib.GAB_LIB_PATH, _lib.GLS_LIB_PATH)
         _mod = mod

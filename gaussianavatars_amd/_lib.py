@@ -230,7 +230,12 @@ GAB_SYMBOLS = {
     "gab_bind_backward_faces": (C.c_int, [C.c_int32, _P, _P, _P, _P]),
     "gab_zero_buffers": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _P]),
     "gab_feed_row": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
+    "gab_profile_enable": (C.c_int, [C.c_int]),
+    "gab_profile_collect": (C.c_int, []),
+    "gab_profile_entry": (C.c_int, [C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "gab_profile_reset": (C.c_int, []),
 }
+GAB_ABI_VERSION = 5
 
 _gab = None
 
@@ -247,8 +252,8 @@ def gab():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.gab_abi_version() != 4:
-            raise RuntimeError(f"gab ABI version {lib.gab_abi_version()} != 4")
+        if lib.gab_abi_version() != GAB_ABI_VERSION:
+            raise RuntimeError(f"gab ABI version {lib.gab_abi_version()} != {GAB_ABI_VERSION}")
         _gab = lib
     return _gab
 
@@ -269,7 +274,12 @@ GLS_SYMBOLS = {
     "gls_l1_backward": (C.c_int, [C.c_int64, _P, _P, _P, C.c_float, _P, _P]),
     "gls_densification_stats": (C.c_int, [C.c_int32] + [_P] * 6),
     "gls_add_densification_stats": (C.c_int, [C.c_int32, _P, _P, C.c_int32, _P, _P, _P]),
+    "gls_profile_enable": (C.c_int, [C.c_int]),
+    "gls_profile_collect": (C.c_int, []),
+    "gls_profile_entry": (C.c_int, [C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "gls_profile_reset": (C.c_int, []),
 }
+GLS_ABI_VERSION = 4
 
 _gls = None
 
@@ -286,10 +296,30 @@ def gls():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.gls_abi_version() != 3:
-            raise RuntimeError(f"gls ABI version {lib.gls_abi_version()} != 3")
+        if lib.gls_abi_version() != GLS_ABI_VERSION:
+            raise RuntimeError(f"gls ABI version {lib.gls_abi_version()} != {GLS_ABI_VERSION}")
         _gls = lib
     return _gls
+
+
+def launch_profile_enable(on: bool) -> None:
+    """Event pairs around every launch of libgab / libgls (include/gab.h, gls.h: *_profile_*); libgsr's twin is gsr_profile_enable."""
+    for lib, tag in ((gab(), "gab"), (gls(), "gls")):
+        getattr(lib, tag + "_profile_enable")(1 if on else 0)
+        if on:
+            getattr(lib, tag + "_profile_reset")()
+
+
+def launch_profile_read() -> dict:
+    """{kernel name: (total_ms, launches)} of libgab's and libgls's launches since launch_profile_enable(True)."""
+    out = {}
+    for lib, tag in ((gab(), "gab"), (gls(), "gls")):
+        n = getattr(lib, tag + "_profile_collect")()
+        for i in range(n):
+            name, ms, k = C.c_char_p(), C.c_double(), C.c_int64()
+            if getattr(lib, tag + "_profile_entry")(i, C.byref(name), C.byref(ms), C.byref(k)) == 0:
+                out[name.value.decode()] = (ms.value, k.value)
+    return out
 
 
 def gls_error() -> str:

@@ -17,6 +17,7 @@
 #include <cstdio>
 
 #include "../../include/gab.h"
+#include "launch_prof.h"
 #include "bind_math.h"
 
 namespace gab {
@@ -1576,15 +1577,15 @@ int gab_flame_forward(const GabRig* rig_, const float* shape, const float* expr,
         return fail(GAB_E_ARG, "gab_flame_forward: NULL buffer");
     hipStream_t st = (hipStream_t)stream_;
     const int E = 3 * rig.V;
-    hipLaunchKernelGGL(gab::k_blend, dim3((E + 3) / 4), dim3(256), 0, st, rig, shape, expr, static_offset, v_shaped);
+    PROF_LAUNCH(gab::k_blend, dim3((E + 3) / 4), dim3(256), 0, st, rig, shape, expr, static_offset, v_shaped);
     LAUNCH_CHECK("k_blend");
     const bool flame_tree = rig.parents[1] == 0 && rig.parents[2] == 1 && rig.parents[3] == 1 && rig.parents[4] == 1;
     if (flame_tree)
-        hipLaunchKernelGGL(gab::k_joints_chain<true>, dim3(1), dim3(1024), 0, st, rig, (const float*)v_shaped, rotation, neck, jaw, eyes, ws);
+        PROF_LAUNCH(gab::k_joints_chain<true>, dim3(1), dim3(1024), 0, st, rig, (const float*)v_shaped, rotation, neck, jaw, eyes, ws);
     else
-        hipLaunchKernelGGL(gab::k_joints_chain<false>, dim3(1), dim3(1024), 0, st, rig, (const float*)v_shaped, rotation, neck, jaw, eyes, ws);
+        PROF_LAUNCH(gab::k_joints_chain<false>, dim3(1), dim3(1024), 0, st, rig, (const float*)v_shaped, rotation, neck, jaw, eyes, ws);
     LAUNCH_CHECK("k_joints_chain");
-    hipLaunchKernelGGL(gab::k_skin, dim3((rig.V + 255) / 256), dim3(256), 0, st, rig, (const float*)ws, (const float*)v_shaped, translation, verts);
+    PROF_LAUNCH(gab::k_skin, dim3((rig.V + 255) / 256), dim3(256), 0, st, rig, (const float*)ws, (const float*)v_shaped, translation, verts);
     LAUNCH_CHECK("k_skin");
     return GAB_OK;
 }
@@ -1613,15 +1614,15 @@ int gab_flame_backward(const GabRig* rig_, const float* shape, const float* expr
         return fail(GAB_E_ARG, "gab_flame_backward: NULL buffer");
     hipStream_t st = (hipStream_t)stream_;
     const int E = 3 * rig.V;
-    hipLaunchKernelGGL(gab::k_skin_bwd, dim3((rig.V + 255) / 256), dim3(256), 0, st, rig, ws, v_shaped, dL_dverts, scratch, zs);
+    PROF_LAUNCH(gab::k_skin_bwd, dim3((rig.V + 255) / 256), dim3(256), 0, st, rig, ws, v_shaped, dL_dverts, scratch, zs);
     LAUNCH_CHECK("k_skin_bwd");
     const bool flame_tree = rig.parents[1] == 0 && rig.parents[2] == 1 && rig.parents[3] == 1 && rig.parents[4] == 1;
     if (flame_tree)
-        hipLaunchKernelGGL(gab::k_chain_bwd<true>, dim3(1), dim3(64), 0, st, rig, ws, rotation, neck, jaw, eyes, d_rotation, d_neck, d_jaw, d_eyes, d_translation, d_expr, d_shape);
+        PROF_LAUNCH(gab::k_chain_bwd<true>, dim3(1), dim3(64), 0, st, rig, ws, rotation, neck, jaw, eyes, d_rotation, d_neck, d_jaw, d_eyes, d_translation, d_expr, d_shape);
     else
-        hipLaunchKernelGGL(gab::k_chain_bwd<false>, dim3(1), dim3(64), 0, st, rig, ws, rotation, neck, jaw, eyes, d_rotation, d_neck, d_jaw, d_eyes, d_translation, d_expr, d_shape);
+        PROF_LAUNCH(gab::k_chain_bwd<false>, dim3(1), dim3(64), 0, st, rig, ws, rotation, neck, jaw, eyes, d_rotation, d_neck, d_jaw, d_eyes, d_translation, d_expr, d_shape);
     LAUNCH_CHECK("k_chain_bwd");
-    hipLaunchKernelGGL(gab::k_blend_bwd, dim3((E + GAB_BLEND_BWD_ROWS - 1) / GAB_BLEND_BWD_ROWS), dim3(256), 0, st, rig, (const float*)ws,
+    PROF_LAUNCH(gab::k_blend_bwd, dim3((E + GAB_BLEND_BWD_ROWS - 1) / GAB_BLEND_BWD_ROWS), dim3(256), 0, st, rig, (const float*)ws,
                        (const float*)scratch, dL_dv_shaped, d_static_offset, d_shape, d_expr);
     LAUNCH_CHECK("k_blend_bwd");
     return GAB_OK;
@@ -1640,9 +1641,9 @@ int gab_flame_prepare(const GabRig* rig_, const float* shape, const float* stati
     if ((rig.n_shape && !shape) || !prepared) return fail(GAB_E_ARG, "gab_flame_prepare: NULL buffer");
     hipStream_t st = (hipStream_t)stream_;
     const int E = 3 * rig.V, outs = 15 + 15 * rig.n_expr;
-    hipLaunchKernelGGL(gab::k_prep_rows, dim3((E + 3) / 4), dim3(256), 0, st, rig, shape, static_offset, prepared);
+    PROF_LAUNCH(gab::k_prep_rows, dim3((E + 3) / 4), dim3(256), 0, st, rig, shape, static_offset, prepared);
     LAUNCH_CHECK("k_prep_rows");
-    hipLaunchKernelGGL(gab::k_prep_joints, dim3((outs + 3) / 4), dim3(256), 0, st, rig, prepared);
+    PROF_LAUNCH(gab::k_prep_joints, dim3((outs + 3) / 4), dim3(256), 0, st, rig, prepared);
     LAUNCH_CHECK("k_prep_joints");
     return GAB_OK;
 }
@@ -1659,9 +1660,9 @@ int gab_flame_forward_prepared(const GabRig* rig_, const float* prepared, const 
     const int blocks = (rig.V + GAB_FUSED_VERTS - 1) / GAB_FUSED_VERTS;
     const bool flame_tree = rig.parents[1] == 0 && rig.parents[2] == 1 && rig.parents[3] == 1 && rig.parents[4] == 1;
     if (flame_tree)
-        hipLaunchKernelGGL(gab::k_flame_fused<true>, dim3(blocks), dim3(256), 0, st, rig, prepared, expr, rotation, neck, jaw, eyes, translation, verts, v_shaped, ws, (const float*)nullptr);
+        PROF_LAUNCH(gab::k_flame_fused<true>, dim3(blocks), dim3(256), 0, st, rig, prepared, expr, rotation, neck, jaw, eyes, translation, verts, v_shaped, ws, (const float*)nullptr);
     else
-        hipLaunchKernelGGL(gab::k_flame_fused<false>, dim3(blocks), dim3(256), 0, st, rig, prepared, expr, rotation, neck, jaw, eyes, translation, verts, v_shaped, ws, (const float*)nullptr);
+        PROF_LAUNCH(gab::k_flame_fused<false>, dim3(blocks), dim3(256), 0, st, rig, prepared, expr, rotation, neck, jaw, eyes, translation, verts, v_shaped, ws, (const float*)nullptr);
     LAUNCH_CHECK("k_flame_fused");
     return GAB_OK;
 }
@@ -1679,7 +1680,7 @@ int gab_blend_sequence(const GabRig* rig_, const float* prepared, const float* e
     const int gx = ((E + 31) / 32 + 3) / 4, mtiles = (T + 31) / 32;
     const int MT = std::min(16, std::max(1, (mtiles * gx + 511) / 512));
     dim3 grid((unsigned)gx, (unsigned)((mtiles + MT - 1) / MT));
-    hipLaunchKernelGGL(gab::k_blend_seq_mfma, grid, dim3(256), 0, (hipStream_t)stream_, rig, prepared, expr_table, (int)T, MT, v_shaped_seq);
+    PROF_LAUNCH(gab::k_blend_seq_mfma, grid, dim3(256), 0, (hipStream_t)stream_, rig, prepared, expr_table, (int)T, MT, v_shaped_seq);
     LAUNCH_CHECK("k_blend_seq_mfma");
     return GAB_OK;
 }
@@ -1696,9 +1697,9 @@ int gab_flame_forward_sequence(const GabRig* rig_, const float* prepared, const 
     const int blocks = (rig.V + GAB_FUSED_VERTS - 1) / GAB_FUSED_VERTS;
     const bool flame_tree = rig.parents[1] == 0 && rig.parents[2] == 1 && rig.parents[3] == 1 && rig.parents[4] == 1;
     if (flame_tree)
-        hipLaunchKernelGGL(gab::k_flame_fused<true>, dim3(blocks), dim3(256), 0, st, rig, prepared, expr, rotation, neck, jaw, eyes, translation, verts, v_shaped, ws, v_shaped_row);
+        PROF_LAUNCH(gab::k_flame_fused<true>, dim3(blocks), dim3(256), 0, st, rig, prepared, expr, rotation, neck, jaw, eyes, translation, verts, v_shaped, ws, v_shaped_row);
     else
-        hipLaunchKernelGGL(gab::k_flame_fused<false>, dim3(blocks), dim3(256), 0, st, rig, prepared, expr, rotation, neck, jaw, eyes, translation, verts, v_shaped, ws, v_shaped_row);
+        PROF_LAUNCH(gab::k_flame_fused<false>, dim3(blocks), dim3(256), 0, st, rig, prepared, expr, rotation, neck, jaw, eyes, translation, verts, v_shaped, ws, v_shaped_row);
     LAUNCH_CHECK("k_flame_fused");
     return GAB_OK;
 }
@@ -1727,16 +1728,16 @@ int gab_flame_backward_prepared(const GabRig* rig_, const float* prepared, const
     if (!covers_expr) { zs.p[zs.count] = d_expr; zs.n[zs.count] = rig.n_expr; ++zs.count; }
     hipStream_t st = (hipStream_t)stream_;
     const int E = 3 * rig.V;
-    hipLaunchKernelGGL(gab::k_skin_bwd, dim3((rig.V + 255) / 256), dim3(256), 0, st, rig, ws, v_shaped, dL_dverts, scratch, zs);
+    PROF_LAUNCH(gab::k_skin_bwd, dim3((rig.V + 255) / 256), dim3(256), 0, st, rig, ws, v_shaped, dL_dverts, scratch, zs);
     LAUNCH_CHECK("k_skin_bwd");
     const float* Mmat = prepared + gab::prep_joint_offset(rig.V) + 16;
     const int blocks = 1 + (E + GAB_BLEND_BWD_ROWS - 1) / GAB_BLEND_BWD_ROWS;
     const bool flame_tree = rig.parents[1] == 0 && rig.parents[2] == 1 && rig.parents[3] == 1 && rig.parents[4] == 1;
     if (flame_tree)
-        hipLaunchKernelGGL(gab::k_chain_blend_bwd<true>, dim3(blocks), dim3(256), 0, st, rig, ws, (const float*)scratch, Mmat, rotation, neck, jaw, eyes,
+        PROF_LAUNCH(gab::k_chain_blend_bwd<true>, dim3(blocks), dim3(256), 0, st, rig, ws, (const float*)scratch, Mmat, rotation, neck, jaw, eyes,
                            d_rotation, d_neck, d_jaw, d_eyes, d_translation, d_expr);
     else
-        hipLaunchKernelGGL(gab::k_chain_blend_bwd<false>, dim3(blocks), dim3(256), 0, st, rig, ws, (const float*)scratch, Mmat, rotation, neck, jaw, eyes,
+        PROF_LAUNCH(gab::k_chain_blend_bwd<false>, dim3(blocks), dim3(256), 0, st, rig, ws, (const float*)scratch, Mmat, rotation, neck, jaw, eyes,
                            d_rotation, d_neck, d_jaw, d_eyes, d_translation, d_expr);
     LAUNCH_CHECK("k_chain_blend_bwd");
     return GAB_OK;
@@ -1772,17 +1773,17 @@ int gab_mesh_backward_prepared(const GabRig* rig_, const float* prepared, const 
     a.d_center = d_center; a.d_R = d_orien_mat; a.d_scaling = d_scaling; a.d_quat = d_orien_quat; a.g_verts = dL_dverts;
     a.g_vs = scratch;
     hipStream_t st = (hipStream_t)stream_;
-    hipLaunchKernelGGL(gab::k_gather_skin_bwd, dim3((rig.V + GAB_MESH_VPB - 1) / GAB_MESH_VPB), dim3(256), 0, st, rig, a, zs);
+    PROF_LAUNCH(gab::k_gather_skin_bwd, dim3((rig.V + GAB_MESH_VPB - 1) / GAB_MESH_VPB), dim3(256), 0, st, rig, a, zs);
     LAUNCH_CHECK("k_gather_skin_bwd");
     const int E = 3 * rig.V;
     const float* Mmat = prepared + gab::prep_joint_offset(rig.V) + 16;
     const int blocks = 1 + (E + GAB_BLEND_BWD_ROWS - 1) / GAB_BLEND_BWD_ROWS;
     const bool flame_tree = rig.parents[1] == 0 && rig.parents[2] == 1 && rig.parents[3] == 1 && rig.parents[4] == 1;
     if (flame_tree)
-        hipLaunchKernelGGL(gab::k_chain_blend_bwd<true>, dim3(blocks), dim3(256), 0, st, rig, ws, (const float*)scratch, Mmat, rotation, neck, jaw, eyes,
+        PROF_LAUNCH(gab::k_chain_blend_bwd<true>, dim3(blocks), dim3(256), 0, st, rig, ws, (const float*)scratch, Mmat, rotation, neck, jaw, eyes,
                            d_rotation, d_neck, d_jaw, d_eyes, d_translation, d_expr);
     else
-        hipLaunchKernelGGL(gab::k_chain_blend_bwd<false>, dim3(blocks), dim3(256), 0, st, rig, ws, (const float*)scratch, Mmat, rotation, neck, jaw, eyes,
+        PROF_LAUNCH(gab::k_chain_blend_bwd<false>, dim3(blocks), dim3(256), 0, st, rig, ws, (const float*)scratch, Mmat, rotation, neck, jaw, eyes,
                            d_rotation, d_neck, d_jaw, d_eyes, d_translation, d_expr);
     LAUNCH_CHECK("k_chain_blend_bwd");
     return GAB_OK;
@@ -1797,7 +1798,7 @@ int gab_face_frames_forward(int32_t V, int32_t F, const float* verts, const void
         return GAB_OK;
     }
     if (!verts || !faces || !center || !orien_mat || !scaling || !orien_quat) return fail(GAB_E_ARG, "gab_face_frames_forward: NULL buffer");
-    hipLaunchKernelGGL(gab::k_face_frames, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream_, F, verts, faces, is64, center, orien_mat,
+    PROF_LAUNCH(gab::k_face_frames, dim3((F + 255) / 256), dim3(256), 0, (hipStream_t)stream_, F, verts, faces, is64, center, orien_mat,
                        scaling, orien_quat, d_verts_zeroed, 3 * V);
     LAUNCH_CHECK("k_face_frames");
     return GAB_OK;
@@ -1813,7 +1814,7 @@ int gab_face_frames_backward(int32_t V, int32_t F, const float* verts, const voi
     if (!d_verts_is_zero) HIP_TRY(hipMemsetAsync(d_verts, 0, (size_t)V * 3 * sizeof(float), st));
     if (F == 0) return GAB_OK;
     if (!verts || !faces) return fail(GAB_E_ARG, "gab_face_frames_backward: NULL buffer");
-    hipLaunchKernelGGL(gab::k_face_frames_bwd, dim3((F + 255) / 256), dim3(256), 0, st, F, verts, faces, is64, d_center, d_orien_mat, d_scaling,
+    PROF_LAUNCH(gab::k_face_frames_bwd, dim3((F + 255) / 256), dim3(256), 0, st, F, verts, faces, is64, d_center, d_orien_mat, d_scaling,
                        d_orien_quat, d_verts);
     LAUNCH_CHECK("k_face_frames_bwd");
     return GAB_OK;
@@ -1830,7 +1831,7 @@ int gab_bind_forward(int32_t N, int32_t F, const float* xyz, const float* log_sc
     if (!xyz || !log_scaling || !rotation || !binding || !face_center || !face_orien_mat || !face_scaling || !face_orien_quat || !out_xyz ||
         !out_scaling || !out_rotation)
         return fail(GAB_E_ARG, "gab_bind_forward: NULL buffer");
-    hipLaunchKernelGGL(gab::k_bind, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream_, N, xyz, log_scaling, rotation, binding, is64,
+    PROF_LAUNCH(gab::k_bind, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream_, N, xyz, log_scaling, rotation, binding, is64,
                        face_center, face_orien_mat, face_scaling, face_orien_quat, out_xyz, out_scaling, out_rotation, opacity_logit, out_opacity);
     LAUNCH_CHECK("k_bind");
     return GAB_OK;
@@ -1852,7 +1853,7 @@ int gab_bind_backward(int32_t N, int32_t F, const float* xyz, const float* log_s
     if (!xyz || !log_scaling || !rotation || !binding || !face_orien_mat || !face_scaling || !face_orien_quat || !d_xyz || !d_log_scaling ||
         !d_rotation)
         return fail(GAB_E_ARG, "gab_bind_backward: NULL buffer");
-    hipLaunchKernelGGL(gab::k_bind_bwd, dim3((N + 255) / 256), dim3(256), 0, st, N, xyz, log_scaling, rotation, binding, is64, face_orien_mat,
+    PROF_LAUNCH(gab::k_bind_bwd, dim3((N + 255) / 256), dim3(256), 0, st, N, xyz, log_scaling, rotation, binding, is64, face_orien_mat,
                        face_scaling, face_orien_quat, d_out_xyz, d_out_scaling, d_out_rotation, d_xyz, d_log_scaling, d_rotation, d_face, F,
                        out_opacity, d_out_opacity, d_opacity_logit);
     LAUNCH_CHECK("k_bind_bwd");
@@ -1875,17 +1876,17 @@ int gab_bind_backward_csr(int32_t N, int32_t F, const float* xyz, const float* l
     const long long threads = 16ll * F;
     if (splat_face && slot && rows) {   // two passes: splat order (coalesced), then face order over contiguous rows
         if (N > 0) {
-            hipLaunchKernelGGL(gab::k_bind_bwd_rows, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, N, xyz, log_scaling,
+            PROF_LAUNCH(gab::k_bind_bwd_rows, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, N, xyz, log_scaling,
                                rotation, splat_face, slot, face_orien_mat, face_scaling, face_orien_quat, d_out_xyz, d_out_scaling,
                                d_out_rotation, d_xyz, d_log_scaling, d_rotation, rows, out_opacity, d_out_opacity, d_opacity_logit);
             LAUNCH_CHECK("k_bind_bwd_rows");
         }
-        hipLaunchKernelGGL(gab::k_bind_bwd_faces, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, F, face_begin,
+        PROF_LAUNCH(gab::k_bind_bwd_faces, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, F, face_begin,
                            (const float*)rows, d_face);
         LAUNCH_CHECK("k_bind_bwd_faces");
         return GAB_OK;
     }
-    hipLaunchKernelGGL(gab::k_bind_bwd_csr, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, F, xyz, log_scaling,
+    PROF_LAUNCH(gab::k_bind_bwd_csr, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, F, xyz, log_scaling,
                        rotation, face_orien_mat, face_scaling, face_orien_quat, d_out_xyz, d_out_scaling, d_out_rotation, order, face_begin,
                        d_xyz, d_log_scaling, d_rotation, d_face, out_opacity, d_out_opacity, d_opacity_logit);
     LAUNCH_CHECK("k_bind_bwd_csr");
@@ -1896,7 +1897,7 @@ int gab_bind_backward_faces(int32_t F, const int32_t* face_begin, const float* r
 {
     if (F <= 0 || !face_begin || !rows || !d_face) return fail(GAB_E_ARG, "gab_bind_backward_faces: bad arguments");
     const long long threads = 16ll * F;
-    hipLaunchKernelGGL(gab::k_bind_bwd_faces, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, F, face_begin, rows, d_face);
+    PROF_LAUNCH(gab::k_bind_bwd_faces, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, F, face_begin, rows, d_face);
     LAUNCH_CHECK("k_bind_bwd_faces");
     return GAB_OK;
 }
@@ -1905,7 +1906,7 @@ int gab_feed_row(const float* packed, int32_t T, int32_t width, const int32_t* s
                  void* stream_)
 {
     if (T <= 0 || width <= 0 || !packed || !cursor || !row || (schedule && n_sched <= 0)) return fail(GAB_E_ARG, "gab_feed_row: bad arguments");
-    hipLaunchKernelGGL(gab::k_feed_row, dim3(1), dim3(256), 0, (hipStream_t)stream_, packed, T, width, schedule, n_sched, cursor, row);
+    PROF_LAUNCH(gab::k_feed_row, dim3(1), dim3(256), 0, (hipStream_t)stream_, packed, T, width, schedule, n_sched, cursor, row);
     LAUNCH_CHECK("k_feed_row");
     return GAB_OK;
 }
@@ -1926,9 +1927,28 @@ int gab_zero_buffers(int32_t count, float* const* buffers_host, const int32_t* s
     int bx = (mx + 255) / 256;
     if (bx < 1) bx = 1;
     if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(gab::k_zero_many, dim3(bx, count), dim3(256), 0, (hipStream_t)stream_, z);
+    PROF_LAUNCH(gab::k_zero_many, dim3(bx, count), dim3(256), 0, (hipStream_t)stream_, z);
     LAUNCH_CHECK("k_zero_many");
     return GAB_OK;
+}
+
+int gab_profile_enable(int on)
+{
+    lprof::g.on.store(on ? 1 : 0);
+    return 0;
+}
+int gab_profile_collect(void) { return lprof::collect(); }
+int gab_profile_entry(int32_t index, const char** name, double* total_ms, int64_t* launches)
+{
+    long long n = 0;
+    const int rc = lprof::entry(index, name, total_ms, &n);
+    if (launches) *launches = (int64_t)n;
+    return rc;
+}
+int gab_profile_reset(void)
+{
+    lprof::reset();
+    return 0;
 }
 
 }  // extern "C"

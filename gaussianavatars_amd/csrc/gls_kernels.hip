@@ -14,6 +14,7 @@
 #include <cstdio>
 
 #include "../../include/gls.h"
+#include "launch_prof.h"
 
 namespace gls {
 
@@ -365,9 +366,9 @@ int gls_l1_ssim_forward(int32_t B, int32_t C, int32_t H, int32_t W, const float*
     hipStream_t stream = (hipStream_t)stream_;
     const dim3 grid((W + gls::TX - 1) / gls::TX, (H + gls::TY - 1) / gls::TY, B * C);
     const size_t stride = (size_t)B * C * H * W;
-    hipLaunchKernelGGL(gls::k_l1_ssim_fwd, grid, dim3(256), 0, stream, H, W, img1, img2, make_window(), maps, stride, (float2*)partial);
+    PROF_LAUNCH(gls::k_l1_ssim_fwd, grid, dim3(256), 0, stream, H, W, img1, img2, make_window(), maps, stride, (float2*)partial);
     LAUNCH_CHECK("k_l1_ssim_fwd");
-    hipLaunchKernelGGL(gls::k_reduce_partials, dim3(B), dim3(256), 0, stream, (const float2*)partial, (int)(grid.x * grid.y * C), scale, (float2*)sums);
+    PROF_LAUNCH(gls::k_reduce_partials, dim3(B), dim3(256), 0, stream, (const float2*)partial, (int)(grid.x * grid.y * C), scale, (float2*)sums);
     LAUNCH_CHECK("k_reduce_partials");
     return GLS_OK;
 }
@@ -380,7 +381,7 @@ static int l1_ssim_backward_impl(int32_t B, int32_t C, int32_t H, int32_t W, con
     hipStream_t stream = (hipStream_t)stream_;
     const dim3 grid((W + gls::TX - 1) / gls::TX, (H + gls::TY - 1) / gls::TY, B * C);
     const size_t stride = (size_t)B * C * H * W;
-    hipLaunchKernelGGL(gls::k_l1_ssim_bwd, grid, dim3(256), 0, stream, C, H, W, img1, img2, maps, stride, make_window(), g_l1, g_ssim, g_stride, scale, d_img1);
+    PROF_LAUNCH(gls::k_l1_ssim_bwd, grid, dim3(256), 0, stream, C, H, W, img1, img2, maps, stride, make_window(), g_l1, g_ssim, g_stride, scale, d_img1);
     LAUNCH_CHECK("k_l1_ssim_bwd");
     return GLS_OK;
 }
@@ -405,10 +406,10 @@ static int l1_forward_impl(int64_t n, const float* a, const float* b, float scal
     hipStream_t stream = (hipStream_t)stream_;
     int blocks = (int)(((n >> 2) + 255) / 256);
     blocks = blocks < 1 ? 1 : (blocks > kL1Blocks ? kL1Blocks : blocks);
-    if (grad) hipLaunchKernelGGL(gls::k_l1_fwd<true>, dim3(blocks), dim3(256), 0, stream, (long long)n, a, b, (float2*)partial, scale, d_a);
-    else hipLaunchKernelGGL(gls::k_l1_fwd<false>, dim3(blocks), dim3(256), 0, stream, (long long)n, a, b, (float2*)partial, scale, (float*)nullptr);
+    if (grad) PROF_LAUNCH(gls::k_l1_fwd<true>, dim3(blocks), dim3(256), 0, stream, (long long)n, a, b, (float2*)partial, scale, d_a);
+    else PROF_LAUNCH(gls::k_l1_fwd<false>, dim3(blocks), dim3(256), 0, stream, (long long)n, a, b, (float2*)partial, scale, (float*)nullptr);
     LAUNCH_CHECK("k_l1_fwd");
-    hipLaunchKernelGGL(gls::k_l1_reduce, dim3(1), dim3(256), 0, stream, (const float2*)partial, blocks, scale, sum);
+    PROF_LAUNCH(gls::k_l1_reduce, dim3(1), dim3(256), 0, stream, (const float2*)partial, blocks, scale, sum);
     LAUNCH_CHECK("k_l1_reduce");
     return GLS_OK;
 }
@@ -431,7 +432,7 @@ int gls_l1_backward(int64_t n, const float* a, const float* b, const float* g, f
     hipStream_t stream = (hipStream_t)stream_;
     int blocks = (int)(((n >> 2) + 255) / 256);
     blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
-    hipLaunchKernelGGL(gls::k_l1_bwd, dim3(blocks), dim3(256), 0, stream, (long long)n, a, b, g, scale, d_a);
+    PROF_LAUNCH(gls::k_l1_bwd, dim3(blocks), dim3(256), 0, stream, (long long)n, a, b, g, scale, d_a);
     LAUNCH_CHECK("k_l1_bwd");
     return GLS_OK;
 }
@@ -442,7 +443,7 @@ int gls_densification_stats(int32_t P, const int32_t* radii, const float* viewsp
     if (P < 0) return fail(GLS_E_ARG, "P < 0");
     if (P == 0) return GLS_OK;
     if (!radii || !viewspace_grad || !max_radii2D || !xyz_gradient_accum || !denom) return fail(GLS_E_ARG, "null pointer");
-    hipLaunchKernelGGL(gls::k_densify_stats, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, P, radii, viewspace_grad,
+    PROF_LAUNCH(gls::k_densify_stats, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, P, radii, viewspace_grad,
                        max_radii2D, xyz_gradient_accum, denom);
     LAUNCH_CHECK("k_densify_stats");
     return GLS_OK;
@@ -454,10 +455,29 @@ int gls_add_densification_stats(int32_t P, const uint8_t* update_filter, const f
     if (P < 0 || grad_stride < 2) return fail(GLS_E_ARG, "P < 0 or grad_stride < 2");
     if (P == 0) return GLS_OK;
     if (!update_filter || !viewspace_grad || !xyz_gradient_accum || !denom) return fail(GLS_E_ARG, "null pointer");
-    hipLaunchKernelGGL(gls::k_add_densify_stats, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, P, update_filter, viewspace_grad, grad_stride,
+    PROF_LAUNCH(gls::k_add_densify_stats, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, P, update_filter, viewspace_grad, grad_stride,
                        xyz_gradient_accum, denom);
     LAUNCH_CHECK("k_add_densify_stats");
     return GLS_OK;
+}
+
+int gls_profile_enable(int on)
+{
+    lprof::g.on.store(on ? 1 : 0);
+    return 0;
+}
+int gls_profile_collect(void) { return lprof::collect(); }
+int gls_profile_entry(int32_t index, const char** name, double* total_ms, int64_t* launches)
+{
+    long long n = 0;
+    const int rc = lprof::entry(index, name, total_ms, &n);
+    if (launches) *launches = (int64_t)n;
+    return rc;
+}
+int gls_profile_reset(void)
+{
+    lprof::reset();
+    return 0;
 }
 
 }  // extern "C"

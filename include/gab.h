@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GAB_ABI_VERSION 4
+#define GAB_ABI_VERSION 5
 #define GAB_OK 0
 #define GAB_E_ARG (-1)
 #define GAB_E_HIP (-2)
@@ -185,6 +185,16 @@ int gab_zero_buffers(int32_t count, float* const* buffers_host, const int32_t* s
  * cursor stays in [0, length) however long the run.  A kernel like any other: capturable, replays walk the schedule on their own. */
 int gab_feed_row(const float* packed, int32_t T, int32_t width, const int32_t* schedule, int32_t n_sched, int32_t* cursor, float* row,
                  void* stream);
+
+/* Optional per-kernel timing with hipEvents on the launch stream (what bench.py's roofline.all_kernels / roofline.step read for this library's
+ * kernels; libgsr has gsr_profile_*).  Off by default.  When on, every launch of this library is bracketed by an event pair;
+ * gab_profile_collect() synchronises the pending pairs, ADDS their elapsed times to a table keyed by kernel name and returns the number of
+ * table entries; gab_profile_entry(i, ...) reads entry i (name: a static string such as "gab::k_...", total milliseconds, launches; -1 past the
+ * end); gab_profile_reset() empties the table.  (ABI 5) */
+int gab_profile_enable(int on);
+int gab_profile_collect(void);
+int gab_profile_entry(int32_t index, const char** name, double* total_ms, int64_t* launches);
+int gab_profile_reset(void);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GLS_ABI_VERSION 3
+#define GLS_ABI_VERSION 4
 #define GLS_OK 0
 #define GLS_E_ARG (-1)
 #define GLS_E_HIP (-2)
@@ -74,6 +74,16 @@ int gls_densification_stats(int32_t P, const int32_t* radii, const float* viewsp
  * read-modify-write chains (each a nonzero + gather + scatter with a host sync for the index count).  (ABI 3) */
 int gls_add_densification_stats(int32_t P, const uint8_t* update_filter, const float* viewspace_grad, int32_t grad_stride,
                                 float* xyz_gradient_accum, float* denom, void* stream);
+
+/* Optional per-kernel timing with hipEvents on the launch stream (what bench.py's roofline.all_kernels / roofline.step read for this library's
+ * kernels; libgsr has gsr_profile_*).  Off by default.  When on, every launch of this library is bracketed by an event pair;
+ * gls_profile_collect() synchronises the pending pairs, ADDS their elapsed times to a table keyed by kernel name and returns the number of
+ * table entries; gls_profile_entry(i, ...) reads entry i (name: a static string such as "gls::k_...", total milliseconds, launches; -1 past the
+ * end); gls_profile_reset() empties the table.  (ABI 4) */
+int gls_profile_enable(int on);
+int gls_profile_collect(void);
+int gls_profile_entry(int32_t index, const char** name, double* total_ms, int64_t* launches);
+int gls_profile_reset(void);
 
 #ifdef __cplusplus
 }

@@ -59,11 +59,11 @@ def test_gls_library_exports_every_declared_symbol():
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "gls.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(gls_[a-z0-9_]+)\s*\(", txt)))
     lib = _lib.gls()
-    assert len(names) == 11
+    assert len(names) == 15
     for n in names:
         assert hasattr(lib, n), f"include/gls.h declares {n} but libgls_hip.so does not export it"
         assert n in _lib.GLS_SYMBOLS
-    assert lib.gls_abi_version() == 3
+    assert lib.gls_abi_version() == 4
     assert lib.gls_partial_floats(1, 3, 802, 550) == 2 * 51 * 18 * 3   # (32 x 16 tiles since round 4)
     # argument errors are reported before any device work
     assert lib.gls_l1_ssim_forward(1, 3, 0, 5, None, None, 1.0, None, None, None, None) < 0

@@ -152,7 +152,7 @@ def run(train_iterations=200, n_iter=500):
             _lib.gsr_profile_enable(False)
         print("SAME_ASSET", json.dumps(dict(fps=out, rasterizer_kernels_us=prof, last_forward=R.last_forward_info())))
     """, 600)
-    summary["same_asset"] = dict(rc=rc, **(_json_after(txt, "SAME_ASSET") or {{}}))
+    summary["same_asset"] = dict(rc=rc, **(_json_after(txt, "SAME_ASSET") or {}))
 
     # 2) train.py: densify_and_prune at iterations 100 and 150; no evaluation pass (LPIPS wants downloaded weights)
     rc, el, txt = _launch("train", f"""
