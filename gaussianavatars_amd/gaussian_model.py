@@ -80,8 +80,10 @@ class GaussianModel:
         arrs = gio.load_ply(str(path), self.max_sh_degree)
         if spatial_sort is None:
             spatial_sort = spatial_order_default()
+        self._gaa_order = None
         if spatial_sort:
-            arrs = gio.spatial_sort(arrs, face_centers)
+            arrs, order = gio.spatial_sort(arrs, face_centers, return_order=True)
+            self._gaa_order = torch.as_tensor(np.asarray(order), dtype=torch.long)   # row i of the model = row _gaa_order[i] of the file (the permutation is kept)
         self.load_arrays(arrs, device=device)
 
     def save_ply(self, path):
@@ -318,4 +320,15 @@ def spatial_resort(model) -> torch.Tensor:
                 setattr(model, aux, t[perm])
         if binding is not None:
             model.binding = binding[perm]
+        # the order is recorded: row i of the model is row `_gaa_order[i]` of what was loaded (composed over every re-sort since; densification's new
+        # splats get -1), so that tools matching splats by index across PLYs / checkpoints can undo it
+        # (`inv = torch.empty_like(o); inv[o] = arange`: row j of the file is row inv[j] of the model)
+        prev = getattr(model, "_gaa_order", None)
+        if isinstance(prev, torch.Tensor) and prev.shape[0] == n:
+            model._gaa_order = prev.to(perm.device)[perm]
+        else:
+            base = torch.arange(n, device=perm.device)
+            if isinstance(prev, torch.Tensor) and prev.shape[0] < n:      # splats appended since the last sort: unknown to the loaded file
+                base = torch.cat([prev.to(perm.device), torch.full((n - prev.shape[0],), -1, dtype=torch.long, device=perm.device)])
+            model._gaa_order = base[perm]
     return perm

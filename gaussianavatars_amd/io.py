@@ -145,11 +145,13 @@ def reorder_splats(arrs: Dict[str, np.ndarray], perm: np.ndarray) -> Dict[str, n
             for k, v in arrs.items()}
 
 
-def spatial_sort(arrs: Dict[str, np.ndarray], face_centers: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
+def spatial_sort(arrs: Dict[str, np.ndarray], face_centers: Optional[np.ndarray] = None, return_order: bool = False):
     """The leaf dict with its splats in Morton order of their positions: `_xyz` for an unbound model; for a mesh-bound one (`binding` present)
     the centre of the splat's face on the template mesh (`face_centers` (F,3)), the local offset breaking ties."""
     if arrs.get("binding") is not None and face_centers is not None:
         pos = np.asarray(face_centers, np.float64)[np.asarray(arrs["binding"]).astype(np.int64)] + 1e-3 * np.asarray(arrs["_xyz"], np.float64)
     else:
         pos = np.asarray(arrs["_xyz"], np.float64)
-    return reorder_splats(arrs, morton_order(pos))
+    order = morton_order(pos)
+    out = reorder_splats(arrs, order)
+    return (out, order) if return_order else out      # order[i] = the input row that became row i

@@ -228,14 +228,26 @@ _late_count = os.environ.get("GSR_LATE_COUNT", "1") != "0"
 _late_slots: dict = {}   # (device index, raw stream) -> persistent slot
 
 
+_LATE_SLOTS_MAX = 8   # persistent slots the late waits may hold at once (of GSR_COUNT_SLOTS = 128: the rest stays with the recordings)
+
+
 def _late_slot(dev, stream) -> int:
+    """The persistent count slot of this (device, stream)'s late waits.  At most _LATE_SLOTS_MAX are held: code that keeps creating streams
+    (lanes re-created, per-iteration streams) recycles the least recently used one -- its frames have been waited for, a late wait never leaves a
+    frame in flight -- instead of draining the pool the recordings draw from; a recycled stream address simply gets a freshly reset slot."""
     k = (dev.index, stream)
-    slot = _late_slots.get(k)
+    slot = _late_slots.pop(k, None)
     if slot is None:
-        if not _free_slots:
+        if len(_late_slots) >= _LATE_SLOTS_MAX:
+            slot = _late_slots.pop(next(iter(_late_slots)))      # least recently used (dicts keep insertion order; a hit re-inserts below)
+        elif _free_slots:
+            slot = _free_slots.pop()
+        elif _late_slots:
+            slot = _late_slots.pop(next(iter(_late_slots)))
+        else:
             return -1   # (every slot handed to recordings: this call takes the blocking form)
-        slot = _late_slots[k] = _free_slots.pop()
         _lib.gsr().gsr_count_slot_overflow(slot, None, 1)
+    _late_slots[k] = slot
     return slot
 
 
