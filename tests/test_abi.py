@@ -227,3 +227,31 @@ def test_integration_stub_matches_the_header():
             depth -= ch in ")]"
             n += ch == "," and depth == 0
         assert n == len(_lib.GSR_SYMBOLS[fn][1]), f"{fn}: the stub passes {n} arguments, the prototype takes {len(_lib.GSR_SYMBOLS[fn][1])}"
+
+
+def test_compiled_host_loads_without_a_gpu_and_refuses_host_tensors():
+    """gaussianavatars_amd/gaa_host.so (csrc/gaa_host.cpp, built by `make host` / __graft_entry__.build()): the compiled host side of the
+    autograd nodes maps on a box without a GPU, resolves every C-ABI entry it launches through from the three libraries (init() raises on a
+    missing symbol or an ABI version other than the headers'), and -- like the Python twins -- has no CPU path: host tensors are an error."""
+    import pytest
+    import torch
+
+    from gaussianavatars_amd import _host, _lib
+
+    H = _host.load()
+    assert (H.GSR_ABI, H.GAB_ABI, H.GLS_ABI) == (_lib.GSR_ABI_VERSION, _lib.GAB_ABI_VERSION, _lib.GLS_ABI_VERSION)
+    assert (H.GSR_ABI, H.GAB_ABI, H.GLS_ABI) == (_header_abi("gsr.h"), _header_abi("gab.h"), _header_abi("gls.h"))
+    for name in ("init", "make_mesh_plan", "mesh_frames", "rasterize_bound", "l1_loss", "l1_ssim", "set_unit_seed", "l1_emit_state"):
+        assert callable(getattr(H, name)), name
+    a, b = torch.rand(3, 4, 5), torch.rand(3, 4, 5)
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        H.l1_loss(a, b, -1, False)
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        H.l1_ssim(a, b)
+    # the switch between the two host sides
+    prev = _host.set_enabled(False)
+    try:
+        assert _host.get() is None
+    finally:
+        _host.set_enabled(prev)
+    assert (_host.get() is H) == prev

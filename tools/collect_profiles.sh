@@ -2,7 +2,7 @@
 # Collects the rocprofv3 evidence for profiles/ on a GPU box:  bash tools/collect_profiles.sh <tag>   (e.g. r02_a)
 # kernel stats and the two PMC counters are separate runs (PMC is never combined with other trace domains).
 set -u
-TAG=${1:-r04_x}
+TAG=${1:-r05_x}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
@@ -34,4 +34,14 @@ G="--steps 200 --warmup 30 --no-cpu-baseline --no-kernel-profile --frame-streams
 timeout 200 python bench.py --graph $G 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3_graph.json
 timeout 200 python bench.py --graph --no-pin $G 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3_graph_unpinned.json
 timeout 200 python bench.py --no-pin $G 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3_eager_unpinned.json
+# round 5: the compiled host side against the Python twins on this box (same libraries, same kernels), host time per step, the reference's own scripts
+GAA_NATIVE_HOST=0 timeout 200 python bench.py --steps 150 --warmup 30 --no-cpu-baseline --frame-streams 0 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3_python_host.json
+GAA_NATIVE_HOST=0 timeout 200 python bench.py --no-pin --steps 200 --warmup 30 --no-cpu-baseline --no-kernel-profile --frame-streams 0 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cfg3_python_host_unpinned.json
+timeout 200 python tools/host_profile.py 300 > $OUT/${TAG}_host_profile.txt 2>&1
+timeout 200 python tools/host_profile.py 300 --small >> $OUT/${TAG}_host_profile.txt 2>&1
+(timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -5) > $OUT/${TAG}_gputests.log
+if [ -d _ref_scratch/reference ]; then
+  (timeout 900 python tools/ref_on_gpu.py run) > $OUT/${TAG}_ref_run.log 2>&1
+  for f in gpurun_out/r05_ref_*; do cp $f $OUT/${TAG}_$(basename $f | sed 's/^r05_//'); done
+fi
 ls -la $OUT
