@@ -848,8 +848,12 @@ def main():
             if pmc_stale and rank == 0:
                 print(f"bench.py: roofline.traffic comes from {os.path.basename(pmc_path)} -- {pmc_stale}", file=sys.stderr)
             for k, v in pmc_json.items():
-                name = k.replace("void ", "").split("::")[-1].split("<")[0]   # the k_tile_sort classes add up
-                name = PMC_ALIAS.get(name, name)                              # kernels that share one timing slot add up as well
+                base = k.replace("void ", "").split("<")[0].split("(")[0]
+                name = base.split("::")[-1]                                  # the k_tile_sort classes add up
+                if base.startswith(("gab::", "gls::")):
+                    name = base                                               # the binding / loss kernels keep their library prefix (all_kernels' keys)
+                else:
+                    name = PMC_ALIAS.get(name, name)                          # kernels that share one timing slot add up as well
                 f, w = pmc_raw.get(name, (0.0, 0.0))
                 pmc_raw[name] = (f + 1024.0 * v["FETCH_SIZE_KB_per_launch"], w + 1024.0 * v["WRITE_SIZE_KB_per_launch"])
             for name, (f, w) in pmc_raw.items():
