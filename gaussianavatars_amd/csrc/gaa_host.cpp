@@ -476,19 +476,26 @@ RasterResult rasterize_bound(const Tensor& xyz, const Tensor& means2D, const Ten
 // ======================================================================================================================================
 // 3. losses
 // ======================================================================================================================================
-Tensor g_unit_seed;            // loss.install_backward_seed's cached constant 1 (set_unit_seed)
+// loss.install_backward_seed's cached constant 1 (set_unit_seed).  Deliberately never destroyed: a device tensor released during static
+// destruction would reach the caching allocator after the HIP runtime has started to shut down.
+Tensor& unit_seed()
+{
+    static Tensor* seed = new Tensor();
+    return *seed;
+}
 uint32_t g_unit_seed_version = 0;
 std::atomic<int> g_l1_emit{1}, g_l1_misses{0};
 
 void set_unit_seed(const c10::optional<Tensor>& seed)
 {
-    g_unit_seed = seed.has_value() ? *seed : Tensor();
-    g_unit_seed_version = g_unit_seed.defined() ? g_unit_seed._version() : 0;
+    unit_seed() = seed.has_value() ? *seed : Tensor();
+    g_unit_seed_version = unit_seed().defined() ? unit_seed()._version() : 0;
     g_l1_emit = 1, g_l1_misses = 0;
 }
 inline bool is_unit_seed(const Tensor& g)
 {
-    return g_unit_seed.defined() && g.defined() && g.dim() == 0 && g.data_ptr() == g_unit_seed.data_ptr() && g_unit_seed._version() == g_unit_seed_version;
+    const Tensor& s = unit_seed();
+    return s.defined() && g.defined() && g.dim() == 0 && g.data_ptr() == s.data_ptr() && s._version() == g_unit_seed_version;
 }
 int64_t l1_emit_state() { return g_l1_emit.load(); }
 
