@@ -521,6 +521,9 @@ def main():
 
     run = make_runner(step_fn, my_frames, dist, device, post_step=(lambda: zero_grads(g)) if train else None)
     run_eager, graphed, lanes = run, None, []
+    # the instrumented pass further down runs on rank 0 ONLY: its runner must not contain the per-step all-reduce (a collective entered by one rank of N pairs
+    # with whatever the other ranks enter next -- their barrier -- and the run hangs; found in round 5, the N > 1 path on RCCL had never executed before)
+    run_profile = make_runner(step_fn, my_frames, None, device, post_step=(lambda: zero_grads(g)) if train else None)
     if args.streams > 1 and not args.graph and not dry:
         raise SystemExit("--streams needs --graph (two eager frame loops in one process are host-bound)")
     # (round 4) lanes x ranks: every rank deals ITS frames to its --streams recorded lanes; the lanes add their losses up on the device and the
@@ -653,6 +656,7 @@ def main():
             return lanes[0]["fixed_step"]()
 
         run_eager = make_runner(eager_fed, my_frames, dist, device, post_step=(lambda: zero_grads(g)) if train else None)
+        run_profile = make_runner(eager_fed, my_frames, None, device, post_step=(lambda: zero_grads(g)) if train else None)
 
         def graph_step(t):
             if lanes[0]["feeder"] is not None:
@@ -686,7 +690,7 @@ def main():
     if rank == 0 and not args.no_kernel_profile:
         _lib.gsr_profile_enable(True)
         _lib.launch_profile_enable(True)     # libgab / libgls: the binding and loss kernels of the step (round 5: the whole step in the roofline record)
-        run_eager(args.steps, args.warmup)
+        run_profile(args.steps, args.warmup)
         torch.cuda.synchronize(device)
         kern = _lib.gsr_profile_read()
         kern_other = _lib.launch_profile_read()

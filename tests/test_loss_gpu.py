@@ -275,3 +275,42 @@ def _l1_unit_seed_body(DEV, _lib, L):
         finally:
             lib.gls_l1_backward, lib.gls_l1_forward_grad = real_bwd, real_fwd_grad
             L.install_backward_seed(False)
+
+
+def test_zero_edit_pair_l1_then_ssim_becomes_one_fused_pass():
+    """What patch_reference() installs on utils.loss_utils (loss.l1_loss_paired / ssim_paired, SURVEY.md 8(f) N3 behind the zero-edit boundary): train.py:131-132
+    calls l1_loss(image, gt) and then ssim(image, gt).  First iteration: two stand-alone passes (and the pattern is noted); from the second on l1_loss runs the
+    FUSED pass and parks the SSIM scalar for the ssim() call that follows.  Values and the gradient of train.py's weighted sum equal the stand-alone functions';
+    a different pair, another window or a CPU of the pattern (three l1_loss calls without an ssim) fall back to the stand-alone kernels."""
+    from gaussianavatars_amd import loss as L
+
+    DEV = _dev()
+    L._PAIR.update(fused=False, last=None, parked=None, unclaimed=0)
+    gt = torch.rand(3, 97, 61, device=DEV)
+    want = None
+    for it in range(4):
+        img = (gt + 0.1 * torch.rand(3, 97, 61, device=DEV)).requires_grad_(True)
+        ref_img = img.detach().clone().requires_grad_(True)
+        ref = 0.8 * L.l1_loss(ref_img, gt) + 0.2 * (1.0 - L.ssim(ref_img, gt))
+        ref.backward()
+        l1 = L.l1_loss_paired(img, gt)
+        assert L._PAIR["fused"] is (it >= 1)
+        if it >= 1:
+            assert L._PAIR["parked"] is not None
+        ss = L.ssim_paired(img, gt)
+        assert L._PAIR["parked"] is None
+        loss = 0.8 * l1 + 0.2 * (1.0 - ss)
+        loss.backward()
+        assert abs(float(loss) - float(ref)) < 1e-6
+        err = float((img.grad - ref_img.grad).abs().max()) / float(ref_img.grad.abs().max())
+        assert err < 1e-5, (it, err)
+    # another image in between: the parked scalar is not handed out for it
+    img2 = torch.rand(3, 97, 61, device=DEV)
+    l1 = L.l1_loss_paired(img, gt)
+    assert L._PAIR["parked"] is not None
+    assert abs(float(L.ssim_paired(img2, gt)) - float(L.ssim(img2, gt))) < 1e-7 and L._PAIR["parked"] is None
+    # three fused results nobody collects: back to the plain L1 kernel
+    for _ in range(4):
+        L.l1_loss_paired(img, gt)
+    assert L._PAIR["fused"] is False
+    L._PAIR.update(fused=False, last=None, parked=None, unclaimed=0)

@@ -97,7 +97,7 @@ def test_bench_under_torch_distributed_run_on_nccl_at_one_gpu():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--dist-at-1", "--no-cpu-baseline", "--no-kernel-profile",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--dist-at-1", "--no-cpu-baseline",
            "--frame-streams", "0", "--min-seconds", "0.3", "--frames", "16"]
     r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=270)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -105,3 +105,5 @@ def test_bench_under_torch_distributed_run_on_nccl_at_one_gpu():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["steps"] == 10
     assert "RCCL" in d["config"]["parallelism"] and "all-reduce" in d["config"]["parallelism"]
+    # the instrumented pass (rank 0 only: its runner carries no collective -- one entered by a single rank of N would pair with the others' barrier) ran as well
+    assert d["roofline"] is not None and d["roofline"]["step"]["launches_per_step"] >= 15
