@@ -411,9 +411,11 @@ def main():
                          "cfg4 = configs[3] 200k-splat 300-frame sequence fwd+bwd; cfg5 = configs[4] 2M-splat 1600x1100 forward stress")
     ap.add_argument("--rounds", type=int, default=3, help="minimum number of timed rounds of --steps steps each (the median round is reported)")
     ap.add_argument("--min-seconds", type=float, default=3.0, help="minimum total timed duration: rounds are added until it is reached")
-    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+    ap.add_argument("--backend", choices=["nccl", "gloo", "gloo_gpu"], default="nccl",
                     help="nccl (= RCCL): the measured path.  gloo: DRY run of the multi-rank plumbing on CPU -- a few hundred splats, composed-torch "
-                         "binding, the rasterizer stubbed at its autograd Function; the line is marked as such and is not a measurement")
+                         "binding, the rasterizer stubbed at its autograd Function; the line is marked as such and is not a measurement.  gloo_gpu: the REAL step "
+                         "(HIP libraries, compiled host) on N ranks that SHARE the visible GPU(s), collectives over gloo -- the multi-rank control flow of the measured "
+                         "path (per-step all-reduce, barriers, rank-0-only passes) on a one-GPU box, where RCCL refuses two ranks on one device; marked, not a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--spatial-sort", action="store_true", help="(the default since round 4; kept so that older command lines still parse)")
@@ -465,6 +467,7 @@ def main():
         raise SystemExit(f"bench.py --gpus {args.gpus} inside a launcher with WORLD_SIZE={world}: the two must agree "
                          "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N)")
     dry = args.backend == "gloo"
+    shared_gpu = args.backend == "gloo_gpu"
     if dry:   # plumbing check without a GPU: tiny scene, reference-shaped composed-torch binding, stubbed rasterizer Function
         device = torch.device("cpu")
         args.splats, args.width, args.height, args.frames = min(args.splats, 12_000), 64, 48, min(args.frames, 16)
@@ -474,6 +477,8 @@ def main():
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: there is no CPU path for the rasterizer (--backend gloo is the dry run of the multi-rank plumbing)")
+        if shared_gpu:     # control-flow run: the ranks share whatever is visible
+            local_rank = local_rank % torch.cuda.device_count()
         if torch.cuda.device_count() <= local_rank:
             raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but {torch.cuda.device_count()} GPU(s) visible")
         torch.cuda.set_device(local_rank)
@@ -483,7 +488,7 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if dry:
+        if dry or shared_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -916,7 +921,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic" if not dry else "DRY RUN (--backend gloo, CPU): rasterizer stubbed at its autograd Function, composed-torch binding, "
+            "data": ("synthetic" if not shared_gpu else "synthetic; NOT A MEASUREMENT (--backend gloo_gpu): %d ranks share %d GPU(s), collectives over gloo -- the multi-rank "
+                                                        "control flow of the measured path on real kernels" % (world, torch.cuda.device_count())) if not dry else "DRY RUN (--backend gloo, CPU): rasterizer stubbed at its autograd Function, composed-torch binding, "
                                                 "reduced scene -- checks the multi-rank plumbing, measures nothing",
             "config": {
                 "workload": {"cfg3": "BASELINE configs[2]: %d mesh-bound SH-3 splats (synthetic stand-in for media/306), %dx%d (HxW), "
@@ -934,7 +940,7 @@ def main():
                 "num_rendered": I_rect, "num_binned": I_binned, "tile_culling": bool(info.get("tile_culling", False)),
                 "binning_path": {0: "rank", 1: "depth-ordered scatter", 2: "per-tile sort"}[path] + (f" ({bands} bands of tile rows)" if path == 0 and bands > 1 else ""),
                 "visible_fraction": round(vis, 4), "binding": args.binding,
-                "parallelism": (((f"frame-parallel x{n_gpus}: {dist.get_world_size()} {'gloo (dry run)' if dry else 'RCCL (torch nccl)'} rank(s), one process per GPU, "
+                "parallelism": (((f"frame-parallel x{n_gpus}: {dist.get_world_size()} {'gloo (dry run)' if dry else ('gloo, ranks sharing the GPU (control-flow run)' if shared_gpu else 'RCCL (torch nccl)')} rank(s), one process per GPU, "
                                   f"frames per rank {counts}, one asynchronous scalar all-reduce (loss) per step") if dist is not None else
                                  f"one process, one GPU, {counts[0]} frames in turn; no collective")
                                 + (f"; {len(lanes)} frame streams inside the GPU (independent frames overlap; ms_per_step is elapsed / steps, "

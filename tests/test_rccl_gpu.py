@@ -107,3 +107,24 @@ def test_bench_under_torch_distributed_run_on_nccl_at_one_gpu():
     assert "RCCL" in d["config"]["parallelism"] and "all-reduce" in d["config"]["parallelism"]
     # the instrumented pass (rank 0 only: its runner carries no collective -- one entered by a single rank of N would pair with the others' barrier) ran as well
     assert d["roofline"] is not None and d["roofline"]["step"]["launches_per_step"] >= 15
+
+
+@pytest.mark.timeout(290)
+def test_two_ranks_sharing_the_gpu_run_the_multi_rank_control_flow():
+    """RCCL refuses two ranks on one device, so a one-GPU box cannot run N = 2 on `nccl`; `--backend gloo_gpu` runs the REAL step (HIP libraries, compiled host)
+    on two ranks that share the GPU with the collectives over gloo: the per-step asynchronous all-reduce, the barriers, the MAX-reduced round times and --
+    what this test exists for -- the passes only rank 0 makes (the instrumented pass must not enter a collective: round 5 found that it did, which would have
+    hung the first N > 1 run) all execute as they will on N GPUs.  The line says it is not a measurement."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo_gpu", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--frame-streams", "0",
+           "--min-seconds", "0.3", "--frames", "16", "--no-pin"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=270)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                     # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "NOT A MEASUREMENT" in d["data"]
+    assert "frames per rank [8, 8]" in d["config"]["parallelism"]
+    assert d["roofline"] is not None and d["roofline"]["step"]["launches_per_step"] >= 15
