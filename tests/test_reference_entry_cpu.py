@@ -173,3 +173,29 @@ def test_train_render_and_fps_benchmark_dataset_run_unchanged(tmp_path):
     fps = [float(ln.split(":")[1].split(" [")[0]) for ln in lines if ln.startswith("FPS:")]
     assert len(fps) == 3 and all(f > 0 for f in fps)
     assert int([ln for ln in lines if ln.startswith("CALLS")][0].split()[1]) == 6
+
+
+@needs_ref
+def test_ref_on_gpu_stage_puts_an_ignored_scratch_copy_with_generated_assets(tmp_path, monkeypatch):
+    """tools/ref_on_gpu.py stage (what precedes the `gpurun` call that runs the reference's scripts on the MI355X): the scratch checkout is a COPY of the
+    reference's files (nothing of ours mixed in, nothing edited), the generated assets are in the places the unchanged scripts open, and git ignores all of it."""
+    import importlib.util
+    import subprocess
+
+    spec = importlib.util.spec_from_file_location("ref_on_gpu", os.path.join(ROOT, "tools", "ref_on_gpu.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    scratch = str(tmp_path / "_ref_scratch")
+    monkeypatch.setattr(tool, "SCRATCH", scratch)
+    monkeypatch.setattr(tool, "REF", os.path.join(scratch, "reference"))
+    tool.stage(n_splats=12_000, n_timesteps=2, width=112, height=160)
+    ref = os.path.join(scratch, "reference")
+    for script in ("train.py", "render.py", "fps_benchmark_demo.py", "fps_benchmark_dataset.py", os.path.join("scene", "gaussian_model.py")):
+        assert open(os.path.join(ref, script), "rb").read() == open(os.path.join(REF, script), "rb").read(), script      # byte for byte the reference's file
+    for asset in ("flame2023.pkl", "FLAME_masks.pkl", "head_template_mesh.obj"):
+        assert os.path.exists(os.path.join(ref, "flame_model", "assets", "flame", asset)), asset
+    assert os.path.exists(os.path.join(scratch, "avatar", "point_cloud.ply")) and os.path.exists(os.path.join(scratch, "avatar", "flame_param.npz"))
+    assert os.path.exists(os.path.join(scratch, "data", "transforms_train.json")) and os.path.exists(os.path.join(scratch, "STAGED.json"))
+    # the real location is git-ignored (never committed): `git check-ignore` knows the rule
+    r = subprocess.run(["git", "check-ignore", "-q", "_ref_scratch/reference/train.py"], cwd=ROOT)
+    assert r.returncode == 0
