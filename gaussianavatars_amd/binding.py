@@ -8,10 +8,11 @@ reference these kernels are tested against); nothing here falls back to it.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
-from . import _lib
+from . import _host, _lib
 
 
 def _p(t):
@@ -113,8 +114,6 @@ def _prepared_rig(head, rig, shape_flat, so_flat):
 
 
 def _sequence_mode() -> str:
-    import os
-
     return os.environ.get("GAA_MESH_SEQUENCE", "off")
 
 
@@ -407,8 +406,6 @@ def vertex_corner_csr(faces: torch.Tensor, num_verts: int):
 def _mesh_backward_mode() -> str:
     """"merged" (default): the face-frame backward and the skinning backward are one launch (gab_mesh_backward_prepared: corner gather,
     no d_verts buffer); "split": the two launches it replaced -- kept for A/B tests and for what the merged entry does not cover."""
-    import os
-
     return os.environ.get("GAA_MESH_BWD", "merged")
 
 
@@ -484,8 +481,6 @@ def _mesh_plan(H, head, fp: dict, faces):
     tables -- made once, kept on the head, and re-made when anything it was made from is replaced or modified in place (object identity + version
     counters of shape / static_offset / faces, identity of the five rig buffers, the two mode switches).  None: this call is outside what the native
     node takes (a gradient for shape or static_offset, the classic three-kernel FLAME, the split backward, the sequence table, other dtypes)."""
-    import os
-
     shape, so = fp["shape"], fp.get("static_offset")
     bufs = head.__dict__.get("_buffers")                      # an nn.Module's registered buffers (no __getattr__ walk), else plain attributes
     if bufs is None or any(n not in bufs for n in _RIG_BUFFERS):
@@ -519,8 +514,6 @@ def mesh_frames_timestep(head, flame_param: dict, t: int, faces):
     """select_mesh_by_timestep + update_mesh_properties in one autograd node:
     -> (verts (1,V,3), verts_cano (1,V,3), face_center, face_orien_mat, face_scaling, face_orien_quat)."""
     fp = flame_param
-    from . import _host
-
     H = _host.get()
     if H is not None:
         expr, rot, neck, jaw, eyes, trans = fp["expr"], fp["rotation"], fp["neck_pose"], fp["jaw_pose"], fp["eyes_pose"], fp["translation"]

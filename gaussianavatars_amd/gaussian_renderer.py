@@ -8,7 +8,9 @@ import math
 
 import torch
 
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from . import patch as _patch   # (module level: a function-level `from . import x` costs ~1.5 us per call on a step whose host side is counted in microseconds)
+from .loss import l1_loss as _l1_loss
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_bound, rasterize_leaves
 
 C0 = 0.28209479177387814
 
@@ -66,9 +68,7 @@ def _bound_fast_path(pc, pipe, override_color) -> bool:
     "unfused" models, `pc.bound_render = False`) takes the reference-shaped path below."""
     if override_color is not None or pipe.compute_cov3D_python or pipe.convert_SHs_python:
         return False
-    from .patch import _default_impl
-
-    if getattr(pc, "binding_impl", _default_impl()) == "unfused" or not getattr(pc, "bound_render", True):
+    if getattr(pc, "binding_impl", _patch._default_impl()) == "unfused" or not getattr(pc, "bound_render", True):
         return False
     if not getattr(type(pc), "_gaa_patched", False) or getattr(pc, "get_features_split", None) is None:
         return False
@@ -76,9 +76,6 @@ def _bound_fast_path(pc, pipe, override_color) -> bool:
 
 
 def _render_bound(viewpoint_camera, pc, pipe, bg_color, scaling_modifier):
-    from .patch import binding_csr_cached
-    from .rasterizer import rasterize_bound, rasterize_leaves
-
     unbound = getattr(pc, "binding", None) is None
     if not unbound and pc.face_center is None:          # same lazy initialisation as the reference's accessors (scene/gaussian_model.py:119-120)
         pc.select_mesh_by_timestep(0)
@@ -94,7 +91,7 @@ def _render_bound(viewpoint_camera, pc, pipe, bg_color, scaling_modifier):
     if unbound:
         image, radii, visible = rasterize_leaves(pc._xyz, screenspace_points, dc, rest, pc._opacity, pc._scaling, pc._rotation, raster_settings)
         return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": visible, "radii": radii}
-    csr = binding_csr_cached(pc, pc.face_center.shape[0])
+    csr = _patch.binding_csr_cached(pc, pc.face_center.shape[0])
     image, radii, visible = rasterize_bound(pc._xyz, screenspace_points, dc, rest, pc._opacity, pc._scaling, pc._rotation, pc.face_orien_mat,
                                             pc.face_scaling, pc.face_center, pc.face_orien_quat, pc.binding, csr, raster_settings)
     return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": visible, "radii": radii}
@@ -161,6 +158,4 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
 
 def l1_loss(network_output, gt):
     """utils/loss_utils.py:17-18, on the fused kernel of include/gls.h (see loss.py)."""
-    from .loss import l1_loss as _l1
-
-    return _l1(network_output, gt)
+    return _l1_loss(network_output, gt)

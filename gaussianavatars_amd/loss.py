@@ -8,10 +8,11 @@ step should call).  There is no torch fallback: a CPU tensor or a missing librar
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
-from . import _lib
+from . import _host, _lib
 
 
 def _p(t):
@@ -86,8 +87,6 @@ def install_backward_seed(enable: bool = True) -> bool:
 
 def _tell_host_seed(seed) -> None:
     """The compiled host's L1 node recognises the unit seed by its storage, like _is_unit_seed below (csrc/gaa_host.cpp: set_unit_seed)."""
-    from . import _host
-
     if _host.enabled() and (seed is not None or _host._mod is not None):
         _host.get().set_unit_seed(seed)
 
@@ -181,8 +180,6 @@ def l1_ssim(image: torch.Tensor, gt: torch.Tensor):
     l1 == l1_loss(image, gt), ssim == ssim(image, gt) (size_average=True)."""
     image, gt = _as_input(image, "image"), _as_input(gt, "gt")
     if image.dim() == 3 and image.shape == gt.shape and not (gt.requires_grad and torch.is_grad_enabled()):
-        from . import _host
-
         H = _host.get()
         if H is not None:   # the compiled host's node (csrc/gaa_host.cpp: l1_ssim): same two launches, no interpreter in the backward
             l1, ss = H.l1_ssim(image, gt)
@@ -220,8 +217,6 @@ _L1_EMIT = {"on": True, "misses": 0}   # the grad-emitting forward is kept while
 
 
 def _l1_emit() -> bool:
-    import os
-
     forced = os.environ.get("GAA_L1_EMIT_GRAD")
     if forced is not None:
         return forced != "0"
@@ -282,12 +277,8 @@ def l1_loss(network_output: torch.Tensor, gt: torch.Tensor):
     if network_output.shape != gt.shape:
         gt = gt.expand_as(network_output)
     a, b = _as_input(network_output, "network_output"), _as_input(gt, "gt")
-    from . import _host
-
     H = _host.get()
     if H is not None:   # the compiled host's node (csrc/gaa_host.cpp: l1_loss)
-        import os
-
         forced = os.environ.get("GAA_L1_EMIT_GRAD")
         return H.l1_loss(a, b, -1 if forced is None else int(forced != "0"), bool(getattr(torch.Tensor.backward, "__gaussianavatars_amd_seed__", False)))
     return _L1.apply(a, b)

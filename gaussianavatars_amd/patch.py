@@ -28,6 +28,8 @@ import sys
 
 import torch
 
+from . import binding as fused
+
 _ORIG: dict = {}   # (class, attribute) -> the original attribute, for unpatch() and the "unfused" opt-out
 
 
@@ -57,8 +59,6 @@ def _same(cache, leaves, faces, binding, grad) -> bool:
 def binding_csr_cached(self, num_faces: int):
     """The per-face CSR of `self.binding` for the atomic-free bind backward; rebuilt whenever the binding tensor is
     replaced (densification: cat / prune), modified in place, or the face count changes."""
-    from . import binding as fused
-
     b = self.binding
     hit = getattr(self, "_gaa_csr", None)
     if hit is None or hit[0] is not b or hit[1] != b._version or hit[2] != num_faces or hit[3][0].numel() != b.shape[0]:
@@ -73,8 +73,6 @@ def bound(self):
     when the mesh, the binding or a leaf does, so they are cached on exactly that.  The shared autograd node keeps its
     inputs for its whole life (binding._Keep), so it can be walked by several backward passes like the reference's
     per-call graphs can."""
-    from . import binding as fused
-
     leaves = (self._xyz, self._scaling, self._rotation, self._opacity)
     faces = (self.face_orien_mat, self.face_scaling, self.face_center, self.face_orien_quat)
     grad = torch.is_grad_enabled()
@@ -136,8 +134,6 @@ def _get_features_split(self):
 def _select_mesh_by_timestep(self, timestep, original=False):
     if not _fused(self):
         return _ORIG[(type(self)._gaa_patched_base, "select_mesh_by_timestep")](self, timestep, original)
-    from . import binding as fused
-
     self.timestep = timestep
     fp = self.flame_param_orig if original and self.flame_param_orig is not None else self.flame_param
     faces = self.flame_model.faces
@@ -149,8 +145,6 @@ def _select_mesh_by_timestep(self, timestep, original=False):
 def _update_mesh_properties(self, verts, verts_cano):
     if not _fused(self):
         return _ORIG[(type(self)._gaa_patched_base, "update_mesh_properties")](self, verts, verts_cano)
-    from . import binding as fused
-
     faces = self.flame_model.faces
     c, R, s, q = fused.face_frames(verts.squeeze(0), faces)
     self.face_center, self.face_orien_mat, self.face_scaling, self.face_orien_quat = c, R, s, q
@@ -181,8 +175,6 @@ def _make_flame_forward(cls):
             kw = dict(zero_centered_at_root_node=zero_centered_at_root_node, return_landmarks=return_landmarks,
                       return_verts_cano=return_verts_cano, static_offset=static_offset, dynamic_offset=dynamic_offset)
             return orig(self, shape, expr, rotation, neck, jaw, eyes, translation, **kw)
-        from . import binding as fused
-
         verts, v_shaped = fused.flame_forward(_prepared(self), shape, expr, rotation, neck, jaw, eyes, translation, static_offset)
         return [verts, v_shaped] if return_verts_cano else verts
 

@@ -19,7 +19,7 @@ from typing import NamedTuple, Optional
 import torch
 from torch import nn
 
-from . import _lib
+from . import _host, _lib
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_bound", "rasterize_leaves", "last_forward_info", "set_tile_culling", "deferred_count",
            "get_tile_culling", "set_exact_scale_grad", "set_deterministic", "set_fast_blend", "set_poison_state"]
@@ -345,8 +345,6 @@ def _native_leaves_entry(H, xyz, means2D, sh_dc, sh_rest, opacity_logit, log_sca
 
 def _apply_leaves_entry(*args):
     if _late_count and _deferred is None and not _poison_state:
-        from . import _host
-
         H = _host.get()
         if H is not None:
             out = _native_leaves_entry(H, *args)
