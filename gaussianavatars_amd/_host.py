@@ -38,9 +38,25 @@ def load():
         import torch  # noqa: F401  (the module links against torch's libraries)
 
         _lib.gsr(), _lib.gab(), _lib.gls()      # mapped (after torch) and ABI-checked before the module resolves their symbols
-        spec = importlib.util.spec_from_file_location("gaussianavatars_amd.gaa_host", HOST_LIB_PATH)
-        mod = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mod)
+        def _import():
+            spec = importlib.util.spec_from_file_location("gaussianavatars_amd.gaa_host", HOST_LIB_PATH)
+            m = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(m)
+            return m
+
+        try:
+            mod = _import()
+        except ImportError as e:
+            # a module built against another torch / interpreter (an upgrade, another venv): undefined symbols at import.  One rebuild against
+            # THIS interpreter, then an error that says what to do -- never a silent switch to the Python host side.
+            import subprocess
+            import sys
+
+            r = subprocess.run([sys.executable, os.path.join(_HERE, "csrc", "build_host.py"), "--force"], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"{HOST_LIB_PATH} does not import under this interpreter ({e}) and rebuilding it failed:\n{(r.stdout + r.stderr)[-1500:]}\n"
+                                   "build it with `python gaussianavatars_amd/csrc/build_host.py --force`, or set GAA_NATIVE_HOST=0 to run the Python host side") from e
+            mod = _import()
         if (mod.GSR_ABI, mod.GAB_ABI, mod.GLS_ABI) != (_lib.GSR_ABI_VERSION, _lib.GAB_ABI_VERSION, _lib.GLS_ABI_VERSION):
             raise RuntimeError(f"gaa_host.so was built for ABI {(mod.GSR_ABI, mod.GAB_ABI, mod.GLS_ABI)}: rebuild it (csrc/build_host.py --force)")
         mod.init(_lib.GSR_LIB_PATH, _lib.GAB_LIB_PATH, _lib.GLS_LIB_PATH)

@@ -254,7 +254,7 @@ std::mutex layout_mutex;
 std::map<std::tuple<int64_t, int, int>, Layouts> layout_cache;
 std::map<std::tuple<int64_t, int, int, int64_t, int>, GsrBinningLayout> binning_cache;
 
-const Layouts& layouts(int64_t P, int W, int H)
+Layouts layouts(int64_t P, int W, int H)   // (by value: the caches are cleared under the lock when they grow, a reference would dangle on a concurrent call)
 {
     std::lock_guard<std::mutex> lock(layout_mutex);
     auto key = std::make_tuple(P, W, H);
@@ -267,7 +267,7 @@ const Layouts& layouts(int64_t P, int W, int H)
     }
     return it->second;
 }
-const GsrBinningLayout& binning_layout(int64_t cap, int W, int H, int64_t P, int mode)
+GsrBinningLayout binning_layout(int64_t cap, int W, int H, int64_t P, int mode)
 {
     std::lock_guard<std::mutex> lock(layout_mutex);
     auto key = std::make_tuple(cap, W, H, P, mode);
@@ -419,8 +419,8 @@ RasterResult rasterize_bound(const Tensor& xyz, const Tensor& means2D, const Ten
 
     DeviceGuard guard(xyz.device().index());
     void* stream = cur_stream(xyz);
-    const Layouts& L = layouts(P, (int)W, (int)H);
-    const GsrBinningLayout& bl = binning_layout(capacity, (int)W, (int)H, P, (int)tile_culling);
+    const Layouts L = layouts(P, (int)W, (int)H);
+    const GsrBinningLayout bl = binning_layout(capacity, (int)W, (int)H, P, (int)tile_culling);
     auto up = [](size_t n) { return (n + 255) / 256 * 256; };
     const size_t off_img = up(L.geom.total), off_binning = off_img + up(L.img.total), total = off_binning + up(bl.total);
     RasterResult r;
@@ -673,7 +673,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("init", &init, "resolve the C ABI from the three loaded libraries");
     py::class_<MeshPlan, std::shared_ptr<MeshPlan>>(m, "MeshPlan");
     m.def("make_mesh_plan", &make_mesh_plan);
-    m.def("mesh_frames", &mesh_frames);
+    // (the GIL is released inside the four per-frame entries: tensors in, tensors / a plain struct out, no Python object touched -- rasterize_bound waits for
+    //  the frame's instance count in there, and the ctypes twins never held the GIL across a native call either)
+    m.def("mesh_frames", &mesh_frames, py::call_guard<py::gil_scoped_release>());
     py::class_<RasterResult>(m, "RasterResult")
         .def_readonly("color", &RasterResult::color)
         .def_readonly("radii", &RasterResult::radii)
@@ -686,11 +688,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         .def_readonly("path", &RasterResult::path)
         .def_readonly("nbands", &RasterResult::nbands)
         .def_readonly("fitted", &RasterResult::fitted);
-    m.def("rasterize_bound", &rasterize_bound);
+    m.def("rasterize_bound", &rasterize_bound, py::call_guard<py::gil_scoped_release>());
     m.def("set_unit_seed", &set_unit_seed);
     m.def("l1_emit_state", &l1_emit_state);
-    m.def("l1_loss", &l1_loss);
-    m.def("l1_ssim", &l1_ssim);
+    m.def("l1_loss", &l1_loss, py::call_guard<py::gil_scoped_release>());
+    m.def("l1_ssim", &l1_ssim, py::call_guard<py::gil_scoped_release>());
     m.attr("GSR_ABI") = GSR_ABI_VERSION;
     m.attr("GAB_ABI") = GAB_ABI_VERSION;
     m.attr("GLS_ABI") = GLS_ABI_VERSION;

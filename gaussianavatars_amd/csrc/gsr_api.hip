@@ -122,6 +122,10 @@ gsr::Settings to_dev_settings(const GsrSettings* s)
     d.forward_only = s->forward_only;
     d.deterministic = s->deterministic;
     d.fast_blend = 0;   // the callers set the effective mode once the binning path is known (fast_effective)
+    // fast blend: the entry (a multiple of the backward's segment) at which a quadrant's lone walk parks its state for the continuation kernel
+    // (gsr_forward.hip, k_render<true, true>); GSR_CONT_CHUNKS=0 keeps every walk in one piece (A/B runs)
+    static const int cont_chunks = [] { const char* e = getenv("GSR_CONT_CHUNKS"); const int v = e ? atoi(e) : GSR_CONT_CHUNKS_DEFAULT; return v < 0 ? 0 : v; }();
+    d.cont_chunks = cont_chunks;
     d.bg = s->bg;
     d.viewmatrix = s->viewmatrix;
     d.projmatrix = s->projmatrix;
@@ -355,8 +359,8 @@ int gsr_image_layout(int32_t width, int32_t height, GsrImageLayout* o)
     o->ck = off;        off = align_up(off + hw * 16 * (GSR_BWD_SEGMENTS - 1), A);
     o->gmax = off;      off = align_up(off + 4, A);
     const size_t tiles = (size_t)((width + GSR_BLOCK_X - 1) / GSR_BLOCK_X) * (size_t)((height + GSR_BLOCK_Y - 1) / GSR_BLOCK_Y);
-    const size_t unit_cap = (4 * tiles + GSR_UNIT_LISTS - 1) / GSR_UNIT_LISTS * (size_t)GSR_BWD_SEGMENTS;
-    o->units = off;     off = align_up(off + ((size_t)32 * GSR_UNIT_LISTS + (size_t)GSR_UNIT_LISTS * unit_cap) * 4, A);
+    // the unit lists, then the forward blend's continuation area (gsr_forward.hip: header, the list of parked quadrants, 1280 bytes of state per quadrant slot)
+    o->units = off;     off = align_up(off + (gsr::cont_hdr_word(tiles) + GSR_CONT_HDR_WORDS + 4 * tiles + 4 * tiles * (size_t)GSR_CONT_STATE_FLOATS) * 4, A);
     o->total = off + A;
     return 0;
 }
@@ -439,6 +443,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         HIP_TRY(hipMemsetAsync(tile_count, 0, (size_t)tiles * 4, stream));
         HIP_TRY(hipMemsetAsync(rect_total, 0, 8, stream));
         HIP_TRY(hipMemsetAsync(im + il.units, 0, (size_t)32 * GSR_UNIT_LISTS * 4, stream));
+        HIP_TRY(hipMemsetAsync(im + il.units + gsr::cont_hdr_word((size_t)tiles) * 4, 0, (size_t)GSR_CONT_HDR_WORDS * 4, stream));
     }
 
     gsr::PreprocessArgs pa;
@@ -715,11 +720,23 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     }   // per-tile sort path
     {
         TIMED(GSR_K_RENDER, stream);
-        hipLaunchKernelGGL(ds.fast_blend ? gsr::k_render<true> : gsr::k_render<false>, dim3(tiles), dim3(256), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
+        auto* const render_k = ds.fast_blend ? &gsr::k_render<true, false> : &gsr::k_render<false, false>;
+        hipLaunchKernelGGL(render_k, dim3(tiles), dim3(256), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
                            (const uint32_t*)qcount, (const float4*)pa.grec, (const uint32_t*)qpos, write_lists ? (const uint32_t*)qlist : nullptr, (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib),
                            (uint32_t*)(im + il.n_contrib_q), (float*)(im + il.c_final), (float4*)(im + il.ck), out_color, cap,
-                           (const unsigned long long*)total_dev, (uint32_t*)(im + il.units));
+                           (const unsigned long long*)total_dev, (uint32_t*)(im + il.units), tiles);
         KERNEL_CHECK("k_render", stream, dbg);
+        if (ds.fast_blend && ds.cont_chunks > 0) {
+            // the quadrants whose walk reached entry cont_chunks * GSR_BWD_SEGMENT with pixels still open: four chunks in flight per quadrant
+            // (a fixed grid whose workgroups pull the parked quadrants; the count stays on the device)
+            static const int cont_grid = [] { const char* e = getenv("GSR_CONT_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : GSR_CONT_GRID_DEFAULT; }();
+            const int cgrid = 4 * tiles < cont_grid ? 4 * tiles : cont_grid;
+            hipLaunchKernelGGL((gsr::k_render<true, true>), dim3(cgrid), dim3(256), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
+                               (const uint32_t*)qcount, (const float4*)pa.grec, (const uint32_t*)qpos, write_lists ? (const uint32_t*)qlist : nullptr, (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib),
+                               (uint32_t*)(im + il.n_contrib_q), (float*)(im + il.c_final), (float4*)(im + il.ck), out_color, cap,
+                               (const unsigned long long*)total_dev, (uint32_t*)(im + il.units), tiles);
+            KERNEL_CHECK("k_render_cont", stream, dbg);
+        }
     }
 
     if (deferred) {   // the count of this frame is not known yet: the caller checks its slot after the fact

@@ -54,6 +54,7 @@ struct Settings {  // by-value kernel argument: scalars + the four device pointe
     int forward_only;
     int deterministic;
     int fast_blend;      // EFFECTIVE fast mode of this frame (gsr_api.hip: off with `deterministic` and on the per-tile sort path)
+    int cont_chunks;     // fast blend: a quadrant's lone walk hands over to the continuation kernel at entry cont_chunks * GSR_BWD_SEGMENT (0: never)
     const float* __restrict__ bg;
     const float* __restrict__ viewmatrix;
     const float* __restrict__ projmatrix;
@@ -577,11 +578,22 @@ template <int KEYS, int THREADS>
 __global__ void k_tile_sort(uint32_t n_lo, uint32_t n_hi, int gx, const uint32_t* tile_order, const uint32_t* tile_count, const uint32_t* tile_start, unsigned long long* keys,
                             uint32_t* point_list, uint32_t* qlist, uint32_t* qpos, uint32_t* qcount, uint32_t* qstart, const float4* grec,
                             unsigned long long capacity, const unsigned long long* total_dev);
-template <bool FAST>
+template <bool FAST, bool CONT>
 __global__ void k_render(Settings s, const uint32_t* tile_order, const uint32_t* qstart, const uint32_t* qcount, const float4* grec,
                          const uint32_t* qpos, const uint32_t* qlist, float* final_T,
                          uint32_t* n_contrib, uint32_t* n_contrib_q, float* c_final, float4* ck, float* out_color, unsigned long long capacity,
-                         const unsigned long long* total_dev, uint32_t* units);
+                         const unsigned long long* total_dev, uint32_t* units, int tiles);
+// the continuation area behind the unit lists of GsrImageLayout.units (k_render): header words, then the list, then the parked states
+#define GSR_CONT_HDR_WORDS 64
+#ifndef GSR_CONT_CHUNKS_DEFAULT
+#define GSR_CONT_CHUNKS_DEFAULT 3   // hand-over at entry 180 (swept on the MI355X: DESIGN.md)
+#endif
+#ifndef GSR_CONT_GRID_DEFAULT
+#define GSR_CONT_GRID_DEFAULT 768   // workgroups of the continuation kernel (three per CU); they pull the parked quadrants in turn
+#endif
+#define GSR_CONT_STATE_FLOATS 320
+__host__ __device__ inline size_t unit_list_cap(size_t tiles) { return (4 * tiles + GSR_UNIT_LISTS - 1) / GSR_UNIT_LISTS * (size_t)GSR_BWD_SEGMENTS; }
+__host__ __device__ inline size_t cont_hdr_word(size_t tiles) { return (size_t)32 * GSR_UNIT_LISTS + (size_t)GSR_UNIT_LISTS * unit_list_cap(tiles); }
 __global__ void k_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present);
 template <bool DET, bool FAST>
 __global__ void k_render_bwd(Settings s, const uint32_t* tile_order, const uint32_t* qstart, const uint32_t* qcount, const float4* grec,

@@ -38,10 +38,12 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         for (int t = i; t < a.nb; t += (int)(gridDim.x * blockDim.x)) a.bcount[t] = 0u;
         // the backward's work lists start empty (k_render<true> appends): the image state is a fresh, uninitialised allocation per forward
         if (i < GSR_UNIT_LISTS) a.units[32 * i] = 0u;
+        if (i < 2) a.units[cont_hdr_word((size_t)a.tiles) + 32 * i] = 0u;   // (and the continuation area's two counters)
     } else {
         // this frame's tile histogram starts at zero (k_count runs after this kernel)
         for (int t = i; t < a.tiles; t += (int)(gridDim.x * blockDim.x)) a.tile_count[t] = 0u;
         if (i < GSR_UNIT_LISTS) a.units[32 * i] = 0u;   // the backward's work lists start empty (k_render<true> appends)
+        if (i < 2) a.units[cont_hdr_word((size_t)a.tiles) + 32 * i] = 0u;   // ... and no quadrant is parked for the continuation kernel, which has pulled none
         if (i == 0) *a.rect_total = 0ull;
         if (a.pstat)   // rank path: the depth-bucket histogram and its fill cursors start at zero as well
             for (int t = i; t < a.nb; t += (int)(gridDim.x * blockDim.x)) { a.bcount[t] = 0u; a.bcursor[t] = 0u; }
@@ -795,7 +797,20 @@ template __global__ void k_tile_sort<GSR_SORT_XL_KEYS, 1024>(uint32_t, uint32_t,
 __device__ unsigned long long gsr_dbg_fwd[4 * 16384];
 extern "C" int gsr_debug_read_fwd(unsigned long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gsr_dbg_fwd), (size_t)n * 8); }
 #endif
-template <bool FAST>
+// CONT (fast blend only): the CONTINUATION kernel, launched right behind k_render<true, false> (gsr_api.hip).  The forward blend ends when its
+// deepest quadrant's serial walk ends (round 5's timeline: the second half of the kernel is a tail of a few hundred deep walks, each alone on
+// its SIMD at the single-wave issue limit), and which quadrants walk deep is only known once they have: the stream length says little (half of
+// cfg3's streams hold more than 600 entries, ten are WALKED beyond 400).  So a walk that reaches entry s.cont_chunks * GSR_BWD_SEGMENT with
+// pixels still open parks its state -- (T, C, last contributor) of its 64 pixels, 1280 bytes -- and leaves; this kernel's workgroups pull those
+// quadrants and walk the rest of each stream FOUR CHUNKS AT A TIME: wave w takes chunks c0 + w, c0 + w + 4, ... of 60 entries; every chunk but
+// the first is walked from T = 1 (its own transmittance product and colour sum), and the waves hand the true state down the chunks in order
+// through LDS:  T = T_prefix * T_chunk,  C = C_prefix + T_prefix * C_chunk  for a pixel that stays open across the chunk (transmittance only
+// falls, so "T_prefix * T_chunk >= 1e-4" says that no record of the chunk closed it); a pixel that closes INSIDE the chunk is evaluated again,
+// from the true prefix, with the record-parallel pass of the tail mode (one wave scan over the chunk's 60 records) -- every pixel closes once.
+// Which chunks are walked from T = 1 and which from the true state depends on the chunk index and on the open pixels the wave itself saw four
+// chunks earlier, never on timing: the result is the same bits run to run.  Same arithmetic per record as the lone walk; what differs is the
+// association of the products (1e-7 relative), inside the fast blend's tolerance.
+template <bool FAST, bool CONT>
 __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ qstart,
                                                  const uint32_t* __restrict__ qcount,
                                                  const float4* __restrict__ grec, const uint32_t* __restrict__ qpos,
@@ -803,25 +818,37 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
                                                  uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ n_contrib_q,
                                                  float* __restrict__ c_final, float4* __restrict__ ck,
                                                  float* __restrict__ out_color, unsigned long long capacity,
-                                                 const unsigned long long* __restrict__ total_dev, uint32_t* __restrict__ units)
+                                                 const unsigned long long* __restrict__ total_dev, uint32_t* __restrict__ units, int tiles)
 {
+    static_assert(FAST || !CONT, "continuations belong to the fast blend");
     if (*total_dev > capacity) return;
 #ifdef GSR_EXPERIMENT_TIMELINE
     const unsigned long long t_start = wall_clock64();
 #endif
     const int W = s.W, H = s.H;
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X;
-    const int tile = (int)tile_order[blockIdx.x];
-    const int tile_x = tile % gx, tile_y = tile / gx;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // the continuation area behind the backward's unit lists (gsr.h: GsrImageLayout.units): header (word 0: continuations parked by
+    // k_render<true, false>, word 32: the pull cursor of this kernel's workgroups; both zeroed by k_preprocess), the list of parked
+    // quadrants (launch position << 2 | quadrant), and 5 x 64 floats of state per quadrant slot
+    const uint32_t ucap = (uint32_t)unit_list_cap((size_t)tiles);
+    uint32_t* const cont_hdr = units + cont_hdr_word((size_t)tiles);
+    uint32_t* const cont_list = cont_hdr + GSR_CONT_HDR_WORDS;
+    float* const cont_state = reinterpret_cast<float*>(cont_list + 4 * (size_t)tiles);
+    const int cont_c = (FAST && s.cont_chunks > 0) ? s.cont_chunks : 0x7fffffff;   // the chunk a lone walk hands over at
+    const int pwave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // this wave inside its workgroup
     const int lane = threadIdx.x & 63;
-    const int pxi = tile_x * GSR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
-    const int pyi = tile_y * GSR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = pxi < W && pyi < H;
-    const float pixx = (float)pxi, pixy = (float)pyi;
+    // per QUADRANT (k_render: once; the continuation kernel: once per pulled quadrant)
+    uint32_t lpos = blockIdx.x;                                  // the tile's position in the launch order
+    int tile = CONT ? 0 : (int)tile_order[blockIdx.x];
+    int tile_x = tile % gx, tile_y = tile / gx;
+    int wave = pwave;                                            // the QUADRANT this wave blends (CONT: all four waves the same one)
+    int pxi = tile_x * GSR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
+    int pyi = tile_y * GSR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
+    bool inside = pxi < W && pyi < H;
+    float pixx = (float)pxi, pixy = (float)pyi;
 
-    const int n = (int)qcount[4 * tile + wave];
-    const uint32_t qs = qstart[4 * tile + wave];
+    int n = CONT ? 0 : (int)qcount[4 * tile + wave];
+    uint32_t qs = CONT ? 0u : qstart[4 * tile + wave];
     const float4* __restrict__ rec = grec;                      // the per-splat records (48 bytes each)
     const uint32_t* __restrict__ qp = qpos + qs;                // this quadrant's stream of splat indices
 
@@ -856,61 +883,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     // 60 records with one wave scan (no serial loop), ~75 instructions per (pixel, chunk) against 60 x 42 for the walk, so it takes over
     // much earlier (model on the cfg3 frame, tools/remap_model.py: 31.7 M -> 26.3 M instructions at 8..16 open pixels).
     constexpr int TAIL_LANES = FAST ? GSR_FAST_TAIL_LANES : 4;
-#ifdef GSR_EXP_SMEM_WALK
-    struct Rec4 { f32x8 a[RB]; float cbl[RB]; float hi[RB]; };   // a = (x, y, conic a, conic b, conic c, opacity | fast: log2 opacity, red, green); blue; fast: alpha's upper bound
-#else
-    struct Rec4 { float a[RB][8]; float cbl[RB]; float hi[RB]; };   // the same fields in vector registers (read from the wave's LDS stage)
-#endif
-    struct Pos4 { uint32_t p[RB]; };
-    // Two-level scalar fetch: stream entries (4-byte splat indices) two batches ahead, the records they name one batch ahead,
-    // every record address the base pointer plus a 32-bit byte offset (s_load with a register offset: no 64-bit address
-    // arithmetic on the scalar unit, which is on the critical path like everything else the wave issues).
-    // Both streams are read through the CONSTANT address space (nothing writes them while this kernel runs): a uniform load
-    // from it is a scalar-memory load by definition, whatever the compiler can or cannot prove about the pointer.
-    typedef const __attribute__((address_space(4))) char* cbytes;
-    const cbytes recb = (cbytes)(uintptr_t)rec;
-    const cbytes qpb = (cbytes)(uintptr_t)qp;
-#ifdef GSR_EXP_SMEM_WALK
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    auto loadp = [&](int jb, Pos4& P, auto whole) {
-#ifndef GSR_EXP_NO_X4
-        if constexpr (decltype(whole)::value && RB <= 4) {
-            // steady state (jb + RB <= n): the batch's positions are ONE s_load_dwordx4 behind one address computation (scalar loads need
-            // dword alignment only); its fourth word -- at most the entry one past the stream, still inside the binning buffer -- is not used
-            const u32x4 v = *(const __attribute__((address_space(4))) u32x4*)(qpb + (uint32_t)jb * 4u);
-#pragma unroll
-            for (int u = 0; u < RB; ++u) P.p[u] = v[u];
-        } else
-#endif
-        {
-#pragma unroll
-            for (int u = 0; u < RB; ++u) {   // past the end: re-read the last one, masked out in blend4<true>
-                const uint32_t j = (uint32_t)min(jb + u, n - 1);
-                P.p[u] = *(const __attribute__((address_space(4))) uint32_t*)(qpb + j * 4u);
-            }
-        }
-    };
-    auto load4 = [&](const Pos4& P, Rec4& R) {
-#pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const uint32_t off = P.p[u] * 48u;   // byte offset of the splat's record: < 4 GiB (89 M splats)
-            R.a[u] = *(const __attribute__((address_space(4))) f32x8*)(recb + off);
-            if constexpr (FAST) {   // blue and the acceptance bound in one 8-byte load
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                const f32x2 bh = *(const __attribute__((address_space(4))) f32x2*)(recb + off + 32);
-                R.cbl[u] = bh[0];
-                R.hi[u] = bh[1];
-            } else {
-                R.cbl[u] = *(const __attribute__((address_space(4))) float*)(recb + off + 32);
-                R.hi[u] = 0.f;
-            }
-        }
-    };
-    // Scalar loads return out of order, so the only wait is lgkmcnt(0); the empty asm pins that wait (first use of the current
-    // batch, whose loads were issued a whole batch ago) ahead of the next issue, instead of letting it land after it and
-    // stall on the fresh loads.
-    auto arrived = [&](Rec4& R, Pos4& P) { asm volatile("" ::"s"(R.a[0]), "s"(P.p[0]) : "memory"); };
-#endif
+    struct Rec4 { float a[RB][8]; float cbl[RB]; float hi[RB]; };   // a = (x, y, conic a, conic b, conic c, opacity | fast: log2 opacity, red, green); blue; fast: alpha's upper bound -- in vector registers, read from the wave's LDS stage
     // last_q is carried RELATIVE to the walk position (lq = last_q - j0 at the top of an iteration): a hit then stores a small constant,
     // which v_cndmask takes inline -- an absolute index costs a scalar add and a v_mov per record on top of the select
     int lq = 0;
@@ -961,10 +934,6 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
             lq = ((int)keep & (int)ok[u]) ? OFF + u + 1 : lq;   // (&, not &&: with the short-circuit form the compiler kept a branch per record once the closing select carried source modifiers)
         }
     };
-    auto blend = [&](int jb, const Rec4& R, auto off) {
-        if (jb + RB <= n) blend4(jb, R, std::false_type{}, off);
-        else blend4(jb, R, std::true_type{}, off);
-    };
     using Off0 = std::integral_constant<int, 0>;
     using Off1 = std::integral_constant<int, RB>;
     auto keep_going = [&](int jb) {
@@ -995,52 +964,6 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         }
     };
     int j0 = 0;
-#ifdef GSR_EXP_SMEM_WALK
-    if (n > 0) {
-        Rec4 A, B;
-        Pos4 PA, PB;
-        loadp(0, PA, std::false_type{});
-        loadp(RB, PB, std::false_type{});
-        asm volatile("" ::"s"(PA.p[0]), "s"(PB.p[0]) : "memory");
-        load4(PA, A);
-        // invariant at the top of both loops: A holds batch j0 (issued a batch ago), PB the positions of batch j0+RB (issued two
-        // batches ago).  Steady state: four whole batches ahead, so nothing in the body needs a bounds test; the open-pixel
-        // test runs once per two batches (a closed pixel ignores the extra records by construction).
-        // (round 4) the steady state really is a loop of its own again: while four whole batches lie ahead no position is clamped (one
-        // dwordx4 load per batch), no batch is masked and nothing tests j0 against n between the two halves
-        while (j0 + 4 * RB <= n && keep_going(j0)) {
-            checkpoint(j0);
-            arrived(A, PB);
-            load4(PB, B);
-            loadp(j0 + 2 * RB, PA, std::true_type{});
-            blend4(j0, A, std::false_type{}, Off0{});
-            j0 += RB;
-            arrived(B, PA);
-            load4(PA, A);
-            loadp(j0 + 2 * RB, PB, std::true_type{});
-            blend4(j0, B, std::false_type{}, Off1{});
-            j0 += RB;
-            lq -= 2 * RB;
-        }
-        // the last batches of the stream: the same walk with every fetch and the last batch bounds-tested
-        while (j0 < n && keep_going(j0)) {
-            checkpoint(j0);
-            arrived(A, PB);
-            load4(PB, B);   // clamped positions are always valid: past the end these re-fetch the last record
-            loadp(j0 + 2 * RB, PA, std::false_type{});
-            blend(j0, A, Off0{});
-            j0 += RB;
-            lq -= RB;
-            if (j0 >= n) break;   // the open-pixel test runs once per two batches: closed pixels ignore the extra records by construction
-            arrived(B, PA);
-            load4(PA, A);
-            loadp(j0 + 2 * RB, PB, std::false_type{});
-            blend(j0, B, Off0{});
-            j0 += RB;
-            lq -= RB;
-        }
-    }
-#else
     // ---- the walk, records staged through LDS (round 4) ------------------------------------------------------------------------
     // Through the scalar unit (above, kept for A/B builds) a batch's records can only be requested ONE batch ahead -- scalar loads
     // return out of order, so the only wait is lgkmcnt(0), which also waits for whatever was issued last -- and a request takes ~300 ns
@@ -1054,63 +977,348 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     constexpr int CH = GSR_BWD_SEGMENT;
     static_assert(CH <= GSR_WAVE && CH % (2 * RB) == 0, "a chunk is one gather of the wave and a whole number of double batches");
     __shared__ float4 stage_all[4][2][CH * 3 + 3];   // (+3: the walk's read-ahead of a chunk's last double batch ends one batch past the chunk -- harmless, never used, but it has to be inside the allocation)
-    float4(*const stage)[CH * 3 + 3] = stage_all[wave];
-    if (n > 0) {
-        float4 g0, g1, g2;   // the chunk in flight: this lane's record
-        auto gather = [&](int c) {   // entries past the end re-read the last one (never walked); lanes CH.. load too (never parked)
-            const size_t idx = (size_t)qp[min(c * CH + lane, n - 1)];
-            g0 = rec[3 * idx + 0];
-            g1 = rec[3 * idx + 1];
-            g2 = rec[3 * idx + 2];
-        };
-        auto park = [&](int c) {
-            if (lane < CH) {
-                float4* d = &stage[c & 1][3 * lane];
-                d[0] = g0; d[1] = g1; d[2] = g2;
-            }
-        };
-        // A batch's records come out of LDS with ds_read_b128 / ds_read_b64 at a wave-uniform address (broadcast), issued from inline
-        // assembly: the reads have to be ISSUED a batch ahead of their use, behind the blend that frees their registers, and left to the
-        // compiler they all end up at the top of the loop body (the fetched batch copied aside, the LDS waited for with nothing to do;
-        // volatile loads turn into flat loads).  LDS returns in order, so `ready` waits with the exact count of reads issued since.
-        // Rules that keep this sound: every `issue` is followed by a `ready` on the same registers before they die (the compiler
-        // believes they were written at the issue), and nothing else of this wave is in flight on lgkmcnt inside the loop (no scalar
-        // loads, no compiler-made LDS access: the parks sit between chunks, behind a full wait).
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        typedef float v2f __attribute__((ext_vector_type(2)));
-        struct RecV { v4f q0[RB], q1[RB]; v2f q2[RB]; };
-        static_assert(RB == 3, "the issue / ready assembly below is written for three records per batch");
-        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)&stage[0][0], lds1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)&stage[1][0];
-        // `addr`: the LDS byte address of the walk's current double batch (a vector register that only ever gets a constant added);
-        // `off`: 0, 144 or 288 bytes ahead of it as an immediate -- no address arithmetic per batch
-        // (a macro: captured variables inside the operand list of an asm in a GENERIC lambda do not compile with this clang)
+    float4(*const stage)[CH * 3 + 3] = stage_all[pwave];
+    float4 g0, g1, g2;   // the chunk in flight: this lane's record
+    auto gather = [&](int c) {   // entries past the end re-read the last one (never walked); lanes CH.. load too (never parked)
+        const size_t idx = (size_t)qp[min(c * CH + lane, n - 1)];
+        g0 = rec[3 * idx + 0];
+        g1 = rec[3 * idx + 1];
+        g2 = rec[3 * idx + 2];
+    };
+    auto park = [&](int c) {
+        if (lane < CH) {
+            float4* d = &stage[c & 1][3 * lane];
+            d[0] = g0; d[1] = g1; d[2] = g2;
+        }
+    };
+    // A batch's records come out of LDS with ds_read_b128 / ds_read_b64 at a wave-uniform address (broadcast), issued from inline
+    // assembly: the reads have to be ISSUED a batch ahead of their use, behind the blend that frees their registers, and left to the
+    // compiler they all end up at the top of the loop body (the fetched batch copied aside, the LDS waited for with nothing to do;
+    // volatile loads turn into flat loads).  LDS returns in order, so `ready` waits with the exact count of reads issued since.
+    // Rules that keep this sound: every `issue` is followed by a `ready` on the same registers before they die (the compiler
+    // believes they were written at the issue), and nothing else of this wave is in flight on lgkmcnt inside the loop (no scalar
+    // loads, no compiler-made LDS access: the parks sit between chunks, behind a full wait).
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    struct RecV { v4f q0[RB], q1[RB]; v2f q2[RB]; };
+    static_assert(RB == 3, "the issue / ready assembly below is written for three records per batch");
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)&stage[0][0], lds1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)&stage[1][0];
+    // `addr`: the LDS byte address of the walk's current double batch (a vector register that only ever gets a constant added);
+    // `off`: 0, 144 or 288 bytes ahead of it as an immediate -- no address arithmetic per batch
+    // (a macro: captured variables inside the operand list of an asm in a GENERIC lambda do not compile with this clang)
 #define GSR_ISSUE(ADDR, O, V)                                                                                                                        \
-        asm volatile("ds_read_b128 %0, %14 offset:%15\n\tds_read_b128 %1, %14 offset:%15+16\n\tds_read_b64 %2, %14 offset:%15+32\n\t"                \
-                     "ds_read_b128 %3, %14 offset:%15+48\n\tds_read_b128 %4, %14 offset:%15+64\n\tds_read_b64 %5, %14 offset:%15+80\n\t"             \
-                     "ds_read_b128 %6, %14 offset:%15+96\n\tds_read_b128 %7, %14 offset:%15+112\n\tds_read_b64 %8, %14 offset:%15+128"                \
-                     : "=&v"(V.q0[0]), "=&v"(V.q1[0]), "=&v"(V.q2[0]), "=&v"(V.q0[1]), "=&v"(V.q1[1]), "=&v"(V.q2[1]), "=&v"(V.q0[2]),              \
-                       "=&v"(V.q1[2]), "=&v"(V.q2[2]), /* the blend state as pass-through operands: the reads are issued BEHIND everything the */    \
-                       /* previous blend computes (its instructions are free to move otherwise, and below this statement they need the old */       \
-                       /* batch copied aside) */                                                                                                    \
-                       "+v"(Tw), "+v"(C0), "+v"(C1), "+v"(C2), "+v"(lq)                                                                             \
-                     : "v"(ADDR), "n"(O))
-        // the batch is in its registers once at most `behind` reads issued after it are still in flight (9 = one batch)
-        auto ready = [&](RecV& V, auto behind, Rec4& R) {
-            if constexpr (decltype(behind)::value == 9)
-                asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(V.q0[0]), "+v"(V.q1[0]), "+v"(V.q2[0]), "+v"(V.q0[1]), "+v"(V.q1[1]), "+v"(V.q2[1]),
-                             "+v"(V.q0[2]), "+v"(V.q1[2]), "+v"(V.q2[2]));
-            else
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V.q0[0]), "+v"(V.q1[0]), "+v"(V.q2[0]), "+v"(V.q0[1]), "+v"(V.q1[1]), "+v"(V.q2[1]),
-                             "+v"(V.q0[2]), "+v"(V.q1[2]), "+v"(V.q2[2]));
+    asm volatile("ds_read_b128 %0, %14 offset:%15\n\tds_read_b128 %1, %14 offset:%15+16\n\tds_read_b64 %2, %14 offset:%15+32\n\t"                \
+                 "ds_read_b128 %3, %14 offset:%15+48\n\tds_read_b128 %4, %14 offset:%15+64\n\tds_read_b64 %5, %14 offset:%15+80\n\t"             \
+                 "ds_read_b128 %6, %14 offset:%15+96\n\tds_read_b128 %7, %14 offset:%15+112\n\tds_read_b64 %8, %14 offset:%15+128"                \
+                 : "=&v"(V.q0[0]), "=&v"(V.q1[0]), "=&v"(V.q2[0]), "=&v"(V.q0[1]), "=&v"(V.q1[1]), "=&v"(V.q2[1]), "=&v"(V.q0[2]),              \
+                   "=&v"(V.q1[2]), "=&v"(V.q2[2]), /* the blend state as pass-through operands: the reads are issued BEHIND everything the */    \
+                   /* previous blend computes (its instructions are free to move otherwise, and below this statement they need the old */       \
+                   /* batch copied aside) */                                                                                                    \
+                   "+v"(Tw), "+v"(C0), "+v"(C1), "+v"(C2), "+v"(lq)                                                                             \
+                 : "v"(ADDR), "n"(O))
+    // the batch is in its registers once at most `behind` reads issued after it are still in flight (9 = one batch)
+    auto ready = [&](RecV& V, auto behind, Rec4& R) {
+        if constexpr (decltype(behind)::value == 9)
+            asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(V.q0[0]), "+v"(V.q1[0]), "+v"(V.q2[0]), "+v"(V.q0[1]), "+v"(V.q1[1]), "+v"(V.q2[1]),
+                         "+v"(V.q0[2]), "+v"(V.q1[2]), "+v"(V.q2[2]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V.q0[0]), "+v"(V.q1[0]), "+v"(V.q2[0]), "+v"(V.q0[1]), "+v"(V.q1[1]), "+v"(V.q2[1]),
+                         "+v"(V.q0[2]), "+v"(V.q1[2]), "+v"(V.q2[2]));
 #pragma unroll
-            for (int u = 0; u < RB; ++u) {
-                R.a[u][0] = V.q0[u].x; R.a[u][1] = V.q0[u].y; R.a[u][2] = V.q0[u].z; R.a[u][3] = V.q0[u].w;
-                R.a[u][4] = V.q1[u].x; R.a[u][5] = V.q1[u].y; R.a[u][6] = V.q1[u].z; R.a[u][7] = V.q1[u].w;
-                R.cbl[u] = V.q2[u].x; R.hi[u] = V.q2[u].y;
+        for (int u = 0; u < RB; ++u) {
+            R.a[u][0] = V.q0[u].x; R.a[u][1] = V.q0[u].y; R.a[u][2] = V.q0[u].z; R.a[u][3] = V.q0[u].w;
+            R.a[u][4] = V.q1[u].x; R.a[u][5] = V.q1[u].y; R.a[u][6] = V.q1[u].z; R.a[u][7] = V.q1[u].w;
+            R.cbl[u] = V.q2[u].x; R.hi[u] = V.q2[u].y;
+        }
+    };
+    using Behind9 = std::integral_constant<int, 9>;
+    using Behind0 = std::integral_constant<int, 0>;
+
+    // ---- the record-parallel pass of the fast blend (tail mode; the continuation kernel's re-evaluation of a pixel that closes inside a
+    // chunk): lanes = the records c0 + lane of ONE chunk (r0, r1, r2; `valid`), the pixels of `todo` take turns two at a time.
+    // T_j = T_p * prod_{i<=j} (1 - alpha_i) is one inclusive wave scan (transmittance only falls: "T >= 1e-4" is a prefix mask, the
+    // pixel closes at its first failing lane), the colour is three wave sums of c * alpha * T_before; no loop over the hits.
+    // Updates (Tw, C, last_q) of the pixels' own lanes; returns the pixels of `todo` that closed.
+    auto tail_pairs = [&](unsigned long long todo, const int c0, const bool valid, const float4 r0, const float4 r1, const float4 r2) {
+        unsigned long long closed_mask = 0ull;
+        while (todo) {
+            // two open pixels per pass (the second one a repeat of the first when only one is left): their scans and sums interleave,
+            // which covers the two wait states a DPP operand needs behind its producer
+            const int pa = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const bool two = todo != 0ull;
+            const int pb = two ? __builtin_ctzll(todo) : pa;
+            todo &= todo - 1;
+            const int pp[2] = {pa, pb};
+            float Tp[2], am[2], prod[2], okf[2];
+            bool ok[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float ppx = (float)(tile_x * GSR_BLOCK_X + (wave & 1) * 8 + (pp[e] & 7));
+                const float ppy = (float)(tile_y * GSR_BLOCK_Y + (wave >> 1) * 8 + (pp[e] >> 3));
+                Tp[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tw), pp[e]));   // open: Tw == T
+                const float dx = r0.x - ppx, dy = r0.y - ppy;
+                const float power = __builtin_fmaf(__builtin_fmaf(r0.w, dy, r0.z * dx), dx, __builtin_fmaf(r1.x * dy, dy, r1.y));   // (the walk's expressions)
+                const float raw = __builtin_amdgcn_exp2f(power);
+                ok[e] = valid && __builtin_amdgcn_fmed3f(raw, 1.0f / 255.0f, r2.y) == raw;
+                const float a = __builtin_amdgcn_fmed3f(raw, 0.0f, 0.99f);
+                am[e] = ok[e] ? a : 0.0f;
+                prod[e] = 1.0f - am[e];
+                okf[e] = am[e] * __builtin_amdgcn_rcpf(prod[e]);   // alpha / (1 - alpha)
             }
-        };
-        using Behind9 = std::integral_constant<int, 9>;
-        using Behind0 = std::integral_constant<int, 0>;
+            // inclusive prefix products over the lanes (v_mul_f32_dpp in place: lanes without a source keep theirs)
+#define GSR_TAIL_STEP(CTRL) "v_mul_f32_dpp %0, %0, %0 " CTRL "\n\tv_mul_f32_dpp %1, %1, %1 " CTRL "\n\ts_nop 0\n\t"
+            asm volatile("s_nop 1\n\t" GSR_TAIL_STEP("row_shr:1 row_mask:0xf bank_mask:0xf") GSR_TAIL_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+                         GSR_TAIL_STEP("row_shr:4 row_mask:0xf bank_mask:0xf") GSR_TAIL_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+                         GSR_TAIL_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") GSR_TAIL_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                         : "+v"(prod[0]), "+v"(prod[1]));
+#undef GSR_TAIL_STEP
+            float Tfull[2], s3[2][3];
+            bool keepl[2];
+            unsigned long long K[2], hits[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                Tfull[e] = Tp[e] * prod[e];                         // transmittance AFTER the lane's record
+                keepl[e] = Tfull[e] >= 0.0001f;                      // false from the record that would saturate the pixel onwards
+                K[e] = __ballot(keepl[e]);
+                hits[e] = __ballot(ok[e] && keepl[e]);
+                const float wgt = keepl[e] ? Tfull[e] * okf[e] : 0.0f;   // alpha * T_before = T_after * alpha / (1 - alpha)
+                s3[e][0] = r1.z * wgt; s3[e][1] = r1.w * wgt; s3[e][2] = r2.x * wgt;
+            }
+            // the six colour sums: halves first (v_permlane32_swap: lanes 0-31 keep pixel a's, lanes 32-63 pixel b's), then 32-lane sums
+            float h3[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s3[0][c]), __float_as_uint(s3[1][c]), false, false);
+                float v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                v += dpp_f<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+                v += dpp_f<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+                v += dpp_f<0x141, 0xf>(v);  // row_half_mirror
+                v += dpp_f<0x140, 0xf>(v);  // row_mirror
+                v += dpp_f<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3: lane 31 holds pixel a's sum, lane 63 pixel b's
+                h3[c] = v;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (e == 1 && !two) break;
+                const int src = e ? 63 : 31;
+                const float A0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h3[0]), src));
+                const float A1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h3[1]), src));
+                const float A2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h3[2]), src));
+                const bool closed = K[e] != ~0ull;
+                const int f = closed ? __builtin_ctzll(~K[e]) : 64;   // first lane whose record does not fit any more
+                const float Tlast = f == 0 ? Tp[e] : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tfull[e]), f - 1));
+                if (lane == pp[e]) {
+                    Tw = closed ? -Tlast : Tlast;
+                    C0 += A0; C1 += A1; C2 += A2;
+                    if (hits[e]) last_q = (uint32_t)(c0 + 64 - __builtin_clzll(hits[e]));
+                }
+                if (closed) closed_mask |= 1ull << pp[e];
+            }
+        }
+        return closed_mask;
+    };
+
+    // ---- the end of a quadrant: the backward's work units, the per-pixel state the backward reads, the image ---------------------------
+    auto finish = [&]() {
+        if (FAST && !s.forward_only) {
+            // the backward's work list (gsr.h: GsrImageLayout.units): one unit per 60-entry segment up to this quadrant's deepest last
+            // contributor, appended to the list of this quadrant's launch position (one returning atomic per wave, spread over 64 counters)
+            const uint32_t qmax = wave_max_u32(inside ? last_q : 0u);
+            const uint32_t nseg = min((qmax + GSR_BWD_SEGMENT - 1u) / GSR_BWD_SEGMENT, (uint32_t)GSR_BWD_SEGMENTS);
+            if (nseg) {
+                const uint32_t w = lpos * 4u + (uint32_t)wave, list = w % (uint32_t)GSR_UNIT_LISTS;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(units + 32u * list, nseg);   // (a 128-byte line per counter: returning atomics on one line queue up in L2)
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if ((uint32_t)lane < nseg)
+                    units[32u * GSR_UNIT_LISTS + list * ucap + base + (uint32_t)lane] = (uint32_t)tile << 6 | (uint32_t)wave << 4 | (uint32_t)lane;
+            }
+        }
+        if (inside) {
+            const int pix_id = W * pyi + pxi;
+            // the reference's n_contrib counts positions in the TILE list: the parity modes keep those in a twin stream; in
+            // production it is the position in the quadrant stream (nothing reads it: the backward walks n_contrib_q)
+            const size_t HW = (size_t)H * W;
+            if (!s.forward_only) {   // what only the backward reads: 24 bytes per pixel (and the checkpoints above) less to store under torch.no_grad()
+                const uint32_t last_contributor = !qlist ? last_q : (last_q ? (qlist + qs)[last_q - 1] + 1u : 0u);
+                final_T[pix_id] = __builtin_fabsf(Tw);
+                n_contrib[pix_id] = last_contributor;
+                n_contrib_q[pix_id] = last_q;
+                c_final[0 * HW + pix_id] = C0;
+                c_final[1 * HW + pix_id] = C1;
+                c_final[2 * HW + pix_id] = C2;
+            }
+            const float T = __builtin_fabsf(Tw);
+            out_color[0 * HW + pix_id] = C0 + T * s.bg[0];
+            out_color[1 * HW + pix_id] = C1 + T * s.bg[1];
+            out_color[2 * HW + pix_id] = C2 + T * s.bg[2];
+        }
+    };
+
+    if constexpr (CONT) {
+        // ================= the continuation kernel: parked quadrants, four chunks in flight =================================================
+        __shared__ uint32_t s_pull;          // the continuation this workgroup works on
+        __shared__ uint32_t s_seq;           // the chunk whose prefix state lies in s_hand (~0: the quadrant is finished)
+        __shared__ float s_hand[5][64];      // (T signed as Tw, C0, C1, C2, last_q) of the 64 pixels before that chunk's first entry
+        const uint32_t parked = min(cont_hdr[0], 4u * (uint32_t)tiles);
+        const size_t HWc = (size_t)H * W;
+        for (;;) {
+            __syncthreads();                 // every wave is done with the previous quadrant (s_seq, s_hand, the stages)
+            if (threadIdx.x == 0) {
+                s_pull = atomicAdd(cont_hdr + 32, 1u);
+                s_seq = (uint32_t)cont_c;
+            }
+            __syncthreads();
+            const uint32_t ei = s_pull;
+            if (ei >= parked) return;
+            const uint32_t ent = cont_list[ei];
+            lpos = ent >> 2;
+            wave = (int)(ent & 3u);
+            tile = (int)tile_order[lpos];
+            tile_x = tile % gx; tile_y = tile / gx;
+            pxi = tile_x * GSR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
+            pyi = tile_y * GSR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
+            inside = pxi < W && pyi < H;
+            pixx = (float)pxi; pixy = (float)pyi;
+            n = (int)qcount[4 * tile + wave];
+            qs = qstart[4 * tile + wave];
+            qp = qpos + qs;
+            const int pix_id = inside ? W * pyi + pxi : 0;
+            const float* st = cont_state + (size_t)(4 * tile + wave) * GSR_CONT_STATE_FLOATS;
+            Tw = st[lane]; C0 = st[64 + lane]; C1 = st[128 + lane]; C2 = st[192 + lane];
+            last_q = reinterpret_cast<const uint32_t*>(st)[256 + lane];
+            const int c_first = cont_c, nchunks = (n + CH - 1) / CH;
+            unsigned long long myopen = __ballot(Tw > 0.0f);   // the open pixels as this wave last saw them
+            bool have_g = false;
+            for (int c = c_first + pwave; c < nchunks; c += 4) {
+                if (__hip_atomic_load(&s_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0xFFFFFFFFu) break;   // finished further up: nothing to add
+                const int m = min(CH, n - c * CH);   // records of this chunk
+                if (!have_g) gather(c);
+                park(0);
+                asm volatile("" ::: "memory");
+                have_g = c + 4 < nchunks;
+                if (have_g) gather(c + 4);           // in flight behind this chunk's walk
+                // the chunk's records, one batch of three per read, a double batch per step (the lone walk's loop without its tests:
+                // pixels that are closed are inert by construction)
+                auto walk_chunk = [&]() {
+                    RecV VA, VB;
+                    Rec4 A, B;
+                    uint32_t addr = lds0;
+                    GSR_ISSUE(addr, 0, VA);
+                    int k = 0;
+                    while (k + 2 * RB <= m) {
+                        GSR_ISSUE(addr, 48 * RB, VB);
+                        ready(VA, Behind9{}, A);
+                        blend4(j0, A, std::false_type{}, Off0{});
+                        GSR_ISSUE(addr, 96 * RB, VA);
+                        ready(VB, Behind9{}, B);
+                        blend4(j0 + RB, B, std::false_type{}, Off1{});
+                        addr += 96 * RB;
+                        j0 += 2 * RB;
+                        lq -= 2 * RB;
+                        k += 2 * RB;
+                    }
+                    ready(VA, Behind0{}, A);
+                    if (k < m) {   // the stream ends inside this chunk: one or two bounds-tested batches (A holds the first)
+                        blend4(j0, A, std::true_type{}, Off0{});
+                        j0 += RB;
+                        lq -= RB;
+                        if (j0 < n) {
+                            GSR_ISSUE(addr, 48 * RB, VB);
+                            ready(VB, Behind0{}, B);
+                            blend4(j0, B, std::true_type{}, Off0{});
+                            j0 += RB;
+                            lq -= RB;
+                        }
+                    }
+                };
+                auto chunk_records = [&](float4& r0, float4& r1, float4& r2) {   // lane l: record c * CH + l, back from the wave's stage
+                    const float4* sp = &stage[0][3 * min(lane, CH - 1)];
+                    r0 = sp[0]; r1 = sp[1]; r2 = sp[2];
+                };
+                // wait for the state before this chunk's first entry; false: the quadrant finished further up
+                auto wait_prefix = [&]() {
+                    for (uint32_t spins = 0; spins < (1u << 22); ++spins) {   // (the chunk below is always on its way: the bound only keeps a logic error from hanging the device)
+                        const uint32_t v = __hip_atomic_load(&s_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (v == 0xFFFFFFFFu) return false;
+                        if (v >= (uint32_t)c) return true;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    return false;
+                };
+                const bool first = c == c_first;
+                const bool spec = !first && __builtin_popcountll(myopen) > TAIL_LANES;
+                if (spec) {
+                    // walked from T = 1 (pixels this wave knows to be closed: from 0) while the chunks below are still on their way
+                    Tw = ((myopen >> lane) & 1ull) ? 1.0f : 0.0f;
+                    C0 = 0.f; C1 = 0.f; C2 = 0.f;
+                    lq = 0; j0 = c * CH;
+                    walk_chunk();
+                    const float Tl = Tw, L0 = C0, L1 = C1, L2 = C2;
+                    const uint32_t hit = (uint32_t)(lq + j0);                       // > c * CH: the chunk's last contributor of this pixel
+                    if (!wait_prefix()) break;
+                    const float Tp = s_hand[0][lane], P0 = s_hand[1][lane], P1 = s_hand[2][lane], P2 = s_hand[3][lane];
+                    const uint32_t lqp = __float_as_uint(s_hand[4][lane]);
+                    const bool open_p = Tp > 0.0f;
+                    const float Tt = Tp * Tl;
+                    const bool thru = open_p && Tl > 0.0f && Tt >= 0.0001f;       // open before the chunk and no record of it closes the pixel
+                    Tw = thru ? Tt : Tp;
+                    C0 = thru ? __builtin_fmaf(Tp, L0, P0) : P0;
+                    C1 = thru ? __builtin_fmaf(Tp, L1, P1) : P1;
+                    C2 = thru ? __builtin_fmaf(Tp, L2, P2) : P2;
+                    last_q = (thru && hit > (uint32_t)(c * CH)) ? hit : lqp;
+                    const unsigned long long closers = __ballot(open_p && !thru);
+                    if (closers) {   // these close inside the chunk: once more from the true prefix, records across the lanes
+                        float4 r0, r1, r2;
+                        chunk_records(r0, r1, r2);
+                        (void)tail_pairs(closers, c * CH, lane < m, r0, r1, r2);
+                    }
+                } else {
+                    if (!first) {
+                        if (!wait_prefix()) break;
+                        Tw = s_hand[0][lane]; C0 = s_hand[1][lane]; C1 = s_hand[2][lane]; C2 = s_hand[3][lane];
+                        last_q = __float_as_uint(s_hand[4][lane]);
+                    }
+                    const unsigned long long open_now = __ballot(Tw > 0.0f);
+                    if (__builtin_popcountll(open_now) > TAIL_LANES) {
+                        j0 = c * CH;
+                        lq = (int)last_q - j0;
+                        walk_chunk();
+                        last_q = (uint32_t)(lq + j0);
+                    } else if (open_now) {
+                        float4 r0, r1, r2;
+                        chunk_records(r0, r1, r2);
+                        (void)tail_pairs(open_now, c * CH, lane < m, r0, r1, r2);
+                    }
+                }
+                myopen = __ballot(Tw > 0.0f);
+                if (myopen == 0ull || c == nchunks - 1) {   // the state after this chunk is the quadrant's result
+                    finish();
+                    if (lane == 0) __hip_atomic_store(&s_seq, 0xFFFFFFFFu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    break;
+                }
+                // the state before entry (c + 1) * CH: the backward's checkpoint (slot c), and the prefix of the next chunk's wave
+                if (!s.forward_only && c + 1 <= GSR_BWD_SEGMENTS - 1 && inside)
+                    ck[(size_t)c * HWc + pix_id] = make_float4(__builtin_fabsf(Tw), C0, C1, C2);
+                s_hand[0][lane] = Tw; s_hand[1][lane] = C0; s_hand[2][lane] = C1; s_hand[3][lane] = C2; s_hand[4][lane] = __uint_as_float(last_q);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(&s_seq, (uint32_t)(c + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    } else {
+    // a lone walk that reaches the hand-over chunk parks its state for the continuation kernel and leaves (nothing of the quadrant's
+    // outputs is written here; the checkpoint before the chunk has been)
+    auto park_quadrant = [&](uint32_t lastq_abs) {
+        int slot = 4 * tile + wave;
+        asm volatile("" : "+s"(slot));   // (the addresses are formed HERE: hoisted out of the walk they cost it eight vector registers and a wave per SIMD)
+        float* st = cont_state + (size_t)slot * GSR_CONT_STATE_FLOATS;
+        st[lane] = Tw; st[64 + lane] = C0; st[128 + lane] = C1; st[192 + lane] = C2;
+        reinterpret_cast<uint32_t*>(st)[256 + lane] = lastq_abs;
+        if (lane == 0) cont_list[atomicAdd(cont_hdr, 1u)] = lpos << 2 | (uint32_t)wave;
+    };
+    bool hand_over = false;   // the walk reached the hand-over chunk with the stream going on
+    if (n > 0) {
         gather(0);
         park(0);
         if (n > CH) gather(1);
@@ -1119,6 +1327,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
             const int b = c & 1;
             const int m = min(CH, n - c * CH);   // records of this chunk
             checkpoint(j0);                      // j0 == c * CH: the state before the chunk's first entry
+            if (FAST && c == cont_c) { hand_over = true; break; }
             RecV VA, VB;
             Rec4 A, B;
             uint32_t addr = b ? lds1 : lds0;
@@ -1171,8 +1380,11 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
             if ((c + 2) * CH < n) gather(c + 2);
         }
     }
-#endif
     last_q = (uint32_t)(lq + j0);   // (lq + j0 >= 0: a pixel without a hit kept lq = -j0)
+    if (hand_over) {
+        park_quadrant(last_q);
+        return;
+    }
 
     if (j0 < n) checkpoint(j0);   // the walk stopped exactly on a checkpoint entry (tail mode takes over from here)
 #ifdef GSR_EXPERIMENT_TIMELINE
@@ -1186,12 +1398,14 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     // (ballot) go through the sequential T/C update, in stream order -- the arithmetic per contributing
     // record and its order are unchanged, so results stay bit-identical.
     if (FAST && j0 < n) {
-        // ---- fast blend: chunks of the stream up to the next checkpoint boundary, lanes = records, one open pixel at a time.
-        // T_j = T_p * prod_{i<=j} (1 - alpha_i) is one inclusive wave scan (transmittance only falls: "T >= 1e-4" is a prefix mask, the
-        // pixel closes at its first failing lane), the colour is three wave sums of c * alpha * T_before; no loop over the hits.
+        // ---- fast blend: chunks of the stream up to the next checkpoint boundary, lanes = records, the open pixels two at a time (tail_pairs)
         unsigned long long open_mask = __ballot(Tw > 0.0f);
         int c0 = j0;
         while (c0 < n && open_mask) {
+            if (c0 % CH == 0 && c0 / CH == cont_c) {   // (the tail's chunks end on checkpoint entries: the hand-over entry is the top of one)
+                park_quadrant(last_q);
+                return;
+            }
             const int c1 = min(n, (c0 / GSR_BWD_SEGMENT + 1) * GSR_BWD_SEGMENT);   // the chunk ends where the next checkpoint sits (<= 60 entries)
             const int j = c0 + lane;
             const bool valid = j < c1;
@@ -1199,82 +1413,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
             const float4 r0 = rec[3 * jc + 0];
             const float4 r1 = rec[3 * jc + 1];
             const float4 r2 = rec[3 * jc + 2];
-            unsigned long long todo = open_mask;
-            while (todo) {
-                // two open pixels per pass (the second one a repeat of the first when only one is left): their scans and sums interleave,
-                // which covers the two wait states a DPP operand needs behind its producer
-                const int pa = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                const bool two = todo != 0ull;
-                const int pb = two ? __builtin_ctzll(todo) : pa;
-                todo &= todo - 1;
-                const int pp[2] = {pa, pb};
-                float Tp[2], am[2], prod[2], okf[2];
-                bool ok[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float ppx = (float)(tile_x * GSR_BLOCK_X + (wave & 1) * 8 + (pp[e] & 7));
-                    const float ppy = (float)(tile_y * GSR_BLOCK_Y + (wave >> 1) * 8 + (pp[e] >> 3));
-                    Tp[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tw), pp[e]));   // open: Tw == T
-                    const float dx = r0.x - ppx, dy = r0.y - ppy;
-                    const float power = __builtin_fmaf(__builtin_fmaf(r0.w, dy, r0.z * dx), dx, __builtin_fmaf(r1.x * dy, dy, r1.y));   // (the walk's expressions)
-                    const float raw = __builtin_amdgcn_exp2f(power);
-                    ok[e] = valid && __builtin_amdgcn_fmed3f(raw, 1.0f / 255.0f, r2.y) == raw;
-                    const float a = __builtin_amdgcn_fmed3f(raw, 0.0f, 0.99f);
-                    am[e] = ok[e] ? a : 0.0f;
-                    prod[e] = 1.0f - am[e];
-                    okf[e] = am[e] * __builtin_amdgcn_rcpf(prod[e]);   // alpha / (1 - alpha)
-                }
-                // inclusive prefix products over the lanes (v_mul_f32_dpp in place: lanes without a source keep theirs)
-#define GSR_TAIL_STEP(CTRL) "v_mul_f32_dpp %0, %0, %0 " CTRL "\n\tv_mul_f32_dpp %1, %1, %1 " CTRL "\n\ts_nop 0\n\t"
-                asm volatile("s_nop 1\n\t" GSR_TAIL_STEP("row_shr:1 row_mask:0xf bank_mask:0xf") GSR_TAIL_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
-                             GSR_TAIL_STEP("row_shr:4 row_mask:0xf bank_mask:0xf") GSR_TAIL_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
-                             GSR_TAIL_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") GSR_TAIL_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
-                             : "+v"(prod[0]), "+v"(prod[1]));
-#undef GSR_TAIL_STEP
-                float Tfull[2], s3[2][3];
-                bool keepl[2];
-                unsigned long long K[2], hits[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    Tfull[e] = Tp[e] * prod[e];                         // transmittance AFTER the lane's record
-                    keepl[e] = Tfull[e] >= 0.0001f;                      // false from the record that would saturate the pixel onwards
-                    K[e] = __ballot(keepl[e]);
-                    hits[e] = __ballot(ok[e] && keepl[e]);
-                    const float wgt = keepl[e] ? Tfull[e] * okf[e] : 0.0f;   // alpha * T_before = T_after * alpha / (1 - alpha)
-                    s3[e][0] = r1.z * wgt; s3[e][1] = r1.w * wgt; s3[e][2] = r2.x * wgt;
-                }
-                // the six colour sums: halves first (v_permlane32_swap: lanes 0-31 keep pixel a's, lanes 32-63 pixel b's), then 32-lane sums
-                float h3[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s3[0][c]), __float_as_uint(s3[1][c]), false, false);
-                    float v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-                    v += dpp_f<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
-                    v += dpp_f<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
-                    v += dpp_f<0x141, 0xf>(v);  // row_half_mirror
-                    v += dpp_f<0x140, 0xf>(v);  // row_mirror
-                    v += dpp_f<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3: lane 31 holds pixel a's sum, lane 63 pixel b's
-                    h3[c] = v;
-                }
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    if (e == 1 && !two) break;
-                    const int src = e ? 63 : 31;
-                    const float A0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h3[0]), src));
-                    const float A1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h3[1]), src));
-                    const float A2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h3[2]), src));
-                    const bool closed = K[e] != ~0ull;
-                    const int f = closed ? __builtin_ctzll(~K[e]) : 64;   // first lane whose record does not fit any more
-                    const float Tlast = f == 0 ? Tp[e] : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tfull[e]), f - 1));
-                    if (lane == pp[e]) {
-                        Tw = closed ? -Tlast : Tlast;
-                        C0 += A0; C1 += A1; C2 += A2;
-                        if (hits[e]) last_q = (uint32_t)(c0 + 64 - __builtin_clzll(hits[e]));
-                    }
-                    if (closed) open_mask &= ~(1ull << pp[e]);
-                }
-            }
+            open_mask &= ~tail_pairs(open_mask, c0, valid, r0, r1, r2);
             c0 = c1;
             if (c0 < n) checkpoint(c0);   // (every lane stores its own pixel's state; closed pixels rewrite slots nobody reads)
         }
@@ -1350,46 +1489,16 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         d[3] = t_main;
     }
 #endif
-    if (FAST && !s.forward_only) {
-        // the backward's work list (gsr.h: GsrImageLayout.units): one unit per 60-entry segment up to this quadrant's deepest last
-        // contributor, appended to the list of this wave's launch position (one returning atomic per wave, spread over 64 counters)
-        const uint32_t qmax = wave_max_u32(inside ? last_q : 0u);
-        const uint32_t nseg = min((qmax + GSR_BWD_SEGMENT - 1u) / GSR_BWD_SEGMENT, (uint32_t)GSR_BWD_SEGMENTS);
-        if (nseg) {
-            const uint32_t w = (uint32_t)blockIdx.x * 4u + (uint32_t)wave, list = w % (uint32_t)GSR_UNIT_LISTS;
-            const uint32_t cap = (4u * gridDim.x + GSR_UNIT_LISTS - 1u) / GSR_UNIT_LISTS * (uint32_t)GSR_BWD_SEGMENTS;
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(units + 32u * list, nseg);   // (a 128-byte line per counter: returning atomics on one line queue up in L2)
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if ((uint32_t)lane < nseg)
-                units[32u * GSR_UNIT_LISTS + list * cap + base + (uint32_t)lane] = (uint32_t)tile << 6 | (uint32_t)wave << 4 | (uint32_t)lane;
-        }
-    }
-    if (inside) {
-        const int pix_id = W * pyi + pxi;
-        // the reference's n_contrib counts positions in the TILE list: the parity modes keep those in a twin stream; in
-        // production it is the position in the quadrant stream (nothing reads it: the backward walks n_contrib_q)
-        const size_t HW = (size_t)H * W;
-        if (!s.forward_only) {   // what only the backward reads: 24 bytes per pixel (and the checkpoints above) less to store under torch.no_grad()
-            const uint32_t last_contributor = !qlist ? last_q : (last_q ? (qlist + qs)[last_q - 1] + 1u : 0u);
-            final_T[pix_id] = __builtin_fabsf(Tw);
-            n_contrib[pix_id] = last_contributor;
-            n_contrib_q[pix_id] = last_q;
-            c_final[0 * HW + pix_id] = C0;
-            c_final[1 * HW + pix_id] = C1;
-            c_final[2 * HW + pix_id] = C2;
-        }
-        const float T = __builtin_fabsf(Tw);
-        out_color[0 * HW + pix_id] = C0 + T * s.bg[0];
-        out_color[1 * HW + pix_id] = C1 + T * s.bg[1];
-        out_color[2 * HW + pix_id] = C2 + T * s.bg[2];
-    }
+    finish();
+    }   // (!CONT)
 }
 
-template __global__ void k_render<false>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
-                                         uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*);
-template __global__ void k_render<true>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
-                                        uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*);
+template __global__ void k_render<false, false>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
+                                                uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*, int);
+template __global__ void k_render<true, false>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
+                                               uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*, int);
+template __global__ void k_render<true, true>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
+                                              uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*, int);
 
 // ------------------------------------------------------------------------------------------
 // k_mark_visible (upstream checkFrustum): present = view z > 0.2

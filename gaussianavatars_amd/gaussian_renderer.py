@@ -58,7 +58,11 @@ def _screenspace_leaf(xyz: torch.Tensor) -> torch.Tensor:
 
 
 def _dev(t, device):
-    return t if isinstance(t, torch.Tensor) and t.device == device else torch.as_tensor(t, device=device)
+    """`t` on `device`.  Host tensors (the DataLoader cameras of train.py: transposed VIEWS, scene/cameras.py:44-46) are made contiguous BEFORE the upload, so that
+    the rasterizer's entry takes the uploaded tensor as it is -- a strided device tensor would be copied once more there and kept in a cache it can never hit."""
+    if isinstance(t, torch.Tensor):
+        return t if t.device == device else t.contiguous().to(device)
+    return torch.as_tensor(t, device=device)
 
 
 def _bound_fast_path(pc, pipe, override_color) -> bool:

@@ -162,6 +162,11 @@ def last_forward_info() -> dict:
     return info
 
 
+def release_last_state() -> None:
+    """Drops the reference last_forward_info() keeps to the most recent frame's state buffers (they are otherwise freed when the next frame is rendered)."""
+    _last_binning[0] = None
+
+
 def _round_cap(n: int) -> int:
     return max(_CAP_QUANTUM, (int(n) + _CAP_QUANTUM - 1) // _CAP_QUANTUM * _CAP_QUANTUM)
 
@@ -339,6 +344,8 @@ def _native_leaves_entry(H, xyz, means2D, sh_dc, sh_rest, opacity_logit, log_sca
         _forward_peak[0] = I
     _last_info.update(num_rendered=I, capacity=cap, replays=replays, tile_culling=bool(tc), production_binning=prod, forward_only=bool(r.forward_only),
                       binning_path=r.path, rank_bands=r.nbands, bound=True, native_host=True)
+    # (state allocation, byte offset of its binning part): last_forward_info() reads the header on request.  This keeps the last frame's ONE state
+    # allocation alive until the next frame replaces it (a view would too, a copy of the header would cost a launch per frame): release_last_state() drops it.
     _last_binning[0] = (r.state, r.off_binning)
     return r.color, r.radii, r.visible
 

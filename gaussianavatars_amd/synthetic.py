@@ -97,7 +97,35 @@ FLAME_PARENTS = (-1, 0, 1, 1, 1)
 N_SHAPE, N_EXPR = 300, 100
 
 
-def head_mesh(half_extent: float = 0.12) -> Tuple[np.ndarray, np.ndarray]:
+# Face-area statistics of the reference's head template (flame_model/assets/flame/head_template_mesh.obj, 9976 faces), the only thing taken from it:
+# its LORENZ CURVE -- (fraction of the faces, smallest first; fraction of the surface area they hold).  Half of the template's faces (eyes, lips,
+# nose, ears) hold 4.5 % of its area, the largest tenth (scalp, neck) 59 %; the lat/long ellipsoid below is far more even (half: 29 %, tenth: 16 %).
+TEMPLATE_AREA_LORENZ = ((0.0, 0.0), (0.01, 0.00011), (0.02, 0.00026), (0.05, 0.00087), (0.1, 0.0025), (0.2, 0.0077), (0.3, 0.01621), (0.4, 0.02878),
+                        (0.5, 0.04498), (0.6, 0.06627), (0.7, 0.10212), (0.75, 0.12977), (0.8, 0.17308), (0.85, 0.26119), (0.9, 0.41049),
+                        (0.95, 0.63332), (0.98, 0.82026), (0.99, 0.89986), (1.0, 1.0))
+TEMPLATE_HALF_EXTENT = (0.1036, 0.1568, 0.1109)   # the template's bounding box / 2 (metres)
+TEMPLATE_DENSE_AXIS = (0.0, 0.3, 0.95)            # where its small faces sit, seen from the box centre: the front, a little above the middle
+
+
+def _template_like_directions(d: np.ndarray) -> np.ndarray:
+    """Moves unit directions `d` along great circles through TEMPLATE_DENSE_AXIS so that the cap holding a fraction F of the (evenly spread)
+    directions ends up covering the fraction TEMPLATE_AREA_LORENZ(F) of the sphere: the faces of a mesh built on them get the template's
+    uneven area distribution -- dense at the front, coarse at the back -- on the same lat/long topology."""
+    c = np.asarray(TEMPLATE_DENSE_AXIS, np.float64)
+    c /= np.linalg.norm(c)
+    cosa = np.clip(d @ c, -1.0, 1.0)
+    perp = d - cosa[:, None] * c
+    pn = np.linalg.norm(perp, axis=1, keepdims=True)
+    perp = np.where(pn > 1e-12, perp / np.maximum(pn, 1e-12), 0.0)
+    F = (1.0 - cosa) / 2.0
+    kf, ka = np.asarray(TEMPLATE_AREA_LORENZ, np.float64).T
+    A = np.interp(F, kf, ka)
+    cos2 = 1.0 - 2.0 * A
+    sin2 = np.sqrt(np.maximum(0.0, 1.0 - cos2 * cos2))
+    return cos2[:, None] * c + sin2[:, None] * perp
+
+
+def head_mesh(half_extent: float = 0.12, kind: str = "ellipsoid") -> Tuple[np.ndarray, np.ndarray]:
     """An ellipsoid 'head' with exactly FLAME_V vertices and FLAME_F faces: a 53-ring x 97-segment
     lat/long sphere (2 + 53*97 = 5143 vertices, 10282 faces) with a 138-face neck hole cut at the
     south pole.  The true template (flame_model/assets/flame/head_template_mesh.obj) is licensed and
@@ -127,12 +155,25 @@ def head_mesh(half_extent: float = 0.12) -> Tuple[np.ndarray, np.ndarray]:
     faces = np.asarray(faces, np.int64)
     assert faces.shape[0] == 10282
     faces = faces[: FLAME_F]  # drops the 97 south-pole fan triangles + 41 of the last band
+    if kind == "template_like":
+        # the same topology with the template's face-area distribution and extent (statistics only: TEMPLATE_AREA_LORENZ)
+        verts = _template_like_directions(verts) * np.asarray(TEMPLATE_HALF_EXTENT)
+        return verts.astype(np.float32), faces
+    if kind != "ellipsoid":
+        raise ValueError(f"head_mesh: unknown kind {kind!r}")
     verts = verts * np.array([0.8, 1.0, 0.9]) * half_extent
     return verts.astype(np.float32), faces
 
 
-def flame_rig(seed: int = 4) -> Dict[str, np.ndarray]:
-    """Buffers with the schemas FlameHead registers (flame_model/flame.py:98-129, after add_teeth)."""
+def flame_rig(seed: int = 4, kind: str = "ellipsoid") -> Dict[str, np.ndarray]:
+    """Buffers with the schemas FlameHead registers (flame_model/flame.py:98-129, after add_teeth).
+    kind="template_like": the rig of `flame_pickle_dict` (what tools/ref_on_gpu.py stages on the real template) on `head_mesh(kind="template_like")`."""
+    if kind != "ellipsoid":
+        v_template, faces = head_mesh(kind=kind)
+        d = flame_pickle_dict(v_template, faces, seed)
+        return dict(v_template=v_template, shapedirs=d["shapedirs"], posedirs=np.ascontiguousarray(d["posedirs"].reshape(-1, 36).T),
+                    J_regressor=d["J_regressor"].astype(np.float32), lbs_weights=d["weights"].astype(np.float32),
+                    parents=np.asarray(FLAME_PARENTS, np.int64), faces=faces)
     g = np.random.default_rng(seed)
     v_template, faces = head_mesh()
     V = FLAME_V
@@ -276,6 +317,14 @@ def flame_masks_dict(v_template: np.ndarray) -> Dict[str, np.ndarray]:
         right_eye_region=sel(eye_r), left_eye_region=sel(eye_l))
 
 
+# bench.py --scene template_like: the splat-scale offset on head_mesh(kind="template_like").  Calibrated with the CPU oracle (tools/template_like_stats.py,
+# 100 000 splats, 802x550, timestep 0) against the avatar tools/ref_on_gpu.py stages on the real template (offset 0.55 there):
+#                       rect instances   deepest contributor per 8x8 quadrant, p50 / p90 / p99 / max   contributors per pixel
+#   staged on template     2.13 M          243 / 547 / 1285 / 3808                                        238
+#   template_like, 0.5     2.02 M          303 / 624 / 1503 / 3989                                        286
+#   ellipsoid (default)    1.83 M          263 / 570 / 1133 / 2191                                        178
+# i.e. a little DEEPER than the staged avatar at 0.95 x its instances (the conservative side for a blend-kernel time).
+TEMPLATE_LIKE_LOG_SCALE_OFFSET = 0.5
 BENCHMARK_LOG_SCALE_OFFSET = 0.55   # measured with the CPU oracle at 100 000 splats, 802x550: 2.2 M rect instances (bench.py cfg2: 2.23 M); -0.5 gives 0.49 M, 0.8 gives 3.3 M
 
 
