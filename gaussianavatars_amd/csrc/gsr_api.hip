@@ -126,6 +126,8 @@ gsr::Settings to_dev_settings(const GsrSettings* s)
     // (gsr_forward.hip, k_render<true, true>); GSR_CONT_CHUNKS=0 keeps every walk in one piece (A/B runs)
     static const int cont_chunks = [] { const char* e = getenv("GSR_CONT_CHUNKS"); const int v = e ? atoi(e) : GSR_CONT_CHUNKS_DEFAULT; return v < 0 ? 0 : v; }();
     d.cont_chunks = cont_chunks;
+    static const int cont_mode = [] { const char* e = getenv("GSR_CONT_MODE"); const int v = e ? atoi(e) : GSR_CONT_MODE_DEFAULT; return v == 2 ? 2 : 1; }();
+    d.cont_mode = cont_mode;
     d.bg = s->bg;
     d.viewmatrix = s->viewmatrix;
     d.projmatrix = s->projmatrix;
@@ -444,6 +446,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         HIP_TRY(hipMemsetAsync(rect_total, 0, 8, stream));
         HIP_TRY(hipMemsetAsync(im + il.units, 0, (size_t)32 * GSR_UNIT_LISTS * 4, stream));
         HIP_TRY(hipMemsetAsync(im + il.units + gsr::cont_hdr_word((size_t)tiles) * 4, 0, (size_t)GSR_CONT_HDR_WORDS * 4, stream));
+        HIP_TRY(hipMemsetAsync(im + il.units + (gsr::cont_hdr_word((size_t)tiles) + GSR_CONT_HDR_WORDS) * 4, 0xFF, (size_t)4 * tiles * 4, stream));
     }
 
     gsr::PreprocessArgs pa;
@@ -720,18 +723,20 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     }   // per-tile sort path
     {
         TIMED(GSR_K_RENDER, stream);
-        auto* const render_k = ds.fast_blend ? &gsr::k_render<true, false> : &gsr::k_render<false, false>;
-        hipLaunchKernelGGL(render_k, dim3(tiles), dim3(256), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
+        // fast blend with continuations (s.cont_chunks > 0): quadrants whose walk reaches entry cont_chunks * GSR_BWD_SEGMENT with pixels still open are
+        // finished four chunks at a time by continuation workgroups -- at the end of the same grid, waiting for them (mode 1), or as a kernel of their own (mode 2)
+        static const int cont_grid = [] { const char* e = getenv("GSR_CONT_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : GSR_CONT_GRID_DEFAULT; }();
+        const int cgrid = 4 * tiles < cont_grid ? 4 * tiles : cont_grid;
+        const bool conts = ds.fast_blend && ds.cont_chunks > 0;
+        if (!conts) ds.cont_chunks = 0;
+        auto* const render_k = !ds.fast_blend ? &gsr::k_render<false, 0> : (conts && ds.cont_mode == 1 ? &gsr::k_render<true, 1> : &gsr::k_render<true, 0>);
+        hipLaunchKernelGGL(render_k, dim3(tiles + (conts && ds.cont_mode == 1 ? cgrid : 0)), dim3(256), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
                            (const uint32_t*)qcount, (const float4*)pa.grec, (const uint32_t*)qpos, write_lists ? (const uint32_t*)qlist : nullptr, (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib),
                            (uint32_t*)(im + il.n_contrib_q), (float*)(im + il.c_final), (float4*)(im + il.ck), out_color, cap,
                            (const unsigned long long*)total_dev, (uint32_t*)(im + il.units), tiles);
         KERNEL_CHECK("k_render", stream, dbg);
-        if (ds.fast_blend && ds.cont_chunks > 0) {
-            // the quadrants whose walk reached entry cont_chunks * GSR_BWD_SEGMENT with pixels still open: four chunks in flight per quadrant
-            // (a fixed grid whose workgroups pull the parked quadrants; the count stays on the device)
-            static const int cont_grid = [] { const char* e = getenv("GSR_CONT_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : GSR_CONT_GRID_DEFAULT; }();
-            const int cgrid = 4 * tiles < cont_grid ? 4 * tiles : cont_grid;
-            hipLaunchKernelGGL((gsr::k_render<true, true>), dim3(cgrid), dim3(256), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
+        if (conts && ds.cont_mode == 2) {
+            hipLaunchKernelGGL((gsr::k_render<true, 2>), dim3(cgrid), dim3(64 * GSR_CONT_WAVES), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
                                (const uint32_t*)qcount, (const float4*)pa.grec, (const uint32_t*)qpos, write_lists ? (const uint32_t*)qlist : nullptr, (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib),
                                (uint32_t*)(im + il.n_contrib_q), (float*)(im + il.c_final), (float4*)(im + il.ck), out_color, cap,
                                (const unsigned long long*)total_dev, (uint32_t*)(im + il.units), tiles);

@@ -54,7 +54,8 @@ struct Settings {  // by-value kernel argument: scalars + the four device pointe
     int forward_only;
     int deterministic;
     int fast_blend;      // EFFECTIVE fast mode of this frame (gsr_api.hip: off with `deterministic` and on the per-tile sort path)
-    int cont_chunks;     // fast blend: a quadrant's lone walk hands over to the continuation kernel at entry cont_chunks * GSR_BWD_SEGMENT (0: never)
+    int cont_chunks;     // fast blend: a quadrant's lone walk hands over to the continuation workgroups at entry cont_chunks * GSR_BWD_SEGMENT (0: never)
+    int cont_mode;       // 1: they sit at the end of k_render's own grid and wait; 2: a kernel of their own behind it
     const float* __restrict__ bg;
     const float* __restrict__ viewmatrix;
     const float* __restrict__ projmatrix;
@@ -578,15 +579,21 @@ template <int KEYS, int THREADS>
 __global__ void k_tile_sort(uint32_t n_lo, uint32_t n_hi, int gx, const uint32_t* tile_order, const uint32_t* tile_count, const uint32_t* tile_start, unsigned long long* keys,
                             uint32_t* point_list, uint32_t* qlist, uint32_t* qpos, uint32_t* qcount, uint32_t* qstart, const float4* grec,
                             unsigned long long capacity, const unsigned long long* total_dev);
-template <bool FAST, bool CONT>
+template <bool FAST, int CONT>   // CONT: 0 tiles only (fast blend: parks deep quadrants for <true, 2> when s.cont_chunks > 0), 1 tiles + waiting continuation workgroups in one grid, 2 the continuation kernel
 __global__ void k_render(Settings s, const uint32_t* tile_order, const uint32_t* qstart, const uint32_t* qcount, const float4* grec,
                          const uint32_t* qpos, const uint32_t* qlist, float* final_T,
                          uint32_t* n_contrib, uint32_t* n_contrib_q, float* c_final, float4* ck, float* out_color, unsigned long long capacity,
                          const unsigned long long* total_dev, uint32_t* units, int tiles);
 // the continuation area behind the unit lists of GsrImageLayout.units (k_render): header words, then the list, then the parked states
-#define GSR_CONT_HDR_WORDS 64
+#define GSR_CONT_HDR_WORDS 576    // word 0 parked, 32 pull cursor, 64 + 32 k (k < 16) reports of the tile waves: a 128-byte line each
 #ifndef GSR_CONT_CHUNKS_DEFAULT
-#define GSR_CONT_CHUNKS_DEFAULT 3   // hand-over at entry 180 (swept on the MI355X: DESIGN.md)
+#define GSR_CONT_CHUNKS_DEFAULT 0   // OFF: measured on the MI355X, the continuation costs more than the tail it removes on both bench scenes; GSR_CONT_CHUNKS=3 or 4 turns it on
+#endif
+#ifndef GSR_CONT_WAVES
+#define GSR_CONT_WAVES 8   // waves per workgroup of the continuation kernel (mode 2): chunks of a quadrant in flight
+#endif
+#ifndef GSR_CONT_MODE_DEFAULT
+#define GSR_CONT_MODE_DEFAULT 1
 #endif
 #ifndef GSR_CONT_GRID_DEFAULT
 #define GSR_CONT_GRID_DEFAULT 768   // workgroups of the continuation kernel (three per CU); they pull the parked quadrants in turn
@@ -625,7 +632,20 @@ __global__ void k_preprocess_bwd(Settings s, PreBwdArgs a);
 // true: the grid of tile corners does not fit the LDS histogram; instances are counted / placed with L2 atomics
 // the splats of one workgroup of the rank path's three chunked passes (k_rcount reserves what k_rdscatter / k_rscatter fill: the same chunks in
 // all three): an even share rounded up to 32 -- round 3 rounded to 256, which at 100 k splats left 60 of the 256 workgroups without a chunk
+// Round 6: the chunks are INTERLEAVED -- groups of GSR_RANK_ILV consecutive splats dealt to the workgroups in turn (group g belongs to workgroup g mod nblk) -- so that
+// a run of large splats (the coarse faces of a head: hundreds of tiles each, contiguous in Morton order) is spread over every workgroup instead of landing in a few
+// (k_rscatter's time is its busiest workgroup's INSTANCE count: 89 us against 23 on the template-like avatar with contiguous chunks).  A group keeps the Morton
+// neighbours together, which is what merges a workgroup's entries in L2.  rank_chunk: local indices per workgroup (a multiple of the group); rank_splat: local -> splat.
+#ifndef GSR_RANK_ILV
+#define GSR_RANK_ILV 0    // 0: contiguous chunks (rounds 3 - 5).  Measured (r06_e): 8 / 16 / 64 take k_rsort_rscatter 88 -> 44 / 53 / 69 us on the template-like avatar and cost k_rcount +6 / +5 / +3 us on both scenes (every workgroup then touches every tile: one returning atomic per non-empty (workgroup, tile) bin)
+#endif
+#if GSR_RANK_ILV > 0
+__host__ __device__ inline int rank_chunk(int P, int nblk) { const int groups = (P + GSR_RANK_ILV - 1) / GSR_RANK_ILV; return (groups + nblk - 1) / nblk * GSR_RANK_ILV; }
+__host__ __device__ inline int rank_splat(int j, int blk, int nblk, int /*chunk*/) { return ((j / GSR_RANK_ILV) * nblk + blk) * GSR_RANK_ILV + (j % GSR_RANK_ILV); }
+#else
 __host__ __device__ inline int rank_chunk(int P, int nblk) { return ((P + nblk - 1) / nblk + 31) / 32 * 32; }
+__host__ __device__ inline int rank_splat(int j, int blk, int /*nblk*/, int chunk) { return blk * chunk + j; }
+#endif
 __host__ __device__ inline bool rank_direct(int gx, int tiles) { return (long long)(gx + 1) * (long long)(tiles / gx + 1) > (long long)GSR_RANK_HIST_TILES; }
 __global__ void k_rcount(int P, int gx, int tiles, int pblocks, uint32_t nb, const ushort4* srect, const uint32_t* tiles_touched,
                          const float* depths, const uint2* pstat, uint32_t* tile_count, unsigned long long* rect_total, uint32_t* block_hist,

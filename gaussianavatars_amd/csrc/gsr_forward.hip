@@ -38,12 +38,14 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         for (int t = i; t < a.nb; t += (int)(gridDim.x * blockDim.x)) a.bcount[t] = 0u;
         // the backward's work lists start empty (k_render<true> appends): the image state is a fresh, uninitialised allocation per forward
         if (i < GSR_UNIT_LISTS) a.units[32 * i] = 0u;
-        if (i < 2) a.units[cont_hdr_word((size_t)a.tiles) + 32 * i] = 0u;   // (and the continuation area's two counters)
+        if (i < GSR_CONT_HDR_WORDS / 32) a.units[cont_hdr_word((size_t)a.tiles) + 32 * i] = 0u;   // (and the continuation area's counters)
+        for (int t = i; t < 4 * a.tiles; t += (int)(gridDim.x * blockDim.x)) a.units[cont_hdr_word((size_t)a.tiles) + GSR_CONT_HDR_WORDS + t] = 0xFFFFFFFFu;
     } else {
         // this frame's tile histogram starts at zero (k_count runs after this kernel)
         for (int t = i; t < a.tiles; t += (int)(gridDim.x * blockDim.x)) a.tile_count[t] = 0u;
         if (i < GSR_UNIT_LISTS) a.units[32 * i] = 0u;   // the backward's work lists start empty (k_render<true> appends)
-        if (i < 2) a.units[cont_hdr_word((size_t)a.tiles) + 32 * i] = 0u;   // ... and no quadrant is parked for the continuation kernel, which has pulled none
+        if (i < GSR_CONT_HDR_WORDS / 32) a.units[cont_hdr_word((size_t)a.tiles) + 32 * i] = 0u;   // ... no quadrant is parked for the continuation workgroups, none pulled, no wave has reported
+        for (int t = i; t < 4 * a.tiles; t += (int)(gridDim.x * blockDim.x)) a.units[cont_hdr_word((size_t)a.tiles) + GSR_CONT_HDR_WORDS + t] = 0xFFFFFFFFu;   // (an unwritten list entry)
         if (i == 0) *a.rect_total = 0ull;
         if (a.pstat)   // rank path: the depth-bucket histogram and its fill cursors start at zero as well
             for (int t = i; t < a.nb; t += (int)(gridDim.x * blockDim.x)) { a.bcount[t] = 0u; a.bcursor[t] = 0u; }
@@ -810,8 +812,11 @@ extern "C" int gsr_debug_read_fwd(unsigned long long* host, int n) { return (int
 // Which chunks are walked from T = 1 and which from the true state depends on the chunk index and on the open pixels the wave itself saw four
 // chunks earlier, never on timing: the result is the same bits run to run.  Same arithmetic per record as the lone walk; what differs is the
 // association of the products (1e-7 relative), inside the fast blend's tolerance.
-template <bool FAST, bool CONT>
-__global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ qstart,
+#ifndef GSR_CONT_WAVES
+#define GSR_CONT_WAVES 8   // waves of a workgroup of the continuation KERNEL (CONT == 2) = chunks of a quadrant in flight
+#endif
+template <bool FAST, int CONT>
+__global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, CONT == 2 ? 1 : 5) void k_render(Settings s, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ qstart,
                                                  const uint32_t* __restrict__ qcount,
                                                  const float4* __restrict__ grec, const uint32_t* __restrict__ qpos,
                                                  const uint32_t* __restrict__ qlist, float* __restrict__ final_T,
@@ -820,16 +825,16 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
                                                  float* __restrict__ out_color, unsigned long long capacity,
                                                  const unsigned long long* __restrict__ total_dev, uint32_t* __restrict__ units, int tiles)
 {
-    static_assert(FAST || !CONT, "continuations belong to the fast blend");
+    static_assert(FAST || CONT == 0, "continuations belong to the fast blend");
     if (*total_dev > capacity) return;
 #ifdef GSR_EXPERIMENT_TIMELINE
     const unsigned long long t_start = wall_clock64();
 #endif
     const int W = s.W, H = s.H;
     const int gx = (W + GSR_BLOCK_X - 1) / GSR_BLOCK_X;
-    // the continuation area behind the backward's unit lists (gsr.h: GsrImageLayout.units): header (word 0: continuations parked by
-    // k_render<true, false>, word 32: the pull cursor of this kernel's workgroups; both zeroed by k_preprocess), the list of parked
-    // quadrants (launch position << 2 | quadrant), and 5 x 64 floats of state per quadrant slot
+    // the continuation area behind the backward's unit lists (gsr.h: GsrImageLayout.units): header (word 0: quadrants parked so far, word 32: the
+    // continuation workgroups' pull cursor, words 64 + 32 k, k < 16: tile waves that have reported; all zeroed by k_preprocess), the list of parked
+    // quadrants (launch position << 2 | quadrant; ~0 = not yet written: k_preprocess fills it), and 5 x 64 floats of state per quadrant slot
     const uint32_t ucap = (uint32_t)unit_list_cap((size_t)tiles);
     uint32_t* const cont_hdr = units + cont_hdr_word((size_t)tiles);
     uint32_t* const cont_list = cont_hdr + GSR_CONT_HDR_WORDS;
@@ -838,8 +843,9 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     const int pwave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // this wave inside its workgroup
     const int lane = threadIdx.x & 63;
     // per QUADRANT (k_render: once; the continuation kernel: once per pulled quadrant)
+    const bool helper = CONT == 2 || (CONT == 1 && blockIdx.x >= (uint32_t)tiles);   // a continuation workgroup (below): no tile of its own
     uint32_t lpos = blockIdx.x;                                  // the tile's position in the launch order
-    int tile = CONT ? 0 : (int)tile_order[blockIdx.x];
+    int tile = helper ? 0 : (int)tile_order[blockIdx.x];
     int tile_x = tile % gx, tile_y = tile / gx;
     int wave = pwave;                                            // the QUADRANT this wave blends (CONT: all four waves the same one)
     int pxi = tile_x * GSR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
@@ -847,8 +853,8 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     bool inside = pxi < W && pyi < H;
     float pixx = (float)pxi, pixy = (float)pyi;
 
-    int n = CONT ? 0 : (int)qcount[4 * tile + wave];
-    uint32_t qs = CONT ? 0u : qstart[4 * tile + wave];
+    int n = helper ? 0 : (int)qcount[4 * tile + wave];
+    uint32_t qs = helper ? 0u : qstart[4 * tile + wave];
     const float4* __restrict__ rec = grec;                      // the per-splat records (48 bytes each)
     const uint32_t* __restrict__ qp = qpos + qs;                // this quadrant's stream of splat indices
 
@@ -936,33 +942,6 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     };
     using Off0 = std::integral_constant<int, 0>;
     using Off1 = std::integral_constant<int, RB>;
-    auto keep_going = [&](int jb) {
-        const unsigned long long open_mask = __ballot(Tw > 0.0f);
-        int open;    // (through asm: the compiler widens popcountll's comparison to 64 bits and then does it on the VECTOR unit)
-        asm("s_bcnt1_i32_b64 %0, %1" : "=s"(open) : "s"(open_mask) : "scc");
-        if (open > TAIL_LANES) return true;
-        return open != 0 && n - jb <= 2 * GSR_WAVE;   // nothing open: stop; few open pixels and a long way to go: tail mode
-    };
-    // Software-pipelined walk: the scalar loads of batch k+1 are issued BEFORE batch k is blended, right after the wait for
-    // batch k's own loads (issued a whole batch ago) -- placed the other way round the wait would stall on the fresh loads.
-    // Blend checkpoints for the backward (include/gsr.h, GsrImageLayout.ck): the state (T, C) of every pixel just before
-    // stream entry s * GSR_BWD_SEGMENT, s = 1 .. GSR_BWD_SEGMENTS-1.  GSR_BWD_SEGMENT is a multiple of the two batches one
-    // iteration of the walk takes, so the test sits at the top of the loop only.  The store is unconditional: lanes outside
-    // the image aim at the spare slot behind the array (the layout's tail padding), closed pixels rewrite slots nobody reads.
-    static_assert(GSR_BWD_SEGMENT % (2 * RB) == 0, "checkpoints sit on iteration boundaries of the walk");
-    const size_t HWs = (size_t)H * W;
-    float4* ck_ptr = ck + (inside ? (size_t)(W * pyi + pxi) : (size_t)(GSR_BWD_SEGMENTS - 1) * HWs);
-    const size_t ck_step = inside ? HWs : 0;
-    int next_ck = s.forward_only ? 0x7fffffff : GSR_BWD_SEGMENT;   // (forward_only: no backward will read a checkpoint -- the test below never fires)
-    auto checkpoint = [&](int jtop) {
-        if (jtop == next_ck) {
-            if (next_ck <= (GSR_BWD_SEGMENTS - 1) * GSR_BWD_SEGMENT) {
-                *ck_ptr = make_float4(__builtin_fabsf(Tw), C0, C1, C2);
-                ck_ptr += ck_step;
-            }
-            next_ck += GSR_BWD_SEGMENT;
-        }
-    };
     int j0 = 0;
     // ---- the walk, records staged through LDS (round 4) ------------------------------------------------------------------------
     // Through the scalar unit (above, kept for A/B builds) a batch's records can only be requested ONE batch ahead -- scalar loads
@@ -976,7 +955,8 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     // Chunks are the backward's segments: the checkpoint test sits at the chunk boundary.
     constexpr int CH = GSR_BWD_SEGMENT;
     static_assert(CH <= GSR_WAVE && CH % (2 * RB) == 0, "a chunk is one gather of the wave and a whole number of double batches");
-    __shared__ float4 stage_all[4][2][CH * 3 + 3];   // (+3: the walk's read-ahead of a chunk's last double batch ends one batch past the chunk -- harmless, never used, but it has to be inside the allocation)
+    constexpr int NWV = CONT == 2 ? GSR_CONT_WAVES : 4;   // waves per workgroup
+    __shared__ float4 stage_all[NWV][2][CH * 3 + 3];   // (+3: the walk's read-ahead of a chunk's last double batch ends one batch past the chunk -- harmless, never used, but it has to be inside the allocation)
     float4(*const stage)[CH * 3 + 3] = stage_all[pwave];
     float4 g0, g1, g2;   // the chunk in flight: this lane's record
     auto gather = [&](int c) {   // entries past the end re-read the last one (never walked); lanes CH.. load too (never parked)
@@ -1156,23 +1136,56 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         }
     };
 
-    if constexpr (CONT) {
-        // ================= the continuation kernel: parked quadrants, four chunks in flight =================================================
-        __shared__ uint32_t s_pull;          // the continuation this workgroup works on
+    if constexpr (CONT != 0) {
+    if (helper) {
+        // ================= continuation workgroups: parked quadrants, four chunks in flight =========================================================
+        // CONT == 1: the LAST workgroups of k_render's own grid (dispatched behind every tile's workgroup, so they never keep one from starting):
+        // they wait for quadrants to be parked while the tiles' walks are still running and leave when every tile wave has reported and the list is
+        // drained.  CONT == 2: a kernel of its own behind k_render<true, 0> (everything is parked by then; nothing waits).
+        __shared__ uint32_t s_pull;          // the parked quadrant this workgroup works on (~0: none left)
         __shared__ uint32_t s_seq;           // the chunk whose prefix state lies in s_hand (~0: the quadrant is finished)
+        __shared__ uint32_t s_pending;       // re-evaluations of closing pixels still on their way to s_fin
         __shared__ float s_hand[5][64];      // (T signed as Tw, C0, C1, C2, last_q) of the 64 pixels before that chunk's first entry
-        const uint32_t parked = min(cont_hdr[0], 4u * (uint32_t)tiles);
+        __shared__ float s_fin[5][64];       // the same five values of every pixel that has CLOSED (written once, by the wave that saw it close)
         const size_t HWc = (size_t)H * W;
+        const uint32_t hidx = CONT == 1 ? blockIdx.x - (uint32_t)tiles : blockIdx.x, nhelp = CONT == 1 ? gridDim.x - (uint32_t)tiles : gridDim.x;
+        bool first_pull = true;
         for (;;) {
-            __syncthreads();                 // every wave is done with the previous quadrant (s_seq, s_hand, the stages)
+            __syncthreads();                 // every wave is done with the previous quadrant (s_seq, s_hand, s_fin, the stages)
             if (threadIdx.x == 0) {
-                s_pull = atomicAdd(cont_hdr + 32, 1u);
+                // the first pull is the workgroup's own index (no atomic: 768 returning atomics on one word are 9 us of queueing), the later ones
+                // come from the shared cursor behind those
+                const uint32_t ei = first_pull ? hidx : nhelp + atomicAdd(cont_hdr + 32, 1u);
+                uint32_t ent = 0xFFFFFFFFu;
+                if (ei < 4u * (uint32_t)tiles) {
+                    if constexpr (CONT == 2) {
+                        if (ei < cont_hdr[0]) ent = cont_list[ei];
+                    } else {
+                        // wait for entry ei of the list, or for the proof that it will never come: every tile wave reports (after its own post, if it
+                        // made one) on one of 16 counters; once they all have and the entry is still empty, the list ended below it
+                        for (uint32_t spins = 0; spins < (1u << 24); ++spins) {
+                            ent = __hip_atomic_load(cont_list + ei, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (ent != 0xFFFFFFFFu) break;
+                            if ((spins & 7u) == 7u) {
+                                uint32_t reported = 0;
+                                for (int k = 0; k < 16; ++k) reported += __hip_atomic_load(cont_hdr + 64 + 32 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (reported >= 4u * (uint32_t)tiles) {
+                                    ent = __hip_atomic_load(cont_list + ei, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    break;
+                                }
+                            }
+                            __builtin_amdgcn_s_sleep(8);
+                        }
+                    }
+                }
+                s_pull = ent;
                 s_seq = (uint32_t)cont_c;
+                s_pending = 0u;
             }
+            first_pull = false;
             __syncthreads();
-            const uint32_t ei = s_pull;
-            if (ei >= parked) return;
-            const uint32_t ent = cont_list[ei];
+            const uint32_t ent = s_pull;
+            if (ent == 0xFFFFFFFFu) return;
             lpos = ent >> 2;
             wave = (int)(ent & 3u);
             tile = (int)tile_order[lpos];
@@ -1185,23 +1198,67 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
             qs = qstart[4 * tile + wave];
             qp = qpos + qs;
             const int pix_id = inside ? W * pyi + pxi : 0;
-            const float* st = cont_state + (size_t)(4 * tile + wave) * GSR_CONT_STATE_FLOATS;
-            Tw = st[lane]; C0 = st[64 + lane]; C1 = st[128 + lane]; C2 = st[192 + lane];
-            last_q = reinterpret_cast<const uint32_t*>(st)[256 + lane];
+            {
+                const float* st = cont_state + (size_t)(4 * tile + wave) * GSR_CONT_STATE_FLOATS;
+                if constexpr (CONT == 1) {   // parked by a wave of THIS launch with write-through stores: read past this CU's L1
+                    Tw = __hip_atomic_load(st + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    C0 = __hip_atomic_load(st + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    C1 = __hip_atomic_load(st + 128 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    C2 = __hip_atomic_load(st + 192 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    last_q = __hip_atomic_load(reinterpret_cast<const uint32_t*>(st) + 256 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    Tw = st[lane]; C0 = st[64 + lane]; C1 = st[128 + lane]; C2 = st[192 + lane];
+                    last_q = reinterpret_cast<const uint32_t*>(st)[256 + lane];
+                }
+            }
+            auto to_fin = [&]() {   // this lane's pixel has closed: its five values, for whoever finishes the quadrant
+                s_fin[0][lane] = Tw; s_fin[1][lane] = C0; s_fin[2][lane] = C1; s_fin[3][lane] = C2; s_fin[4][lane] = __uint_as_float(last_q);
+            };
+            if (pwave == 0) to_fin();        // (the pixels that were closed when the quadrant was parked; the open ones are rewritten when they close)
+            __syncthreads();
             const int c_first = cont_c, nchunks = (n + CH - 1) / CH;
             unsigned long long myopen = __ballot(Tw > 0.0f);   // the open pixels as this wave last saw them
             bool have_g = false;
-            for (int c = c_first + pwave; c < nchunks; c += 4) {
+            for (int c = c_first + pwave; c < nchunks; c += NWV) {
                 if (__hip_atomic_load(&s_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0xFFFFFFFFu) break;   // finished further up: nothing to add
                 const int m = min(CH, n - c * CH);   // records of this chunk
                 if (!have_g) gather(c);
                 park(0);
                 asm volatile("" ::: "memory");
-                have_g = c + 4 < nchunks;
-                if (have_g) gather(c + 4);           // in flight behind this chunk's walk
-                // the chunk's records, one batch of three per read, a double batch per step (the lone walk's loop without its tests:
-                // pixels that are closed are inert by construction)
-                auto walk_chunk = [&]() {
+                have_g = c + NWV < nchunks;
+                if (have_g) gather(c + NWV);         // in flight behind this chunk's walk
+                // wait for the state before this chunk's first entry; false: the quadrant finished further up
+                auto wait_prefix = [&]() {
+                    for (uint32_t spins = 0; spins < (1u << 22); ++spins) {   // (the chunk below is always on its way: the bound only keeps a logic error from hanging the device)
+                        const uint32_t v = __hip_atomic_load(&s_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (v == 0xFFFFFFFFu) return false;
+                        if (v >= (uint32_t)c) return true;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    return false;
+                };
+                const bool first = c == c_first;
+                const bool spec = !first && __builtin_popcountll(myopen) > TAIL_LANES;
+                bool walk = spec;
+                if (spec) {
+                    // walked from T = 1 (pixels this wave knows to be closed: from 0) while the chunks below are still on their way
+                    Tw = ((myopen >> lane) & 1ull) ? 1.0f : 0.0f;
+                    C0 = 0.f; C1 = 0.f; C2 = 0.f;
+                    lq = 0; j0 = c * CH;
+                } else {
+                    if (!first) {
+                        if (!wait_prefix()) break;
+                        Tw = s_hand[0][lane]; C0 = s_hand[1][lane]; C1 = s_hand[2][lane]; C2 = s_hand[3][lane];
+                        last_q = __float_as_uint(s_hand[4][lane]);
+                    }
+                    myopen = __ballot(Tw > 0.0f);
+                    walk = __builtin_popcountll(myopen) > TAIL_LANES;   // (only the first chunk can get here with many pixels open)
+                    j0 = c * CH;
+                    lq = (int)last_q - j0;
+                }
+                if (walk) {
+                    // the chunk's records, one batch of three per read, a double batch per step (the lone walk's loop without its tests: pixels that are
+                    // closed are inert by construction)
                     RecV VA, VB;
                     Rec4 A, B;
                     uint32_t addr = lds0;
@@ -1232,29 +1289,11 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
                             lq -= RB;
                         }
                     }
-                };
-                auto chunk_records = [&](float4& r0, float4& r1, float4& r2) {   // lane l: record c * CH + l, back from the wave's stage
-                    const float4* sp = &stage[0][3 * min(lane, CH - 1)];
-                    r0 = sp[0]; r1 = sp[1]; r2 = sp[2];
-                };
-                // wait for the state before this chunk's first entry; false: the quadrant finished further up
-                auto wait_prefix = [&]() {
-                    for (uint32_t spins = 0; spins < (1u << 22); ++spins) {   // (the chunk below is always on its way: the bound only keeps a logic error from hanging the device)
-                        const uint32_t v = __hip_atomic_load(&s_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (v == 0xFFFFFFFFu) return false;
-                        if (v >= (uint32_t)c) return true;
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                    return false;
-                };
-                const bool first = c == c_first;
-                const bool spec = !first && __builtin_popcountll(myopen) > TAIL_LANES;
+                }
+                unsigned long long todo;         // pixels to evaluate with the record-parallel pass, from the TRUE state in their lanes
+                const unsigned long long open_before = myopen;
+                bool last;                        // the state after this chunk is the quadrant's result
                 if (spec) {
-                    // walked from T = 1 (pixels this wave knows to be closed: from 0) while the chunks below are still on their way
-                    Tw = ((myopen >> lane) & 1ull) ? 1.0f : 0.0f;
-                    C0 = 0.f; C1 = 0.f; C2 = 0.f;
-                    lq = 0; j0 = c * CH;
-                    walk_chunk();
                     const float Tl = Tw, L0 = C0, L1 = C1, L2 = C2;
                     const uint32_t hit = (uint32_t)(lq + j0);                       // > c * CH: the chunk's last contributor of this pixel
                     if (!wait_prefix()) break;
@@ -1263,59 +1302,127 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
                     const bool open_p = Tp > 0.0f;
                     const float Tt = Tp * Tl;
                     const bool thru = open_p && Tl > 0.0f && Tt >= 0.0001f;       // open before the chunk and no record of it closes the pixel
+                    todo = __ballot(open_p && !thru);                              // these close inside the chunk
+                    myopen = __ballot(thru);
+                    last = myopen == 0ull || c == nchunks - 1;
+                    if (!last) {
+                        // the chunks above only need to know WHICH pixels are still open: the state goes down the chain before the closing pixels
+                        // are evaluated (their values go to s_fin, off the chain)
+                        if (todo && lane == 0) __hip_atomic_fetch_add(&s_pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        s_hand[0][lane] = thru ? Tt : -1.0f;
+                        s_hand[1][lane] = __builtin_fmaf(Tp, L0, P0); s_hand[2][lane] = __builtin_fmaf(Tp, L1, P1); s_hand[3][lane] = __builtin_fmaf(Tp, L2, P2);
+                        s_hand[4][lane] = __uint_as_float(hit > (uint32_t)(c * CH) ? hit : lqp);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) __hip_atomic_store(&s_seq, (uint32_t)(c + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (!s.forward_only && c + 1 <= GSR_BWD_SEGMENTS - 1 && inside && thru)   // (the backward reads a checkpoint only where the pixel goes on)
+                            ck[(size_t)c * HWc + pix_id] = make_float4(Tt, __builtin_fmaf(Tp, L0, P0), __builtin_fmaf(Tp, L1, P1), __builtin_fmaf(Tp, L2, P2));
+                    }
                     Tw = thru ? Tt : Tp;
                     C0 = thru ? __builtin_fmaf(Tp, L0, P0) : P0;
                     C1 = thru ? __builtin_fmaf(Tp, L1, P1) : P1;
                     C2 = thru ? __builtin_fmaf(Tp, L2, P2) : P2;
                     last_q = (thru && hit > (uint32_t)(c * CH)) ? hit : lqp;
-                    const unsigned long long closers = __ballot(open_p && !thru);
-                    if (closers) {   // these close inside the chunk: once more from the true prefix, records across the lanes
-                        float4 r0, r1, r2;
-                        chunk_records(r0, r1, r2);
-                        (void)tail_pairs(closers, c * CH, lane < m, r0, r1, r2);
+                } else {
+                    if (walk) last_q = (uint32_t)(lq + j0);
+                    todo = walk ? 0ull : myopen;
+                }
+                if (todo) {   // records across the lanes, the pixels two at a time
+                    const float4* sp = &stage[0][3 * min(lane, CH - 1)];
+                    (void)tail_pairs(todo, c * CH, lane < m, sp[0], sp[1], sp[2]);
+                }
+                if (spec) {
+                    if (todo) {
+                        if ((todo >> lane) & 1ull) to_fin();
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (!last && lane == 0) __hip_atomic_fetch_sub(&s_pending, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 } else {
-                    if (!first) {
-                        if (!wait_prefix()) break;
-                        Tw = s_hand[0][lane]; C0 = s_hand[1][lane]; C1 = s_hand[2][lane]; C2 = s_hand[3][lane];
-                        last_q = __float_as_uint(s_hand[4][lane]);
-                    }
-                    const unsigned long long open_now = __ballot(Tw > 0.0f);
-                    if (__builtin_popcountll(open_now) > TAIL_LANES) {
-                        j0 = c * CH;
-                        lq = (int)last_q - j0;
-                        walk_chunk();
-                        last_q = (uint32_t)(lq + j0);
-                    } else if (open_now) {
-                        float4 r0, r1, r2;
-                        chunk_records(r0, r1, r2);
-                        (void)tail_pairs(open_now, c * CH, lane < m, r0, r1, r2);
+                    myopen = __ballot(Tw > 0.0f);
+                    if (((open_before & ~myopen) >> lane) & 1ull) to_fin();   // closed in this chunk
+                    last = myopen == 0ull || c == nchunks - 1;
+                    if (!last) {
+                        if (!s.forward_only && c + 1 <= GSR_BWD_SEGMENTS - 1 && inside)
+                            ck[(size_t)c * HWc + pix_id] = make_float4(__builtin_fabsf(Tw), C0, C1, C2);
+                        s_hand[0][lane] = Tw; s_hand[1][lane] = C0; s_hand[2][lane] = C1; s_hand[3][lane] = C2; s_hand[4][lane] = __uint_as_float(last_q);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) __hip_atomic_store(&s_seq, (uint32_t)(c + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
-                myopen = __ballot(Tw > 0.0f);
-                if (myopen == 0ull || c == nchunks - 1) {   // the state after this chunk is the quadrant's result
+                if (last) {
+                    // every pixel that closed on the way left its values in s_fin (the waves still evaluating theirs are counted in s_pending)
+                    for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+                        if (__hip_atomic_load(&s_pending, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (!(Tw > 0.0f)) {
+                        Tw = s_fin[0][lane]; C0 = s_fin[1][lane]; C1 = s_fin[2][lane]; C2 = s_fin[3][lane];
+                        last_q = __float_as_uint(s_fin[4][lane]);
+                    }
                     finish();
                     if (lane == 0) __hip_atomic_store(&s_seq, 0xFFFFFFFFu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     break;
                 }
-                // the state before entry (c + 1) * CH: the backward's checkpoint (slot c), and the prefix of the next chunk's wave
-                if (!s.forward_only && c + 1 <= GSR_BWD_SEGMENTS - 1 && inside)
-                    ck[(size_t)c * HWc + pix_id] = make_float4(__builtin_fabsf(Tw), C0, C1, C2);
-                s_hand[0][lane] = Tw; s_hand[1][lane] = C0; s_hand[2][lane] = C1; s_hand[3][lane] = C2; s_hand[4][lane] = __uint_as_float(last_q);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) __hip_atomic_store(&s_seq, (uint32_t)(c + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-    } else {
+    }
+    }
+    {
+    auto keep_going = [&](int jb) {
+        const unsigned long long open_mask = __ballot(Tw > 0.0f);
+        int open;    // (through asm: the compiler widens popcountll's comparison to 64 bits and then does it on the VECTOR unit)
+        asm("s_bcnt1_i32_b64 %0, %1" : "=s"(open) : "s"(open_mask) : "scc");
+        if (open > TAIL_LANES) return true;
+        return open != 0 && n - jb <= 2 * GSR_WAVE;   // nothing open: stop; few open pixels and a long way to go: tail mode
+    };
+    // Software-pipelined walk: the scalar loads of batch k+1 are issued BEFORE batch k is blended, right after the wait for
+    // batch k's own loads (issued a whole batch ago) -- placed the other way round the wait would stall on the fresh loads.
+    // Blend checkpoints for the backward (include/gsr.h, GsrImageLayout.ck): the state (T, C) of every pixel just before
+    // stream entry s * GSR_BWD_SEGMENT, s = 1 .. GSR_BWD_SEGMENTS-1.  GSR_BWD_SEGMENT is a multiple of the two batches one
+    // iteration of the walk takes, so the test sits at the top of the loop only.  The store is unconditional: lanes outside
+    // the image aim at the spare slot behind the array (the layout's tail padding), closed pixels rewrite slots nobody reads.
+    static_assert(GSR_BWD_SEGMENT % (2 * RB) == 0, "checkpoints sit on iteration boundaries of the walk");
+    const size_t HWs = (size_t)H * W;
+    float4* ck_ptr = ck + (inside ? (size_t)(W * pyi + pxi) : (size_t)(GSR_BWD_SEGMENTS - 1) * HWs);
+    const size_t ck_step = inside ? HWs : 0;
+    int next_ck = s.forward_only ? 0x7fffffff : GSR_BWD_SEGMENT;   // (forward_only: no backward will read a checkpoint -- the test below never fires)
+    auto checkpoint = [&](int jtop) {
+        if (jtop == next_ck) {
+            if (next_ck <= (GSR_BWD_SEGMENTS - 1) * GSR_BWD_SEGMENT) {
+                *ck_ptr = make_float4(__builtin_fabsf(Tw), C0, C1, C2);
+                ck_ptr += ck_step;
+            }
+            next_ck += GSR_BWD_SEGMENT;
+        }
+    };
     // a lone walk that reaches the hand-over chunk parks its state for the continuation kernel and leaves (nothing of the quadrant's
     // outputs is written here; the checkpoint before the chunk has been)
     auto park_quadrant = [&](uint32_t lastq_abs) {
         int slot = 4 * tile + wave;
         asm volatile("" : "+s"(slot));   // (the addresses are formed HERE: hoisted out of the walk they cost it eight vector registers and a wave per SIMD)
         float* st = cont_state + (size_t)slot * GSR_CONT_STATE_FLOATS;
-        st[lane] = Tw; st[64 + lane] = C0; st[128 + lane] = C1; st[192 + lane] = C2;
-        reinterpret_cast<uint32_t*>(st)[256 + lane] = lastq_abs;
-        if (lane == 0) cont_list[atomicAdd(cont_hdr, 1u)] = lpos << 2 | (uint32_t)wave;
+        if constexpr (CONT == 1) {
+            // read by a workgroup of THIS launch, on any XCD: write-through stores, drained, then the list entry (MI355X_MICROARCH.md, hand-off forms)
+            __hip_atomic_store(st + lane, Tw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st + 64 + lane, C0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st + 128 + lane, C1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st + 192 + lane, C2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<uint32_t*>(st) + 256 + lane, lastq_abs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                const uint32_t at = atomicAdd(cont_hdr, 1u);
+                __hip_atomic_store(cont_list + at, lpos << 2 | (uint32_t)wave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the entry is out before this wave reports: a waiting workgroup that has seen every report has seen every entry)
+            }
+        } else {
+            st[lane] = Tw; st[64 + lane] = C0; st[128 + lane] = C1; st[192 + lane] = C2;
+            reinterpret_cast<uint32_t*>(st)[256 + lane] = lastq_abs;
+            if (lane == 0) cont_list[atomicAdd(cont_hdr, 1u)] = lpos << 2 | (uint32_t)wave;
+        }
+    };
+    auto report = [&]() {   // CONT == 1: this tile wave is done (parked or finished): one of 16 counters the waiting continuation workgroups add up
+        if constexpr (CONT == 1) {
+            if (lane == 0) (void)__hip_atomic_fetch_add(cont_hdr + 64 + 32 * (blockIdx.x & 15u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     };
     bool hand_over = false;   // the walk reached the hand-over chunk with the stream going on
     if (n > 0) {
@@ -1383,6 +1490,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     last_q = (uint32_t)(lq + j0);   // (lq + j0 >= 0: a pixel without a hit kept lq = -j0)
     if (hand_over) {
         park_quadrant(last_q);
+        report();
         return;
     }
 
@@ -1404,6 +1512,7 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
         while (c0 < n && open_mask) {
             if (c0 % CH == 0 && c0 / CH == cont_c) {   // (the tail's chunks end on checkpoint entries: the hand-over entry is the top of one)
                 park_quadrant(last_q);
+                report();
                 return;
             }
             const int c1 = min(n, (c0 / GSR_BWD_SEGMENT + 1) * GSR_BWD_SEGMENT);   // the chunk ends where the next checkpoint sits (<= 60 entries)
@@ -1490,15 +1599,18 @@ __global__ __launch_bounds__(256) void k_render(Settings s, const uint32_t* __re
     }
 #endif
     finish();
-    }   // (!CONT)
+    report();
+    }   // (a tile's workgroup)
 }
 
-template __global__ void k_render<false, false>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
+template __global__ void k_render<false, 0>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
                                                 uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*, int);
-template __global__ void k_render<true, false>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
+template __global__ void k_render<true, 0>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
                                                uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*, int);
-template __global__ void k_render<true, true>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
-                                              uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*, int);
+template __global__ void k_render<true, 2>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
+                                           uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*, int);
+template __global__ void k_render<true, 1>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
+                                           uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*, int);
 
 // ------------------------------------------------------------------------------------------
 // k_mark_visible (upstream checkFrustum): present = view z > 0.2

@@ -108,17 +108,16 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int P, int gx, 
     float lo, scale;
     rank_bucket_map(mn, mx, nb, lo, scale);
 
-    const int chunk = rank_chunk(P, (int)gridDim.x);
-    const int begin = blockIdx.x * chunk;
-    const int end = min(P, begin + chunk);
+    const int chunk = rank_chunk(P, (int)gridDim.x);   // local indices 0 .. chunk - 1 of this workgroup's (interleaved) splats: rank_splat
+    const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
     unsigned long long touched = 0;
     const int gy = tiles / gx, sx = gx + 1;   // the LDS grid has one more column and row: rect corners lie on tile CORNERS
     if (direct) {
-        for (int base = begin; base < end; base += NT / G) {
-            const int i = base + tid / G;
+        for (int base = 0; base < chunk; base += NT / G) {
+            const int j = base + tid / G, i = j < chunk ? rank_splat(j, blk, nblk, chunk) : P;
             uint32_t n = 0;
             int minx = 0, miny = 0, maxx = 0, maxy = 0;
-            if (i < end) {
+            if (i < P) {
                 const ushort4 r = srect[i];
                 minx = r.x; miny = r.y; maxx = r.z; maxy = r.w;
                 n = (uint32_t)((maxx - minx) * (maxy - miny));
@@ -132,7 +131,9 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int P, int gx, 
     } else {
         // A rect adds 1 to every tile it covers = +1 / -1 / -1 / +1 at its four corners followed by a 2-D prefix sum over the grid:
         // four LDS atomics per splat whatever its size (18 tiles on average), one splat per lane
-        for (int i = begin + tid; i < end; i += NT) {
+        for (int j = tid; j < chunk; j += NT) {
+            const int i = rank_splat(j, blk, nblk, chunk);
+            if (i >= P) continue;
             const ushort4 r = srect[i];
             touched += tiles_touched[i];
             if (r.z != r.x) {
@@ -422,8 +423,9 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rdscatter(int P, uint3
     float lo, scale;
     rank_bucket_map(hdr->dmin_bits, hdr->dmax_bits, nb, lo, scale);
     const int chunk = rank_chunk(P, (int)nblk);
-    const int begin = blockIdx.x * chunk, end = min(P, begin + chunk);
-    for (int i = begin + tid; i < end; i += NT) {
+    for (int j = tid; j < chunk; j += NT) {
+        const int i = rank_splat(j, (int)blockIdx.x, (int)nblk, chunk);
+        if (i >= P) continue;
         const ushort4 r = srect[i];
         if (r.z == r.x) continue;   // not binned
         const float d = depths[i];
@@ -608,30 +610,30 @@ __device__ __forceinline__ void rscatter_body(int P, int gx, int tiles, BandTabl
     const bool bands = !LEAN && bt.nbands > 1;
     const uint4* __restrict__ rank4 = reinterpret_cast<const uint4*>(rank);   // bands: the ranks inside the first four bands of the rect
     const int chunk = rank_chunk(P, nblk);
-    const int begin = blockIdx.x * chunk;
-    const int end = min(P, begin + chunk);
+    const int blk = (int)blockIdx.x;
+    auto splat_of = [&](int j) { return j < chunk ? rank_splat(j, blk, nblk, chunk) : P; };   // local index -> splat (P: none)
     // a splat's inputs, fetched one round ahead of their use (all four loads are independent: rank / operands of a splat that is
     // not binned are never looked at)
     struct In { ushort4 q; uint4 rk; float4 s0, s1; };
     auto fetch = [&](int i) {
         In v;
         v.q = make_ushort4(0, 0, 0, 0); v.rk = make_uint4(0u, 0u, 0u, 0u); v.s0 = v.s1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < end) {
+        if (i < P) {
             v.q = srect[i]; v.s0 = sspan[2 * (size_t)i]; v.s1 = sspan[2 * (size_t)i + 1];
             if (bands) v.rk = rank4[i]; else if (!LEAN) v.rk.x = rank[i];
         }
         return v;
     };
-    In nxt = fetch(begin + tid / G);
+    In nxt = fetch(splat_of(tid / G));
     if (!direct) {
         const uint32_t* __restrict__ mine = block_hist + (size_t)blockIdx.x * tiles;
         for (int t = tid; t < tiles; t += NT) hist[t] = tile_start[t] + mine[t];   // first slot of this workgroup in tile t (k_rcount reserved it)
         __syncthreads();
     }
-    for (int base = begin; base < end; base += NT / G) {
-        const int i = base + tid / G;
+    for (int base = 0; base < chunk; base += NT / G) {
+        const int i = splat_of(base + tid / G);
         const In cur = nxt;
-        nxt = fetch(i + NT / G);
+        nxt = fetch(splat_of(base + tid / G + NT / G));
         const int minx = cur.q.x, miny = cur.q.y, maxx = cur.q.z, maxy = cur.q.w;
         const uint32_t n = (uint32_t)((maxx - minx) * (maxy - miny));
         const uint4 rk = cur.rk;
@@ -730,15 +732,14 @@ __device__ __forceinline__ void rscatter_balanced(RscatterStage<LEAN>& stage, in
     const bool bands = !LEAN && bt.nbands > 1;
     const uint4* __restrict__ rank4 = reinterpret_cast<const uint4*>(rank);
     const int chunk = rank_chunk(P, nblk);
-    const int begin = blockIdx.x * chunk;
-    const int end = min(P, begin + chunk);
+    const int blk = (int)blockIdx.x;
     uint4(*const rows)[ROW] = stage.row[wv];
     uint32_t* const own = stage.own[wv];
     struct In { ushort4 q; uint4 rk; float4 s0, s1; };
     auto fetch = [&](int i) {
         In v;
         v.q = make_ushort4(0, 0, 0, 0); v.rk = make_uint4(0u, 0u, 0u, 0u); v.s0 = v.s1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < end) {
+        if (i < P) {
             v.q = srect[i]; v.s0 = sspan[2 * (size_t)i]; v.s1 = sspan[2 * (size_t)i + 1];
             if (bands) v.rk = rank4[i]; else if (!LEAN) v.rk.x = rank[i];
         }
@@ -748,8 +749,11 @@ __device__ __forceinline__ void rscatter_balanced(RscatterStage<LEAN>& stage, in
     // ones the chunk is dealt over all sixteen waves -- at 100 k splats a workgroup's ~400 would otherwise keep seven waves busy and nine idle
     const int SB = min(64, max(8, (chunk + NT / 64 - 1) / (NT / 64)));
     const int stride = SB * (NT / 64);
-    auto mine_of = [&](int base) { return lane < SB ? base + wv * SB + lane : end; };
-    In nxt = fetch(mine_of(begin));
+    auto mine_of = [&](int base) {   // this lane's splat of the round that starts at local index `base` (P: none)
+        const int j = base + wv * SB + lane;
+        return lane < SB && j < chunk ? rank_splat(j, blk, nblk, chunk) : P;
+    };
+    In nxt = fetch(mine_of(0));
     if (!direct) {
         const uint32_t* __restrict__ mine = block_hist + (size_t)blockIdx.x * tiles;
         for (int t = tid; t < tiles; t += NT) hist[t] = tile_start[t] + mine[t];   // first slot of this workgroup in tile t (k_rcount reserved it)
@@ -771,7 +775,7 @@ __device__ __forceinline__ void rscatter_balanced(RscatterStage<LEAN>& stage, in
         if (LEAN) lean[slot] = bidx | (m << GSR_RANK_IDX_BITS);
         else ranks[slot] = make_uint2(brk, bidx | (m << GSR_RANK_IDX_BITS));
     };
-    for (int base = begin; base < end; base += stride) {
+    for (int base = 0; base < chunk; base += stride) {
         const int i = mine_of(base);
         const In cur = nxt;
         nxt = fetch(mine_of(base + stride));

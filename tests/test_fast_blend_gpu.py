@@ -143,7 +143,7 @@ def test_fast_backward_on_poisoned_state_buffers(oracle, name, culling):
         assert err < REL_GRAD, f"{name}/culling {culling}/{k}: rel err {err:.3e}"
 
 
-def test_fast_and_exact_agree_on_the_benchmark_frame():
+def test_fast_and_exact_agree_on_the_benchmark_frame(oracle):
     """BASELINE configs[2] (100 k bound splats, 802x550) through render(): the two modes on the same frame -- integers equal, image within
     the stated tolerance, leaf gradients within REL_GRAD of each other."""
     import bench
@@ -169,9 +169,29 @@ def test_fast_and_exact_agree_on_the_benchmark_frame():
     for a, b, nm in zip(out[True]["grads"], out[False]["grads"], ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")):
         err = np.abs(a - b).max() / (np.abs(b).max() + 1e-20)
         assert err < REL_GRAD, f"{nm}: {err:.3e}"
+    # the FLAME rows of the two modes against each other: each within twice its own bar against fp64 (tests/test_fullsize_gpu.py: _flame_row_bars -- a multiple
+    # of the composed-torch binding's fp32-vs-fp64 deviation on this frame's gradients; both modes are held to that bar against the oracle in
+    # test_config3_benchmarked_step_in_the_benchmarked_mode / the exact-mode tests)
+    from tests.test_fullsize_gpu import _flame_row_bars, _leaf_gradients_fp64
+
+    O = oracle
+
+    tfx, tfy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    s = O.make_settings(802, 550, tfx, tfy, [1, 1, 1], 1.0, _np(cam.world_view_transform), _np(cam.full_proj_transform), 3, _np(cam.camera_center))
+    g.select_mesh_by_timestep(1)
+    with torch.no_grad():
+        w = {k: _np(v) for k, v in dict(means3D=g.get_xyz, opacities=g.get_opacity, scales=g.get_scaling, rotations=g.get_rotation).items()}
+        shs = _np(g.get_features)
+    st = O.forward(s, w["means3D"], shs, None, w["opacities"], w["scales"], w["rotations"], None)
+    ref = O.backward(s, st, (np.sign(st.color - 1.0) / st.color.size).astype(np.float32))
+    bars = _flame_row_bars(g, 1, ref, _leaf_gradients_fp64(g, 1, ref))
     for k in out[False]["flame"]:
         a, b = out[True]["flame"][k], out[False]["flame"][k]
-        assert np.abs(a - b).max() <= 2e-3 * (np.abs(b).max() + 1e-20), k
+        if k not in bars:
+            continue
+        err = np.abs(a - b).max() / (np.abs(b).max() + 1e-20)
+        print(f"cfg3 fast vs exact d flame {k}: {err:.2e} (bar 2 x {bars[k][1]:.2e})")
+        assert err <= 2.0 * bars[k][1], k
     print(f"cfg3: {n} threshold pixel(s), image max|diff| {np.abs(out[True]['img'] - out[False]['img']).max():.2e}")
 
 
@@ -182,7 +202,7 @@ def test_fast_bound_entry_on_the_rigged_200k_frame_vs_oracle(oracle):
     import bench
     from gaussianavatars_amd.gaussian_renderer import l1_loss, render
     from gaussianavatars_amd.rasterizer import set_fast_blend
-    from tests.test_fullsize_gpu import _leaf_gradients_fp64
+    from tests.test_fullsize_gpu import _check_flame_rows, _leaf_gradients_fp64
 
     dev = _dev()
     H, W, N, T, ts = 802, 550, 200_000, 300, 137
@@ -212,4 +232,5 @@ def test_fast_bound_entry_on_the_rigged_200k_frame_vs_oracle(oracle):
         r = np.asarray(want[k], np.float64).reshape(tuple(v.shape))
         err = np.abs(_np(v).astype(np.float64) - r).max() / (np.abs(r).max() + 1e-30)
         assert err < 5e-4, f"bound entry, fast blend: d{k} rel err {err:.2e}"
+    _check_flame_rows(g, ts, ref, want, "cfg4 fast blend")
     print(f"cfg4 fast blend: {n} threshold pixel(s)")

@@ -105,13 +105,14 @@ def test_config2_100k_bound_forward_backward_vs_oracle(oracle):
     assert float(err) < 1e-4
 
 
-def _leaf_gradients_fp64(g, ts, ref):
+def _leaf_gradients(g, ts, ref, dtype=torch.float64):
     """The oracle's world-space gradients `ref` (means3D, scales, rotations, opacities, shs) carried to the model's leaves and to row `ts`
-    of the FLAME tables by the composed-torch binding in double precision."""
+    of the FLAME tables by the composed-torch binding (gaussianavatars_amd/unfused.py: the reference's scene/gaussian_model.py:113-150,
+    utils/graphics_utils.py:116-135, flame_model/lbs.py restated and pinned to the reference's classes by tests/test_model_pins.py) in `dtype`."""
     from gaussianavatars_amd import unfused as U
 
     dev = g._xyz.device
-    d = lambda t: t.detach().to(torch.float64)
+    d = lambda t: t.detach().to(dtype)
     fm = g.flame_model
     rig = {k: d(getattr(fm, k)) for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights")}
     rig["parents"] = fm.parents
@@ -123,13 +124,99 @@ def _leaf_gradients_fp64(g, ts, ref):
     c, R, sc, q = U.face_frames(verts[0], fm.faces)
     world = [U.bind_xyz(leaves["_xyz"], g.binding, R, sc, c), U.bind_scaling(leaves["_scaling"], g.binding, sc),
              U.bind_rotation(leaves["_rotation"], g.binding, q), torch.sigmoid(leaves["_opacity"])]
-    grads = [torch.as_tensor(ref[k], dtype=torch.float64, device=dev).reshape(w.shape) for k, w in zip(("means3D", "scales", "rotations", "opacities"), world)]
+    grads = [torch.as_tensor(ref[k], dtype=dtype, device=dev).reshape(w.shape) for k, w in zip(("means3D", "scales", "rotations", "opacities"), world)]
     torch.autograd.backward(world, grads)
     out = {k: v.grad.cpu().numpy() for k, v in leaves.items()}
     out.update({"flame_" + k: v.grad[0].cpu().numpy() for k, v in rows.items()})
     shs = np.asarray(ref["shs"], np.float64)
     out["_features_dc"], out["_features_rest"] = shs[:, :1], shs[:, 1:]
     return out
+
+
+def _leaf_gradients_fp64(g, ts, ref):
+    return _leaf_gradients(g, ts, ref, torch.float64)
+
+
+FLAME_ROWS = ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation")
+FLAME_ROW_FLOOR = 3e-5   # the floor of a FLAME-row bar (rounds 3 - 5 held these rows to a flat 2e-3).  Measured on the MI355X, round 6: errors 2e-7 .. 9e-6, the composed-torch binding's own fp32 deviation 1e-8 .. 2e-5
+FLAME_ROW_FACTOR = 6.0   # ... and otherwise this multiple of the composed-torch binding's OWN fp32-vs-fp64 deviation on the same gradients (as tests/test_model_pins.py:88-113)
+
+
+def _flame_row_bars(g, ts, ref, want64):
+    """{row: (deviation, bar)}: a FLAME row's gradient is a sum over every splat of terms that largely cancel (the orientation and scale parts of a
+    rigid motion), so ANY fp32 evaluation is a draw around the fp64 value.  The yardstick is how far the reference-shaped composed-torch binding lands from
+    its own fp64 result when it is run in fp32 on the SAME world-space gradients; the bar is FLAME_ROW_FACTOR times that, never below FLAME_ROW_FLOOR."""
+    w32 = _leaf_gradients(g, ts, ref, torch.float32)
+    out = {}
+    for k in FLAME_ROWS:
+        r = np.asarray(want64["flame_" + k], np.float64)
+        dev = float(np.abs(np.asarray(w32["flame_" + k], np.float64) - r).max() / (np.abs(r).max() + 1e-30))
+        out[k] = (dev, max(FLAME_ROW_FLOOR, FLAME_ROW_FACTOR * dev))
+    return out
+
+
+def _check_flame_rows(g, ts, ref, want64, what):
+    """The FLAME-row gradients of the model against `want64` (the oracle carried to row ts in fp64), each held to its own bar; the measured errors are printed."""
+    bars = _flame_row_bars(g, ts, ref, want64)
+    for k in FLAME_ROWS:
+        r = np.asarray(want64["flame_" + k], np.float64)
+        err = float(np.abs(_np(g.flame_param[k].grad[ts]).astype(np.float64) - r).max() / (np.abs(r).max() + 1e-30))
+        dev, bar = bars[k]
+        print(f"{what} d flame {k}: err {err:.2e}  composed-torch fp32 deviation {dev:.2e}  bar {bar:.2e}")
+        assert err < bar, f"{what} d flame {k}: rel err {err:.2e} (bar {bar:.2e} = max({FLAME_ROW_FLOOR:g}, {FLAME_ROW_FACTOR:g} x {dev:.2e}))"
+
+
+def test_config3_benchmarked_step_in_the_benchmarked_mode(oracle):
+    """BASELINE configs[2], the step bench.py times, in the mode it times it: 100 000 Morton-ordered mesh-bound splats through select_mesh_by_timestep ->
+    render() -> l1_loss -> backward() with the PRODUCT defaults -- fast blend, tile culling, the bound entry, the compiled host (asserted from
+    last_forward_info) -- against the oracle directly: image within the fast blend's stated tolerance, radii equal, the six leaf gradients and the
+    screen-space gradient within 5e-4 of the oracle's world-space gradients carried to the leaves in fp64, every FLAME row within its own bar."""
+    import bench
+    from gaussianavatars_amd import _host
+    from gaussianavatars_amd import rasterizer as R
+    from gaussianavatars_amd.gaussian_renderer import l1_loss, render
+    from tests.test_fast_blend_gpu import check_image
+
+    dev = _dev()
+    H, W, N, T = 802, 550, 100_000, 8
+    assert bench.SPATIAL_SORT
+    g, cam = bench.build_scene(dev, N, 3, W, H, T, "fused", True)
+    bg = torch.ones(3, device=dev)
+    target = torch.ones((3, H, W), device=dev)
+    tfx, tfy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    s = oracle.make_settings(H, W, tfx, tfy, [1, 1, 1], 1.0, _np(cam.world_view_transform), _np(cam.full_proj_transform), 3, _np(cam.camera_center))
+    prev = R.set_fast_blend(True)
+    try:
+        for ts in (0, 5):
+            g.select_mesh_by_timestep(ts)
+            with torch.no_grad():
+                a = {k: _np(v) for k, v in dict(means3D=g.get_xyz, opacities=g.get_opacity, scales=g.get_scaling, rotations=g.get_rotation).items()}
+                shs = _np(g.get_features)
+            st = oracle.forward(s, a["means3D"], shs, None, a["opacities"], a["scales"], a["rotations"], None)
+            ref = oracle.backward(s, st, (np.sign(st.color - 1.0) / st.color.size).astype(np.float32))
+            want = _leaf_gradients_fp64(g, ts, ref)
+            want["means2D"] = ref["means2D"]
+            # the benchmarked step (bench.one_step)
+            bench.zero_grads(g)
+            g.select_mesh_by_timestep(ts)
+            pkg = render(cam, g, bench.Pipe, bg)
+            l1_loss(pkg["render"], target).backward()
+            info = R.last_forward_info()
+            assert info.get("bound") and info.get("tile_culling") and not info.get("forward_only"), info
+            assert bool(info.get("native_host")) == (_host.get() is not None), info
+            np.testing.assert_array_equal(_np(pkg["radii"]), st.radii)
+            n = check_image(_np(pkg["render"]), st.color, float(st.rgb[st.radii > 0].max()), f"cfg3 t={ts}")
+            got = dict(_xyz=g._xyz.grad, _scaling=g._scaling.grad, _rotation=g._rotation.grad, _opacity=g._opacity.grad,
+                       _features_dc=g._features_dc.grad, _features_rest=g._features_rest.grad, means2D=pkg["viewspace_points"].grad)
+            for k, v in got.items():
+                r = np.asarray(want[k], np.float64).reshape(tuple(v.shape))
+                err = np.abs(_np(v).astype(np.float64) - r).max() / (np.abs(r).max() + 1e-30)
+                assert err < 5e-4, f"cfg3 t={ts} benchmarked mode d{k}: rel err {err:.2e}"
+            _check_flame_rows(g, ts, ref, want, f"cfg3 t={ts} benchmarked mode")
+            print(f"cfg3 t={ts} benchmarked mode ({'compiled' if info.get('native_host') else 'python'} host): {n} threshold pixel(s), "
+                  f"image max|diff| {np.abs(_np(pkg['render']) - st.color).max():.2e}")
+    finally:
+        R.set_fast_blend(prev)
 
 
 def test_config4_200k_rigged_sequence_vs_oracle(oracle):
@@ -203,10 +290,7 @@ def test_config4_200k_rigged_sequence_vs_oracle(oracle):
             r = np.asarray(want[k], np.float64).reshape(tuple(v.shape))
             err = np.abs(_np(v).astype(np.float64) - r).max() / (np.abs(r).max() + 1e-30)
             assert err < 5e-4, f"t={ts} bound entry d{k}: rel err {err:.2e}"
-        for k in ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation"):
-            r = want["flame_" + k]
-            err = np.abs(_np(g.flame_param[k].grad[ts]).astype(np.float64) - r).max() / (np.abs(r).max() + 1e-30)
-            assert err < 2e-3, f"t={ts} bound entry d flame {k}: rel err {err:.2e}"    # (sums over 200 k splats of cancelling terms: the fp32 kernels' own noise, cf. test_model_pins)
+        _check_flame_rows(g, ts, ref, want, f"cfg4 t={ts} bound entry")   # (sums over 200 k splats of cancelling terms: each row's bar is a multiple of the composed-torch binding's own fp32 noise)
 
 
 def test_config5_2m_stress_forward(oracle):
