@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <thread>
 #include <vector>
 
@@ -173,6 +175,34 @@ int ensure_dynamic_lds(const void* fn, size_t bytes)
     return 0;
 }
 
+// ---- the posted word: seq << 40 | flag << 39 | I.  The flag is the rank path's "the tile instances are spread unevenly along the splat order" (k_rcount from
+// k_preprocess's per-workgroup sums): the NEXT frames of that (device, image size) deal their rank-pass chunks out in groups of GSR_RANK_ILV_AUTO splats
+// instead of contiguous runs (gsr_device.h: rank_chunk).  A running hint like the callers' capacity estimate: it changes how long a frame takes, never what it computes.
+constexpr unsigned long long kCountMask = 0x7FFFFFFFFFull;
+std::mutex g_ilv_mutex;
+std::map<std::tuple<int, int, int>, int> g_ilv_hint;        // (device, W, H) -> uneven?
+std::tuple<int, int, int> g_slot_frame[GSR_COUNT_SLOTS + 1]; // the frame whose count a slot holds (index GSR_COUNT_SLOTS: the blocking call's own slot)
+void note_posted(int slot_index, unsigned long long v)
+{
+    if (!v) return;
+    std::lock_guard<std::mutex> lock(g_ilv_mutex);
+    const auto key = g_slot_frame[slot_index];
+    if (std::get<1>(key) > 0) g_ilv_hint[key] = (int)((v >> 39) & 1ull);
+}
+int rank_ilv_for(int device, int W, int H)
+{
+    static const int forced = [] { const char* e = getenv("GSR_RANK_ILV"); return e ? atoi(e) : -1; }();   // -1 (default): from the previous frame; 0: contiguous; n: groups of n
+    if (forced >= 0) return forced;
+    std::lock_guard<std::mutex> lock(g_ilv_mutex);
+    auto it = g_ilv_hint.find(std::make_tuple(device, W, H));
+    return it != g_ilv_hint.end() && it->second ? GSR_RANK_ILV_AUTO : 0;
+}
+void slot_holds_frame(int slot_index, int device, int W, int H)
+{
+    std::lock_guard<std::mutex> lock(g_ilv_mutex);
+    g_slot_frame[slot_index] = std::make_tuple(device, W, H);
+}
+
 }  // namespace
 
 extern "C" {
@@ -185,8 +215,9 @@ int gsr_count_slot_read(int32_t slot, int64_t* count, int64_t* seq)
     if (slot < 0 || slot >= GSR_COUNT_SLOTS || !count) return fail(GSR_E_ARG, "gsr_count_slot_read: bad arguments");
     if (int rc = g_mail.init()) return rc;
     const unsigned long long v = __atomic_load_n(g_mail.host + Mailbox::kSlots + slot, __ATOMIC_ACQUIRE);
-    *count = v ? (int64_t)(v & 0xFFFFFFFFFFull) : -1;
+    *count = v ? (int64_t)(v & kCountMask) : -1;
     if (seq) *seq = (int64_t)(v >> 40);
+    note_posted(slot, v);
     return GSR_OK;
 }
 
@@ -220,7 +251,8 @@ int gsr_count_slot_wait(int32_t slot, int64_t want_seq, void* stream_, int64_t* 
     }
     g_wait_ns.fetch_add((long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
     g_waits.fetch_add(1);
-    *count = (int64_t)(v & 0xFFFFFFFFFFull);
+    *count = (int64_t)(v & kCountMask);
+    note_posted(slot, v);
     return GSR_OK;
 }
 
@@ -338,7 +370,7 @@ int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, int32_t 
     o->bandcnt = off;     off = align_up(off + (bands ? nbands * nwc * 4 : 0), A);
     o->srect = off;       off = align_up(off + (rankp ? n * 8 : 0), A);
     o->sspan = off;       off = align_up(off + (rankp ? n * 32 : 0), A);
-    o->pstat = off;       off = align_up(off + (rankp ? ((n + 255) / 256) * 8 : 0), A);
+    o->pstat = off;       off = align_up(off + (rankp ? ((n + 255) / 256) * 16 : 0), A);
     o->tdesc = off;       off = align_up(off + (rankp ? tiles * 16 : 0), A);
     o->path = (size_t)path;
     o->chunks = chunks;
@@ -473,7 +505,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     pa.nb = (int)bl.nb;
     const bool rankp = bl.path == 0;                  // tiles ordered by global depth rank (gsr_rank.hip)
     pa.bcursor = (uint32_t*)(b + bl.bcursor);
-    pa.pstat = rankp ? (uint2*)(b + bl.pstat) : nullptr;
+    pa.pstat = rankp ? (uint4*)(b + bl.pstat) : nullptr;
     pa.srect = (ushort4*)(b + bl.srect);
     pa.sspan = (float4*)(b + bl.sspan);
     pa.cull = settings->tile_culling != 0;
@@ -495,6 +527,14 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     *slot = 0;   // (a persistent slot may still hold what its previous owner's last frame posted)
     unsigned long long* slot_dev = g_mail.dev + slot_index;
     const unsigned long long post_cap = deferred ? (unsigned long long)binning_capacity : ~0ull;   // deferred: an overflowing frame marks the slot's sticky word
+    // rank path: contiguous chunks of splats per workgroup, or -- when the previous frame of this (device, size) reported its tile instances unevenly spread
+    // along the splat order -- small groups dealt round-robin (gsr_device.h: rank_chunk / rank_splat; this frame's own report rides in the posted count)
+    int dev_id = 0, rank_ilv = 0;
+    if (rankp) {
+        HIP_TRY(hipGetDevice(&dev_id));
+        rank_ilv = rank_ilv_for(dev_id, settings->image_width, settings->image_height);
+    }
+    slot_holds_frame(deferred ? settings->deferred_count - 1 : GSR_COUNT_SLOTS, dev_id, rankp ? settings->image_width : 0, settings->image_height);
     const unsigned long long cap = (unsigned long long)binning_capacity;
     uint32_t* tile_order = (uint32_t*)(b + bl.tile_order);
     uint32_t* qpos = (uint32_t*)(b + bl.qpos);
@@ -606,9 +646,9 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         uint2* ranges = (uint2*)(b + bl.ranges);
         if (pblocks > 0) {
             TIMED(GSR_K_COUNT, stream);
-            hipLaunchKernelGGL(gsr::k_rcount, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), count_lds, stream, P, gx, tiles,
+            hipLaunchKernelGGL(gsr::k_rcount, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), count_lds, stream, rank_ilv, P, gx, tiles,
                                pblocks, nb, (const ushort4*)srect, (const uint32_t*)pa.tiles_touched,
-                               (const float*)pa.depths, (const uint2*)pa.pstat, tile_count, rect_total, block_hist, bcount, bhist, hdr);
+                               (const float*)pa.depths, (const uint4*)pa.pstat, tile_count, rect_total, block_hist, bcount, bhist, hdr);
             KERNEL_CHECK("k_rcount", stream, dbg);
         }
         const bool one_band = nbands <= 1;
@@ -619,7 +659,8 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
             ts.tiles = tiles; ts.tile_count = tile_count; ts.tile_start = tile_start; ts.tile_cursor = tile_cursor; ts.ranges = ranges;
             ts.tile_order = tile_order; ts.tdesc = (uint4*)(b + bl.tdesc); ts.total_dev = total_dev; ts.mailbox = slot_dev; ts.seq = seq;
             ts.post_capacity = post_cap;
-            hipLaunchKernelGGL(gsr::k_rdscatter, dim3((pblocks > 0 ? bin_blocks : 0) + 1), dim3(GSR_RANK_BIN_THREADS), (size_t)nb * 4, stream, P, nb,
+            ts.hdr = pblocks > 0 ? hdr : nullptr;   // (P == 0: k_rcount did not run, the header word is not written)
+            hipLaunchKernelGGL(gsr::k_rdscatter, dim3((pblocks > 0 ? bin_blocks : 0) + 1), dim3(GSR_RANK_BIN_THREADS), (size_t)nb * 4, stream, rank_ilv, P, nb,
                                (const ushort4*)srect, (const float*)pa.depths, hdr, (const uint32_t*)bcount, bstart, bcursor, dkeys, (const uint32_t*)bhist, ts);
             KERNEL_CHECK("k_rdscatter", stream, dbg);
             if (!one_band && pblocks > 0) {
@@ -639,13 +680,13 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         if (pblocks > 0) {
             TIMED(GSR_K_SCATTER, stream);
             if (one_band) {   // the depth sort beside the scatter, one launch (k_rsort_rscatter): 4-byte entries, k_tile_rank gathers the ranks
-                hipLaunchKernelGGL(gsr::k_rsort_rscatter, dim3(bin_blocks + nb), dim3(GSR_RANK_BIN_THREADS), scatter_lds, stream, bin_blocks, P, gx, tiles,
+                hipLaunchKernelGGL(gsr::k_rsort_rscatter, dim3(bin_blocks + nb), dim3(GSR_RANK_BIN_THREADS), scatter_lds, stream, rank_ilv, bin_blocks, P, gx, tiles,
                                    (const ushort4*)srect, (const float4*)pa.sspan, (const uint32_t*)tile_start, tile_cursor, (uint32_t*)ranks, cap,
                                    (const unsigned long long*)total_dev, (const uint32_t*)block_hist, (const uint32_t*)bcount, (const uint32_t*)bstart,
                                    dkeys, dtmp, rank, stage_off);
                 KERNEL_CHECK("k_rsort_rscatter", stream, dbg);
             } else {
-                hipLaunchKernelGGL(gsr::k_rscatter<8>, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), scatter_lds, stream, P, gx, tiles, bt,
+                hipLaunchKernelGGL(gsr::k_rscatter<8>, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), scatter_lds, stream, rank_ilv, P, gx, tiles, bt,
                                    (const ushort4*)srect, (const uint32_t*)rank, (const float4*)pa.sspan, (const uint32_t*)tile_start, tile_cursor, ranks, cap,
                                    (const unsigned long long*)total_dev, (const uint32_t*)block_hist, stage_off);
                 KERNEL_CHECK("k_rscatter", stream, dbg);
@@ -772,7 +813,8 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     }
     g_wait_ns.fetch_add((long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
     g_waits.fetch_add(1);
-    const int64_t I = (int64_t)(v & 0xFFFFFFFFFFull);
+    const int64_t I = (int64_t)(v & kCountMask);
+    note_posted(GSR_COUNT_SLOTS, v);
     *num_rendered_host = I;
     if (I > 0xFFFFFFFFll) return fail(GSR_E_ARG, "%lld (splat, tile) instances exceed the 32-bit offsets of the binning state", (long long)I);
     if (I > binning_capacity) return fail(GSR_E_CAPACITY, "binning capacity %lld < %lld instances", (long long)binning_capacity, (long long)I);

@@ -460,7 +460,8 @@ struct BinHeader {              // first bytes of the binning buffer (include/gs
     uint32_t dmin_bits;             // = ~dmin_inv
     unsigned long long binned_tiles;// production: tile instances after snug-rect culling (what the per-tile sort path would bin)
     uint32_t band_total[GSR_RANK_MAX_BANDS];   // rank path with bands: binned splats whose rect touches band b (= the band's rank space)
-    uint32_t pad[22];
+    uint32_t chunk_imbalance;       // rank path: 1 when the busiest 256 consecutive splats hold more than GSR_RANK_IMBALANCE x the mean's tile instances (k_rcount; posted with the count)
+    uint32_t pad[21];
     BinStatSlot slot[GSR_STAT_SLOTS];
 };
 static_assert(sizeof(BinHeader) == 256 + 64 * GSR_STAT_SLOTS, "header layout is part of include/gsr.h");
@@ -530,7 +531,7 @@ struct PreprocessArgs {
     int nb;
     // rank path (gsr_rank.hip); pstat == nullptr otherwise
     uint32_t* __restrict__ bcursor;       // [nb] bucket fill cursors, zeroed here
-    uint2* __restrict__ pstat;            // [workgroups] (min, max) depth bits of this workgroup's visible splats; (~0, 0) when it has none
+    uint4* __restrict__ pstat;            // [workgroups] (min, max) depth bits of this workgroup's visible splats ((~0, 0) when it has none), the tile instances its splats are binned into, 0
     ushort4* __restrict__ srect;          // [P] tile rect the splat is binned into (snug when cull != 0); zero area = not binned
     float4* __restrict__ sspan;           // [P][2] the splat's Span (px, py, B, det | twoTA, A, dyr, mode): operands of the quadrant test
     int cull;                             // settings.tile_culling != 0
@@ -636,19 +637,25 @@ __global__ void k_preprocess_bwd(Settings s, PreBwdArgs a);
 // a run of large splats (the coarse faces of a head: hundreds of tiles each, contiguous in Morton order) is spread over every workgroup instead of landing in a few
 // (k_rscatter's time is its busiest workgroup's INSTANCE count: 89 us against 23 on the template-like avatar with contiguous chunks).  A group keeps the Morton
 // neighbours together, which is what merges a workgroup's entries in L2.  rank_chunk: local indices per workgroup (a multiple of the group); rank_splat: local -> splat.
-#ifndef GSR_RANK_ILV
-#define GSR_RANK_ILV 0    // 0: contiguous chunks (rounds 3 - 5).  Measured (r06_e): 8 / 16 / 64 take k_rsort_rscatter 88 -> 44 / 53 / 69 us on the template-like avatar and cost k_rcount +6 / +5 / +3 us on both scenes (every workgroup then touches every tile: one returning atomic per non-empty (workgroup, tile) bin)
-#endif
-#if GSR_RANK_ILV > 0
-__host__ __device__ inline int rank_chunk(int P, int nblk) { const int groups = (P + GSR_RANK_ILV - 1) / GSR_RANK_ILV; return (groups + nblk - 1) / nblk * GSR_RANK_ILV; }
-__host__ __device__ inline int rank_splat(int j, int blk, int nblk, int /*chunk*/) { return ((j / GSR_RANK_ILV) * nblk + blk) * GSR_RANK_ILV + (j % GSR_RANK_ILV); }
-#else
-__host__ __device__ inline int rank_chunk(int P, int nblk) { return ((P + nblk - 1) / nblk + 31) / 32 * 32; }
-__host__ __device__ inline int rank_splat(int j, int blk, int /*nblk*/, int chunk) { return blk * chunk + j; }
-#endif
+// `ilv` = 0: contiguous chunks (rounds 3 - 5); > 0: groups of `ilv` splats (a power of two) dealt round-robin.  Measured (r06_e, compile-time variants):
+// groups of 8 / 16 / 64 take k_rsort_rscatter 88 -> 44 / 53 / 69 us on the template-like avatar, and cost k_rcount +6 / +5 / +3 us on BOTH scenes (every
+// workgroup then touches every tile: one returning atomic per non-empty (workgroup, tile) bin) -- so it is chosen per frame size from what the previous frame's
+// k_preprocess measured (gsr_api.hip: rank_ilv_for; BinHeader::chunk_imbalance).
+#define GSR_RANK_ILV_AUTO 8      // the group size taken when the splats' instance counts are that uneven along the splat order
+__host__ __device__ inline int rank_chunk(int P, int nblk, int ilv)
+{
+    if (ilv <= 0) return ((P + nblk - 1) / nblk + 31) / 32 * 32;
+    const int groups = (P + ilv - 1) / ilv;
+    return (groups + nblk - 1) / nblk * ilv;
+}
+__host__ __device__ inline int rank_splat(int j, int blk, int nblk, int chunk, int ilv)
+{
+    return ilv <= 0 ? blk * chunk + j : ((j / ilv) * nblk + blk) * ilv + (j % ilv);
+}
 __host__ __device__ inline bool rank_direct(int gx, int tiles) { return (long long)(gx + 1) * (long long)(tiles / gx + 1) > (long long)GSR_RANK_HIST_TILES; }
-__global__ void k_rcount(int P, int gx, int tiles, int pblocks, uint32_t nb, const ushort4* srect, const uint32_t* tiles_touched,
-                         const float* depths, const uint2* pstat, uint32_t* tile_count, unsigned long long* rect_total, uint32_t* block_hist,
+#define GSR_RANK_IMBALANCE 3
+__global__ void k_rcount(int ilv, int P, int gx, int tiles, int pblocks, uint32_t nb, const ushort4* srect, const uint32_t* tiles_touched,
+                         const float* depths, const uint4* pstat, uint32_t* tile_count, unsigned long long* rect_total, uint32_t* block_hist,
                          uint32_t* bcount, uint32_t* bhist, BinHeader* hdr);
 struct TileScanArgs {            // the tile-counter scan that rides in k_rdscatter's last workgroup (gsr_rank.hip: tile_scan_256)
     int tiles;
@@ -657,8 +664,9 @@ struct TileScanArgs {            // the tile-counter scan that rides in k_rdscat
     uint2* __restrict__ ranges; uint32_t* __restrict__ tile_order; uint4* __restrict__ tdesc;
     unsigned long long* __restrict__ total_dev; unsigned long long* mailbox;
     unsigned long long seq, post_capacity;
+    const BinHeader* hdr;        // (chunk_imbalance rides in bit 39 of the posted count)
 };
-__global__ void k_rdscatter(int P, uint32_t nb, const ushort4* srect, const float* depths, BinHeader* hdr, const uint32_t* bcount, uint32_t* bstart,
+__global__ void k_rdscatter(int ilv, int P, uint32_t nb, const ushort4* srect, const float* depths, BinHeader* hdr, const uint32_t* bcount, uint32_t* bstart,
                             uint32_t* bcursor, unsigned long long* dkeys, const uint32_t* bhist, TileScanArgs ts);
 // bands of the rank path: 1 (the whole frame) up to GSR_RANK_MAX_SPLATS splats, else bands of *band_rows tile rows
 __host__ __device__ inline int rank_bands(long long P, int gy, bool force, int* band_rows)
@@ -680,12 +688,12 @@ __global__ void k_band_scan(BinHeader* hdr, uint32_t nwc, uint32_t* bandcnt);
 __global__ void k_band_rank(const BinHeader* hdr, const uint2* obs, uint32_t nbands, uint32_t nwc, const uint32_t* bandcnt, uint4* rank4, uint32_t* over);
 __global__ void k_rdsort(const uint32_t* bcount, const uint32_t* bstart, unsigned long long* dkeys, unsigned long long* tmp,
                          uint32_t* rank, uint2* obs, const ushort4* srect, int band_rows);
-__global__ void k_rsort_rscatter(int scatter_blocks, int P, int gx, int tiles, const ushort4* srect, const float4* sspan, const uint32_t* tile_start,
+__global__ void k_rsort_rscatter(int ilv, int scatter_blocks, int P, int gx, int tiles, const ushort4* srect, const float4* sspan, const uint32_t* tile_start,
                                  uint32_t* tile_cursor, uint32_t* entries, unsigned long long capacity, const unsigned long long* total_dev,
                                  const uint32_t* block_hist, const uint32_t* bcount, const uint32_t* bstart, unsigned long long* dkeys,
                                  unsigned long long* dtmp, uint32_t* rank, int stage_off);
 template <int G>
-__global__ void k_rscatter(int P, int gx, int tiles, BandTables bt, const ushort4* srect, const uint32_t* rank, const float4* sspan, const uint32_t* tile_start,
+__global__ void k_rscatter(int ilv, int P, int gx, int tiles, BandTables bt, const ushort4* srect, const uint32_t* rank, const float4* sspan, const uint32_t* tile_start,
                            uint32_t* tile_cursor, uint2* ranks, unsigned long long capacity, const unsigned long long* total_dev, const uint32_t* block_hist,
                            int stage_off);
 __global__ void k_tile_rank(uint32_t words, int gx, int nbands, float inv_band_rows, const uint4* tdesc, const uint2* ranks, const uint32_t* rank_of,

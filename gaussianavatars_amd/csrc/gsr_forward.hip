@@ -309,10 +309,11 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         if ((threadIdx.x & 63) == 0) { ps_mn[threadIdx.x >> 6] = mn_inv; ps_mx[threadIdx.x >> 6] = mx; }
         __syncthreads();
         if (threadIdx.x == 0)
-            a.pstat[blockIdx.x] = make_uint2(~max(max(ps_mn[0], ps_mn[1]), max(ps_mn[2], ps_mn[3])), max(max(ps_mx[0], ps_mx[1]), max(ps_mx[2], ps_mx[3])));
+            *reinterpret_cast<uint2*>(&a.pstat[blockIdx.x]) = make_uint2(~max(max(ps_mn[0], ps_mn[1]), max(ps_mn[2], ps_mn[3])), max(max(ps_mx[0], ps_mx[1]), max(ps_mx[2], ps_mx[3])));
         // the tile rect this splat is binned into (snug in the culling modes) and the operands of the per-quadrant reach test
         // (gsr_device.h: band_of): computed here, once per splat, for the two binning passes that expand the rect
         float4 span2[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};   // (rows of splats that are not binned are never read)
+        uint32_t ps_nt = 0;
         if (i < a.P) {
             uint32_t nt = 0;
             int minx = rminx, miny = rminy, maxx = rmaxx, maxy = rmaxy;
@@ -327,6 +328,14 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
                 }
             }
             a.srect[i] = nt ? make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy) : make_ushort4(0, 0, 0, 0);
+            ps_nt = nt;
+        }
+        {   // the tile instances this workgroup's 256 splats are binned into: how evenly they are spread along the splat order decides the chunking of the NEXT frame's rank passes
+            __shared__ uint32_t ps_sum[4];
+            const uint32_t wsum = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl_u32(ps_nt), 63);
+            if ((threadIdx.x & 63) == 0) ps_sum[threadIdx.x >> 6] = wsum;
+            __syncthreads();
+            if (threadIdx.x == 0) a.pstat[blockIdx.x].z = (ps_sum[0] + ps_sum[1]) + (ps_sum[2] + ps_sum[3]);
         }
         put_rows(a.sspan, span2, std::integral_constant<int, 2>{});
     }

@@ -72,9 +72,9 @@ __device__ __forceinline__ void for_each_tile_grouped(int minx, int miny, int ma
 // scatters (same chunking).  The rect of every splat comes from k_preprocess (srect: snug in the culling modes).
 // The frame's depth range comes from k_preprocess's per-workgroup (min, max) pairs: no atomics, nothing to zero.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int P, int gx, int tiles, int pblocks, uint32_t nb, const ushort4* __restrict__ srect,
+__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int ilv, int P, int gx, int tiles, int pblocks, uint32_t nb, const ushort4* __restrict__ srect,
                                                                   const uint32_t* __restrict__ tiles_touched, const float* __restrict__ depths,
-                                                                  const uint2* __restrict__ pstat, uint32_t* __restrict__ tile_count,
+                                                                  const uint4* __restrict__ pstat, uint32_t* __restrict__ tile_count,
                                                                   unsigned long long* __restrict__ rect_total, uint32_t* __restrict__ block_hist,
                                                                   uint32_t* __restrict__ bcount, uint32_t* __restrict__ bhist,
                                                                   BinHeader* __restrict__ hdr)
@@ -87,14 +87,22 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int P, int gx, 
     __shared__ uint32_t s_mn[NWV], s_mx[NWV];
     const int tid = threadIdx.x;
     const bool direct = rank_direct(gx, tiles);
-    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u, imax = 0u, isum = 0u;   // (isum: 2^32 instances is also the limit of the binning state's offsets)
     for (int j = tid; j < pblocks; j += NT) {
-        const uint2 v = pstat[j];
+        const uint4 v = pstat[j];
         mn = min(mn, v.x);
         mx = max(mx, v.y);
+        imax = max(imax, v.z);
+        isum += v.z;
     }
     mn = wave_min_u32(mn);
     mx = wave_max_u32(mx);
+    __shared__ uint32_t s_imax[NWV], s_isum[NWV];
+    if (blockIdx.x == 0) {   // how unevenly the tile instances are spread along the splat order (for the NEXT frame's chunking: gsr_api.hip)
+        imax = wave_max_u32(imax);
+        isum = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl_u32(isum), 63);
+        if ((tid & 63) == 0) { s_imax[tid >> 6] = imax; s_isum[tid >> 6] = isum; }
+    }
     if ((tid & 63) == 0) { s_mn[tid >> 6] = mn; s_mx[tid >> 6] = mx; }
     for (uint32_t t = tid; t < nb; t += NT) dh[t] = 0u;
     if (!direct)
@@ -104,17 +112,24 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int P, int gx, 
 #pragma unroll
     for (int w = 1; w < NWV; ++w) { mn = min(mn, s_mn[w]); mx = max(mx, s_mx[w]); }
     if (mn > mx) { mn = 0u; mx = 0u; }   // nothing visible
-    if (blockIdx.x == 0 && tid == 0) { hdr->dmin_bits = mn; hdr->dmax_bits = mx; }
+    if (blockIdx.x == 0 && tid == 0) {
+        hdr->dmin_bits = mn; hdr->dmax_bits = mx;
+        uint32_t bmax = 0u;
+        unsigned long long bsum = 0ull;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { bmax = max(bmax, s_imax[w]); bsum += s_isum[w]; }
+        hdr->chunk_imbalance = (pblocks >= 64 && (unsigned long long)bmax * (unsigned long long)pblocks > (unsigned long long)GSR_RANK_IMBALANCE * bsum) ? 1u : 0u;
+    }
     float lo, scale;
     rank_bucket_map(mn, mx, nb, lo, scale);
 
-    const int chunk = rank_chunk(P, (int)gridDim.x);   // local indices 0 .. chunk - 1 of this workgroup's (interleaved) splats: rank_splat
+    const int chunk = rank_chunk(P, (int)gridDim.x, ilv);   // local indices 0 .. chunk - 1 of this workgroup's (interleaved) splats: rank_splat
     const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
     unsigned long long touched = 0;
     const int gy = tiles / gx, sx = gx + 1;   // the LDS grid has one more column and row: rect corners lie on tile CORNERS
     if (direct) {
         for (int base = 0; base < chunk; base += NT / G) {
-            const int j = base + tid / G, i = j < chunk ? rank_splat(j, blk, nblk, chunk) : P;
+            const int j = base + tid / G, i = j < chunk ? rank_splat(j, blk, nblk, chunk, ilv) : P;
             uint32_t n = 0;
             int minx = 0, miny = 0, maxx = 0, maxy = 0;
             if (i < P) {
@@ -132,7 +147,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int P, int gx, 
         // A rect adds 1 to every tile it covers = +1 / -1 / -1 / +1 at its four corners followed by a 2-D prefix sum over the grid:
         // four LDS atomics per splat whatever its size (18 tiles on average), one splat per lane
         for (int j = tid; j < chunk; j += NT) {
-            const int i = rank_splat(j, blk, nblk, chunk);
+            const int i = rank_splat(j, blk, nblk, chunk, ilv);
             if (i >= P) continue;
             const ushort4 r = srect[i];
             touched += tiles_touched[i];
@@ -200,7 +215,8 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int P, int gx, 
 __device__ __forceinline__ void tile_scan_256(int tiles, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
                                               uint32_t* __restrict__ tile_cursor, uint2* __restrict__ ranges,
                                               uint32_t* __restrict__ tile_order, uint4* __restrict__ tdesc,
-                                              unsigned long long* __restrict__ total_dev, unsigned long long* mailbox, unsigned long long seq, unsigned long long post_capacity)
+                                              unsigned long long* __restrict__ total_dev, unsigned long long* mailbox, unsigned long long seq, unsigned long long post_capacity,
+                                              const BinHeader* __restrict__ hdr = nullptr)
 {
     __shared__ uint32_t wave_tot[4];
     __shared__ unsigned long long carry_s;
@@ -245,7 +261,8 @@ __device__ __forceinline__ void tile_scan_256(int tiles, const uint32_t* __restr
         const unsigned long long grand = carry_s;
         *total_dev = grand;
         // post (seq, I) to the host: one 8-byte system-scope store into mapped pinned memory
-        __hip_atomic_store(mailbox, (seq << 40) | (grand & 0xFFFFFFFFFFull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (bit 39 of the count: this frame's splat order is uneven in tile instances -- BinHeader::chunk_imbalance, written by k_rcount in the launch before)
+        __hip_atomic_store(mailbox, (seq << 40) | (grand & 0x7FFFFFFFFFull) | ((unsigned long long)(hdr ? hdr->chunk_imbalance & 1u : 0u) << 39), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         // deferred count (post_capacity = the binning capacity, else ~0): a frame that does not fit leaves a STICKY mark in the slot's second
         // word -- later frames overwrite the count above, nothing but the host clears this one (gsr_count_slot_overflow)
         if (grand > post_capacity) __hip_atomic_store(mailbox + GSR_COUNT_SLOTS, grand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -333,7 +350,7 @@ __device__ __forceinline__ void tile_scan_wide(const TileScanArgs& ts)
     if (tid == 0) {
         *ts.total_dev = grand;
         // post (seq, I) to the host: one 8-byte system-scope store into mapped pinned memory
-        __hip_atomic_store(ts.mailbox, (ts.seq << 40) | (grand & 0xFFFFFFFFFFull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(ts.mailbox, (ts.seq << 40) | (grand & 0x7FFFFFFFFFull) | ((unsigned long long)(ts.hdr ? ts.hdr->chunk_imbalance & 1u : 0u) << 39), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         // deferred count (post_capacity = the binning capacity, else ~0): a frame that does not fit leaves a STICKY mark in the slot's second
         // word -- later frames overwrite the count above, nothing but the host clears this one (gsr_count_slot_overflow)
         if (grand > ts.post_capacity) __hip_atomic_store(ts.mailbox + GSR_COUNT_SLOTS, grand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -375,7 +392,7 @@ __device__ __forceinline__ void tile_scan_wide(const TileScanArgs& ts)
 // reserved for it in every bucket.  Workgroup 0 publishes the bucket offsets and the number
 // of ranked splats.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rdscatter(int P, uint32_t nb, const ushort4* __restrict__ srect, const float* __restrict__ depths,
+__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rdscatter(int ilv, int P, uint32_t nb, const ushort4* __restrict__ srect, const float* __restrict__ depths,
                                                     BinHeader* __restrict__ hdr, const uint32_t* __restrict__ bcount,
                                                     uint32_t* __restrict__ bstart, uint32_t* __restrict__ bcursor,
                                                     unsigned long long* __restrict__ dkeys, const uint32_t* __restrict__ bhist, TileScanArgs ts)
@@ -387,7 +404,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rdscatter(int P, uint3
         if (ts.tiles <= TS_PER * NT) { tile_scan_wide(ts); return; }
         if (threadIdx.x >= 256) return;
         tile_scan_256(ts.tiles, ts.tile_count, ts.tile_start, ts.tile_cursor, ts.ranges, ts.tile_order, ts.tdesc, ts.total_dev, ts.mailbox, ts.seq,
-                      ts.post_capacity);
+                      ts.post_capacity, ts.hdr);
         return;
     }
     __shared__ uint32_t wave_tot[NWV];
@@ -422,9 +439,9 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rdscatter(int P, uint3
     __syncthreads();
     float lo, scale;
     rank_bucket_map(hdr->dmin_bits, hdr->dmax_bits, nb, lo, scale);
-    const int chunk = rank_chunk(P, (int)nblk);
+    const int chunk = rank_chunk(P, (int)nblk, ilv);
     for (int j = tid; j < chunk; j += NT) {
-        const int i = rank_splat(j, (int)blockIdx.x, (int)nblk, chunk);
+        const int i = rank_splat(j, (int)blockIdx.x, (int)nblk, chunk, ilv);
         if (i >= P) continue;
         const ushort4 r = srect[i];
         if (r.z == r.x) continue;   // not binned
@@ -599,7 +616,7 @@ __device__ __forceinline__ void rscatter_body(int P, int gx, int tiles, BandTabl
                                               const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
                                               uint2* __restrict__ ranks, unsigned long long capacity,
                                               const unsigned long long* __restrict__ total_dev,
-                                              const uint32_t* __restrict__ block_hist, int nblk)
+                                              const uint32_t* __restrict__ block_hist, int nblk, int ilv)
 {
     extern __shared__ uint32_t hist[];
     uint32_t* __restrict__ const lean = reinterpret_cast<uint32_t*>(ranks);
@@ -609,9 +626,9 @@ __device__ __forceinline__ void rscatter_body(int P, int gx, int tiles, BandTabl
     const bool direct = rank_direct(gx, tiles);
     const bool bands = !LEAN && bt.nbands > 1;
     const uint4* __restrict__ rank4 = reinterpret_cast<const uint4*>(rank);   // bands: the ranks inside the first four bands of the rect
-    const int chunk = rank_chunk(P, nblk);
+    const int chunk = rank_chunk(P, nblk, ilv);
     const int blk = (int)blockIdx.x;
-    auto splat_of = [&](int j) { return j < chunk ? rank_splat(j, blk, nblk, chunk) : P; };   // local index -> splat (P: none)
+    auto splat_of = [&](int j) { return j < chunk ? rank_splat(j, blk, nblk, chunk, ilv) : P; };   // local index -> splat (P: none)
     // a splat's inputs, fetched one round ahead of their use (all four loads are independent: rank / operands of a splat that is
     // not binned are never looked at)
     struct In { ushort4 q; uint4 rk; float4 s0, s1; };
@@ -720,7 +737,7 @@ __device__ __forceinline__ void rscatter_balanced(RscatterStage<LEAN>& stage, in
                                                   const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
                                                   uint2* __restrict__ ranks, unsigned long long capacity,
                                                   const unsigned long long* __restrict__ total_dev,
-                                                  const uint32_t* __restrict__ block_hist, int nblk)
+                                                  const uint32_t* __restrict__ block_hist, int nblk, int ilv)
 {
     extern __shared__ uint32_t hist[];
     uint32_t* __restrict__ const lean = reinterpret_cast<uint32_t*>(ranks);
@@ -731,7 +748,7 @@ __device__ __forceinline__ void rscatter_balanced(RscatterStage<LEAN>& stage, in
     const bool direct = rank_direct(gx, tiles);
     const bool bands = !LEAN && bt.nbands > 1;
     const uint4* __restrict__ rank4 = reinterpret_cast<const uint4*>(rank);
-    const int chunk = rank_chunk(P, nblk);
+    const int chunk = rank_chunk(P, nblk, ilv);
     const int blk = (int)blockIdx.x;
     uint4(*const rows)[ROW] = stage.row[wv];
     uint32_t* const own = stage.own[wv];
@@ -751,7 +768,7 @@ __device__ __forceinline__ void rscatter_balanced(RscatterStage<LEAN>& stage, in
     const int stride = SB * (NT / 64);
     auto mine_of = [&](int base) {   // this lane's splat of the round that starts at local index `base` (P: none)
         const int j = base + wv * SB + lane;
-        return lane < SB && j < chunk ? rank_splat(j, blk, nblk, chunk) : P;
+        return lane < SB && j < chunk ? rank_splat(j, blk, nblk, chunk, ilv) : P;
     };
     In nxt = fetch(mine_of(0));
     if (!direct) {
@@ -841,7 +858,7 @@ __device__ __forceinline__ void rscatter_balanced(RscatterStage<LEAN>& stage, in
 // stage_off >= 0: the balanced expansion, its staging rows at that byte offset of the dynamic LDS (behind the tile histogram); < 0: the
 // lockstep form (the API takes it when the rows do not fit beside the histogram: tile grids of ~23 k tiles and more)
 template <int G>
-__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx, int tiles, BandTables bt, const ushort4* __restrict__ srect,
+__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int ilv, int P, int gx, int tiles, BandTables bt, const ushort4* __restrict__ srect,
                                                                     const uint32_t* __restrict__ rank, const float4* __restrict__ sspan,
                                                                     const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
                                                                     uint2* __restrict__ ranks, unsigned long long capacity,
@@ -851,9 +868,9 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
     extern __shared__ uint32_t dyn_lds[];
     if (stage_off >= 0)
         rscatter_balanced<false>(*reinterpret_cast<RscatterStage<false>*>(reinterpret_cast<unsigned char*>(dyn_lds) + stage_off), P, gx, tiles, bt, srect, rank, sspan,
-                                 tile_start, tile_cursor, ranks, capacity, total_dev, block_hist, (int)gridDim.x);
+                                 tile_start, tile_cursor, ranks, capacity, total_dev, block_hist, (int)gridDim.x, ilv);
     else
-        rscatter_body<G, false>(P, gx, tiles, bt, srect, rank, sspan, tile_start, tile_cursor, ranks, capacity, total_dev, block_hist, (int)gridDim.x);
+        rscatter_body<G, false>(P, gx, tiles, bt, srect, rank, sspan, tile_start, tile_cursor, ranks, capacity, total_dev, block_hist, (int)gridDim.x, ilv);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -862,7 +879,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int P, int gx
 // (k_rdscatter: bucket contents, tile offsets) -- and the scatter, one 16-wave workgroup per CU at 67 VGPRs, leaves three wave slots per SIMD
 // and 130 KB of LDS per CU for the sorting workgroups: the depth sort (10.6 - 15 us as a launch of its own) disappears behind the scatter.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rsort_rscatter(int scatter_blocks, int P, int gx, int tiles, const ushort4* __restrict__ srect,
+__global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rsort_rscatter(int ilv, int scatter_blocks, int P, int gx, int tiles, const ushort4* __restrict__ srect,
                                                                           const float4* __restrict__ sspan, const uint32_t* __restrict__ tile_start,
                                                                           uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ entries,
                                                                           unsigned long long capacity, const unsigned long long* __restrict__ total_dev,
@@ -876,10 +893,10 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rsort_rscatter(int sca
         bt.nbands = 1u; bt.inv_band_rows = 1.f; bt.over = nullptr;
         if (stage_off >= 0)   // (52 KB of rows + the histogram: two workgroups per CU at 802 x 550 -- a scatter workgroup and a sorting one beside it)
             rscatter_balanced<true>(*reinterpret_cast<RscatterStage<true>*>(reinterpret_cast<unsigned char*>(dyn_lds) + stage_off), P, gx, tiles, bt, srect, nullptr,
-                                    sspan, tile_start, tile_cursor, reinterpret_cast<uint2*>(entries), capacity, total_dev, block_hist, scatter_blocks);
+                                    sspan, tile_start, tile_cursor, reinterpret_cast<uint2*>(entries), capacity, total_dev, block_hist, scatter_blocks, ilv);
         else
             rscatter_body<GSR_RANK_GROUP, true>(P, gx, tiles, bt, srect, nullptr, sspan, tile_start, tile_cursor, reinterpret_cast<uint2*>(entries), capacity,
-                                                total_dev, block_hist, scatter_blocks);
+                                                total_dev, block_hist, scatter_blocks, ilv);
         return;
     }
     if (threadIdx.x >= 256) return;   // (ended waves do not take part in the barriers of the sort)
@@ -887,7 +904,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rsort_rscatter(int sca
     depth_sort_bucket(blockIdx.x - (uint32_t)scatter_blocks, bcount, bstart, dkeys, dtmp, rank, nullptr, nullptr, 1, skeys);
 }
 
-template __global__ void k_rscatter<8>(int, int, int, BandTables, const ushort4*, const uint32_t*, const float4*, const uint32_t*, uint32_t*, uint2*, unsigned long long,
+template __global__ void k_rscatter<8>(int, int, int, int, BandTables, const ushort4*, const uint32_t*, const float4*, const uint32_t*, uint32_t*, uint2*, unsigned long long,
                                        const unsigned long long*, const uint32_t*, int);
 
 // ------------------------------------------------------------------------------------------

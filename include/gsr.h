@@ -193,7 +193,8 @@ typedef struct GsrBinningLayout {
     size_t srect;       /* uint16 [P][4] tile rect (minx, miny, maxx, maxy) every splat is binned into (snug in the culling modes);
                            zero area = not binned                                                                          */
     size_t sspan;       /* float  [P][8] operands of the per-quadrant reach test of a binned splat (csrc/gsr_device.h: Span)          */
-    size_t pstat;       /* uint32 [ceil(P/256)][2] (min, max) depth bits of each k_preprocess workgroup's visible splats       */
+    size_t pstat;       /* uint32 [ceil(P/256)][4] per k_preprocess workgroup: (min, max) depth bits of its visible splats, the tile
+                           instances its splats are binned into (how evenly those are spread decides the next frame's chunking), 0    */
     size_t tdesc;       /* uint32 [tiles][4] (tile, entries, first entry, 0) in launch order (heaviest tiles first)                       */
     size_t obs;         /* uint32 [P][2] bands only: (splat, first band | last band << 8) of the binned splats in depth order         */
     size_t bandcnt;     /* uint32 [nbands][ceil(P/256)] bands only: splats of band b before each run of 256 consecutive depth ranks  */
@@ -221,7 +222,9 @@ typedef struct GsrImageLayout {
                           of the wave) mod GSR_UNIT_LISTS: the counters first (word 32 l = list l's, a 128-byte line each; zeroed by the frame's first kernel), then the lists, `cap` slots
                           each (the mapping wave -> list is static, so `cap` cannot overflow).  The backward's waves take the units of list
                           (wave id mod GSR_UNIT_LISTS) in turn: no workgroup is launched for a (tile, segment) pair nothing reaches -- four of
-                          five were, round 3 -- and a workgroup's four waves all carry work                                            */
+                          five were, round 3 -- and a workgroup's four waves all carry work.  Behind the lists (round 6, GSR_CONT_CHUNKS > 0 only):
+                          the forward blend's continuation area -- counters, the list of quadrants whose walk was parked at entry
+                          GSR_CONT_CHUNKS * GSR_BWD_SEGMENT, 1280 bytes of parked state per quadrant (csrc/gsr_forward.hip: k_render<true, 1 / 2>)  */
     size_t total;
 } GsrImageLayout;
 
