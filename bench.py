@@ -857,6 +857,8 @@ def main():
         for name, (ms, n) in kern_other.items():
             if n:
                 short = name.replace("void ", "").split("<")[0]
+                if short.startswith("gls::k_l1_fwd"):
+                    short = "gls::k_l1_fwd"   # (the launch sites' plain names of its four instances: one launch / two launches, with / without the gradient image)
                 prev = per_kernel.get(short)
                 tot_ms, tot_n = ms + (prev["avg_us"] * prev["launches"] / 1e3 if prev else 0.0), n + (prev["launches"] if prev else 0)
                 per_kernel[short] = dict(avg_us=1e3 * tot_ms / tot_n, launches=tot_n)

@@ -991,11 +991,36 @@ __global__ __launch_bounds__(256) void k_gather_skin_bwd(Rig rig, GatherSkinArgs
     static_assert(VPB == 16 || VPB == 32 || VPB == 64, "a wave holds the workgroup's vertices");
     __shared__ float gv[ROWS];          // dL/d(posed vertex) of this workgroup's vertices
     __shared__ float red[100];          // the 99 block sums
+    // Round 6: the kernel is a chain of memory round trips behind a launch floor (corner entry -> vertices and face gradients -> LDS; then, for the
+    // skinning backward, the pose-corrective rows, the shaped vertices and the weights): the second chain does not depend on the first, so its loads
+    // are ISSUED before the gather and only waited for behind it -- the workgroup's block of the pose-corrective table (36 rows x 3 VPB floats) once,
+    // cooperatively, into LDS (every wave used to fetch it for itself, twice), the per-vertex values into registers.
+    constexpr int PDN = GAB_POSE_FEATURES * ROWS, PDK = (PDN + 255) / 256;
+    __shared__ float pd[GAB_POSE_FEATURES][ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int gid = blockIdx.x * 256 + tid;
     for (int b = 0; b < zero.count; ++b)
         for (int i = gid; i < zero.n[b]; i += (int)(gridDim.x * 256)) zero.p[b][i] = 0.f;
     const int vbase = blockIdx.x * VPB, vend = min(vbase + VPB, rig.V);
+    const int E = 3 * rig.V;
+    const int p0 = a.vf_begin[vbase], p1 = a.vf_begin[vend];
+    // ---- loads of the skinning half, in flight across the gather
+    float pdr[PDK];
+#pragma unroll
+    for (int i = 0; i < PDK; ++i) {
+        const int k = tid + 256 * i, p = k / ROWS, c = k - p * ROWS;
+        pdr[i] = (k < PDN && 3 * vbase + c < E) ? rig.posedirs[(size_t)p * E + 3 * vbase + c] : 0.f;
+    }
+    const int v = vbase + lane;
+    const bool ok = lane < VPB && v < rig.V;
+    float vs[3] = {0.f, 0.f, 0.f}, gx[3] = {0.f, 0.f, 0.f};
+    float w[GAB_NUM_JOINTS] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { vs[k] = a.v_shaped[3 * v + k]; gx[k] = a.g_verts ? a.g_verts[3 * v + k] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < GAB_NUM_JOINTS; ++j) w[j] = rig.lbs_weights[(size_t)v * GAB_NUM_JOINTS + j];
+    }
     for (int k = tid; k < ROWS; k += 256) gv[k] = 0.f;
     __syncthreads();
     // ---- gather the corners
@@ -1004,7 +1029,6 @@ __global__ __launch_bounds__(256) void k_gather_skin_bwd(Rig rig, GatherSkinArgs
     // max in arrival-order atomics, tools/mesh_bwd_repeat.py).  What survives the sum is each face centre's gradient, a third per corner:
     // that is summed here directly (tc), and the vertex sums below only add the external vertex gradient to it.
     float tc[3] = {0.f, 0.f, 0.f};
-    const int p0 = a.vf_begin[vbase], p1 = a.vf_begin[vend];
     for (int p = p0 + tid; p < p1; p += 256) {
         const int4 e = a.vf_list[p];
         const int f = e.x >> 2, c = e.x & 3;
@@ -1024,29 +1048,39 @@ __global__ __launch_bounds__(256) void k_gather_skin_bwd(Rig rig, GatherSkinArgs
         const float s = wave_sum_hi(tc[r]);
         if (lane == 63) tcs[wid][r] = s;
     }
+#pragma unroll
+    for (int i = 0; i < PDK; ++i) {
+        const int k = tid + 256 * i;
+        if (k < PDN) (&pd[0][0])[k] = pdr[i];
+    }
     __syncthreads();
-    // ---- skinning backward: every wave evaluates the workgroup's vertices (lane = vertex), each reduces a quarter of the sums
-    const int v = vbase + lane;
-    const bool ok = lane < VPB && v < rig.V;
-    const int E = 3 * rig.V;
-    float g[3] = {0.f, 0.f, 0.f}, gx[3] = {0.f, 0.f, 0.f}, vp[3] = {0.f, 0.f, 0.f}, T[12], gvp[3] = {0.f, 0.f, 0.f};
-    float w[GAB_NUM_JOINTS] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    // ---- skinning backward: every wave evaluates the workgroup's vertices (lane = vertex) from LDS, each reduces a quarter of the sums
+    float g[3] = {0.f, 0.f, 0.f}, vp[3] = {0.f, 0.f, 0.f}, T[12], gvp[3] = {0.f, 0.f, 0.f};
     float pf[GAB_POSE_FEATURES];
 #pragma unroll
     for (int p = 0; p < GAB_POSE_FEATURES; ++p) pf[p] = 0.f;
     if (ok) {
-        vertex_posed_and_T<true>(rig, a.ws, a.v_shaped, v, vp, T);
+        // the posed-before-skinning vertex and its blended transform (vertex_posed_and_T's arithmetic, the rows from LDS: same order of the sums)
+        float po[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { gx[k] = a.g_verts ? a.g_verts[3 * v + k] : 0.f; g[k] = gv[3 * lane + k] + gx[k]; }
+        for (int p = 0; p < GAB_POSE_FEATURES; ++p) {
+            const float f = a.ws[WS_PF + p];
+            po[0] += f * pd[p][3 * lane]; po[1] += f * pd[p][3 * lane + 1]; po[2] += f * pd[p][3 * lane + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vp[k] = po[k] + vs[k];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) T[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < GAB_NUM_JOINTS; ++j)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) T[k] += w[j] * a.ws[WS_A + 12 * j + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g[k] = gv[3 * lane + k] + gx[k];
 #pragma unroll
         for (int c = 0; c < 3; ++c) gvp[c] = T[c] * g[0] + T[4 + c] * g[1] + T[8 + c] * g[2];
 #pragma unroll
-        for (int j = 0; j < GAB_NUM_JOINTS; ++j) w[j] = rig.lbs_weights[(size_t)v * GAB_NUM_JOINTS + j];
-#pragma unroll
-        for (int p = 0; p < GAB_POSE_FEATURES; ++p) {
-            const float* row = rig.posedirs + (size_t)p * E + 3 * v;
-            pf[p] = row[0] * gvp[0] + row[1] * gvp[1] + row[2] * gvp[2];
-        }
+        for (int p = 0; p < GAB_POSE_FEATURES; ++p) pf[p] = pd[p][3 * lane] * gvp[0] + pd[p][3 * lane + 1] * gvp[1] + pd[p][3 * lane + 2] * gvp[2];
         if (wid == 0) { a.g_vs[3 * v] = gvp[0]; a.g_vs[3 * v + 1] = gvp[1]; a.g_vs[3 * v + 2] = gvp[2]; }
     }
     const float vph[4] = {vp[0], vp[1], vp[2], ok ? 1.f : 0.f};

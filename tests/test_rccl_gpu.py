@@ -106,7 +106,7 @@ def test_bench_under_torch_distributed_run_on_nccl_at_one_gpu():
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["steps"] == 10
     assert "RCCL" in d["config"]["parallelism"] and "all-reduce" in d["config"]["parallelism"]
     # the instrumented pass (rank 0 only: its runner carries no collective -- one entered by a single rank of N would pair with the others' barrier) ran as well
-    assert d["roofline"] is not None and d["roofline"]["step"]["launches_per_step"] >= 15
+    assert d["roofline"] is not None and d["roofline"]["step"]["launches_per_step"] >= 14   # (round 6: the L1 forward and its reduction are one launch)
 
 
 @pytest.mark.timeout(290)
@@ -127,4 +127,4 @@ def test_two_ranks_sharing_the_gpu_run_the_multi_rank_control_flow():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and "NOT A MEASUREMENT" in d["data"]
     assert "frames per rank [8, 8]" in d["config"]["parallelism"]
-    assert d["roofline"] is not None and d["roofline"]["step"]["launches_per_step"] >= 15
+    assert d["roofline"] is not None and d["roofline"]["step"]["launches_per_step"] >= 14   # (round 6: the L1 forward and its reduction are one launch)

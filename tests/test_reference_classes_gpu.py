@@ -25,6 +25,22 @@ needs_scratch = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "scene"))
 
 
 @needs_scratch
+def test_a_staged_run_of_the_reference_scripts_exited_clean():
+    """`python tools/ref_on_gpu.py run` leaves its summary beside the scratch checkout: when there is one, every unchanged entry script of the reference
+    (fps_benchmark_demo.py, train.py, render.py, fps_benchmark_dataset.py) must have exited 0 on this box -- a FAILED run is a failure here, not a skip."""
+    import json
+
+    path = os.path.join(ROOT, "_ref_scratch", "last_run.json")
+    if not os.path.exists(path):
+        pytest.skip("staged, but tools/ref_on_gpu.py run has not been run on this copy")
+    summary = json.load(open(path))
+    bad = {k: v.get("rc") for k, v in summary["scripts"].items() if v.get("rc") != 0}
+    assert not bad, f"reference entry scripts that did not exit 0: {bad}"
+    assert summary.get("same_asset", {}).get("rc") == 0, summary.get("same_asset")
+    assert summary["scripts"]["train.py"].get("complete"), "train.py did not reach 'Training complete.'"
+
+
+@needs_scratch
 @pytest.mark.timeout(290)
 def test_patched_reference_classes_equal_the_mirror_classes_bit_for_bit():
     if not torch.cuda.is_available():
@@ -98,7 +114,7 @@ def test_patched_reference_classes_equal_the_mirror_classes_bit_for_bit():
             assert float((x - y).abs().max()) / float(y.abs().max()) < 3e-4
             for k in ("expr", "jaw_pose", "rotation", "translation"):
                 x, y = a.flame_param[k].grad[ts], b.flame_param[k].grad[ts]
-                assert float((x - y).abs().max()) / (float(y.abs().max()) + 1e-30) < 2e-3, k
+                assert float((x - y).abs().max()) / (float(y.abs().max()) + 1e-30) < 1e-4, k   # (the same kernels on both sides: float atomics reorder the sums, measured ~1e-6)
             # the statistics lines of train.py:197-198 on the reference's object (add_densification_stats rebound) against torch's own arithmetic
             vis, radii = pa["visibility_filter"], pa["radii"]
             a.xyz_gradient_accum = torch.rand((P, 1), device=dev); a.denom = torch.rand((P, 1), device=dev)

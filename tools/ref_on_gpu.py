@@ -46,11 +46,40 @@ def stage(src="/root/reference", n_splats=100_000, n_timesteps=6, width=550, hei
     out = S.write_reference_assets(os.path.join(REF, "flame_model", "assets", "flame"), os.path.join(SCRATCH, "avatar"), template, n_splats=n_splats, n_frames=8,
                                    benchmark_scale=True)
     info = S.write_reference_dataset(os.path.join(SCRATCH, "data"), template, n_timesteps=n_timesteps, width=width, height=height)
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
+        dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], text=True, stderr=subprocess.DEVNULL).strip())
+    except Exception:   # noqa: BLE001
+        commit, dirty = os.environ.get("GRAFT_COMMIT", ""), None
     with open(os.path.join(SCRATCH, "STAGED.json"), "w") as fh:
-        json.dump(dict(source=src, splats=n_splats, point_cloud=os.path.relpath(out["point_cloud"], ROOT), dataset={k: info[k] for k in ("timesteps", "cameras", "train", "val", "test")},
+        json.dump(dict(source=src, commit=commit, tree_dirty=dirty, splats=n_splats, point_cloud=os.path.relpath(out["point_cloud"], ROOT), dataset={k: info[k] for k in ("timesteps", "cameras", "train", "val", "test")},
                        width=width, height=height), fh)
     size = sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(SCRATCH) for f in fs)
     print(f"staged {SCRATCH}: {size / 1e6:.1f} MB (git-ignored; travels with gpurun; `python tools/ref_on_gpu.py clean` removes it)")
+
+
+def provenance(staged):
+    """What the run below was made on (as tools/pmc_per_launch.py stamps the PMC files): the commit the scratch copy was staged at (the GPU box has no .git),
+    a digest of every native library as loaded, the GPU."""
+    import hashlib
+
+    libs = {}
+    for name in ("libgsr_hip.so", "libgab_hip.so", "libgls_hip.so", "gaa_host.so"):
+        path = os.path.join(ROOT, "gaussianavatars_amd", name)
+        if os.path.exists(path):
+            libs[name] = hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    meta = dict(commit=staged.get("commit") or os.environ.get("GRAFT_COMMIT", ""), tree_dirty_when_staged=staged.get("tree_dirty"), libraries=libs)
+    try:
+        import torch
+
+        meta["gpu"] = torch.cuda.get_device_name(0) if torch.cuda.is_available() else None
+        meta["torch"] = torch.__version__
+    except Exception:   # noqa: BLE001
+        pass
+    return meta
+
+
+TAG = os.environ.get("GAA_REF_TAG", "r06_ref")   # file names under gpurun_out/
 
 
 def _launch(name, body, timeout, env_extra=None):
@@ -62,7 +91,7 @@ def _launch(name, body, timeout, env_extra=None):
     """) + textwrap.dedent(body)
     env = dict(os.environ, PYTHONPATH=ROOT, MPLBACKEND="Agg")
     env.update(env_extra or {})
-    log = os.path.join(OUT, f"r05_ref_{name}.log")
+    log = os.path.join(OUT, f"{TAG}_{name}.log")
     t0 = time.time()
     with open(log, "w") as fh:
         r = subprocess.run([sys.executable, "-c", code], cwd=REF, env=env, stdout=fh, stderr=subprocess.STDOUT, text=True, timeout=timeout)
@@ -92,7 +121,7 @@ def run(train_iterations=200, n_iter=500):
     avatar = os.path.join(ROOT, staged["point_cloud"])
     data, model = os.path.join(SCRATCH, "data"), os.path.join(SCRATCH, "model")
     shutil.rmtree(model, ignore_errors=True)
-    summary = dict(staged=staged, scripts={})
+    summary = dict(staged=staged, scripts={}, _meta=provenance(staged))
 
     # 1) fps_benchmark_demo.py, its own defaults (802x550, 500 iterations, 3 rounds): the harness that defines BASELINE configs[1]
     rc, el, txt = _launch("fps_benchmark_demo", f"""
@@ -207,11 +236,12 @@ def run(train_iterations=200, n_iter=500):
     if line:
         d = json.loads(line[-1])
         summary["bench_cfg2"] = dict(value=d["value"], ms_per_step=d["ms_per_step"], num_rendered=d["config"].get("num_rendered"), num_binned=d["config"].get("num_binned"))
-        open(os.path.join(OUT, "r05_ref_bench_cfg2.json"), "w").write(line[-1] + "\n")
+        open(os.path.join(OUT, f"{TAG}_bench_cfg2.json"), "w").write(line[-1] + "\n")
     else:
         summary["bench_cfg2"] = dict(error=(r.stdout + r.stderr)[-1500:])
-    with open(os.path.join(OUT, "r05_ref_summary.json"), "w") as fh:
-        json.dump(summary, fh, indent=1)
+    for path in (os.path.join(OUT, f"{TAG}_summary.json"), os.path.join(SCRATCH, "last_run.json")):   # (the second one: tests/test_reference_classes_gpu.py fails on a script that did not exit 0)
+        with open(path, "w") as fh:
+            json.dump(summary, fh, indent=1)
     print(json.dumps(summary, indent=1))
     return 0 if all(v.get("rc") == 0 for v in summary["scripts"].values()) else 1
 
