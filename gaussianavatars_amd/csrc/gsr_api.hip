@@ -529,10 +529,12 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
     const unsigned long long post_cap = deferred ? (unsigned long long)binning_capacity : ~0ull;   // deferred: an overflowing frame marks the slot's sticky word
     // rank path: contiguous chunks of splats per workgroup, or -- when the previous frame of this (device, size) reported its tile instances unevenly spread
     // along the splat order -- small groups dealt round-robin (gsr_device.h: rank_chunk / rank_splat; this frame's own report rides in the posted count)
-    int dev_id = 0, rank_ilv = 0;
+    int dev_id = 0, rank_ilv = -1;
     if (rankp) {
         HIP_TRY(hipGetDevice(&dev_id));
-        rank_ilv = rank_ilv_for(dev_id, settings->image_width, settings->image_height);
+        const int ilv = rank_ilv_for(dev_id, settings->image_width, settings->image_height);   // 0: contiguous, else a group size (rounded down to a power of two)
+        rank_ilv = -1;
+        for (int v = ilv; v > 0; v >>= 1) ++rank_ilv;                                                // log2, -1 for contiguous
     }
     slot_holds_frame(deferred ? settings->deferred_count - 1 : GSR_COUNT_SLOTS, dev_id, rankp ? settings->image_width : 0, settings->image_height);
     const unsigned long long cap = (unsigned long long)binning_capacity;

@@ -642,15 +642,16 @@ __global__ void k_preprocess_bwd(Settings s, PreBwdArgs a);
 // workgroup then touches every tile: one returning atomic per non-empty (workgroup, tile) bin) -- so it is chosen per frame size from what the previous frame's
 // k_preprocess measured (gsr_api.hip: rank_ilv_for; BinHeader::chunk_imbalance).
 #define GSR_RANK_ILV_AUTO 8      // the group size taken when the splats' instance counts are that uneven along the splat order
-__host__ __device__ inline int rank_chunk(int P, int nblk, int ilv)
+// (`ilv` is passed to the kernels as its base-2 logarithm, -1 for contiguous chunks: shifts, no integer division per splat)
+__host__ __device__ inline int rank_chunk(int P, int nblk, int ilv_log2)
 {
-    if (ilv <= 0) return ((P + nblk - 1) / nblk + 31) / 32 * 32;
-    const int groups = (P + ilv - 1) / ilv;
-    return (groups + nblk - 1) / nblk * ilv;
+    if (ilv_log2 < 0) return ((P + nblk - 1) / nblk + 31) / 32 * 32;
+    const int groups = (P + (1 << ilv_log2) - 1) >> ilv_log2;
+    return ((groups + nblk - 1) / nblk) << ilv_log2;
 }
-__host__ __device__ inline int rank_splat(int j, int blk, int nblk, int chunk, int ilv)
+__host__ __device__ inline int rank_splat(int j, int blk, int nblk, int chunk, int ilv_log2)
 {
-    return ilv <= 0 ? blk * chunk + j : ((j / ilv) * nblk + blk) * ilv + (j % ilv);
+    return ilv_log2 < 0 ? blk * chunk + j : ((((j >> ilv_log2) * nblk + blk) << ilv_log2) | (j & ((1 << ilv_log2) - 1)));
 }
 __host__ __device__ inline bool rank_direct(int gx, int tiles) { return (long long)(gx + 1) * (long long)(tiles / gx + 1) > (long long)GSR_RANK_HIST_TILES; }
 #define GSR_RANK_IMBALANCE 3

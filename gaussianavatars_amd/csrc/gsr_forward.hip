@@ -302,14 +302,6 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         }
     }
     if (a.pstat) {
-        // ---- rank path: this workgroup's depth range (plain stores, one pair per workgroup; k_rcount folds them)
-        __shared__ uint32_t ps_mn[4], ps_mx[4];
-        const uint32_t dbits = __float_as_uint(depth);
-        const uint32_t mn_inv = wave_max_u32(visible ? ~dbits : 0u), mx = wave_max_u32(visible ? dbits : 0u);
-        if ((threadIdx.x & 63) == 0) { ps_mn[threadIdx.x >> 6] = mn_inv; ps_mx[threadIdx.x >> 6] = mx; }
-        __syncthreads();
-        if (threadIdx.x == 0)
-            *reinterpret_cast<uint2*>(&a.pstat[blockIdx.x]) = make_uint2(~max(max(ps_mn[0], ps_mn[1]), max(ps_mn[2], ps_mn[3])), max(max(ps_mx[0], ps_mx[1]), max(ps_mx[2], ps_mx[3])));
         // the tile rect this splat is binned into (snug in the culling modes) and the operands of the per-quadrant reach test
         // (gsr_device.h: band_of): computed here, once per splat, for the two binning passes that expand the rect
         float4 span2[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};   // (rows of splats that are not binned are never read)
@@ -330,13 +322,17 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
             a.srect[i] = nt ? make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy) : make_ushort4(0, 0, 0, 0);
             ps_nt = nt;
         }
-        {   // the tile instances this workgroup's 256 splats are binned into: how evenly they are spread along the splat order decides the chunking of the NEXT frame's rank passes
-            __shared__ uint32_t ps_sum[4];
-            const uint32_t wsum = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl_u32(ps_nt), 63);
-            if ((threadIdx.x & 63) == 0) ps_sum[threadIdx.x >> 6] = wsum;
-            __syncthreads();
-            if (threadIdx.x == 0) a.pstat[blockIdx.x].z = (ps_sum[0] + ps_sum[1]) + (ps_sum[2] + ps_sum[3]);
-        }
+        // ---- rank path: this workgroup's depth range and the tile instances its 256 splats are binned into (plain stores, one row per workgroup; k_rcount folds
+        // them: the range maps depths to buckets, how evenly the instances are spread along the splat order decides the chunking of the NEXT frame's rank passes)
+        __shared__ uint32_t ps_mn[4], ps_mx[4], ps_sum[4];
+        const uint32_t dbits = __float_as_uint(depth);
+        const uint32_t mn_inv = wave_max_u32(visible ? ~dbits : 0u), mx = wave_max_u32(visible ? dbits : 0u);
+        const uint32_t wsum = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl_u32(ps_nt), 63);
+        if ((threadIdx.x & 63) == 0) { ps_mn[threadIdx.x >> 6] = mn_inv; ps_mx[threadIdx.x >> 6] = mx; ps_sum[threadIdx.x >> 6] = wsum; }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            a.pstat[blockIdx.x] = make_uint4(~max(max(ps_mn[0], ps_mn[1]), max(ps_mn[2], ps_mn[3])), max(max(ps_mx[0], ps_mx[1]), max(ps_mx[2], ps_mx[3])),
+                                             (ps_sum[0] + ps_sum[1]) + (ps_sum[2] + ps_sum[3]), 0u);
         put_rows(a.sspan, span2, std::integral_constant<int, 2>{});
     }
     if (a.brec) {
@@ -825,7 +821,10 @@ extern "C" int gsr_debug_read_fwd(unsigned long long* host, int n) { return (int
 #define GSR_CONT_WAVES 8   // waves of a workgroup of the continuation KERNEL (CONT == 2) = chunks of a quadrant in flight
 #endif
 template <bool FAST, int CONT>
-__global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, CONT == 2 ? 1 : 5) void k_render(Settings s, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ qstart,
+#ifndef GSR_EXP_LB
+#define GSR_EXP_LB (CONT == 1 ? 5 : 1)   // (only the instance that carries the continuation workgroups needs its register budget capped: their body would take the tiles' walks from five waves per SIMD to four)
+#endif
+__global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, GSR_EXP_LB) void k_render(Settings s, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ qstart,
                                                  const uint32_t* __restrict__ qcount,
                                                  const float4* __restrict__ grec, const uint32_t* __restrict__ qpos,
                                                  const uint32_t* __restrict__ qlist, float* __restrict__ final_T,

@@ -92,8 +92,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int ilv, int P,
         const uint4 v = pstat[j];
         mn = min(mn, v.x);
         mx = max(mx, v.y);
-        imax = max(imax, v.z);
-        isum += v.z;
+        if (blockIdx.x == 0) { imax = max(imax, v.z); isum += v.z; }
     }
     mn = wave_min_u32(mn);
     mx = wave_max_u32(mx);
