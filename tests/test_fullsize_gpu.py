@@ -166,8 +166,11 @@ def _check_flame_rows(g, ts, ref, want64, what):
         assert err < bar, f"{what} d flame {k}: rel err {err:.2e} (bar {bar:.2e} = max({FLAME_ROW_FLOOR:g}, {FLAME_ROW_FACTOR:g} x {dev:.2e}))"
 
 
-def test_config3_benchmarked_step_in_the_benchmarked_mode(oracle):
-    """BASELINE configs[2], the step bench.py times, in the mode it times it: 100 000 Morton-ordered mesh-bound splats through select_mesh_by_timestep ->
+@pytest.mark.parametrize("head", ["ellipsoid", "template_like"])
+def test_config3_benchmarked_step_in_the_benchmarked_mode(oracle, head):
+    """(`head`: the two scenes bench.py reports -- the ellipsoid stand-in of the default line and the head with the reference template's face-area
+    distribution, whose tiles are as deep as the avatar staged on the real template.)
+    BASELINE configs[2], the step bench.py times, in the mode it times it: 100 000 Morton-ordered mesh-bound splats through select_mesh_by_timestep ->
     render() -> l1_loss -> backward() with the PRODUCT defaults -- fast blend, tile culling, the bound entry, the compiled host (asserted from
     last_forward_info) -- against the oracle directly: image within the fast blend's stated tolerance, radii equal, the six leaf gradients and the
     screen-space gradient within 5e-4 of the oracle's world-space gradients carried to the leaves in fp64, every FLAME row within its own bar."""
@@ -180,14 +183,18 @@ def test_config3_benchmarked_step_in_the_benchmarked_mode(oracle):
     dev = _dev()
     H, W, N, T = 802, 550, 100_000, 8
     assert bench.SPATIAL_SORT
-    g, cam = bench.build_scene(dev, N, 3, W, H, T, "fused", True)
+    prev_scene, bench.SCENE = bench.SCENE, head
+    try:
+        g, cam = bench.build_scene(dev, N, 3, W, H, T, "fused", True)
+    finally:
+        bench.SCENE = prev_scene
     bg = torch.ones(3, device=dev)
     target = torch.ones((3, H, W), device=dev)
     tfx, tfy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
     s = oracle.make_settings(H, W, tfx, tfy, [1, 1, 1], 1.0, _np(cam.world_view_transform), _np(cam.full_proj_transform), 3, _np(cam.camera_center))
     prev = R.set_fast_blend(True)
     try:
-        for ts in (0, 5):
+        for ts in ((0, 5) if head == "ellipsoid" else (3,)):
             g.select_mesh_by_timestep(ts)
             with torch.no_grad():
                 a = {k: _np(v) for k, v in dict(means3D=g.get_xyz, opacities=g.get_opacity, scales=g.get_scaling, rotations=g.get_rotation).items()}
@@ -205,15 +212,15 @@ def test_config3_benchmarked_step_in_the_benchmarked_mode(oracle):
             assert info.get("bound") and info.get("tile_culling") and not info.get("forward_only"), info
             assert bool(info.get("native_host")) == (_host.get() is not None), info
             np.testing.assert_array_equal(_np(pkg["radii"]), st.radii)
-            n = check_image(_np(pkg["render"]), st.color, float(st.rgb[st.radii > 0].max()), f"cfg3 t={ts}")
+            n = check_image(_np(pkg["render"]), st.color, float(st.rgb[st.radii > 0].max()), f"cfg3 {head} t={ts}")
             got = dict(_xyz=g._xyz.grad, _scaling=g._scaling.grad, _rotation=g._rotation.grad, _opacity=g._opacity.grad,
                        _features_dc=g._features_dc.grad, _features_rest=g._features_rest.grad, means2D=pkg["viewspace_points"].grad)
             for k, v in got.items():
                 r = np.asarray(want[k], np.float64).reshape(tuple(v.shape))
                 err = np.abs(_np(v).astype(np.float64) - r).max() / (np.abs(r).max() + 1e-30)
-                assert err < 5e-4, f"cfg3 t={ts} benchmarked mode d{k}: rel err {err:.2e}"
-            _check_flame_rows(g, ts, ref, want, f"cfg3 t={ts} benchmarked mode")
-            print(f"cfg3 t={ts} benchmarked mode ({'compiled' if info.get('native_host') else 'python'} host): {n} threshold pixel(s), "
+                assert err < 5e-4, f"cfg3 {head} t={ts} benchmarked mode d{k}: rel err {err:.2e}"
+            _check_flame_rows(g, ts, ref, want, f"cfg3 {head} t={ts} benchmarked mode")
+            print(f"cfg3 {head} t={ts} benchmarked mode ({'compiled' if info.get('native_host') else 'python'} host): {n} threshold pixel(s), "
                   f"image max|diff| {np.abs(_np(pkg['render']) - st.color).max():.2e}")
     finally:
         R.set_fast_blend(prev)
