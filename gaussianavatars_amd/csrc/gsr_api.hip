@@ -772,11 +772,8 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         const int cgrid = 4 * tiles < cont_grid ? 4 * tiles : cont_grid;
         const bool conts = ds.fast_blend && ds.cont_chunks > 0;
         if (!conts) ds.cont_chunks = 0;
-        // GSR_RENDER_PC=1: the fast blend with a producer and a consumer wave per quadrant (gsr_forward_pc.hip; same bits as k_render<true, 0>)
-        static const bool render_pc = [] { const char* e = getenv("GSR_RENDER_PC"); return e ? atoi(e) != 0 : GSR_RENDER_PC_DEFAULT != 0; }();
-        const bool pc = render_pc && ds.fast_blend && !conts;
-        auto* const render_k = pc ? &gsr::k_render_pc : !ds.fast_blend ? &gsr::k_render<false, 0> : (conts && ds.cont_mode == 1 ? &gsr::k_render<true, 1> : &gsr::k_render<true, 0>);
-        hipLaunchKernelGGL(render_k, dim3(tiles + (conts && ds.cont_mode == 1 ? cgrid : 0)), dim3(pc ? 512 : 256), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
+        auto* const render_k = !ds.fast_blend ? &gsr::k_render<false, 0> : (conts && ds.cont_mode == 1 ? &gsr::k_render<true, 1> : &gsr::k_render<true, 0>);
+        hipLaunchKernelGGL(render_k, dim3(tiles + (conts && ds.cont_mode == 1 ? cgrid : 0)), dim3(256), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
                            (const uint32_t*)qcount, (const float4*)pa.grec, (const uint32_t*)qpos, write_lists ? (const uint32_t*)qlist : nullptr, (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib),
                            (uint32_t*)(im + il.n_contrib_q), (float*)(im + il.c_final), (float4*)(im + il.ck), out_color, cap,
                            (const unsigned long long*)total_dev, (uint32_t*)(im + il.units), tiles);

@@ -585,11 +585,6 @@ __global__ void k_render(Settings s, const uint32_t* tile_order, const uint32_t*
                          const uint32_t* qpos, const uint32_t* qlist, float* final_T,
                          uint32_t* n_contrib, uint32_t* n_contrib_q, float* c_final, float4* ck, float* out_color, unsigned long long capacity,
                          const unsigned long long* total_dev, uint32_t* units, int tiles);
-// the fast blend's forward with a producer and a consumer wave per quadrant (gsr_forward_pc.hip): k_render<true, 0>'s arguments, 512 threads per tile
-__global__ void k_render_pc(Settings s, const uint32_t* tile_order, const uint32_t* qstart, const uint32_t* qcount, const float4* grec,
-                            const uint32_t* qpos, const uint32_t* qlist, float* final_T,
-                            uint32_t* n_contrib, uint32_t* n_contrib_q, float* c_final, float4* ck, float* out_color, unsigned long long capacity,
-                            const unsigned long long* total_dev, uint32_t* units, int tiles);
 // the continuation area behind the unit lists of GsrImageLayout.units (k_render): header words, then the list, then the parked states
 #define GSR_CONT_HDR_WORDS 576    // word 0 parked, 32 pull cursor, 64 + 32 k (k < 16) reports of the tile waves: a 128-byte line each
 #ifndef GSR_CONT_CHUNKS_DEFAULT
@@ -597,9 +592,6 @@ __global__ void k_render_pc(Settings s, const uint32_t* tile_order, const uint32
 #endif
 #ifndef GSR_CONT_WAVES
 #define GSR_CONT_WAVES 8   // waves per workgroup of the continuation kernel (mode 2): chunks of a quadrant in flight
-#endif
-#ifndef GSR_RENDER_PC_DEFAULT
-#define GSR_RENDER_PC_DEFAULT 0
 #endif
 #ifndef GSR_CONT_MODE_DEFAULT
 #define GSR_CONT_MODE_DEFAULT 1

@@ -36,10 +36,8 @@ sel = jm > 50
 print("us per record vs depth: corr(dur, jmax) = %.3f;  median us/record (jmax>50) %.3f" % (np.corrcoef(dur, jm)[0, 1], np.median(dur[sel] / jm[sel])))
 
 # ---- forward (k_render)
-import os
-fwd_read = lib.gsr_debug_read_pc if os.environ.get("GSR_RENDER_PC", "0") not in ("", "0") else lib.gsr_debug_read_fwd   # (k_render_pc: the consumer waves' stamps)
-fwd_read.restype = C.c_int
-assert fwd_read(buf, 4 * 16384) == 0
+lib.gsr_debug_read_fwd.restype = C.c_int
+assert lib.gsr_debug_read_fwd(buf, 4 * 16384) == 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4)[:7140].astype(np.int64)
 t0, t1, nj, tm = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
 live = t1 > 0
