@@ -239,14 +239,16 @@ __device__ __forceinline__ float sgn_scaled(float d, float g) { return d > 0.f ?
 // stream's next call.  Integer adds commute: the same bits whatever order the workgroups arrive in.  (Rounds 2 - 3 measured a ticket + fence +
 // re-read of the partials at the price of the launch it replaced; here nothing is re-read.)  At most 255 workgroups; |a - b| sums below 2^26.
 template <bool GRAD, bool FUSED>
-__global__ __launch_bounds__(256) void k_l1_fwd(long long n, const float* __restrict__ a, const float* __restrict__ b, float2* __restrict__ partial,
-                                                 float gs, float* __restrict__ d_a, unsigned long long* __restrict__ word, float* __restrict__ sum)
+__global__ __launch_bounds__(1024) void k_l1_fwd(long long n, const float* __restrict__ a, const float* __restrict__ b, float2* __restrict__ partial,
+                                                  float gs, float* __restrict__ d_a, unsigned long long* __restrict__ word, float* __restrict__ sum)
 {
-    __shared__ float red[4];
-    const int tid = threadIdx.x;
+    // (blockDim.x: 256 in the two-launch form; the one-launch form is held to 255 workgroups by its arrival count and takes WIDE ones -- with
+    //  256 threads it ran one wave per SIMD, five dependent trips of two loads each: 7.6 us for 16 MB)
+    __shared__ float red[16];
+    const int tid = threadIdx.x, nt = (int)blockDim.x;
     const long long n4 = n >> 2;
     float s = 0.f;
-    for (long long i = (long long)blockIdx.x * 256 + tid; i < n4; i += (long long)gridDim.x * 256) {
+    for (long long i = (long long)blockIdx.x * nt + tid; i < n4; i += (long long)gridDim.x * nt) {
         const float4 u = ((const float4*)a)[i], v = ((const float4*)b)[i];
         const float dx = u.x - v.x, dy = u.y - v.y, dz = u.z - v.z, dw = u.w - v.w;
         s += (fabsf(dx) + fabsf(dy)) + (fabsf(dz) + fabsf(dw));
@@ -261,7 +263,8 @@ __global__ __launch_bounds__(256) void k_l1_fwd(long long n, const float* __rest
     if ((tid & 63) == 63) red[tid >> 6] = s;
     __syncthreads();
     if (tid == 0) {
-        const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        for (int w = 4; w < (nt >> 6); w += 4) tot += (red[w] + red[w + 1]) + (red[w + 2] + red[w + 3]);
         if constexpr (FUSED) {
             const unsigned long long mine = (unsigned long long)((double)tot * 1073741824.0 + 0.5) & 0x00FFFFFFFFFFFFFFull;
             const unsigned long long old = atomicAdd(word, mine + (1ull << 56));
@@ -471,9 +474,11 @@ static int l1_forward_impl(int64_t n, const float* a, const float* b, float scal
     unsigned long long* word = (fused_on && n < (1ll << 26)) ? l1_word_for(stream) : nullptr;
     if (word) {
         static const int fmax = [] { const char* e = getenv("GLS_L1_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 255 ? v : 255; }();   // (A/B runs)
-        const int fb = blocks > fmax ? fmax : blocks;
-        if (grad) PROF_LAUNCH(gls::k_l1_fwd_1g, dim3(fb), dim3(256), 0, stream, (long long)n, a, b, (float2*)partial, scale, d_a, word, sum);
-        else PROF_LAUNCH(gls::k_l1_fwd_1, dim3(fb), dim3(256), 0, stream, (long long)n, a, b, (float2*)partial, scale, (float*)nullptr, word, sum);
+        static const int fthreads = [] { const char* e = getenv("GLS_L1_THREADS"); const int v = e ? atoi(e) : 0; return v == 256 || v == 512 || v == 1024 ? v : 1024; }();
+        const int wide = (int)(((n >> 2) + fthreads - 1) / fthreads);
+        const int fb = wide < 1 ? 1 : (wide > fmax ? fmax : wide);
+        if (grad) PROF_LAUNCH(gls::k_l1_fwd_1g, dim3(fb), dim3(fthreads), 0, stream, (long long)n, a, b, (float2*)partial, scale, d_a, word, sum);
+        else PROF_LAUNCH(gls::k_l1_fwd_1, dim3(fb), dim3(fthreads), 0, stream, (long long)n, a, b, (float2*)partial, scale, (float*)nullptr, word, sum);
         LAUNCH_CHECK("k_l1_fwd");
         return GLS_OK;
     }

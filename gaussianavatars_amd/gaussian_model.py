@@ -326,9 +326,11 @@ def spatial_resort(model) -> torch.Tensor:
         prev = getattr(model, "_gaa_order", None)
         if isinstance(prev, torch.Tensor) and prev.shape[0] == n:
             model._gaa_order = prev.to(perm.device)[perm]
+        elif prev is None and not getattr(model, "_gaa_order_lost", False):
+            model._gaa_order = perm.clone()          # first sort of a freshly loaded model: the file's order is the order it had until now
         else:
-            base = torch.arange(n, device=perm.device)
-            if isinstance(prev, torch.Tensor) and prev.shape[0] < n:      # splats appended since the last sort: unknown to the loaded file
-                base = torch.cat([prev.to(perm.device), torch.full((n - prev.shape[0],), -1, dtype=torch.long, device=perm.device)])
-            model._gaa_order = base[perm]
+            # the row count changed without the rows being followed (patch._hook_spatial_order follows the reference's prune_points /
+            # densification_postfix; anything else does not): no permutation is better than one that names the wrong rows
+            model._gaa_order = None
+            model._gaa_order_lost = True
     return perm

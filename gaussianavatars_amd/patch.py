@@ -200,12 +200,49 @@ def _hook_spatial_order(G) -> None:
             out = load(self, *a, **k)
             from .gaussian_model import spatial_order_default, spatial_resort
 
+            if getattr(self, "_xyz", None) is not None:
+                self._gaa_order = torch.arange(self._xyz.shape[0], device=self._xyz.device)   # row i of the model = row i of the file, so far
+                self._gaa_order_lost = False
             if spatial_order_default() and getattr(self, "_xyz", None) is not None and self._xyz.shape[0] > 1:
                 spatial_resort(self)
             return out
 
         load_ply.__doc__ = load.__doc__
         G.load_ply = load_ply
+    # `_gaa_order` (row i of the model = row _gaa_order[i] of the loaded file, -1 for splats born since) follows the rows through the reference's
+    # own pruning and appending (scene/gaussian_model.py:371-399, :426-444); a row count that changed any other way drops it (None) instead of
+    # leaving a permutation that points at the wrong rows
+    prune = G.__dict__.get("prune_points")
+    if prune is not None:
+        _ORIG[(G, "prune_points")] = prune
+
+        def prune_points(self, mask):
+            order, n = getattr(self, "_gaa_order", None), self._xyz.shape[0]
+            out = prune(self, mask)        # (narrows `mask` in place to the splats it really removes: every face keeps one)
+            tracked = isinstance(order, torch.Tensor) and order.shape[0] == n and mask.shape[0] == n
+            self._gaa_order = order.to(mask.device)[~mask] if tracked else None
+            if self._gaa_order is None or self._gaa_order.shape[0] != self._xyz.shape[0]:
+                self._gaa_order, self._gaa_order_lost = None, True
+            return out
+
+        prune_points.__doc__ = prune.__doc__
+        G.prune_points = prune_points
+    postfix = G.__dict__.get("densification_postfix")
+    if postfix is not None:
+        _ORIG[(G, "densification_postfix")] = postfix
+
+        def densification_postfix(self, *a, **k):
+            order, n = getattr(self, "_gaa_order", None), self._xyz.shape[0]
+            out = postfix(self, *a, **k)   # (appends the new splats behind the old ones)
+            grown = self._xyz.shape[0] - n
+            if isinstance(order, torch.Tensor) and order.shape[0] == n and grown >= 0:
+                self._gaa_order = torch.cat([order, torch.full((grown,), -1, dtype=order.dtype, device=order.device)])
+            else:
+                self._gaa_order, self._gaa_order_lost = None, True
+            return out
+
+        densification_postfix.__doc__ = postfix.__doc__
+        G.densification_postfix = densification_postfix
     dens = G.__dict__.get("densify_and_prune")
     if dens is not None:
         _ORIG[(G, "densify_and_prune")] = dens

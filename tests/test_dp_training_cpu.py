@@ -86,6 +86,19 @@ def _train(rank, world, port, farm, ply, q):
     # itself is exercised after that
     os.environ["GAA_SPATIAL_SORT"] = "0"
     g.load_ply(Path(ply), has_target=False)
+    binding_in_file = g.binding.clone()
+
+    def order_holds(what):
+        # `_gaa_order`: row i of the model is row _gaa_order[i] of the loaded file, -1 for splats born since -- followed through the reference's
+        # prune_points / densification_postfix and every re-sort (a splat never changes its face, so the binding tells)
+        o = g._gaa_order
+        assert o is not None and o.shape[0] == g._xyz.shape[0], what
+        old = o >= 0
+        assert torch.equal(g.binding[old], binding_in_file[o[old]]), what + ": the recorded order names other rows of the file"
+        assert o[old].unique().numel() == int(old.sum()), what
+        return int(old.sum())
+
+    assert order_holds("as loaded") == binding_in_file.shape[0]
     g.spatial_lr_scale = 1.0
     g.max_radii2D = torch.zeros(g.get_xyz.shape[0])     # (create_from_pcd / restore set it in train.py's own start-up, load_ply does not)
     opt = types.SimpleNamespace(percent_dense=0.01, position_lr_init=0.005, position_lr_final=0.00005, position_lr_delay_mult=0.01,
@@ -134,8 +147,11 @@ def _train(rank, world, port, farm, ply, q):
                 st[grp["opacity"]]["exp_avg_sq"], st[grp["f_rest"]]["exp_avg"].flatten(1), g.binding[:, None], g.max_radii2D[:, None], g.denom, g.xyz_gradient_accum]
         return torch.cat([c.detach().double().reshape(c.shape[0], -1) for c in cols], 1)
 
+    survivors = order_holds("after four rounds of densify_and_prune")
+    assert 0 < survivors and survivors < int(g._xyz.shape[0]) and (sizes[-1] != sizes[0] or survivors < sizes[0])   # (splats were born, some of the file's may be gone)
     before = rows()
     perm = spatial_resort(g)
+    assert order_holds("after the re-sort") == survivors
     assert sorted(perm.tolist()) == list(range(before.shape[0])) and not torch.equal(perm, torch.arange(before.shape[0]))
     assert torch.equal(before[perm], rows()), "a per-splat quantity did not move with its splat"
     assert all(g.optimizer.state.get(gr["params"][0]) is not None for gr in g.optimizer.param_groups if gr["name"] in ("xyz", "opacity", "f_rest"))
@@ -160,6 +176,7 @@ def _train(rank, world, port, farm, ply, q):
         g.densify_and_prune(6e-3, 0.3, 1.0, 20)
         again = spatial_resort(g)
     assert torch.equal(again, torch.arange(again.shape[0])), "densify_and_prune did not leave the model in Morton order"
+    order_holds("after densify_and_prune with the re-sort hook on")
     assert g._xyz is [gr["params"][0] for gr in g.optimizer.param_groups if gr["name"] == "xyz"][0]
     state = {k: _digest(getattr(g, k)) for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "binding",
                                                    "binding_counter", "max_radii2D", "xyz_gradient_accum", "denom")}
