@@ -472,6 +472,11 @@ __global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_
             if (!rm) continue;
             const float dy = yq - (float)r;
             const float Bdy = cB * dy, Cdy2 = (cC * dy) * dy;
+#ifndef GSR_EXP_NO_ROW_SUMS
+            // the six position moments of tq = G dL/dG: dy is the same for the row's eight pixels, so the row adds up (sum tq, sum tq dx, sum tq dx^2)
+            // and the three dy-weighted sums are formed once per row (4 packed operations per pixel pair instead of 8)
+            f2 rs0 = {0.f, 0.f}, rs1 = rs0, rs2 = rs0;
+#endif
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if (!((rm >> (4 * h)) & 0xFu)) continue;
@@ -490,8 +495,13 @@ __global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_
                     const f2 G = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
                     const f2 araw = op * G;
                     const int l0 = __float_as_int(t[e][2].z), l1 = __float_as_int(t[e][2].w);
+#ifdef GSR_EXP_HI_TEST
                     a0m[e].x = (l0 > jrec && pw.x <= 0.0f && araw.x >= 1.0f / 255.0f) ? araw.x : 0.0f;
                     a0m[e].y = (l1 > jrec && pw.y <= 0.0f && araw.y >= 1.0f / 255.0f) ? araw.y : 0.0f;
+#else
+                    a0m[e].x = (l0 > jrec && araw.x >= 1.0f / 255.0f) ? araw.x : 0.0f;
+                    a0m[e].y = (l1 > jrec && araw.y >= 1.0f / 255.0f) ? araw.y : 0.0f;
+#endif
                     al[e] = f2{__builtin_fminf(0.99f, a0m[e].x), __builtin_fminf(0.99f, a0m[e].y)};
                     const f2 om = 1.0f - al[e];
                     rv[e] = f2{__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
@@ -520,16 +530,23 @@ __global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_
                     // 1 + alpha / (1 - alpha) = 1 / (1 - alpha) that is (T c.g - inclusive sum - S_end) / (1 - alpha)
                     const f2 dLda = ((Tj[e] * cg[e] - Pw[e]) - Sx) * rv[e];
                     const f2 tq = a0m[e] * dLda;                        // opacity * G * dL/dalpha  (= G * dL/dG; the 0.99 clamp has no gradient)
-                    const f2 ax = tq * dx[e], ay = tq * dy;
                     a0 += aT[e] * g0;
                     a1 += aT[e] * g1;
                     a2 += aT[e] * g2;
+#ifndef GSR_EXP_NO_ROW_SUMS
+                    const f2 ax = tq * dx[e];
+                    rs0 += tq;
+                    rs1 += ax;
+                    rs2 += ax * dx[e];
+#else
+                    const f2 ax = tq * dx[e], ay = tq * dy;
                     a3 += ax;                                           // k_preprocess_bwd forms A sx + B sy, C sy + B sx and the constant factors
                     a4 += ay;
                     a5 += ax * dx[e];
                     a6 += ax * dy;
                     a7 += ay * dy;
                     a8 += tq;                                           // / opacity, once per splat
+#endif
                     if (more) {
                         // state at the chunk's lower end for the chunk below: lane CH-1 holds the lowest entry -- the transmittance in front of it
                         // and, inclusive of it, the sum behind
@@ -544,6 +561,14 @@ __global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_
                     }
                 }
             }
+#ifndef GSR_EXP_NO_ROW_SUMS
+            a3 += rs1;                                                  // k_preprocess_bwd forms A sx + B sy, C sy + B sx and the constant factors
+            a4 += rs0 * dy;
+            a5 += rs2;
+            a6 += rs1 * dy;
+            a7 += rs0 * (dy * dy);
+            a8 += rs0;                                                  // / opacity, once per splat
+#endif
         }
         // ---- nine sums per record.  A lane adding its own nine would send 60 different cache lines per instruction through the L2 atomic
         // units (measured: the kernel three times slower than the walk it replaces); instead the sums cross the wave through LDS and leave

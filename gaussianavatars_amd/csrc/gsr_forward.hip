@@ -916,7 +916,11 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, GSR_EXP_LB) 
                 // ONE median + ONE comparison (a NaN -- an opacity below 1/255 has L = NaN -- fails it)
                 power = __builtin_fmaf(__builtin_fmaf(R.a[u][3], dy, R.a[u][2] * dx), dx, __builtin_fmaf(R.a[u][4] * dy, dy, R.a[u][5]));
                 const float raw = __builtin_amdgcn_exp2f(power);
+#ifdef GSR_EXP_HI_TEST
                 ok[u] = __builtin_amdgcn_fmed3f(raw, 1.0f / 255.0f, R.hi[u]) == raw;
+#else
+                ok[u] = raw >= 1.0f / 255.0f;   // (NaN fails)
+#endif
                 a = __builtin_amdgcn_fmed3f(raw, 0.0f, 0.99f);   // = min(0.99, raw) for raw >= 0.  (fminf would first canonicalise the exponential's result, one more
                                                                  // instruction; an inline-asm v_min hides the operand from the compiler's hazard recogniser, which has to
                                                                  // put a wait state between a transcendental and the VALU instruction that reads its result: measured, T > 1)
@@ -1048,7 +1052,11 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, GSR_EXP_LB) 
                 const float dx = r0.x - ppx, dy = r0.y - ppy;
                 const float power = __builtin_fmaf(__builtin_fmaf(r0.w, dy, r0.z * dx), dx, __builtin_fmaf(r1.x * dy, dy, r1.y));   // (the walk's expressions)
                 const float raw = __builtin_amdgcn_exp2f(power);
+#ifdef GSR_EXP_HI_TEST
                 ok[e] = valid && __builtin_amdgcn_fmed3f(raw, 1.0f / 255.0f, r2.y) == raw;
+#else
+                ok[e] = valid && raw >= 1.0f / 255.0f;
+#endif
                 const float a = __builtin_amdgcn_fmed3f(raw, 0.0f, 0.99f);
                 am[e] = ok[e] ? a : 0.0f;
                 prod[e] = 1.0f - am[e];

@@ -10,14 +10,14 @@ set -eu
 which=${1:-forward}
 here=$(cd "$(dirname "$0")/../gaussianavatars_amd/csrc" && pwd)
 case "$which" in
-  forward)       src=gsr_forward.hip;  fp=off;  kern=_ZN3gsr8k_renderILb0ELb0EE;            r=${2:-6};;
-  forward_fast)  src=gsr_forward.hip;  fp=off;  kern=_ZN3gsr8k_renderILb1ELb0EE;            r=${2:-6};;   # GsrSettings.fast_blend
+  forward)       src=gsr_forward.hip;  fp=off;  kern=_ZN3gsr8k_renderILb0ELi0EE;            r=${2:-6};;
+  forward_fast)  src=gsr_forward.hip;  fp=off;  kern=_ZN3gsr8k_renderILb1ELi0EE;            r=${2:-6};;   # GsrSettings.fast_blend
   backward)      src=gsr_backward.hip; fp=fast; kern=_ZN3gsr12k_render_bwdILb0ELb0EE;   r=${2:-4};;
   backward_fast) src=gsr_backward.hip; fp=fast; kern=_ZN3gsr12k_render_bwdILb0ELb1EE;   r=${2:-4};;
   *) echo "forward | forward_fast | backward | backward_fast"; exit 2;;
 esac
 tmp=$(mktemp -d)
-(cd "$here" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=$fp ${ISA_DEFS:-} -S --cuda-device-only $src -o $tmp/k.s 2>/dev/null)
+(cd "$here" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=$fp -fno-slp-vectorize ${ISA_DEFS:-} -S --cuda-device-only $src -o $tmp/k.s 2>/dev/null)
 awk -v k="$kern" '$0 ~ "^"k".*:" {on=1} on && /s_endpgm/ {on=0} on {print}' $tmp/k.s > $tmp/kernel.s
 hdr=$(grep -m1 "Loop Header: Depth=1" $tmp/kernel.s | sed 's/:.*//; s/^\.L//')
 awk -v h="$hdr" -v r="$r" '
