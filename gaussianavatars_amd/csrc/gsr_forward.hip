@@ -968,19 +968,49 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, GSR_EXP_LB) 
     constexpr int CH = GSR_BWD_SEGMENT;
     static_assert(CH <= GSR_WAVE && CH % (2 * RB) == 0, "a chunk is one gather of the wave and a whole number of double batches");
     constexpr int NWV = CONT == 2 ? GSR_CONT_WAVES : 4;   // waves per workgroup
-    __shared__ float4 stage_all[NWV][2][CH * 3 + 3];   // (+3: the walk's read-ahead of a chunk's last double batch ends one batch past the chunk -- harmless, never used, but it has to be inside the allocation)
-    float4(*const stage)[CH * 3 + 3] = stage_all[pwave];
-    float4 g0, g1, g2;   // the chunk in flight: this lane's record
+    // DIRECT (round 6, the instances without continuation code): the gather goes straight into LDS (global_load_lds_dwordx4: lane l's 16 bytes land at
+    // base + 16 l, so a chunk is staged as three planes of 64 float4 -- part k of record j at [64 k + j]) instead of through twelve vector
+    // registers that stay live across the whole walk of the chunk before; nothing is parked.
+#ifndef GSR_EXP_NO_DIRECT
+    constexpr bool DIRECT = CONT == 0;
+#else
+    constexpr bool DIRECT = false;
+#endif
+    constexpr int STAGE_F4 = DIRECT ? 3 * GSR_WAVE : CH * 3 + 3;   // (+3: the walk's read-ahead of a chunk's last double batch ends one batch past the chunk -- harmless, never used, but it has to be inside the allocation; DIRECT: the planes hold 64 entries)
+    constexpr int RS = DIRECT ? 16 : 48;                           // bytes from a record to the next in the stage
+    constexpr int P1 = DIRECT ? 16 * GSR_WAVE : 16, P2 = DIRECT ? 32 * GSR_WAVE : 32;   // ... and to a record's second and third part
+    constexpr int BB = RB * RS;                                    // bytes per batch
+    __shared__ float4 stage_all[NWV][2][STAGE_F4];
+    float4(*const stage)[STAGE_F4] = stage_all[pwave];
+    float4 g0, g1, g2;   // (not DIRECT) the chunk in flight: this lane's record
+    uint32_t nidx = 0;   // DIRECT: this lane's stream entry of the chunk to be gathered NEXT, fetched a chunk ahead (the record loads depend on it: fetched
+                         // where it is needed, every chunk boundary waits out one more round trip to memory)
+    if constexpr (DIRECT) nidx = n > 0 ? qp[min(lane, n - 1)] : 0u;
     auto gather = [&](int c) {   // entries past the end re-read the last one (never walked); lanes CH.. load too (never parked)
-        const size_t idx = (size_t)qp[min(c * CH + lane, n - 1)];
-        g0 = rec[3 * idx + 0];
-        g1 = rec[3 * idx + 1];
-        g2 = rec[3 * idx + 2];
+        const size_t idx = DIRECT ? (size_t)nidx : (size_t)qp[min(c * CH + lane, n - 1)];
+        if constexpr (DIRECT) {
+            typedef const __attribute__((address_space(1))) void* gptr;
+            typedef __attribute__((address_space(3))) void* lptr;
+            const float4* p = rec + 3 * idx;
+            nidx = qp[min((c + 1) * CH + lane, n - 1)];
+            __builtin_amdgcn_global_load_lds((gptr)(p + 0), (lptr)&stage[c & 1][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(p + 1), (lptr)&stage[c & 1][GSR_WAVE], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(p + 2), (lptr)&stage[c & 1][2 * GSR_WAVE], 16, 0, 0);
+        } else {
+            g0 = rec[3 * idx + 0];
+            g1 = rec[3 * idx + 1];
+            g2 = rec[3 * idx + 2];
+        }
+    };
+    auto landed = [&]() {   // DIRECT: everything gathered so far is in LDS
+        if constexpr (DIRECT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     auto park = [&](int c) {
-        if (lane < CH) {
-            float4* d = &stage[c & 1][3 * lane];
-            d[0] = g0; d[1] = g1; d[2] = g2;
+        if constexpr (!DIRECT) {
+            if (lane < CH) {
+                float4* d = &stage[c & 1][3 * lane];
+                d[0] = g0; d[1] = g1; d[2] = g2;
+            }
         }
     };
     // A batch's records come out of LDS with ds_read_b128 / ds_read_b64 at a wave-uniform address (broadcast), issued from inline
@@ -992,22 +1022,30 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, GSR_EXP_LB) 
     // loads, no compiler-made LDS access: the parks sit between chunks, behind a full wait).
     typedef float v4f __attribute__((ext_vector_type(4)));
     typedef float v2f __attribute__((ext_vector_type(2)));
-    struct RecV { v4f q0[RB], q1[RB]; v2f q2[RB]; };
+#ifdef GSR_EXP_HI_TEST
+    typedef v2f q2_t;   // (blue, alpha's upper bound)
+#define GSR_Q2_READ "ds_read_b64"
+#else
+    typedef float q2_t;   // blue
+#define GSR_Q2_READ "ds_read_b32"
+#endif
+    struct RecV { v4f q0[RB], q1[RB]; q2_t q2[RB]; };
     static_assert(RB == 3, "the issue / ready assembly below is written for three records per batch");
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)&stage[0][0], lds1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)&stage[1][0];
     // `addr`: the LDS byte address of the walk's current double batch (a vector register that only ever gets a constant added);
-    // `off`: 0, 144 or 288 bytes ahead of it as an immediate -- no address arithmetic per batch
+    // `O`: 0, 1 or 2 batches (BB bytes each) ahead of it, as immediates -- no address arithmetic per batch
     // (a macro: captured variables inside the operand list of an asm in a GENERIC lambda do not compile with this clang)
 #define GSR_ISSUE(ADDR, O, V)                                                                                                                        \
-    asm volatile("ds_read_b128 %0, %14 offset:%15\n\tds_read_b128 %1, %14 offset:%15+16\n\tds_read_b64 %2, %14 offset:%15+32\n\t"                \
-                 "ds_read_b128 %3, %14 offset:%15+48\n\tds_read_b128 %4, %14 offset:%15+64\n\tds_read_b64 %5, %14 offset:%15+80\n\t"             \
-                 "ds_read_b128 %6, %14 offset:%15+96\n\tds_read_b128 %7, %14 offset:%15+112\n\tds_read_b64 %8, %14 offset:%15+128"                \
+    asm volatile("ds_read_b128 %0, %14 offset:%15\n\tds_read_b128 %1, %14 offset:%16\n\t" GSR_Q2_READ " %2, %14 offset:%17\n\t"                       \
+                 "ds_read_b128 %3, %14 offset:%18\n\tds_read_b128 %4, %14 offset:%19\n\t" GSR_Q2_READ " %5, %14 offset:%20\n\t"                       \
+                 "ds_read_b128 %6, %14 offset:%21\n\tds_read_b128 %7, %14 offset:%22\n\t" GSR_Q2_READ " %8, %14 offset:%23"                             \
                  : "=&v"(V.q0[0]), "=&v"(V.q1[0]), "=&v"(V.q2[0]), "=&v"(V.q0[1]), "=&v"(V.q1[1]), "=&v"(V.q2[1]), "=&v"(V.q0[2]),              \
                    "=&v"(V.q1[2]), "=&v"(V.q2[2]), /* the blend state as pass-through operands: the reads are issued BEHIND everything the */    \
                    /* previous blend computes (its instructions are free to move otherwise, and below this statement they need the old */       \
                    /* batch copied aside) */                                                                                                    \
                    "+v"(Tw), "+v"(C0), "+v"(C1), "+v"(C2), "+v"(lq)                                                                             \
-                 : "v"(ADDR), "n"(O))
+                 : "v"(ADDR), "n"((O)), "n"((O) + P1), "n"((O) + P2), "n"((O) + RS), "n"((O) + RS + P1), "n"((O) + RS + P2), "n"((O) + 2 * RS),  \
+                   "n"((O) + 2 * RS + P1), "n"((O) + 2 * RS + P2))
     // the batch is in its registers once at most `behind` reads issued after it are still in flight (9 = one batch)
     auto ready = [&](RecV& V, auto behind, Rec4& R) {
         if constexpr (decltype(behind)::value == 9)
@@ -1020,7 +1058,11 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, GSR_EXP_LB) 
         for (int u = 0; u < RB; ++u) {
             R.a[u][0] = V.q0[u].x; R.a[u][1] = V.q0[u].y; R.a[u][2] = V.q0[u].z; R.a[u][3] = V.q0[u].w;
             R.a[u][4] = V.q1[u].x; R.a[u][5] = V.q1[u].y; R.a[u][6] = V.q1[u].z; R.a[u][7] = V.q1[u].w;
+#ifdef GSR_EXP_HI_TEST
             R.cbl[u] = V.q2[u].x; R.hi[u] = V.q2[u].y;
+#else
+            R.cbl[u] = V.q2[u]; R.hi[u] = 0.0f;
+#endif
         }
     };
     using Behind9 = std::integral_constant<int, 9>;
@@ -1281,13 +1323,13 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, GSR_EXP_LB) 
                     GSR_ISSUE(addr, 0, VA);
                     int k = 0;
                     while (k + 2 * RB <= m) {
-                        GSR_ISSUE(addr, 48 * RB, VB);
+                        GSR_ISSUE(addr, BB, VB);
                         ready(VA, Behind9{}, A);
                         blend4(j0, A, std::false_type{}, Off0{});
-                        GSR_ISSUE(addr, 96 * RB, VA);
+                        GSR_ISSUE(addr, 2 * BB, VA);
                         ready(VB, Behind9{}, B);
                         blend4(j0 + RB, B, std::false_type{}, Off1{});
-                        addr += 96 * RB;
+                        addr += 2 * BB;
                         j0 += 2 * RB;
                         lq -= 2 * RB;
                         k += 2 * RB;
@@ -1298,7 +1340,7 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, GSR_EXP_LB) 
                         j0 += RB;
                         lq -= RB;
                         if (j0 < n) {
-                            GSR_ISSUE(addr, 48 * RB, VB);
+                            GSR_ISSUE(addr, BB, VB);
                             ready(VB, Behind0{}, B);
                             blend4(j0, B, std::true_type{}, Off0{});
                             j0 += RB;
@@ -1443,6 +1485,7 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, GSR_EXP_LB) 
     bool hand_over = false;   // the walk reached the hand-over chunk with the stream going on
     if (n > 0) {
         gather(0);
+        landed();
         park(0);
         if (n > CH) gather(1);
         bool go = true;
@@ -1473,13 +1516,13 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, GSR_EXP_LB) 
                 return open > TAIL_LANES;
             };
             auto double_batch = [&]() {
-                GSR_ISSUE(addr, 48 * RB, VB);
+                GSR_ISSUE(addr, BB, VB);
                 ready(VA, Behind9{}, A);
                 blend4(j0, A, std::false_type{}, Off0{});
-                GSR_ISSUE(addr, 96 * RB, VA);   // the next double batch's (or the remainder's) first batch; at a chunk's end: one batch past it, unused
+                GSR_ISSUE(addr, 2 * BB, VA);   // the next double batch's (or the remainder's) first batch; at a chunk's end: one batch past it, unused
                 ready(VB, Behind9{}, B);
                 blend4(j0 + RB, B, std::false_type{}, Off1{});
-                addr += 96 * RB;
+                addr += 2 * BB;
                 j0 += 2 * RB;
                 lq -= 2 * RB;
                 k += 2 * RB;
@@ -1495,7 +1538,7 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, GSR_EXP_LB) 
                     j0 += RB;
                     lq -= RB;
                     if (j0 < n) {
-                        GSR_ISSUE(addr, 48 * RB, VB);
+                        GSR_ISSUE(addr, BB, VB);
                         ready(VB, Behind0{}, B);
                         blend4(j0, B, std::true_type{}, Off0{});
                         j0 += RB;
@@ -1506,6 +1549,7 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, GSR_EXP_LB) 
                 }
             }
             if (!go || j0 >= n) break;
+            landed();   // (DIRECT: chunk c + 1 is in its buffer; the gather below goes into the buffer this chunk has just been walked out of)
             park(c + 1);
             if ((c + 2) * CH < n) gather(c + 2);
         }
