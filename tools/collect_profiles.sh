@@ -14,6 +14,7 @@ for W in cfg3 cfg4 cfg5; do
   timeout 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${W}_fetch -- $B --workload $W $S > $OUT/${W}_fetch.log 2>&1
   timeout 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${W}_write -- $B --workload $W $S > $OUT/${W}_write.log 2>&1
   python tools/pmc_per_launch.py $OUT/${TAG}_${W}_pmc_fetch_write_per_launch.json $OUT/${W}_fetch $OUT/${W}_write
+  cp $OUT/${TAG}_${W}_pmc_fetch_write_per_launch.json profiles/   # (this box's copy of the tree: the bench lines below read roofline.traffic from the passes of THESE libraries)
   cp $(ls $OUT/${W}_stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_${W}_kernel_stats.csv
   rm -rf $OUT/${W}_fetch $OUT/${W}_write   # raw per-dispatch tables are large; the summaries are what is kept
   python tools/trace_busy.py $OUT/${W}_stats > $OUT/${TAG}_${W}_busy.json
