@@ -1021,8 +1021,8 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, GSR_EXP_LB) 
     // believes they were written at the issue), and nothing else of this wave is in flight on lgkmcnt inside the loop (no scalar
     // loads, no compiler-made LDS access: the parks sit between chunks, behind a full wait).
     typedef float v4f __attribute__((ext_vector_type(4)));
-    typedef float v2f __attribute__((ext_vector_type(2)));
 #ifdef GSR_EXP_HI_TEST
+    typedef float v2f __attribute__((ext_vector_type(2)));
     typedef v2f q2_t;   // (blue, alpha's upper bound)
 #define GSR_Q2_READ "ds_read_b64"
 #else
