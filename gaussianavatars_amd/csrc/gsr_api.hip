@@ -903,9 +903,16 @@ static int backward_impl(const GsrSettings* settings, int32_t P, int32_t M, cons
 #ifndef GSR_EXP_RP_GRID
 #define GSR_EXP_RP_GRID 3072
 #endif
+#ifndef GSR_RP_WAVES_PER_WG_DEFAULT
+#define GSR_RP_WAVES_PER_WG_DEFAULT 1
+#endif
             int rp_grid = gx * gy * GSR_BWD_SEGMENTS;
             rp_grid = rp_grid < GSR_EXP_RP_GRID ? (rp_grid + 15) / 16 * 16 : GSR_EXP_RP_GRID;   // a multiple of GSR_UNIT_LISTS / 4 workgroups: every list sees the same stride
-            hipLaunchKernelGGL(gsr::k_render_bwd_rp, dim3(rp_grid), dim3(256), 0, stream, ds,
+            // ONE wave per workgroup (round 6): a wave gets about one unit and units differ in cost by the half-rows that reach them (1 .. 16); in a
+            // workgroup of four the slot of a finished wave stays taken until the slowest of the four is done
+            static const int rp_waves = [] { const char* e = getenv("GSR_RP_WAVES_PER_WG"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 || v == 4 ? v : GSR_RP_WAVES_PER_WG_DEFAULT; }();
+            auto* const rp_k = rp_waves == 1 ? &gsr::k_render_bwd_rp<1> : (rp_waves == 2 ? &gsr::k_render_bwd_rp<2> : &gsr::k_render_bwd_rp<4>);
+            hipLaunchKernelGGL(rp_k, dim3(rp_grid * (4 / rp_waves)), dim3(64 * rp_waves), 0, stream, ds,
                                (const uint32_t*)(b + bl.qstart), (const uint32_t*)(b + bl.qcount), (const float4*)(g + gl.grec), (const uint32_t*)(b + bl.qpos),
                                (const float*)(im + il.final_T), (const uint32_t*)(im + il.n_contrib_q), dL_dpix, grad_scratch,
                                (const float*)(im + il.c_final), (const float4*)(im + il.ck), gx * gy,

@@ -381,7 +381,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifdef GSR_EXP_RP_WAVES
 __attribute__((amdgpu_waves_per_eu(GSR_EXP_RP_WAVES, GSR_EXP_RP_WAVES)))
 #endif
-__global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_t* __restrict__ qstart,
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_render_bwd_rp(Settings s, const uint32_t* __restrict__ qstart,
                                                         const uint32_t* __restrict__ qcount, const float4* __restrict__ grec,
                                                         const uint32_t* __restrict__ qpos, const float* __restrict__ final_T,
                                                         const uint32_t* __restrict__ n_contrib_q, const float* __restrict__ dL_dpix,
@@ -390,8 +391,8 @@ __global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_
                                                         const unsigned long long* __restrict__ total_dev, const uint32_t* __restrict__ units)
 {
     if (*total_dev > capacity) return;
-    __shared__ __attribute__((aligned(16))) float tab_all[4][32 * 12];   // per wave: the pixel table (below)
-    __shared__ float xpose_all[4][64 * 9];                                // per wave: the nine sums of every lane on their way out
+    __shared__ __attribute__((aligned(16))) float tab_all[WPB][32 * 12];   // per wave: the pixel table (below)
+    __shared__ float xpose_all[WPB][64 * 9];                                // per wave: the nine sums of every lane on their way out
     constexpr int CH = GSR_BWD_SEGMENT;          // records per chunk = lanes in use (60 of 64)
     static_assert(CH <= 64 && CH > 32, "a chunk of the stream has to fit the wave");
     const int W = s.W, H = s.H;
@@ -401,15 +402,23 @@ __global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_
     // ---- the wave's UNITS (gsr.h: GsrImageLayout.units): entries p, p + stride, ... of list (wave id mod GSR_UNIT_LISTS); every unit is a
     // (tile, quadrant, segment) the forward found a contributor in, so a wave that gets one has work (round 3 launched a workgroup per (tile,
     // segment): four of five found nothing, and the waves of the others were tied to the four quadrants whether those reached the segment or not)
-    const uint32_t wid = (uint32_t)blockIdx.x * 4u + (uint32_t)wave_in_wg, list = wid % (uint32_t)GSR_UNIT_LISTS;
-    const uint32_t ustride = (uint32_t)gridDim.x * 4u / (uint32_t)GSR_UNIT_LISTS;
+    // (the waves of a workgroup share nothing: the launch decides how many there are -- gsr_api.hip)
+    constexpr uint32_t wpb = (uint32_t)WPB;
+    const uint32_t wid = (uint32_t)blockIdx.x * wpb + (uint32_t)wave_in_wg, list = wid % (uint32_t)GSR_UNIT_LISTS;
+    const uint32_t ustride = (uint32_t)gridDim.x * wpb / (uint32_t)GSR_UNIT_LISTS;
     const uint32_t ucap = (4u * (uint32_t)tiles + GSR_UNIT_LISTS - 1u) / GSR_UNIT_LISTS * (uint32_t)GSR_BWD_SEGMENTS;
     const uint32_t ucount = min(units[32u * list], ucap);
     const uint32_t* __restrict__ ulist = units + 32u * GSR_UNIT_LISTS + list * ucap;
     float* const tab = tab_all[wave_in_wg];
     float* const xs = xpose_all[wave_in_wg];
     for (uint32_t up = wid / (uint32_t)GSR_UNIT_LISTS; up < ucount; up += ustride) {
+    // (from the END of the list: the forward appends a quadrant's units when its walk is over, so the deep quadrants -- whose open-ended last segment
+    //  is many chunks for one wave -- come last in the list; taken first they are not the kernel's tail: template-like frame 109.8 -> see DESIGN.md 7.6)
+#ifndef GSR_EXP_RP_FORWARD_ORDER
+    const uint32_t unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)ulist[ucount - 1u - up]);
+#else
     const uint32_t unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)ulist[up]);
+#endif
     const int seg = (int)(unit & 15u), wave = (int)((unit >> 4) & 3u), tile = (int)(unit >> 6);   // `wave`: the quadrant
     const int tile_x = tile % gx, tile_y = tile / gx;
     const int nq = (int)qcount[4 * tile + wave];
@@ -601,6 +610,13 @@ __global__ __launch_bounds__(256) void k_render_bwd_rp(Settings s, const uint32_
     }
     }   // units
 }
+
+template __global__ void k_render_bwd_rp<1>(Settings, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const float*, const uint32_t*, const float*, float*, const float*,
+                                             const float4*, int, unsigned long long, const unsigned long long*, const uint32_t*);
+template __global__ void k_render_bwd_rp<2>(Settings, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const float*, const uint32_t*, const float*, float*, const float*,
+                                             const float4*, int, unsigned long long, const unsigned long long*, const uint32_t*);
+template __global__ void k_render_bwd_rp<4>(Settings, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const float*, const uint32_t*, const float*, float*, const float*,
+                                             const float4*, int, unsigned long long, const unsigned long long*, const uint32_t*);
 
 // ------------------------------------------------------------------------------------------
 

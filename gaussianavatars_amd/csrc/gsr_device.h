@@ -608,6 +608,7 @@ __global__ void k_render_bwd(Settings s, const uint32_t* tile_order, const uint3
                              const uint32_t* qpos, const float* final_T,
                              const uint32_t* n_contrib_q, const float* dL_dpix, float* acc, const float* c_final, const float4* ck, int tiles,
                              long long* acc64, const uint32_t* gmax, unsigned long long capacity, const unsigned long long* total_dev);
+template <int WPB>   // waves per workgroup (they share nothing; the LDS tables are per wave)
 __global__ void k_render_bwd_rp(Settings s, const uint32_t* qstart, const uint32_t* qcount, const float4* grec,
                                 const uint32_t* qpos, const float* final_T, const uint32_t* n_contrib_q, const float* dL_dpix, float* acc,
                                 const float* c_final, const float4* ck, int tiles, unsigned long long capacity, const unsigned long long* total_dev,
