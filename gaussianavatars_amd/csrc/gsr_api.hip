@@ -773,7 +773,12 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         const bool conts = ds.fast_blend && ds.cont_chunks > 0;
         if (!conts) ds.cont_chunks = 0;
         auto* const render_k = !ds.fast_blend ? &gsr::k_render<false, 0> : (conts && ds.cont_mode == 1 ? &gsr::k_render<true, 1> : &gsr::k_render<true, 0>);
-        hipLaunchKernelGGL(render_k, dim3(tiles + (conts && ds.cont_mode == 1 ? cgrid : 0)), dim3(256), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
+#ifndef GSR_EXP_NO_SOLO
+        const bool solo = !(conts && ds.cont_mode == 1);   // (k_render<., 0>: one wave per workgroup, four workgroups per tile -- gsr_forward.hip)
+#else
+        const bool solo = false;
+#endif
+        hipLaunchKernelGGL(render_k, solo ? dim3(4 * tiles) : dim3(tiles + cgrid), dim3(solo ? 64 : 256), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
                            (const uint32_t*)qcount, (const float4*)pa.grec, (const uint32_t*)qpos, write_lists ? (const uint32_t*)qlist : nullptr, (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib),
                            (uint32_t*)(im + il.n_contrib_q), (float*)(im + il.c_final), (float4*)(im + il.ck), out_color, cap,
                            (const unsigned long long*)total_dev, (uint32_t*)(im + il.units), tiles);

@@ -820,11 +820,16 @@ extern "C" int gsr_debug_read_fwd(unsigned long long* host, int n) { return (int
 #ifndef GSR_CONT_WAVES
 #define GSR_CONT_WAVES 8   // waves of a workgroup of the continuation KERNEL (CONT == 2) = chunks of a quadrant in flight
 #endif
+#ifndef GSR_EXP_NO_SOLO
+#define GSR_SOLO_THREADS 64
+#else
+#define GSR_SOLO_THREADS 256
+#endif
 template <bool FAST, int CONT>
 #ifndef GSR_EXP_LB
 #define GSR_EXP_LB (CONT == 1 ? 5 : 1)   // (only the instance that carries the continuation workgroups needs its register budget capped: their body would take the tiles' walks from five waves per SIMD to four)
 #endif
-__global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, GSR_EXP_LB) void k_render(Settings s, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ qstart,
+__global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : (CONT == 0 ? GSR_SOLO_THREADS : 256), GSR_EXP_LB) void k_render(Settings s, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ qstart,
                                                  const uint32_t* __restrict__ qcount,
                                                  const float4* __restrict__ grec, const uint32_t* __restrict__ qpos,
                                                  const uint32_t* __restrict__ qlist, float* __restrict__ final_T,
@@ -848,14 +853,22 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, GSR_EXP_LB) 
     uint32_t* const cont_list = cont_hdr + GSR_CONT_HDR_WORDS;
     float* const cont_state = reinterpret_cast<float*>(cont_list + 4 * (size_t)tiles);
     const int cont_c = (FAST && s.cont_chunks > 0) ? s.cont_chunks : 0x7fffffff;   // the chunk a lone walk hands over at
-    const int pwave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // this wave inside its workgroup
+    // SOLO (round 6, the instances without continuation code): ONE wave per workgroup, workgroup 4 p + q = quadrant q of the tile at launch position p.
+    // A tile's four quadrant walks share nothing; as four waves of one workgroup the slots of the three that finish first stay taken until the
+    // deepest is done.
+#ifndef GSR_EXP_NO_SOLO
+    constexpr bool SOLO = CONT == 0;
+#else
+    constexpr bool SOLO = false;
+#endif
+    const int pwave = SOLO ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // this wave inside its workgroup
     const int lane = threadIdx.x & 63;
     // per QUADRANT (k_render: once; the continuation kernel: once per pulled quadrant)
     const bool helper = CONT == 2 || (CONT == 1 && blockIdx.x >= (uint32_t)tiles);   // a continuation workgroup (below): no tile of its own
-    uint32_t lpos = blockIdx.x;                                  // the tile's position in the launch order
-    int tile = helper ? 0 : (int)tile_order[blockIdx.x];
+    uint32_t lpos = SOLO ? blockIdx.x >> 2 : blockIdx.x;         // the tile's position in the launch order
+    int tile = helper ? 0 : (int)tile_order[lpos];
     int tile_x = tile % gx, tile_y = tile / gx;
-    int wave = pwave;                                            // the QUADRANT this wave blends (CONT: all four waves the same one)
+    int wave = SOLO ? (int)(blockIdx.x & 3u) : pwave;            // the QUADRANT this wave blends (CONT: all four waves the same one)
     int pxi = tile_x * GSR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
     int pyi = tile_y * GSR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
     bool inside = pxi < W && pyi < H;
@@ -967,7 +980,7 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, GSR_EXP_LB) 
     // Chunks are the backward's segments: the checkpoint test sits at the chunk boundary.
     constexpr int CH = GSR_BWD_SEGMENT;
     static_assert(CH <= GSR_WAVE && CH % (2 * RB) == 0, "a chunk is one gather of the wave and a whole number of double batches");
-    constexpr int NWV = CONT == 2 ? GSR_CONT_WAVES : 4;   // waves per workgroup
+    constexpr int NWV = CONT == 2 ? GSR_CONT_WAVES : (SOLO ? 1 : 4);   // waves per workgroup
     // DIRECT (round 6, the instances without continuation code): the gather goes straight into LDS (global_load_lds_dwordx4: lane l's 16 bytes land at
     // base + 16 l, so a chunk is staged as three planes of 64 float4 -- part k of record j at [64 k + j]) instead of through twelve vector
     // registers that stay live across the whole walk of the chunk before; nothing is parked.
@@ -1657,8 +1670,8 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : 256, GSR_EXP_LB) 
         }
     }
 #ifdef GSR_EXPERIMENT_TIMELINE
-    if (lane == 0 && (size_t)blockIdx.x * 4 + wave < 16384) {
-        unsigned long long* d = gsr_dbg_fwd + 4 * ((size_t)blockIdx.x * 4 + wave);
+    if (lane == 0 && (size_t)lpos * 4 + wave < 16384) {
+        unsigned long long* d = gsr_dbg_fwd + 4 * ((size_t)lpos * 4 + wave);
         d[0] = t_start;
         d[1] = wall_clock64();
         d[2] = ((unsigned long long)(uint32_t)n << 32) | (uint32_t)j_main;
