@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of bench.py under the caller's environment, printing the rows whose kernel name matches PATTERN:
 #   GSR_CONT_CHUNKS=3 bash tools/kstat_env.sh TAG k_render [bench args]        (on the GPU box; the A/B tables of profiles/r06_exp_*.txt)
-TAG=$1; PATTERN=$2; shift 2
+TAG=$(echo "$1" | tr -c "A-Za-z0-9_\n" "_"); PATTERN=$2; shift 2
 OUT=$GRAFT_REPO_ROOT/gpurun_out/ks_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
