@@ -220,9 +220,9 @@ typedef struct GsrImageLayout {
                           backward's WORK LIST.  A wave of the forward blend knows how deep its quadrant's last contributor sits and appends
                           one unit tile << 6 | quadrant << 4 | segment per 60-entry segment the backward has to walk to list (launch position
                           of the wave) mod GSR_UNIT_LISTS: the counters first (word 32 l = list l's, a 128-byte line each; zeroed by the frame's first kernel), then the lists, `cap` slots
-                          each (the mapping wave -> list is static, so `cap` cannot overflow).  The backward's waves take the units of list
-                          (wave id mod GSR_UNIT_LISTS) in turn: no workgroup is launched for a (tile, segment) pair nothing reaches -- four of
-                          five were, round 3 -- and a workgroup's four waves all carry work.  Behind the lists (round 6, GSR_CONT_CHUNKS > 0 only):
+                          each (the mapping wave -> list is static, so `cap` cannot overflow).  The backward's waves (one-wave workgroups, round 6) take the units of list
+                          (wave id mod GSR_UNIT_LISTS) in turn, from the list's END -- the deep quadrants are appended last and would be the kernel's tail --: no
+                          wave is launched for a (tile, segment) pair nothing reaches (four of five workgroups were, round 3).  Behind the lists (round 6, GSR_CONT_CHUNKS > 0 only):
                           the forward blend's continuation area -- counters, the list of quadrants whose walk was parked at entry
                           GSR_CONT_CHUNKS * GSR_BWD_SEGMENT, 1280 bytes of parked state per quadrant (csrc/gsr_forward.hip: k_render<true, 1 / 2>)  */
     size_t total;
