@@ -772,7 +772,9 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         const int cgrid = 4 * tiles < cont_grid ? 4 * tiles : cont_grid;
         const bool conts = ds.fast_blend && ds.cont_chunks > 0;
         if (!conts) ds.cont_chunks = 0;
-        auto* const render_k = !ds.fast_blend ? &gsr::k_render<false, 0> : (conts && ds.cont_mode == 1 ? &gsr::k_render<true, 1> : &gsr::k_render<true, 0>);
+        const bool infer = ds.forward_only && !conts;   // (torch.no_grad() / fps benchmarks: the instances without the backward's bookkeeping)
+        auto* const render_k = !ds.fast_blend ? (infer ? &gsr::k_render<false, 0, true> : &gsr::k_render<false, 0, false>)
+                               : (conts && ds.cont_mode == 1 ? &gsr::k_render<true, 1, false> : (infer ? &gsr::k_render<true, 0, true> : &gsr::k_render<true, 0, false>));
 #ifndef GSR_EXP_NO_SOLO
         const bool solo = !(conts && ds.cont_mode == 1);   // (k_render<., 0>: one wave per workgroup, four workgroups per tile -- gsr_forward.hip)
 #else
@@ -784,7 +786,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
                            (const unsigned long long*)total_dev, (uint32_t*)(im + il.units), tiles);
         KERNEL_CHECK("k_render", stream, dbg);
         if (conts && ds.cont_mode == 2) {
-            hipLaunchKernelGGL((gsr::k_render<true, 2>), dim3(cgrid), dim3(64 * GSR_CONT_WAVES), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
+            hipLaunchKernelGGL((gsr::k_render<true, 2, false>), dim3(cgrid), dim3(64 * GSR_CONT_WAVES), 0, stream, ds, (const uint32_t*)tile_order, (const uint32_t*)qstart,
                                (const uint32_t*)qcount, (const float4*)pa.grec, (const uint32_t*)qpos, write_lists ? (const uint32_t*)qlist : nullptr, (float*)(im + il.final_T), (uint32_t*)(im + il.n_contrib),
                                (uint32_t*)(im + il.n_contrib_q), (float*)(im + il.c_final), (float4*)(im + il.ck), out_color, cap,
                                (const unsigned long long*)total_dev, (uint32_t*)(im + il.units), tiles);

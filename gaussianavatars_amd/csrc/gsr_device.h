@@ -580,7 +580,7 @@ template <int KEYS, int THREADS>
 __global__ void k_tile_sort(uint32_t n_lo, uint32_t n_hi, int gx, const uint32_t* tile_order, const uint32_t* tile_count, const uint32_t* tile_start, unsigned long long* keys,
                             uint32_t* point_list, uint32_t* qlist, uint32_t* qpos, uint32_t* qcount, uint32_t* qstart, const float4* grec,
                             unsigned long long capacity, const unsigned long long* total_dev);
-template <bool FAST, int CONT>   // CONT: 0 tiles only (fast blend: parks deep quadrants for <true, 2> when s.cont_chunks > 0), 1 tiles + waiting continuation workgroups in one grid, 2 the continuation kernel
+template <bool FAST, int CONT, bool INFER>   // INFER: forward_only frames (no last-contributor bookkeeping); CONT: 0 tiles only (fast blend: parks deep quadrants for <true, 2> when s.cont_chunks > 0), 1 tiles + waiting continuation workgroups in one grid, 2 the continuation kernel
 __global__ void k_render(Settings s, const uint32_t* tile_order, const uint32_t* qstart, const uint32_t* qcount, const float4* grec,
                          const uint32_t* qpos, const uint32_t* qlist, float* final_T,
                          uint32_t* n_contrib, uint32_t* n_contrib_q, float* c_final, float4* ck, float* out_color, unsigned long long capacity,

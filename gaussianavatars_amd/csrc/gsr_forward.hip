@@ -825,7 +825,7 @@ extern "C" int gsr_debug_read_fwd(unsigned long long* host, int n) { return (int
 #else
 #define GSR_SOLO_THREADS 256
 #endif
-template <bool FAST, int CONT>
+template <bool FAST, int CONT, bool INFER>   // INFER: the instance for frames no backward can follow (GsrSettings.forward_only): no last-contributor bookkeeping in the walk
 #ifndef GSR_EXP_LB
 #define GSR_EXP_LB (CONT == 1 ? 5 : 1)   // (only the instance that carries the continuation workgroups needs its register budget capped: their body would take the tiles' walks from five waves per SIMD to four)
 #endif
@@ -839,6 +839,8 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : (CONT == 0 ? GSR_
                                                  const unsigned long long* __restrict__ total_dev, uint32_t* __restrict__ units, int tiles)
 {
     static_assert(FAST || CONT == 0, "continuations belong to the fast blend");
+    static_assert(!INFER || CONT == 0, "the inference instances carry no continuation code");
+    const bool fwd_only = INFER || s.forward_only;
     if (*total_dev > capacity) return;
 #ifdef GSR_EXPERIMENT_TIMELINE
     const unsigned long long t_start = wall_clock64();
@@ -962,7 +964,7 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : (CONT == 0 ? GSR_
                 C2 = C2 + R.cbl[u] * ae * Tw;
             }
             Tw = keep ? test_T : -__builtin_fabsf(Tw);
-            lq = ((int)keep & (int)ok[u]) ? OFF + u + 1 : lq;   // (&, not &&: with the short-circuit form the compiler kept a branch per record once the closing select carried source modifiers)
+            if constexpr (!INFER) lq = ((int)keep & (int)ok[u]) ? OFF + u + 1 : lq;   // (&, not &&: with the short-circuit form the compiler kept a branch per record once the closing select carried source modifiers)
         }
     };
     using Off0 = std::integral_constant<int, 0>;
@@ -1162,7 +1164,7 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : (CONT == 0 ? GSR_
                 if (lane == pp[e]) {
                     Tw = closed ? -Tlast : Tlast;
                     C0 += A0; C1 += A1; C2 += A2;
-                    if (hits[e]) last_q = (uint32_t)(c0 + 64 - __builtin_clzll(hits[e]));
+                    if (!INFER && hits[e]) last_q = (uint32_t)(c0 + 64 - __builtin_clzll(hits[e]));
                 }
                 if (closed) closed_mask |= 1ull << pp[e];
             }
@@ -1172,7 +1174,7 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : (CONT == 0 ? GSR_
 
     // ---- the end of a quadrant: the backward's work units, the per-pixel state the backward reads, the image ---------------------------
     auto finish = [&]() {
-        if (FAST && !s.forward_only) {
+        if (FAST && !fwd_only) {
             // the backward's work list (gsr.h: GsrImageLayout.units): one unit per 60-entry segment up to this quadrant's deepest last
             // contributor, appended to the list of this quadrant's launch position (one returning atomic per wave, spread over 64 counters)
             const uint32_t qmax = wave_max_u32(inside ? last_q : 0u);
@@ -1191,7 +1193,7 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : (CONT == 0 ? GSR_
             // the reference's n_contrib counts positions in the TILE list: the parity modes keep those in a twin stream; in
             // production it is the position in the quadrant stream (nothing reads it: the backward walks n_contrib_q)
             const size_t HW = (size_t)H * W;
-            if (!s.forward_only) {   // what only the backward reads: 24 bytes per pixel (and the checkpoints above) less to store under torch.no_grad()
+            if (!fwd_only) {   // what only the backward reads: 24 bytes per pixel (and the checkpoints above) less to store under torch.no_grad()
                 const uint32_t last_contributor = !qlist ? last_q : (last_q ? (qlist + qs)[last_q - 1] + 1u : 0u);
                 final_T[pix_id] = __builtin_fabsf(Tw);
                 n_contrib[pix_id] = last_contributor;
@@ -1385,7 +1387,7 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : (CONT == 0 ? GSR_
                         s_hand[4][lane] = __uint_as_float(hit > (uint32_t)(c * CH) ? hit : lqp);
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) __hip_atomic_store(&s_seq, (uint32_t)(c + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (!s.forward_only && c + 1 <= GSR_BWD_SEGMENTS - 1 && inside && thru)   // (the backward reads a checkpoint only where the pixel goes on)
+                        if (!fwd_only && c + 1 <= GSR_BWD_SEGMENTS - 1 && inside && thru)   // (the backward reads a checkpoint only where the pixel goes on)
                             ck[(size_t)c * HWc + pix_id] = make_float4(Tt, __builtin_fmaf(Tp, L0, P0), __builtin_fmaf(Tp, L1, P1), __builtin_fmaf(Tp, L2, P2));
                     }
                     Tw = thru ? Tt : Tp;
@@ -1412,7 +1414,7 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : (CONT == 0 ? GSR_
                     if (((open_before & ~myopen) >> lane) & 1ull) to_fin();   // closed in this chunk
                     last = myopen == 0ull || c == nchunks - 1;
                     if (!last) {
-                        if (!s.forward_only && c + 1 <= GSR_BWD_SEGMENTS - 1 && inside)
+                        if (!fwd_only && c + 1 <= GSR_BWD_SEGMENTS - 1 && inside)
                             ck[(size_t)c * HWc + pix_id] = make_float4(__builtin_fabsf(Tw), C0, C1, C2);
                         s_hand[0][lane] = Tw; s_hand[1][lane] = C0; s_hand[2][lane] = C1; s_hand[3][lane] = C2; s_hand[4][lane] = __uint_as_float(last_q);
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1455,7 +1457,7 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : (CONT == 0 ? GSR_
     const size_t HWs = (size_t)H * W;
     float4* ck_ptr = ck + (inside ? (size_t)(W * pyi + pxi) : (size_t)(GSR_BWD_SEGMENTS - 1) * HWs);
     const size_t ck_step = inside ? HWs : 0;
-    int next_ck = s.forward_only ? 0x7fffffff : GSR_BWD_SEGMENT;   // (forward_only: no backward will read a checkpoint -- the test below never fires)
+    int next_ck = fwd_only ? 0x7fffffff : GSR_BWD_SEGMENT;   // (forward_only: no backward will read a checkpoint -- the test below never fires)
     auto checkpoint = [&](int jtop) {
         if (jtop == next_ck) {
             if (next_ck <= (GSR_BWD_SEGMENTS - 1) * GSR_BWD_SEGMENT) {
@@ -1621,7 +1623,7 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : (CONT == 0 ? GSR_
             uint32_t lastqp = (uint32_t)__builtin_amdgcn_readlane((int)last_q, p);
             bool donep = false;
             int e_ck = next_ck;                               // this pixel's next checkpoint (the main loop stored the earlier ones)
-            float4* at_ck = ck + (size_t)((s.forward_only ? GSR_BWD_SEGMENT : e_ck) / GSR_BWD_SEGMENT - 1) * HWs + (size_t)(W * (int)ppy + (int)ppx);
+            float4* at_ck = ck + (size_t)((fwd_only ? GSR_BWD_SEGMENT : e_ck) / GSR_BWD_SEGMENT - 1) * HWs + (size_t)(W * (int)ppy + (int)ppx);
             for (int c0 = j0; c0 < n && !donep; c0 += GSR_WAVE) {
                 const int j = c0 + lane;
                 const bool valid = j < n;
@@ -1683,14 +1685,18 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : (CONT == 0 ? GSR_
     }   // (a tile's workgroup)
 }
 
-template __global__ void k_render<false, 0>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
+template __global__ void k_render<false, 0, false>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
                                                 uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*, int);
-template __global__ void k_render<true, 0>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
-                                               uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*, int);
-template __global__ void k_render<true, 2>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
-                                           uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*, int);
-template __global__ void k_render<true, 1>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
-                                           uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*, int);
+template __global__ void k_render<true, 0, false>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
+                                                uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*, int);
+template __global__ void k_render<true, 2, false>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
+                                                uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*, int);
+template __global__ void k_render<true, 1, false>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
+                                                uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*, int);
+template __global__ void k_render<false, 0, true>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
+                                                uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*, int);
+template __global__ void k_render<true, 0, true>(Settings, const uint32_t*, const uint32_t*, const uint32_t*, const float4*, const uint32_t*, const uint32_t*, float*, uint32_t*,
+                                                uint32_t*, float*, float4*, float*, unsigned long long, const unsigned long long*, uint32_t*, int);
 
 // ------------------------------------------------------------------------------------------
 // k_mark_visible (upstream checkFrustum): present = view z > 0.2
