@@ -948,23 +948,43 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : (CONT == 0 ? GSR_
             if (decltype(masked)::value) ok[u] = ok[u] && (jb + u) < n;
             alpha[u] = ok[u] ? a : 0.0f;
         }
+        if constexpr (FAST) {
+            // (the colour sums of record u are issued between record u + 1's acceptance compare and the selects that read its mask: a VALU
+            //  instruction that reads an SGPR pair as a mask needs two wait states behind the compare that wrote it -- left in source order the
+            //  compiler fills them with s_nop, one issue slot per record)
+            float wprev = 0.0f;
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const float test_T = FAST ? __builtin_fmaf(-alpha[u], Tw, Tw) : Tw * (1.0f - alpha[u]);      // alpha == 0 (skipped record): exactly Tw, accepted, nothing changes
-            const bool keep = test_T >= 0.0001f;              // false at the record that saturates the pixel, and forever after
-            const float ae = keep ? alpha[u] : 0.0f;          // adding (c * 0) * T == +0 leaves C bit-identical: no selects on C
-            if constexpr (FAST) {
-                const float wgt = ae * Tw;
-                C0 = __builtin_fmaf(R.a[u][6], wgt, C0);
-                C1 = __builtin_fmaf(R.a[u][7], wgt, C1);
-                C2 = __builtin_fmaf(R.cbl[u], wgt, C2);
-            } else {
+            for (int u = 0; u < RB; ++u) {
+                const float test_T = __builtin_fmaf(-alpha[u], Tw, Tw);   // alpha == 0 (skipped record): exactly Tw, accepted, nothing changes
+                const bool keep = test_T >= 0.0001f;                       // false at the record that saturates the pixel, and forever after
+                if (u > 0) {
+                    C0 = __builtin_fmaf(R.a[u - 1][6], wprev, C0);
+                    C1 = __builtin_fmaf(R.a[u - 1][7], wprev, C1);
+                    C2 = __builtin_fmaf(R.cbl[u - 1], wprev, C2);
+                }
+#ifdef GSR_EXP_SCHED_BARRIER
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                const float ae = keep ? alpha[u] : 0.0f;                   // adding (c * 0) * T == +0 leaves C bit-identical: no selects on C
+                wprev = ae * Tw;
+                Tw = keep ? test_T : -__builtin_fabsf(Tw);
+                if constexpr (!INFER) lq = ((int)keep & (int)ok[u]) ? OFF + u + 1 : lq;   // (&, not &&: with the short-circuit form the compiler kept a branch per record once the closing select carried source modifiers)
+            }
+            C0 = __builtin_fmaf(R.a[RB - 1][6], wprev, C0);
+            C1 = __builtin_fmaf(R.a[RB - 1][7], wprev, C1);
+            C2 = __builtin_fmaf(R.cbl[RB - 1], wprev, C2);
+        } else {
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const float test_T = Tw * (1.0f - alpha[u]);
+                const bool keep = test_T >= 0.0001f;
+                const float ae = keep ? alpha[u] : 0.0f;
                 C0 = C0 + R.a[u][6] * ae * Tw;
                 C1 = C1 + R.a[u][7] * ae * Tw;
                 C2 = C2 + R.cbl[u] * ae * Tw;
+                Tw = keep ? test_T : -__builtin_fabsf(Tw);
+                if constexpr (!INFER) lq = ((int)keep & (int)ok[u]) ? OFF + u + 1 : lq;
             }
-            Tw = keep ? test_T : -__builtin_fabsf(Tw);
-            if constexpr (!INFER) lq = ((int)keep & (int)ok[u]) ? OFF + u + 1 : lq;   // (&, not &&: with the short-circuit form the compiler kept a branch per record once the closing select carried source modifiers)
         }
     };
     using Off0 = std::integral_constant<int, 0>;

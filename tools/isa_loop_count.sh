@@ -10,8 +10,8 @@ set -eu
 which=${1:-forward}
 here=$(cd "$(dirname "$0")/../gaussianavatars_amd/csrc" && pwd)
 case "$which" in
-  forward)       src=gsr_forward.hip;  fp=off;  kern=_ZN3gsr8k_renderILb0ELi0EE;            r=${2:-6};;
-  forward_fast)  src=gsr_forward.hip;  fp=off;  kern=_ZN3gsr8k_renderILb1ELi0EE;            r=${2:-6};;   # GsrSettings.fast_blend
+  forward)       src=gsr_forward.hip;  fp=off;  kern=_ZN3gsr8k_renderILb0ELi0ELb0EE;            r=${2:-6};;
+  forward_fast)  src=gsr_forward.hip;  fp=off;  kern=_ZN3gsr8k_renderILb1ELi0ELb0EE;            r=${2:-6};;   # GsrSettings.fast_blend
   backward)      src=gsr_backward.hip; fp=fast; kern=_ZN3gsr12k_render_bwdILb0ELb0EE;   r=${2:-4};;
   backward_fast) src=gsr_backward.hip; fp=fast; kern=_ZN3gsr12k_render_bwdILb0ELb1EE;   r=${2:-4};;
   *) echo "forward | forward_fast | backward | backward_fast"; exit 2;;
