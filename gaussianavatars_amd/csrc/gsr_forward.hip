@@ -1529,13 +1529,6 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : (CONT == 0 ? GSR_
             const int m = min(CH, n - c * CH);   // records of this chunk
             checkpoint(j0);                      // j0 == c * CH: the state before the chunk's first entry
             if (FAST && c == cont_c) { hand_over = true; break; }
-#ifdef GSR_EXP_PRIO
-            // the kernel ends when its deepest walk ends: a walk that has come this far is one of the few hundred that decide it -- let it win issue
-            // arbitration over the shallow walks it shares its SIMD with (stream LENGTH says little about this: half of cfg3's streams hold > 600 entries)
-            if (c == GSR_EXP_PRIO) __builtin_amdgcn_s_setprio(1);
-            else if (c == 2 * GSR_EXP_PRIO) __builtin_amdgcn_s_setprio(2);
-            else if (c == 3 * GSR_EXP_PRIO) __builtin_amdgcn_s_setprio(3);
-#endif
             RecV VA, VB;
             Rec4 A, B;
             uint32_t addr = b ? lds1 : lds0;
