@@ -962,9 +962,6 @@ __global__ __launch_bounds__(CONT == 2 ? 64 * GSR_CONT_WAVES : (CONT == 0 ? GSR_
                     C1 = __builtin_fmaf(R.a[u - 1][7], wprev, C1);
                     C2 = __builtin_fmaf(R.cbl[u - 1], wprev, C2);
                 }
-#ifdef GSR_EXP_SCHED_BARRIER
-                __builtin_amdgcn_sched_barrier(0);
-#endif
                 const float ae = keep ? alpha[u] : 0.0f;                   // adding (c * 0) * T == +0 leaves C bit-identical: no selects on C
                 wprev = ae * Tw;
                 Tw = keep ? test_T : -__builtin_fabsf(Tw);
