@@ -370,7 +370,7 @@ int gsr_binning_layout(int64_t capacity, int32_t width, int32_t height, int32_t 
     o->bandcnt = off;     off = align_up(off + (bands ? nbands * nwc * 4 : 0), A);
     o->srect = off;       off = align_up(off + (rankp ? n * 8 : 0), A);
     o->sspan = off;       off = align_up(off + (rankp ? n * 32 : 0), A);
-    o->pstat = off;       off = align_up(off + (rankp ? ((n + 255) / 256) * 16 : 0), A);
+    o->pstat = off;       off = align_up(off + (rankp ? ((n + 255) / 256) * 80 + (GSR_RANK_BLOCKS + 4) * 4 : 0), A);   // (stats, four planes of group sums, k_rcount's chunk boundaries)
     o->tdesc = off;       off = align_up(off + (rankp ? tiles * 16 : 0), A);
     o->path = (size_t)path;
     o->chunks = chunks;
@@ -535,6 +535,14 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         const int ilv = rank_ilv_for(dev_id, settings->image_width, settings->image_height);   // 0: contiguous, else a group size (rounded down to a power of two)
         rank_ilv = -1;
         for (int v = ilv; v > 0; v >>= 1) ++rank_ilv;                                                // log2, -1 for contiguous
+        // ... and on frames of one band the answer to an uneven spread is not the interleave but contiguous chunks of equal WEIGHT, cut by k_rcount from
+        // k_preprocess's group sums (gsr_device.h: rank_map; round 6): the template-like head's scatter 44 -> 31 us where the interleave had brought it from
+        // 88 to 44, and k_rcount keeps its compact set of tiles.  (It costs k_rcount 3.5 us of prologue, so an even frame keeps its equal-count chunks.)
+        // GSR_RANK_BALANCED=0: the interleave; =2: balanced chunks on every frame (A/B runs)
+        static const int balanced = [] { const char* e = getenv("GSR_RANK_BALANCED"); return e ? atoi(e) : 1; }();
+        static const bool forced_ilv = getenv("GSR_RANK_ILV") != nullptr;
+        const bool can = (long long)P <= (long long)GSR_RANK_MAX_SPLATS && (int)bl.nbands <= 1 && !forced_ilv;
+        if (can && ((balanced == 1 && ilv > 0) || balanced == 2)) rank_ilv = -2;
     }
     slot_holds_frame(deferred ? settings->deferred_count - 1 : GSR_COUNT_SLOTS, dev_id, rankp ? settings->image_width : 0, settings->image_height);
     const unsigned long long cap = (unsigned long long)binning_capacity;
@@ -606,6 +614,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
         const uint32_t nb = (uint32_t)bl.nb;
         const int bin_blocks = pblocks < GSR_RANK_BLOCKS ? pblocks : GSR_RANK_BLOCKS;
         const bool direct = gsr::rank_direct(gx, tiles);
+        uint32_t* const chunk_bounds = reinterpret_cast<uint32_t*>((uint4*)(b + bl.pstat) + 5 * (size_t)pblocks);   // behind pstat's rows and the four planes of group sums
         const size_t hist_bytes = direct ? 0 : (size_t)tiles * sizeof(uint32_t);
         const size_t count_lds = (size_t)nb * 4 + (direct ? 0 : (size_t)(gx + 1) * (size_t)(gy + 1) * sizeof(uint32_t));   // corner grid of the tile rects
         if (count_lds > 48 * 1024) {
@@ -650,7 +659,7 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
             TIMED(GSR_K_COUNT, stream);
             hipLaunchKernelGGL(gsr::k_rcount, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), count_lds, stream, rank_ilv, P, gx, tiles,
                                pblocks, nb, (const ushort4*)srect, (const uint32_t*)pa.tiles_touched,
-                               (const float*)pa.depths, (const uint4*)pa.pstat, tile_count, rect_total, block_hist, bcount, bhist, hdr);
+                               (const float*)pa.depths, (const uint4*)pa.pstat, tile_count, rect_total, block_hist, bcount, bhist, hdr, chunk_bounds);
             KERNEL_CHECK("k_rcount", stream, dbg);
         }
         const bool one_band = nbands <= 1;
@@ -663,7 +672,8 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
             ts.post_capacity = post_cap;
             ts.hdr = pblocks > 0 ? hdr : nullptr;   // (P == 0: k_rcount did not run, the header word is not written)
             hipLaunchKernelGGL(gsr::k_rdscatter, dim3((pblocks > 0 ? bin_blocks : 0) + 1), dim3(GSR_RANK_BIN_THREADS), (size_t)nb * 4, stream, rank_ilv, P, nb,
-                               (const ushort4*)srect, (const float*)pa.depths, hdr, (const uint32_t*)bcount, bstart, bcursor, dkeys, (const uint32_t*)bhist, ts);
+                               (const ushort4*)srect, (const float*)pa.depths, hdr, (const uint32_t*)bcount, bstart, bcursor, dkeys, (const uint32_t*)bhist, ts,
+                               (const uint32_t*)chunk_bounds);
             KERNEL_CHECK("k_rdscatter", stream, dbg);
             if (!one_band && pblocks > 0) {
                 // large frames: a rank per (splat, band of tile rows) -- see gsr_rank.hip
@@ -685,12 +695,12 @@ static int forward_impl(const GsrSettings* settings, int32_t P, int32_t M, const
                 hipLaunchKernelGGL(gsr::k_rsort_rscatter, dim3(bin_blocks + nb), dim3(GSR_RANK_BIN_THREADS), scatter_lds, stream, rank_ilv, bin_blocks, P, gx, tiles,
                                    (const ushort4*)srect, (const float4*)pa.sspan, (const uint32_t*)tile_start, tile_cursor, (uint32_t*)ranks, cap,
                                    (const unsigned long long*)total_dev, (const uint32_t*)block_hist, (const uint32_t*)bcount, (const uint32_t*)bstart,
-                                   dkeys, dtmp, rank, stage_off);
+                                   dkeys, dtmp, rank, stage_off, (const uint32_t*)chunk_bounds);
                 KERNEL_CHECK("k_rsort_rscatter", stream, dbg);
             } else {
                 hipLaunchKernelGGL(gsr::k_rscatter<8>, dim3(bin_blocks), dim3(GSR_RANK_BIN_THREADS), scatter_lds, stream, rank_ilv, P, gx, tiles, bt,
                                    (const ushort4*)srect, (const uint32_t*)rank, (const float4*)pa.sspan, (const uint32_t*)tile_start, tile_cursor, ranks, cap,
-                                   (const unsigned long long*)total_dev, (const uint32_t*)block_hist, stage_off);
+                                   (const unsigned long long*)total_dev, (const uint32_t*)block_hist, stage_off, (const uint32_t*)chunk_bounds);
                 KERNEL_CHECK("k_rscatter", stream, dbg);
             }
         }

@@ -531,7 +531,8 @@ struct PreprocessArgs {
     int nb;
     // rank path (gsr_rank.hip); pstat == nullptr otherwise
     uint32_t* __restrict__ bcursor;       // [nb] bucket fill cursors, zeroed here
-    uint4* __restrict__ pstat;            // [workgroups] (min, max) depth bits of this workgroup's visible splats ((~0, 0) when it has none), the tile instances its splats are binned into, 0
+    uint4* __restrict__ pstat;            // [workgroups] (min, max) depth bits of this workgroup's visible splats ((~0, 0) when it has none), the tile instances its splats are binned into, 0;
+                                          // then four planes [workgroups] of uint4: the instance sums of the workgroup's sixteen 16-splat groups (plane q: groups 4 q .. 4 q + 3), then k_rcount's chunk boundaries
     ushort4* __restrict__ srect;          // [P] tile rect the splat is binned into (snug when cull != 0); zero area = not binned
     float4* __restrict__ sspan;           // [P][2] the splat's Span (px, py, B, det | twoTA, A, dyr, mode): operands of the quadrant test
     int cull;                             // settings.tile_culling != 0
@@ -654,11 +655,25 @@ __host__ __device__ inline int rank_splat(int j, int blk, int nblk, int chunk, i
 {
     return ilv_log2 < 0 ? blk * chunk + j : ((((j >> ilv_log2) * nblk + blk) << ilv_log2) | (j & ((1 << ilv_log2) - 1)));
 }
+// BALANCED chunks (round 6, `ilv` == -2: frames of one band): contiguous runs of splats of equal WEIGHT -- tile instances plus GSR_RANK_SPLAT_WEIGHT per splat --
+// cut at groups of 16 splats.  k_preprocess leaves the instance sums of its sixteen 16-splat groups per workgroup behind its pstat rows, k_rcount (every
+// workgroup for itself: <= 1024 rows, one per thread) finds its own two boundaries and leaves them in cb[] for the passes that follow.  The time of a rank
+// pass is its busiest workgroup's instance count: equal splat counts left the busiest at 1.5 x the mean on the ellipsoid head and 10 x on the template-like one.
+#ifndef GSR_RANK_SPLAT_WEIGHT
+#define GSR_RANK_SPLAT_WEIGHT 4
+#endif
+struct RankMap { int chunk, start; };   // start < 0: rank_splat's arithmetic
+__device__ __forceinline__ RankMap rank_map(int P, int nblk, int blk, int ilv, const uint32_t* __restrict__ cb)
+{
+    if (ilv == -2) { const int s0 = (int)cb[blk]; return RankMap{(int)cb[blk + 1] - s0, s0}; }
+    return RankMap{rank_chunk(P, nblk, ilv), -1};
+}
+__device__ __forceinline__ int rank_splat_of(int j, int blk, int nblk, RankMap m, int ilv) { return m.start >= 0 ? m.start + j : rank_splat(j, blk, nblk, m.chunk, ilv); }
 __host__ __device__ inline bool rank_direct(int gx, int tiles) { return (long long)(gx + 1) * (long long)(tiles / gx + 1) > (long long)GSR_RANK_HIST_TILES; }
 #define GSR_RANK_IMBALANCE 3
 __global__ void k_rcount(int ilv, int P, int gx, int tiles, int pblocks, uint32_t nb, const ushort4* srect, const uint32_t* tiles_touched,
                          const float* depths, const uint4* pstat, uint32_t* tile_count, unsigned long long* rect_total, uint32_t* block_hist,
-                         uint32_t* bcount, uint32_t* bhist, BinHeader* hdr);
+                         uint32_t* bcount, uint32_t* bhist, BinHeader* hdr, uint32_t* cb);
 struct TileScanArgs {            // the tile-counter scan that rides in k_rdscatter's last workgroup (gsr_rank.hip: tile_scan_256)
     int tiles;
     const uint32_t* __restrict__ tile_count;
@@ -669,7 +684,7 @@ struct TileScanArgs {            // the tile-counter scan that rides in k_rdscat
     const BinHeader* hdr;        // (chunk_imbalance rides in bit 39 of the posted count)
 };
 __global__ void k_rdscatter(int ilv, int P, uint32_t nb, const ushort4* srect, const float* depths, BinHeader* hdr, const uint32_t* bcount, uint32_t* bstart,
-                            uint32_t* bcursor, unsigned long long* dkeys, const uint32_t* bhist, TileScanArgs ts);
+                            uint32_t* bcursor, unsigned long long* dkeys, const uint32_t* bhist, TileScanArgs ts, const uint32_t* cb);
 // bands of the rank path: 1 (the whole frame) up to GSR_RANK_MAX_SPLATS splats, else bands of *band_rows tile rows
 __host__ __device__ inline int rank_bands(long long P, int gy, bool force, int* band_rows)
 {
@@ -693,11 +708,11 @@ __global__ void k_rdsort(const uint32_t* bcount, const uint32_t* bstart, unsigne
 __global__ void k_rsort_rscatter(int ilv, int scatter_blocks, int P, int gx, int tiles, const ushort4* srect, const float4* sspan, const uint32_t* tile_start,
                                  uint32_t* tile_cursor, uint32_t* entries, unsigned long long capacity, const unsigned long long* total_dev,
                                  const uint32_t* block_hist, const uint32_t* bcount, const uint32_t* bstart, unsigned long long* dkeys,
-                                 unsigned long long* dtmp, uint32_t* rank, int stage_off);
+                                 unsigned long long* dtmp, uint32_t* rank, int stage_off, const uint32_t* cb);
 template <int G>
 __global__ void k_rscatter(int ilv, int P, int gx, int tiles, BandTables bt, const ushort4* srect, const uint32_t* rank, const float4* sspan, const uint32_t* tile_start,
                            uint32_t* tile_cursor, uint2* ranks, unsigned long long capacity, const unsigned long long* total_dev, const uint32_t* block_hist,
-                           int stage_off);
+                           int stage_off, const uint32_t* cb);
 __global__ void k_tile_rank(uint32_t words, int gx, int nbands, float inv_band_rows, const uint4* tdesc, const uint2* ranks, const uint32_t* rank_of,
                             const float* depths, const BinHeader* hdr, unsigned long long* keys, uint32_t* point_list,
                             uint32_t* qlist, uint32_t* qpos, uint32_t* qcount, uint32_t* qstart, unsigned long long capacity,

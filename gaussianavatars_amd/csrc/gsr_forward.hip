@@ -329,7 +329,19 @@ __global__ __launch_bounds__(256) void k_preprocess(Settings s, PreprocessArgs a
         const uint32_t mn_inv = wave_max_u32(visible ? ~dbits : 0u), mx = wave_max_u32(visible ? dbits : 0u);
         const uint32_t wsum = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl_u32(ps_nt), 63);
         if ((threadIdx.x & 63) == 0) { ps_mn[threadIdx.x >> 6] = mn_inv; ps_mx[threadIdx.x >> 6] = mx; ps_sum[threadIdx.x >> 6] = wsum; }
-        __syncthreads();
+        {   // the instance sums of the workgroup's sixteen 16-splat groups (for k_rcount's balanced chunks): a 16-lane row sum, four rows per wave
+            __shared__ uint32_t ps_grp[16];
+            uint32_t r = ps_nt;
+            r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x111, 0xf, 0xf, false);   // row_shr:1
+            r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x112, 0xf, 0xf, false);   // row_shr:2
+            r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x114, 0xf, 0xf, false);   // row_shr:4
+            r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x118, 0xf, 0xf, false);   // row_shr:8
+            if ((threadIdx.x & 15) == 15) ps_grp[threadIdx.x >> 4] = r;
+            __syncthreads();
+            if (threadIdx.x < 4)
+                a.pstat[(size_t)gridDim.x * (1 + threadIdx.x) + blockIdx.x] =
+                    make_uint4(ps_grp[4 * threadIdx.x], ps_grp[4 * threadIdx.x + 1], ps_grp[4 * threadIdx.x + 2], ps_grp[4 * threadIdx.x + 3]);
+        }
         if (threadIdx.x == 0)
             a.pstat[blockIdx.x] = make_uint4(~max(max(ps_mn[0], ps_mn[1]), max(ps_mn[2], ps_mn[3])), max(max(ps_mx[0], ps_mx[1]), max(ps_mx[2], ps_mx[3])),
                                              (ps_sum[0] + ps_sum[1]) + (ps_sum[2] + ps_sum[3]), 0u);

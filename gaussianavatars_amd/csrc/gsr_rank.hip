@@ -77,7 +77,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int ilv, int P,
                                                                   const uint4* __restrict__ pstat, uint32_t* __restrict__ tile_count,
                                                                   unsigned long long* __restrict__ rect_total, uint32_t* __restrict__ block_hist,
                                                                   uint32_t* __restrict__ bcount, uint32_t* __restrict__ bhist,
-                                                                  BinHeader* __restrict__ hdr)
+                                                                  BinHeader* __restrict__ hdr, uint32_t* __restrict__ cb)
 {
     extern __shared__ uint32_t lds[];
     uint32_t* const dh = lds;            // [nb] depth buckets
@@ -122,13 +122,61 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int ilv, int P,
     float lo, scale;
     rank_bucket_map(mn, mx, nb, lo, scale);
 
-    const int chunk = rank_chunk(P, (int)gridDim.x, ilv);   // local indices 0 .. chunk - 1 of this workgroup's (interleaved) splats: rank_splat
     const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
+    RankMap rmap = RankMap{rank_chunk(P, nblk, ilv), -1};   // local indices 0 .. chunk - 1 of this workgroup's splats: rank_splat_of
+    if (ilv == -2) {
+        // balanced chunks (gsr_device.h): thread t holds the sixteen 16-splat group sums of k_preprocess's workgroup t (pblocks <= NT on this path);
+        // weight = instances + GSR_RANK_SPLAT_WEIGHT per splat; this workgroup's chunk = the groups between the weight targets total * blk / nblk and
+        // total * (blk + 1) / nblk -- the number of groups whose inclusive prefix is <= the target, the same function in every workgroup
+        __shared__ uint32_t s_wv[NWV], s_c0[NWV], s_c1[NWV];
+        uint32_t g[16];
+        uint32_t local = 0;
+        const int ngroups = (P + 15) >> 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 v = tid < pblocks ? pstat[(size_t)pblocks * (1 + q) + tid] : make_uint4(0u, 0u, 0u, 0u);
+            g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            g[k] = 16 * tid + k < ngroups ? g[k] + 16u * GSR_RANK_SPLAT_WEIGHT : 0u;
+            local += g[k];
+        }
+        const uint32_t incl = wave_scan_incl_u32(local);
+        if ((tid & 63) == 63) s_wv[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { const uint32_t v = s_wv[w]; if (w < (tid >> 6)) before += v; total += v; }
+        const unsigned long long t0 = (unsigned long long)total * (unsigned long long)blk / (unsigned long long)nblk;
+        const unsigned long long t1 = (unsigned long long)total * (unsigned long long)(blk + 1) / (unsigned long long)nblk;
+        uint32_t run = before + incl - local, c0 = 0, c1 = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            run += g[k];
+            const bool exists = 16 * tid + k < ngroups;
+            c0 += (exists && (unsigned long long)run <= t0) ? 1u : 0u;
+            c1 += (exists && (unsigned long long)run <= t1) ? 1u : 0u;
+        }
+        c0 = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl_u32(c0), 63);
+        c1 = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl_u32(c1), 63);
+        if ((tid & 63) == 0) { s_c0[tid >> 6] = c0; s_c1[tid >> 6] = c1; }
+        __syncthreads();
+        uint32_t g0 = 0, g1 = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { g0 += s_c0[w]; g1 += s_c1[w]; }
+        if (blk == 0) g0 = 0u;
+        if (blk == nblk - 1) g1 = (uint32_t)ngroups;
+        const int s0 = min(P, (int)(g0 << 4)), s1 = min(P, (int)(g1 << 4));
+        rmap = RankMap{s1 - s0, s0};
+        if (tid == 0) { cb[blk] = (uint32_t)s0; if (blk == nblk - 1) cb[nblk] = (uint32_t)s1; }
+    }
+    const int chunk = rmap.chunk;
     unsigned long long touched = 0;
     const int gy = tiles / gx, sx = gx + 1;   // the LDS grid has one more column and row: rect corners lie on tile CORNERS
     if (direct) {
         for (int base = 0; base < chunk; base += NT / G) {
-            const int j = base + tid / G, i = j < chunk ? rank_splat(j, blk, nblk, chunk, ilv) : P;
+            const int j = base + tid / G, i = j < chunk ? rank_splat_of(j, blk, nblk, rmap, ilv) : P;
             uint32_t n = 0;
             int minx = 0, miny = 0, maxx = 0, maxy = 0;
             if (i < P) {
@@ -146,7 +194,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rcount(int ilv, int P,
         // A rect adds 1 to every tile it covers = +1 / -1 / -1 / +1 at its four corners followed by a 2-D prefix sum over the grid:
         // four LDS atomics per splat whatever its size (18 tiles on average), one splat per lane
         for (int j = tid; j < chunk; j += NT) {
-            const int i = rank_splat(j, blk, nblk, chunk, ilv);
+            const int i = rank_splat_of(j, blk, nblk, rmap, ilv);
             if (i >= P) continue;
             const ushort4 r = srect[i];
             touched += tiles_touched[i];
@@ -394,7 +442,8 @@ __device__ __forceinline__ void tile_scan_wide(const TileScanArgs& ts)
 __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rdscatter(int ilv, int P, uint32_t nb, const ushort4* __restrict__ srect, const float* __restrict__ depths,
                                                     BinHeader* __restrict__ hdr, const uint32_t* __restrict__ bcount,
                                                     uint32_t* __restrict__ bstart, uint32_t* __restrict__ bcursor,
-                                                    unsigned long long* __restrict__ dkeys, const uint32_t* __restrict__ bhist, TileScanArgs ts)
+                                                    unsigned long long* __restrict__ dkeys, const uint32_t* __restrict__ bhist, TileScanArgs ts,
+                                                    const uint32_t* __restrict__ cb)
 {
     extern __shared__ uint32_t base[];   // [nb]
     constexpr int NT = GSR_RANK_BIN_THREADS, NWV = NT / 64;
@@ -438,9 +487,10 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rdscatter(int ilv, int
     __syncthreads();
     float lo, scale;
     rank_bucket_map(hdr->dmin_bits, hdr->dmax_bits, nb, lo, scale);
-    const int chunk = rank_chunk(P, (int)nblk, ilv);
+    const RankMap rmap = rank_map(P, (int)nblk, (int)blockIdx.x, ilv, cb);
+    const int chunk = rmap.chunk;
     for (int j = tid; j < chunk; j += NT) {
-        const int i = rank_splat(j, (int)blockIdx.x, (int)nblk, chunk, ilv);
+        const int i = rank_splat_of(j, (int)blockIdx.x, (int)nblk, rmap, ilv);
         if (i >= P) continue;
         const ushort4 r = srect[i];
         if (r.z == r.x) continue;   // not binned
@@ -615,7 +665,7 @@ __device__ __forceinline__ void rscatter_body(int P, int gx, int tiles, BandTabl
                                               const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
                                               uint2* __restrict__ ranks, unsigned long long capacity,
                                               const unsigned long long* __restrict__ total_dev,
-                                              const uint32_t* __restrict__ block_hist, int nblk, int ilv)
+                                              const uint32_t* __restrict__ block_hist, int nblk, int ilv, const uint32_t* __restrict__ cb)
 {
     extern __shared__ uint32_t hist[];
     uint32_t* __restrict__ const lean = reinterpret_cast<uint32_t*>(ranks);
@@ -625,9 +675,10 @@ __device__ __forceinline__ void rscatter_body(int P, int gx, int tiles, BandTabl
     const bool direct = rank_direct(gx, tiles);
     const bool bands = !LEAN && bt.nbands > 1;
     const uint4* __restrict__ rank4 = reinterpret_cast<const uint4*>(rank);   // bands: the ranks inside the first four bands of the rect
-    const int chunk = rank_chunk(P, nblk, ilv);
     const int blk = (int)blockIdx.x;
-    auto splat_of = [&](int j) { return j < chunk ? rank_splat(j, blk, nblk, chunk, ilv) : P; };   // local index -> splat (P: none)
+    const RankMap rmap = rank_map(P, nblk, blk, ilv, cb);
+    const int chunk = rmap.chunk;
+    auto splat_of = [&](int j) { return j < chunk ? rank_splat_of(j, blk, nblk, rmap, ilv) : P; };   // local index -> splat (P: none)
     // a splat's inputs, fetched one round ahead of their use (all four loads are independent: rank / operands of a splat that is
     // not binned are never looked at)
     struct In { ushort4 q; uint4 rk; float4 s0, s1; };
@@ -736,7 +787,7 @@ __device__ __forceinline__ void rscatter_balanced(RscatterStage<LEAN>& stage, in
                                                   const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
                                                   uint2* __restrict__ ranks, unsigned long long capacity,
                                                   const unsigned long long* __restrict__ total_dev,
-                                                  const uint32_t* __restrict__ block_hist, int nblk, int ilv)
+                                                  const uint32_t* __restrict__ block_hist, int nblk, int ilv, const uint32_t* __restrict__ cb)
 {
     extern __shared__ uint32_t hist[];
     uint32_t* __restrict__ const lean = reinterpret_cast<uint32_t*>(ranks);
@@ -747,8 +798,9 @@ __device__ __forceinline__ void rscatter_balanced(RscatterStage<LEAN>& stage, in
     const bool direct = rank_direct(gx, tiles);
     const bool bands = !LEAN && bt.nbands > 1;
     const uint4* __restrict__ rank4 = reinterpret_cast<const uint4*>(rank);
-    const int chunk = rank_chunk(P, nblk, ilv);
     const int blk = (int)blockIdx.x;
+    const RankMap rmap = rank_map(P, nblk, blk, ilv, cb);
+    const int chunk = rmap.chunk;
     uint4(*const rows)[ROW] = stage.row[wv];
     uint32_t* const own = stage.own[wv];
     struct In { ushort4 q; uint4 rk; float4 s0, s1; };
@@ -767,7 +819,7 @@ __device__ __forceinline__ void rscatter_balanced(RscatterStage<LEAN>& stage, in
     const int stride = SB * (NT / 64);
     auto mine_of = [&](int base) {   // this lane's splat of the round that starts at local index `base` (P: none)
         const int j = base + wv * SB + lane;
-        return lane < SB && j < chunk ? rank_splat(j, blk, nblk, chunk, ilv) : P;
+        return lane < SB && j < chunk ? rank_splat_of(j, blk, nblk, rmap, ilv) : P;
     };
     In nxt = fetch(mine_of(0));
     if (!direct) {
@@ -862,14 +914,14 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rscatter(int ilv, int 
                                                                     const uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
                                                                     uint2* __restrict__ ranks, unsigned long long capacity,
                                                                     const unsigned long long* __restrict__ total_dev,
-                                                                    const uint32_t* __restrict__ block_hist, int stage_off)
+                                                                    const uint32_t* __restrict__ block_hist, int stage_off, const uint32_t* __restrict__ cb)
 {
     extern __shared__ uint32_t dyn_lds[];
     if (stage_off >= 0)
         rscatter_balanced<false>(*reinterpret_cast<RscatterStage<false>*>(reinterpret_cast<unsigned char*>(dyn_lds) + stage_off), P, gx, tiles, bt, srect, rank, sspan,
-                                 tile_start, tile_cursor, ranks, capacity, total_dev, block_hist, (int)gridDim.x, ilv);
+                                 tile_start, tile_cursor, ranks, capacity, total_dev, block_hist, (int)gridDim.x, ilv, cb);
     else
-        rscatter_body<G, false>(P, gx, tiles, bt, srect, rank, sspan, tile_start, tile_cursor, ranks, capacity, total_dev, block_hist, (int)gridDim.x, ilv);
+        rscatter_body<G, false>(P, gx, tiles, bt, srect, rank, sspan, tile_start, tile_cursor, ranks, capacity, total_dev, block_hist, (int)gridDim.x, ilv, cb);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -884,7 +936,8 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rsort_rscatter(int ilv
                                                                           unsigned long long capacity, const unsigned long long* __restrict__ total_dev,
                                                                           const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ bcount,
                                                                           const uint32_t* __restrict__ bstart, unsigned long long* __restrict__ dkeys,
-                                                                          unsigned long long* __restrict__ dtmp, uint32_t* __restrict__ rank, int stage_off)
+                                                                          unsigned long long* __restrict__ dtmp, uint32_t* __restrict__ rank, int stage_off,
+                                                                          const uint32_t* __restrict__ cb)
 {
     extern __shared__ uint32_t dyn_lds[];
     if ((int)blockIdx.x < scatter_blocks) {
@@ -892,10 +945,10 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rsort_rscatter(int ilv
         bt.nbands = 1u; bt.inv_band_rows = 1.f; bt.over = nullptr;
         if (stage_off >= 0)   // (52 KB of rows + the histogram: two workgroups per CU at 802 x 550 -- a scatter workgroup and a sorting one beside it)
             rscatter_balanced<true>(*reinterpret_cast<RscatterStage<true>*>(reinterpret_cast<unsigned char*>(dyn_lds) + stage_off), P, gx, tiles, bt, srect, nullptr,
-                                    sspan, tile_start, tile_cursor, reinterpret_cast<uint2*>(entries), capacity, total_dev, block_hist, scatter_blocks, ilv);
+                                    sspan, tile_start, tile_cursor, reinterpret_cast<uint2*>(entries), capacity, total_dev, block_hist, scatter_blocks, ilv, cb);
         else
             rscatter_body<GSR_RANK_GROUP, true>(P, gx, tiles, bt, srect, nullptr, sspan, tile_start, tile_cursor, reinterpret_cast<uint2*>(entries), capacity,
-                                                total_dev, block_hist, scatter_blocks, ilv);
+                                                total_dev, block_hist, scatter_blocks, ilv, cb);
         return;
     }
     if (threadIdx.x >= 256) return;   // (ended waves do not take part in the barriers of the sort)
@@ -904,7 +957,7 @@ __global__ __launch_bounds__(GSR_RANK_BIN_THREADS) void k_rsort_rscatter(int ilv
 }
 
 template __global__ void k_rscatter<8>(int, int, int, int, BandTables, const ushort4*, const uint32_t*, const float4*, const uint32_t*, uint32_t*, uint2*, unsigned long long,
-                                       const unsigned long long*, const uint32_t*, int);
+                                       const unsigned long long*, const uint32_t*, int, const uint32_t*);
 
 // ------------------------------------------------------------------------------------------
 // The tile's sorted list -> its four quadrant streams, GSR_RANK_WINDOW entries at a time (striped like round 1's epilogue): every

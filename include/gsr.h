@@ -194,7 +194,9 @@ typedef struct GsrBinningLayout {
                            zero area = not binned                                                                          */
     size_t sspan;       /* float  [P][8] operands of the per-quadrant reach test of a binned splat (csrc/gsr_device.h: Span)          */
     size_t pstat;       /* uint32 [ceil(P/256)][4] per k_preprocess workgroup: (min, max) depth bits of its visible splats, the tile
-                           instances its splats are binned into (how evenly those are spread decides the next frame's chunking), 0    */
+                           instances its splats are binned into (how evenly those are spread decides the next frame's chunking), 0;
+                           behind the rows (round 6) four planes [ceil(P/256)][4] with the instance sums of the workgroup's sixteen 16-splat
+                           groups and k_rcount's chunk boundaries (balanced chunks: csrc/gsr_device.h, rank_map)                          */
     size_t tdesc;       /* uint32 [tiles][4] (tile, entries, first entry, 0) in launch order (heaviest tiles first)                       */
     size_t obs;         /* uint32 [P][2] bands only: (splat, first band | last band << 8) of the binned splats in depth order         */
     size_t bandcnt;     /* uint32 [nbands][ceil(P/256)] bands only: splats of band b before each run of 256 consecutive depth ranks  */
